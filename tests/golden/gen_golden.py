@@ -1,0 +1,184 @@
+"""Generate the committed golden fixtures under tests/golden/.
+
+Run ONLY in the build container (needs /root/reference):  python tests/golden/gen_golden.py
+
+* ``target_*.npz``  - outputs of the REFERENCE's own numpy ``TopDownGenerateTarget``
+  (mindpose/data/transform/topdown_transform.py:264-430), loaded by file path so that
+  ``mindpose/__init__.py`` (which imports MindSpore) is bypassed.  ``cv2`` is absent here; the
+  module only calls ``cv2.setNumThreads`` at import (:29) and the target code never touches it,
+  so an empty ``cv2`` module object is registered for the import.  No reference source or
+  bytecode is written anywhere; only inputs and expected outputs are saved.
+* ``decoder_*.npz``, ``loss.npz``, ``flip.npz`` - outputs of the CPU oracle restatement
+  (MindSpore is not installable, so the reference itself cannot produce them: parity unpinned).
+  They freeze the oracle so later edits cannot silently change it.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from tests.golden import recipes  # noqa: E402
+
+REF = "/root/reference/mindpose"
+
+
+def load_reference_target_class():
+    for name in ["mindpose", "mindpose.data", "mindpose.data.transform"]:
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+    cv2 = types.ModuleType("cv2")
+    cv2.setNumThreads = lambda n: None
+    sys.modules["cv2"] = cv2
+
+    def load(modname, path):
+        spec = importlib.util.spec_from_file_location(modname, path)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[modname] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    load("mindpose.register", REF + "/register.py")
+    load("mindpose.data.column_names", REF + "/data/column_names.py")
+    load("mindpose.data.transform.transform", REF + "/data/transform/transform.py")
+    load("mindpose.data.transform.utils", REF + "/data/transform/utils.py")
+    tt = load("mindpose.data.transform.topdown_transform", REF + "/data/transform/topdown_transform.py")
+    return tt.TopDownGenerateTarget
+
+
+def sparse_pack(target):
+    """Store only the non-zero entries (targets are ~98 % zeros)."""
+    flat = target.reshape(-1)
+    nz = np.flatnonzero(flat)
+    return nz.astype(np.int32), flat[nz]
+
+
+def gen_targets():
+    cls = load_reference_target_class()
+    cases = [
+        ("target_plain_64x48", dict(image_size=[192, 256], heatmap_size=[48, 64]), 2.0, False, None, 101),
+        ("target_udp_64x48", dict(image_size=[192, 256], heatmap_size=[48, 64]), 2.0, True, None, 102),
+        ("target_plain_96x72_s3", dict(image_size=[288, 384], heatmap_size=[72, 96]), 3.0, False, None, 103),
+        ("target_udp_96x72_s3", dict(image_size=[288, 384], heatmap_size=[72, 96]), 3.0, True, None, 104),
+        ("target_plain_jw", dict(image_size=[192, 256], heatmap_size=[48, 64]), 2.0, False,
+         [1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.2, 1.2, 1.5, 1.5, 1.0, 1.0, 1.2, 1.2, 1.5, 1.5], 105),
+    ]
+    for name, geom, sigma, udp, jw, seed in cases:
+        cfg = dict(geom, flip_pairs=recipes.FLIP_PAIRS, upper_body_ids=list(range(11)),
+                   pixel_std=200.0, scale_padding=1.25)
+        if jw is not None:
+            cfg["joint_weights"] = jw
+        t = cls(is_train=True, config=cfg, sigma=sigma, use_udp=udp,
+                use_different_joint_weights=jw is not None)
+        n = 24
+        kp = recipes.keypoint_sets(n, 17, geom["image_size"][0], geom["image_size"][1], seed)
+        targets, weights = [], []
+        for b in range(n):
+            out = t.transform({"keypoints": kp[b]})
+            targets.append(np.asarray(out["target"], dtype=np.float32))
+            weights.append(np.asarray(out["target_weight"]))
+        target = np.stack(targets)
+        weight = np.stack(weights)
+        nz_idx, nz_val = sparse_pack(target)
+        np.savez_compressed(
+            os.path.join(HERE, name + ".npz"), keypoints=kp, target_shape=np.array(target.shape),
+            target_nz_idx=nz_idx, target_nz_val=nz_val, target_weight=weight.astype(np.float32),
+            weight_dtype=str(weight.dtype), sigma=sigma, use_udp=udp,
+            image_size=np.array(geom["image_size"]), heatmap_size=np.array(geom["heatmap_size"]),
+            joint_weights=np.array(jw if jw is not None else [], dtype=np.float64),
+            source="reference:mindpose/data/transform/topdown_transform.py TopDownGenerateTarget "
+                   "(numpy %s)" % np.__version__)
+        print(name, target.shape, "nnz", nz_idx.size, "weights>0", int((weight > 0).sum()))
+
+
+DECODER_CASES = [
+    # name, heatmap recipe, (n,k,h,w), seed, kwargs
+    ("uniform_plain", "uniform", (8, 17, 64, 48), 201, dict()),
+    ("uniform_shift", "uniform", (8, 17, 64, 48), 202, dict(shift_coord=True)),
+    ("uniform_dark_udp", "uniform", (8, 17, 64, 48), 203, dict(use_udp=True, dark_udp_refine=True)),
+    ("refshape_plain", "uniform", (8, 17, 48, 64), 204, dict()),  # the reference test's own shape
+    ("blob_plain", "blob", (4, 17, 64, 48), 211, dict()),
+    ("blob_shift", "blob", (4, 17, 64, 48), 211, dict(shift_coord=True)),
+    ("blob_dark", "blob", (4, 17, 64, 48), 211, dict(dark_udp_refine=True)),
+    ("blob_dark_udp", "blob", (4, 17, 64, 48), 211, dict(use_udp=True, dark_udp_refine=True)),
+    ("blob_udp_plain", "blob", (4, 17, 64, 48), 211, dict(use_udp=True)),
+    ("blob_noorig_shift", "blob", (4, 17, 64, 48), 211, dict(shift_coord=True, to_original=False)),
+    ("blob96_dark_udp_k17", "blob3", (3, 17, 96, 72), 212, dict(use_udp=True, dark_udp_refine=True, kernel_size=17)),
+    ("blob_k5_odd", "blob", (2, 5, 20, 14), 213, dict(shift_coord=True)),
+]
+
+
+def decoder_inputs(kind, shape, seed):
+    n, k, h, w = shape
+    if kind == "uniform":
+        hm = recipes.uniform_heatmaps(n, k, h, w, seed)
+    elif kind == "blob":
+        hm = recipes.blob_heatmaps(n, k, h, w, seed, sigma=2.0)
+    else:
+        hm = recipes.blob_heatmaps(n, k, h, w, seed, sigma=3.0)
+    center, scale, score = recipes.boxes(n, seed + 1000)
+    return hm, center, scale, score
+
+
+def gen_decoder():
+    from oracle import decoder as od
+    out = {}
+    for name, kind, shape, seed, kw in DECODER_CASES:
+        hm, center, scale, score = decoder_inputs(kind, shape, seed)
+        preds, boxes, idx = od.decode(hm, center, scale, score, **kw)
+        out[name + "/preds"] = preds
+        out[name + "/boxes"] = boxes
+        out[name + "/idx"] = idx.astype(np.int32)
+        print("decoder", name, preds.shape, float(np.abs(preds).max()))
+    np.savez_compressed(os.path.join(HERE, "decoder.npz"), source="oracle/decoder.py (parity unpinned)", **out)
+
+
+def gen_flip():
+    from oracle import decoder as od
+    out = {}
+    for shift in (False, True):
+        h = recipes.blob_heatmaps(3, 17, 64, 48, 301)
+        hf = recipes.blob_heatmaps(3, 17, 64, 48, 302)
+        center, scale, score = recipes.boxes(3, 1301)
+        avg = od.flip_aggregate(h, hf, recipes.FLIP_INDEX, shift_heatmap=shift)
+        preds, boxes, idx = od.decode(avg, center, scale, score, shift_coord=True)
+        tag = "shift" if shift else "noshift"
+        out[tag + "/avg_checksum"] = np.array([avg.astype(np.float64).sum(), np.abs(avg).astype(np.float64).sum()])
+        out[tag + "/avg_sample"] = avg[:, :, ::7, ::5].copy()
+        out[tag + "/preds"] = preds
+        out[tag + "/boxes"] = boxes
+        out[tag + "/idx"] = idx.astype(np.int32)
+    np.savez_compressed(os.path.join(HERE, "flip.npz"), source="oracle/decoder.py (parity unpinned)", **out)
+    print("flip done")
+
+
+def gen_loss():
+    from oracle import loss as ol
+    out = {}
+    for name, (shape, seed) in recipes.LOSS_CASES.items():
+        pred, target, w = recipes.loss_inputs(shape, seed)
+        out[name + "/loss_plain"] = ol.joints_mse(pred, target)
+        out[name + "/loss_weighted"] = ol.joints_mse(pred, target, w, use_target_weight=True)
+        g = ol.joints_mse_grad(pred, target, w, use_target_weight=True)
+        out[name + "/grad_sample"] = g[:, :, ::8, ::8].copy()
+        out[name + "/grad_abs_sum"] = np.abs(g).astype(np.float64).sum()
+    np.savez_compressed(os.path.join(HERE, "loss.npz"), source="oracle/loss.py (parity unpinned)", **out)
+    print("loss done")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["targets", "decoder", "flip", "loss"]
+    if "targets" in which:
+        gen_targets()
+    if "decoder" in which:
+        gen_decoder()
+    if "flip" in which:
+        gen_flip()
+    if "loss" in which:
+        gen_loss()
