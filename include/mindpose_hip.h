@@ -1,0 +1,164 @@
+/*
+ * mindpose_hip.h - C ABI of libmindpose_hip.so: the MI355X (gfx950) hot path of the
+ * top-down heat-map pose pipeline.
+ *
+ * The reference (mindspore-lab/mindpose) has no FFI for this path: every function below
+ * replaces a MindSpore-op sequence issued from a Python `construct`/`transform` method
+ * (file:line cited per entry).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / HIP types in the signatures
+ *     (`mp_stream_t` is a hipStream_t passed as void*; NULL = the default stream).
+ *   - every pointer marked `dev` is DEVICE memory owned by the caller, contiguous, NCHW, fp32.
+ *   - asynchronous on `stream`; no hidden synchronisation, no internal allocation
+ *     (scratch comes from a caller-provided workspace sized by mp_*_workspace_bytes).
+ *   - returns MP_OK (0) or a negative MP_ERR_* code; never throws, never aborts.
+ *   - re-entrant; thread-safe for distinct streams.
+ */
+#ifndef MINDPOSE_HIP_H
+#define MINDPOSE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mp_stream_t;
+
+#define MP_OK 0
+#define MP_ERR_NULL (-1)        /* required pointer is NULL */
+#define MP_ERR_SHAPE (-2)       /* non-positive / inconsistent dimension */
+#define MP_ERR_UNSUPPORTED (-3) /* valid request outside what the kernels implement */
+#define MP_ERR_HIP (-4)         /* HIP runtime error at launch (see mp_last_hip_error) */
+#define MP_ERR_WORKSPACE (-5)   /* workspace missing or too small */
+
+const char* mp_version(void);
+const char* mp_error_string(int code);
+int mp_last_hip_error(void); /* hipError_t of the most recent MP_ERR_HIP on this thread */
+
+/* ------------------------------------------------------------------------------------------
+ * Decoder: TopDownHeatMapDecoder.construct, mindpose/models/decoders/top_down_decoder.py:72-94
+ *   _get_max_preds :96-116 (per-joint arg-max, first index on ties, no maxval>0 mask)
+ *   _shift_coordinate :118-141 | _dark_udp_refine_coords :171-205 | _transform_preds :143-169
+ * heatmap [N,K,H,W]; center,scale [N,2]; score [N] -> preds [N,K,3]=(x,y,maxval), boxes [N,6].
+ * argmax_idx (optional, may be NULL): [N,K] int32 flat arg-max index (bit-exact target).
+ * blur_kernel: dev [kernel_size^2] normalised Gaussian (:207-215), required for MP_REFINE_DARK.
+ * ------------------------------------------------------------------------------------------ */
+#define MP_REFINE_NONE 0
+#define MP_REFINE_SHIFT 1 /* shift_coordinate=True */
+#define MP_REFINE_DARK 2  /* dark_udp_refine=True  */
+
+int mp_decode_topdown(const float* heatmap_dev, const float* center_dev, const float* scale_dev,
+                      const float* score_dev, float* preds_dev, float* boxes_dev, int32_t* argmax_idx_dev,
+                      int n, int k, int h, int w, int refine_mode, int use_udp, int to_original,
+                      float pixel_std, const float* blur_kernel_dev, int kernel_size, mp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Flip-test aggregation: _MultiRunNet.construct, mindpose/engine/inferencer/topdown_inferencer.py:165-187
+ *   avg = (heatmap + flip_back(flipped)[shifted]) * 0.5 ; decoder(avg, ...)
+ * flip_index [K] int32 (:78-80).  avg_out (optional, may be NULL): [N,K,H,W] averaged heat-map.
+ * mp_flip_aggregate_decode fuses aggregation and decode in one pass (avg never leaves registers
+ * unless avg_out is given).
+ * ------------------------------------------------------------------------------------------ */
+int mp_flip_aggregate(const float* heatmap_dev, const float* flipped_dev, const int32_t* flip_index_dev,
+                      float* avg_out_dev, int n, int k, int h, int w, int shift_heatmap, mp_stream_t stream);
+
+int mp_flip_aggregate_decode(const float* heatmap_dev, const float* flipped_dev, const int32_t* flip_index_dev,
+                             int shift_heatmap, float* avg_out_dev, const float* center_dev,
+                             const float* scale_dev, const float* score_dev, float* preds_dev, float* boxes_dev,
+                             int32_t* argmax_idx_dev, int n, int k, int h, int w, int refine_mode, int use_udp,
+                             int to_original, float pixel_std, const float* blur_kernel_dev, int kernel_size,
+                             mp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Target generation: TopDownGenerateTarget._encoding / _udp_encoding,
+ * mindpose/data/transform/topdown_transform.py:324-375, :377-430 (batched over samples).
+ * keypoints [N,K,3] (x,y,vis) in input-image px -> target [N,K,H,W], target_weight [N,K].
+ * feat_stride_x/y: the reference's float64 feature stride (image/heatmap, or (image-1)/(heatmap-1)
+ * for UDP), computed by the host mirror exactly as the reference does.
+ * patch_dev: plain mode only - the precomputed un-normalised Gaussian patch [patch_side^2] fp32
+ * (:335-344), built on the host with the reference's numpy expression so values are bit-identical.
+ * joint_weights_dev: optional [K] float64 (use_different_joint_weights), else NULL.
+ * ------------------------------------------------------------------------------------------ */
+int mp_gaussian_target(const float* keypoints_dev, const float* patch_dev, int patch_side,
+                       const double* joint_weights_dev, float* target_dev, float* target_weight_dev, int n,
+                       int k, int h, int w, double feat_stride_x, double feat_stride_y, double sigma,
+                       int use_udp, mp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Loss: JointsMSELoss.construct, mindpose/models/loss/mse.py:36-44
+ *   L = mean_{n,k,h,w}( w[n,k] * (pred-target)^2 ) ; weight_dev NULL -> use_target_weight=False.
+ * Deterministic two-stage fp32/fp64 reduction; workspace >= mp_joints_mse_workspace_bytes(n,k).
+ * bwd: grad_pred = grad_out * 2 * w * (pred-target) / (N*K*H*W); grad_out_dev NULL means 1.0.
+ * ------------------------------------------------------------------------------------------ */
+size_t mp_joints_mse_workspace_bytes(int n, int k);
+int mp_joints_mse_fwd(const float* pred_dev, const float* target_dev, const float* weight_dev, float* loss_dev,
+                      void* workspace_dev, size_t workspace_bytes, int n, int k, int hw, mp_stream_t stream);
+int mp_joints_mse_bwd(const float* pred_dev, const float* target_dev, const float* weight_dev,
+                      const float* grad_out_dev, float* grad_pred_dev, int n, int k, int hw, mp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution family (direct, im2col-free, LDS-tiled, fp32 MFMA v_mfma_f32_16x16x4_f32):
+ *   nn.Conv2d + nn.BatchNorm2d(eval) + residual add + nn.ReLU of
+ *     BasicBlock  mindpose/models/backbones/hrnet.py:66-83, Bottleneck :126-146,
+ *     HRModule fuse rows :318-344 (incl. ResizeNearestNeighbor + add :333-336),
+ *     transitions :440-496, stem :568-573, HRNetHead heads/hrnet_head.py:47-49,
+ *     ResNet stem/blocks backbones/resnet.py:118-138,:247-264,
+ *     SimpleBaselineHead heads/simple_baseline_head.py:80-90 (Conv2dTranspose k4 s2 p1 as four
+ *     2x2 sub-pixel phase convolutions) and its final 1x1 conv :57-62.
+ *
+ * out[n,co,oy,ox] = act( conv(x,w)[n,co,y,x] * scale[co] + shift[co] (+ res1[...]) (+ res2[...]) )
+ * with (oy,ox) = (y*out_mul + out_off_y + a, x*out_mul + out_off_x + b), a,b in [0,out_rep):
+ *   normal conv          out_mul=1 out_rep=1
+ *   nearest-upsample+add out_mul=s out_rep=s   (HRModule fuse, j>i)
+ *   deconv phase (py,px) out_mul=2 out_rep=1 out_off=(py,px)
+ * res1/res2 (optional) are indexed like `out` ([N,Cout,out_h,out_w]); res1 may alias out.
+ * Weights are pre-packed once by mp_conv_pack_weight (device -> device).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mp_conv_desc {
+    int32_t n, cin, h, w;          /* input [N,Cin,H,W] */
+    int32_t cout, kh, kw;          /* kernel (kh == kw in {1,2,3,7}) */
+    int32_t stride;                /* 1 or 2 */
+    int32_t pad_top, pad_left;     /* zero padding before the first row / column */
+    int32_t conv_h, conv_w;        /* conv output extent (before the output mapping) */
+    int32_t out_h, out_w;          /* extent of the out / res tensors */
+    int32_t out_mul, out_rep, out_off_y, out_off_x;
+    int32_t relu;                  /* apply ReLU last */
+    int32_t tap_dilation_unused;   /* reserved, must be 0 */
+} mp_conv_desc;
+
+/* bytes of the packed weight buffer for a (cout, cin, kh, kw) kernel */
+size_t mp_conv_packed_weight_bytes(int cout, int cin, int kh, int kw);
+/* w_dev: [Cout,Cin,kh,kw] (Conv2d) when transposed==0; [Cin,Cout,4,4] Conv2dTranspose weights when
+ * transposed==1, in which case phase (py,px) in {0,1}^2 selects the 2x2 sub-kernel and kh=kw=2. */
+int mp_conv_pack_weight(const float* w_dev, float* packed_dev, int cout, int cin, int kh, int kw,
+                        int transposed, int phase_y, int phase_x, mp_stream_t stream);
+int mp_conv2d_fwd(const mp_conv_desc* desc, const float* x_dev, const float* packed_w_dev,
+                  const float* scale_dev, const float* shift_dev, const float* res1_dev, const float* res2_dev,
+                  float* out_dev, mp_stream_t stream);
+
+/* nn.MaxPool2d(kernel_size=3, stride=2, pad_mode="same"), resnet.py:190: pads bottom/right only. */
+int mp_maxpool3x3s2_same(const float* x_dev, float* out_dev, int n, int c, int h, int w, mp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Launch plan: a recorded sequence of the calls above (one HRNet / ResNet forward = ~300 launches)
+ * replayed by ONE native call, so the per-layer host cost is paid once at build time.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mp_plan mp_plan;
+mp_plan* mp_plan_create(void);
+void mp_plan_destroy(mp_plan* plan);
+int mp_plan_add_conv(mp_plan* plan, const mp_conv_desc* desc, const float* x_dev, const float* packed_w_dev,
+                     const float* scale_dev, const float* shift_dev, const float* res1_dev,
+                     const float* res2_dev, float* out_dev);
+int mp_plan_add_maxpool(mp_plan* plan, const float* x_dev, float* out_dev, int n, int c, int h, int w);
+int mp_plan_size(const mp_plan* plan);
+int mp_plan_run(const mp_plan* plan, mp_stream_t stream);
+/* run entries [first, first+count) only (profiling / per-layer timing) */
+int mp_plan_run_range(const mp_plan* plan, int first, int count, mp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MINDPOSE_HIP_H */

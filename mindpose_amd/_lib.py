@@ -1,0 +1,112 @@
+"""ctypes binding of ``libmindpose_hip.so`` (C ABI declared in ``include/mindpose_hip.h``).
+
+There is NO fallback: if the shared library is missing or a call fails, an exception is raised.
+PyTorch is used only for device memory (``tensor.data_ptr()``) and the current HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmindpose_hip.so")
+
+MP_REFINE_NONE, MP_REFINE_SHIFT, MP_REFINE_DARK = 0, 1, 2
+
+c_f32p = ctypes.c_void_p  # device pointers travel as integers
+c_int = ctypes.c_int
+c_size_t = ctypes.c_size_t
+
+
+class ConvDesc(ctypes.Structure):
+    """``mp_conv_desc`` of include/mindpose_hip.h."""
+    _fields_ = [(name, ctypes.c_int32) for name in (
+        "n", "cin", "h", "w", "cout", "kh", "kw", "stride", "pad_top", "pad_left", "conv_h", "conv_w",
+        "out_h", "out_w", "out_mul", "out_rep", "out_off_y", "out_off_x", "relu", "tap_dilation_unused")]
+
+
+class MindposeHipError(RuntimeError):
+    pass
+
+
+_PROTOTYPES = {
+    "mp_version": (ctypes.c_char_p, []),
+    "mp_error_string": (ctypes.c_char_p, [c_int]),
+    "mp_last_hip_error": (c_int, []),
+    "mp_decode_topdown": (c_int, [c_f32p] * 7 + [c_int] * 7 + [ctypes.c_float, c_f32p, c_int, ctypes.c_void_p]),
+    "mp_flip_aggregate": (c_int, [c_f32p] * 4 + [c_int] * 5 + [ctypes.c_void_p]),
+    "mp_flip_aggregate_decode": (c_int, [c_f32p] * 3 + [c_int] + [c_f32p] * 7 + [c_int] * 7
+                                 + [ctypes.c_float, c_f32p, c_int, ctypes.c_void_p]),
+    "mp_gaussian_target": (c_int, [c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_f32p] + [c_int] * 4
+                           + [ctypes.c_double] * 3 + [c_int, ctypes.c_void_p]),
+    "mp_joints_mse_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "mp_joints_mse_fwd": (c_int, [c_f32p] * 5 + [c_size_t] + [c_int] * 3 + [ctypes.c_void_p]),
+    "mp_joints_mse_bwd": (c_int, [c_f32p] * 5 + [c_int] * 3 + [ctypes.c_void_p]),
+    "mp_conv_packed_weight_bytes": (c_size_t, [c_int] * 4),
+    "mp_conv_pack_weight": (c_int, [c_f32p, c_f32p] + [c_int] * 7 + [ctypes.c_void_p]),
+    "mp_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc)] + [c_f32p] * 7 + [ctypes.c_void_p]),
+    "mp_maxpool3x3s2_same": (c_int, [c_f32p, c_f32p] + [c_int] * 4 + [ctypes.c_void_p]),
+    "mp_plan_create": (ctypes.c_void_p, []),
+    "mp_plan_destroy": (None, [ctypes.c_void_p]),
+    "mp_plan_add_conv": (c_int, [ctypes.c_void_p, ctypes.POINTER(ConvDesc)] + [c_f32p] * 7),
+    "mp_plan_add_maxpool": (c_int, [ctypes.c_void_p, c_f32p, c_f32p] + [c_int] * 4),
+    "mp_plan_size": (c_int, [ctypes.c_void_p]),
+    "mp_plan_run": (c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "mp_plan_run_range": (c_int, [ctypes.c_void_p, c_int, c_int, ctypes.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises ``MindposeHipError`` if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MindposeHipError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C mindpose_amd/csrc -j8`.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in _PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the export is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        lib = load()
+        msg = lib.mp_error_string(rc).decode()
+        extra = f" (hipError {lib.mp_last_hip_error()})" if rc == -4 else ""
+        raise MindposeHipError(f"{what} failed: {msg}{extra}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32/int32/fp64 CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MindposeHipError("tensor must live on the GPU: the HIP path has no CPU fallback")
+    if not t.is_contiguous():
+        raise MindposeHipError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda_f32(t, name):
+    if not torch.is_tensor(t):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise MindposeHipError(f"{name} must be a CUDA tensor: the HIP path has no CPU fallback")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()

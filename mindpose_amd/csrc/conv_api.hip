@@ -1,0 +1,280 @@
+// C-ABI entry points of the convolution family: weight packing, tile-configuration choice,
+// launch, and the recorded launch plan (one native call replays a whole network forward).
+#include <string.h>
+
+#include <vector>
+
+#include "conv_mfma.h"
+
+namespace mp {
+
+static inline unsigned magic_of(unsigned d) { return d <= 1 ? 0u : (unsigned)(0x100000000ULL / d) + 1u; }
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// [Cout,Cin,kh,kw] (or the (py,px) 2x2 phase of a [Cin,Cout,4,4] transposed-conv weight)
+//   -> [Cin_pad4/4][T][4][Cout_pad16], zero padded.
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int cout,
+                                                          int cin, int kh, int kw, int cin_pad4, int cout_pad16,
+                                                          int transposed, int py, int px) {
+    const int T = kh * kw;
+    const size_t total = (size_t)cin_pad4 * T * cout_pad16;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % cout_pad16);
+        size_t r = i / cout_pad16;
+        const int kq = (int)(r & 3);
+        r >>= 2;
+        const int t = (int)(r % T);
+        const int q = (int)(r / T);
+        const int ci = q * 4 + kq;
+        float v = 0.f;
+        if (co < cout && ci < cin) {
+            const int ty = t / kw, tx = t % kw;
+            if (!transposed) {
+                v = w[(((size_t)co * cin + ci) * kh + ty) * kw + tx];
+            } else {
+                // Conv2dTranspose k=4 s=2 p=1: out row 2m+py reads in row m-1+py+ty with kernel row
+                // ky = 3-2*ty (py=0) or 2-2*ty (py=1); same along x.
+                const int ky = py == 0 ? 3 - 2 * ty : 2 - 2 * ty;
+                const int kx = px == 0 ? 3 - 2 * tx : 2 - 2 * tx;
+                v = w[(((size_t)ci * cout + co) * 4 + ky) * 4 + kx];
+            }
+        }
+        out[i] = v;
+    }
+}
+
+struct ConvLaunch {
+    ConvKParams p;
+    int ks, stride, variant;
+    size_t lds_bytes;
+};
+
+static const int kLdsBudget = 78 * 1024;   // two workgroups per CU (160 KiB LDS)
+static const int kLdsMax = 150 * 1024;
+
+static int plane_pad(int raw) {  // smallest value >= raw that is == 16 (mod 32)
+    int v = (raw + 15) / 32 * 32 + 16;
+    if (v - 32 >= raw) v -= 32;
+    return v;
+}
+
+// geometry for a given variant; returns false when it cannot fit LDS
+static bool configure(const mp_conv_desc& d, int variant, ConvLaunch& L) {
+    int CT, PT;
+    variant_dims(variant, CT, PT);
+    ConvKParams& p = L.p;
+    const int S = d.stride, KS = d.kh;
+    p.N = d.n; p.Cin = d.cin; p.H = d.h; p.W = d.w; p.Cout = d.cout;
+    p.Cout_pad16 = round_up(d.cout, 16);
+    p.Cin_pad4 = round_up(d.cin, 4);
+    p.Ho = d.conv_h; p.Wo = d.conv_w; p.pad_t = d.pad_top; p.pad_l = d.pad_left;
+    if (p.Wo > PT) return false;
+    const int rows_fit = PT / p.Wo;
+    if (rows_fit >= p.Ho) {
+        p.R = p.Ho;
+        p.G = PT / (p.Ho * p.Wo);
+        if (p.G > p.N) p.G = p.N;
+        if (p.G < 1) p.G = 1;
+    } else {
+        p.R = rows_fit;
+        p.G = 1;
+    }
+    p.RWo = p.R * p.Wo;
+    p.Rin = (p.R - 1) * S + KS;
+    p.Wp = (p.Wo - 1) * S + KS;
+    p.img_plane = p.Rin * p.Wp;
+    p.cin_plane = plane_pad(p.G * p.img_plane);
+    p.ncols = p.W < p.Wp - p.pad_l ? p.W : p.Wp - p.pad_l;
+    if (p.ncols < 1) return false;
+    const int T = KS * KS;
+    // largest cin chunk (multiple of 4) whose input + weight tiles fit the LDS budget
+    const int per_c = (p.cin_plane + T * CT) * 4;  // bytes per input channel
+    int ck = kLdsBudget / per_c / 4 * 4;
+    if (ck < 4) {
+        ck = kLdsMax / per_c / 4 * 4;
+        if (ck < 4) return false;
+        if (ck > 8) ck = 8;
+    }
+    if (ck > 64) ck = 64;
+    if (ck > p.Cin_pad4) ck = p.Cin_pad4;
+    p.n_chunks = (p.Cin_pad4 + ck - 1) / ck;
+    p.CK = round_up((p.Cin_pad4 + p.n_chunks - 1) / p.n_chunks, 4);  // balanced chunks
+    p.n_chunks = (p.Cin_pad4 + p.CK - 1) / p.CK;
+    p.n_ct = (p.Cout_pad16 + CT - 1) / CT;
+    p.tiles_y = (p.G > 1 || p.R >= p.Ho) ? 1 : (p.Ho + p.R - 1) / p.R;
+    p.tiles_n = (p.N + p.G - 1) / p.G;
+    p.lds_w_off = p.CK * p.cin_plane;
+    p.out_h = d.out_h; p.out_w = d.out_w; p.out_mul = d.out_mul; p.out_rep = d.out_rep;
+    p.off_y = d.out_off_y; p.off_x = d.out_off_x; p.relu = d.relu;
+    p.magic_ncols = magic_of(p.ncols);
+    p.magic_rwo = magic_of(p.RWo);
+    p.magic_wo = magic_of(p.Wo);
+    p.magic_perc = magic_of(p.Rin * p.ncols);
+    p.total_blocks = p.n_ct * p.tiles_y * p.tiles_n;
+    L.ks = KS; L.stride = S; L.variant = variant;
+    L.lds_bytes = (size_t)(p.CK * p.cin_plane + p.CK * T * CT) * 4;
+    return L.lds_bytes <= (size_t)kLdsMax;
+}
+
+static int choose_variant(const mp_conv_desc& d, ConvLaunch& best) {
+    // cout tile by divisibility; pixel tile 192 unless that leaves the chip under-filled
+    int order[V_COUNT];
+    int n = 0;
+    const int c = d.cout;
+    if (c % 64 == 0) { order[n++] = V_CT64_PT192; order[n++] = V_CT64_PT96; order[n++] = V_CT32_PT192; order[n++] = V_CT32_PT96; }
+    else if (c % 48 == 0) { order[n++] = V_CT48_PT192; order[n++] = V_CT64_PT192; order[n++] = V_CT64_PT96; }
+    else if (c <= 32) { order[n++] = V_CT32_PT192; order[n++] = V_CT32_PT96; }
+    else if (c <= 48) { order[n++] = V_CT48_PT192; order[n++] = V_CT64_PT96; }
+    else { order[n++] = V_CT64_PT192; order[n++] = V_CT64_PT96; order[n++] = V_CT32_PT192; }
+    bool have = false;
+    double best_score = 0;
+    for (int i = 0; i < n; ++i) {
+        ConvLaunch L{};
+        if (!configure(d, order[i], L)) continue;
+        int CT, PT;
+        variant_dims(order[i], CT, PT);
+        // useful fraction of the MFMA tile x how well the grid fills 256 CUs x 2 workgroups
+        const double pix_eff = (double)(L.p.G * L.p.RWo) / PT;
+        const double co_eff = (double)d.cout / (L.p.n_ct * CT);
+        const double waves = (double)L.p.total_blocks / 512.0;
+        const double fill = waves >= 1.0 ? waves / (double)((long long)waves + ((waves - (long long)waves) > 1e-9 ? 1 : 0)) : waves;
+        const double big = (CT >= 48 ? 1.0 : 0.93) * (PT >= 192 ? 1.0 : 0.95);  // bigger tiles re-use LDS operands
+        const double score = pix_eff * co_eff * fill * big;
+        if (!have || score > best_score * 1.02) {
+            best = L;
+            best_score = score;
+            have = true;
+        }
+    }
+    return have ? MP_OK : MP_ERR_UNSUPPORTED;
+}
+
+static int validate_desc(const mp_conv_desc* d) {
+    if (!d) return MP_ERR_NULL;
+    if (d->n <= 0 || d->cin <= 0 || d->h <= 0 || d->w <= 0 || d->cout <= 0) return MP_ERR_SHAPE;
+    if (d->kh != d->kw) return MP_ERR_UNSUPPORTED;
+    if (!(d->kh == 1 || d->kh == 2 || d->kh == 3 || d->kh == 7)) return MP_ERR_UNSUPPORTED;
+    if (!(d->stride == 1 || d->stride == 2)) return MP_ERR_UNSUPPORTED;
+    if ((d->kh == 2 && d->stride != 1) || (d->kh == 7 && d->stride != 2)) return MP_ERR_UNSUPPORTED;
+    if (d->pad_top < 0 || d->pad_left < 0 || d->pad_top >= d->kh + 1 || d->pad_left >= d->kw + 1) return MP_ERR_SHAPE;
+    if (d->conv_h <= 0 || d->conv_w <= 0 || d->out_h <= 0 || d->out_w <= 0) return MP_ERR_SHAPE;
+    if (d->out_mul < 1 || d->out_rep < 1 || d->out_off_y < 0 || d->out_off_x < 0) return MP_ERR_SHAPE;
+    if (d->tap_dilation_unused != 0) return MP_ERR_UNSUPPORTED;
+    // output mapping must stay inside [out_h, out_w]
+    if ((d->conv_h - 1) * d->out_mul + d->out_off_y + d->out_rep > d->out_h) return MP_ERR_SHAPE;
+    if ((d->conv_w - 1) * d->out_mul + d->out_off_x + d->out_rep > d->out_w) return MP_ERR_SHAPE;
+    if ((long long)d->n * d->cout * d->out_h * d->out_w >= (1LL << 40)) return MP_ERR_UNSUPPORTED;
+    return MP_OK;
+}
+
+static int launch(const ConvLaunch& L, hipStream_t s) {
+    switch (L.ks) {
+        case 1: return launch_conv_k1(L.p, L.stride, L.variant, L.lds_bytes, s);
+        case 2: return launch_conv_k2(L.p, L.stride, L.variant, L.lds_bytes, s);
+        case 3: return launch_conv_k3(L.p, L.stride, L.variant, L.lds_bytes, s);
+        case 7: return launch_conv_k7(L.p, L.stride, L.variant, L.lds_bytes, s);
+        default: return MP_ERR_UNSUPPORTED;
+    }
+}
+
+static int build_launch(const mp_conv_desc* desc, const float* x, const float* w, const float* scale,
+                        const float* shift, const float* res1, const float* res2, float* out, ConvLaunch& L) {
+    int rc = validate_desc(desc);
+    if (rc != MP_OK) return rc;
+    if (!x || !w || !scale || !shift || !out) return MP_ERR_NULL;
+    rc = choose_variant(*desc, L);
+    if (rc != MP_OK) return rc;
+    L.p.x = x; L.p.wp = w; L.p.scale = scale; L.p.shift = shift; L.p.res1 = res1; L.p.res2 = res2; L.p.out = out;
+    return MP_OK;
+}
+
+}  // namespace mp
+
+using namespace mp;
+
+struct mp_plan {
+    struct Entry {
+        int kind;  // 0 conv, 1 maxpool
+        ConvLaunch conv;
+        const float* x;
+        float* out;
+        int n, c, h, w;
+    };
+    std::vector<Entry> entries;
+};
+
+extern "C" {
+
+size_t mp_conv_packed_weight_bytes(int cout, int cin, int kh, int kw) {
+    if (cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0) return 0;
+    return (size_t)round_up(cin, 4) * kh * kw * round_up(cout, 16) * sizeof(float);
+}
+
+int mp_conv_pack_weight(const float* w, float* packed, int cout, int cin, int kh, int kw, int transposed, int phase_y,
+                        int phase_x, mp_stream_t stream) {
+    if (!w || !packed) return MP_ERR_NULL;
+    if (cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0) return MP_ERR_SHAPE;
+    if (transposed && (kh != 2 || kw != 2 || phase_y < 0 || phase_y > 1 || phase_x < 0 || phase_x > 1))
+        return MP_ERR_UNSUPPORTED;
+    const int cin_pad4 = round_up(cin, 4), cout_pad16 = round_up(cout, 16);
+    const size_t total = (size_t)cin_pad4 * kh * kw * cout_pad16;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, packed, cout, cin, kh, kw,
+                       cin_pad4, cout_pad16, transposed ? 1 : 0, phase_y, phase_x);
+    return check_launch();
+}
+
+int mp_conv2d_fwd(const mp_conv_desc* desc, const float* x, const float* packed_w, const float* scale,
+                  const float* shift, const float* res1, const float* res2, float* out, mp_stream_t stream) {
+    ConvLaunch L{};
+    int rc = build_launch(desc, x, packed_w, scale, shift, res1, res2, out, L);
+    if (rc != MP_OK) return rc;
+    return launch(L, as_stream(stream));
+}
+
+mp_plan* mp_plan_create(void) { return new (std::nothrow) mp_plan(); }
+
+void mp_plan_destroy(mp_plan* plan) { delete plan; }
+
+int mp_plan_add_conv(mp_plan* plan, const mp_conv_desc* desc, const float* x, const float* packed_w,
+                     const float* scale, const float* shift, const float* res1, const float* res2, float* out) {
+    if (!plan) return MP_ERR_NULL;
+    mp_plan::Entry e{};
+    e.kind = 0;
+    int rc = build_launch(desc, x, packed_w, scale, shift, res1, res2, out, e.conv);
+    if (rc != MP_OK) return rc;
+    plan->entries.push_back(e);
+    return MP_OK;
+}
+
+int mp_plan_add_maxpool(mp_plan* plan, const float* x, float* out, int n, int c, int h, int w) {
+    if (!plan || !x || !out) return MP_ERR_NULL;
+    if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return MP_ERR_SHAPE;
+    mp_plan::Entry e{};
+    e.kind = 1;
+    e.x = x; e.out = out; e.n = n; e.c = c; e.h = h; e.w = w;
+    plan->entries.push_back(e);
+    return MP_OK;
+}
+
+int mp_plan_size(const mp_plan* plan) { return plan ? (int)plan->entries.size() : MP_ERR_NULL; }
+
+int mp_plan_run_range(const mp_plan* plan, int first, int count, mp_stream_t stream) {
+    if (!plan) return MP_ERR_NULL;
+    if (first < 0 || count < 0 || (size_t)first + count > plan->entries.size()) return MP_ERR_SHAPE;
+    for (int i = first; i < first + count; ++i) {
+        const mp_plan::Entry& e = plan->entries[i];
+        int rc = e.kind == 0 ? launch(e.conv, as_stream(stream))
+                             : mp_maxpool3x3s2_same(e.x, e.out, e.n, e.c, e.h, e.w, stream);
+        if (rc != MP_OK) return rc;
+    }
+    return MP_OK;
+}
+
+int mp_plan_run(const mp_plan* plan, mp_stream_t stream) {
+    if (!plan) return MP_ERR_NULL;
+    return mp_plan_run_range(plan, 0, (int)plan->entries.size(), stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,98 @@
+"""Top-down inference engine incl. flip-test aggregation on the MI355X HIP path.
+
+Mirror of mindpose/engine/inferencer/topdown_inferencer.py:17-187: ``TopDownHeatMapInferencer`` loops
+over batches and packs records; ``_MultiRunNet`` is the flip test.  Natively the second forward's
+flip-back, one-pixel shift, averaging and the decode are ONE kernel (the averaged heat-map is never
+materialised), and the two decodes the reference computes and throws away (:168,:170) are skipped.
+"""
+from typing import Any, Dict, Iterable, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ...models import EvalNet
+from ...models.decoders import TopDownHeatMapDecoder
+from ...register import register
+
+
+class _MultiRunNet(nn.Module):
+    """Running the inference twice with horizontal-flip TTA (topdown_inferencer.py:146-187)."""
+
+    def __init__(self, net: EvalNet, decoder: TopDownHeatMapDecoder, flip_index: Union[np.ndarray, torch.Tensor],
+                 shift_heatmap: bool = False) -> None:
+        super().__init__()
+        self.net = net
+        self.decoder = decoder
+        self.shift_heatmap = shift_heatmap
+        fi = torch.as_tensor(np.asarray(flip_index) if not torch.is_tensor(flip_index) else flip_index)
+        self.register_buffer("flip_index", fi.to(torch.int32), persistent=False)
+
+    @torch.no_grad()
+    def forward(self, image: torch.Tensor, center: torch.Tensor, scale: torch.Tensor,
+                score: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        raw_net = self.net.net  # EvalNet.net: backbone + head
+        heatmap = raw_net(image).clone()  # the plan's output buffer is reused by the second run
+        flipped = raw_net(torch.flip(image, dims=[3]))
+        return self.decoder.decode_flip_aggregated(heatmap, flipped, self.flip_index, self.shift_heatmap,
+                                                   center, scale, score)
+
+
+@register("inferencer", extra_name="topdown_heatmap")
+class TopDownHeatMapInferencer:
+    """Runs the (flip-test) network over an iterable of batches and returns the reference's records."""
+
+    def __init__(self, net: EvalNet, config: Optional[Dict[str, Any]] = None, progress_bar: bool = False,
+                 decoder: Optional[TopDownHeatMapDecoder] = None) -> None:
+        self.net = net
+        self.config = config if config else dict()
+        self._inference_cfg = self.load_inference_cfg()
+        self.progress_bar = progress_bar
+        self.decoder = decoder
+        if self.decoder is None and self._inference_cfg["hflip_tta"]:
+            raise ValueError("Decoder must be provided for flip TTA")
+        if self._inference_cfg["hflip_tta"] and not self._inference_cfg["has_heatmap_output"]:
+            raise ValueError("flip TTA need heatmap output.")
+        if self._inference_cfg["hflip_tta"]:
+            self._multi_run_net = _MultiRunNet(self.net, self.decoder, self._inference_cfg["flip_index"],
+                                               shift_heatmap=self._inference_cfg["shift_heatmap"])
+            self._multi_run_net.eval()
+        else:
+            self._multi_run_net = None
+
+    def load_inference_cfg(self) -> Dict[str, Any]:
+        """topdown_inferencer.py:65-82."""
+        cfg = dict()
+        cfg["has_heatmap_output"] = self.config["has_heatmap_output"]
+        cfg["hflip_tta"] = self.config["hflip_tta"]
+        cfg["shift_heatmap"] = self.config["shift_heatmap"]
+        flip_index = np.array(self.config["flip_pairs"])[:, ::-1].flatten()
+        cfg["flip_index"] = np.insert(flip_index, 0, 0)
+        return cfg
+
+    def __call__(self, dataset: Iterable[Dict[str, Any]]) -> List[Dict[str, Any]]:
+        return self.infer(dataset)
+
+    @torch.no_grad()
+    def infer(self, dataset: Iterable[Dict[str, Any]]) -> List[Dict[str, Any]]:
+        """``dataset`` yields dicts with ``image, center, scale, bbox_scores`` (CUDA tensors) and optional
+        ``image_file, bbox_ids``; returns records ``{pred, box, image_path, bbox_id}`` (:84-143)."""
+        outputs = []
+        for data in dataset:
+            args = (data["image"], data["center"], data["scale"], data["bbox_scores"])
+            if self._inference_cfg["hflip_tta"]:
+                preds, boxes = self._multi_run_net(*args)
+            elif self._inference_cfg["has_heatmap_output"]:
+                (preds, boxes), _ = self.net(*args)
+            else:
+                preds, boxes = self.net(*args)
+            preds = preds.cpu().numpy()  # one device->host sync per batch, N*(17*3+6) floats
+            boxes = boxes.cpu().numpy()
+            n = preds.shape[0]
+            paths = data.get("image_file", [None] * n)
+            ids = data.get("bbox_ids", list(range(n)))
+            for i in range(n):
+                path = paths[i].tolist() if hasattr(paths[i], "tolist") else paths[i]
+                bid = ids[i].tolist() if hasattr(ids[i], "tolist") else ids[i]
+                outputs.append(dict(pred=preds[i].tolist(), box=boxes[i].tolist(), image_path=path, bbox_id=bid))
+        return outputs

@@ -1,0 +1,297 @@
+"""HRNet backbone on the MI355X HIP path.
+
+Same graph, constructor arguments, registry names and parameter names as the reference
+(mindpose/models/backbones/hrnet.py:348-718); every conv+BN(+add)(+ReLU) group is one launch of the
+direct fp32-MFMA convolution, and the HRModule fuse rows (:318-344) accumulate in place through the
+conv epilogue (nearest up-sampling happens while storing; nothing is materialised).
+"""
+from typing import Dict, List, Tuple, Type, Union
+
+import torch
+import torch.nn as nn
+
+from ...register import register
+from ..layers import BatchNorm2d, Conv2d, Plan
+from .backbone import Backbone
+from .utils import load_pretrained
+
+__all__ = ["HRNet", "hrnet_w32", "hrnet_w48"]
+
+
+class BasicBlock(nn.Module):
+    """relu(bn2(conv2(relu(bn1(conv1 x)))) + identity) - hrnet.py:30-83 (2 launches)."""
+
+    expansion: int = 1
+
+    def __init__(self, in_channels: int, channels: int, stride: int = 1, down_sample: nn.Module = None) -> None:
+        super().__init__()
+        self.conv1 = Conv2d(in_channels, channels, 3, stride=stride, padding=1)
+        self.bn1 = BatchNorm2d(channels)
+        self.conv2 = Conv2d(channels, channels, 3, stride=1, padding=1)
+        self.bn2 = BatchNorm2d(channels)
+        self.down_sample = down_sample
+
+    def emit(self, plan: Plan, x: torch.Tensor) -> torch.Tensor:
+        identity = x
+        if self.down_sample is not None:
+            identity = plan.conv(x, self.down_sample[0], self.down_sample[1])
+        out = plan.conv(x, self.conv1, self.bn1, relu=True)
+        return plan.conv(out, self.conv2, self.bn2, relu=True, res1=identity)
+
+
+class Bottleneck(nn.Module):
+    """1x1 -> 3x3 (stride) -> 1x1, + identity / down_sample - hrnet.py:86-146 (3-4 launches)."""
+
+    expansion: int = 4
+
+    def __init__(self, in_channels: int, channels: int, stride: int = 1, down_sample: nn.Module = None) -> None:
+        super().__init__()
+        width = channels
+        self.conv1 = Conv2d(in_channels, width, 1)
+        self.bn1 = BatchNorm2d(width)
+        self.conv2 = Conv2d(width, width, 3, stride=stride, padding=1)
+        self.bn2 = BatchNorm2d(width)
+        self.conv3 = Conv2d(width, channels * self.expansion, 1)
+        self.bn3 = BatchNorm2d(channels * self.expansion)
+        self.down_sample = down_sample
+
+    def emit(self, plan: Plan, x: torch.Tensor) -> torch.Tensor:
+        identity = x
+        if self.down_sample is not None:
+            identity = plan.conv(x, self.down_sample[0], self.down_sample[1])
+        out = plan.conv(x, self.conv1, self.bn1, relu=True)
+        out = plan.conv(out, self.conv2, self.bn2, relu=True)
+        return plan.conv(out, self.conv3, self.bn3, relu=True, res1=identity)
+
+
+def _conv_bn(cin: int, cout: int, k: int, stride: int = 1, padding: int = 0, relu: bool = False) -> nn.Sequential:
+    """SequentialCell(conv, bn[, relu]) of the reference; the ReLU is a marker only (fused in the epilogue)."""
+    layers = [Conv2d(cin, cout, k, stride=stride, padding=padding), BatchNorm2d(cout)]
+    if relu:
+        layers.append(nn.ReLU())
+    return nn.Sequential(*layers)
+
+
+def _emit_conv_bn(plan: Plan, seq: nn.Sequential, x: torch.Tensor, **kw) -> torch.Tensor:
+    return plan.conv(x, seq[0], seq[1], relu=kw.pop("relu", len(seq) > 2), **kw)
+
+
+class HRModule(nn.Module):
+    """High-resolution module: 4 blocks per branch, then the exchange unit - hrnet.py:149-344."""
+
+    def __init__(self, num_branches: int, block: Type[Union[BasicBlock, Bottleneck]], num_blocks: List[int],
+                 num_inchannels: List[int], num_channels: List[int], multi_scale_output: bool = True) -> None:
+        super().__init__()
+        self._check_branches(num_branches, num_blocks, num_inchannels, num_channels)
+        self.num_inchannels = num_inchannels
+        self.num_branches = num_branches
+        self.multi_scale_output = multi_scale_output
+        self.branches = nn.ModuleList(
+            [self._make_one_branch(i, block, num_blocks, num_channels) for i in range(num_branches)])
+        self.fuse_layers = self._make_fuse_layers()
+
+    @staticmethod
+    def _check_branches(num_branches, num_blocks, num_inchannels, num_channels) -> None:
+        if num_branches != len(num_blocks):
+            raise ValueError(f"NUM_BRANCHES({num_branches})!= NUM_BLOCKS({len(num_blocks)})")
+        if num_branches != len(num_channels):
+            raise ValueError(f"NUM_BRANCHES({num_branches})!= NUM_CHANNELS({len(num_channels)})")
+        if num_branches != len(num_inchannels):
+            raise ValueError(f"NUM_BRANCHES({num_branches}) != NUM_INCHANNELS({len(num_inchannels)})")
+
+    def _make_one_branch(self, i, block, num_blocks, num_channels, stride: int = 1) -> nn.Sequential:
+        down = None
+        if stride != 1 or self.num_inchannels[i] != num_channels[i] * block.expansion:
+            down = _conv_bn(self.num_inchannels[i], num_channels[i] * block.expansion, 1, stride=stride)
+        layers = [block(self.num_inchannels[i], num_channels[i], stride, down_sample=down)]
+        self.num_inchannels[i] = num_channels[i] * block.expansion
+        for _ in range(1, num_blocks[i]):
+            layers.append(block(self.num_inchannels[i], num_channels[i]))
+        return nn.Sequential(*layers)
+
+    def _make_fuse_layers(self):
+        if self.num_branches == 1:
+            return None
+        nb, ch = self.num_branches, self.num_inchannels
+        rows = []
+        for i in range(nb if self.multi_scale_output else 1):
+            row = []
+            for j in range(nb):
+                if j > i:
+                    row.append(_conv_bn(ch[j], ch[i], 1))
+                elif j == i:
+                    row.append(nn.Identity())
+                else:
+                    chain = []
+                    for k in range(i - j):
+                        last = k == i - j - 1
+                        chain.append(_conv_bn(ch[j], ch[i] if last else ch[j], 3, stride=2, padding=1, relu=not last))
+                    row.append(nn.Sequential(*chain))
+            rows.append(nn.ModuleList(row))
+        return nn.ModuleList(rows)
+
+    def emit(self, plan: Plan, xs: List[torch.Tensor]) -> List[torch.Tensor]:
+        xs = list(xs)
+        for i in range(self.num_branches):
+            for blk in self.branches[i]:
+                xs[i] = blk.emit(plan, xs[i])
+        if self.num_branches == 1:
+            return xs
+        outs = []
+        nb = self.num_branches
+        for i in range(len(self.fuse_layers)):
+            # reference order (hrnet.py:327-339): y = t_0; y = y + t_1; ... ; relu(y).  Every term except
+            # the identity x_i is a conv launch whose epilogue adds the running sum (res1); the identity
+            # rides as res2 on the launch that precedes it (or as res1 of the first launch when i == 0).
+            conv_terms = [j for j in range(nb) if j != i]
+            acc = xs[0] if i == 0 else None
+            ybuf = None
+            for j in conv_terms:
+                relu = j == conv_terms[-1]
+                res2 = xs[i] if (i >= 1 and j == i - 1) else None
+                if j > i:
+                    seq = self.fuse_layers[i][j]
+                    up = xs[i].shape[2] // xs[j].shape[2]
+                    if ybuf is None:
+                        ybuf = plan.alloc(*xs[i].shape)
+                    plan.conv(xs[j], seq[0], seq[1], relu=relu, res1=acc, res2=res2, out=ybuf, upsample=up)
+                else:
+                    chain = self.fuse_layers[i][j]
+                    t = xs[j]
+                    for k in range(len(chain) - 1):
+                        t = _emit_conv_bn(plan, chain[k], t)
+                    if ybuf is None:
+                        ybuf = plan.alloc(*xs[i].shape)
+                    _emit_conv_bn(plan, chain[-1], t, relu=relu, res1=acc, res2=res2, out=ybuf)
+                acc = ybuf
+            outs.append(ybuf)
+        return outs
+
+
+@register("backbone")
+class HRNet(Backbone):
+    """HRNet backbone - hrnet.py:348-614.  ``stage_cfg`` has the reference's schema."""
+
+    blocks_dict = {"BASIC": BasicBlock, "BOTTLENECK": Bottleneck}
+
+    def __init__(self, stage_cfg: Dict[str, Dict[str, int]], in_channels: int = 3) -> None:
+        super().__init__()
+        self.stage_cfg = stage_cfg
+        self.conv1 = Conv2d(in_channels, 64, 3, stride=2, padding=1)
+        self.bn1 = BatchNorm2d(64)
+        self.conv2 = Conv2d(64, 64, 3, stride=2, padding=1)
+        self.bn2 = BatchNorm2d(64)
+
+        self.stage1_cfg = stage_cfg["stage1"]
+        block = self.blocks_dict[self.stage1_cfg["block"]]
+        self.layer1 = self._make_layer(block, 64, self.stage1_cfg["num_channels"][0], self.stage1_cfg["num_blocks"][0])
+        pre = [self.stage1_cfg["num_channels"][0] * block.expansion]
+
+        for idx in (2, 3, 4):
+            cfg = stage_cfg[f"stage{idx}"]
+            setattr(self, f"stage{idx}_cfg", cfg)
+            block = self.blocks_dict[cfg["block"]]
+            channels = [c * block.expansion for c in cfg["num_channels"]]
+            trans, flags = self._make_transition_layer(pre, channels)
+            setattr(self, f"transition{idx - 1}", trans)
+            setattr(self, f"transition{idx - 1}_flags", flags)
+            mso = True if idx < 4 else cfg.get("multiscale_output", False)
+            stage, pre = self._make_stage(cfg, channels, multi_scale_output=mso)
+            setattr(self, f"stage{idx}", stage)
+
+    def _make_transition_layer(self, pre: List[int], cur: List[int]) -> Tuple[nn.ModuleList, List[bool]]:
+        layers, flags = [], []
+        for i in range(len(cur)):
+            if i < len(pre):
+                if cur[i] != pre[i]:
+                    layers.append(_conv_bn(pre[i], cur[i], 3, padding=1, relu=True))
+                    flags.append(True)
+                else:
+                    layers.append(nn.Identity())
+                    flags.append(False)
+            else:
+                chain = []
+                for j in range(i + 1 - len(pre)):
+                    cout = cur[i] if j == i - len(pre) else pre[-1]
+                    chain.append(_conv_bn(pre[-1], cout, 3, stride=2, padding=1, relu=True))
+                layers.append(nn.Sequential(*chain))
+                flags.append(True)
+        return nn.ModuleList(layers), flags
+
+    def _make_layer(self, block, in_channels: int, out_channels: int, blocks: int, stride: int = 1) -> nn.Sequential:
+        down = None
+        if stride != 1 or in_channels != out_channels * block.expansion:
+            down = _conv_bn(in_channels, out_channels * block.expansion, 1, stride=stride)
+        layers = [block(in_channels, out_channels, stride, down_sample=down)]
+        for _ in range(1, blocks):
+            layers.append(block(out_channels * block.expansion, out_channels))
+        return nn.Sequential(*layers)
+
+    def _make_stage(self, cfg, num_inchannels, multi_scale_output: bool = True):
+        block = self.blocks_dict[cfg["block"]]
+        modules = []
+        for i in range(cfg["num_modules"]):
+            mso = not (not multi_scale_output and i == cfg["num_modules"] - 1)
+            modules.append(HRModule(cfg["num_branches"], block, cfg["num_blocks"], num_inchannels,
+                                    cfg["num_channels"], mso))
+            num_inchannels = modules[-1].num_inchannels
+        return nn.Sequential(*modules), num_inchannels
+
+    def emit(self, plan: Plan, x: torch.Tensor) -> torch.Tensor:
+        """Recorded form of ``forward_feature`` hrnet.py:559-605."""
+        x = plan.conv(x, self.conv1, self.bn1, relu=True)
+        x = plan.conv(x, self.conv2, self.bn2, relu=True)
+        for blk in self.layer1:
+            x = blk.emit(plan, x)
+        ys = [x]
+        for idx in (2, 3, 4):
+            trans = getattr(self, f"transition{idx - 1}")
+            flags = getattr(self, f"transition{idx - 1}_flags")
+            cfg = getattr(self, f"stage{idx}_cfg")
+            xs = []
+            for i in range(cfg["num_branches"]):
+                if not flags[i]:
+                    xs.append(ys[i])
+                elif i < len(ys):
+                    xs.append(_emit_conv_bn(plan, trans[i], ys[i]))
+                else:
+                    t = ys[-1]  # new branches are fed from the LAST previous output (hrnet.py:591,:600)
+                    for seq in trans[i]:
+                        t = _emit_conv_bn(plan, seq, t)
+                    xs.append(t)
+            for mod in getattr(self, f"stage{idx}"):
+                xs = mod.emit(plan, xs)
+            ys = xs
+        return ys[0]
+
+    @property
+    def out_channels(self) -> int:
+        return self.stage4_cfg["num_channels"][0]
+
+
+def _hrnet_cfg(c: int) -> Dict[str, Dict]:
+    return dict(
+        stage1=dict(num_modules=1, num_branches=1, block="BOTTLENECK", num_blocks=[4], num_channels=[64]),
+        stage2=dict(num_modules=1, num_branches=2, block="BASIC", num_blocks=[4, 4], num_channels=[c, 2 * c]),
+        stage3=dict(num_modules=4, num_branches=3, block="BASIC", num_blocks=[4, 4, 4], num_channels=[c, 2 * c, 4 * c]),
+        stage4=dict(num_modules=3, num_branches=4, block="BASIC", num_blocks=[4, 4, 4, 4],
+                    num_channels=[c, 2 * c, 4 * c, 8 * c], multiscale_output=False),
+    )
+
+
+@register("backbone")
+def hrnet_w32(pretrained: bool = False, ckpt_url: str = "", in_channels: int = 3) -> HRNet:
+    """HRNet with width 32 - hrnet.py:618-666."""
+    model = HRNet(_hrnet_cfg(32), in_channels=in_channels)
+    if pretrained:
+        load_pretrained(model, ckpt_url=ckpt_url)
+    return model
+
+
+@register("backbone")
+def hrnet_w48(pretrained: bool = False, ckpt_url: str = "", in_channels: int = 3) -> HRNet:
+    """HRNet with width 48 - hrnet.py:670-718."""
+    model = HRNet(_hrnet_cfg(48), in_channels=in_channels)
+    if pretrained:
+        load_pretrained(model, ckpt_url=ckpt_url)
+    return model

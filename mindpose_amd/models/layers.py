@@ -1,0 +1,240 @@
+"""Parameter holders and the launch-plan builder shared by the backbones and heads.
+
+The modules only OWN parameters (named exactly like the reference's MindSpore cells so a mindpose
+checkpoint maps 1:1); all arithmetic happens in ``libmindpose_hip.so``.  A network forward is
+recorded once per input shape into a native launch plan (``mp_plan_*``) and replayed by one C call.
+"""
+import ctypes
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+BN_EPS = 1e-5  # mindspore.nn.BatchNorm2d default eps
+
+
+class Conv2d(nn.Module):
+    """Parameter holder for ``mindspore.nn.Conv2d`` (weight [Cout,Cin,k,k], optional bias)."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int, stride: int = 1, padding: int = 0,
+                 has_bias: bool = False) -> None:
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if has_bias else None
+
+
+class Conv2dTranspose(nn.Module):
+    """Parameter holder for ``mindspore.nn.Conv2dTranspose(k=4, s=2, pad_mode="pad", padding=1)``
+    (weight [Cin,Cout,4,4], no bias) - simple_baseline_head.py:80-88."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 4) -> None:
+        super().__init__()
+        if kernel_size != 4:
+            raise ValueError("Invalid deconv_kernel.")  # only the k=4 / padding=1 recipe is implemented natively
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        self.weight = nn.Parameter(torch.empty(in_channels, out_channels, 4, 4))
+
+
+class BatchNorm2d(nn.Module):
+    """Parameter holder for ``mindspore.nn.BatchNorm2d`` (gamma, beta, moving_mean, moving_variance)."""
+
+    def __init__(self, num_features: int) -> None:
+        super().__init__()
+        self.num_features = num_features
+        self.gamma = nn.Parameter(torch.ones(num_features))
+        self.beta = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("moving_mean", torch.zeros(num_features))
+        self.register_buffer("moving_variance", torch.ones(num_features))
+
+    def folded(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Eval-mode affine: y = x*scale + shift."""
+        scale = self.gamma.detach().float() / torch.sqrt(self.moving_variance.float() + BN_EPS)
+        shift = self.beta.detach().float() - self.moving_mean.float() * scale
+        return scale.contiguous(), shift.contiguous()
+
+
+class Plan:
+    """A recorded forward: native ``mp_plan`` + the tensors it points into."""
+
+    def __init__(self, device: torch.device) -> None:
+        self.lib = _lib.load()
+        self.device = device
+        self.handle = ctypes.c_void_p(self.lib.mp_plan_create())
+        if not self.handle:
+            raise _lib.MindposeHipError("mp_plan_create failed")
+        self.keep: List[torch.Tensor] = []  # every buffer the plan references
+        self.input: Optional[torch.Tensor] = None
+        self.output: Optional[torch.Tensor] = None
+        self.layer_info: List[Dict] = []  # per entry: kind, shapes, MACs (for the roofline report)
+        self._packed: Dict[Tuple[int, int, int], torch.Tensor] = {}
+        self._folded: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.mp_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def alloc(self, *shape: int) -> torch.Tensor:
+        t = torch.empty(shape, device=self.device, dtype=torch.float32)
+        self.keep.append(t)
+        return t
+
+    def run(self) -> None:
+        _lib.check(self.lib.mp_plan_run(self.handle, _lib.stream()), "mp_plan_run")
+
+    def run_range(self, first: int, count: int) -> None:
+        _lib.check(self.lib.mp_plan_run_range(self.handle, first, count, _lib.stream()), "mp_plan_run_range")
+
+    def __len__(self) -> int:
+        return int(self.lib.mp_plan_size(self.handle))
+
+    @property
+    def total_macs(self) -> int:
+        return sum(e.get("macs", 0) for e in self.layer_info)
+
+    # -- weights ------------------------------------------------------------------------------
+    def _pack(self, weight: torch.Tensor, cout: int, cin: int, k: int, transposed: bool, py: int, px: int) -> torch.Tensor:
+        key = (id(weight), py if transposed else -1, px if transposed else -1)
+        if key in self._packed:
+            return self._packed[key]
+        w = weight.detach().to(self.device, torch.float32).contiguous()
+        nbytes = self.lib.mp_conv_packed_weight_bytes(cout, cin, k, k)
+        packed = torch.empty(nbytes // 4, device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.mp_conv_pack_weight(_lib.ptr(w), _lib.ptr(packed), cout, cin, k, k, int(transposed), py, px,
+                                                _lib.stream()), "mp_conv_pack_weight")
+        self.keep += [w, packed]
+        self._packed[key] = packed
+        return packed
+
+    def _affine(self, cout: int, bn: Optional[BatchNorm2d], bias: Optional[torch.Tensor]):
+        key = id(bn) if bn is not None else id(bias)
+        if key in self._folded:
+            return self._folded[key]
+        if bn is not None:
+            scale, shift = bn.folded()
+            scale, shift = scale.to(self.device), shift.to(self.device)
+        else:
+            scale = torch.ones(cout, device=self.device)
+            shift = bias.detach().float().to(self.device).contiguous() if bias is not None else torch.zeros(cout, device=self.device)
+        self.keep += [scale, shift]
+        self._folded[key] = (scale, shift)
+        return scale, shift
+
+    # -- ops ----------------------------------------------------------------------------------
+    def conv(self, x: torch.Tensor, conv: Conv2d, bn: Optional[BatchNorm2d] = None, relu: bool = False,
+             res1: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None,
+             out: Optional[torch.Tensor] = None, upsample: int = 1) -> torch.Tensor:
+        """conv (+BN or bias) (+res1) (+res2) (+ReLU); ``upsample`` = nearest factor applied while storing
+        (``out`` / ``res*`` then live at the up-sampled resolution)."""
+        n, cin, h, w = x.shape
+        k, s, pad = conv.kernel_size, conv.stride, conv.padding
+        if cin != conv.in_channels:
+            raise ValueError(f"conv expects {conv.in_channels} input channels, got {cin}")
+        ho = (h + 2 * pad - k) // s + 1
+        wo = (w + 2 * pad - k) // s + 1
+        oh, ow = ho * upsample, wo * upsample
+        if out is None:
+            out = self.alloc(n, conv.out_channels, oh, ow)
+        if tuple(out.shape) != (n, conv.out_channels, oh, ow):
+            raise ValueError(f"bad out shape {tuple(out.shape)}")
+        for r in (res1, res2):
+            if r is not None and tuple(r.shape) != tuple(out.shape):
+                raise ValueError(f"residual shape {tuple(r.shape)} != out shape {tuple(out.shape)}")
+        packed = self._pack(conv.weight, conv.out_channels, cin, k, False, 0, 0)
+        scale, shift = self._affine(conv.out_channels, bn, conv.bias)
+        d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=conv.out_channels, kh=k, kw=k, stride=s, pad_top=pad,
+                          pad_left=pad, conv_h=ho, conv_w=wo, out_h=oh, out_w=ow, out_mul=upsample, out_rep=upsample,
+                          out_off_y=0, out_off_x=0, relu=int(relu), tap_dilation_unused=0)
+        _lib.check(self.lib.mp_plan_add_conv(self.handle, ctypes.byref(d), _lib.ptr(x), _lib.ptr(packed),
+                                             _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(res1), _lib.ptr(res2),
+                                             _lib.ptr(out)), "mp_plan_add_conv")
+        self.layer_info.append(dict(kind="conv", k=k, stride=s, cin=cin, cout=conv.out_channels, h=h, w=w, n=n,
+                                    macs=n * ho * wo * conv.out_channels * cin * k * k))
+        return out
+
+    def deconv4x4s2(self, x: torch.Tensor, deconv: Conv2dTranspose, bn: BatchNorm2d, relu: bool = True) -> torch.Tensor:
+        """Conv2dTranspose(k=4, s=2, p=1) + BN + ReLU as four 2x2 sub-pixel phase convolutions."""
+        n, cin, h, w = x.shape
+        cout = deconv.out_channels
+        out = self.alloc(n, cout, 2 * h, 2 * w)
+        scale, shift = self._affine(cout, bn, None)
+        for py in (0, 1):
+            for px in (0, 1):
+                packed = self._pack(deconv.weight, cout, cin, 2, True, py, px)
+                d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=2, kw=2, stride=1, pad_top=1 - py,
+                                  pad_left=1 - px, conv_h=h, conv_w=w, out_h=2 * h, out_w=2 * w, out_mul=2, out_rep=1,
+                                  out_off_y=py, out_off_x=px, relu=int(relu), tap_dilation_unused=0)
+                _lib.check(self.lib.mp_plan_add_conv(self.handle, ctypes.byref(d), _lib.ptr(x), _lib.ptr(packed),
+                                                     _lib.ptr(scale), _lib.ptr(shift), None, None, _lib.ptr(out)),
+                           "mp_plan_add_conv(deconv phase)")
+                self.layer_info.append(dict(kind="deconv_phase", k=2, stride=1, cin=cin, cout=cout, h=h, w=w, n=n,
+                                            macs=n * h * w * cout * cin * 4))
+        return out
+
+    def maxpool3x3s2_same(self, x: torch.Tensor) -> torch.Tensor:
+        n, c, h, w = x.shape
+        out = self.alloc(n, c, (h + 1) // 2, (w + 1) // 2)
+        _lib.check(self.lib.mp_plan_add_maxpool(self.handle, _lib.ptr(x), _lib.ptr(out), n, c, h, w), "mp_plan_add_maxpool")
+        self.layer_info.append(dict(kind="maxpool", n=n, c=c, h=h, w=w, macs=0))
+        return out
+
+
+class PlannedModule(nn.Module):
+    """Base of every module whose forward is a recorded HIP launch plan.
+
+    Sub-classes implement ``emit(plan, x) -> out`` (record launches, return the output buffer).
+    ``forward`` copies the batch into the plan's static input buffer (skipped when the caller already
+    wrote into ``input_buffer(shape)``), replays the plan and returns the plan's output buffer
+    (a view that the next call overwrites - clone it if it must outlive the next forward).
+    """
+
+    def __init__(self) -> None:
+        super().__init__()
+        self._plans: Dict[Tuple, Plan] = {}
+
+    def emit(self, plan: Plan, x: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError("Child class must implement this method.")
+
+    def invalidate_plans(self) -> None:
+        """Call after parameters change (checkpoint load, optimizer step): packed weights are re-built."""
+        for m in self.modules():
+            if isinstance(m, PlannedModule):
+                m._plans.clear()
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._plans.clear()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def get_plan(self, shape, device) -> Plan:
+        key = (tuple(shape), str(device))
+        plan = self._plans.get(key)
+        if plan is None:
+            if device.type != "cuda":
+                raise _lib.MindposeHipError(
+                    "mindpose_amd networks run on the MI355X HIP path only (no CPU fallback): move the module and "
+                    "its inputs to a CUDA device")
+            with torch.no_grad():
+                plan = Plan(device)
+                plan.input = plan.alloc(*shape)
+                plan.output = self.emit(plan, plan.input)
+            self._plans[key] = plan
+        return plan
+
+    def input_buffer(self, shape, device=None) -> torch.Tensor:
+        device = device or next(self.parameters()).device
+        return self.get_plan(shape, torch.device(device)).input
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = _lib.require_cuda_f32(x, "input")
+        plan = self.get_plan(x.shape, x.device)
+        if x.data_ptr() != plan.input.data_ptr():
+            plan.input.copy_(x)
+        plan.run()
+        return plan.output

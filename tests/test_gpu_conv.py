@@ -1,0 +1,207 @@
+"""GPU parity of the direct fp32-MFMA convolution family and of the whole networks, through the C ABI
+(launch plan), against independent torch-CPU formulations / the CPU oracle.
+
+Tolerance: BASELINE.json asks heat-maps within 1e-3 (fp32).  v_mfma_f32_16x16x4_f32 is an exact fp32 FMA
+chain, so single layers are held to 2e-5 of the output scale and whole networks to 1e-3."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import mindpose_amd as mp  # noqa: E402
+from mindpose_amd.models.layers import BatchNorm2d, Conv2d, Conv2dTranspose, Plan  # noqa: E402
+from oracle import nets as onets  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def _rand_bn(c, g):
+    bn = BatchNorm2d(c)
+    with torch.no_grad():
+        bn.gamma.copy_(torch.rand(c, generator=g) + 0.5)
+        bn.beta.copy_(torch.randn(c, generator=g) * 0.1)
+        bn.moving_mean.copy_(torch.randn(c, generator=g) * 0.1)
+        bn.moving_variance.copy_(torch.rand(c, generator=g) + 0.5)
+    return bn
+
+
+def _nerr(got, ref):
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-20))
+
+
+CONV_CASES = [
+    # n, cin, cout, k, s, pad, h, w, relu, res, bias
+    (2, 32, 32, 3, 1, 1, 64, 48, True, True, False),    # W32 branch 0
+    (3, 64, 64, 3, 1, 1, 32, 24, True, True, False),    # branch 1
+    (3, 128, 128, 3, 1, 1, 16, 12, True, False, False),  # branch 2
+    (5, 256, 256, 3, 1, 1, 8, 6, True, True, False),    # branch 3 (multi-image tiles, W % 4 != 0)
+    (2, 3, 64, 3, 2, 1, 256, 192, True, False, False),  # stem conv1 (cin padded to 4)
+    (2, 64, 64, 3, 2, 1, 128, 96, True, False, False),  # stem conv2
+    (2, 256, 32, 3, 1, 1, 64, 48, True, False, False),  # transition1.0
+    (2, 256, 64, 3, 2, 1, 64, 48, True, False, False),  # transition1.1
+    (2, 64, 256, 1, 1, 0, 64, 48, False, True, False),  # bottleneck conv3 + identity
+    (2, 256, 64, 1, 1, 0, 64, 48, True, False, False),  # bottleneck conv1
+    (2, 32, 17, 1, 1, 0, 64, 48, False, False, True),   # HRNet head (bias, cout=17)
+    (2, 32, 64, 3, 2, 1, 64, 48, False, True, False),   # fuse down
+    (2, 48, 48, 3, 1, 1, 64, 48, True, True, False),    # W48 branch 0
+    (2, 96, 192, 3, 2, 1, 18, 14, True, False, False),  # odd-ish sizes
+    (1, 5, 7, 3, 1, 1, 9, 7, True, True, False),        # tiny ragged
+    (3, 8, 40, 1, 2, 0, 10, 6, False, False, False),    # 1x1 stride 2 (ResNet down_sample), cout=40
+    (2, 3, 64, 7, 2, 3, 64, 48, True, False, False),    # ResNet stem 7x7
+    (1, 3, 64, 7, 2, 3, 256, 192, True, False, False),  # ResNet stem full size
+    (2, 512, 2048, 1, 1, 0, 8, 6, False, True, False),  # ResNet layer4 conv3
+    (7, 16, 16, 3, 1, 1, 4, 4, True, True, False),      # N not a multiple of the image group
+    (2, 32, 32, 3, 1, 1, 96, 72, True, True, False),    # 384x288 config, W=72
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[f"n{c[0]}_{c[1]}to{c[2]}_k{c[3]}s{c[4]}_{c[6]}x{c[7]}" for c in CONV_CASES])
+def test_conv_bn_act_vs_torch(case):
+    n, cin, cout, k, s, pad, h, w, relu, res, bias = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    conv = Conv2d(cin, cout, k, stride=s, padding=pad, has_bias=bias)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (cin * k * k)) ** 0.5)
+        if bias:
+            conv.bias.copy_(torch.randn(cout, generator=g))
+    bn = None if bias else _rand_bn(cout, g)
+    x = torch.randn(n, cin, h, w, generator=g)
+    ho, wo = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+    r = torch.randn(n, cout, ho, wo, generator=g) if res else None
+    ref = F.conv2d(x, conv.weight, conv.bias, stride=s, padding=pad)
+    if bn is not None:
+        ref = F.batch_norm(ref, bn.moving_mean, bn.moving_variance, bn.gamma, bn.beta, False, 0.0, 1e-5)
+    if res:
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    plan = Plan(DEV)
+    xd = x.to(DEV)
+    rd = r.to(DEV) if res else None
+    out = plan.conv(xd, conv, bn, relu=relu, res1=rd)
+    plan.run()
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape
+    assert _nerr(out.cpu(), ref.detach()) < 2e-5
+
+
+@pytest.mark.parametrize("up", [2, 4, 8])
+def test_fuse_upsample_add_two_residuals(up):
+    # HRModule fuse term j > i: relu(res1 + up_nearest(bn(conv1x1(x))) + res2), in place on res1
+    g = torch.Generator().manual_seed(up)
+    cin, cout, h, w, n = 32 * up, 32, 64 // up, 48 // up, 2
+    conv = Conv2d(cin, cout, 1)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (1.0 / cin) ** 0.5)
+    bn = _rand_bn(cout, g)
+    x = torch.randn(n, cin, h, w, generator=g)
+    acc = torch.randn(n, cout, 64, 48, generator=g)
+    idt = torch.randn(n, cout, 64, 48, generator=g)
+    t = F.batch_norm(F.conv2d(x, conv.weight), bn.moving_mean, bn.moving_variance, bn.gamma, bn.beta, False, 0.0, 1e-5)
+    ref = F.relu(acc + F.interpolate(t, size=(64, 48), mode="nearest") + idt)
+    plan = Plan(DEV)
+    accd = acc.to(DEV)
+    out = plan.conv(x.to(DEV), conv, bn, relu=True, res1=accd, res2=idt.to(DEV), out=accd, upsample=up)
+    plan.run()
+    torch.cuda.synchronize()
+    assert out.data_ptr() == accd.data_ptr()
+    assert _nerr(out.cpu(), ref.detach()) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 32, 8, 6), (1, 2048, 256, 8, 6), (3, 20, 24, 5, 7)])
+def test_deconv4x4s2_bn_relu_vs_torch(shape):
+    n, cin, cout, h, w = shape
+    g = torch.Generator().manual_seed(cin)
+    dc = Conv2dTranspose(cin, cout, 4)
+    with torch.no_grad():
+        dc.weight.copy_(torch.randn(dc.weight.shape, generator=g) * (0.5 / cin) ** 0.5)
+    bn = _rand_bn(cout, g)
+    x = torch.randn(n, cin, h, w, generator=g)
+    ref = F.relu(F.batch_norm(F.conv_transpose2d(x, dc.weight, None, stride=2, padding=1), bn.moving_mean,
+                              bn.moving_variance, bn.gamma, bn.beta, False, 0.0, 1e-5))
+    plan = Plan(DEV)
+    out = plan.deconv4x4s2(x.to(DEV), dc, bn, relu=True)
+    plan.run()
+    torch.cuda.synchronize()
+    assert out.shape == (n, cout, 2 * h, 2 * w)
+    assert _nerr(out.cpu(), ref.detach()) < 2e-5
+
+
+def _net(backbone, head):
+    return mp.init_synthetic(mp.create_network(backbone, head), seed=0).to(DEV).eval()
+
+
+def test_reference_shape_tests():
+    # the reference's own (shape-only) tests: tests/models/backbones/test_hrnet.py, test_resnet.py, heads/*
+    x = torch.rand(4, 3, 32, 32, device=DEV)
+    for name, ch in (("hrnet_w32", 32), ("hrnet_w48", 48)):
+        bb = mp.init_synthetic(mp.create_backbone(name), 0).to(DEV)
+        assert bb(x).shape == (4, ch, 8, 8) and bb.out_channels == ch
+    bb = mp.init_synthetic(mp.create_backbone("resnet50"), 0).to(DEV)
+    assert bb(x).shape == (4, 2048, 1, 1) and bb.out_channels == 2048
+    head = mp.init_synthetic(mp.create_head("hrnet_head", in_channels=32), 0).to(DEV)
+    assert head(torch.rand(4, 32, 8, 8, device=DEV)).shape == (4, 17, 8, 8)
+    head = mp.init_synthetic(mp.create_head("simple_baseline_head", in_channels=32), 0).to(DEV)
+    assert head(torch.rand(4, 32, 8, 8, device=DEV)).shape == (4, 17, 64, 64)
+
+
+@pytest.mark.parametrize("backbone,head,shape", [
+    ("hrnet_w32", "hrnet_head", (2, 3, 64, 48)),
+    ("hrnet_w32", "hrnet_head", (3, 3, 256, 192)),
+    ("hrnet_w48", "hrnet_head", (1, 3, 128, 96)),
+    ("resnet50", "simple_baseline_head", (2, 3, 256, 192)),
+    ("resnet50", "simple_baseline_head", (1, 3, 64, 64)),
+])
+def test_network_heatmaps_vs_oracle(backbone, head, shape):
+    net = _net(backbone, head)
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(0))
+    got = net(x.to(DEV)).cpu()
+    ref = onets.net_forward({k: v.cpu() for k, v in net.state_dict().items()}, x, backbone, head)
+    assert got.shape == ref.shape
+    err = _nerr(got, ref)
+    assert err < 1e-3, f"normalised max error {err}"
+    # arg-max agreement wherever the oracle's top-1/top-2 margin exceeds the heat-map tolerance
+    n, k = got.shape[:2]
+    rf = ref.reshape(n, k, -1)
+    top2 = rf.topk(2, dim=2).values
+    safe = (top2[..., 0] - top2[..., 1]) > 2e-3 * ref.abs().max()
+    assert torch.equal(got.reshape(n, k, -1).argmax(2)[safe], rf.argmax(2)[safe])
+
+
+def test_eval_net_and_flip_tta_end_to_end():
+    from oracle import decoder as od
+    from tests.golden import recipes
+    net = _net("hrnet_w32", "hrnet_head")
+    dec = mp.create_decoder("topdown_heatmap", shift_coordinate=True).to(DEV)
+    ev = mp.create_eval_network(net, dec, output_raw=True)
+    x = torch.randn(2, 3, 256, 192, generator=torch.Generator().manual_seed(3))
+    center, scale, score = (torch.from_numpy(a) for a in recipes.boxes(2, 4))
+    (preds, boxes), hm = ev(x.to(DEV), center.to(DEV), scale.to(DEV), score.to(DEV))
+    rp, rb, ri = od.decode(hm.cpu().numpy(), center.numpy(), scale.numpy(), score.numpy(), shift_coord=True)
+    assert np.array_equal(dec.last_argmax.cpu().numpy(), ri.astype(np.int32))
+    assert np.array_equal(preds.cpu().numpy(), rp) and np.array_equal(boxes.cpu().numpy(), rb)
+    hm0 = hm.clone()
+    inf = mp.TopDownHeatMapInferencer(ev, config=dict(has_heatmap_output=True, hflip_tta=True, shift_heatmap=True,
+                                                      flip_pairs=recipes.FLIP_PAIRS), decoder=dec)
+    recs = inf([dict(image=x.to(DEV), center=center.to(DEV), scale=scale.to(DEV), bbox_scores=score.to(DEV))])
+    hf = net(torch.flip(x, dims=[3]).to(DEV)).cpu().numpy()
+    avg = od.flip_aggregate(hm0.cpu().numpy(), hf, recipes.FLIP_INDEX, shift_heatmap=True)
+    rp, rb, _ = od.decode(avg, center.numpy(), scale.numpy(), score.numpy(), shift_coord=True)
+    assert len(recs) == 2 and set(recs[0]) == {"pred", "box", "image_path", "bbox_id"}
+    assert np.array_equal(np.array([r["pred"] for r in recs], dtype=np.float32), rp)
+    assert np.array_equal(np.array([r["box"] for r in recs], dtype=np.float32), rb)
+
+
+def test_network_with_loss_and_cpu_input_fails_loudly():
+    net = _net("hrnet_w32", "hrnet_head")
+    nwl = mp.create_network_with_loss(net, mp.create_loss("joint_mse", use_target_weight=True), has_extra_inputs=True)
+    x = torch.randn(2, 3, 64, 48, device=DEV)
+    t = mp.TopDownGenerateTarget(config=dict(image_size=[48, 64], heatmap_size=[12, 16]), sigma=2.0)
+    kp = torch.tensor([[[10.0, 20.0, 1.0]] * 17, [[30.0, 40.0, 1.0]] * 17], device=DEV)
+    target, w = t(kp)
+    loss = nwl(x, target, w)
+    assert loss.numel() == 1 and torch.isfinite(loss)
+    with pytest.raises(mp._lib.MindposeHipError):
+        net(torch.randn(1, 3, 64, 48))  # CPU input: no fallback
