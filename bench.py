@@ -1,0 +1,214 @@
+"""Benchmark of the hot path: HRNet-W32 256x192 top-down inference (BASELINE.json metric / configs[2]).
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A step = one pass of the hot path over one per-GPU batch of synthetic 256x192 crops that is already
+resident in HBM: HRNet-W32 backbone + HRNetHead (direct fp32-MFMA conv plan) + TopDownHeatMapDecoder
+(arg-max + +-0.25 shift + back-projection).  Crops shard over ranks with no data-path collective
+(weak scaling); value = images all ranks processed / max-over-ranks wall time.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     - the dominant kernel (the conv instantiation with the largest share of step time):
+                 algorithmic FLOP per launch / its average launch duration, measured live with HIP
+                 events on the launch stream; peak = fp32 matrix-core rate of MI355X_MICROARCH.md.
+  cpu_baseline - the CPU oracle (torch-CPU fp32 restatement; the literal MindSpore-CPU path cannot run:
+                 MindSpore is not installable here or on the GPU box) timed on a bounded sample on the
+                 host cores, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+VARIANT_TEMPLATE = {0: "3,2,4,1", 1: "3,4,4,1", 2: "3,3,4,1", 3: "3,2,2,2", 4: "3,1,2,2"}  # PS,CS,WAVES_P,WAVES_C
+
+
+def kernel_name(info):
+    return f"conv_mfma_kernel<{info['ks']},{info['stride']},{VARIANT_TEMPLATE[info['variant']]}>"
+
+
+def time_plan_entries(plan, reps):
+    """Average device time of every plan entry, HIP events on the current (launch) stream."""
+    n = len(plan)
+    out = []
+    stream = torch.cuda.current_stream()
+    for i in range(n):
+        plan.run_range(i, 1)  # warm
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            plan.run_range(i, 1)
+        e1.record(stream)
+        e1.synchronize()
+        out.append(e0.elapsed_time(e1) * 1e-3 / reps)
+    return out
+
+
+def roofline_report(plan, reps=5):
+    per_entry = time_plan_entries(plan, reps)
+    groups = {}
+    for i, t in enumerate(per_entry):
+        info = plan.entry_info(i)
+        if info["kind_id"] != 0:
+            continue
+        g = groups.setdefault(kernel_name(info), dict(time=0.0, flops=0.0, launches=0))
+        g["time"] += t
+        g["flops"] += 2.0 * info["macs"]
+        g["launches"] += 1
+    dom = max(groups, key=lambda k: groups[k]["time"])
+    g = groups[dom]
+    fam_t = sum(v["time"] for v in groups.values())
+    fam_f = sum(v["flops"] for v in groups.values())
+    achieved = g["flops"] / g["time"] / 1e12
+    return {
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+        "kernel": dom, "launches_per_step": g["launches"],
+        "flop_per_launch": round(g["flops"] / g["launches"]), "avg_launch_us": round(g["time"] / g["launches"] * 1e6, 2),
+        "share_of_conv_time": round(g["time"] / fam_t, 3),
+        "all_conv_launches": {"launches_per_step": sum(v["launches"] for v in groups.values()),
+                              "achieved": round(fam_f / fam_t / 1e12, 2), "frac": round(fam_f / fam_t / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                              "sum_launch_ms": round(fam_t * 1e3, 3)},
+        "per_kernel": {k: {"launches": v["launches"], "ms": round(v["time"] * 1e3, 3),
+                           "tflops": round(v["flops"] / v["time"] / 1e12, 2)} for k, v in sorted(groups.items())},
+    }
+
+
+def cpu_baseline(state_dict, batch, budget_s=20.0):
+    """CPU oracle on the host cores: HRNet-W32 forward + decode on `batch` crops, repeated until ~budget."""
+    from oracle import decoder as od
+    from oracle import nets as onets
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = {k: v.detach().cpu() for k, v in state_dict.items()}
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(batch, 3, 256, 192, generator=g)
+    center = np.full((batch, 2), [96.0, 128.0], dtype=np.float32)
+    scale = np.full((batch, 2), [0.96, 1.28], dtype=np.float32)
+    score = np.ones(batch, dtype=np.float32)
+
+    def one():
+        hm = onets.net_forward(sd, x, "hrnet_w32", "hrnet_head").numpy()
+        od.decode(hm, center, scale, score, shift_coord=True)
+
+    one()  # warm-up
+    t0 = time.perf_counter()
+    iters = 0
+    while True:
+        one()
+        iters += 1
+        if time.perf_counter() - t0 > budget_s or iters >= 20:
+            break
+    dt = time.perf_counter() - t0
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": round(batch * iters / dt, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{iters} x batch {batch} HRNet-W32 256x192 forward+decode, torch-CPU fp32 oracle "
+                      f"(MindSpore-CPU reference path not installable), os.cpu_count={os.cpu_count()}, cpu='{model}'"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="crops per GPU per step (reference per-device batch_size)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group(backend="nccl", device_id=dev)  # RCCL; only the timing barrier / MAX uses it
+
+    import mindpose_amd as mp
+
+    torch.manual_seed(0)
+    net = mp.init_synthetic(mp.create_network("hrnet_w32", "hrnet_head"), seed=0).to(dev).eval()
+    decoder = mp.create_decoder("topdown_heatmap", shift_coordinate=True).to(dev)
+    eval_net = mp.create_eval_network(net, decoder, output_raw=True)
+
+    n = args.batch
+    # synthetic crops written straight into the plan's resident input buffer (inputs in HBM before timing)
+    gen = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    image = net.input_buffer((n, 3, 256, 192), dev)
+    image.copy_(torch.randn(n, 3, 256, 192, generator=gen))
+    center = (torch.rand(n, 2, generator=gen) * 400).to(dev)
+    scale = (torch.rand(n, 2, generator=gen) * 2.7 + 0.3).to(dev)
+    score = torch.rand(n, generator=gen).to(dev)
+
+    def step():
+        return eval_net(image, center, scale, score)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        plan = net.get_plan((n, 3, 256, 192), dev)
+        result = {
+            "metric": "images/sec at 256x192, HRNet-W32 top-down inference (backbone+head+decode)",
+            "value": round(world * n * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[2]: HRNet-W32 256x192 inference, 1xMI355X per rank, multi-branch conv + "
+                                   "fuse layers on fp32 MFMA, HRNetHead, arg-max+shift decode",
+                       "per_gpu_batch": n, "global_batch": n * world, "image": "256x192", "heatmap": "64x48x17",
+                       "sharding": "crops split over ranks, no data-path collective",
+                       "gflop_per_image": round(2e-9 * plan.total_macs / n, 3), "launches_per_step": len(plan) + 1},
+        }
+        if not args.no_roofline:
+            result["roofline"] = roofline_report(plan)
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(net.state_dict(), batch=8)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -53,6 +53,7 @@ _PROTOTYPES = {
     "mp_plan_size": (c_int, [ctypes.c_void_p]),
     "mp_plan_run": (c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "mp_plan_run_range": (c_int, [ctypes.c_void_p, c_int, c_int, ctypes.c_void_p]),
+    "mp_plan_entry_info": (c_int, [ctypes.c_void_p, c_int, ctypes.POINTER(ctypes.c_int64)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)

@@ -272,6 +272,22 @@ int mp_plan_run_range(const mp_plan* plan, int first, int count, mp_stream_t str
     return MP_OK;
 }
 
+int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]) {
+    if (!plan || !info) return MP_ERR_NULL;
+    if (index < 0 || (size_t)index >= plan->entries.size()) return MP_ERR_SHAPE;
+    const mp_plan::Entry& e = plan->entries[index];
+    for (int i = 0; i < 12; ++i) info[i] = 0;
+    info[0] = e.kind;
+    if (e.kind == 0) {
+        int ct, pt;
+        variant_dims(e.conv.variant, ct, pt);
+        info[1] = e.conv.ks; info[2] = e.conv.stride; info[3] = e.conv.variant; info[4] = e.conv.p.total_blocks;
+        info[5] = (int64_t)e.conv.lds_bytes; info[6] = ct; info[7] = pt; info[8] = e.conv.p.CK; info[9] = e.conv.p.G;
+        info[10] = e.conv.p.R;
+    }
+    return MP_OK;
+}
+
 int mp_plan_run(const mp_plan* plan, mp_stream_t stream) {
     if (!plan) return MP_ERR_NULL;
     return mp_plan_run_range(plan, 0, (int)plan->entries.size(), stream);

@@ -152,6 +152,10 @@ class HRModule(nn.Module):
                 if j > i:
                     seq = self.fuse_layers[i][j]
                     up = xs[i].shape[2] // xs[j].shape[2]
+                    if xs[j].shape[2] * up != xs[i].shape[2] or xs[j].shape[3] * up != xs[i].shape[3]:
+                        raise ValueError(
+                            f"HRNet fuse needs an integer nearest-upsample factor, got {tuple(xs[j].shape[2:])} -> "
+                            f"{tuple(xs[i].shape[2:])}; use an input whose height and width are multiples of 32")
                     if ybuf is None:
                         ybuf = plan.alloc(*xs[i].shape)
                     plan.conv(xs[j], seq[0], seq[1], relu=relu, res1=acc, res2=res2, out=ybuf, upsample=up)

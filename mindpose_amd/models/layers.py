@@ -92,6 +92,16 @@ class Plan:
     def run_range(self, first: int, count: int) -> None:
         _lib.check(self.lib.mp_plan_run_range(self.handle, first, count, _lib.stream()), "mp_plan_run_range")
 
+    def entry_info(self, index: int) -> Dict[str, int]:
+        """Launch geometry the native side chose for entry ``index`` (+ the python-side shape record)."""
+        buf = (ctypes.c_int64 * 12)()
+        _lib.check(self.lib.mp_plan_entry_info(self.handle, index, buf), "mp_plan_entry_info")
+        keys = ["kind_id", "ks", "stride", "variant", "workgroups", "lds_bytes", "cout_tile", "pixel_tile", "cin_chunk",
+                "images_per_tile", "rows_per_tile"]
+        info = dict(zip(keys, [int(v) for v in buf]))
+        info.update(self.layer_info[index])
+        return info
+
     def __len__(self) -> int:
         return int(self.lib.mp_plan_size(self.handle))
 

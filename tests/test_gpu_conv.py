@@ -148,7 +148,7 @@ def test_reference_shape_tests():
 
 
 @pytest.mark.parametrize("backbone,head,shape", [
-    ("hrnet_w32", "hrnet_head", (2, 3, 64, 48)),
+    ("hrnet_w32", "hrnet_head", (2, 3, 96, 64)),
     ("hrnet_w32", "hrnet_head", (3, 3, 256, 192)),
     ("hrnet_w48", "hrnet_head", (1, 3, 128, 96)),
     ("resnet50", "simple_baseline_head", (2, 3, 256, 192)),
@@ -197,11 +197,11 @@ def test_eval_net_and_flip_tta_end_to_end():
 def test_network_with_loss_and_cpu_input_fails_loudly():
     net = _net("hrnet_w32", "hrnet_head")
     nwl = mp.create_network_with_loss(net, mp.create_loss("joint_mse", use_target_weight=True), has_extra_inputs=True)
-    x = torch.randn(2, 3, 64, 48, device=DEV)
-    t = mp.TopDownGenerateTarget(config=dict(image_size=[48, 64], heatmap_size=[12, 16]), sigma=2.0)
+    x = torch.randn(2, 3, 64, 64, device=DEV)
+    t = mp.TopDownGenerateTarget(config=dict(image_size=[64, 64], heatmap_size=[16, 16]), sigma=2.0)
     kp = torch.tensor([[[10.0, 20.0, 1.0]] * 17, [[30.0, 40.0, 1.0]] * 17], device=DEV)
     target, w = t(kp)
     loss = nwl(x, target, w)
     assert loss.numel() == 1 and torch.isfinite(loss)
     with pytest.raises(mp._lib.MindposeHipError):
-        net(torch.randn(1, 3, 64, 48))  # CPU input: no fallback
+        net(torch.randn(1, 3, 64, 64))  # CPU input: no fallback

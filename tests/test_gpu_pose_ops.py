@@ -51,8 +51,12 @@ def test_decoder_vs_golden_and_oracle(case):
         # offset is compared in heat-map pixels on well-conditioned joints (Gaussian blobs)
         ref = g[name + "/preds"]
         if kind == "uniform":
-            # U(0,1) noise maps: Hessian of log(blur) is tiny -> ill-conditioned by construction
-            np.testing.assert_allclose(preds[..., :2], ref[..., :2], rtol=2e-2, atol=2.0)
+            # U(0,1) noise maps: the Hessian of log(blur) is nearly singular on some joints, so
+            # inv(Hessian) amplifies last-ulp blur differences without bound there: require 99 % of the
+            # coordinates within 1e-3 relative and every one within 10 %
+            close = np.isclose(preds[..., :2], ref[..., :2], rtol=1e-3, atol=0.5)
+            assert close.mean() >= 0.99
+            np.testing.assert_allclose(preds[..., :2], ref[..., :2], rtol=0.1, atol=2.0)
         else:
             mask = np.ones(shape[:2], dtype=bool)
             if shape[0] > 1:
@@ -172,14 +176,14 @@ def test_loss_fwd_bwd(name):
     weighted = mp.create_loss("joint_mse", use_target_weight=True)(tp, tt, tw)
     assert plain.numel() == 1 and weighted.numel() == 1
     # tolerance: heat-maps/loss within 1e-3 (BASELINE.json); we hold 1e-6 relative
-    assert abs(float(plain) - float(g[name + "/loss_plain"])) <= 1e-6 * abs(float(g[name + "/loss_plain"]))
-    assert abs(float(weighted) - float(g[name + "/loss_weighted"])) <= 1e-6 * abs(float(g[name + "/loss_weighted"]))
+    assert abs(float(plain.detach()) - float(g[name + "/loss_plain"])) <= 1e-6 * abs(float(g[name + "/loss_plain"]))
+    assert abs(float(weighted.detach()) - float(g[name + "/loss_weighted"])) <= 1e-6 * abs(float(g[name + "/loss_weighted"]))
     (weighted * 3.0).backward()
     ref = ol.joints_mse_grad(pred, target, w, use_target_weight=True, grad_out=3.0)
     np.testing.assert_allclose(tp.grad.cpu().numpy(), ref, rtol=1e-6, atol=1e-12)
     # determinism: two runs are bit-identical
     again = mp.create_loss("joint_mse", use_target_weight=True)(tp.detach(), tt, tw)
-    assert float(again) == float(weighted)
+    assert float(again) == float(weighted.detach())
 
 
 def test_loss_known_answer_and_full_size():
