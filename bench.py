@@ -31,6 +31,10 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP
 VARIANT_TEMPLATE = {0: "3,2,4,1", 1: "3,4,4,1", 2: "3,3,4,1", 3: "3,2,2,2", 4: "3,1,2,2"}  # PS,CS,WAVES_P,WAVES_C
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def kernel_name(info):
     return f"conv_mfma_kernel<{info['ks']},{info['stride']},{VARIANT_TEMPLATE[info['variant']]}>"
 
@@ -87,7 +91,12 @@ def cpu_baseline(state_dict, batch, budget_s=20.0):
     """CPU oracle on the host cores: HRNet-W32 forward + decode on `batch` crops, repeated until ~budget."""
     from oracle import decoder as od
     from oracle import nets as onets
-    torch.set_num_threads(os.cpu_count() or 1)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))  # the GPU box grants ~16 host cores per GPU; more threads only thrash
+    torch.set_num_threads(cores)
     sd = {k: v.detach().cpu() for k, v in state_dict.items()}
     g = torch.Generator().manual_seed(0)
     x = torch.randn(batch, 3, 256, 192, generator=g)
@@ -99,13 +108,17 @@ def cpu_baseline(state_dict, batch, budget_s=20.0):
         hm = onets.net_forward(sd, x, "hrnet_w32", "hrnet_head").numpy()
         od.decode(hm, center, scale, score, shift_coord=True)
 
-    one()  # warm-up
+    t0 = time.perf_counter()
+    one()  # warm-up, also sizes the sample
+    warm = time.perf_counter() - t0
+    log(f"cpu_baseline: warm-up iteration {warm:.1f}s on {cores} threads")
+    max_iters = max(1, min(20, int(budget_s / max(warm, 1e-3))))
     t0 = time.perf_counter()
     iters = 0
-    while True:
+    while iters < max_iters:
         one()
         iters += 1
-        if time.perf_counter() - t0 > budget_s or iters >= 20:
+        if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
     model = "unknown"
@@ -172,9 +185,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    log(f"rank {rank}: plan built ({len(net.get_plan((n, 3, 256, 192), dev))} launches), warming up")
     for _ in range(args.warmup):
         step()
     sync_all()
+    log("timing")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -185,6 +200,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    log(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step")
     result = None
     if rank == 0:
         plan = net.get_plan((n, 3, 256, 192), dev)
@@ -201,6 +217,7 @@ def main():
         }
         if not args.no_roofline:
             result["roofline"] = roofline_report(plan)
+            log("roofline done")
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(net.state_dict(), batch=8)
     if dist is not None:

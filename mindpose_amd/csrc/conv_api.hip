@@ -1,5 +1,6 @@
 // C-ABI entry points of the convolution family: weight packing, tile-configuration choice,
 // launch, and the recorded launch plan (one native call replays a whole network forward).
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -49,8 +50,19 @@ struct ConvLaunch {
     size_t lds_bytes;
 };
 
-static const int kLdsBudget = 78 * 1024;   // two workgroups per CU (160 KiB LDS)
 static const int kLdsMax = 150 * 1024;
+
+// LDS budget per workgroup: 78 KiB = two workgroups per CU (160 KiB LDS).  MP_CONV_LDS_KB overrides it
+// (tuning experiments only).
+static int lds_budget() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MP_CONV_LDS_KB");
+        int kb = e ? atoi(e) : 0;
+        v = (kb >= 16 && kb <= 150) ? kb * 1024 : 78 * 1024;
+    }
+    return v;
+}
 
 static int plane_pad(int raw) {  // smallest value >= raw that is == 16 (mod 32)
     int v = (raw + 15) / 32 * 32 + 16;
@@ -89,7 +101,7 @@ static bool configure(const mp_conv_desc& d, int variant, ConvLaunch& L) {
     const int T = KS * KS;
     // largest cin chunk (multiple of 4) whose input + weight tiles fit the LDS budget
     const int per_c = (p.cin_plane + T * CT) * 4;  // bytes per input channel
-    int ck = kLdsBudget / per_c / 4 * 4;
+    int ck = lds_budget() / per_c / 4 * 4;
     if (ck < 4) {
         ck = kLdsMax / per_c / 4 * 4;
         if (ck < 4) return false;
