@@ -1,0 +1,63 @@
+"""N>1 path on CPU: world_size-2 gloo ranks shard crops, run their share of the (oracle) decode, gather,
+and the union equals the single-process result; bench.py's timing reduction (MAX over ranks) is exercised."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp_
+
+from mindpose_amd.utils import shard_range
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import decoder as od
+    from tests.golden import recipes
+    hm = recipes.uniform_heatmaps(total, 17, 64, 48, 123)
+    center, scale, score = recipes.boxes(total, 124)
+    b, e = shard_range(total, world, rank)
+    preds, boxes, _ = od.decode(hm[b:e], center[b:e], scale[b:e], score[b:e], shift_coord=True)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (b, e, preds))
+    t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)  # bench.py: elapsed = MAX over ranks
+    dist.barrier()
+    if rank == 0:
+        full = np.concatenate([g[2] for g in sorted(gathered, key=lambda g: g[0])])
+        np.save(os.path.join(out_dir, "gathered.npy"), full)
+        np.save(os.path.join(out_dir, "tmax.npy"), t.numpy())
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions():
+    for total in (0, 1, 7, 128, 129):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_world_size_2_gloo_sharded_decode(tmp_path):
+    from oracle import decoder as od
+    from tests.golden import recipes
+    total, world = 9, 2
+    port = _free_port()
+    mp_.spawn(_worker, args=(world, port, total, str(tmp_path)), nprocs=world, join=True)
+    hm = recipes.uniform_heatmaps(total, 17, 64, 48, 123)
+    center, scale, score = recipes.boxes(total, 124)
+    ref, _, _ = od.decode(hm, center, scale, score, shift_coord=True)
+    assert np.array_equal(np.load(tmp_path / "gathered.npy"), ref)
+    assert np.load(tmp_path / "tmax.npy")[0] == 0.2
