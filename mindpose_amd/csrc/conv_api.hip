@@ -99,32 +99,42 @@ static bool configure(const mp_conv_desc& d, int variant, ConvLaunch& L) {
     p.ncols = p.W < p.Wp - p.pad_l ? p.W : p.Wp - p.pad_l;
     if (p.ncols < 1) return false;
     const int T = KS * KS;
-    // largest cin chunk (multiple of 4) whose input + weight tiles fit the LDS budget
-    const int per_c = (p.cin_plane + T * CT) * 4;  // bytes per input channel
-    int ck = lds_budget() / per_c / 4 * 4;
-    if (ck < 4) {
-        ck = kLdsMax / per_c / 4 * 4;
-        if (ck < 4) return false;
-        if (ck > 8) ck = 8;
+    // staging units: 4 consecutive columns (one 16-B global load) when rows are 16-B aligned
+    p.vec = ((p.W & 3) == 0 && (p.ncols & 3) == 0) ? 1 : 0;
+    p.upr = p.vec ? p.ncols / 4 : p.ncols;
+    p.upc = p.G * p.Rin * p.upr;
+    // cin chunk: the largest multiple of 4 that divides Cin_pad4, fits the per-thread staging registers
+    // (kNI / NW units of 16 B) and - double-buffered when there is more than one chunk - the LDS budget
+    const int nw = stage_nw(KS);
+    int best_ck = 0;
+    for (int ck = 4; ck <= p.Cin_pad4 && ck <= 128; ck += 4) {
+        if (p.Cin_pad4 % ck) continue;
+        if ((long long)ck * p.upc > (long long)kNI * 256) continue;
+        if ((long long)ck * T * CT / 4 > (long long)nw * 256) continue;
+        const int nbuf = ck < p.Cin_pad4 ? 2 : 1;
+        const long long bytes = (long long)nbuf * (ck * p.cin_plane + ck * T * CT) * 4;
+        if (bytes > lds_budget() && !(ck == 4 && bytes <= kLdsMax)) continue;
+        best_ck = ck;
     }
-    if (ck > 64) ck = 64;
-    if (ck > p.Cin_pad4) ck = p.Cin_pad4;
-    p.n_chunks = (p.Cin_pad4 + ck - 1) / ck;
-    p.CK = round_up((p.Cin_pad4 + p.n_chunks - 1) / p.n_chunks, 4);  // balanced chunks
-    p.n_chunks = (p.Cin_pad4 + p.CK - 1) / p.CK;
+    if (best_ck == 0) return false;
+    p.CK = best_ck;
+    p.n_chunks = p.Cin_pad4 / p.CK;
+    p.nbuf = p.n_chunks > 1 ? 2 : 1;
+    p.in_buf = p.CK * p.cin_plane;
+    p.w_buf = p.CK * T * CT;
     p.n_ct = (p.Cout_pad16 + CT - 1) / CT;
     p.tiles_y = (p.G > 1 || p.R >= p.Ho) ? 1 : (p.Ho + p.R - 1) / p.R;
     p.tiles_n = (p.N + p.G - 1) / p.G;
-    p.lds_w_off = p.CK * p.cin_plane;
     p.out_h = d.out_h; p.out_w = d.out_w; p.out_mul = d.out_mul; p.out_rep = d.out_rep;
     p.off_y = d.out_off_y; p.off_x = d.out_off_x; p.relu = d.relu;
-    p.magic_ncols = magic_of(p.ncols);
+    p.magic_upr = magic_of(p.upr);
+    p.magic_upc = magic_of(p.upc);
+    p.magic_rin = magic_of(p.Rin);
     p.magic_rwo = magic_of(p.RWo);
     p.magic_wo = magic_of(p.Wo);
-    p.magic_perc = magic_of(p.Rin * p.ncols);
     p.total_blocks = p.n_ct * p.tiles_y * p.tiles_n;
     L.ks = KS; L.stride = S; L.variant = variant;
-    L.lds_bytes = (size_t)(p.CK * p.cin_plane + p.CK * T * CT) * 4;
+    L.lds_bytes = (size_t)p.nbuf * (p.in_buf + p.w_buf) * 4;
     return L.lds_bytes <= (size_t)kLdsMax;
 }
 

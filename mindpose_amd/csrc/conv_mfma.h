@@ -39,16 +39,21 @@ struct ConvKParams {
     int Rin, Wp;       // LDS rows / pitch per image
     int img_plane;     // Rin * Wp
     int cin_plane;     // >= G * img_plane, == 16 (mod 32)
-    int CK;            // cin per chunk (multiple of 4)
+    int CK;            // cin per chunk (multiple of 4, divides Cin_pad4)
     int n_chunks;
     int n_ct;          // cout tiles
     int tiles_y;       // row bands per image (1 when G > 1)
     int tiles_n;       // image groups
     int ncols;         // input columns copied per row
-    int lds_w_off;     // float offset of the weight tile inside dynamic LDS
+    int vec;           // 1: staging unit = 4 consecutive columns (float4 global load)
+    int upr;           // staging units per input row (ncols / 4 or ncols)
+    int upc;           // staging units per input channel (G * Rin * upr)
+    int in_buf;        // floats per input buffer  (CK * cin_plane)
+    int w_buf;         // floats per weight buffer (CK * T * CT)
+    int nbuf;          // 2 = double-buffered chunks, 1 = single chunk
     int out_h, out_w, out_mul, out_rep, off_y, off_x;
     int relu;
-    unsigned magic_ncols, magic_perc, magic_rwo, magic_wo;  // fast-division multipliers
+    unsigned magic_upr, magic_upc, magic_rin, magic_rwo, magic_wo;  // fast-division multipliers
     int RWo;           // R * Wo
     int total_blocks;
 };
@@ -58,15 +63,22 @@ __device__ __forceinline__ unsigned fastdiv(unsigned e, unsigned d, unsigned mag
     return d == 1 ? e : __umulhi(e, magic);
 }
 
-template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C>
+// Software-pipelined workgroup:
+//   prologue   zero both input buffers (halo), build the per-thread staging tables, stage chunk 0
+//   per chunk  issue the global loads of chunk c+1 into registers  ->  MFMA over chunk c (operand
+//              fragments prefetched one k-step ahead, so an MFMA never waits on LDS)  ->  write the
+//              registers into the other LDS buffer  ->  ONE barrier
+// NI / NW = staging units (16 B) per thread per chunk for input / weights; the host picks CK to fit.
+template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, int NI, int NW>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvKParams p) {
     static_assert(WAVES_P * WAVES_C == 4, "4 waves per workgroup");
     constexpr int T = KS * KS;
     constexpr int CT = 16 * CS * WAVES_C;
+    constexpr int C4 = CT / 4;
     constexpr bool SWZ = (CT % 32) == 0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* __restrict__ lds_in = smem;
-    float* __restrict__ lds_w = smem + p.lds_w_off;
+    float* __restrict__ lds_in = smem;                       // [nbuf][in_buf]
+    float* __restrict__ lds_w = smem + p.nbuf * p.in_buf;    // [nbuf][w_buf]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp_i = wave % WAVES_P, wc_i = wave / WAVES_P;
@@ -86,15 +98,39 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvKParams p) 
     const int y_in0 = y0 * S - p.pad_t;
     const int HW = p.H * p.W;
 
-    // zero the input tile once: halo positions are never overwritten by the chunk copies
+    // zero the input buffers once: halo positions are never overwritten by the chunk copies
     {
-        const int n4 = (p.CK * p.cin_plane) >> 2;
+        const int n4 = (p.nbuf * p.in_buf) >> 2;
         float4* z = reinterpret_cast<float4*>(lds_in);
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int i = tid; i < n4; i += 256) z[i] = zero;
     }
 
-    // lane-constant LDS offsets
+    // per-thread staging tables (same for every chunk): source offset relative to the chunk base,
+    // destination offset inside the input buffer with the chunk-local cin in the top bits
+    int isrc[NI], idst[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const unsigned u = tid + 256 * i;
+        isrc[i] = -1;
+        idst[i] = 0;
+        if (u < (unsigned)(p.CK * p.upc)) {
+            const unsigned c = fastdiv(u, p.upc, p.magic_upc);
+            const unsigned rem = u - c * p.upc;
+            const unsigned gr = fastdiv(rem, p.upr, p.magic_upr);
+            const unsigned xu = rem - gr * p.upr;
+            const unsigned g = p.G > 1 ? fastdiv(gr, p.Rin, p.magic_rin) : 0u;
+            const unsigned r = gr - g * p.Rin;
+            const int yin = y_in0 + (int)r;
+            const unsigned xx = p.vec ? xu * 4 : xu;
+            if (yin >= 0 && yin < p.H && n0 + (int)g < p.N) {
+                isrc[i] = (int)((g * p.Cin + c) * HW + yin * p.W + xx);
+                idst[i] = (int)((c << 20) | (c * p.cin_plane + g * p.img_plane + r * p.Wp + p.pad_l + xx));
+            }
+        }
+    }
+
+    // lane-constant LDS offsets of the MFMA operands
     int a_off[PS];
 #pragma unroll
     for (int ps = 0; ps < PS; ++ps) {
@@ -120,67 +156,104 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvKParams p) 
 #pragma unroll
         for (int cs = 0; cs < CS; ++cs) acc[ps][cs] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int perc = p.Rin * p.ncols;  // staged elements per input channel (rows outside the image are skipped)
+    const float* __restrict__ xg = p.x + (size_t)n0 * p.Cin * HW;
+    const float* __restrict__ wg = p.wp + ct * CT;
+    const int w_rows = (p.CK >> 2) * T * 4;  // weight rows (of CT floats) per chunk
+    const bool w_full = (ct + 1) * CT <= p.Cout_pad16;
 
-    for (int ch = 0; ch < p.n_chunks; ++ch) {
+    float4 vin[NI], vw[NW];
+    auto stage_load = [&](int ch) {
         const int c0 = ch * p.CK;
-        const int ckv = min(p.CK, p.Cin - c0);           // real input channels in this chunk
-        const int nq = min(p.CK, p.Cin_pad4 - c0) >> 2;  // cin quads (weights are zero-padded)
-        __syncthreads();  // previous chunk fully consumed (also orders the zero fill)
-        // ---- stage the input chunk: coalesced global rows -> LDS rows with halo offset
-        for (int g = 0; g < p.G; ++g) {
-            if (n0 + g >= p.N) break;
-            const float* __restrict__ src = p.x + ((size_t)(n0 + g) * p.Cin + c0) * HW;
-            float* __restrict__ dst = lds_in + g * p.img_plane + p.pad_l;
-            const int total = ckv * perc;
-#pragma unroll 4
-            for (int e = tid; e < total; e += 256) {
-                const unsigned c = fastdiv(e, perc, p.magic_perc);
-                const unsigned rem = e - c * perc;
-                const unsigned r = fastdiv(rem, p.ncols, p.magic_ncols);
-                const unsigned xx = rem - r * p.ncols;
-                const int yin = y_in0 + (int)r;
-                if (yin >= 0 && yin < p.H) dst[c * p.cin_plane + r * p.Wp + xx] = src[(size_t)c * HW + yin * p.W + xx];
+        const float* __restrict__ src = xg + (size_t)c0 * HW;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            vin[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (isrc[i] >= 0 && c0 + (idst[i] >> 20) < p.Cin) {
+                if (p.vec) vin[i] = *reinterpret_cast<const float4*>(src + isrc[i]);
+                else vin[i].x = src[isrc[i]];
             }
         }
-        // ---- stage the weight chunk: rows of CT floats out of [quad][tap][kq][Cout_pad16]
-        {
-            constexpr int C4 = CT / 4;
-            const int rows = nq * T * 4;
-            const float* __restrict__ wsrc = p.wp + (size_t)(c0 >> 2) * T * 4 * p.Cout_pad16 + ct * CT;
-            const int total4 = rows * C4;
-#pragma unroll 2
-            for (int i = tid; i < total4; i += 256) {
-                const int row = i / C4, c4 = (i - row * C4) << 2;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ct * CT + c4 < p.Cout_pad16)
-                    v = *reinterpret_cast<const float4*>(wsrc + (size_t)row * p.Cout_pad16 + c4);
-                int dc = c4;
-                if (SWZ) dc ^= (row & 1) << 4;
-                *reinterpret_cast<float4*>(lds_w + row * CT + dc) = v;
+        const float* __restrict__ wsrc = wg + (size_t)(c0 >> 2) * T * 4 * p.Cout_pad16;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int u = tid + 256 * i;
+            const int row = u / C4, c4 = (u - row * C4) << 2;
+            vw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < w_rows && (w_full || ct * CT + c4 < p.Cout_pad16))
+                vw[i] = *reinterpret_cast<const float4*>(wsrc + (size_t)row * p.Cout_pad16 + c4);
+        }
+    };
+    auto stage_store = [&](int ch, int buf) {
+        const int c0 = ch * p.CK;
+        float* __restrict__ din = lds_in + buf * p.in_buf;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (isrc[i] >= 0 && c0 + (idst[i] >> 20) < p.Cin) {
+                float* d = din + (idst[i] & 0xFFFFF);
+                d[0] = vin[i].x;
+                if (p.vec) { d[1] = vin[i].y; d[2] = vin[i].z; d[3] = vin[i].w; }
             }
         }
-        __syncthreads();
-        // ---- MFMA over this chunk
+        float* __restrict__ dw = lds_w + buf * p.w_buf;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int u = tid + 256 * i;
+            const int row = u / C4;
+            int c4 = (u - row * C4) << 2;
+            if (row < w_rows) {
+                if (SWZ) c4 ^= (row & 1) << 4;
+                *reinterpret_cast<float4*>(dw + row * CT + c4) = vw[i];
+            }
+        }
+    };
+
+    stage_load(0);
+    __syncthreads();  // zero fill complete before the first copy lands
+    stage_store(0, 0);
+    __syncthreads();
+
+    const int nq = p.CK >> 2;
+    for (int ch = 0; ch < p.n_chunks; ++ch) {
+        const int buf = p.nbuf == 2 ? (ch & 1) : 0;
+        const bool more = ch + 1 < p.n_chunks;
+        if (more) stage_load(ch + 1);  // global loads fly while this chunk computes
+        const float* __restrict__ lin = lds_in + buf * p.in_buf;
+        const float* __restrict__ lw = lds_w + buf * p.w_buf;
+        // ---- MFMA over this chunk, fragments prefetched one k-step ahead
+        float av[PS], bv[CS];
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps) av[ps] = lin[a_off[ps]];
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs) bv[cs] = lw[b_off[cs]];
         for (int q = 0; q < nq; ++q) {
             const int in_q = q * 4 * p.cin_plane;
             const int w_q = q * T * 4 * CT;
+            const int qn = min(q + 1, nq - 1);  // the final prefetch re-reads a valid k-step (discarded)
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                const int dy = t / KS, dx = t % KS;
-                const int in_off = in_q + dy * p.Wp + dx;
-                const int w_off = w_q + t * 4 * CT;
-                float av[PS], bv[CS];
+                const int tn = (t + 1 < T) ? t + 1 : 0;
+                const int in_off = ((t + 1 < T) ? in_q : qn * 4 * p.cin_plane) + (tn / KS) * p.Wp + (tn % KS);
+                const int w_off = ((t + 1 < T) ? w_q : qn * T * 4 * CT) + tn * 4 * CT;
+                float an[PS], bn[CS];
 #pragma unroll
-                for (int ps = 0; ps < PS; ++ps) av[ps] = lds_in[a_off[ps] + in_off];
+                for (int ps = 0; ps < PS; ++ps) an[ps] = lin[a_off[ps] + in_off];
 #pragma unroll
-                for (int cs = 0; cs < CS; ++cs) bv[cs] = lds_w[b_off[cs] + w_off];
+                for (int cs = 0; cs < CS; ++cs) bn[cs] = lw[b_off[cs] + w_off];
 #pragma unroll
                 for (int ps = 0; ps < PS; ++ps)
 #pragma unroll
                     for (int cs = 0; cs < CS; ++cs)
                         acc[ps][cs] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ps], bv[cs], acc[ps][cs], 0, 0, 0);
+#pragma unroll
+                for (int ps = 0; ps < PS; ++ps) av[ps] = an[ps];
+#pragma unroll
+                for (int cs = 0; cs < CS; ++cs) bv[cs] = bn[cs];
             }
+        }
+        if (more) {
+            if (p.nbuf == 1) __syncthreads();  // (not used: nbuf == 1 implies a single chunk)
+            stage_store(ch + 1, buf ^ 1);
+            __syncthreads();
         }
     }
 
@@ -285,9 +358,12 @@ inline void variant_dims(int v, int& ct, int& pt) {
     pt = pts[v];
 }
 
+constexpr int kNI = 8;                                          // input staging units per thread per chunk
+constexpr int stage_nw(int ks) { return ks == 7 ? 13 : 6; }    // weight staging units per thread per chunk
+
 template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C>
 int launch_variant(const ConvKParams& p, size_t lds_bytes, hipStream_t s) {
-    auto kern = conv_mfma_kernel<KS, S, PS, CS, WAVES_P, WAVES_C>;
+    auto kern = conv_mfma_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, kNI, stage_nw(KS)>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
