@@ -162,6 +162,11 @@ int mp_plan_run_range(const mp_plan* plan, int first, int count, mp_stream_t str
  * [8]=cin chunk, [9]=images per tile, [10]=rows per tile */
 int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]);
 
+/* Diagnostics: only a library built with -DMP_CONV_STAMPS=1 (never the product build) records per-workgroup
+ * phase cycle counters (8 x uint64 per workgroup) of each conv launch into this device buffer; the product
+ * build returns MP_ERR_UNSUPPORTED. */
+int mp_debug_set_stamp_buffer(void* dev_ptr, size_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmindpose_hip.so")
+LIB_PATH = os.environ.get("MINDPOSE_HIP_LIB", os.path.join(_HERE, "csrc", "libmindpose_hip.so"))
 
 MP_REFINE_NONE, MP_REFINE_SHIFT, MP_REFINE_DARK = 0, 1, 2
 
@@ -54,6 +54,7 @@ _PROTOTYPES = {
     "mp_plan_run": (c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "mp_plan_run_range": (c_int, [ctypes.c_void_p, c_int, c_int, ctypes.c_void_p]),
     "mp_plan_entry_info": (c_int, [ctypes.c_void_p, c_int, ctypes.POINTER(ctypes.c_int64)]),
+    "mp_debug_set_stamp_buffer": (c_int, [ctypes.c_void_p, c_size_t]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)

@@ -44,6 +44,9 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     }
 }
 
+static unsigned long long* g_stamp_buf = nullptr;
+static size_t g_stamp_bytes = 0;
+
 struct ConvLaunch {
     ConvKParams p;
     int ks, stride, variant;
@@ -74,6 +77,7 @@ static int plane_pad(int raw) {  // smallest value >= raw that is == 16 (mod 32)
 static bool configure(const mp_conv_desc& d, int variant, ConvLaunch& L) {
     int CT, PT;
     variant_dims(variant, CT, PT);
+    if (d.kh == 7 && variant != V_CT64_PT192 && variant != V_CT32_PT192) return false;  // only these are built
     ConvKParams& p = L.p;
     const int S = d.stride, KS = d.kh;
     p.N = d.n; p.Cin = d.cin; p.H = d.h; p.W = d.w; p.Cout = d.cout;
@@ -94,6 +98,7 @@ static bool configure(const mp_conv_desc& d, int variant, ConvLaunch& L) {
     p.RWo = p.R * p.Wo;
     p.Rin = (p.R - 1) * S + KS;
     p.Wp = (p.Wo - 1) * S + KS;
+    if (p.Wp < p.pad_l + p.W && p.pad_l + p.W - p.Wp <= 2) p.Wp = p.pad_l + p.W;  // copy whole rows (16-B units)
     p.img_plane = p.Rin * p.Wp;
     p.cin_plane = plane_pad(p.G * p.img_plane);
     p.ncols = p.W < p.Wp - p.pad_l ? p.W : p.Wp - p.pad_l;
@@ -189,11 +194,14 @@ static int validate_desc(const mp_conv_desc* d) {
     return MP_OK;
 }
 
-static int launch(const ConvLaunch& L, hipStream_t s) {
+static int launch(const ConvLaunch& L0, hipStream_t s) {
+    ConvLaunch L = L0;
+    L.p.dbg = (g_stamp_buf && (size_t)L.p.total_blocks * 64 <= g_stamp_bytes) ? g_stamp_buf : nullptr;
     switch (L.ks) {
         case 1: return launch_conv_k1(L.p, L.stride, L.variant, L.lds_bytes, s);
         case 2: return launch_conv_k2(L.p, L.stride, L.variant, L.lds_bytes, s);
-        case 3: return launch_conv_k3(L.p, L.stride, L.variant, L.lds_bytes, s);
+        case 3: return L.stride == 1 ? launch_conv_k3s1(L.p, L.variant, L.lds_bytes, s)
+                                     : launch_conv_k3s2(L.p, L.variant, L.lds_bytes, s);
         case 7: return launch_conv_k7(L.p, L.stride, L.variant, L.lds_bytes, s);
         default: return MP_ERR_UNSUPPORTED;
     }
@@ -253,6 +261,17 @@ int mp_conv2d_fwd(const mp_conv_desc* desc, const float* x, const float* packed_
     int rc = build_launch(desc, x, packed_w, scale, shift, res1, res2, out, L);
     if (rc != MP_OK) return rc;
     return launch(L, as_stream(stream));
+}
+
+int mp_debug_set_stamp_buffer(void* dev_ptr, size_t bytes) {
+#if MP_CONV_STAMPS
+    g_stamp_buf = reinterpret_cast<unsigned long long*>(dev_ptr);
+    g_stamp_bytes = dev_ptr ? bytes : 0;
+    return MP_OK;
+#else
+    (void)dev_ptr; (void)bytes;
+    return MP_ERR_UNSUPPORTED;
+#endif
 }
 
 mp_plan* mp_plan_create(void) { return new (std::nothrow) mp_plan(); }

@@ -17,7 +17,21 @@
 //                   no up-sampled tensor is ever materialised) and the sub-pixel phases of the
 //                   4x4 stride-2 transposed convolution.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
+
+#ifndef MP_CONV_SCHED
+#define MP_CONV_SCHED 1
+#endif
+#ifndef MP_CONV_STAMPS
+#define MP_CONV_STAMPS 0  // 1: per-workgroup phase cycle counters into ConvKParams::dbg (never in the product build)
+#endif
+#if MP_CONV_STAMPS
+#define MP_STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F)
+#else
+#define MP_STAMP(var) [[maybe_unused]] const unsigned long long var = 0
+#endif
 
 namespace mp {
 
@@ -56,6 +70,7 @@ struct ConvKParams {
     unsigned magic_upr, magic_upc, magic_rin, magic_rwo, magic_wo;  // fast-division multipliers
     int RWo;           // R * Wo
     int total_blocks;
+    unsigned long long* dbg;  // diagnostic builds (MP_CONV_STAMPS) only: 8 x u64 per workgroup
 };
 
 __device__ __forceinline__ unsigned fastdiv(unsigned e, unsigned d, unsigned magic) {
@@ -69,17 +84,20 @@ __device__ __forceinline__ unsigned fastdiv(unsigned e, unsigned d, unsigned mag
 //              fragments prefetched one k-step ahead, so an MFMA never waits on LDS)  ->  write the
 //              registers into the other LDS buffer  ->  ONE barrier
 // NI / NW = staging units (16 B) per thread per chunk for input / weights; the host picks CK to fit.
-template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, int NI, int NW>
+template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, int NI, int NW, bool VEC>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvKParams p) {
     static_assert(WAVES_P * WAVES_C == 4, "4 waves per workgroup");
     constexpr int T = KS * KS;
     constexpr int CT = 16 * CS * WAVES_C;
     constexpr int C4 = CT / 4;
     constexpr bool SWZ = (CT % 32) == 0;
+    constexpr bool SCHED = MP_CONV_SCHED != 0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* __restrict__ lds_in = smem;                       // [nbuf][in_buf]
     float* __restrict__ lds_w = smem + p.nbuf * p.in_buf;    // [nbuf][w_buf]
 
+    MP_STAMP(t_start);
+    unsigned long long s_load = 0, s_comp = 0, s_store = 0, s_bar = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp_i = wave % WAVES_P, wc_i = wave / WAVES_P;
     const int lq = lane >> 4, lr = lane & 15;
@@ -122,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvKParams p) 
             const unsigned g = p.G > 1 ? fastdiv(gr, p.Rin, p.magic_rin) : 0u;
             const unsigned r = gr - g * p.Rin;
             const int yin = y_in0 + (int)r;
-            const unsigned xx = p.vec ? xu * 4 : xu;
+            const unsigned xx = VEC ? xu * 4 : xu;
             if (yin >= 0 && yin < p.H && n0 + (int)g < p.N) {
                 isrc[i] = (int)((g * p.Cin + c) * HW + yin * p.W + xx);
                 idst[i] = (int)((c << 20) | (c * p.cin_plane + g * p.img_plane + r * p.Wp + p.pad_l + xx));
@@ -161,26 +179,29 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvKParams p) 
     const int w_rows = (p.CK >> 2) * T * 4;  // weight rows (of CT floats) per chunk
     const bool w_full = (ct + 1) * CT <= p.Cout_pad16;
 
-    float4 vin[NI], vw[NW];
+    using in_t = typename std::conditional<VEC, float4, float>::type;
+    in_t vin[NI];
+    float4 vw[NW];
+    // Branch-free: invalid units load from a safe address (the chunk base) and are zeroed by a select, so all
+    // NI + NW loads issue back to back and stay in flight across the MFMA loop.
     auto stage_load = [&](int ch) {
         const int c0 = ch * p.CK;
         const float* __restrict__ src = xg + (size_t)c0 * HW;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            vin[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (isrc[i] >= 0 && c0 + (idst[i] >> 20) < p.Cin) {
-                if (p.vec) vin[i] = *reinterpret_cast<const float4*>(src + isrc[i]);
-                else vin[i].x = src[isrc[i]];
-            }
+            const bool ok = isrc[i] >= 0 && c0 + (idst[i] >> 20) < p.Cin;
+            const in_t v = *reinterpret_cast<const in_t*>(src + (ok ? isrc[i] : 0));
+            if constexpr (VEC) vin[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            else vin[i] = ok ? v : 0.f;
         }
         const float* __restrict__ wsrc = wg + (size_t)(c0 >> 2) * T * 4 * p.Cout_pad16;
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             const int u = tid + 256 * i;
             const int row = u / C4, c4 = (u - row * C4) << 2;
-            vw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < w_rows && (w_full || ct * CT + c4 < p.Cout_pad16))
-                vw[i] = *reinterpret_cast<const float4*>(wsrc + (size_t)row * p.Cout_pad16 + c4);
+            const bool ok = row < w_rows && (w_full || ct * CT + c4 < p.Cout_pad16);
+            const float4 v = *reinterpret_cast<const float4*>(wsrc + (ok ? (size_t)row * p.Cout_pad16 + c4 : 0));
+            vw[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto stage_store = [&](int ch, int buf) {
@@ -190,8 +211,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvKParams p) 
         for (int i = 0; i < NI; ++i) {
             if (isrc[i] >= 0 && c0 + (idst[i] >> 20) < p.Cin) {
                 float* d = din + (idst[i] & 0xFFFFF);
-                d[0] = vin[i].x;
-                if (p.vec) { d[1] = vin[i].y; d[2] = vin[i].z; d[3] = vin[i].w; }
+                if constexpr (VEC) { d[0] = vin[i].x; d[1] = vin[i].y; d[2] = vin[i].z; d[3] = vin[i].w; }
+                else d[0] = vin[i];
             }
         }
         float* __restrict__ dw = lds_w + buf * p.w_buf;
@@ -211,12 +232,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvKParams p) 
     __syncthreads();  // zero fill complete before the first copy lands
     stage_store(0, 0);
     __syncthreads();
+    MP_STAMP(t_pro);
 
     const int nq = p.CK >> 2;
     for (int ch = 0; ch < p.n_chunks; ++ch) {
         const int buf = p.nbuf == 2 ? (ch & 1) : 0;
         const bool more = ch + 1 < p.n_chunks;
+        MP_STAMP(t0);
         if (more) stage_load(ch + 1);  // global loads fly while this chunk computes
+        MP_STAMP(t1);
         const float* __restrict__ lin = lds_in + buf * p.in_buf;
         const float* __restrict__ lw = lds_w + buf * p.w_buf;
         // ---- MFMA over this chunk, fragments prefetched one k-step ahead
@@ -225,41 +249,139 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvKParams p) 
         for (int ps = 0; ps < PS; ++ps) av[ps] = lin[a_off[ps]];
 #pragma unroll
         for (int cs = 0; cs < CS; ++cs) bv[cs] = lw[b_off[cs]];
-        for (int q = 0; q < nq; ++q) {
-            const int in_q = q * 4 * p.cin_plane;
-            const int w_q = q * T * 4 * CT;
-            const int qn = min(q + 1, nq - 1);  // the final prefetch re-reads a valid k-step (discarded)
+        if constexpr (KS <= 3) {
+            for (int q = 0; q < nq; ++q) {
+                const int in_q = q * 4 * p.cin_plane;
+                const int w_q = q * T * 4 * CT;
+                const int qn = min(q + 1, nq - 1);  // the final prefetch re-reads a valid k-step (discarded)
+    #pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const int tn = (t + 1 < T) ? t + 1 : 0;
+                    const int in_off = ((t + 1 < T) ? in_q : qn * 4 * p.cin_plane) + (tn / KS) * p.Wp + (tn % KS);
+                    const int w_off = ((t + 1 < T) ? w_q : qn * T * 4 * CT) + tn * 4 * CT;
+                    float an[PS], bn[CS];
+    #pragma unroll
+                    for (int ps = 0; ps < PS; ++ps) an[ps] = lin[a_off[ps] + in_off];
+    #pragma unroll
+                    for (int cs = 0; cs < CS; ++cs) bn[cs] = lw[b_off[cs] + w_off];
+    #pragma unroll
+                    for (int ps = 0; ps < PS; ++ps)
+    #pragma unroll
+                        for (int cs = 0; cs < CS; ++cs)
+                            acc[ps][cs] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ps], bv[cs], acc[ps][cs], 0, 0, 0);
+                    // pin the software pipeline: this k-step's MFMAs with the NEXT k-step's LDS reads spread
+                    // between them (an fp32 MFMA occupies the pipe 32 cycles but the issue port only 8)
+                    if (SCHED) {
+                        constexpr int NR = PS + CS, NM = PS * CS, NPAIR = NR < NM ? NR : NM;
+    #pragma unroll
+                        for (int i = 0; i < NPAIR; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+                        }
+                        if (NM > NPAIR) __builtin_amdgcn_sched_group_barrier(0x008, NM - NPAIR, 0);
+                        if (NR > NPAIR) __builtin_amdgcn_sched_group_barrier(0x100, NR - NPAIR, 0);
+                    }
+    #pragma unroll
+                    for (int ps = 0; ps < PS; ++ps) av[ps] = an[ps];
+    #pragma unroll
+                    for (int cs = 0; cs < CS; ++cs) bv[cs] = bn[cs];
+                }
+            }
+
+        } else {
+            // large kernels (7x7 stem): rows walked at run time, columns unrolled; no pinned pipeline
+            // (a fully unrolled 49-tap body costs minutes of compile time for one launch per forward)
+            for (int q = 0; q < nq; ++q) {
+                for (int dy = 0; dy < KS; ++dy) {
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-                const int tn = (t + 1 < T) ? t + 1 : 0;
-                const int in_off = ((t + 1 < T) ? in_q : qn * 4 * p.cin_plane) + (tn / KS) * p.Wp + (tn % KS);
-                const int w_off = ((t + 1 < T) ? w_q : qn * T * 4 * CT) + tn * 4 * CT;
-                float an[PS], bn[CS];
+                    for (int dx = 0; dx < KS; ++dx) {
+                        const int in_off = q * 4 * p.cin_plane + dy * p.Wp + dx;
+                        const int w_off = (q * T + dy * KS + dx) * 4 * CT;
 #pragma unroll
-                for (int ps = 0; ps < PS; ++ps) an[ps] = lin[a_off[ps] + in_off];
+                        for (int ps = 0; ps < PS; ++ps) av[ps] = lin[a_off[ps] + in_off];
 #pragma unroll
-                for (int cs = 0; cs < CS; ++cs) bn[cs] = lw[b_off[cs] + w_off];
+                        for (int cs = 0; cs < CS; ++cs) bv[cs] = lw[b_off[cs] + w_off];
 #pragma unroll
-                for (int ps = 0; ps < PS; ++ps)
+                        for (int ps = 0; ps < PS; ++ps)
 #pragma unroll
-                    for (int cs = 0; cs < CS; ++cs)
-                        acc[ps][cs] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ps], bv[cs], acc[ps][cs], 0, 0, 0);
-#pragma unroll
-                for (int ps = 0; ps < PS; ++ps) av[ps] = an[ps];
-#pragma unroll
-                for (int cs = 0; cs < CS; ++cs) bv[cs] = bn[cs];
+                            for (int cs = 0; cs < CS; ++cs)
+                                acc[ps][cs] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ps], bv[cs], acc[ps][cs], 0, 0, 0);
+                    }
+                }
             }
         }
-        if (more) {
-            if (p.nbuf == 1) __syncthreads();  // (not used: nbuf == 1 implies a single chunk)
-            stage_store(ch + 1, buf ^ 1);
-            __syncthreads();
-        }
+        MP_STAMP(t2);
+        if (more) stage_store(ch + 1, buf ^ 1);
+        MP_STAMP(t3);
+        if (more) __syncthreads();
+        MP_STAMP(t4);
+        s_load += t1 - t0; s_comp += t2 - t1; s_store += t3 - t2; s_bar += t4 - t3;
     }
+    MP_STAMP(t_epi);
 
     // ---- epilogue: BN scale/shift (+res1) (+res2) (+ReLU) -> NCHW, with the output mapping
     const int plane_o = p.out_h * p.out_w;
     const bool vec_ok = ((p.Wo & 3) == 0);
+    if (vec_ok && p.out_mul == 1 && p.out_rep == 1) {
+        // plain mapping: 16 B per lane.  All residual loads are issued first (clamped address + select, no
+        // branches), then combined and stored, so their latencies overlap instead of adding up.
+        size_t pix_off[PS];
+        bool pix_ok[PS];
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps) {
+            const unsigned p4 = (unsigned)((wp_i * PS + ps) * 16 + lq * 4);
+            const unsigned pc = p4 < (unsigned)(p.G * p.RWo) ? p4 : 0u;
+            const unsigned g = fastdiv(pc, p.RWo, p.magic_rwo);
+            const unsigned rem = pc - g * p.RWo;
+            const unsigned y = fastdiv(rem, p.Wo, p.magic_wo);
+            const unsigned xx = rem - y * p.Wo;
+            const int n = n0 + g, yy = y0 + y;
+            pix_ok[ps] = p4 < (unsigned)(p.G * p.RWo) && n < p.N && yy < p.Ho;
+            pix_off[ps] = (size_t)n * p.Cout * plane_o + (size_t)(yy + p.off_y) * p.out_w + xx + p.off_x;
+        }
+        float4 r1[CS][PS], r2[CS][PS];
+        float sc[CS], sh[CS];
+        bool co_ok[CS];
+        size_t co_off[CS];
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs) {
+            const int co = ct * CT + (wc_i * CS + cs) * 16 + lr;
+            co_ok[cs] = co < p.Cout;
+            const int cc = co_ok[cs] ? co : 0;
+            sc[cs] = p.scale[cc];
+            sh[cs] = p.shift[cc];
+            co_off[cs] = (size_t)cc * plane_o;
+        }
+        if (p.res1) {
+#pragma unroll
+            for (int cs = 0; cs < CS; ++cs)
+#pragma unroll
+                for (int ps = 0; ps < PS; ++ps) {
+                    const bool ok = co_ok[cs] && pix_ok[ps];
+                    r1[cs][ps] = *reinterpret_cast<const float4*>(p.res1 + (ok ? co_off[cs] + pix_off[ps] : 0));
+                }
+        }
+        if (p.res2) {
+#pragma unroll
+            for (int cs = 0; cs < CS; ++cs)
+#pragma unroll
+                for (int ps = 0; ps < PS; ++ps) {
+                    const bool ok = co_ok[cs] && pix_ok[ps];
+                    r2[cs][ps] = *reinterpret_cast<const float4*>(p.res2 + (ok ? co_off[cs] + pix_off[ps] : 0));
+                }
+        }
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs)
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps) {
+                float4 v = make_float4(acc[ps][cs][0] * sc[cs] + sh[cs], acc[ps][cs][1] * sc[cs] + sh[cs],
+                                       acc[ps][cs][2] * sc[cs] + sh[cs], acc[ps][cs][3] * sc[cs] + sh[cs]);
+                if (p.res1) { v.x += r1[cs][ps].x; v.y += r1[cs][ps].y; v.z += r1[cs][ps].z; v.w += r1[cs][ps].w; }
+                if (p.res2) { v.x += r2[cs][ps].x; v.y += r2[cs][ps].y; v.z += r2[cs][ps].z; v.w += r2[cs][ps].w; }
+                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (co_ok[cs] && pix_ok[ps]) *reinterpret_cast<float4*>(p.out + co_off[cs] + pix_off[ps]) = v;
+            }
+    } else {
 #pragma unroll
     for (int cs = 0; cs < CS; ++cs) {
         const int co = ct * CT + (wc_i * CS + cs) * 16 + lr;
@@ -346,6 +468,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvKParams p) 
             }
         }
     }
+    }
+#if MP_CONV_STAMPS
+    {
+        MP_STAMP(t_end);
+        if (p.dbg && tid == 0) {
+            unsigned long long* d = p.dbg + (size_t)blockIdx.x * 8;
+            d[0] = t_end - t_start; d[1] = t_pro - t_start; d[2] = s_load; d[3] = s_comp; d[4] = s_store; d[5] = s_bar;
+            d[6] = t_end - t_epi; d[7] = t_start;
+        }
+    }
+#endif
 }
 
 // tile variants: index -> (PS, CS, WAVES_P, WAVES_C); CT = 16*CS*WAVES_C, PT = 16*PS*WAVES_P
@@ -361,9 +494,9 @@ inline void variant_dims(int v, int& ct, int& pt) {
 constexpr int kNI = 8;                                          // input staging units per thread per chunk
 constexpr int stage_nw(int ks) { return ks == 7 ? 13 : 6; }    // weight staging units per thread per chunk
 
-template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C>
+template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, bool VEC>
 int launch_variant(const ConvKParams& p, size_t lds_bytes, hipStream_t s) {
-    auto kern = conv_mfma_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, kNI, stage_nw(KS)>;
+    auto kern = conv_mfma_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, kNI, stage_nw(KS), VEC>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -374,22 +507,28 @@ int launch_variant(const ConvKParams& p, size_t lds_bytes, hipStream_t s) {
     return check_launch();
 }
 
-template <int KS, int S>
-int launch_ks(const ConvKParams& p, int variant, size_t lds_bytes, hipStream_t s) {
+template <int KS, int S, bool VEC>
+int launch_ks_v(const ConvKParams& p, int variant, size_t lds_bytes, hipStream_t s) {
     switch (variant) {
-        case V_CT32_PT192: return launch_variant<KS, S, 3, 2, 4, 1>(p, lds_bytes, s);
-        case V_CT64_PT192: return launch_variant<KS, S, 3, 4, 4, 1>(p, lds_bytes, s);
-        case V_CT48_PT192: return launch_variant<KS, S, 3, 3, 4, 1>(p, lds_bytes, s);
-        case V_CT64_PT96: return launch_variant<KS, S, 3, 2, 2, 2>(p, lds_bytes, s);
-        case V_CT32_PT96: return launch_variant<KS, S, 3, 1, 2, 2>(p, lds_bytes, s);
+        case V_CT32_PT192: return launch_variant<KS, S, 3, 2, 4, 1, VEC>(p, lds_bytes, s);
+        case V_CT64_PT192: return launch_variant<KS, S, 3, 4, 4, 1, VEC>(p, lds_bytes, s);
+        case V_CT48_PT192: return launch_variant<KS, S, 3, 3, 4, 1, VEC>(p, lds_bytes, s);
+        case V_CT64_PT96: return launch_variant<KS, S, 3, 2, 2, 2, VEC>(p, lds_bytes, s);
+        case V_CT32_PT96: return launch_variant<KS, S, 3, 1, 2, 2, VEC>(p, lds_bytes, s);
         default: return MP_ERR_UNSUPPORTED;
     }
+}
+
+template <int KS, int S>
+int launch_ks(const ConvKParams& p, int variant, size_t lds_bytes, hipStream_t s) {
+    return p.vec ? launch_ks_v<KS, S, true>(p, variant, lds_bytes, s) : launch_ks_v<KS, S, false>(p, variant, lds_bytes, s);
 }
 
 // one translation unit per kernel size (parallel compilation)
 int launch_conv_k1(const ConvKParams& p, int stride, int variant, size_t lds_bytes, hipStream_t s);
 int launch_conv_k2(const ConvKParams& p, int stride, int variant, size_t lds_bytes, hipStream_t s);
-int launch_conv_k3(const ConvKParams& p, int stride, int variant, size_t lds_bytes, hipStream_t s);
+int launch_conv_k3s1(const ConvKParams& p, int variant, size_t lds_bytes, hipStream_t s);
+int launch_conv_k3s2(const ConvKParams& p, int variant, size_t lds_bytes, hipStream_t s);
 int launch_conv_k7(const ConvKParams& p, int stride, int variant, size_t lds_bytes, hipStream_t s);
 
 }  // namespace mp
