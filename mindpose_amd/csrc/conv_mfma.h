@@ -36,6 +36,23 @@
 namespace mp {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Raw buffer access: the hardware range check makes invalid lanes free - an offset >= num_records loads 0 /
+// drops the store - so masked staging and epilogue traffic needs no branches (and no s_waitcnt between loads).
+constexpr unsigned kOob = 0x80000000u;  // every descriptor below spans < 2 GiB
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes < 0x7FFFFFF0u ? bytes : 0x7FFFFFF0u), 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+}
 
 struct ConvKParams {
     const float* x;
@@ -126,11 +143,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvKParams p) 
 
     // per-thread staging tables (same for every chunk): source offset relative to the chunk base,
     // destination offset inside the input buffer with the chunk-local cin in the top bits
-    int isrc[NI], idst[NI];
+    unsigned isrc[NI];  // byte offset from the image-group base, kOob when the unit is outside the image
+    int idst[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const unsigned u = tid + 256 * i;
-        isrc[i] = -1;
+        isrc[i] = kOob;
         idst[i] = 0;
         if (u < (unsigned)(p.CK * p.upc)) {
             const unsigned c = fastdiv(u, p.upc, p.magic_upc);
@@ -142,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvKParams p) 
             const int yin = y_in0 + (int)r;
             const unsigned xx = VEC ? xu * 4 : xu;
             if (yin >= 0 && yin < p.H && n0 + (int)g < p.N) {
-                isrc[i] = (int)((g * p.Cin + c) * HW + yin * p.W + xx);
+                isrc[i] = ((g * p.Cin + c) * HW + yin * p.W + xx) * 4u;
                 idst[i] = (int)((c << 20) | (c * p.cin_plane + g * p.img_plane + r * p.Wp + p.pad_l + xx));
             }
         }
@@ -177,39 +195,42 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvKParams p) 
     const float* __restrict__ xg = p.x + (size_t)n0 * p.Cin * HW;
     const float* __restrict__ wg = p.wp + ct * CT;
     const int w_rows = (p.CK >> 2) * T * 4;  // weight rows (of CT floats) per chunk
-    const bool w_full = (ct + 1) * CT <= p.Cout_pad16;
 
-    using in_t = typename std::conditional<VEC, float4, float>::type;
+    using in_t = typename std::conditional<VEC, f32x4, float>::type;
     in_t vin[NI];
-    float4 vw[NW];
-    // Branch-free: invalid units load from a safe address (the chunk base) and are zeroed by a select, so all
-    // NI + NW loads issue back to back and stay in flight across the MFMA loop.
+    f32x4 vw[NW];
+    const int n_img = min(p.G, p.N - n0);
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(xg, (size_t)n_img * p.Cin * HW * 4);
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(wg, ((size_t)(p.Cin_pad4 >> 2) * T * 4 * p.Cout_pad16 - (size_t)ct * CT) * 4);
+    unsigned wsrc[NW];  // byte offset inside one weight chunk, kOob beyond the chunk / the padded couts
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int u = tid + 256 * i;
+        const int row = u / C4, c4 = (u - row * C4) << 2;
+        wsrc[i] = (row < w_rows && ct * CT + c4 < p.Cout_pad16) ? (unsigned)(row * p.Cout_pad16 + c4) * 4u : kOob;
+    }
+    // All NI + NW loads issue back to back (range-checked buffer loads, no branches) and stay in flight
+    // across the MFMA loop; the first use is stage_store after the loop.
     auto stage_load = [&](int ch) {
         const int c0 = ch * p.CK;
-        const float* __restrict__ src = xg + (size_t)c0 * HW;
+        const unsigned xo = (unsigned)c0 * HW * 4u;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const bool ok = isrc[i] >= 0 && c0 + (idst[i] >> 20) < p.Cin;
-            const in_t v = *reinterpret_cast<const in_t*>(src + (ok ? isrc[i] : 0));
-            if constexpr (VEC) vin[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            else vin[i] = ok ? v : 0.f;
+            unsigned off = isrc[i] + xo;
+            if (p.Cin & 3) off = (c0 + (idst[i] >> 20) < p.Cin) ? off : kOob;  // zero-padded cin tail
+            if constexpr (VEC) vin[i] = buf_load4(rs_x, off);
+            else vin[i] = buf_load1(rs_x, off);
         }
-        const float* __restrict__ wsrc = wg + (size_t)(c0 >> 2) * T * 4 * p.Cout_pad16;
+        const unsigned wo = (unsigned)(c0 >> 2) * T * 4u * p.Cout_pad16 * 4u;
 #pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const int u = tid + 256 * i;
-            const int row = u / C4, c4 = (u - row * C4) << 2;
-            const bool ok = row < w_rows && (w_full || ct * CT + c4 < p.Cout_pad16);
-            const float4 v = *reinterpret_cast<const float4*>(wsrc + (ok ? (size_t)row * p.Cout_pad16 + c4 : 0));
-            vw[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int i = 0; i < NW; ++i) vw[i] = buf_load4(rs_w, wsrc[i] + wo);
     };
     auto stage_store = [&](int ch, int buf) {
         const int c0 = ch * p.CK;
         float* __restrict__ din = lds_in + buf * p.in_buf;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            if (isrc[i] >= 0 && c0 + (idst[i] >> 20) < p.Cin) {
+            if (isrc[i] != kOob && c0 + (idst[i] >> 20) < p.Cin) {
                 float* d = din + (idst[i] & 0xFFFFF);
                 if constexpr (VEC) { d[0] = vin[i].x; d[1] = vin[i].y; d[2] = vin[i].z; d[3] = vin[i].w; }
                 else d[0] = vin[i];
@@ -223,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvKParams p) 
             int c4 = (u - row * C4) << 2;
             if (row < w_rows) {
                 if (SWZ) c4 ^= (row & 1) << 4;
-                *reinterpret_cast<float4*>(dw + row * CT + c4) = vw[i];
+                *reinterpret_cast<f32x4*>(dw + row * CT + c4) = vw[i];
             }
         }
     };
@@ -325,8 +346,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvKParams p) 
     if (vec_ok && p.out_mul == 1 && p.out_rep == 1) {
         // plain mapping: 16 B per lane.  All residual loads are issued first (clamped address + select, no
         // branches), then combined and stored, so their latencies overlap instead of adding up.
-        size_t pix_off[PS];
-        bool pix_ok[PS];
+        const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(p.out + (size_t)n0 * p.Cout * plane_o, (size_t)n_img * p.Cout * plane_o * 4);
+        unsigned pix_off[PS];  // float offset inside the image group, kOob for padding lanes
 #pragma unroll
         for (int ps = 0; ps < PS; ++ps) {
             const unsigned p4 = (unsigned)((wp_i * PS + ps) * 16 + lq * 4);
@@ -335,51 +356,46 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvKParams p) 
             const unsigned rem = pc - g * p.RWo;
             const unsigned y = fastdiv(rem, p.Wo, p.magic_wo);
             const unsigned xx = rem - y * p.Wo;
-            const int n = n0 + g, yy = y0 + y;
-            pix_ok[ps] = p4 < (unsigned)(p.G * p.RWo) && n < p.N && yy < p.Ho;
-            pix_off[ps] = (size_t)n * p.Cout * plane_o + (size_t)(yy + p.off_y) * p.out_w + xx + p.off_x;
+            const int yy = y0 + y;
+            const bool ok = p4 < (unsigned)(p.G * p.RWo) && n0 + (int)g < p.N && yy < p.Ho;
+            pix_off[ps] = ok ? g * p.Cout * plane_o + (yy + p.off_y) * p.out_w + xx + p.off_x : kOob;
         }
-        float4 r1[CS][PS], r2[CS][PS];
         float sc[CS], sh[CS];
-        bool co_ok[CS];
-        size_t co_off[CS];
+        unsigned co_off[CS];
 #pragma unroll
         for (int cs = 0; cs < CS; ++cs) {
             const int co = ct * CT + (wc_i * CS + cs) * 16 + lr;
-            co_ok[cs] = co < p.Cout;
-            const int cc = co_ok[cs] ? co : 0;
+            const int cc = co < p.Cout ? co : 0;
             sc[cs] = p.scale[cc];
             sh[cs] = p.shift[cc];
-            co_off[cs] = (size_t)cc * plane_o;
+            co_off[cs] = co < p.Cout ? (unsigned)cc * plane_o : kOob;
         }
+        f32x4 r1[CS][PS], r2[CS][PS];
         if (p.res1) {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.res1 + (size_t)n0 * p.Cout * plane_o, (size_t)n_img * p.Cout * plane_o * 4);
 #pragma unroll
             for (int cs = 0; cs < CS; ++cs)
 #pragma unroll
-                for (int ps = 0; ps < PS; ++ps) {
-                    const bool ok = co_ok[cs] && pix_ok[ps];
-                    r1[cs][ps] = *reinterpret_cast<const float4*>(p.res1 + (ok ? co_off[cs] + pix_off[ps] : 0));
-                }
+                for (int ps = 0; ps < PS; ++ps)
+                    r1[cs][ps] = buf_load4(rs, ((co_off[cs] | pix_off[ps]) & kOob) ? kOob : (co_off[cs] + pix_off[ps]) * 4u);
         }
         if (p.res2) {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.res2 + (size_t)n0 * p.Cout * plane_o, (size_t)n_img * p.Cout * plane_o * 4);
 #pragma unroll
             for (int cs = 0; cs < CS; ++cs)
 #pragma unroll
-                for (int ps = 0; ps < PS; ++ps) {
-                    const bool ok = co_ok[cs] && pix_ok[ps];
-                    r2[cs][ps] = *reinterpret_cast<const float4*>(p.res2 + (ok ? co_off[cs] + pix_off[ps] : 0));
-                }
+                for (int ps = 0; ps < PS; ++ps)
+                    r2[cs][ps] = buf_load4(rs, ((co_off[cs] | pix_off[ps]) & kOob) ? kOob : (co_off[cs] + pix_off[ps]) * 4u);
         }
 #pragma unroll
         for (int cs = 0; cs < CS; ++cs)
 #pragma unroll
             for (int ps = 0; ps < PS; ++ps) {
-                float4 v = make_float4(acc[ps][cs][0] * sc[cs] + sh[cs], acc[ps][cs][1] * sc[cs] + sh[cs],
-                                       acc[ps][cs][2] * sc[cs] + sh[cs], acc[ps][cs][3] * sc[cs] + sh[cs]);
-                if (p.res1) { v.x += r1[cs][ps].x; v.y += r1[cs][ps].y; v.z += r1[cs][ps].z; v.w += r1[cs][ps].w; }
-                if (p.res2) { v.x += r2[cs][ps].x; v.y += r2[cs][ps].y; v.z += r2[cs][ps].z; v.w += r2[cs][ps].w; }
+                f32x4 v = acc[ps][cs] * sc[cs] + sh[cs];
+                if (p.res1) v += r1[cs][ps];
+                if (p.res2) v += r2[cs][ps];
                 if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                if (co_ok[cs] && pix_ok[ps]) *reinterpret_cast<float4*>(p.out + co_off[cs] + pix_off[ps]) = v;
+                buf_store4(rs_o, ((co_off[cs] | pix_off[ps]) & kOob) ? kOob : (co_off[cs] + pix_off[ps]) * 4u, v);
             }
     } else {
 #pragma unroll
