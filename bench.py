@@ -57,6 +57,21 @@ def time_plan_entries(plan, reps):
     return out
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*_pmc_traffic.json;
+    bench.py cannot collect PMC counters itself).  None when no summary names the kernel."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                k = json.load(f)["kernels"].get(kernel)
+            if k:
+                return {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "source": os.path.relpath(path, ROOT)}
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
+
+
 def roofline_report(plan, reps=5):
     per_entry = time_plan_entries(plan, reps)
     groups = {}
@@ -75,7 +90,7 @@ def roofline_report(plan, reps=5):
     achieved = g["flops"] / g["time"] / 1e12
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+        "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(dom),
         "kernel": dom, "launches_per_step": g["launches"],
         "flop_per_launch": round(g["flops"] / g["launches"]), "avg_launch_us": round(g["time"] / g["launches"] * 1e6, 2),
         "share_of_conv_time": round(g["time"] / fam_t, 3),
