@@ -428,20 +428,38 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvKParams p) 
                     if (p.relu) { r4.x = fmaxf(r4.x, 0.f); r4.y = fmaxf(r4.y, 0.f); r4.z = fmaxf(r4.z, 0.f); r4.w = fmaxf(r4.w, 0.f); }
                     *reinterpret_cast<float4*>(p.out + o) = r4;
                 } else if (p.out_rep == p.out_mul && (p.out_rep == 2 || p.out_rep == 4 || p.out_rep == 8)) {
-                    // nearest up-sample by s: 4 pixels -> 4s contiguous outputs per row, s rows
+                    // nearest up-sample by s (HRModule fuse rows): 4 pixels -> 4s contiguous outputs per row, s rows.
+                    // Per output row: all residual loads first (range-checked buffer loads), then the stores.
                     const int s = p.out_rep;
+                    const size_t img_base = (size_t)n * p.Cout * plane_o;
+                    const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.out + img_base, (size_t)p.Cout * plane_o * 4);
+                    const __amdgpu_buffer_rsrc_t r1s = make_rsrc((p.res1 ? p.res1 : p.out) + img_base, (size_t)p.Cout * plane_o * 4);
+                    const __amdgpu_buffer_rsrc_t r2s = make_rsrc((p.res2 ? p.res2 : p.out) + img_base, (size_t)p.Cout * plane_o * 4);
+                    const f32x4 vv = (f32x4){v[0], v[1], v[2], v[3]};
                     for (int a = 0; a < s; ++a) {
-                        const size_t o = base + (size_t)(yy * s + a + p.off_y) * p.out_w + (size_t)xx * s + p.off_x;
-                        for (int j = 0; j < s; ++j) {
-                            float4 r4;
-                            if (s == 2) r4 = (j == 0) ? make_float4(v[0], v[0], v[1], v[1]) : make_float4(v[2], v[2], v[3], v[3]);
-                            else if (s == 4) { const float e = (j == 0) ? v[0] : (j == 1) ? v[1] : (j == 2) ? v[2] : v[3]; r4 = make_float4(e, e, e, e); }
-                            else { const int jj = j >> 1; const float e = (jj == 0) ? v[0] : (jj == 1) ? v[1] : (jj == 2) ? v[2] : v[3]; r4 = make_float4(e, e, e, e); }
-                            const size_t oo = o + 4 * j;
-                            if (p.res1) { const float4 t4 = *reinterpret_cast<const float4*>(p.res1 + oo); r4.x += t4.x; r4.y += t4.y; r4.z += t4.z; r4.w += t4.w; }
-                            if (p.res2) { const float4 t4 = *reinterpret_cast<const float4*>(p.res2 + oo); r4.x += t4.x; r4.y += t4.y; r4.z += t4.z; r4.w += t4.w; }
-                            if (p.relu) { r4.x = fmaxf(r4.x, 0.f); r4.y = fmaxf(r4.y, 0.f); r4.z = fmaxf(r4.z, 0.f); r4.w = fmaxf(r4.w, 0.f); }
-                            *reinterpret_cast<float4*>(p.out + oo) = r4;
+                        const unsigned o = ((unsigned)co * plane_o + (unsigned)(yy * s + a + p.off_y) * p.out_w + xx * s + p.off_x) * 4u;
+                        for (int jb = 0; jb < s; jb += 4) {  // batches of <= 4 x 16 B keep the register footprint small
+                            f32x4 t1[4], t2[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                if (jb + j < s) {
+                                    if (p.res1) t1[j] = buf_load4(r1s, o + 16u * (jb + j));
+                                    if (p.res2) t2[j] = buf_load4(r2s, o + 16u * (jb + j));
+                                }
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                if (jb + j < s) {
+                                    const int jj = s == 2 ? 0 : (s == 4 ? jb + j : ((jb + j) >> 1));
+                                    const float e = (jj == 0) ? vv.x : (jj == 1) ? vv.y : (jj == 2) ? vv.z : vv.w;
+                                    f32x4 r4 = (f32x4){e, e, e, e};
+                                    if (s == 2) r4 = (j == 0) ? (f32x4){vv.x, vv.x, vv.y, vv.y} : (f32x4){vv.z, vv.z, vv.w, vv.w};
+                                    if (p.res1) r4 += t1[j];
+                                    if (p.res2) r4 += t2[j];
+                                    if (p.relu) { r4.x = fmaxf(r4.x, 0.f); r4.y = fmaxf(r4.y, 0.f); r4.z = fmaxf(r4.z, 0.f); r4.w = fmaxf(r4.w, 0.f); }
+                                    buf_store4(ro, o + 16u * (jb + j), r4);
+                                }
+                            }
                         }
                     }
                 } else {
