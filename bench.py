@@ -31,6 +31,21 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP
 VARIANT_TEMPLATE = {0: "3,2,4,1", 1: "3,4,4,1", 2: "3,3,4,1", 3: "3,2,2,2", 4: "3,1,2,2"}  # PS,CS,WAVES_P,WAVES_C
 
 
+# name -> (backbone, head, image HxW, decoder kwargs, flip test, description)
+WORKLOADS = {
+    "hrnet_w32": ("hrnet_w32", "hrnet_head", (256, 192), dict(shift_coordinate=True), False,
+                  "configs[2]: HRNet-W32 256x192 inference, 1xMI355X per rank, multi-branch conv + fuse layers on fp32 MFMA, "
+                  "HRNetHead, arg-max+shift decode"),
+    "simplebaseline_r50": ("resnet50", "simple_baseline_head", (256, 192), dict(shift_coordinate=True), False,
+                           "configs[1]: SimpleBaseline ResNet-50 256x192 inference, HIP deconv head (4 sub-pixel phase convs) + "
+                           "arg-max+shift decode"),
+    "hrnet_w48_384_udp_flip": ("hrnet_w48", "hrnet_head", (384, 288),
+                               dict(use_udp=True, dark_udp_refine=True, kernel_size=17), True,
+                               "configs[4] shape in fp32: HRNet-W48 384x288, flip-test aggregation fused with UDP/DARK decode "
+                               "(two forwards per crop)"),
+}
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -156,6 +171,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="crops per GPU per step (reference per-device batch_size)")
+    ap.add_argument("--workload", default="hrnet_w32", choices=list(WORKLOADS),
+                    help="hrnet_w32 = BASELINE.json metric / configs[2] (default); the others are extra measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -178,20 +195,30 @@ def main():
     import mindpose_amd as mp
 
     torch.manual_seed(0)
-    net = mp.init_synthetic(mp.create_network("hrnet_w32", "hrnet_head"), seed=0).to(dev).eval()
-    decoder = mp.create_decoder("topdown_heatmap", shift_coordinate=True).to(dev)
+    backbone, head, (ih, iw), dec_kw, flip, workload_desc = WORKLOADS[args.workload]
+    net = mp.init_synthetic(mp.create_network(backbone, head), seed=0).to(dev).eval()
+    decoder = mp.create_decoder("topdown_heatmap", **dec_kw).to(dev)
     eval_net = mp.create_eval_network(net, decoder, output_raw=True)
+    multi_run = None
+    if flip:
+        from mindpose_amd.engine.inferencer.topdown_inferencer import _MultiRunNet
+        from tests.golden.recipes import FLIP_INDEX
+        multi_run = _MultiRunNet(eval_net, decoder, np.array(FLIP_INDEX), shift_heatmap=False).to(dev)
 
     n = args.batch
     # synthetic crops written straight into the plan's resident input buffer (inputs in HBM before timing)
     gen = torch.Generator(device="cpu").manual_seed(1000 + rank)
-    image = net.input_buffer((n, 3, 256, 192), dev)
-    image.copy_(torch.randn(n, 3, 256, 192, generator=gen))
+    image = net.input_buffer((n, 3, ih, iw), dev)
+    image.copy_(torch.randn(n, 3, ih, iw, generator=gen))
+    if flip:
+        image = image.clone()  # the flip test runs two forwards through the same plan input buffer
     center = (torch.rand(n, 2, generator=gen) * 400).to(dev)
     scale = (torch.rand(n, 2, generator=gen) * 2.7 + 0.3).to(dev)
     score = torch.rand(n, generator=gen).to(dev)
 
     def step():
+        if multi_run is not None:
+            return multi_run(image, center, scale, score)
         return eval_net(image, center, scale, score)
 
     def sync_all():
@@ -200,7 +227,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    log(f"rank {rank}: plan built ({len(net.get_plan((n, 3, 256, 192), dev))} launches), warming up")
+    log(f"rank {rank}: plan built ({len(net.get_plan((n, 3, ih, iw), dev))} launches), warming up")
     for _ in range(args.warmup):
         step()
     sync_all()
@@ -218,22 +245,23 @@ def main():
     log(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step")
     result = None
     if rank == 0:
-        plan = net.get_plan((n, 3, 256, 192), dev)
+        plan = net.get_plan((n, 3, ih, iw), dev)
         result = {
-            "metric": "images/sec at 256x192, HRNet-W32 top-down inference (backbone+head+decode)",
+            "metric": ("images/sec at 256x192, HRNet-W32 top-down inference (backbone+head+decode)" if args.workload == "hrnet_w32"
+                       else f"images/sec, {args.workload} top-down inference (backbone+head+decode)"),
             "value": round(world * n * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[2]: HRNet-W32 256x192 inference, 1xMI355X per rank, multi-branch conv + "
-                                   "fuse layers on fp32 MFMA, HRNetHead, arg-max+shift decode",
-                       "per_gpu_batch": n, "global_batch": n * world, "image": "256x192", "heatmap": "64x48x17",
+            "config": {"workload": workload_desc,
+                       "per_gpu_batch": n, "global_batch": n * world, "image": f"{ih}x{iw}", "heatmap": f"{ih // 4}x{iw // 4}x17",
                        "sharding": "crops split over ranks, no data-path collective",
-                       "gflop_per_image": round(2e-9 * plan.total_macs / n, 3), "launches_per_step": len(plan) + 1},
+                       "gflop_per_image": round(2e-9 * plan.total_macs / n * (2 if flip else 1), 3),
+                       "launches_per_step": (len(plan) + 1) * (2 if flip else 1)},
         }
         if not args.no_roofline:
             result["roofline"] = roofline_report(plan)
             log("roofline done")
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "hrnet_w32":
             result["cpu_baseline"] = cpu_baseline(net.state_dict(), batch=8)
     if dist is not None:
         dist.barrier()

@@ -205,3 +205,32 @@ def test_network_with_loss_and_cpu_input_fails_loudly():
     assert loss.numel() == 1 and torch.isfinite(loss)
     with pytest.raises(mp._lib.MindposeHipError):
         net(torch.randn(1, 3, 64, 64))  # CPU input: no fallback
+
+
+def test_config5_w48_384x288_udp_dark_flip_end_to_end():
+    # BASELINE.json configs[4] shape (HRNet-W48 384x288, UDP + DARK k=17, flip test) at N=2, fp32
+    from oracle import decoder as od
+    from tests.golden import recipes
+    from mindpose_amd.engine.inferencer.topdown_inferencer import _MultiRunNet
+    net = _net("hrnet_w48", "hrnet_head")
+    dec = mp.create_decoder("topdown_heatmap", use_udp=True, dark_udp_refine=True, kernel_size=17).to(DEV)
+    ev = mp.create_eval_network(net, dec, output_raw=True)
+    mr = _MultiRunNet(ev, dec, np.array(recipes.FLIP_INDEX), shift_heatmap=False).to(DEV)
+    x = torch.randn(2, 3, 384, 288, generator=torch.Generator().manual_seed(5))
+    center, scale, score = (torch.from_numpy(a) for a in recipes.boxes(2, 6))
+    preds, boxes = mr(x.to(DEV), center.to(DEV), scale.to(DEV), score.to(DEV))
+    sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    h = onets.net_forward(sd, x, "hrnet_w48", "hrnet_head").numpy()
+    hf = onets.net_forward(sd, torch.flip(x, dims=[3]), "hrnet_w48", "hrnet_head").numpy()
+    assert h.shape == (2, 17, 96, 72)
+    # heat-maps of the HIP path vs oracle (both runs)
+    got_h = net(x.to(DEV)).cpu().numpy()
+    assert np.abs(got_h - h).max() / np.abs(h).max() < 1e-3
+    # decode on the oracle-aggregated map: identical arg-max wherever the top-2 margin is safe, boxes exact
+    avg = od.flip_aggregate(h, hf, recipes.FLIP_INDEX, shift_heatmap=False)
+    rp, rb, ri = od.decode(avg, center.numpy(), scale.numpy(), score.numpy(), use_udp=True, dark_udp_refine=True, kernel_size=17)
+    flat = avg.reshape(2, 17, -1)
+    top2 = np.sort(flat, axis=2)[..., -2:]
+    safe = (top2[..., 1] - top2[..., 0]) > 2e-3 * np.abs(avg).max()
+    assert np.array_equal(dec.last_argmax.cpu().numpy()[safe], ri.astype(np.int32)[safe])
+    assert np.array_equal(boxes.cpu().numpy(), rb)
