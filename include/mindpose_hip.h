@@ -142,6 +142,15 @@ int mp_conv2d_fwd(const mp_conv_desc* desc, const float* x_dev, const float* pac
 /* nn.MaxPool2d(kernel_size=3, stride=2, pad_mode="same"), resnet.py:190: pads bottom/right only. */
 int mp_maxpool3x3s2_same(const float* x_dev, float* out_dev, int n, int c, int h, int w, mp_stream_t stream);
 
+/* HRModule exchange unit, up-sampling side (mindpose/models/backbones/hrnet.py:327-339, j > i terms):
+ *   out = act( ((base + up_s1(t1)) + up_s2(t2)) + up_s3(t3) )      (reference summation order)
+ * base/out [N,C,H,W]; t_k [N,C,H/s_k,W/s_k] already holds BN(conv1x1(x_j)); up_s = nearest (src = dst / s).
+ * t2/t3 may be NULL (s ignored).  One streaming pass: the up-sampled terms are never materialised and the
+ * full-resolution sum is read and written once per fuse row.  out may alias base. */
+int mp_fuse_upsample_sum(const float* base_dev, const float* t1_dev, int s1, const float* t2_dev, int s2,
+                         const float* t3_dev, int s3, float* out_dev, int n, int c, int h, int w, int relu,
+                         mp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Launch plan: a recorded sequence of the calls above (one HRNet / ResNet forward = ~300 launches)
  * replayed by ONE native call, so the per-layer host cost is paid once at build time.
@@ -153,11 +162,13 @@ int mp_plan_add_conv(mp_plan* plan, const mp_conv_desc* desc, const float* x_dev
                      const float* scale_dev, const float* shift_dev, const float* res1_dev,
                      const float* res2_dev, float* out_dev);
 int mp_plan_add_maxpool(mp_plan* plan, const float* x_dev, float* out_dev, int n, int c, int h, int w);
+int mp_plan_add_fuse_sum(mp_plan* plan, const float* base_dev, const float* t1_dev, int s1, const float* t2_dev, int s2,
+                         const float* t3_dev, int s3, float* out_dev, int n, int c, int h, int w, int relu);
 int mp_plan_size(const mp_plan* plan);
 int mp_plan_run(const mp_plan* plan, mp_stream_t stream);
 /* run entries [first, first+count) only (profiling / per-layer timing) */
 int mp_plan_run_range(const mp_plan* plan, int first, int count, mp_stream_t stream);
-/* launch geometry of entry `index` (roofline report): info[0]=kind (0 conv, 1 maxpool), [1]=kernel size,
+/* launch geometry of entry `index` (roofline report): info[0]=kind (0 conv, 1 maxpool, 2 fuse-sum), [1]=kernel size,
  * [2]=stride, [3]=tile variant, [4]=workgroups, [5]=LDS bytes per workgroup, [6]=cout tile, [7]=pixel tile,
  * [8]=cin chunk, [9]=images per tile, [10]=rows per tile */
 int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]);

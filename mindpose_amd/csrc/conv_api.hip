@@ -224,11 +224,14 @@ using namespace mp;
 
 struct mp_plan {
     struct Entry {
-        int kind;  // 0 conv, 1 maxpool
+        int kind;  // 0 conv, 1 maxpool, 2 fuse-sum
         ConvLaunch conv;
         const float* x;
         float* out;
         int n, c, h, w;
+        const float* t[3];
+        int s[3];
+        int relu;
     };
     std::vector<Entry> entries;
 };
@@ -299,6 +302,19 @@ int mp_plan_add_maxpool(mp_plan* plan, const float* x, float* out, int n, int c,
     return MP_OK;
 }
 
+int mp_plan_add_fuse_sum(mp_plan* plan, const float* base, const float* t1, int s1, const float* t2, int s2,
+                         const float* t3, int s3, float* out, int n, int c, int h, int w, int relu) {
+    if (!plan || !base || !t1 || !out) return MP_ERR_NULL;
+    if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return MP_ERR_SHAPE;
+    if (w & 3) return MP_ERR_UNSUPPORTED;
+    mp_plan::Entry e{};
+    e.kind = 2;
+    e.x = base; e.out = out; e.n = n; e.c = c; e.h = h; e.w = w; e.relu = relu;
+    e.t[0] = t1; e.t[1] = t2; e.t[2] = t3; e.s[0] = s1; e.s[1] = s2; e.s[2] = s3;
+    plan->entries.push_back(e);
+    return MP_OK;
+}
+
 int mp_plan_size(const mp_plan* plan) { return plan ? (int)plan->entries.size() : MP_ERR_NULL; }
 
 int mp_plan_run_range(const mp_plan* plan, int first, int count, mp_stream_t stream) {
@@ -306,8 +322,10 @@ int mp_plan_run_range(const mp_plan* plan, int first, int count, mp_stream_t str
     if (first < 0 || count < 0 || (size_t)first + count > plan->entries.size()) return MP_ERR_SHAPE;
     for (int i = first; i < first + count; ++i) {
         const mp_plan::Entry& e = plan->entries[i];
-        int rc = e.kind == 0 ? launch(e.conv, as_stream(stream))
-                             : mp_maxpool3x3s2_same(e.x, e.out, e.n, e.c, e.h, e.w, stream);
+        int rc = e.kind == 0   ? launch(e.conv, as_stream(stream))
+                 : e.kind == 1 ? mp_maxpool3x3s2_same(e.x, e.out, e.n, e.c, e.h, e.w, stream)
+                               : mp_fuse_upsample_sum(e.x, e.t[0], e.s[0], e.t[1], e.s[1], e.t[2], e.s[2], e.out, e.n, e.c,
+                                                      e.h, e.w, e.relu, stream);
         if (rc != MP_OK) return rc;
     }
     return MP_OK;

@@ -386,6 +386,44 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_same_kernel(const float* __r
     }
 }
 
+// HRModule exchange unit, up-sampling side: out = act(((base + up(t1)) + up(t2)) + up(t3)), nearest up-sampling by
+// s_k = 1 << sh_k.  One thread per 4 output columns (16 B loads/stores of base/out); a low-resolution term
+// contributes one value per s_k columns, served from L2 (each low-res row is re-read by s_k output rows).
+struct FuseSumParams {
+    const float* base;
+    const float* t[3];
+    float* out;
+    int sh[3];  // log2(scale), -1 = absent
+    int n_planes, h, w, relu;
+};
+
+__global__ __launch_bounds__(256) void fuse_sum_kernel(FuseSumParams p) {
+    const int wq = p.w >> 2;
+    const size_t total = (size_t)p.n_planes * p.h * wq;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int xq = (int)(i % wq);
+        const size_t r = i / wq;
+        const int y = (int)(r % p.h);
+        const size_t plane = r / p.h;
+        const size_t o = (plane * p.h + y) * p.w + (size_t)xq * 4;
+        float4 v = *reinterpret_cast<const float4*>(p.base + o);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (p.sh[k] < 0) continue;
+            const int sh = p.sh[k];
+            const int lw = p.w >> sh, lh = p.h >> sh;
+            const float* row = p.t[k] + (plane * lh + (y >> sh)) * lw;
+            const int x0 = xq * 4;
+            v.x += row[(x0 + 0) >> sh];
+            v.y += row[(x0 + 1) >> sh];
+            v.z += row[(x0 + 2) >> sh];
+            v.w += row[(x0 + 3) >> sh];
+        }
+        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(p.out + o) = v;
+    }
+}
+
 static int launch_decode(const DecodeParams& p, hipStream_t s) {
     const int rows = p.n * p.k;
     dim3 grid((rows + 3) / 4), block(256);
@@ -517,6 +555,36 @@ int mp_joints_mse_bwd(const float* pred, const float* target, const float* weigh
     const float c = (float)(2.0 / ((double)n * k * (double)hw));
     hipLaunchKernelGGL(mse_bwd_kernel, dim3(n * k), dim3(256), 0, as_stream(stream), pred, target, weight, grad_out,
                        grad_pred, hw, c);
+    return check_launch();
+}
+
+static int log2_exact(int v) {
+    for (int i = 0; i < 16; ++i)
+        if ((1 << i) == v) return i;
+    return -1;
+}
+
+int mp_fuse_upsample_sum(const float* base, const float* t1, int s1, const float* t2, int s2, const float* t3, int s3,
+                         float* out, int n, int c, int h, int w, int relu, mp_stream_t stream) {
+    if (!base || !t1 || !out) return MP_ERR_NULL;
+    if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return MP_ERR_SHAPE;
+    if (w & 3) return MP_ERR_UNSUPPORTED;
+    FuseSumParams p{};
+    p.base = base; p.out = out; p.n_planes = n * c; p.h = h; p.w = w; p.relu = relu ? 1 : 0;
+    const float* ts[3] = {t1, t2, t3};
+    const int ss[3] = {s1, s2, s3};
+    for (int k = 0; k < 3; ++k) {
+        p.t[k] = ts[k];
+        p.sh[k] = -1;
+        if (!ts[k]) continue;
+        const int sh = log2_exact(ss[k]);
+        if (sh < 0 || (h % ss[k]) || (w % ss[k])) return MP_ERR_UNSUPPORTED;
+        p.sh[k] = sh;
+    }
+    const size_t total = (size_t)n * c * h * (w >> 2);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(fuse_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p);
     return check_launch();
 }
 

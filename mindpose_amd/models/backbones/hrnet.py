@@ -143,31 +143,45 @@ class HRModule(nn.Module):
             # reference order (hrnet.py:327-339): y = t_0; y = y + t_1; ... ; relu(y).  Every term except
             # the identity x_i is a conv launch whose epilogue adds the running sum (res1); the identity
             # rides as res2 on the launch that precedes it (or as res1 of the first launch when i == 0).
-            conv_terms = [j for j in range(nb) if j != i]
+            down_terms = [j for j in range(nb) if j < i]
+            up_terms = [j for j in range(nb) if j > i]
+            vec = xs[i].shape[3] % 4 == 0  # the streaming fuse-sum kernel moves 16 B per lane
             acc = xs[0] if i == 0 else None
             ybuf = None
-            for j in conv_terms:
-                relu = j == conv_terms[-1]
-                res2 = xs[i] if (i >= 1 and j == i - 1) else None
-                if j > i:
+            # (a) down-sampling terms j < i: 3x3 s2 chains whose last conv accumulates into ybuf in its epilogue;
+            #     the identity x_i rides as res2 of the launch that precedes it in the reference order
+            for j in down_terms:
+                last = j == down_terms[-1]
+                relu = last and not up_terms
+                res2 = xs[i] if j == i - 1 else None
+                chain = self.fuse_layers[i][j]
+                t = xs[j]
+                for k in range(len(chain) - 1):
+                    t = _emit_conv_bn(plan, chain[k], t)
+                if ybuf is None:
+                    ybuf = plan.alloc(*xs[i].shape)
+                _emit_conv_bn(plan, chain[-1], t, relu=relu, res1=acc, res2=res2, out=ybuf)
+                acc = ybuf
+            # (b) up-sampling terms j > i: BN(conv1x1(x_j)) stays at low resolution; ONE streaming pass adds all of
+            #     them (nearest up-sampling on the fly, reference order) and applies the ReLU
+            if up_terms:
+                if ybuf is None:
+                    ybuf = plan.alloc(*xs[i].shape)
+                ups = []
+                for j in up_terms:
                     seq = self.fuse_layers[i][j]
                     up = xs[i].shape[2] // xs[j].shape[2]
                     if xs[j].shape[2] * up != xs[i].shape[2] or xs[j].shape[3] * up != xs[i].shape[3]:
                         raise ValueError(
                             f"HRNet fuse needs an integer nearest-upsample factor, got {tuple(xs[j].shape[2:])} -> "
                             f"{tuple(xs[i].shape[2:])}; use an input whose height and width are multiples of 32")
-                    if ybuf is None:
-                        ybuf = plan.alloc(*xs[i].shape)
-                    plan.conv(xs[j], seq[0], seq[1], relu=relu, res1=acc, res2=res2, out=ybuf, upsample=up)
-                else:
-                    chain = self.fuse_layers[i][j]
-                    t = xs[j]
-                    for k in range(len(chain) - 1):
-                        t = _emit_conv_bn(plan, chain[k], t)
-                    if ybuf is None:
-                        ybuf = plan.alloc(*xs[i].shape)
-                    _emit_conv_bn(plan, chain[-1], t, relu=relu, res1=acc, res2=res2, out=ybuf)
-                acc = ybuf
+                    if vec:
+                        ups.append((plan.conv(xs[j], seq[0], seq[1]), up))
+                    else:  # odd widths: accumulate through the conv epilogue's up-sample mapping
+                        plan.conv(xs[j], seq[0], seq[1], relu=j == up_terms[-1], res1=acc, out=ybuf, upsample=up)
+                        acc = ybuf
+                if vec:
+                    plan.fuse_sum(acc, ups, ybuf, relu=True)
             outs.append(ybuf)
         return outs
 

@@ -188,6 +188,21 @@ class Plan:
                                             macs=n * h * w * cout * cin * 4))
         return out
 
+    def fuse_sum(self, base: torch.Tensor, terms, out: torch.Tensor, relu: bool = True) -> torch.Tensor:
+        """out = act(((base + up(t1)) + up(t2)) + up(t3)); ``terms`` = [(low-res tensor, integer scale), ...] (1-3)."""
+        n, c, h, w = base.shape
+        if not 1 <= len(terms) <= 3:
+            raise ValueError("fuse_sum takes 1 to 3 up-sampled terms")
+        args = []
+        for t, sc in list(terms) + [(None, 1)] * (3 - len(terms)):
+            if t is not None and tuple(t.shape) != (n, c, h // sc, w // sc):
+                raise ValueError(f"fuse term shape {tuple(t.shape)} does not match {(n, c, h // sc, w // sc)}")
+            args += [_lib.ptr(t), int(sc)]
+        _lib.check(self.lib.mp_plan_add_fuse_sum(self.handle, _lib.ptr(base), *args, _lib.ptr(out), n, c, h, w, int(relu)),
+                   "mp_plan_add_fuse_sum")
+        self.layer_info.append(dict(kind="fuse_sum", n=n, c=c, h=h, w=w, terms=len(terms), macs=0))
+        return out
+
     def maxpool3x3s2_same(self, x: torch.Tensor) -> torch.Tensor:
         n, c, h, w = x.shape
         out = self.alloc(n, c, (h + 1) // 2, (w + 1) // 2)

@@ -234,3 +234,22 @@ def test_config5_w48_384x288_udp_dark_flip_end_to_end():
     safe = (top2[..., 1] - top2[..., 0]) > 2e-3 * np.abs(avg).max()
     assert np.array_equal(dec.last_argmax.cpu().numpy()[safe], ri.astype(np.int32)[safe])
     assert np.array_equal(boxes.cpu().numpy(), rb)
+
+
+@pytest.mark.parametrize("terms", [[2], [2, 4], [2, 4, 8]])
+def test_fuse_upsample_sum_vs_torch(terms):
+    # out = relu(((base + up(t1)) + up(t2)) + up(t3)), same order as hrnet.py:327-339 -> bit-exact vs torch
+    g = torch.Generator().manual_seed(len(terms))
+    n, c, h, w = 3, 8, 32, 24
+    base = torch.randn(n, c, h, w, generator=g)
+    ts = [torch.randn(n, c, h // s, w // s, generator=g) for s in terms]
+    ref = base.clone()
+    for t, s in zip(ts, terms):
+        ref = ref + F.interpolate(t, size=(h, w), mode="nearest")
+    ref = F.relu(ref)
+    plan = Plan(DEV)
+    out = plan.alloc(n, c, h, w)
+    plan.fuse_sum(base.to(DEV), [(t.to(DEV), s) for t, s in zip(ts, terms)], out, relu=True)
+    plan.run()
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), ref)
