@@ -110,15 +110,18 @@ static bool configure(const mp_conv_desc& d, int variant, ConvLaunch& L) {
     p.upc = p.G * p.Rin * p.upr;
     // cin chunk: the largest multiple of 4 that divides Cin_pad4, fits the per-thread staging registers
     // (kNI / NW units of 16 B) and - double-buffered when there is more than one chunk - the LDS budget
-    const int nw = stage_nw(KS);
+    const int cs_v = variant_cs(variant), wc_v = variant_waves_c(variant);
+    const int nw = stage_nw(KS, cs_v, wc_v), ni = stage_ni(KS, cs_v, wc_v, p.vec != 0);
+    // three workgroups per CU for the light variant (160 KiB / 3), two otherwise
+    const int budget = (stage_occ(KS, cs_v, wc_v) == 3 && !getenv("MP_CONV_LDS_KB")) ? 52 * 1024 : lds_budget();
     int best_ck = 0;
     for (int ck = 4; ck <= p.Cin_pad4 && ck <= 128; ck += 4) {
         if (p.Cin_pad4 % ck) continue;
-        if ((long long)ck * p.upc > (long long)kNI * 256) continue;
+        if ((long long)ck * p.upc > (long long)ni * 256) continue;
         if ((long long)ck * T * CT / 4 > (long long)nw * 256) continue;
         const int nbuf = ck < p.Cin_pad4 ? 2 : 1;
         const long long bytes = (long long)nbuf * (ck * p.cin_plane + ck * T * CT) * 4;
-        if (bytes > lds_budget() && !(ck == 4 && bytes <= kLdsMax)) continue;
+        if (bytes > budget && !(ck == 4 && bytes <= kLdsMax)) continue;
         best_ck = ck;
     }
     if (best_ck == 0) return false;

@@ -101,8 +101,8 @@ __device__ __forceinline__ unsigned fastdiv(unsigned e, unsigned d, unsigned mag
 //              fragments prefetched one k-step ahead, so an MFMA never waits on LDS)  ->  write the
 //              registers into the other LDS buffer  ->  ONE barrier
 // NI / NW = staging units (16 B) per thread per chunk for input / weights; the host picks CK to fit.
-template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, int NI, int NW, bool VEC>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvKParams p) {
+template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, int NI, int NW, bool VEC, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvKParams p) {
     static_assert(WAVES_P * WAVES_C == 4, "4 waves per workgroup");
     constexpr int T = KS * KS;
     constexpr int CT = 16 * CS * WAVES_C;
@@ -518,6 +518,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvKParams p) 
 // tile variants: index -> (PS, CS, WAVES_P, WAVES_C); CT = 16*CS*WAVES_C, PT = 16*PS*WAVES_P
 enum ConvVariant { V_CT32_PT192 = 0, V_CT64_PT192 = 1, V_CT48_PT192 = 2, V_CT64_PT96 = 3, V_CT32_PT96 = 4, V_COUNT = 5 };
 
+inline int variant_cs(int v) {
+    static const int css[V_COUNT] = {2, 4, 3, 2, 1};
+    return css[v];
+}
+inline int variant_waves_c(int v) {
+    static const int wcs[V_COUNT] = {1, 1, 1, 2, 2};
+    return wcs[v];
+}
+
 inline void variant_dims(int v, int& ct, int& pt) {
     static const int cts[V_COUNT] = {32, 64, 48, 64, 32};
     static const int pts[V_COUNT] = {192, 192, 192, 96, 96};
@@ -525,12 +534,18 @@ inline void variant_dims(int v, int& ct, int& pt) {
     pt = pts[v];
 }
 
-constexpr int kNI = 8;                                          // input staging units per thread per chunk
-constexpr int stage_nw(int ks) { return ks == 7 ? 13 : 6; }    // weight staging units per thread per chunk
+// Staging units (16 B) per thread per chunk and the occupancy the kernel is compiled for.  The 32-cout x 192-pixel
+// variant serves the small-K layers (K = 9 x 32 on the 64x48 branch): its workgroups are short, so it takes small
+// chunks and runs THREE workgroups per CU - one workgroup's prologue / staging / epilogue hides under the others'
+// MFMA phases (measured +11 % on that kernel).  Large-K variants keep big chunks and two workgroups (measured better).
+constexpr bool light_variant(int ks, int cs, int waves_c) { return ks <= 3 && cs == 2 && waves_c == 1; }
+constexpr int stage_ni(int ks, int cs, int waves_c, bool vec) { return vec ? (light_variant(ks, cs, waves_c) ? 4 : 8) : (light_variant(ks, cs, waves_c) ? 10 : 8); }
+constexpr int stage_nw(int ks, int cs, int waves_c) { return ks == 7 ? 13 : (light_variant(ks, cs, waves_c) ? 3 : 6); }
+constexpr int stage_occ(int ks, int cs, int waves_c) { return light_variant(ks, cs, waves_c) ? 3 : 2; }
 
 template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, bool VEC>
 int launch_variant(const ConvKParams& p, size_t lds_bytes, hipStream_t s) {
-    auto kern = conv_mfma_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, kNI, stage_nw(KS), VEC>;
+    auto kern = conv_mfma_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, stage_ni(KS, CS, WAVES_C, VEC), stage_nw(KS, CS, WAVES_C), VEC, stage_occ(KS, CS, WAVES_C)>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
