@@ -87,8 +87,18 @@ def pmc_traffic(kernel):
     return None
 
 
-def roofline_report(plan, reps=5):
+def roofline_report(plan, reps=5, layers_csv=""):
     per_entry = time_plan_entries(plan, reps)
+    if layers_csv:
+        with open(layers_csv, "w") as f:
+            f.write("index,kind,kernel,us,tflops,n,cin,cout,k,stride,h,w,workgroups,lds_bytes,cin_chunk,images_per_tile,rows_per_tile\n")
+            for i, t in enumerate(per_entry):
+                e = plan.entry_info(i)
+                name = kernel_name(e) if e["kind_id"] == 0 else e["kind"]
+                tf = 2.0 * e.get("macs", 0) / t / 1e12 if t > 0 else 0.0
+                f.write(f"{i},{e['kind']},\"{name}\",{t * 1e6:.2f},{tf:.2f},{e.get('n', '')},{e.get('cin', e.get('c', ''))},"
+                        f"{e.get('cout', '')},{e.get('k', '')},{e.get('stride', '')},{e.get('h', '')},{e.get('w', '')},"
+                        f"{e['workgroups']},{e['lds_bytes']},{e['cin_chunk']},{e['images_per_tile']},{e['rows_per_tile']}\n")
     groups = {}
     for i, t in enumerate(per_entry):
         info = plan.entry_info(i)
@@ -173,6 +183,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="crops per GPU per step (reference per-device batch_size)")
     ap.add_argument("--workload", default="hrnet_w32", choices=list(WORKLOADS),
                     help="hrnet_w32 = BASELINE.json metric / configs[2] (default); the others are extra measurements")
+    ap.add_argument("--layers", default="", help="write a per-launch timing table (CSV) to this path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -259,7 +270,7 @@ def main():
                        "launches_per_step": (len(plan) + 1) * (2 if flip else 1)},
         }
         if not args.no_roofline:
-            result["roofline"] = roofline_report(plan)
+            result["roofline"] = roofline_report(plan, layers_csv=args.layers)
             log("roofline done")
         if world == 1 and not args.no_cpu_baseline and args.workload == "hrnet_w32":
             result["cpu_baseline"] = cpu_baseline(net.state_dict(), batch=8)
