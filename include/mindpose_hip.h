@@ -131,8 +131,13 @@ typedef struct mp_conv_desc {
 
 /* bytes of the packed weight buffer for a (cout, cin, kh, kw) kernel */
 size_t mp_conv_packed_weight_bytes(int cout, int cin, int kh, int kw);
-/* w_dev: [Cout,Cin,kh,kw] (Conv2d) when transposed==0; [Cin,Cout,4,4] Conv2dTranspose weights when
- * transposed==1, in which case phase (py,px) in {0,1}^2 selects the 2x2 sub-kernel and kh=kw=2. */
+/* Weight source layouts (`transposed` selects how w_dev is read; cout/cin/kh/kw describe the PACKED convolution):
+ *   0  w_dev = [Cout,Cin,kh,kw]   forward Conv2d
+ *   1  w_dev = [Cin,Cout,4,4]     Conv2dTranspose(k4,s2,p1) sub-pixel phase (py,px), kh=kw=2
+ *   2  w_dev = [Cin,Cout,kh,kw]   data gradient of a stride-1 Conv2d whose forward weight is w_dev (roles swapped,
+ *                                 taps mirrored): dx = conv(dz, pack2(W)) with the same padding
+ *   3  w_dev = [Cin,Cout,3,3]     data gradient of a 3x3 stride-2 pad-1 Conv2d, output parity phase (py,px), kh=kw=2,
+ *                                 run with pad 0 and the deconv output mapping (out_mul=2, out_off=(py,px)) */
 int mp_conv_pack_weight(const float* w_dev, float* packed_dev, int cout, int cin, int kh, int kw,
                         int transposed, int phase_y, int phase_x, mp_stream_t stream);
 int mp_conv2d_fwd(const mp_conv_desc* desc, const float* x_dev, const float* packed_w_dev,
@@ -172,6 +177,49 @@ int mp_plan_run_range(const mp_plan* plan, int first, int count, mp_stream_t str
  * [2]=stride, [3]=tile variant, [4]=workgroups, [5]=LDS bytes per workgroup, [6]=cout tile, [7]=pixel tile,
  * [8]=cin chunk, [9]=images per tile, [10]=rows per tile */
 int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]);
+
+/* ------------------------------------------------------------------------------------------
+ * Training-side kernels (reference: mindspore.Model.train over NetWithLoss, tools/train.py:170-233, amp aside:
+ * everything here computes in fp32).  All reductions are deterministic (fixed partition, fixed combine order).
+ *
+ * BatchNorm2d in training mode (nn.BatchNorm2d cells of hrnet.py / resnet.py; eps 1e-5, momentum 0.9 meaning
+ * moving = 0.9*moving + 0.1*batch [MS-knowledge]):
+ *   fwd: per-channel batch mean / biased variance over (N,H,W) of z [N,C,HW];
+ *        y = act(gamma*(z-mean)*invstd + beta (+ res)); saves mean/invstd; updates the moving statistics when given
+ *        (moving variance takes the unbiased batch variance).
+ *   bwd: g = dy masked by (y > 0) when relu; dgamma = sum g*xhat; dbeta = sum g;
+ *        dz = gamma*invstd*(g - dbeta/M - xhat*dgamma/M); dres (optional) = g.
+ * workspace >= mp_bn_workspace_bytes(c).
+ * ------------------------------------------------------------------------------------------ */
+size_t mp_bn_workspace_bytes(int c);
+int mp_bn_train_fwd(const float* z_dev, const float* gamma_dev, const float* beta_dev, const float* res_dev, float* y_dev,
+                    float* save_mean_dev, float* save_invstd_dev, float* moving_mean_dev, float* moving_var_dev, int n,
+                    int c, int hw, float eps, float momentum, int relu, void* workspace_dev, size_t workspace_bytes,
+                    mp_stream_t stream);
+int mp_bn_train_bwd(const float* dy_dev, const float* z_dev, const float* y_dev, const float* gamma_dev,
+                    const float* save_mean_dev, const float* save_invstd_dev, float* dz_dev, float* dres_dev,
+                    float* dgamma_dev, float* dbeta_dev, int n, int c, int hw, int relu, void* workspace_dev,
+                    size_t workspace_bytes, mp_stream_t stream);
+
+/* backward of mp_fuse_upsample_sum: g = dy*(out>0 when relu); dbase = g; dt_k = s_k x s_k block sums of g.
+ * Any of dbase / dt_k may be NULL (not needed). */
+int mp_fuse_upsample_sum_bwd(const float* dy_dev, const float* out_dev, float* dbase_dev, float* dt1_dev, int s1,
+                             float* dt2_dev, int s2, float* dt3_dev, int s3, int n, int c, int h, int w, int relu,
+                             mp_stream_t stream);
+
+/* mindspore.nn.AdamWeightDecay (selected by mindpose/optim/optim_factory.py:69-72 for "adamw"): Adam WITHOUT bias
+ * correction, eps added to sqrt(v), decoupled weight decay:  m=b1*m+(1-b1)*g; v=b2*v+(1-b2)*g*g;
+ * p -= lr*(m/(sqrt(v)+eps) + wd*p).  Operates on one flat fp32 arena (params, grads, moments). */
+int mp_adamw_step(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, size_t count,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, mp_stream_t stream);
+
+/* Conv2d weight gradient (training backward of every conv of hrnet.py): dW[co,ci,ky,kx] = sum_{n,y,x}
+ * dz[n,co,y,x] * x[n,ci,y*s+ky-p,x*s+kx-p] for k in {1,3}, s in {1,2}, p = k/2 (desc as for the forward conv; its
+ * output-mapping fields are ignored).  fp32 MFMA, pixel axis split over workgroups into slabs that are summed in a
+ * fixed order (deterministic).  accumulate != 0 adds into dw.  workspace >= mp_conv_wgrad_workspace_bytes(desc). */
+size_t mp_conv_wgrad_workspace_bytes(const mp_conv_desc* desc);
+int mp_conv_wgrad(const mp_conv_desc* desc, const float* x_dev, const float* dz_dev, float* dw_dev, int accumulate,
+                  void* workspace_dev, size_t workspace_bytes, mp_stream_t stream);
 
 /* Diagnostics: only a library built with -DMP_CONV_STAMPS=1 (never the product build) records per-workgroup
  * phase cycle counters (8 x uint64 per workgroup) of each conv launch into this device buffer; the product

@@ -57,6 +57,13 @@ _PROTOTYPES = {
     "mp_plan_run_range": (c_int, [ctypes.c_void_p, c_int, c_int, ctypes.c_void_p]),
     "mp_plan_entry_info": (c_int, [ctypes.c_void_p, c_int, ctypes.POINTER(ctypes.c_int64)]),
     "mp_debug_set_stamp_buffer": (c_int, [ctypes.c_void_p, c_size_t]),
+    "mp_bn_workspace_bytes": (c_size_t, [c_int]),
+    "mp_bn_train_fwd": (c_int, [c_f32p] * 9 + [c_int] * 3 + [ctypes.c_float, ctypes.c_float, c_int, c_f32p, c_size_t, ctypes.c_void_p]),
+    "mp_bn_train_bwd": (c_int, [c_f32p] * 10 + [c_int] * 4 + [c_f32p, c_size_t, ctypes.c_void_p]),
+    "mp_fuse_upsample_sum_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_int, c_f32p, c_int] + [c_int] * 5 + [ctypes.c_void_p]),
+    "mp_conv_wgrad_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),
+    "mp_conv_wgrad": (c_int, [ctypes.POINTER(ConvDesc), c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_size_t, ctypes.c_void_p]),
+    "mp_adamw_step": (c_int, [c_f32p] * 4 + [c_size_t] + [ctypes.c_float] * 5 + [ctypes.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)

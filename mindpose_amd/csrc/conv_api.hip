@@ -30,8 +30,18 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
         float v = 0.f;
         if (co < cout && ci < cin) {
             const int ty = t / kw, tx = t % kw;
-            if (!transposed) {
+            if (transposed == 0) {
                 v = w[(((size_t)co * cin + ci) * kh + ty) * kw + tx];
+            } else if (transposed == 2) {
+                // data gradient of a stride-1 conv whose weight is [cin, cout, kh, kw] in forward terms (this packed
+                // conv's cout = forward cin): roles swapped, taps mirrored
+                v = w[(((size_t)ci * cout + co) * kh + (kh - 1 - ty)) * kw + (kw - 1 - tx)];
+            } else if (transposed == 3) {
+                // data gradient of a 3x3 stride-2 pad-1 conv, output parity phase (py, px), as a 2x2 conv over dy:
+                // dx[2a+p] = sum_t dy[a+t] * w[k(p,t)],  k(0,0)=1, k(0,1)=none, k(1,0)=2, k(1,1)=0
+                const int ky = py == 0 ? (ty == 0 ? 1 : -1) : (ty == 0 ? 2 : 0);
+                const int kx = px == 0 ? (tx == 0 ? 1 : -1) : (tx == 0 ? 2 : 0);
+                v = (ky < 0 || kx < 0) ? 0.f : w[(((size_t)ci * cout + co) * 3 + ky) * 3 + kx];
             } else {
                 // Conv2dTranspose k=4 s=2 p=1: out row 2m+py reads in row m-1+py+ty with kernel row
                 // ky = 3-2*ty (py=0) or 2-2*ty (py=1); same along x.
@@ -250,14 +260,15 @@ int mp_conv_pack_weight(const float* w, float* packed, int cout, int cin, int kh
                         int phase_x, mp_stream_t stream) {
     if (!w || !packed) return MP_ERR_NULL;
     if (cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0) return MP_ERR_SHAPE;
-    if (transposed && (kh != 2 || kw != 2 || phase_y < 0 || phase_y > 1 || phase_x < 0 || phase_x > 1))
+    if (transposed < 0 || transposed > 3) return MP_ERR_UNSUPPORTED;
+    if ((transposed == 1 || transposed == 3) && (kh != 2 || kw != 2 || phase_y < 0 || phase_y > 1 || phase_x < 0 || phase_x > 1))
         return MP_ERR_UNSUPPORTED;
     const int cin_pad4 = round_up(cin, 4), cout_pad16 = round_up(cout, 16);
     const size_t total = (size_t)cin_pad4 * kh * kw * cout_pad16;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, packed, cout, cin, kh, kw,
-                       cin_pad4, cout_pad16, transposed ? 1 : 0, phase_y, phase_x);
+                       cin_pad4, cout_pad16, transposed, phase_y, phase_x);
     return check_launch();
 }
 
@@ -309,7 +320,6 @@ int mp_plan_add_fuse_sum(mp_plan* plan, const float* base, const float* t1, int 
                          const float* t3, int s3, float* out, int n, int c, int h, int w, int relu) {
     if (!plan || !base || !t1 || !out) return MP_ERR_NULL;
     if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return MP_ERR_SHAPE;
-    if (w & 3) return MP_ERR_UNSUPPORTED;
     mp_plan::Entry e{};
     e.kind = 2;
     e.x = base; e.out = out; e.n = n; e.c = c; e.h = h; e.w = w; e.relu = relu;

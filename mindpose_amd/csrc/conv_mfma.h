@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvKParams p
     float* __restrict__ lds_w = smem + p.nbuf * p.in_buf;    // [nbuf][w_buf]
 
     MP_STAMP(t_start);
-    unsigned long long s_load = 0, s_comp = 0, s_store = 0, s_bar = 0;
+    [[maybe_unused]] unsigned long long s_load = 0, s_comp = 0, s_store = 0, s_bar = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp_i = wave % WAVES_P, wc_i = wave / WAVES_P;
     const int lq = lane >> 4, lr = lane & 15;

@@ -1,0 +1,191 @@
+// Convolution weight gradient on the fp32 matrix cores (gfx950):
+//   dW[co][ci][ky][kx] = sum_{n,y,x} dz[n,co,y,x] * x[n,ci,y*S+ky-pad, x*S+kx-pad]
+// One GEMM per tap t: dW_t[Cout x Cin] = dZ[Cout x P] * X_t^T[P x Cin], P = N*Ho*Wo, on v_mfma_f32_16x16x4_f32
+// (lane l feeds A[cout l&15][pixel l>>4] and B[pixel l>>4][cin l&15]; K = 4 pixels per MFMA).
+// Workgroup = 32 couts x 32 cins x all taps; wave w owns the 16x16 sub-tile (w&1, w>>1) for every tap
+// (T accumulators).  The pixel axis is split over blockIdx.y; every split writes its partial dW into its own
+// slab and a second kernel sums the slabs in a fixed order (deterministic, no atomics).
+#include "common.h"
+
+namespace mp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct WgradParams {
+    const float* x;    // [N,Cin,H,W]
+    const float* dz;   // [N,Cout,Ho,Wo]
+    float* slabs;      // [splits][Cout][Cin][T]
+    int N, Cin, H, W, Cout, Ho, Wo, pad;
+    int R;             // output rows per pixel tile
+    int Rin, Wp;       // staged input rows / pitch
+    int xplane;        // per-cin LDS plane (odd)
+    int zpitch;        // per-cout LDS pitch of the dz tile (odd)
+    int tiles_y, n_tiles, splits;
+    int ci_tiles;
+};
+
+template <int KS, int S>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+    constexpr int T = KS * KS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* __restrict__ lz = smem;                       // [32][zpitch]
+    float* __restrict__ lx = smem + 32 * p.zpitch;       // [32][xplane]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co_sub = wave & 1, ci_sub = wave >> 1;
+    const int lq = lane >> 4, lr = lane & 15;
+    const int cot = blockIdx.x / p.ci_tiles, cit = blockIdx.x % p.ci_tiles;
+    const int co0 = cot * 32, ci0 = cit * 32;
+    const int HW = p.H * p.W, HoWo = p.Ho * p.Wo;
+
+    f32x4 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.y; tile < p.n_tiles; tile += p.splits) {
+        const int n = tile / p.tiles_y, y0 = (tile % p.tiles_y) * p.R;
+        const int rows = min(p.R, p.Ho - y0);
+        const int npix = rows * p.Wo;
+        const int yin0 = y0 * S - p.pad;
+        __syncthreads();  // previous tile consumed
+        // dz tile: 32 couts x npix (rows are contiguous in NCHW), zero beyond Cout / npix (rounded up to 4)
+        const int npix4 = (npix + 3) & ~3;
+        for (int e = tid; e < 32 * npix4; e += 256) {
+            const int c = e / npix4, px = e - c * npix4;
+            float v = 0.f;
+            if (co0 + c < p.Cout && px < npix) v = p.dz[((size_t)n * p.Cout + co0 + c) * HoWo + (size_t)y0 * p.Wo + px];
+            lz[c * p.zpitch + px] = v;
+        }
+        // x tile with halo: 32 cins x Rin x Wp, zero outside the image / beyond Cin
+        const int per_c = p.Rin * p.Wp;
+        for (int e = tid; e < 32 * per_c; e += 256) {
+            const int c = e / per_c, rem = e - c * per_c;
+            const int r = rem / p.Wp, xx = rem - r * p.Wp;
+            const int yin = yin0 + r, xin = xx - p.pad;
+            float v = 0.f;
+            if (ci0 + c < p.Cin && yin >= 0 && yin < p.H && xin >= 0 && xin < p.W)
+                v = p.x[((size_t)n * p.Cin + ci0 + c) * HW + (size_t)yin * p.W + xin];
+            lx[c * p.xplane + rem] = v;
+        }
+        __syncthreads();
+        const float* __restrict__ az = lz + (co_sub * 16 + lr) * p.zpitch;
+        const float* __restrict__ bx = lx + (ci_sub * 16 + lr) * p.xplane;
+        for (int q = 0; q < npix4; q += 4) {
+            const int px = q + lq;                 // this lane's pixel of the k-step (zero-padded beyond npix)
+            const int pc = px < npix ? px : 0;     // clamp the address; its dz value is 0 anyway
+            const int y = pc / p.Wo, xo = pc - y * p.Wo;
+            const float a = az[px];
+            const int boff = (y * S) * p.Wp + xo * S;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const float b = bx[boff + (t / KS) * p.Wp + (t % KS)];
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // D layout: col = lane & 15 -> cin, row = (lane >> 4) * 4 + r -> cout
+    float* __restrict__ slab = p.slabs + (size_t)blockIdx.y * p.Cout * p.Cin * T;
+    const int ci = ci0 + ci_sub * 16 + lr;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + co_sub * 16 + lq * 4 + r;
+            if (co < p.Cout && ci < p.Cin) slab[((size_t)co * p.Cin + ci) * T + t] = acc[t][r];
+        }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, size_t count,
+                                                           int splits, int accumulate) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += slabs[(size_t)k * count + i];  // fixed order
+        dw[i] = accumulate ? dw[i] + s : s;
+    }
+}
+
+static int odd_up(int v) { return v | 1; }
+
+static int wgrad_geometry(const mp_conv_desc* d, WgradParams& p, size_t& lds_bytes) {
+    if (!d) return MP_ERR_NULL;
+    if (d->n <= 0 || d->cin <= 0 || d->cout <= 0 || d->h <= 0 || d->w <= 0 || d->conv_h <= 0 || d->conv_w <= 0) return MP_ERR_SHAPE;
+    if (d->kh != d->kw || !(d->kh == 1 || d->kh == 3)) return MP_ERR_UNSUPPORTED;
+    if (!(d->stride == 1 || d->stride == 2)) return MP_ERR_UNSUPPORTED;
+    if (d->pad_top != d->pad_left || d->pad_top != d->kh / 2) return MP_ERR_UNSUPPORTED;
+    p.N = d->n; p.Cin = d->cin; p.H = d->h; p.W = d->w; p.Cout = d->cout; p.Ho = d->conv_h; p.Wo = d->conv_w; p.pad = d->pad_top;
+    const int S = d->stride, KS = d->kh;
+    int R = 192 / p.Wo;
+    if (R < 1) R = 1;
+    if (R > p.Ho) R = p.Ho;
+    for (;;) {
+        p.R = R;
+        p.Rin = (R - 1) * S + KS;
+        p.Wp = (p.Wo - 1) * S + KS;
+        p.xplane = odd_up(p.Rin * p.Wp);
+        p.zpitch = odd_up(((R * p.Wo + 3) & ~3) + 1);
+        lds_bytes = (size_t)32 * (p.xplane + p.zpitch) * 4;
+        if (lds_bytes <= 150 * 1024 || R == 1) break;
+        R = (R + 1) / 2;
+    }
+    if (lds_bytes > 150 * 1024) return MP_ERR_UNSUPPORTED;
+    p.tiles_y = (p.Ho + p.R - 1) / p.R;
+    p.n_tiles = p.N * p.tiles_y;
+    p.ci_tiles = (p.Cin + 31) / 32;
+    const int out_tiles = ((p.Cout + 31) / 32) * p.ci_tiles;
+    int splits = 1024 / out_tiles;
+    if (splits < 1) splits = 1;
+    if (splits > p.n_tiles) splits = p.n_tiles;
+    if (splits > 256) splits = 256;
+    p.splits = splits;
+    return MP_OK;
+}
+
+}  // namespace mp
+
+using namespace mp;
+
+extern "C" {
+
+size_t mp_conv_wgrad_workspace_bytes(const mp_conv_desc* desc) {
+    WgradParams p{};
+    size_t lds = 0;
+    if (wgrad_geometry(desc, p, lds) != MP_OK) return 0;
+    return (size_t)p.splits * p.Cout * p.Cin * desc->kh * desc->kw * sizeof(float);
+}
+
+int mp_conv_wgrad(const mp_conv_desc* desc, const float* x, const float* dz, float* dw, int accumulate, void* workspace,
+                  size_t workspace_bytes, mp_stream_t stream) {
+    if (!x || !dz || !dw) return MP_ERR_NULL;
+    WgradParams p{};
+    size_t lds = 0;
+    int rc = wgrad_geometry(desc, p, lds);
+    if (rc != MP_OK) return rc;
+    const size_t count = (size_t)p.Cout * p.Cin * desc->kh * desc->kw;
+    if (!workspace || workspace_bytes < (size_t)p.splits * count * sizeof(float)) return MP_ERR_WORKSPACE;
+    p.x = x; p.dz = dz; p.slabs = reinterpret_cast<float*>(workspace);
+    hipStream_t s = as_stream(stream);
+    dim3 grid(((p.Cout + 31) / 32) * p.ci_tiles, p.splits), block(256);
+#define MP_WGRAD_LAUNCH(KS_, S_)                                                                                        \
+    do {                                                                                                                \
+        auto kern = conv_wgrad_kernel<KS_, S_>;                                                                         \
+        static bool attr = false;                                                                                       \
+        if (!attr) {                                                                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            (void)hipGetLastError();                                                                                    \
+            attr = true;                                                                                                \
+        }                                                                                                               \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, p);                                                               \
+    } while (0)
+    if (desc->kh == 3 && desc->stride == 1) MP_WGRAD_LAUNCH(3, 1);
+    else if (desc->kh == 3 && desc->stride == 2) MP_WGRAD_LAUNCH(3, 2);
+    else if (desc->kh == 1 && desc->stride == 1) MP_WGRAD_LAUNCH(1, 1);
+    else MP_WGRAD_LAUNCH(1, 2);
+#undef MP_WGRAD_LAUNCH
+    rc = check_launch();
+    if (rc != MP_OK) return rc;
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p.slabs, dw, count, p.splits, accumulate ? 1 : 0);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -397,6 +397,25 @@ struct FuseSumParams {
     int n_planes, h, w, relu;
 };
 
+__global__ __launch_bounds__(256) void fuse_sum_scalar_kernel(FuseSumParams p) {
+    const size_t total = (size_t)p.n_planes * p.h * p.w;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % p.w);
+        const size_t r = i / p.w;
+        const int y = (int)(r % p.h);
+        const size_t plane = r / p.h;
+        float v = p.base[i];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (p.sh[k] < 0) continue;
+            const int sh = p.sh[k];
+            v += p.t[k][(plane * (p.h >> sh) + (y >> sh)) * (p.w >> sh) + (x >> sh)];
+        }
+        if (p.relu) v = fmaxf(v, 0.f);
+        p.out[i] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseSumParams p) {
     const int wq = p.w >> 2;
     const size_t total = (size_t)p.n_planes * p.h * wq;
@@ -568,7 +587,6 @@ int mp_fuse_upsample_sum(const float* base, const float* t1, int s1, const float
                          float* out, int n, int c, int h, int w, int relu, mp_stream_t stream) {
     if (!base || !t1 || !out) return MP_ERR_NULL;
     if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return MP_ERR_SHAPE;
-    if (w & 3) return MP_ERR_UNSUPPORTED;
     FuseSumParams p{};
     p.base = base; p.out = out; p.n_planes = n * c; p.h = h; p.w = w; p.relu = relu ? 1 : 0;
     const float* ts[3] = {t1, t2, t3};
@@ -581,10 +599,12 @@ int mp_fuse_upsample_sum(const float* base, const float* t1, int s1, const float
         if (sh < 0 || (h % ss[k]) || (w % ss[k])) return MP_ERR_UNSUPPORTED;
         p.sh[k] = sh;
     }
-    const size_t total = (size_t)n * c * h * (w >> 2);
+    const bool vec = (w & 3) == 0;
+    const size_t total = vec ? (size_t)n * c * h * (w >> 2) : (size_t)n * c * h * w;
     size_t blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(fuse_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p);
+    if (vec) hipLaunchKernelGGL(fuse_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p);
+    else hipLaunchKernelGGL(fuse_sum_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p);
     return check_launch();
 }
 

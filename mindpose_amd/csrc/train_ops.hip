@@ -1,0 +1,294 @@
+// Training-side HBM-bound kernels (gfx950): BatchNorm2d in training mode (batch statistics, forward and
+// backward), the backward of the exchange-unit sum, and the AdamWeightDecay update.  All reductions are
+// two-stage with a fixed partition and a fixed combine order, so results are bit-reproducible run to run.
+#include "common.h"
+
+#include <math.h>
+
+namespace mp {
+
+constexpr int kBnSplit = 32;  // per-channel partial reductions (fixed: determinism)
+
+__device__ __forceinline__ double block_sum_256(double v, double* sm) {
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    const double r = sm[0];
+    __syncthreads();
+    return r;
+}
+
+// stage 1: grid (C, kBnSplit); block (c, s) reduces images n = s, s + kBnSplit, ... of channel c.
+// out: part[(c * kBnSplit + s) * 2 + {0,1}] = (sum a, sum a*b) in fp64, where
+//   forward  a = z,            b = z            -> sum z, sum z^2
+//   backward a = g (masked dy), b = xhat         -> sum g, sum g*xhat
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ a_in, const float* __restrict__ z,
+                                                        const float* __restrict__ y, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, double* __restrict__ part,
+                                                        int n, int c, int hw, int relu) {
+    const int ch = blockIdx.x, sp = blockIdx.y;
+    double s0 = 0.0, s1 = 0.0;
+    const float mu = BWD ? mean[ch] : 0.f, is = BWD ? invstd[ch] : 0.f;
+    for (int img = sp; img < n; img += kBnSplit) {
+        const size_t base = ((size_t)img * c + ch) * hw;
+        float f0 = 0.f, f1 = 0.f;  // fp32 per-thread partial over <= hw/256 elements, then fp64
+        for (int i = threadIdx.x; i < hw; i += 256) {
+            if (BWD) {
+                float g = a_in[base + i];
+                if (relu && !(y[base + i] > 0.f)) g = 0.f;
+                const float xh = (z[base + i] - mu) * is;
+                f0 += g;
+                f1 += g * xh;
+            } else {
+                const float v = z[base + i];
+                f0 += v;
+                f1 += v * v;
+            }
+        }
+        s0 += (double)f0;
+        s1 += (double)f1;
+    }
+    __shared__ double sm[256];
+    s0 = block_sum_256(s0, sm);
+    s1 = block_sum_256(s1, sm);
+    if (threadIdx.x == 0) {
+        part[((size_t)ch * kBnSplit + sp) * 2 + 0] = s0;
+        part[((size_t)ch * kBnSplit + sp) * 2 + 1] = s1;
+    }
+}
+
+// stage 2 (forward): per channel mean / biased variance -> scale/shift, saved stats, moving-average update.
+// mindspore.nn.BatchNorm2d(momentum=0.9): moving = 0.9 * moving + 0.1 * batch; the moving variance takes the
+// UNBIASED batch variance (cuDNN / PyTorch convention) [MS-knowledge, unverifiable here - affects only the
+// moving statistics, never the training-mode output or any gradient].
+__global__ void bn_finalize_fwd_kernel(const double* __restrict__ part, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float* __restrict__ save_mean,
+                                       float* __restrict__ save_invstd, float* __restrict__ scale,
+                                       float* __restrict__ shift, float* __restrict__ moving_mean,
+                                       float* __restrict__ moving_var, int c, double count, float eps, float momentum) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int sp = 0; sp < kBnSplit; ++sp) {
+        s0 += part[((size_t)ch * kBnSplit + sp) * 2 + 0];
+        s1 += part[((size_t)ch * kBnSplit + sp) * 2 + 1];
+    }
+    const double mean = s0 / count;
+    double var = s1 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    save_mean[ch] = (float)mean;
+    save_invstd[ch] = invstd;
+    const float sc = gamma[ch] * invstd;
+    scale[ch] = sc;
+    shift[ch] = beta[ch] - (float)mean * sc;
+    if (moving_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        moving_mean[ch] = momentum * moving_mean[ch] + (1.f - momentum) * (float)mean;
+        moving_var[ch] = momentum * moving_var[ch] + (1.f - momentum) * (float)unbiased;
+    }
+}
+
+// y = act(z * scale[c] + shift[c] (+ res)) - block per (n, c) plane, 16 B per lane when hw % 4 == 0
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ res,
+                                                       float* __restrict__ y, int c, int hw, int relu) {
+    const size_t plane = blockIdx.x;
+    const int ch = (int)(plane % c);
+    const float sc = scale[ch], sh = shift[ch];
+    const size_t base = plane * hw;
+    if ((hw & 3) == 0) {
+        for (int q = threadIdx.x; q < (hw >> 2); q += 256) {
+            float4 v = reinterpret_cast<const float4*>(z + base)[q];
+            v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+            if (res) { const float4 r = reinterpret_cast<const float4*>(res + base)[q]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            reinterpret_cast<float4*>(y + base)[q] = v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < hw; i += 256) {
+            float v = z[base + i] * sc + sh;
+            if (res) v += res[base + i];
+            if (relu) v = fmaxf(v, 0.f);
+            y[base + i] = v;
+        }
+    }
+}
+
+// stage 2 (backward): dgamma = sum g*xhat, dbeta = sum g
+__global__ void bn_finalize_bwd_kernel(const double* __restrict__ part, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int c) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int sp = 0; sp < kBnSplit; ++sp) {
+        s0 += part[((size_t)ch * kBnSplit + sp) * 2 + 0];
+        s1 += part[((size_t)ch * kBnSplit + sp) * 2 + 1];
+    }
+    dbeta[ch] = (float)s0;
+    dgamma[ch] = (float)s1;
+}
+
+// dz = gamma*invstd * (g - dbeta/M - xhat*dgamma/M), dres = g  (g = dy masked by the ReLU of the forward output)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                           const float* __restrict__ y, const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                           float* __restrict__ dz, float* __restrict__ dres, int c, int hw,
+                                                           int relu, float inv_count) {
+    const size_t plane = blockIdx.x;
+    const int ch = (int)(plane % c);
+    const float mu = mean[ch], is = invstd[ch];
+    const float k = gamma[ch] * is, mb = dbeta[ch] * inv_count, mg = dgamma[ch] * inv_count;
+    const size_t base = plane * hw;
+    for (int i = threadIdx.x; i < hw; i += 256) {
+        float g = dy[base + i];
+        if (relu && !(y[base + i] > 0.f)) g = 0.f;
+        const float xh = (z[base + i] - mu) * is;
+        dz[base + i] = k * (g - mb - xh * mg);
+        if (dres) dres[base + i] = g;
+    }
+}
+
+// backward of out = act(base + sum_k up_{s_k}(t_k)):  g = dy * (out > 0);  dbase = g;  dt_k = s_k x s_k block sums of g
+__global__ __launch_bounds__(256) void fuse_sum_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ out,
+                                                           float* __restrict__ dbase, float* __restrict__ dt, int planes,
+                                                           int h, int w, int sh, int relu) {
+    // one thread per element of the LOW-resolution grid of this term (sh = log2 scale); sh == 0 covers dbase-like terms
+    const int lh = h >> sh, lw = w >> sh, s = 1 << sh;
+    const size_t total = (size_t)planes * lh * lw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int lx = (int)(i % lw);
+        const size_t r = i / lw;
+        const int ly = (int)(r % lh);
+        const size_t plane = r / lh;
+        const size_t o = (plane * h + (size_t)ly * s) * w + (size_t)lx * s;
+        float acc = 0.f;
+        for (int a = 0; a < s; ++a)
+            for (int b = 0; b < s; ++b) {
+                float g = dy[o + (size_t)a * w + b];
+                if (relu && !(out[o + (size_t)a * w + b] > 0.f)) g = 0.f;
+                acc += g;
+                if (dbase && sh == 0) dbase[o] = g;
+            }
+        if (dt) dt[i] = acc;
+    }
+}
+
+// mindspore.nn.AdamWeightDecay: Adam WITHOUT bias correction, decoupled weight decay, eps added to sqrt(v)
+// (mindpose/optim/optim_factory.py:69-72 selects it for "adamw")
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
+                                                    float wd) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        float upd = mi / (sqrtf(vi) + eps);
+        upd += wd * p[i];
+        p[i] = p[i] - lr * upd;
+    }
+}
+
+static int log2_exact_t(int v) {
+    for (int i = 0; i < 16; ++i)
+        if ((1 << i) == v) return i;
+    return -1;
+}
+
+}  // namespace mp
+
+using namespace mp;
+
+extern "C" {
+
+size_t mp_bn_workspace_bytes(int c) {
+    if (c <= 0) return 0;
+    // fp64 partials [C][kBnSplit][2] + scale/shift (fwd) or nothing extra (bwd)
+    return (size_t)c * kBnSplit * 2 * sizeof(double) + (size_t)c * 2 * sizeof(float) + 256;
+}
+
+int mp_bn_train_fwd(const float* z, const float* gamma, const float* beta, const float* res, float* y, float* save_mean,
+                    float* save_invstd, float* moving_mean, float* moving_var, int n, int c, int hw, float eps,
+                    float momentum, int relu, void* workspace, size_t workspace_bytes, mp_stream_t stream) {
+    if (!z || !gamma || !beta || !y || !save_mean || !save_invstd) return MP_ERR_NULL;
+    if ((moving_mean == nullptr) != (moving_var == nullptr)) return MP_ERR_NULL;
+    if (n <= 0 || c <= 0 || hw <= 0) return MP_ERR_SHAPE;
+    if (!workspace || workspace_bytes < mp_bn_workspace_bytes(c)) return MP_ERR_WORKSPACE;
+    double* part = reinterpret_cast<double*>(workspace);
+    float* scale = reinterpret_cast<float*>(part + (size_t)c * kBnSplit * 2);
+    float* shift = scale + c;
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(bn_reduce_kernel<false>, dim3(c, kBnSplit), dim3(256), 0, s, nullptr, z, nullptr, nullptr, nullptr, part,
+                       n, c, hw, 0);
+    int rc = check_launch();
+    if (rc != MP_OK) return rc;
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((c + 63) / 64), dim3(64), 0, s, part, gamma, beta, save_mean, save_invstd,
+                       scale, shift, moving_mean, moving_var, c, (double)n * hw, eps, momentum);
+    rc = check_launch();
+    if (rc != MP_OK) return rc;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(n * c), dim3(256), 0, s, z, scale, shift, res, y, c, hw, relu ? 1 : 0);
+    return check_launch();
+}
+
+int mp_bn_train_bwd(const float* dy, const float* z, const float* y, const float* gamma, const float* save_mean,
+                    const float* save_invstd, float* dz, float* dres, float* dgamma, float* dbeta, int n, int c, int hw,
+                    int relu, void* workspace, size_t workspace_bytes, mp_stream_t stream) {
+    if (!dy || !z || !gamma || !save_mean || !save_invstd || !dz || !dgamma || !dbeta) return MP_ERR_NULL;
+    if (relu && !y) return MP_ERR_NULL;
+    if (n <= 0 || c <= 0 || hw <= 0) return MP_ERR_SHAPE;
+    if (!workspace || workspace_bytes < mp_bn_workspace_bytes(c)) return MP_ERR_WORKSPACE;
+    double* part = reinterpret_cast<double*>(workspace);
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(bn_reduce_kernel<true>, dim3(c, kBnSplit), dim3(256), 0, s, dy, z, y, save_mean, save_invstd, part, n, c,
+                       hw, relu ? 1 : 0);
+    int rc = check_launch();
+    if (rc != MP_OK) return rc;
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((c + 63) / 64), dim3(64), 0, s, part, dgamma, dbeta, c);
+    rc = check_launch();
+    if (rc != MP_OK) return rc;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(n * c), dim3(256), 0, s, dy, z, y, gamma, save_mean, save_invstd, dgamma, dbeta,
+                       dz, dres, c, hw, relu ? 1 : 0, (float)(1.0 / ((double)n * hw)));
+    return check_launch();
+}
+
+int mp_fuse_upsample_sum_bwd(const float* dy, const float* out, float* dbase, float* dt1, int s1, float* dt2, int s2,
+                             float* dt3, int s3, int n, int c, int h, int w, int relu, mp_stream_t stream) {
+    if (!dy || (relu && !out)) return MP_ERR_NULL;
+    if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return MP_ERR_SHAPE;
+    hipStream_t s = as_stream(stream);
+    float* dts[4] = {dbase, dt1, dt2, dt3};
+    const int ss[4] = {1, s1, s2, s3};
+    for (int k = 0; k < 4; ++k) {
+        if (!dts[k]) continue;
+        const int sh = log2_exact_t(ss[k]);
+        if (sh < 0 || (h % ss[k]) || (w % ss[k])) return MP_ERR_UNSUPPORTED;
+        const size_t total = (size_t)n * c * (h >> sh) * (w >> sh);
+        size_t blocks = (total + 255) / 256;
+        if (blocks > 256 * 32) blocks = 256 * 32;
+        hipLaunchKernelGGL(fuse_sum_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dy, out, nullptr, dts[k], n * c, h, w, sh,
+                           relu ? 1 : 0);
+        int rc = check_launch();
+        if (rc != MP_OK) return rc;
+    }
+    return MP_OK;
+}
+
+int mp_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t count, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, mp_stream_t stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq) return MP_ERR_NULL;
+    if (count == 0) return MP_OK;
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq,
+                       count, lr, beta1, beta2, eps, weight_decay);
+    return check_launch();
+}
+
+}  // extern "C"

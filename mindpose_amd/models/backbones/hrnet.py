@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from ...register import register
+from .. import train_ops as T
 from ..layers import BatchNorm2d, Conv2d, Plan
 from .backbone import Backbone
 from .utils import load_pretrained
@@ -38,6 +39,13 @@ class BasicBlock(nn.Module):
         out = plan.conv(x, self.conv1, self.bn1, relu=True)
         return plan.conv(out, self.conv2, self.bn2, relu=True, res1=identity)
 
+    def train_forward(self, x: torch.Tensor) -> torch.Tensor:
+        identity = x
+        if self.down_sample is not None:
+            identity = T.conv_bn_act(x, self.down_sample[0], self.down_sample[1], relu=False)
+        out = T.conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        return T.conv_bn_act(out, self.conv2, self.bn2, relu=True, res=identity)
+
 
 class Bottleneck(nn.Module):
     """1x1 -> 3x3 (stride) -> 1x1, + identity / down_sample - hrnet.py:86-146 (3-4 launches)."""
@@ -63,6 +71,14 @@ class Bottleneck(nn.Module):
         out = plan.conv(out, self.conv2, self.bn2, relu=True)
         return plan.conv(out, self.conv3, self.bn3, relu=True, res1=identity)
 
+    def train_forward(self, x: torch.Tensor) -> torch.Tensor:
+        identity = x
+        if self.down_sample is not None:
+            identity = T.conv_bn_act(x, self.down_sample[0], self.down_sample[1], relu=False)
+        out = T.conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        out = T.conv_bn_act(out, self.conv2, self.bn2, relu=True)
+        return T.conv_bn_act(out, self.conv3, self.bn3, relu=True, res=identity)
+
 
 def _conv_bn(cin: int, cout: int, k: int, stride: int = 1, padding: int = 0, relu: bool = False) -> nn.Sequential:
     """SequentialCell(conv, bn[, relu]) of the reference; the ReLU is a marker only (fused in the epilogue)."""
@@ -74,6 +90,10 @@ def _conv_bn(cin: int, cout: int, k: int, stride: int = 1, padding: int = 0, rel
 
 def _emit_conv_bn(plan: Plan, seq: nn.Sequential, x: torch.Tensor, **kw) -> torch.Tensor:
     return plan.conv(x, seq[0], seq[1], relu=kw.pop("relu", len(seq) > 2), **kw)
+
+
+def _train_conv_bn(seq: nn.Sequential, x: torch.Tensor, relu=None) -> torch.Tensor:
+    return T.conv_bn_act(x, seq[0], seq[1], relu=(len(seq) > 2) if relu is None else relu)
 
 
 class HRModule(nn.Module):
@@ -185,6 +205,35 @@ class HRModule(nn.Module):
             outs.append(ybuf)
         return outs
 
+    def train_forward(self, xs: List[torch.Tensor]) -> List[torch.Tensor]:
+        """Training form of hrnet.py:318-344: same term order; one exchange-unit sum kernel per row."""
+        xs = list(xs)
+        for i in range(self.num_branches):
+            for blk in self.branches[i]:
+                xs[i] = blk.train_forward(xs[i])
+        if self.num_branches == 1:
+            return xs
+        outs = []
+        for i in range(len(self.fuse_layers)):
+            terms = []
+            for j in range(self.num_branches):
+                if j == i:
+                    terms.append((xs[j], 1))
+                elif j > i:
+                    seq = self.fuse_layers[i][j]
+                    up = xs[i].shape[2] // xs[j].shape[2]
+                    if xs[j].shape[2] * up != xs[i].shape[2] or xs[j].shape[3] * up != xs[i].shape[3]:
+                        raise ValueError("HRNet fuse needs an integer nearest-upsample factor")
+                    terms.append((_train_conv_bn(seq, xs[j], relu=False), up))
+                else:
+                    chain = self.fuse_layers[i][j]
+                    t = xs[j]
+                    for k in range(len(chain)):
+                        t = _train_conv_bn(chain[k], t)
+                    terms.append((t, 1))
+            outs.append(T.fuse_sum(terms[0][0], terms[1:]))
+        return outs
+
 
 @register("backbone")
 class HRNet(Backbone):
@@ -279,6 +328,33 @@ class HRNet(Backbone):
                     xs.append(t)
             for mod in getattr(self, f"stage{idx}"):
                 xs = mod.emit(plan, xs)
+            ys = xs
+        return ys[0]
+
+    def train_forward(self, x: torch.Tensor) -> torch.Tensor:
+        """Training form of ``forward_feature`` hrnet.py:559-605 (batch-statistics BatchNorm, autograd)."""
+        x = T.conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        x = T.conv_bn_act(x, self.conv2, self.bn2, relu=True)
+        for blk in self.layer1:
+            x = blk.train_forward(x)
+        ys = [x]
+        for idx in (2, 3, 4):
+            trans = getattr(self, f"transition{idx - 1}")
+            flags = getattr(self, f"transition{idx - 1}_flags")
+            cfg = getattr(self, f"stage{idx}_cfg")
+            xs = []
+            for i in range(cfg["num_branches"]):
+                if not flags[i]:
+                    xs.append(ys[i])
+                elif i < len(ys):
+                    xs.append(_train_conv_bn(trans[i], ys[i]))
+                else:
+                    t = ys[-1]
+                    for seq in trans[i]:
+                        t = _train_conv_bn(seq, t)
+                    xs.append(t)
+            for mod in getattr(self, f"stage{idx}"):
+                xs = mod.train_forward(xs)
             ys = xs
         return ys[0]
 

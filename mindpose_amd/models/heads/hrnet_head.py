@@ -18,3 +18,7 @@ class HRNetHead(Head):
 
     def emit(self, plan: Plan, x: torch.Tensor) -> torch.Tensor:
         return plan.conv(x, self.head)
+
+    def train_forward(self, x: torch.Tensor) -> torch.Tensor:
+        from .. import train_ops as T
+        return T.conv_bn_act(x, self.head, None, relu=False)

@@ -223,6 +223,15 @@ class PlannedModule(nn.Module):
     def __init__(self) -> None:
         super().__init__()
         self._plans: Dict[Tuple, Plan] = {}
+        self.training = False  # like mindspore.nn.Cell: inference mode until .train() / set_train(True)
+
+    def set_train(self, mode: bool = True):
+        """mindspore.nn.Cell.set_train alias."""
+        return self.train(mode)
+
+    def train_forward(self, x: torch.Tensor) -> torch.Tensor:
+        """Training-mode forward (batch-statistics BatchNorm, autograd through the HIP backward kernels)."""
+        raise NotImplementedError("this module has no training path yet")
 
     def emit(self, plan: Plan, x: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError("Child class must implement this method.")
@@ -258,6 +267,9 @@ class PlannedModule(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         x = _lib.require_cuda_f32(x, "input")
+        if self.training:
+            self._plans.clear()  # parameters are about to change: packed weights of recorded plans go stale
+            return self.train_forward(x)
         plan = self.get_plan(x.shape, x.device)
         if x.data_ptr() != plan.input.data_ptr():
             plan.input.copy_(x)

@@ -28,6 +28,11 @@ class Net(PlannedModule):
             x = self.neck.emit(plan, x)
         return self.head.emit(plan, x)
 
+    def train_forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.has_neck:
+            raise NotImplementedError("no concrete neck exists in the reference")
+        return self.head.train_forward(self.backbone.train_forward(x))
+
 
 class EvalNet(nn.Module):
     """net + decoder (networks.py:47-76): returns ``(result, raw)`` when ``output_raw``."""

@@ -1,0 +1,206 @@
+"""Training-mode building blocks: torch.autograd Functions whose forward AND backward are HIP kernels behind the
+C ABI (conv forward / data-gradient on the direct MFMA conv, weight-gradient MFMA kernel, BatchNorm2d with batch
+statistics, exchange-unit sum).  torch.autograd only records the graph and owns the tensors.
+
+Reference semantics: the cells of mindpose/models/backbones/hrnet.py run by mindspore.Model.train
+(tools/train.py:176-233); amp aside, everything here computes in fp32.
+"""
+import ctypes
+from typing import Optional
+
+import torch
+
+from .. import _lib
+from .layers import BN_EPS
+
+BN_MOMENTUM = 0.9  # mindspore.nn.BatchNorm2d(momentum=0.9): moving = 0.9*moving + 0.1*batch [MS-knowledge]
+
+_const_cache = {}
+
+
+def _ones_zeros(c: int, device):
+    key = (c, str(device))
+    if key not in _const_cache:
+        _const_cache[key] = (torch.ones(c, device=device), torch.zeros(c, device=device))
+    return _const_cache[key]
+
+
+def _desc(n, cin, h, w, cout, k, stride, pad_t, pad_l, conv_h, conv_w, out_h, out_w, out_mul=1, out_rep=1, off_y=0,
+          off_x=0):
+    return _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=k, kw=k, stride=stride, pad_top=pad_t, pad_left=pad_l,
+                         conv_h=conv_h, conv_w=conv_w, out_h=out_h, out_w=out_w, out_mul=out_mul, out_rep=out_rep,
+                         out_off_y=off_y, out_off_x=off_x, relu=0, tap_dilation_unused=0)
+
+
+def _pack(lib, w, cout, cin, k, mode, py=0, px=0):
+    nbytes = lib.mp_conv_packed_weight_bytes(cout, cin, k, k)
+    packed = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
+    _lib.check(lib.mp_conv_pack_weight(_lib.ptr(w), _lib.ptr(packed), cout, cin, k, k, mode, py, px, _lib.stream()),
+               "mp_conv_pack_weight")
+    return packed
+
+
+class Conv2dFn(torch.autograd.Function):
+    """z = conv2d(x, weight) (+ bias); k in {1, 3}, stride in {1, 2}, padding = k // 2."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding):
+        lib = _lib.load()
+        x = _lib.require_cuda_f32(x, "x")
+        w = weight.detach().contiguous()
+        n, cin, h, wd = x.shape
+        cout, _, k, _ = w.shape
+        if padding != k // 2 or k not in (1, 3) or stride not in (1, 2):
+            raise NotImplementedError("training path covers k in {1,3}, stride in {1,2}, padding = k//2")
+        ho, wo = (h + 2 * padding - k) // stride + 1, (wd + 2 * padding - k) // stride + 1
+        ones, zeros = _ones_zeros(cout, x.device)
+        shift = bias.detach().contiguous() if bias is not None else zeros
+        z = torch.empty(n, cout, ho, wo, device=x.device, dtype=torch.float32)
+        d = _desc(n, cin, h, wd, cout, k, stride, padding, padding, ho, wo, ho, wo)
+        packed = _pack(lib, w, cout, cin, k, 0)
+        _lib.check(lib.mp_conv2d_fwd(ctypes.byref(d), _lib.ptr(x), _lib.ptr(packed), _lib.ptr(ones), _lib.ptr(shift), None,
+                                     None, _lib.ptr(z), _lib.stream()), "mp_conv2d_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.stride, ctx.padding, ctx.has_bias = stride, padding, bias is not None
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        dz = dz.contiguous()
+        n, cin, h, wd = x.shape
+        cout, _, k, _ = w.shape
+        s, pad = ctx.stride, ctx.padding
+        ho, wo = dz.shape[2], dz.shape[3]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            ones, zeros = _ones_zeros(cin, x.device)
+            if s == 1:
+                dx = torch.empty_like(x)
+                d = _desc(n, cout, ho, wo, cin, k, 1, k - 1 - pad, k - 1 - pad, h, wd, h, wd)
+                packed = _pack(lib, w, cin, cout, k, 2)
+                _lib.check(lib.mp_conv2d_fwd(ctypes.byref(d), _lib.ptr(dz), _lib.ptr(packed), _lib.ptr(ones), _lib.ptr(zeros),
+                                             None, None, _lib.ptr(dx), _lib.stream()), "conv dgrad")
+            else:
+                if h != 2 * ho or wd != 2 * wo:
+                    raise NotImplementedError("stride-2 data gradient needs even input extents")
+                if k == 3:
+                    dx = torch.empty_like(x)
+                    for py in (0, 1):
+                        for px in (0, 1):
+                            d = _desc(n, cout, ho, wo, cin, 2, 1, 0, 0, ho, wo, h, wd, out_mul=2, off_y=py, off_x=px)
+                            packed = _pack(lib, w, cin, cout, 2, 3, py, px)
+                            _lib.check(lib.mp_conv2d_fwd(ctypes.byref(d), _lib.ptr(dz), _lib.ptr(packed), _lib.ptr(ones),
+                                                         _lib.ptr(zeros), None, None, _lib.ptr(dx), _lib.stream()),
+                                       "conv dgrad phase")
+                else:  # 1x1 stride 2: only even positions receive gradient
+                    dx = torch.zeros_like(x)
+                    d = _desc(n, cout, ho, wo, cin, 1, 1, 0, 0, ho, wo, h, wd, out_mul=2)
+                    packed = _pack(lib, w, cin, cout, 1, 2)
+                    _lib.check(lib.mp_conv2d_fwd(ctypes.byref(d), _lib.ptr(dz), _lib.ptr(packed), _lib.ptr(ones),
+                                                 _lib.ptr(zeros), None, None, _lib.ptr(dx), _lib.stream()), "conv dgrad 1x1s2")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            d = _desc(n, cin, h, wd, cout, k, s, pad, pad, ho, wo, ho, wo)
+            ws_bytes = lib.mp_conv_wgrad_workspace_bytes(ctypes.byref(d))
+            ws = torch.empty(max(ws_bytes // 4, 1), device=x.device, dtype=torch.float32)
+            _lib.check(lib.mp_conv_wgrad(ctypes.byref(d), _lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), 0, _lib.ptr(ws), ws_bytes,
+                                         _lib.stream()), "mp_conv_wgrad")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dz.sum(dim=(0, 2, 3))  # [Cout] reduction of the head conv's bias gradient (17 values)
+        return dx, dw, db, None, None
+
+
+class BatchNormActFn(torch.autograd.Function):
+    """y = act(BN_train(z) (+ res)); updates the moving statistics in place (mindspore.nn.BatchNorm2d training)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, res, moving_mean, moving_var, relu):
+        lib = _lib.load()
+        z = _lib.require_cuda_f32(z, "z")
+        n, c, h, w = z.shape
+        y = torch.empty_like(z)
+        mean = torch.empty(c, device=z.device)
+        invstd = torch.empty(c, device=z.device)
+        ws_bytes = lib.mp_bn_workspace_bytes(c)
+        ws = torch.empty(ws_bytes // 4 + 1, device=z.device, dtype=torch.float32)
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        r = res.contiguous() if res is not None else None
+        _lib.check(lib.mp_bn_train_fwd(_lib.ptr(z), _lib.ptr(g), _lib.ptr(b), _lib.ptr(r), _lib.ptr(y), _lib.ptr(mean),
+                                       _lib.ptr(invstd), _lib.ptr(moving_mean), _lib.ptr(moving_var), n, c, h * w, BN_EPS,
+                                       BN_MOMENTUM, int(relu), _lib.ptr(ws), ws_bytes, _lib.stream()), "mp_bn_train_fwd")
+        ctx.save_for_backward(z, y, g, mean, invstd)
+        ctx.relu, ctx.has_res = relu, res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        z, y, g, mean, invstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, c, h, w = z.shape
+        dz = torch.empty_like(z)
+        dres = torch.empty_like(z) if ctx.has_res else None
+        dgamma = torch.empty(c, device=z.device)
+        dbeta = torch.empty(c, device=z.device)
+        ws_bytes = lib.mp_bn_workspace_bytes(c)
+        ws = torch.empty(ws_bytes // 4 + 1, device=z.device, dtype=torch.float32)
+        _lib.check(lib.mp_bn_train_bwd(_lib.ptr(dy), _lib.ptr(z), _lib.ptr(y), _lib.ptr(g), _lib.ptr(mean), _lib.ptr(invstd),
+                                       _lib.ptr(dz), _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta), n, c, h * w,
+                                       int(ctx.relu), _lib.ptr(ws), ws_bytes, _lib.stream()), "mp_bn_train_bwd")
+        return dz, dgamma, dbeta, dres, None, None, None
+
+
+class FuseSumFn(torch.autograd.Function):
+    """out = relu(((base + up(t1)) + up(t2)) + up(t3)); terms at scale 1 are plain adds (hrnet.py:327-339)."""
+
+    @staticmethod
+    def forward(ctx, base, scales, *terms):
+        lib = _lib.load()
+        n, c, h, w = base.shape
+        base = base.contiguous()
+        ts = [t.contiguous() for t in terms]
+        out = torch.empty_like(base)
+        args = []
+        for i in range(3):
+            if i < len(ts):
+                args += [_lib.ptr(ts[i]), int(scales[i])]
+            else:
+                args += [None, 1]
+        _lib.check(lib.mp_fuse_upsample_sum(_lib.ptr(base), *args, _lib.ptr(out), n, c, h, w, 1, _lib.stream()),
+                   "mp_fuse_upsample_sum")
+        ctx.save_for_backward(out)
+        ctx.scales = [int(s) for s in scales[:len(ts)]]
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (out,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, c, h, w = out.shape
+        dbase = torch.empty_like(out)
+        dts = [torch.empty(n, c, h // s, w // s, device=out.device) for s in ctx.scales]
+        args = []
+        for i in range(3):
+            if i < len(dts):
+                args += [_lib.ptr(dts[i]), ctx.scales[i]]
+            else:
+                args += [None, 1]
+        _lib.check(lib.mp_fuse_upsample_sum_bwd(_lib.ptr(dy), _lib.ptr(out), _lib.ptr(dbase), *args, n, c, h, w, 1,
+                                                _lib.stream()), "mp_fuse_upsample_sum_bwd")
+        return (dbase, None, *dts)
+
+
+def conv_bn_act(x, conv, bn, relu: bool, res: Optional[torch.Tensor] = None):
+    """One conv + BatchNorm(train) (+ residual) (+ ReLU) group of the reference's cells."""
+    z = Conv2dFn.apply(x, conv.weight, conv.bias, conv.stride, conv.padding)
+    if bn is None:
+        return z
+    return BatchNormActFn.apply(z, bn.gamma, bn.beta, res, bn.moving_mean, bn.moving_variance, relu)
+
+
+def fuse_sum(base, terms):
+    """terms = [(tensor, integer scale), ...] (1-3 entries)."""
+    return FuseSumFn.apply(base, [s for _, s in terms], *[t for t, _ in terms])

@@ -41,18 +41,22 @@ RESNET_LAYERS = {"resnet50": [3, 4, 6, 3], "resnet101": [3, 4, 23, 3], "resnet15
 
 
 class _P:
-    """Prefix view over the flat parameter dict."""
+    """Prefix view over the flat parameter dict.  ``train=True`` switches BatchNorm to batch statistics (moving
+    statistics updated in place with momentum 0.9, mindspore.nn.BatchNorm2d training) and keeps the autograd graph
+    of the parameter tensors (used to check the HIP backward kernels)."""
 
-    def __init__(self, params, prefix=""):
-        self.params, self.prefix = params, prefix
+    def __init__(self, params, prefix="", train=False):
+        self.params, self.prefix, self.train = params, prefix, train
 
     def sub(self, name):
-        return _P(self.params, f"{self.prefix}{name}.")
+        return _P(self.params, f"{self.prefix}{name}.", self.train)
 
     def __getitem__(self, name):
         t = self.params[self.prefix + name]
         if not torch.is_tensor(t):
             t = torch.as_tensor(t)
+        if self.train:
+            return t
         return t.detach().to(torch.float32).cpu()
 
     def has(self, name):
@@ -65,6 +69,9 @@ def _conv(p, x, stride=1, padding=0):
 
 
 def _bn(p, x):
+    if p.train:  # torch momentum 0.1 == MindSpore momentum 0.9 (weight of the OLD moving value)
+        return F.batch_norm(x, p["moving_mean"], p["moving_variance"], p["gamma"], p["beta"],
+                            training=True, momentum=0.1, eps=BN_EPS)
     return F.batch_norm(x, p["moving_mean"], p["moving_variance"], p["gamma"], p["beta"],
                         training=False, eps=BN_EPS)
 
@@ -118,11 +125,11 @@ def _hr_module(p, xs, num_branches, num_blocks, multi_scale_output):
     return outs
 
 
-def hrnet_forward(params, x, name="hrnet_w32", prefix=""):
+def hrnet_forward(params, x, name="hrnet_w32", prefix="", train=False):
     """HRNet.forward_feature hrnet.py:559-605."""
     cfg = HRNET_CFG[name]
-    p = _P(params, prefix)
-    x = torch.as_tensor(x, dtype=torch.float32)
+    p = _P(params, prefix, train)
+    x = torch.as_tensor(x) if train else torch.as_tensor(x, dtype=torch.float32)  # train: keep dtype (fp64 oracle runs)
     x = F.relu(_bn(p.sub("bn1"), _conv(p.sub("conv1"), x, 2, 1)))
     x = F.relu(_bn(p.sub("bn2"), _conv(p.sub("conv2"), x, 2, 1)))
     for b in range(cfg["stage1"]["num_blocks"][0]):
@@ -182,9 +189,9 @@ def resnet_forward(params, x, name="resnet50", prefix=""):
     return x
 
 
-def hrnet_head_forward(params, x, prefix=""):
+def hrnet_head_forward(params, x, prefix="", train=False):
     """HRNetHead.construct hrnet_head.py:47-49: 1x1 conv + bias."""
-    return _conv(_P(params, prefix).sub("head"), x)
+    return _conv(_P(params, prefix, train).sub("head"), x)
 
 
 def simple_baseline_head_forward(params, x, prefix="", num_deconv_layers=3):
@@ -196,6 +203,13 @@ def simple_baseline_head_forward(params, x, prefix="", num_deconv_layers=3):
         x = F.conv_transpose2d(x, w, None, stride=2, padding=1)
         x = F.relu(_bn(p.sub(f"deconv_layer.{3 * i + 1}"), x))
     return _conv(p.sub("final_layer"), x)
+
+
+def net_forward_train(params, x, backbone="hrnet_w32", head="hrnet_head"):
+    """Net.construct in training mode (HRNet + HRNetHead): batch-statistics BatchNorm, autograd graph kept.
+    ``params`` must hold torch tensors (leaf tensors with requires_grad for the trainable ones)."""
+    f = hrnet_forward(params, x, backbone, prefix="backbone.", train=True)
+    return hrnet_head_forward(params, f, prefix="head.", train=True)
 
 
 def net_forward(params, x, backbone="hrnet_w32", head="hrnet_head"):

@@ -1,0 +1,198 @@
+"""GPU parity of the training-side kernels (BatchNorm train fwd/bwd, conv data/weight gradients, exchange-unit sum
+backward, AdamWeightDecay) and of one full HRNet-W32 training step, against torch-CPU autograd over the oracle graph.
+fp32 everywhere; tolerances are relative to each tensor's scale."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import mindpose_amd as mp  # noqa: E402
+from mindpose_amd.models import train_ops as T  # noqa: E402
+from mindpose_amd.models.layers import BatchNorm2d, Conv2d  # noqa: E402
+from oracle import nets as onets  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def _rel(got, ref):
+    return float((got.cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-20))
+
+
+@pytest.mark.parametrize("shape,relu,res", [((4, 8, 16, 12), True, True), ((3, 32, 8, 6), True, False),
+                                            ((5, 5, 7, 3), False, True), ((64, 17, 4, 4), False, False)])
+def test_bn_train_fwd_bwd_vs_torch(shape, relu, res):
+    g = torch.Generator().manual_seed(sum(shape))
+    n, c, h, w = shape
+    z = torch.randn(shape, generator=g) * 2 + 0.5
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+    r = torch.randn(shape, generator=g) if res else None
+    dy = torch.randn(shape, generator=g)
+    mm, mv = torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) + 0.5
+    # torch reference
+    zt, gt, bt = z.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    rt = r.clone().requires_grad_() if res else None
+    rm, rv = mm.clone(), mv.clone()
+    y_ref = F.batch_norm(zt, rm, rv, gt, bt, training=True, momentum=0.1, eps=1e-5)
+    if res:
+        y_ref = y_ref + rt
+    if relu:
+        y_ref = F.relu(y_ref)
+    y_ref.backward(dy)
+    # HIP
+    zd, gd, bd = z.to(DEV).requires_grad_(), gamma.to(DEV).requires_grad_(), beta.to(DEV).requires_grad_()
+    rd = r.to(DEV).requires_grad_() if res else None
+    mmd, mvd = mm.to(DEV), mv.to(DEV)
+    y = T.BatchNormActFn.apply(zd, gd, bd, rd, mmd, mvd, relu)
+    y.backward(dy.to(DEV))
+    assert _rel(y.detach(), y_ref.detach()) < 1e-5
+    assert _rel(zd.grad, zt.grad) < 1e-4
+    assert _rel(gd.grad, gt.grad) < 1e-4 and _rel(bd.grad, bt.grad) < 1e-4
+    if res:
+        assert _rel(rd.grad, rt.grad) < 1e-6
+    assert _rel(mmd, rm) < 1e-5 and _rel(mvd, rv) < 1e-5  # moving statistics (unbiased variance convention)
+    # determinism
+    zd2 = z.to(DEV).requires_grad_()
+    y2 = T.BatchNormActFn.apply(zd2, gd.detach(), bd.detach(), rd.detach() if res else None, mm.to(DEV), mv.to(DEV), relu)
+    assert torch.equal(y2, y)
+
+
+CONV_TRAIN_CASES = [
+    # n, cin, cout, k, s, h, w, bias
+    (2, 32, 32, 3, 1, 16, 12, False),
+    (3, 64, 32, 1, 1, 8, 8, False),
+    (2, 32, 64, 3, 2, 16, 12, False),
+    (2, 16, 40, 1, 2, 8, 6, False),
+    (2, 3, 64, 3, 2, 32, 24, False),
+    (4, 32, 17, 1, 1, 16, 12, True),
+    (1, 5, 7, 3, 1, 9, 7, False),
+    (2, 256, 256, 3, 1, 8, 6, False),
+    (8, 32, 32, 3, 1, 64, 48, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_TRAIN_CASES, ids=[f"{c[1]}to{c[2]}_k{c[3]}s{c[4]}_{c[5]}x{c[6]}" for c in CONV_TRAIN_CASES])
+def test_conv_fwd_dgrad_wgrad_vs_torch(case):
+    n, cin, cout, k, s, h, w, bias = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    b = torch.randn(cout, generator=g) if bias else None
+    xr, wr = x.clone().requires_grad_(), wt.clone().requires_grad_()
+    br = b.clone().requires_grad_() if bias else None
+    ref = F.conv2d(xr, wr, br, stride=s, padding=k // 2)
+    dz = torch.randn(ref.shape, generator=g)
+    ref.backward(dz)
+    xd, wd = x.to(DEV).requires_grad_(), wt.to(DEV).requires_grad_()
+    bd = b.to(DEV).requires_grad_() if bias else None
+    z = T.Conv2dFn.apply(xd, wd, bd, s, k // 2)
+    z.backward(dz.to(DEV))
+    assert _rel(z.detach(), ref.detach()) < 2e-5
+    assert _rel(xd.grad, xr.grad) < 2e-5
+    assert _rel(wd.grad, wr.grad) < 5e-5
+    if bias:
+        assert _rel(bd.grad, br.grad) < 1e-5
+    # weight-gradient determinism (slab reduction, no atomics)
+    xd2, wd2 = x.to(DEV).requires_grad_(), wt.to(DEV).requires_grad_()
+    T.Conv2dFn.apply(xd2, wd2, None, s, k // 2).backward(dz.to(DEV))
+    assert torch.equal(wd2.grad, wd.grad)
+
+
+@pytest.mark.parametrize("scales", [[1], [1, 2], [2, 4, 8], [1, 1, 2]])
+def test_fuse_sum_fwd_bwd_vs_torch(scales):
+    g = torch.Generator().manual_seed(len(scales) * 7)
+    n, c, h, w = 2, 6, 16, 24
+    base = torch.randn(n, c, h, w, generator=g)
+    ts = [torch.randn(n, c, h // s, w // s, generator=g) for s in scales]
+    dy = torch.randn(n, c, h, w, generator=g)
+    br = base.clone().requires_grad_()
+    tr = [t.clone().requires_grad_() for t in ts]
+    acc = br
+    for t, s in zip(tr, scales):
+        acc = acc + (F.interpolate(t, size=(h, w), mode="nearest") if s > 1 else t)
+    ref = F.relu(acc)
+    ref.backward(dy)
+    bd = base.to(DEV).requires_grad_()
+    td = [t.to(DEV).requires_grad_() for t in ts]
+    out = T.fuse_sum(bd, list(zip(td, scales)))
+    out.backward(dy.to(DEV))
+    assert torch.equal(out.detach().cpu(), ref.detach())
+    assert _rel(bd.grad, br.grad) < 1e-6
+    for a, b_ in zip(td, tr):
+        assert _rel(a.grad, b_.grad) < 1e-5
+
+
+def test_adamw_no_bias_correction():
+    lib = mp._lib.load()
+    g = torch.Generator().manual_seed(1)
+    n = 100003
+    p, gr = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    m, v = torch.randn(n, generator=g) * 0.1, torch.rand(n, generator=g) * 0.01
+    lr, b1, b2, eps, wd = 1e-3, 0.9, 0.999, 1e-6, 0.05
+    # MindSpore keeps beta1/beta2/eps/lr as fp32 tensors, so (1 - beta) is formed in fp32
+    tb1, tb2, one = torch.tensor(b1), torch.tensor(b2), torch.tensor(1.0)
+    m_ref = tb1 * m + (one - tb1) * gr
+    v_ref = tb2 * v + (one - tb2) * gr * gr
+    p_ref = p - torch.tensor(lr) * (m_ref / (v_ref.sqrt() + torch.tensor(eps)) + torch.tensor(wd) * p)
+    pd, gd, md, vd = (t.to(DEV).contiguous() for t in (p, gr, m, v))
+    mp._lib.check(lib.mp_adamw_step(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, lr, b1, b2, eps, wd, None),
+                  "adamw")
+    assert _rel(pd, p_ref) < 1e-6 and _rel(md, m_ref) < 1e-6 and _rel(vd, v_ref) < 1e-6
+
+
+def test_hrnet_w32_training_step_vs_oracle_autograd():
+    """NetWithLoss in training mode: loss and EVERY parameter gradient of HRNet-W32 + head vs torch-CPU autograd of the
+    oracle graph (batch-statistics BatchNorm), plus the moving statistics after the step.
+
+    ~300 layers of ReLU + batch-statistics BatchNorm make a few deep gradients ill-conditioned (one ReLU mask flip
+    changes an element's gradient by O(1)): torch-CPU fp32 itself is 5e-2 away from an fp64 run on the worst tensor.
+    The yardstick is therefore an fp64 oracle, and the HIP path must be as close to it as fp32 torch-CPU is."""
+    torch.manual_seed(0)
+    net = mp.init_synthetic(mp.create_network("hrnet_w32", "hrnet_head"), seed=0)
+
+    def leaf_params(dtype):
+        d = {k: (v.clone().to(dtype) if v.dtype.is_floating_point else v.clone()) for k, v in net.state_dict().items()}
+        for k, v in d.items():
+            if v.dtype.is_floating_point and not k.endswith(("moving_mean", "moving_variance")):
+                v.requires_grad_()
+        return d
+
+    p32, p64 = leaf_params(torch.float32), leaf_params(torch.float64)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 3, 128, 96, generator=g)
+    kp = torch.rand(4, 17, 3, generator=g) * torch.tensor([96.0, 128.0, 2.0])
+    net = net.to(DEV).train()
+    tgt = mp.TopDownGenerateTarget(config=dict(image_size=[96, 128], heatmap_size=[24, 32]), sigma=2.0)
+    target, weight = tgt(kp.to(DEV))
+    nwl = mp.create_network_with_loss(net, mp.create_loss("joint_mse", use_target_weight=True), has_extra_inputs=True)
+    loss = nwl(x.to(DEV), target, weight)
+    loss.backward()
+
+    def oracle_step(params, dtype):
+        out = onets.net_forward_train(params, x.to(dtype), "hrnet_w32", "hrnet_head")
+        ref_loss = (((out - target.cpu().to(dtype)) ** 2) * weight.cpu().to(dtype)[..., None, None]).mean()
+        ref_loss.backward()
+        return float(ref_loss.detach())
+
+    l32, l64 = oracle_step(p32, torch.float32), oracle_step(p64, torch.float64)
+    assert abs(float(loss.detach()) - l64) <= 1e-6 * abs(l64)
+
+    def rel64(a, b):
+        return float((a.double().cpu() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+    e_hip = {n: rel64(p.grad, p64[n].grad) for n, p in net.named_parameters()}
+    e_cpu = {n: rel64(p32[n].grad, p64[n].grad) for n in e_hip}
+    assert all(p.grad is not None for p in net.parameters())
+    med_hip, med_cpu = float(np.median(list(e_hip.values()))), float(np.median(list(e_cpu.values())))
+    worst_hip, worst_cpu = max(e_hip.values()), max(e_cpu.values())
+    print(f"gradient error vs fp64 oracle: HIP median {med_hip:.2e} worst {worst_hip:.2e}; "
+          f"torch-CPU fp32 median {med_cpu:.2e} worst {worst_cpu:.2e}; loss {float(loss.detach())} / {l32} / {l64}")
+    assert med_hip < max(2 * med_cpu, 1e-4)
+    assert worst_hip < max(2 * worst_cpu, 1e-3)
+    # well-conditioned tensors (last layers of the backward) are tight
+    for name in ("head.head.weight", "head.head.bias", "backbone.stage4.2.fuse_layers.0.3.0.weight"):
+        assert e_hip[name] < 5e-5, (name, e_hip[name])
+    sd = net.state_dict()
+    for name in ("backbone.bn1.moving_mean", "backbone.stage4.2.branches.3.3.bn2.moving_variance"):
+        assert rel64(sd[name], p64[name].detach()) < 1e-4, name
