@@ -175,13 +175,71 @@ def cpu_baseline(state_dict, batch, budget_s=20.0):
                       f"(MindSpore-CPU reference path not installable), os.cpu_count={os.cpu_count()}, cpu='{model}'"}
 
 
+def train_bench(args, mp, dev, dist, world, rank):
+    """configs[3] in fp32: HRNet-W32 256x192 training step, data parallel - Gaussian targets on the device, forward
+    with batch-statistics BatchNorm, JointsMSELoss, backward (MFMA dgrad/wgrad), bucketed RCCL gradient mean
+    overlapped with backward, AdamWeightDecay.  Extra measurement (the contract metric is inference)."""
+    from mindpose_amd.utils import AdamWeightDecay
+    n = args.batch
+    net = mp.init_synthetic(mp.create_network("hrnet_w32", "hrnet_head"), seed=0).to(dev).train()
+    nwl = mp.create_network_with_loss(net, mp.create_loss("joint_mse", use_target_weight=True), has_extra_inputs=True)
+    opt = AdamWeightDecay(net, lr=1e-3, weight_decay=0.05, filter_bias_and_bn=True)
+    tgt = mp.TopDownGenerateTarget(config=dict(image_size=[192, 256], heatmap_size=[48, 64]), sigma=2.0)
+    gen = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    image = torch.randn(n, 3, 256, 192, generator=gen).to(dev)
+    kp = torch.empty(n, 17, 3)
+    kp[..., 0] = torch.rand(n, 17, generator=gen) * 232 - 20
+    kp[..., 1] = torch.rand(n, 17, generator=gen) * 296 - 20
+    kp[..., 2] = (torch.rand(n, 17, generator=gen) < 0.7).float()
+    kp = kp.to(dev)
+
+    def step():
+        opt.zero_grad()
+        target, weight = tgt(kp)
+        loss = nwl(image, target, weight)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "images/sec, HRNet-W32 256x192 training step (targets+fwd+loss+bwd+grad mean+AdamWeightDecay)",
+            "value": round(world * n * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[3] in fp32: HRNet-W32 256x192 training, DP, Gaussian targets + JointsMSE + "
+                                   "bucketed RCCL gradient mean (114 MB/step) + AdamWeightDecay",
+                       "per_gpu_batch": n, "global_batch": n * world, "final_loss": float(loss.detach())},
+            "roofline": None, "cpu_baseline": None}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="crops per GPU per step (reference per-device batch_size)")
-    ap.add_argument("--workload", default="hrnet_w32", choices=list(WORKLOADS),
+    ap.add_argument("--workload", default="hrnet_w32", choices=list(WORKLOADS) + ["hrnet_w32_train"],
                     help="hrnet_w32 = BASELINE.json metric / configs[2] (default); the others are extra measurements")
     ap.add_argument("--layers", default="", help="write a per-launch timing table (CSV) to this path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -206,6 +264,8 @@ def main():
     import mindpose_amd as mp
 
     torch.manual_seed(0)
+    if args.workload == "hrnet_w32_train":
+        return train_bench(args, mp, dev, dist, world, rank)
     backbone, head, (ih, iw), dec_kw, flip, workload_desc = WORKLOADS[args.workload]
     net = mp.init_synthetic(mp.create_network(backbone, head), seed=0).to(dev).eval()
     decoder = mp.create_decoder("topdown_heatmap", **dec_kw).to(dev)

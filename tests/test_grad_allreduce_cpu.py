@@ -1,0 +1,70 @@
+"""Row a17 (DP gradient mean) on CPU: world_size-2 gloo ranks, flat gradient arena, bucketed all-reduce launched from
+post-accumulate-grad hooks (overlap) - the averaged gradients equal the single-process gradient of the full batch."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp_
+
+from mindpose_amd.utils.grad_allreduce import GradientAverager
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.ReLU(), torch.nn.Linear(64, 64), torch.nn.ReLU(),
+                               torch.nn.Linear(64, 8))
+
+
+def _worker(rank, world, port, out_dir, overlap):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = _model()
+    avg = GradientAverager(net.parameters(), bucket_mb=0.01, overlap=overlap)  # tiny buckets -> several of them
+    assert len(avg.buckets) >= 3
+    g = torch.Generator().manual_seed(5)
+    x, y = torch.randn(8, 16, generator=g), torch.randn(8, 8, generator=g)
+    xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+    for _ in range(2):  # two steps: the arena is re-armed and zeroed correctly
+        avg.begin_step()
+        loss = ((net(xs) - ys) ** 2).mean()
+        loss.backward()
+        avg.finish()
+    if rank == 0:
+        torch.save([p.grad.clone() for p in net.parameters()], os.path.join(out_dir, f"grads_{int(overlap)}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_overlapped_allreduce_matches_full_batch(tmp_path):
+    net = _model()
+    g = torch.Generator().manual_seed(5)
+    x, y = torch.randn(8, 16, generator=g), torch.randn(8, 8, generator=g)
+    ((net(x) - y) ** 2).mean().backward()
+    ref = [p.grad.clone() for p in net.parameters()]
+    for overlap in (True, False):
+        mp_.spawn(_worker, args=(2, _free_port(), str(tmp_path), overlap), nprocs=2, join=True)
+        got = torch.load(os.path.join(tmp_path, f"grads_{int(overlap)}.pt"))
+        for a, b in zip(got, ref):
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
+
+
+def test_single_process_arena_views():
+    net = _model()
+    avg = GradientAverager(net.parameters(), bucket_mb=0.01)
+    x = torch.randn(4, 16)
+    net(x).sum().backward()
+    avg.finish()
+    total = sum(p.numel() for p in net.parameters())
+    assert avg.arena.numel() == total
+    for p in net.parameters():
+        assert p.grad.data_ptr() >= avg.arena.data_ptr() and p.grad.abs().sum() > 0
+    assert abs(float(avg.arena.abs().sum()) - sum(float(p.grad.abs().sum()) for p in net.parameters())) < 1e-3
