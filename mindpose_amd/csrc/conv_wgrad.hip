@@ -5,6 +5,8 @@
 // Workgroup = 32 couts x 32 cins x all taps; wave w owns the 16x16 sub-tile (w&1, w>>1) for every tap
 // (T accumulators).  The pixel axis is split over blockIdx.y; every split writes its partial dW into its own
 // slab and a second kernel sums the slabs in a fixed order (deterministic, no atomics).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mp {
@@ -22,7 +24,159 @@ struct WgradParams {
     int zpitch;        // per-cout LDS pitch of the dz tile (odd)
     int tiles_y, n_tiles, splits;
     int ci_tiles;
+    int vec;           // 1: pipelined kernel with 16-B range-checked staging (needs W % 4 == 0 and Wo % 4 == 0)
+    int zq, xw4;       // 16-B units per cout row of the dz tile (R*Wo/4) / per input row (W/4)
 };
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOobW = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const void* base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes < 0x7FFFFFF0u ? bytes : 0x7FFFFFF0u), 0x00020000);
+}
+__device__ __forceinline__ f32x4 wg_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+
+// Pipelined variant: the dz tile [32 couts][R*Wo] and the input tile [32 cins][Rin][Wp] are double-buffered in LDS;
+// while the MFMA loop runs on tile t the NZ + NX 16-B range-checked buffer loads of tile t+1 are in flight into
+// registers (rows outside the image / channels beyond Cout, Cin read 0 with no branch), one barrier per tile.
+// LDS pitches are == 2 (mod 32) floats: the 16 channels x 2 adjacent pixels a half-wave reads hit 32 distinct banks.
+template <int KS, int S, int NZ, int NX>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const WgradParams p) {
+    constexpr int T = KS * KS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int zbuf = 32 * p.zpitch, xbuf = 32 * p.xplane;
+    float* __restrict__ lz = smem;              // [2][32][zpitch]
+    float* __restrict__ lx = smem + 2 * zbuf;   // [2][32][xplane]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co_sub = wave & 1, ci_sub = wave >> 1;
+    const int lq = lane >> 4, lr = lane & 15;
+    const int cot = blockIdx.x / p.ci_tiles, cit = blockIdx.x % p.ci_tiles;
+    const int co0 = cot * 32, ci0 = cit * 32;
+    const int HW = p.H * p.W, HoWo = p.Ho * p.Wo;
+
+    // zero both x buffers once (halo columns are never written) and both z buffers (pad pixels beyond a short tile)
+    for (int i = tid; i < 2 * (zbuf + xbuf); i += 256) smem[i] = 0.f;
+
+    // staging tables (tile independent)
+    unsigned zsrc[NZ], zdst[NZ];  // float offsets; zdst packs the pixel offset (for the rows < R check) in the top bits
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+        const int u = tid + 256 * i;
+        zsrc[i] = kOobW;
+        zdst[i] = 0;
+        if (u < 32 * p.zq) {
+            const int c = u / p.zq, q4 = (u - c * p.zq) * 4;
+            if (co0 + c < p.Cout) zsrc[i] = (unsigned)((co0 + c) * HoWo + q4);
+            zdst[i] = ((unsigned)q4 << 16) | (unsigned)(c * p.zpitch + q4);
+        }
+    }
+    unsigned xsrc[NX], xdst[NX];  // xdst packs the input row index in the top bits
+    const int xper = p.Rin * p.xw4;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int u = tid + 256 * i;
+        xsrc[i] = kOobW;
+        xdst[i] = 0;
+        if (u < 32 * xper) {
+            const int c = u / xper, rem = u - c * xper;
+            const int r = rem / p.xw4, x4 = (rem - r * p.xw4) * 4;
+            if (ci0 + c < p.Cin) xsrc[i] = (unsigned)((ci0 + c) * HW + r * p.W + x4);
+            xdst[i] = ((unsigned)r << 16) | (unsigned)(c * p.xplane + r * p.Wp + p.pad + x4);
+        }
+    }
+
+    f32x4 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 vz[NZ], vx[NX];
+    auto tile_geom = [&](int tile, int& n, int& y0, int& npix, int& yin0) {
+        n = tile / p.tiles_y;
+        y0 = (tile - n * p.tiles_y) * p.R;
+        npix = min(p.R, p.Ho - y0) * p.Wo;
+        yin0 = y0 * S - p.pad;
+    };
+    auto stage_load = [&](int tile) {
+        int n, y0, npix, yin0;
+        tile_geom(tile, n, y0, npix, yin0);
+        const __amdgpu_buffer_rsrc_t rz = wg_rsrc(p.dz + (size_t)n * p.Cout * HoWo, (size_t)p.Cout * HoWo * 4);
+        const __amdgpu_buffer_rsrc_t rx = wg_rsrc(p.x + (size_t)n * p.Cin * HW, (size_t)p.Cin * HW * 4);
+        unsigned oz = 0;
+        asm volatile("" : "+v"(oz));  // keep the per-unit field arithmetic out of loop-invariant hoisting
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) {
+            const bool ok = zsrc[i] != kOobW && (int)((zdst[i] + oz) >> 16) < npix;
+            vz[i] = wg_load4(rz, ok ? (zsrc[i] + (unsigned)(y0 * p.Wo)) * 4u : kOobW);
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int yin = yin0 + (int)((xdst[i] + oz) >> 16);
+            const bool ok = xsrc[i] != kOobW && (unsigned)yin < (unsigned)p.H;
+            vx[i] = wg_load4(rx, ok ? (unsigned)((int)xsrc[i] + yin0 * p.W) * 4u : kOobW);
+        }
+    };
+    auto stage_store = [&](int buf) {
+        float* __restrict__ dz_l = lz + buf * zbuf;
+        float* __restrict__ dx_l = lx + buf * xbuf;
+        unsigned oz = 0;
+        asm volatile("" : "+v"(oz));
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) {
+            if (tid + 256 * i < 32 * p.zq) {
+                float* d = dz_l + ((zdst[i] + oz) & 0xFFFFu);
+                *reinterpret_cast<float2*>(d) = make_float2(vz[i].x, vz[i].y);  // pitch is even: 8-B aligned
+                *reinterpret_cast<float2*>(d + 2) = make_float2(vz[i].z, vz[i].w);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            if (tid + 256 * i < 32 * xper) {
+                float* d = dx_l + ((xdst[i] + oz) & 0xFFFFu);
+                d[0] = vx[i].x; d[1] = vx[i].y; d[2] = vx[i].z; d[3] = vx[i].w;
+            }
+        }
+    };
+
+    int tile = blockIdx.y;
+    if (tile < p.n_tiles) stage_load(tile);
+    __syncthreads();  // zero fill done
+    if (tile < p.n_tiles) stage_store(0);
+    __syncthreads();
+    int buf = 0;
+    for (; tile < p.n_tiles; tile += p.splits, buf ^= 1) {
+        const int next = tile + p.splits;
+        if (next < p.n_tiles) stage_load(next);
+        int n, y0, npix, yin0;
+        tile_geom(tile, n, y0, npix, yin0);
+        const int npix4 = (npix + 3) & ~3;
+        const float* __restrict__ az = lz + buf * zbuf + (co_sub * 16 + lr) * p.zpitch;
+        const float* __restrict__ bx = lx + buf * xbuf + (ci_sub * 16 + lr) * p.xplane;
+        for (int q = 0; q < npix4; q += 4) {
+            const int px = q + lq;  // Wo % 4 == 0: the 4 pixels of a k-step share one output row
+            const int y = q / p.Wo, xo = px - y * p.Wo;
+            const float a = az[px];
+            const int boff = (y * S) * p.Wp + xo * S;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const float b = bx[boff + (t / KS) * p.Wp + (t % KS)];
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+        if (next < p.n_tiles) stage_store(buf ^ 1);
+        __syncthreads();
+    }
+    float* __restrict__ slab = p.slabs + (size_t)blockIdx.y * p.Cout * p.Cin * T;
+    const int ci = ci0 + ci_sub * 16 + lr;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + co_sub * 16 + lq * 4 + r;
+            if (co < p.Cout && ci < p.Cin) slab[((size_t)co * p.Cin + ci) * T + t] = acc[t][r];
+        }
+}
+
 
 template <int KS, int S>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
@@ -94,11 +248,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         }
 }
 
+// Sum the slabs in a FIXED order (deterministic): eight interleaved partial sums (slab k goes to partial k & 7) keep
+// eight loads in flight per thread, then the partials are combined left to right.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, size_t count,
                                                            int splits, int accumulate) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += slabs[(size_t)k * count + i];  // fixed order
+        float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 8 <= splits; k += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part[j] += slabs[(size_t)(k + j) * count + i];
+        }
+        for (int j = 0; k < splits; ++k, ++j) part[j] += slabs[(size_t)k * count + i];
+        const float s = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
         dw[i] = accumulate ? dw[i] + s : s;
     }
 }
@@ -116,17 +278,42 @@ static int wgrad_geometry(const mp_conv_desc* d, WgradParams& p, size_t& lds_byt
     int R = 192 / p.Wo;
     if (R < 1) R = 1;
     if (R > p.Ho) R = p.Ho;
-    for (;;) {
-        p.R = R;
-        p.Rin = (R - 1) * S + KS;
-        p.Wp = (p.Wo - 1) * S + KS;
-        p.xplane = odd_up(p.Rin * p.Wp);
-        p.zpitch = odd_up(((R * p.Wo + 3) & ~3) + 1);
-        lds_bytes = (size_t)32 * (p.xplane + p.zpitch) * 4;
-        if (lds_bytes <= 150 * 1024 || R == 1) break;
-        R = (R + 1) / 2;
+    p.vec = ((p.W & 3) == 0 && (p.Wo & 3) == 0 && !getenv("MP_WGRAD_SIMPLE")) ? 1 : 0;
+    if (p.vec) {
+        // pipelined kernel: double-buffered tiles; R limited by the per-thread staging registers (NZ = 6, NX = 9
+        // 16-B units) and by 2 workgroups per CU (<= 78 KiB LDS)
+        for (;; --R) {
+            p.R = R;
+            p.Rin = (R - 1) * S + KS;
+            p.Wp = (p.Wo - 1) * S + KS;
+            if (p.Wp < p.pad + p.W) p.Wp = p.pad + p.W;  // whole input rows are staged
+            p.zq = R * p.Wo / 4;
+            p.xw4 = p.W / 4;
+            p.xplane = ((p.Rin * p.Wp + 31) / 32) * 32 + 2;
+            p.zpitch = ((R * p.Wo + 31) / 32) * 32 + 2;
+            lds_bytes = (size_t)2 * 32 * (p.xplane + p.zpitch) * 4;
+            const bool fits = 32 * p.zq <= 6 * 256 && 32 * p.Rin * p.xw4 <= 9 * 256 && lds_bytes <= 78 * 1024 &&
+                              p.zpitch < 65536 && 32 * p.xplane < 65536;
+            if (fits) break;
+            if (R == 1) { p.vec = 0; break; }
+        }
     }
-    if (lds_bytes > 150 * 1024) return MP_ERR_UNSUPPORTED;
+    if (!p.vec) {
+        R = 192 / p.Wo;
+        if (R < 1) R = 1;
+        if (R > p.Ho) R = p.Ho;
+        for (;;) {
+            p.R = R;
+            p.Rin = (R - 1) * S + KS;
+            p.Wp = (p.Wo - 1) * S + KS;
+            p.xplane = odd_up(p.Rin * p.Wp);
+            p.zpitch = odd_up(((R * p.Wo + 3) & ~3) + 1);
+            lds_bytes = (size_t)32 * (p.xplane + p.zpitch) * 4;
+            if (lds_bytes <= 150 * 1024 || R == 1) break;
+            R = (R + 1) / 2;
+        }
+        if (lds_bytes > 150 * 1024) return MP_ERR_UNSUPPORTED;
+    }
     p.tiles_y = (p.Ho + p.R - 1) / p.R;
     p.n_tiles = p.N * p.tiles_y;
     p.ci_tiles = (p.Cin + 31) / 32;
@@ -175,10 +362,29 @@ int mp_conv_wgrad(const mp_conv_desc* desc, const float* x, const float* dz, flo
         }                                                                                                               \
         hipLaunchKernelGGL(kern, grid, block, lds, s, p);                                                               \
     } while (0)
-    if (desc->kh == 3 && desc->stride == 1) MP_WGRAD_LAUNCH(3, 1);
-    else if (desc->kh == 3 && desc->stride == 2) MP_WGRAD_LAUNCH(3, 2);
-    else if (desc->kh == 1 && desc->stride == 1) MP_WGRAD_LAUNCH(1, 1);
-    else MP_WGRAD_LAUNCH(1, 2);
+#define MP_WGRAD_LAUNCH_PIPE(KS_, S_)                                                                                   \
+    do {                                                                                                                \
+        auto kern = conv_wgrad_pipe_kernel<KS_, S_, 6, 9>;                                                              \
+        static bool attr = false;                                                                                       \
+        if (!attr) {                                                                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            (void)hipGetLastError();                                                                                    \
+            attr = true;                                                                                                \
+        }                                                                                                               \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, p);                                                               \
+    } while (0)
+    if (p.vec) {
+        if (desc->kh == 3 && desc->stride == 1) MP_WGRAD_LAUNCH_PIPE(3, 1);
+        else if (desc->kh == 3 && desc->stride == 2) MP_WGRAD_LAUNCH_PIPE(3, 2);
+        else if (desc->kh == 1 && desc->stride == 1) MP_WGRAD_LAUNCH_PIPE(1, 1);
+        else MP_WGRAD_LAUNCH_PIPE(1, 2);
+    } else {
+        if (desc->kh == 3 && desc->stride == 1) MP_WGRAD_LAUNCH(3, 1);
+        else if (desc->kh == 3 && desc->stride == 2) MP_WGRAD_LAUNCH(3, 2);
+        else if (desc->kh == 1 && desc->stride == 1) MP_WGRAD_LAUNCH(1, 1);
+        else MP_WGRAD_LAUNCH(1, 2);
+    }
+#undef MP_WGRAD_LAUNCH_PIPE
 #undef MP_WGRAD_LAUNCH
     rc = check_launch();
     if (rc != MP_OK) return rc;
