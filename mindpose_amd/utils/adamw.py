@@ -45,10 +45,11 @@ class AdamWeightDecay:
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.lr, self.beta1, self.beta2, self.eps, self.weight_decay = lr, beta1, beta2, eps, weight_decay
-        # gradients: one arena in the SAME order, bucketed all-reduce overlapped with backward
-        self.grads = GradientAverager(self.params, bucket_mb=bucket_mb, process_group=process_group, overlap=overlap)
-        # GradientAverager lays the arena out in reverse parameter order; map it back to parameter order lazily
-        self._grad_flat = torch.empty_like(self.flat)
+        # gradients: one arena in the SAME order as the parameter arena (no gather before the update), bucketed
+        # all-reduce overlapped with backward
+        self.grads = GradientAverager(self.params, bucket_mb=bucket_mb, process_group=process_group, overlap=overlap,
+                                      arena_order="given")
+        self._grad_flat = self.grads.arena
         self.global_step = 0
 
     def zero_grad(self) -> None:
@@ -58,12 +59,6 @@ class AdamWeightDecay:
         """All-reduce (mean) the gradients, then one fused update per decay group."""
         lib = _lib.load()
         self.grads.finish()
-        # gather gradient views into parameter order (device-to-device copies of views of one arena)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            self._grad_flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
         s = _lib.stream()
         for start, count, wd in ((0, self.n_decay, self.weight_decay), (self.n_decay, self.flat.numel() - self.n_decay, 0.0)):
             if count == 0:

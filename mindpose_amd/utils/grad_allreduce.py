@@ -16,7 +16,10 @@ import torch.distributed as dist
 
 class GradientAverager:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 32.0, process_group=None,
-                 overlap: bool = True) -> None:
+                 overlap: bool = True, arena_order: str = "reverse") -> None:
+        """``arena_order``: "reverse" lays the arena out last-parameter-first (buckets fill front to back during
+        backward); "given" keeps the caller's order, e.g. to alias an optimizer's flat parameter layout (buckets then
+        complete back to front - the overlap is the same, every bucket still launches when its last gradient lands)."""
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -25,8 +28,9 @@ class GradientAverager:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         total = sum(p.numel() for p in self.params)
         self.arena = torch.zeros(total, device=dev, dtype=dtype)
-        # reverse order: the last layers' gradients are ready first
-        order = list(reversed(self.params))
+        if arena_order not in ("reverse", "given"):
+            raise ValueError("arena_order must be 'reverse' or 'given'")
+        order = list(reversed(self.params)) if arena_order == "reverse" else list(self.params)
         limit = max(1, int(bucket_mb * 1024 * 1024 / 4))
         self.buckets: List[dict] = []
         off = 0
