@@ -5,6 +5,7 @@ checkpoint maps 1:1); all arithmetic happens in ``libmindpose_hip.so``.  A netwo
 recorded once per input shape into a native launch plan (``mp_plan_*``) and replayed by one C call.
 """
 import ctypes
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -72,6 +73,9 @@ class Plan:
         self.layer_info: List[Dict] = []  # per entry: kind, shapes, MACs (for the roofline report)
         self._packed: Dict[Tuple[int, int, int], torch.Tensor] = {}
         self._folded: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._graph = None
+        self._graph_ok = True
+        self._runs = 0
 
     def __del__(self):
         try:
@@ -87,7 +91,27 @@ class Plan:
         return t
 
     def run(self) -> None:
+        """Replay the recorded forward: as one hipGraph launch once captured (MINDPOSE_HIP_GRAPH=0 disables it),
+        otherwise as one native call that issues the launches back to back."""
+        if self._graph is not None:
+            self._graph.replay()
+            return
         _lib.check(self.lib.mp_plan_run(self.handle, _lib.stream()), "mp_plan_run")
+        self._runs += 1
+        if self._runs == 2 and self._graph_ok and os.environ.get("MINDPOSE_HIP_GRAPH", "1") != "0":
+            self._capture()
+
+    def _capture(self) -> None:
+        # the plan has run twice (kernel attributes set, nothing allocates): capture the launch sequence
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                _lib.check(self.lib.mp_plan_run(self.handle, _lib.stream()), "mp_plan_run (capture)")
+            self._graph = graph
+        except Exception as exc:  # capture unsupported in this context: keep direct launches (same kernels)
+            self._graph_ok = False
+            import warnings
+            warnings.warn(f"hipGraph capture of the launch plan failed, using direct launches: {exc}")
 
     def run_range(self, first: int, count: int) -> None:
         _lib.check(self.lib.mp_plan_run_range(self.handle, first, count, _lib.stream()), "mp_plan_run_range")
