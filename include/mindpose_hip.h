@@ -144,6 +144,13 @@ int mp_conv2d_fwd(const mp_conv_desc* desc, const float* x_dev, const float* pac
                   const float* scale_dev, const float* shift_dev, const float* res1_dev, const float* res2_dev,
                   float* out_dev, mp_stream_t stream);
 
+/* Same as mp_conv2d_fwd / mp_plan_add_conv with the tile variant forced (0..4 = cout tile x pixel tile
+ * 32x192, 64x192, 48x192, 64x96, 32x96; -1 = library heuristic).  Returns MP_ERR_UNSUPPORTED when that variant cannot
+ * run the shape.  Used by the host-side autotuner, which times the candidates once per distinct layer shape. */
+int mp_conv2d_fwd_variant(const mp_conv_desc* desc, int variant, const float* x_dev, const float* packed_w_dev,
+                          const float* scale_dev, const float* shift_dev, const float* res1_dev, const float* res2_dev,
+                          float* out_dev, mp_stream_t stream);
+
 /* nn.MaxPool2d(kernel_size=3, stride=2, pad_mode="same"), resnet.py:190: pads bottom/right only. */
 int mp_maxpool3x3s2_same(const float* x_dev, float* out_dev, int n, int c, int h, int w, mp_stream_t stream);
 
@@ -166,6 +173,9 @@ void mp_plan_destroy(mp_plan* plan);
 int mp_plan_add_conv(mp_plan* plan, const mp_conv_desc* desc, const float* x_dev, const float* packed_w_dev,
                      const float* scale_dev, const float* shift_dev, const float* res1_dev,
                      const float* res2_dev, float* out_dev);
+int mp_plan_add_conv_variant(mp_plan* plan, const mp_conv_desc* desc, int variant, const float* x_dev,
+                             const float* packed_w_dev, const float* scale_dev, const float* shift_dev,
+                             const float* res1_dev, const float* res2_dev, float* out_dev);
 int mp_plan_add_maxpool(mp_plan* plan, const float* x_dev, float* out_dev, int n, int c, int h, int w);
 int mp_plan_add_fuse_sum(mp_plan* plan, const float* base_dev, const float* t1_dev, int s1, const float* t2_dev, int s2,
                          const float* t3_dev, int s3, float* out_dev, int n, int c, int h, int w, int relu);

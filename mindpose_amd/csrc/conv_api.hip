@@ -156,7 +156,11 @@ static bool configure(const mp_conv_desc& d, int variant, ConvLaunch& L) {
     return L.lds_bytes <= (size_t)kLdsMax;
 }
 
-static int choose_variant(const mp_conv_desc& d, ConvLaunch& best) {
+static int choose_variant(const mp_conv_desc& d, ConvLaunch& best, int forced = -1) {
+    if (forced >= 0) {
+        if (forced >= V_COUNT) return MP_ERR_UNSUPPORTED;
+        return configure(d, forced, best) ? MP_OK : MP_ERR_UNSUPPORTED;
+    }
     // cout tile by divisibility; pixel tile 192 unless that leaves the chip under-filled
     int order[V_COUNT];
     int n = 0;
@@ -221,11 +225,12 @@ static int launch(const ConvLaunch& L0, hipStream_t s) {
 }
 
 static int build_launch(const mp_conv_desc* desc, const float* x, const float* w, const float* scale,
-                        const float* shift, const float* res1, const float* res2, float* out, ConvLaunch& L) {
+                        const float* shift, const float* res1, const float* res2, float* out, ConvLaunch& L,
+                        int forced = -1) {
     int rc = validate_desc(desc);
     if (rc != MP_OK) return rc;
     if (!x || !w || !scale || !shift || !out) return MP_ERR_NULL;
-    rc = choose_variant(*desc, L);
+    rc = choose_variant(*desc, L, forced);
     if (rc != MP_OK) return rc;
     L.p.x = x; L.p.wp = w; L.p.scale = scale; L.p.shift = shift; L.p.res1 = res1; L.p.res2 = res2; L.p.out = out;
     return MP_OK;
@@ -289,6 +294,25 @@ int mp_debug_set_stamp_buffer(void* dev_ptr, size_t bytes) {
     (void)dev_ptr; (void)bytes;
     return MP_ERR_UNSUPPORTED;
 #endif
+}
+
+int mp_conv2d_fwd_variant(const mp_conv_desc* desc, int variant, const float* x, const float* packed_w, const float* scale,
+                          const float* shift, const float* res1, const float* res2, float* out, mp_stream_t stream) {
+    ConvLaunch L{};
+    int rc = build_launch(desc, x, packed_w, scale, shift, res1, res2, out, L, variant);
+    if (rc != MP_OK) return rc;
+    return launch(L, as_stream(stream));
+}
+
+int mp_plan_add_conv_variant(mp_plan* plan, const mp_conv_desc* desc, int variant, const float* x, const float* packed_w,
+                             const float* scale, const float* shift, const float* res1, const float* res2, float* out) {
+    if (!plan) return MP_ERR_NULL;
+    mp_plan::Entry e{};
+    e.kind = 0;
+    int rc = build_launch(desc, x, packed_w, scale, shift, res1, res2, out, e.conv, variant);
+    if (rc != MP_OK) return rc;
+    plan->entries.push_back(e);
+    return MP_OK;
 }
 
 mp_plan* mp_plan_create(void) { return new (std::nothrow) mp_plan(); }
