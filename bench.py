@@ -28,7 +28,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
-VARIANT_TEMPLATE = {0: "3,2,4,1", 1: "3,4,4,1", 2: "3,3,4,1", 3: "3,2,2,2", 4: "3,1,2,2"}  # PS,CS,WAVES_P,WAVES_C
+VARIANT_TEMPLATE = {0: "3,2,4,1", 1: "3,4,4,1", 2: "3,3,4,1", 3: "3,2,2,2", 4: "3,1,2,2", 5: "3,2,2,2", 6: "3,2,4,1",
+                    7: "3,1,2,2"}  # PS,CS,WAVES_P,WAVES_C
 
 
 # name -> (backbone, head, image HxW, decoder kwargs, flip test, description)
@@ -51,7 +52,9 @@ def log(msg):
 
 
 def kernel_name(info):
-    return f"conv_mfma_kernel<{info['ks']},{info['stride']},{VARIANT_TEMPLATE[info['variant']]}>"
+    """Template head <KS,S,PS,CS,WAVES_P,WAVES_C> of the instantiation; '/occ3' marks the light build (rocprof shows it as
+    the trailing template argument OCC = 3)."""
+    return f"conv_mfma_kernel<{info['ks']},{info['stride']},{VARIANT_TEMPLATE[info['variant']]}>" + ("/occ3" if info.get("light") else "")
 
 
 def time_plan_entries(plan, reps):

@@ -185,7 +185,7 @@ int mp_plan_run(const mp_plan* plan, mp_stream_t stream);
 int mp_plan_run_range(const mp_plan* plan, int first, int count, mp_stream_t stream);
 /* launch geometry of entry `index` (roofline report): info[0]=kind (0 conv, 1 maxpool, 2 fuse-sum), [1]=kernel size,
  * [2]=stride, [3]=tile variant, [4]=workgroups, [5]=LDS bytes per workgroup, [6]=cout tile, [7]=pixel tile,
- * [8]=cin chunk, [9]=images per tile, [10]=rows per tile */
+ * [8]=cin chunk, [9]=images per tile, [10]=rows per tile, [11]=light variant (3 workgroups/CU) */
 int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]);
 
 /* ------------------------------------------------------------------------------------------

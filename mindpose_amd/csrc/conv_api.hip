@@ -87,7 +87,7 @@ static int plane_pad(int raw) {  // smallest value >= raw that is == 16 (mod 32)
 static bool configure(const mp_conv_desc& d, int variant, ConvLaunch& L) {
     int CT, PT;
     variant_dims(variant, CT, PT);
-    if (d.kh == 7 && variant != V_CT64_PT192 && variant != V_CT32_PT192) return false;  // only these are built
+    if (d.kh == 7 && variant != V_CT64_PT192 && variant != V_CT32_PT192_H) return false;  // only these are built
     ConvKParams& p = L.p;
     const int S = d.stride, KS = d.kh;
     p.N = d.n; p.Cin = d.cin; p.H = d.h; p.W = d.w; p.Cout = d.cout;
@@ -120,10 +120,10 @@ static bool configure(const mp_conv_desc& d, int variant, ConvLaunch& L) {
     p.upc = p.G * p.Rin * p.upr;
     // cin chunk: the largest multiple of 4 that divides Cin_pad4, fits the per-thread staging registers
     // (kNI / NW units of 16 B) and - double-buffered when there is more than one chunk - the LDS budget
-    const int cs_v = variant_cs(variant), wc_v = variant_waves_c(variant);
-    const int nw = stage_nw(KS, cs_v, wc_v), ni = stage_ni(KS, cs_v, wc_v, p.vec != 0);
-    // three workgroups per CU for the light variant (160 KiB / 3), two otherwise
-    const int budget = (stage_occ(KS, cs_v, wc_v) == 3 && !getenv("MP_CONV_LDS_KB")) ? 52 * 1024 : lds_budget();
+    const bool light = variant_light(variant) && KS <= 3;
+    const int nw = stage_nw(KS, light), ni = stage_ni(KS, light, p.vec != 0);
+    // three workgroups per CU for the light variants (160 KiB / 3), two otherwise
+    const int budget = (light && !getenv("MP_CONV_LDS_KB")) ? 52 * 1024 : lds_budget();
     int best_ck = 0;
     for (int ck = 4; ck <= p.Cin_pad4 && ck <= 128; ck += 4) {
         if (p.Cin_pad4 % ck) continue;
@@ -165,7 +165,8 @@ static int choose_variant(const mp_conv_desc& d, ConvLaunch& best, int forced = 
     int order[V_COUNT];
     int n = 0;
     const int c = d.cout;
-    if (c % 64 == 0) { order[n++] = V_CT64_PT192; order[n++] = V_CT64_PT96; order[n++] = V_CT32_PT192; order[n++] = V_CT32_PT96; }
+    if (d.kh == 7) { order[n++] = V_CT64_PT192; order[n++] = V_CT32_PT192_H; }
+    else if (c % 64 == 0) { order[n++] = V_CT64_PT192; order[n++] = V_CT64_PT96; order[n++] = V_CT32_PT192; order[n++] = V_CT32_PT96; }
     else if (c % 48 == 0) { order[n++] = V_CT48_PT192; order[n++] = V_CT64_PT192; order[n++] = V_CT64_PT96; }
     else if (c <= 32) { order[n++] = V_CT32_PT192; order[n++] = V_CT32_PT96; }
     else if (c <= 48) { order[n++] = V_CT48_PT192; order[n++] = V_CT64_PT96; }
@@ -380,6 +381,7 @@ int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]) {
         info[1] = e.conv.ks; info[2] = e.conv.stride; info[3] = e.conv.variant; info[4] = e.conv.p.total_blocks;
         info[5] = (int64_t)e.conv.lds_bytes; info[6] = ct; info[7] = pt; info[8] = e.conv.p.CK; info[9] = e.conv.p.G;
         info[10] = e.conv.p.R;
+        info[11] = variant_light(e.conv.variant) ? 1 : 0;
     }
     return MP_OK;
 }

@@ -7,9 +7,11 @@ namespace mp {
 int launch_conv_k7(const ConvKParams& p, int stride, int variant, size_t lds_bytes, hipStream_t s) {
     if (stride != 2) return MP_ERR_UNSUPPORTED;
     if (variant == V_CT64_PT192)
-        return p.vec ? launch_variant<7, 2, 3, 4, 4, 1, true>(p, lds_bytes, s) : launch_variant<7, 2, 3, 4, 4, 1, false>(p, lds_bytes, s);
-    if (variant == V_CT32_PT192)
-        return p.vec ? launch_variant<7, 2, 3, 2, 4, 1, true>(p, lds_bytes, s) : launch_variant<7, 2, 3, 2, 4, 1, false>(p, lds_bytes, s);
+        return p.vec ? launch_variant<7, 2, 3, 4, 4, 1, true, false>(p, lds_bytes, s)
+                     : launch_variant<7, 2, 3, 4, 4, 1, false, false>(p, lds_bytes, s);
+    if (variant == V_CT32_PT192_H)
+        return p.vec ? launch_variant<7, 2, 3, 2, 4, 1, true, false>(p, lds_bytes, s)
+                     : launch_variant<7, 2, 3, 2, 4, 1, false, false>(p, lds_bytes, s);
     return MP_ERR_UNSUPPORTED;
 }
 

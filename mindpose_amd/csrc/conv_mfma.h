@@ -516,36 +516,41 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvKParams p
 }
 
 // tile variants: index -> (PS, CS, WAVES_P, WAVES_C); CT = 16*CS*WAVES_C, PT = 16*PS*WAVES_P
-enum ConvVariant { V_CT32_PT192 = 0, V_CT64_PT192 = 1, V_CT48_PT192 = 2, V_CT64_PT96 = 3, V_CT32_PT96 = 4, V_COUNT = 5 };
-
-inline int variant_cs(int v) {
-    static const int css[V_COUNT] = {2, 4, 3, 2, 1};
-    return css[v];
-}
-inline int variant_waves_c(int v) {
-    static const int wcs[V_COUNT] = {1, 1, 1, 2, 2};
-    return wcs[v];
-}
+// tile variants: cout tile x pixel tile (+ _L light / _H regular where both exist); CT = 16*CS*WAVES_C, PT = 16*PS*WAVES_P
+enum ConvVariant {
+    V_CT32_PT192 = 0,   // light (3 workgroups / CU)
+    V_CT64_PT192 = 1,
+    V_CT48_PT192 = 2,
+    V_CT64_PT96 = 3,
+    V_CT32_PT96 = 4,
+    V_CT64_PT96_L = 5,  // light
+    V_CT32_PT192_H = 6, // regular
+    V_CT32_PT96_L = 7,  // light
+    V_COUNT = 8
+};
 
 inline void variant_dims(int v, int& ct, int& pt) {
-    static const int cts[V_COUNT] = {32, 64, 48, 64, 32};
-    static const int pts[V_COUNT] = {192, 192, 192, 96, 96};
+    static const int cts[V_COUNT] = {32, 64, 48, 64, 32, 64, 32, 32};
+    static const int pts[V_COUNT] = {192, 192, 192, 96, 96, 96, 192, 96};
     ct = cts[v];
     pt = pts[v];
 }
+inline bool variant_light(int v) {
+    static const bool l[V_COUNT] = {true, false, false, false, false, true, false, true};
+    return l[v];
+}
 
-// Staging units (16 B) per thread per chunk and the occupancy the kernel is compiled for.  The 32-cout x 192-pixel
-// variant serves the small-K layers (K = 9 x 32 on the 64x48 branch): its workgroups are short, so it takes small
-// chunks and runs THREE workgroups per CU - one workgroup's prologue / staging / epilogue hides under the others'
-// MFMA phases (measured +11 % on that kernel).  Large-K variants keep big chunks and two workgroups (measured better).
-constexpr bool light_variant(int ks, int cs, int waves_c) { return ks <= 3 && cs == 2 && waves_c == 1; }
-constexpr int stage_ni(int ks, int cs, int waves_c, bool vec) { return vec ? (light_variant(ks, cs, waves_c) ? 4 : 8) : (light_variant(ks, cs, waves_c) ? 10 : 8); }
-constexpr int stage_nw(int ks, int cs, int waves_c) { return ks == 7 ? 13 : (light_variant(ks, cs, waves_c) ? 3 : 6); }
-constexpr int stage_occ(int ks, int cs, int waves_c) { return light_variant(ks, cs, waves_c) ? 3 : 2; }
+// Staging units (16 B) per thread per chunk and the occupancy a kernel is compiled for.  LIGHT kernels take small
+// chunks (few staging registers, <= 52 KiB LDS) and run THREE workgroups per CU, so one workgroup's prologue / staging /
+// epilogue hides under the others' MFMA phases; the regular ones keep big chunks and two workgroups.  Which is faster
+// depends on the layer (K, map size, batch): the plan-time autotuner measures both.
+constexpr int stage_ni(int ks, bool light, bool vec) { return vec ? (light ? 4 : 8) : (light ? 10 : 8); }
+constexpr int stage_nw(int ks, bool light) { return ks == 7 ? 13 : (light ? 3 : 6); }
+constexpr int stage_occ(bool light) { return light ? 3 : 2; }
 
-template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, bool VEC>
+template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, bool VEC, bool LIGHT>
 int launch_variant(const ConvKParams& p, size_t lds_bytes, hipStream_t s) {
-    auto kern = conv_mfma_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, stage_ni(KS, CS, WAVES_C, VEC), stage_nw(KS, CS, WAVES_C), VEC, stage_occ(KS, CS, WAVES_C)>;
+    auto kern = conv_mfma_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, stage_ni(KS, LIGHT, VEC), stage_nw(KS, LIGHT), VEC, stage_occ(LIGHT)>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -559,11 +564,14 @@ int launch_variant(const ConvKParams& p, size_t lds_bytes, hipStream_t s) {
 template <int KS, int S, bool VEC>
 int launch_ks_v(const ConvKParams& p, int variant, size_t lds_bytes, hipStream_t s) {
     switch (variant) {
-        case V_CT32_PT192: return launch_variant<KS, S, 3, 2, 4, 1, VEC>(p, lds_bytes, s);
-        case V_CT64_PT192: return launch_variant<KS, S, 3, 4, 4, 1, VEC>(p, lds_bytes, s);
-        case V_CT48_PT192: return launch_variant<KS, S, 3, 3, 4, 1, VEC>(p, lds_bytes, s);
-        case V_CT64_PT96: return launch_variant<KS, S, 3, 2, 2, 2, VEC>(p, lds_bytes, s);
-        case V_CT32_PT96: return launch_variant<KS, S, 3, 1, 2, 2, VEC>(p, lds_bytes, s);
+        case V_CT32_PT192: return launch_variant<KS, S, 3, 2, 4, 1, VEC, true>(p, lds_bytes, s);
+        case V_CT64_PT192: return launch_variant<KS, S, 3, 4, 4, 1, VEC, false>(p, lds_bytes, s);
+        case V_CT48_PT192: return launch_variant<KS, S, 3, 3, 4, 1, VEC, false>(p, lds_bytes, s);
+        case V_CT64_PT96: return launch_variant<KS, S, 3, 2, 2, 2, VEC, false>(p, lds_bytes, s);
+        case V_CT32_PT96: return launch_variant<KS, S, 3, 1, 2, 2, VEC, false>(p, lds_bytes, s);
+        case V_CT64_PT96_L: return launch_variant<KS, S, 3, 2, 2, 2, VEC, true>(p, lds_bytes, s);
+        case V_CT32_PT192_H: return launch_variant<KS, S, 3, 2, 4, 1, VEC, false>(p, lds_bytes, s);
+        case V_CT32_PT96_L: return launch_variant<KS, S, 3, 1, 2, 2, VEC, true>(p, lds_bytes, s);
         default: return MP_ERR_UNSUPPORTED;
     }
 }

@@ -121,7 +121,7 @@ class Plan:
         buf = (ctypes.c_int64 * 12)()
         _lib.check(self.lib.mp_plan_entry_info(self.handle, index, buf), "mp_plan_entry_info")
         keys = ["kind_id", "ks", "stride", "variant", "workgroups", "lds_bytes", "cout_tile", "pixel_tile", "cin_chunk",
-                "images_per_tile", "rows_per_tile"]
+                "images_per_tile", "rows_per_tile", "light"]
         info = dict(zip(keys, [int(v) for v in buf]))
         info.update(self.layer_info[index])
         return info
@@ -214,7 +214,7 @@ class Plan:
             # in-place accumulation (out aliases res1) must not be disturbed by trial launches: tune into a scratch copy
             alias = res1 is not None and res1.data_ptr() == out.data_ptr()
             trial_out = torch.empty_like(out) if alias else out
-            for v in range(5):
+            for v in range(8):
                 args = (ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(res1),
                         _lib.ptr(res2), _lib.ptr(trial_out), stream)
                 if self.lib.mp_conv2d_fwd_variant(*args) != 0:
