@@ -58,6 +58,44 @@ class BatchNorm2d(nn.Module):
         return scale.contiguous(), shift.contiguous()
 
 
+_TUNE_CACHE: Dict[Tuple, int] = {}
+
+
+def tune_conv_variant(lib, d, x, packed, scale, shift, res1, res2, out) -> int:
+    """Pick the tile variant for one conv launch shape by timing the candidates once (HIP events, 3 launches each) on
+    the layer's real buffers; -1 = library heuristic when tuning is off (MINDPOSE_AUTOTUNE=0) or pointless (tiny
+    layers).  Results are cached per shape, so a network's ~40 distinct shapes are tuned once per process."""
+    if os.environ.get("MINDPOSE_AUTOTUNE", "1") == "0":
+        return -1
+    key = tuple(getattr(d, f) for f, _ in d._fields_) + (res1 is not None, res2 is not None, str(out.device))
+    hit = _TUNE_CACHE.get(key)
+    if hit is not None:
+        return hit
+    macs = d.n * d.conv_h * d.conv_w * d.cout * d.cin * d.kh * d.kw
+    best, best_t = -1, None
+    if macs >= (1 << 26):
+        stream = _lib.stream()
+        # in-place accumulation (out aliases res1) must not be disturbed by trial launches: tune into a scratch copy
+        alias = res1 is not None and res1.data_ptr() == out.data_ptr()
+        trial_out = torch.empty_like(out) if alias else out
+        for v in range(8):
+            args = (ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(res1),
+                    _lib.ptr(res2), _lib.ptr(trial_out), stream)
+            if lib.mp_conv2d_fwd_variant(*args) != 0:
+                continue
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                lib.mp_conv2d_fwd_variant(*args)
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            if best_t is None or t < best_t:
+                best, best_t = v, t
+    _TUNE_CACHE[key] = best
+    return best
+
+
 class Plan:
     """A recorded forward: native ``mp_plan`` + the tensors it points into."""
 
@@ -194,42 +232,8 @@ class Plan:
                                     macs=n * ho * wo * conv.out_channels * cin * k * k))
         return out
 
-    # -- autotuning ---------------------------------------------------------------------------------
-    _tune_cache: Dict[Tuple, int] = {}
-
     def _tune(self, d, x, packed, scale, shift, res1, res2, out) -> int:
-        """Pick the tile variant for this layer shape by timing the candidates once (HIP events, 3 launches each) on
-        the layer's real buffers; -1 = library heuristic when tuning is off (MINDPOSE_AUTOTUNE=0) or pointless (tiny
-        layers).  Results are cached per shape, so a network's ~40 distinct shapes are tuned once per process."""
-        if os.environ.get("MINDPOSE_AUTOTUNE", "1") == "0":
-            return -1
-        key = tuple(getattr(d, f) for f, _ in d._fields_) + (res1 is not None, res2 is not None, str(self.device))
-        hit = Plan._tune_cache.get(key)
-        if hit is not None:
-            return hit
-        macs = d.n * d.conv_h * d.conv_w * d.cout * d.cin * d.kh * d.kw
-        best, best_t = -1, None
-        if macs >= (1 << 26):
-            stream = _lib.stream()
-            # in-place accumulation (out aliases res1) must not be disturbed by trial launches: tune into a scratch copy
-            alias = res1 is not None and res1.data_ptr() == out.data_ptr()
-            trial_out = torch.empty_like(out) if alias else out
-            for v in range(8):
-                args = (ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(res1),
-                        _lib.ptr(res2), _lib.ptr(trial_out), stream)
-                if self.lib.mp_conv2d_fwd_variant(*args) != 0:
-                    continue
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(3):
-                    self.lib.mp_conv2d_fwd_variant(*args)
-                e1.record()
-                e1.synchronize()
-                t = e0.elapsed_time(e1)
-                if best_t is None or t < best_t:
-                    best, best_t = v, t
-        Plan._tune_cache[key] = best
-        return best
+        return tune_conv_variant(self.lib, d, x, packed, scale, shift, res1, res2, out)
 
     def deconv4x4s2(self, x: torch.Tensor, deconv: Conv2dTranspose, bn: BatchNorm2d, relu: bool = True) -> torch.Tensor:
         """Conv2dTranspose(k=4, s=2, p=1) + BN + ReLU as four 2x2 sub-pixel phase convolutions."""

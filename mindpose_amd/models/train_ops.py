@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from .. import _lib
-from .layers import BN_EPS
+from .layers import BN_EPS, tune_conv_variant
 
 BN_MOMENTUM = 0.9  # mindspore.nn.BatchNorm2d(momentum=0.9): moving = 0.9*moving + 0.1*batch [MS-knowledge]
 
@@ -30,6 +30,13 @@ def _desc(n, cin, h, w, cout, k, stride, pad_t, pad_l, conv_h, conv_w, out_h, ou
     return _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=k, kw=k, stride=stride, pad_top=pad_t, pad_left=pad_l,
                          conv_h=conv_h, conv_w=conv_w, out_h=out_h, out_w=out_w, out_mul=out_mul, out_rep=out_rep,
                          out_off_y=off_y, out_off_x=off_x, relu=0, tap_dilation_unused=0)
+
+
+def _conv_launch(lib, d, x, packed, scale, shift, out, what):
+    """One forward-kernel launch (forward conv or a data-gradient conv) with the autotuned tile variant."""
+    v = tune_conv_variant(lib, d, x, packed, scale, shift, None, None, out)
+    _lib.check(lib.mp_conv2d_fwd_variant(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift),
+                                         None, None, _lib.ptr(out), _lib.stream()), what)
 
 
 def _pack(lib, w, cout, cin, k, mode, py=0, px=0):
@@ -58,8 +65,7 @@ class Conv2dFn(torch.autograd.Function):
         z = torch.empty(n, cout, ho, wo, device=x.device, dtype=torch.float32)
         d = _desc(n, cin, h, wd, cout, k, stride, padding, padding, ho, wo, ho, wo)
         packed = _pack(lib, w, cout, cin, k, 0)
-        _lib.check(lib.mp_conv2d_fwd(ctypes.byref(d), _lib.ptr(x), _lib.ptr(packed), _lib.ptr(ones), _lib.ptr(shift), None,
-                                     None, _lib.ptr(z), _lib.stream()), "mp_conv2d_fwd")
+        _conv_launch(lib, d, x, packed, ones, shift, z, "mp_conv2d_fwd")
         ctx.save_for_backward(x, w)
         ctx.stride, ctx.padding, ctx.has_bias = stride, padding, bias is not None
         return z
@@ -80,8 +86,7 @@ class Conv2dFn(torch.autograd.Function):
                 dx = torch.empty_like(x)
                 d = _desc(n, cout, ho, wo, cin, k, 1, k - 1 - pad, k - 1 - pad, h, wd, h, wd)
                 packed = _pack(lib, w, cin, cout, k, 2)
-                _lib.check(lib.mp_conv2d_fwd(ctypes.byref(d), _lib.ptr(dz), _lib.ptr(packed), _lib.ptr(ones), _lib.ptr(zeros),
-                                             None, None, _lib.ptr(dx), _lib.stream()), "conv dgrad")
+                _conv_launch(lib, d, dz, packed, ones, zeros, dx, "conv dgrad")
             else:
                 if h != 2 * ho or wd != 2 * wo:
                     raise NotImplementedError("stride-2 data gradient needs even input extents")
@@ -91,15 +96,12 @@ class Conv2dFn(torch.autograd.Function):
                         for px in (0, 1):
                             d = _desc(n, cout, ho, wo, cin, 2, 1, 0, 0, ho, wo, h, wd, out_mul=2, off_y=py, off_x=px)
                             packed = _pack(lib, w, cin, cout, 2, 3, py, px)
-                            _lib.check(lib.mp_conv2d_fwd(ctypes.byref(d), _lib.ptr(dz), _lib.ptr(packed), _lib.ptr(ones),
-                                                         _lib.ptr(zeros), None, None, _lib.ptr(dx), _lib.stream()),
-                                       "conv dgrad phase")
+                            _conv_launch(lib, d, dz, packed, ones, zeros, dx, "conv dgrad phase")
                 else:  # 1x1 stride 2: only even positions receive gradient
                     dx = torch.zeros_like(x)
                     d = _desc(n, cout, ho, wo, cin, 1, 1, 0, 0, ho, wo, h, wd, out_mul=2)
                     packed = _pack(lib, w, cin, cout, 1, 2)
-                    _lib.check(lib.mp_conv2d_fwd(ctypes.byref(d), _lib.ptr(dz), _lib.ptr(packed), _lib.ptr(ones),
-                                                 _lib.ptr(zeros), None, None, _lib.ptr(dx), _lib.stream()), "conv dgrad 1x1s2")
+                    _conv_launch(lib, d, dz, packed, ones, zeros, dx, "conv dgrad 1x1s2")
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             d = _desc(n, cin, h, wd, cout, k, s, pad, pad, ho, wo, ho, wo)

@@ -1,3 +1,4 @@
 from .adamw import AdamWeightDecay, split_decay  # noqa: F401
 from .grad_allreduce import GradientAverager  # noqa: F401
+from .lr import WarmupMultiStepDecayLR  # noqa: F401
 from .sharding import shard_range  # noqa: F401

@@ -61,3 +61,12 @@ def test_world_size_2_gloo_sharded_decode(tmp_path):
     ref, _, _ = od.decode(hm, center, scale, score, shift_coord=True)
     assert np.array_equal(np.load(tmp_path / "gathered.npy"), ref)
     assert np.load(tmp_path / "tmax.npy")[0] == 0.2
+
+
+def test_warmup_multistep_lr_schedule():
+    from mindpose_amd.utils import WarmupMultiStepDecayLR
+    # reference recipe: lr 1e-3, warm-up 500 steps, milestones [170, 200] epochs (configs/hrnet/hrnet_w32_ascend.yaml:75-88)
+    sched = WarmupMultiStepDecayLR(1e-3, warmup=500, milestones=[170, 200], decay_rate=0.1, steps_per_epoch=100)
+    assert sched(0) == 0.0 and abs(sched(250) - 5e-4) < 1e-12 and sched(500) == 1e-3
+    assert sched(169 * 100 - 1) == 1e-3 and abs(sched(169 * 100) - 1e-4) < 1e-15
+    assert abs(sched(199 * 100) - 1e-5) < 1e-15 and abs(sched(10 ** 6) - 1e-5) < 1e-15
