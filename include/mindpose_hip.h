@@ -231,6 +231,31 @@ size_t mp_conv_wgrad_workspace_bytes(const mp_conv_desc* desc);
 int mp_conv_wgrad(const mp_conv_desc* desc, const float* x_dev, const float* dz_dev, float* dw_dev, int accumulate,
                   void* workspace_dev, size_t workspace_bytes, mp_stream_t stream);
 
+/* ---- fp16 matrix-core inference path (amp level O2 / O3; BASELINE.json configs[4] "fp16 MFMA") -----------------------
+ * Replaces what mindspore.amp.auto_mixed_precision(network, "O2") does to the cells of mindpose/models/backbones/hrnet.py
+ * when they run on the Ascend cube unit: fp16 conv operands, fp32 accumulation, BatchNorm in fp32, fp16 activations.
+ * Activations are CHANNEL-BLOCKED fp16, [N][ceil(C/8)][H][W][8] ("c8"; padding channels zero), weights are packed
+ * [ceil(Cin/32)][kh*kw][4][Cout_pad16][8] fp16; scale / shift are fp32 arrays of Cout_pad16 entries (zero beyond Cout).
+ * Only the plain output mapping is supported (desc->out_* must equal the conv output, kernel 1x1 or 3x3); the
+ * exchange-unit up-sampling runs in mp_f16_fuse_upsample_sum.  variant -1 = heuristic, 0..4 = forced tile shape. */
+size_t mp_f16_packed_weight_bytes(int cout, int cin, int kh, int kw);
+size_t mp_f16_activation_bytes(int n, int c, int h, int w);
+int mp_f16_pack_weight(const float* w_dev, void* packed_dev, int cout, int cin, int kh, int kw, mp_stream_t stream);
+int mp_f16_to_c8(const float* x_nchw_dev, void* out_c8_dev, int n, int c, int h, int w, mp_stream_t stream);
+int mp_f16_from_c8(const void* x_c8_dev, float* out_nchw_dev, int n, int c, int h, int w, mp_stream_t stream);
+int mp_f16_conv2d_fwd(const mp_conv_desc* desc, int variant, const void* x_c8_dev, const void* packed_w_dev,
+                      const float* scale_dev, const float* shift_dev, const void* res1_c8_dev, const void* res2_c8_dev,
+                      void* out_c8_dev, mp_stream_t stream);
+int mp_f16_fuse_upsample_sum(const void* base_dev, const void* t1_dev, int s1, const void* t2_dev, int s2, const void* t3_dev,
+                             int s3, void* out_dev, int n, int c, int h, int w, int relu, mp_stream_t stream);
+int mp_plan_add_conv_f16(mp_plan* plan, const mp_conv_desc* desc, int variant, const void* x_c8_dev, const void* packed_w_dev,
+                         const float* scale_dev, const float* shift_dev, const void* res1_c8_dev, const void* res2_c8_dev,
+                         void* out_c8_dev);
+int mp_plan_add_fuse_sum_f16(mp_plan* plan, const void* base_dev, const void* t1_dev, int s1, const void* t2_dev, int s2,
+                             const void* t3_dev, int s3, void* out_dev, int n, int c, int h, int w, int relu);
+/* to_c8 != 0: NCHW fp32 -> c8 fp16, else c8 fp16 -> NCHW fp32 */
+int mp_plan_add_layout_f16(mp_plan* plan, int to_c8, const void* x_dev, void* out_dev, int n, int c, int h, int w);
+
 /* Diagnostics: only a library built with -DMP_CONV_STAMPS=1 (never the product build) records per-workgroup
  * phase cycle counters (8 x uint64 per workgroup) of each conv launch into this device buffer; the product
  * build returns MP_ERR_UNSUPPORTED. */

@@ -66,6 +66,17 @@ _PROTOTYPES = {
     "mp_conv_wgrad_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "mp_conv_wgrad": (c_int, [ctypes.POINTER(ConvDesc), c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_size_t, ctypes.c_void_p]),
     "mp_adamw_step": (c_int, [c_f32p] * 4 + [c_size_t] + [ctypes.c_float] * 5 + [ctypes.c_void_p]),
+    # fp16 matrix-core inference path (channel-blocked activations)
+    "mp_f16_packed_weight_bytes": (c_size_t, [c_int] * 4),
+    "mp_f16_activation_bytes": (c_size_t, [c_int] * 4),
+    "mp_f16_pack_weight": (c_int, [c_f32p, c_f32p] + [c_int] * 4 + [ctypes.c_void_p]),
+    "mp_f16_to_c8": (c_int, [c_f32p, c_f32p] + [c_int] * 4 + [ctypes.c_void_p]),
+    "mp_f16_from_c8": (c_int, [c_f32p, c_f32p] + [c_int] * 4 + [ctypes.c_void_p]),
+    "mp_f16_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_int] + [c_f32p] * 7 + [ctypes.c_void_p]),
+    "mp_f16_fuse_upsample_sum": (c_int, [c_f32p, c_f32p, c_int, c_f32p, c_int, c_f32p, c_int, c_f32p] + [c_int] * 5 + [ctypes.c_void_p]),
+    "mp_plan_add_conv_f16": (c_int, [ctypes.c_void_p, ctypes.POINTER(ConvDesc), c_int] + [c_f32p] * 7),
+    "mp_plan_add_fuse_sum_f16": (c_int, [ctypes.c_void_p, c_f32p, c_f32p, c_int, c_f32p, c_int, c_f32p, c_int, c_f32p] + [c_int] * 5),
+    "mp_plan_add_layout_f16": (c_int, [ctypes.c_void_p, c_int, c_f32p, c_f32p] + [c_int] * 4),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
@@ -104,6 +115,7 @@ def ptr(t):
     """Device pointer of a contiguous fp32/int32/fp64 CUDA tensor (None -> NULL)."""
     if t is None:
         return None
+    t = getattr(t, "c8_tensor", t)  # channel-blocked fp16 activation wrapper
     if not t.is_cuda:
         raise MindposeHipError("tensor must live on the GPU: the HIP path has no CPU fallback")
     if not t.is_contiguous():

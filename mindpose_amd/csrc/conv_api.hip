@@ -5,6 +5,7 @@
 
 #include <vector>
 
+#include "conv_f16.h"
 #include "conv_mfma.h"
 
 namespace mp {
@@ -243,8 +244,12 @@ using namespace mp;
 
 struct mp_plan {
     struct Entry {
-        int kind;  // 0 conv, 1 maxpool, 2 fuse-sum
+        int kind;  // 0 conv, 1 maxpool, 2 fuse-sum; fp16 layout: 3 conv, 4 fuse-sum, 5 NCHW fp32 -> c8, 6 c8 -> NCHW fp32
         ConvLaunch conv;
+        ConvF16Launch conv16;
+        const void* t16[3];
+        const void* x16;
+        void* out16;
         const float* x;
         float* out;
         int n, c, h, w;
@@ -353,6 +358,41 @@ int mp_plan_add_fuse_sum(mp_plan* plan, const float* base, const float* t1, int 
     return MP_OK;
 }
 
+int mp_plan_add_conv_f16(mp_plan* plan, const mp_conv_desc* desc, int variant, const void* x, const void* packed_w,
+                         const float* scale, const float* shift, const void* res1, const void* res2, void* out) {
+    if (!plan) return MP_ERR_NULL;
+    mp_plan::Entry e{};
+    e.kind = 3;
+    int rc = f16_build_launch(desc, variant, x, packed_w, scale, shift, res1, res2, out, e.conv16);
+    if (rc != MP_OK) return rc;
+    plan->entries.push_back(e);
+    return MP_OK;
+}
+
+int mp_plan_add_fuse_sum_f16(mp_plan* plan, const void* base, const void* t1, int s1, const void* t2, int s2, const void* t3,
+                             int s3, void* out, int n, int c, int h, int w, int relu) {
+    if (!plan || !base || !t1 || !out) return MP_ERR_NULL;
+    if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return MP_ERR_SHAPE;
+    mp_plan::Entry e{};
+    e.kind = 4;
+    e.x16 = base; e.out16 = out; e.n = n; e.c = c; e.h = h; e.w = w; e.relu = relu;
+    e.t16[0] = t1; e.t16[1] = t2; e.t16[2] = t3; e.s[0] = s1; e.s[1] = s2; e.s[2] = s3;
+    plan->entries.push_back(e);
+    return MP_OK;
+}
+
+int mp_plan_add_layout_f16(mp_plan* plan, int to_c8, const void* x, void* out, int n, int c, int h, int w) {
+    if (!plan || !x || !out) return MP_ERR_NULL;
+    if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return MP_ERR_SHAPE;
+    mp_plan::Entry e{};
+    e.kind = to_c8 ? 5 : 6;
+    if (to_c8) { e.x = reinterpret_cast<const float*>(x); e.out16 = out; }
+    else { e.x16 = x; e.out = reinterpret_cast<float*>(out); }
+    e.n = n; e.c = c; e.h = h; e.w = w;
+    plan->entries.push_back(e);
+    return MP_OK;
+}
+
 int mp_plan_size(const mp_plan* plan) { return plan ? (int)plan->entries.size() : MP_ERR_NULL; }
 
 int mp_plan_run_range(const mp_plan* plan, int first, int count, mp_stream_t stream) {
@@ -360,10 +400,23 @@ int mp_plan_run_range(const mp_plan* plan, int first, int count, mp_stream_t str
     if (first < 0 || count < 0 || (size_t)first + count > plan->entries.size()) return MP_ERR_SHAPE;
     for (int i = first; i < first + count; ++i) {
         const mp_plan::Entry& e = plan->entries[i];
-        int rc = e.kind == 0   ? launch(e.conv, as_stream(stream))
-                 : e.kind == 1 ? mp_maxpool3x3s2_same(e.x, e.out, e.n, e.c, e.h, e.w, stream)
-                               : mp_fuse_upsample_sum(e.x, e.t[0], e.s[0], e.t[1], e.s[1], e.t[2], e.s[2], e.out, e.n, e.c,
-                                                      e.h, e.w, e.relu, stream);
+        int rc;
+        switch (e.kind) {
+            case 0: rc = launch(e.conv, as_stream(stream)); break;
+            case 1: rc = mp_maxpool3x3s2_same(e.x, e.out, e.n, e.c, e.h, e.w, stream); break;
+            case 2:
+                rc = mp_fuse_upsample_sum(e.x, e.t[0], e.s[0], e.t[1], e.s[1], e.t[2], e.s[2], e.out, e.n, e.c, e.h, e.w, e.relu,
+                                          stream);
+                break;
+            case 3: rc = f16_launch(e.conv16, as_stream(stream)); break;
+            case 4:
+                rc = mp_f16_fuse_upsample_sum(e.x16, e.t16[0], e.s[0], e.t16[1], e.s[1], e.t16[2], e.s[2], e.out16, e.n, e.c, e.h,
+                                              e.w, e.relu, stream);
+                break;
+            case 5: rc = mp_f16_to_c8(e.x, e.out16, e.n, e.c, e.h, e.w, stream); break;
+            case 6: rc = mp_f16_from_c8(e.x16, e.out, e.n, e.c, e.h, e.w, stream); break;
+            default: rc = MP_ERR_UNSUPPORTED;
+        }
         if (rc != MP_OK) return rc;
     }
     return MP_OK;
@@ -382,6 +435,12 @@ int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]) {
         info[5] = (int64_t)e.conv.lds_bytes; info[6] = ct; info[7] = pt; info[8] = e.conv.p.CK; info[9] = e.conv.p.G;
         info[10] = e.conv.p.R;
         info[11] = variant_light(e.conv.variant) ? 1 : 0;
+    } else if (e.kind == 3) {
+        int ct, pt;
+        f16_variant_dims(e.conv16.variant, ct, pt);
+        info[1] = e.conv16.ks; info[2] = e.conv16.stride; info[3] = e.conv16.variant; info[4] = e.conv16.p.total_blocks;
+        info[5] = (int64_t)e.conv16.lds_bytes; info[6] = ct; info[7] = pt; info[8] = e.conv16.p.PK * 8; info[9] = e.conv16.p.G;
+        info[10] = e.conv16.p.R;
     }
     return MP_OK;
 }

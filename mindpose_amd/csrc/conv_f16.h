@@ -1,0 +1,51 @@
+// fp16-MFMA convolution family (amp level O2/O3 inference): declarations shared by conv_f16.hip and the launch plan.
+//
+// Activations live in HBM channel-blocked, [N][ceil(C/8)][H][W][8] halfs ("c8"): one pixel of one 8-channel block is a
+// 16-byte element, which is exactly the per-lane operand of v_mfma_f32_16x16x32_f16 (8 consecutive k), so global ->
+// LDS staging is plain 16-byte copies and every MFMA operand is ONE ds_read_b128 at any tap offset or stride.
+// Padding channels of the last block are kept zero by every producer.
+#pragma once
+#include "common.h"
+
+namespace mp {
+
+struct ConvF16Params {
+    const void* x;       // c8 halfs
+    const void* wp;      // packed weights [Cin_pad32/32][T][4][Cout_pad16][8] halfs
+    const float* scale;  // [Cout_pad16] fp32 (zero beyond Cout)
+    const float* shift;  // [Cout_pad16]
+    const void* res1;    // c8 halfs, output geometry
+    const void* res2;
+    void* out;           // c8 halfs
+    int N, C8in, H, W;
+    int Cout, Cout_pad16, C8out;
+    int Ho, Wo, pad_t, pad_l;
+    int R, G, Rin, Wp, img_plane;
+    int plane;       // LDS elements (16 B) per 8-channel plane: == 0 (mod 16) for stride 1, odd for stride 2
+    int PK;          // planes per chunk (multiple of 4 = one MFMA k-step of 32 channels)
+    int PKs;         // planes per chunk that are staged (PK, or C8in when the single chunk is zero padded)
+    int n_chunks, n_ct, tiles_y, tiles_n;
+    int ncols, upc;  // staged columns per row, staging units per plane (G * Rin * ncols)
+    int in_buf;      // LDS elements per input buffer (PK * plane)
+    int w_buf;       // LDS elements per weight buffer (PK * T * CT)
+    int nbuf;
+    int relu;
+    unsigned magic_upc, magic_ncols, magic_rin, magic_rwo, magic_wo;
+    int RWo, total_blocks;
+};
+
+struct ConvF16Launch {
+    ConvF16Params p;
+    int ks, stride, variant;
+    size_t lds_bytes;
+};
+
+enum ConvF16Variant { F_CT32_PT192 = 0, F_CT64_PT192 = 1, F_CT48_PT192 = 2, F_CT64_PT96 = 3, F_CT32_PT96 = 4, F_CT64_PT384 = 5,
+                      F_CT32_PT384 = 6, F_COUNT = 7 };
+
+int f16_build_launch(const mp_conv_desc* desc, int variant, const void* x, const void* w, const float* scale,
+                     const float* shift, const void* res1, const void* res2, void* out, ConvF16Launch& L);
+int f16_launch(const ConvF16Launch& L, hipStream_t s);
+void f16_variant_dims(int v, int& ct, int& pt);
+
+}  // namespace mp

@@ -1,0 +1,604 @@
+// fp16-MFMA direct convolution (v_mfma_f32_16x16x32_f16, fp32 accumulate) over channel-blocked activations, plus the
+// layout converters and the exchange-unit sum in that layout.  See conv_f16.h for the data layout.
+//
+//   implicit GEMM:  rows (MFMA A) = output channels, columns (MFMA B) = output pixels, K = Cin x KS x KS; one k-step =
+//                   32 input channels = 4 channel-block planes, lane l feeding plane (l >> 4), pixel / cout (l & 15).
+//   D layout:       lane holds couts 4*(l>>4) .. +3 of one pixel (l & 15): four halfs = one 8-byte store into the pixel's
+//                   16-byte channel block; a wave's store instruction covers whole 256-byte runs.
+//   LDS:            input tile [PK planes][G images][Rin rows][Wp cols] x 16 B with zero halo; plane stride == 0 mod 16
+//                   elements (stride 1) or odd (stride 2) keeps every ds_read_b128 conflict-free; weight tile
+//                   [PK/4][T][4][CT] x 16 B is a lane-linear image of the A operands.
+//   pipeline:       as the fp32 kernel: chunk c+1 is fetched into registers (range-checked buffer loads) while chunk c
+//                   computes, operand fragments are read one k-step ahead, one barrier per chunk.
+//   epilogue:       fp32 scale/shift (folded BatchNorm or bias), up to two residual tensors, ReLU, one rounding to fp16.
+#include "conv_f16.h"
+
+namespace mp {
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr unsigned kOob = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes < 0x7FFFFFF0u ? bytes : 0x7FFFFFF0u), 0x00020000);
+}
+__device__ __forceinline__ unsigned fastdiv(unsigned e, unsigned d, unsigned magic) { return d == 1 ? e : __umulhi(e, magic); }
+
+inline unsigned magic_of(unsigned d) { return d <= 1 ? 0u : (unsigned)(0x100000000ULL / d) + 1u; }
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, int NI, int NW>
+__global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvF16Params p) {
+    static_assert(WAVES_P * WAVES_C == 4, "4 waves per workgroup");
+    constexpr int T = KS * KS;
+    constexpr int CT = 16 * CS * WAVES_C;
+    extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
+    u32x4* __restrict__ lds_in = smem16;                     // [nbuf][in_buf]
+    u32x4* __restrict__ lds_w = smem16 + p.nbuf * p.in_buf;  // [nbuf][w_buf]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp_i = wave % WAVES_P, wc_i = wave / WAVES_P;
+    const int lq = lane >> 4, lr = lane & 15;
+
+    // XCD-aware tile id (blocks b, b+8, ... share an XCD): every XCD walks a contiguous run of tiles
+    int b = blockIdx.x;
+    {
+        const int nb = p.total_blocks, q8 = nb >> 3, r8 = nb & 7, xcd = b & 7, j = b >> 3;
+        b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
+    }
+    const int ct = b % p.n_ct;
+    b /= p.n_ct;
+    const int ty = b % p.tiles_y, tn = b / p.tiles_y;
+    const int n0 = tn * p.G, y0 = ty * p.R;
+    const int y_in0 = y0 * S - p.pad_t;
+    const int HW = p.H * p.W;
+
+    {
+        const int n16 = p.nbuf * p.in_buf;
+        const u32x4 zero = (u32x4){0u, 0u, 0u, 0u};
+        for (int i = tid; i < n16; i += 256) lds_in[i] = zero;
+    }
+
+    unsigned isrc[NI];
+    int idst[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const unsigned u = tid + 256 * i;
+        isrc[i] = kOob;
+        idst[i] = -1;
+        if (u < (unsigned)(p.PKs * p.upc)) {
+            const unsigned pl = fastdiv(u, p.upc, p.magic_upc);
+            const unsigned rem = u - pl * p.upc;
+            const unsigned gr = fastdiv(rem, p.ncols, p.magic_ncols);
+            const unsigned xu = rem - gr * p.ncols;
+            const unsigned g = p.G > 1 ? fastdiv(gr, p.Rin, p.magic_rin) : 0u;
+            const unsigned r = gr - g * p.Rin;
+            const int yin = y_in0 + (int)r;
+            if (yin >= 0 && yin < p.H && n0 + (int)g < p.N) {
+                isrc[i] = ((g * p.C8in + pl) * HW + yin * p.W + xu) * 16u;
+                idst[i] = (int)((pl << 20) | (pl * p.plane + g * p.img_plane + r * p.Wp + p.pad_l + xu));
+            }
+        }
+    }
+
+    int b_off[PS];  // pixel operand
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps) {
+        unsigned pl = (unsigned)((wp_i * PS + ps) * 16 + lr);
+        if (pl >= (unsigned)(p.G * p.RWo)) pl = 0;
+        const unsigned g = fastdiv(pl, p.RWo, p.magic_rwo);
+        const unsigned rem = pl - g * p.RWo;
+        const unsigned y = fastdiv(rem, p.Wo, p.magic_wo);
+        const unsigned xx = rem - y * p.Wo;
+        b_off[ps] = lq * p.plane + g * p.img_plane + (y * S) * p.Wp + xx * S;
+    }
+    int a_off[CS];  // weight operand
+#pragma unroll
+    for (int cs = 0; cs < CS; ++cs) a_off[cs] = lq * CT + (wc_i * CS + cs) * 16 + lr;
+
+    f32x4 acc[PS][CS];
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps)
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs) acc[ps][cs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int n_img = min(p.G, p.N - n0);
+    const char* xg = reinterpret_cast<const char*>(p.x) + (size_t)n0 * p.C8in * HW * 16;
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(xg, (size_t)n_img * p.C8in * HW * 16);
+    const int w_units = p.PK * T * CT;  // 16-B elements of one weight chunk of this cout tile
+    const __amdgpu_buffer_rsrc_t rs_w =
+        make_rsrc(p.wp, (size_t)p.n_chunks * p.PK * T * p.Cout_pad16 * 16);
+    unsigned wsrc[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int u = tid + 256 * i;
+        const int row = u / CT, c = u - row * CT;
+        wsrc[i] = (u < w_units && ct * CT + c < p.Cout_pad16) ? (unsigned)(row * p.Cout_pad16 + ct * CT + c) * 16u : kOob;
+    }
+
+    u32x4 vin[NI], vw[NW];
+    auto stage_load = [&](int ch) {
+        const int c0 = ch * p.PK;
+        const unsigned xo = (unsigned)c0 * HW * 16u;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            unsigned off = isrc[i] + xo;
+            if (idst[i] >= 0 && c0 + (idst[i] >> 20) >= p.C8in) off = kOob;  // zero planes beyond the real channels
+            vin[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
+        }
+        const unsigned wo = (unsigned)ch * p.PK * T * p.Cout_pad16 * 16u;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) vw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wsrc[i] == kOob ? kOob : wsrc[i] + wo, 0, 0);
+    };
+    auto stage_store = [&](int buf) {
+        u32x4* __restrict__ din = lds_in + buf * p.in_buf;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (idst[i] >= 0) din[idst[i] & 0xFFFFF] = vin[i];
+        u32x4* __restrict__ dw = lds_w + buf * p.w_buf;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int u = tid + 256 * i;
+            if (u < w_units) dw[u] = vw[i];
+        }
+    };
+
+    stage_load(0);
+    __syncthreads();  // zero fill complete before the first copy lands
+    stage_store(0);
+    __syncthreads();
+
+    const int nq = p.PK >> 2;
+    for (int ch = 0; ch < p.n_chunks; ++ch) {
+        const int buf = p.nbuf == 2 ? (ch & 1) : 0;
+        const bool more = ch + 1 < p.n_chunks;
+        if (more) stage_load(ch + 1);
+        const u32x4* __restrict__ lin = lds_in + buf * p.in_buf;
+        const u32x4* __restrict__ lw = lds_w + buf * p.w_buf;
+        u32x4 bv[PS], av[CS];
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps) bv[ps] = lin[b_off[ps]];
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs) av[cs] = lw[a_off[cs]];
+        for (int q = 0; q < nq; ++q) {
+            const int in_q = q * 4 * p.plane;
+            const int w_q = q * T * 4 * CT;
+            const int qn = min(q + 1, nq - 1);  // the final prefetch re-reads a valid k-step (discarded)
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int tn = (t + 1 < T) ? t + 1 : 0;
+                const int in_off = ((t + 1 < T) ? in_q : qn * 4 * p.plane) + (tn / KS) * p.Wp + (tn % KS);
+                const int w_off = ((t + 1 < T) ? w_q : qn * T * 4 * CT) + tn * 4 * CT;
+                u32x4 bn[PS], an[CS];
+#pragma unroll
+                for (int ps = 0; ps < PS; ++ps) bn[ps] = lin[b_off[ps] + in_off];
+#pragma unroll
+                for (int cs = 0; cs < CS; ++cs) an[cs] = lw[a_off[cs] + w_off];
+#pragma unroll
+                for (int ps = 0; ps < PS; ++ps)
+#pragma unroll
+                    for (int cs = 0; cs < CS; ++cs)
+                        acc[ps][cs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[cs]),
+                                                                              __builtin_bit_cast(f16x8, bv[ps]), acc[ps][cs], 0, 0, 0);
+                {
+                    constexpr int NR = PS + CS, NM = PS * CS, NPAIR = NR < NM ? NR : NM;
+#pragma unroll
+                    for (int i = 0; i < NPAIR; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+                    }
+                    if (NM > NPAIR) __builtin_amdgcn_sched_group_barrier(0x008, NM - NPAIR, 0);
+                    if (NR > NPAIR) __builtin_amdgcn_sched_group_barrier(0x100, NR - NPAIR, 0);
+                }
+#pragma unroll
+                for (int ps = 0; ps < PS; ++ps) bv[ps] = bn[ps];
+#pragma unroll
+                for (int cs = 0; cs < CS; ++cs) av[cs] = an[cs];
+            }
+        }
+        if (more) {
+            stage_store(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: lane = (pixel lr of tile ps) x (couts 4*lq .. +3 of tile cs) -> one 8-byte store
+    const int plane_o = p.Ho * p.Wo;
+    const size_t grp = (size_t)n0 * p.C8out * plane_o * 16;
+    const size_t grp_bytes = (size_t)n_img * p.C8out * plane_o * 16;
+    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(reinterpret_cast<char*>(p.out) + grp, grp_bytes);
+    unsigned pix_off[PS];
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps) {
+        const unsigned pl = (unsigned)((wp_i * PS + ps) * 16 + lr);
+        const unsigned pc = pl < (unsigned)(p.G * p.RWo) ? pl : 0u;
+        const unsigned g = fastdiv(pc, p.RWo, p.magic_rwo);
+        const unsigned rem = pc - g * p.RWo;
+        const unsigned y = fastdiv(rem, p.Wo, p.magic_wo);
+        const unsigned xx = rem - y * p.Wo;
+        const int yy = y0 + y;
+        const bool ok = pl < (unsigned)(p.G * p.RWo) && n0 + (int)g < p.N && yy < p.Ho;
+        pix_off[ps] = ok ? (g * p.C8out * plane_o + yy * p.Wo + xx) * 16u : kOob;
+    }
+    f32x4 sc[CS], sh[CS];
+    unsigned co_off[CS];
+#pragma unroll
+    for (int cs = 0; cs < CS; ++cs) {
+        const int co = ct * CT + (wc_i * CS + cs) * 16 + 4 * lq;
+        const bool ok = co < p.C8out * 8;
+        const int cc = co < p.Cout_pad16 ? co : 0;
+        sc[cs] = *reinterpret_cast<const f32x4*>(p.scale + cc);
+        sh[cs] = *reinterpret_cast<const f32x4*>(p.shift + cc);
+        co_off[cs] = ok ? (unsigned)(co >> 3) * plane_o * 16u + ((co >> 2) & 1) * 8u : kOob;
+    }
+    u32x2 r1[CS][PS], r2[CS][PS];
+    if (p.res1) {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const char*>(p.res1) + grp, grp_bytes);
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs)
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps)
+                r1[cs][ps] = __builtin_amdgcn_raw_buffer_load_b64(rs, ((co_off[cs] | pix_off[ps]) & kOob) ? kOob : co_off[cs] + pix_off[ps], 0, 0);
+    }
+    if (p.res2) {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const char*>(p.res2) + grp, grp_bytes);
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs)
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps)
+                r2[cs][ps] = __builtin_amdgcn_raw_buffer_load_b64(rs, ((co_off[cs] | pix_off[ps]) & kOob) ? kOob : co_off[cs] + pix_off[ps], 0, 0);
+    }
+#pragma unroll
+    for (int cs = 0; cs < CS; ++cs)
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps) {
+            f32x4 v = acc[ps][cs] * sc[cs] + sh[cs];
+            if (p.res1) {
+                const f16x4 h = __builtin_bit_cast(f16x4, r1[cs][ps]);
+                v += (f32x4){(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+            }
+            if (p.res2) {
+                const f16x4 h = __builtin_bit_cast(f16x4, r2[cs][ps]);
+                v += (f32x4){(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+            }
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            const f16x4 o = (f16x4){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs_o,
+                                                  ((co_off[cs] | pix_off[ps]) & kOob) ? kOob : co_off[cs] + pix_off[ps], 0, 0);
+        }
+}
+
+constexpr int f16_ni(int ks) { return 10; }
+constexpr int f16_nw(int ks) { return ks == 3 ? 9 : 8; }
+
+template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C>
+int launch_f16_variant(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
+    auto kern = conv_f16_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, f16_ni(KS), f16_nw(KS)>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(256), lds_bytes, s, p);
+    return check_launch();
+}
+
+template <int KS, int S>
+int launch_f16_ks(const ConvF16Params& p, int variant, size_t lds_bytes, hipStream_t s) {
+    switch (variant) {
+        case F_CT32_PT192: return launch_f16_variant<KS, S, 3, 2, 4, 1>(p, lds_bytes, s);
+        case F_CT64_PT192: return launch_f16_variant<KS, S, 3, 4, 4, 1>(p, lds_bytes, s);
+        case F_CT48_PT192: return launch_f16_variant<KS, S, 3, 3, 4, 1>(p, lds_bytes, s);
+        case F_CT64_PT96: return launch_f16_variant<KS, S, 3, 2, 2, 2>(p, lds_bytes, s);
+        case F_CT32_PT96: return launch_f16_variant<KS, S, 3, 1, 2, 2>(p, lds_bytes, s);
+        default: return MP_ERR_UNSUPPORTED;
+    }
+}
+
+const int kLdsMax = 150 * 1024;
+const int kLdsBudget = 78 * 1024;  // two workgroups per CU
+
+bool f16_configure(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
+    int CT, PT;
+    f16_variant_dims(variant, CT, PT);
+    ConvF16Params& p = L.p;
+    const int S = d.stride, KS = d.kh, T = KS * KS;
+    p.N = d.n; p.H = d.h; p.W = d.w; p.Cout = d.cout;
+    p.C8in = (d.cin + 7) / 8;
+    p.Cout_pad16 = round_up(d.cout, 16);
+    p.C8out = (d.cout + 7) / 8;
+    p.Ho = d.conv_h; p.Wo = d.conv_w; p.pad_t = d.pad_top; p.pad_l = d.pad_left;
+    const int planes_total = round_up(d.cin, 32) / 8;
+    if (p.Wo > PT) return false;
+    const int ni = f16_ni(KS), nw = f16_nw(KS);
+    int rows_fit = PT / p.Wo;
+    if (rows_fit > p.Ho) rows_fit = p.Ho;
+    bool found = false;
+    for (int pass = 0; pass < 2 && !found; ++pass) {  // pass 0: two workgroups per CU, pass 1: whatever fits
+        const long long budget = pass == 0 ? kLdsBudget : kLdsMax;
+        for (int R = rows_fit; R >= 1 && !found; --R) {
+            p.R = R;
+            p.G = 1;
+            if (R == p.Ho) {
+                p.G = PT / (p.Ho * p.Wo);
+                if (p.G > p.N) p.G = p.N;
+                if (p.G < 1) p.G = 1;
+            }
+            p.RWo = p.R * p.Wo;
+            p.Rin = (p.R - 1) * S + KS;
+            p.Wp = (p.Wo - 1) * S + KS;
+            if (p.Wp < p.pad_l + p.W && p.pad_l + p.W - p.Wp <= 2) p.Wp = p.pad_l + p.W;
+            p.img_plane = p.Rin * p.Wp;
+            p.plane = S == 1 ? round_up(p.G * p.img_plane, 16) : ((p.G * p.img_plane) | 1);
+            p.ncols = p.W < p.Wp - p.pad_l ? p.W : p.Wp - p.pad_l;
+            if (p.ncols < 1) return false;
+            p.upc = p.G * p.Rin * p.ncols;
+            for (int pk = planes_total; pk >= 4; pk -= 4) {
+                if (planes_total % pk) continue;
+                const int n_chunks = planes_total / pk;
+                const int pks = (n_chunks == 1 && p.C8in < pk) ? p.C8in : pk;
+                if ((long long)pks * p.upc > (long long)ni * 256) continue;
+                if ((long long)pk * T * CT > (long long)nw * 256) continue;
+                const int nbuf = n_chunks > 1 ? 2 : 1;
+                const long long bytes = (long long)nbuf * (pk * p.plane + pk * T * CT) * 16;
+                if (bytes > budget) continue;
+                p.PK = pk; p.PKs = pks; p.n_chunks = n_chunks; p.nbuf = nbuf;
+                found = true;
+                break;
+            }
+        }
+    }
+    if (!found) return false;
+    p.in_buf = p.PK * p.plane;
+    p.w_buf = p.PK * T * CT;
+    p.n_ct = (p.Cout_pad16 + CT - 1) / CT;
+    p.tiles_y = (p.G > 1 || p.R >= p.Ho) ? 1 : (p.Ho + p.R - 1) / p.R;
+    p.tiles_n = (p.N + p.G - 1) / p.G;
+    p.relu = d.relu;
+    p.magic_upc = magic_of(p.upc);
+    p.magic_ncols = magic_of(p.ncols);
+    p.magic_rin = magic_of(p.Rin);
+    p.magic_rwo = magic_of(p.RWo);
+    p.magic_wo = magic_of(p.Wo);
+    p.total_blocks = p.n_ct * p.tiles_y * p.tiles_n;
+    L.ks = KS; L.stride = S; L.variant = variant;
+    L.lds_bytes = (size_t)p.nbuf * (p.in_buf + p.w_buf) * 16;
+    return L.lds_bytes <= (size_t)kLdsMax;
+}
+
+int f16_validate(const mp_conv_desc* d) {
+    if (!d) return MP_ERR_NULL;
+    if (d->n <= 0 || d->cin <= 0 || d->h <= 0 || d->w <= 0 || d->cout <= 0) return MP_ERR_SHAPE;
+    if (d->kh != d->kw || !(d->kh == 1 || d->kh == 3)) return MP_ERR_UNSUPPORTED;
+    if (!(d->stride == 1 || d->stride == 2)) return MP_ERR_UNSUPPORTED;
+    if (d->pad_top < 0 || d->pad_left < 0 || d->pad_top > d->kh || d->pad_left > d->kw) return MP_ERR_SHAPE;
+    if (d->conv_h <= 0 || d->conv_w <= 0) return MP_ERR_SHAPE;
+    // plain output mapping only: the exchange-unit up-sampling has its own streaming kernel in this layout
+    if (d->out_h != d->conv_h || d->out_w != d->conv_w || d->out_mul != 1 || d->out_rep != 1 || d->out_off_y != 0 ||
+        d->out_off_x != 0 || d->tap_dilation_unused != 0)
+        return MP_ERR_UNSUPPORTED;
+    // every input row / column a tap reads must exist or be zero padding on the top / left only up to pad; the bottom /
+    // right overhang is covered by the LDS halo, as in the fp32 kernel
+    if ((long long)d->n * ((d->cout + 7) / 8) * d->conv_h * d->conv_w * 16 >= (1LL << 40)) return MP_ERR_UNSUPPORTED;
+    return MP_OK;
+}
+
+// [Cout,Cin,kh,kw] fp32 -> [Cin_pad32/32][T][4][Cout_pad16][8] fp16 (round to nearest even), zero padded
+__global__ __launch_bounds__(256) void pack_weight_f16_kernel(const float* __restrict__ w, _Float16* __restrict__ out,
+                                                              int cout, int cin, int kh, int kw, int kq, int cout_pad16) {
+    const int T = kh * kw;
+    const size_t total = (size_t)kq * T * 4 * cout_pad16 * 8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7);
+        size_t r = i >> 3;
+        const int co = (int)(r % cout_pad16);
+        r /= cout_pad16;
+        const int g = (int)(r & 3);
+        r >>= 2;
+        const int t = (int)(r % T);
+        const int q = (int)(r / T);
+        const int ci = q * 32 + g * 8 + j;
+        float v = 0.f;
+        if (co < cout && ci < cin) v = w[(((size_t)co * cin + ci) * kh + t / kw) * kw + t % kw];
+        out[i] = (_Float16)v;
+    }
+}
+
+// NCHW fp32 -> c8 fp16: one thread per (n, block, pixel): 8 strided plane reads (coalesced across lanes), one 16-B store
+__global__ __launch_bounds__(256) void to_c8_kernel(const float* __restrict__ x, u32x4* __restrict__ out, int n, int c, int hw) {
+    const int c8 = (c + 7) >> 3;
+    const size_t total = (size_t)n * c8 * hw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int pix = (int)(i % hw);
+        const size_t r = i / hw;
+        const int blk = (int)(r % c8);
+        const size_t img = r / c8;
+        f16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ch = blk * 8 + j;
+            v[j] = ch < c ? (_Float16)x[(img * c + ch) * hw + pix] : (_Float16)0.f;
+        }
+        out[i] = __builtin_bit_cast(u32x4, v);
+    }
+}
+
+// c8 fp16 -> NCHW fp32
+__global__ __launch_bounds__(256) void from_c8_kernel(const u32x4* __restrict__ x, float* __restrict__ out, int n, int c, int hw) {
+    const int c8 = (c + 7) >> 3;
+    const size_t total = (size_t)n * c8 * hw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int pix = (int)(i % hw);
+        const size_t r = i / hw;
+        const int blk = (int)(r % c8);
+        const size_t img = r / c8;
+        const f16x8 v = __builtin_bit_cast(f16x8, x[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ch = blk * 8 + j;
+            if (ch < c) out[(img * c + ch) * hw + pix] = (float)v[j];
+        }
+    }
+}
+
+// exchange-unit sum in the c8 layout: out = act(((base + up(t1)) + up(t2)) + up(t3)), nearest up-sampling by s_i;
+// fp32 sums in the reference's term order, one rounding to fp16
+__global__ __launch_bounds__(256) void fuse_sum_f16_kernel(const u32x4* __restrict__ base, const u32x4* __restrict__ t1, int s1,
+                                                           const u32x4* __restrict__ t2, int s2, const u32x4* __restrict__ t3,
+                                                           int s3, u32x4* __restrict__ out, int planes, int h, int w, int relu) {
+    const size_t total = (size_t)planes * h * w;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % w);
+        const size_t r = i / w;
+        const int y = (int)(r % h);
+        const size_t pl = r / h;
+        const f16x8 bv = __builtin_bit_cast(f16x8, base[i]);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)bv[j];
+        auto add = [&](const u32x4* __restrict__ t, int s) {
+            const int hs = h / s, ws = w / s;
+            const f16x8 tv = __builtin_bit_cast(f16x8, t[(pl * hs + y / s) * ws + x / s]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += (float)tv[j];
+        };
+        add(t1, s1);
+        if (t2) add(t2, s2);
+        if (t3) add(t3, s3);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (_Float16)(relu ? fmaxf(v[j], 0.f) : v[j]);
+        out[i] = __builtin_bit_cast(u32x4, o);
+    }
+}
+
+int grid_for(size_t total) {
+    size_t blocks = (total + 255) / 256;
+    return (int)(blocks > 8192 ? 8192 : (blocks < 1 ? 1 : blocks));
+}
+
+}  // namespace
+
+void f16_variant_dims(int v, int& ct, int& pt) {
+    static const int cts[F_COUNT] = {32, 64, 48, 64, 32, 64, 32};
+    static const int pts[F_COUNT] = {192, 192, 192, 96, 96, 384, 384};
+    ct = cts[v];
+    pt = pts[v];
+}
+
+int f16_build_launch(const mp_conv_desc* desc, int variant, const void* x, const void* w, const float* scale,
+                     const float* shift, const void* res1, const void* res2, void* out, ConvF16Launch& L) {
+    int rc = f16_validate(desc);
+    if (rc != MP_OK) return rc;
+    if (!x || !w || !scale || !shift || !out) return MP_ERR_NULL;
+    if (variant >= F_COUNT) return MP_ERR_UNSUPPORTED;
+    bool ok = false;
+    if (variant >= 0) {
+        ok = variant <= F_CT32_PT96 && f16_configure(*desc, variant, L);
+    } else {
+        // heuristic: widest cout tile that divides the padded couts, 192-pixel tiles unless the grid would not fill the chip
+        const int c16 = round_up(desc->cout, 16);
+        int order[5], n = 0;
+        if (c16 % 64 == 0) { order[n++] = F_CT64_PT192; order[n++] = F_CT64_PT96; order[n++] = F_CT32_PT192; order[n++] = F_CT32_PT96; }
+        else if (c16 % 48 == 0) { order[n++] = F_CT48_PT192; order[n++] = F_CT64_PT96; order[n++] = F_CT32_PT192; }
+        else { order[n++] = F_CT32_PT192; order[n++] = F_CT32_PT96; order[n++] = F_CT64_PT96; }
+        double best = -1;
+        for (int i = 0; i < n; ++i) {
+            ConvF16Launch c{};
+            if (!f16_configure(*desc, order[i], c)) continue;
+            int CT, PT;
+            f16_variant_dims(order[i], CT, PT);
+            const double pix_eff = (double)(c.p.G * c.p.RWo) / PT;
+            const double co_eff = (double)desc->cout / (c.p.n_ct * CT);
+            const double waves = (double)c.p.total_blocks / 512.0;
+            const double fill = waves >= 1.0 ? waves / (double)((long long)waves + ((waves - (long long)waves) > 1e-9 ? 1 : 0)) : waves;
+            const double score = pix_eff * co_eff * fill;
+            if (score > best * 1.02) { best = score; L = c; ok = true; }
+        }
+    }
+    if (!ok) return MP_ERR_UNSUPPORTED;
+    L.p.x = x; L.p.wp = w; L.p.scale = scale; L.p.shift = shift; L.p.res1 = res1; L.p.res2 = res2; L.p.out = out;
+    return MP_OK;
+}
+
+int f16_launch(const ConvF16Launch& L, hipStream_t s) {
+    if (L.ks == 1) return L.stride == 1 ? launch_f16_ks<1, 1>(L.p, L.variant, L.lds_bytes, s) : launch_f16_ks<1, 2>(L.p, L.variant, L.lds_bytes, s);
+    if (L.ks == 3) return L.stride == 1 ? launch_f16_ks<3, 1>(L.p, L.variant, L.lds_bytes, s) : launch_f16_ks<3, 2>(L.p, L.variant, L.lds_bytes, s);
+    return MP_ERR_UNSUPPORTED;
+}
+
+}  // namespace mp
+
+using namespace mp;
+
+extern "C" {
+
+size_t mp_f16_packed_weight_bytes(int cout, int cin, int kh, int kw) {
+    if (cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0) return 0;
+    return (size_t)round_up(cin, 32) * kh * kw * round_up(cout, 16) * 2;
+}
+
+size_t mp_f16_activation_bytes(int n, int c, int h, int w) {
+    if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return 0;
+    return (size_t)n * ((c + 7) / 8) * h * w * 16;
+}
+
+int mp_f16_pack_weight(const float* w, void* packed, int cout, int cin, int kh, int kw, mp_stream_t stream) {
+    if (!w || !packed) return MP_ERR_NULL;
+    if (cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0) return MP_ERR_SHAPE;
+    const int kq = round_up(cin, 32) / 32, cp = round_up(cout, 16);
+    const size_t total = (size_t)kq * kh * kw * 4 * cp * 8;
+    hipLaunchKernelGGL(pack_weight_f16_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), w,
+                       reinterpret_cast<_Float16*>(packed), cout, cin, kh, kw, kq, cp);
+    return check_launch();
+}
+
+int mp_f16_to_c8(const float* x, void* out, int n, int c, int h, int w, mp_stream_t stream) {
+    if (!x || !out) return MP_ERR_NULL;
+    if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return MP_ERR_SHAPE;
+    const size_t total = (size_t)n * ((c + 7) / 8) * h * w;
+    hipLaunchKernelGGL(to_c8_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, reinterpret_cast<u32x4*>(out), n, c, h * w);
+    return check_launch();
+}
+
+int mp_f16_from_c8(const void* x, float* out, int n, int c, int h, int w, mp_stream_t stream) {
+    if (!x || !out) return MP_ERR_NULL;
+    if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return MP_ERR_SHAPE;
+    const size_t total = (size_t)n * ((c + 7) / 8) * h * w;
+    hipLaunchKernelGGL(from_c8_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), reinterpret_cast<const u32x4*>(x), out, n, c, h * w);
+    return check_launch();
+}
+
+int mp_f16_conv2d_fwd(const mp_conv_desc* desc, int variant, const void* x, const void* packed_w, const float* scale,
+                      const float* shift, const void* res1, const void* res2, void* out, mp_stream_t stream) {
+    ConvF16Launch L{};
+    int rc = f16_build_launch(desc, variant, x, packed_w, scale, shift, res1, res2, out, L);
+    if (rc != MP_OK) return rc;
+    return f16_launch(L, as_stream(stream));
+}
+
+int mp_f16_fuse_upsample_sum(const void* base, const void* t1, int s1, const void* t2, int s2, const void* t3, int s3, void* out,
+                             int n, int c, int h, int w, int relu, mp_stream_t stream) {
+    if (!base || !t1 || !out) return MP_ERR_NULL;
+    if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return MP_ERR_SHAPE;
+    const int ss[3] = {s1, t2 ? s2 : 1, t3 ? s3 : 1};
+    for (int i = 0; i < 3; ++i)
+        if (ss[i] < 1 || h % ss[i] || w % ss[i]) return MP_ERR_SHAPE;
+    if (t3 && !t2) return MP_ERR_NULL;
+    const int planes = n * ((c + 7) / 8);
+    const size_t total = (size_t)planes * h * w;
+    hipLaunchKernelGGL(fuse_sum_f16_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const u32x4*>(base), reinterpret_cast<const u32x4*>(t1), s1,
+                       reinterpret_cast<const u32x4*>(t2), s2, reinterpret_cast<const u32x4*>(t3), s3,
+                       reinterpret_cast<u32x4*>(out), planes, h, w, relu);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -165,7 +165,7 @@ class HRModule(nn.Module):
             # rides as res2 on the launch that precedes it (or as res1 of the first launch when i == 0).
             down_terms = [j for j in range(nb) if j < i]
             up_terms = [j for j in range(nb) if j > i]
-            vec = xs[i].shape[3] % 4 == 0  # the streaming fuse-sum kernel moves 16 B per lane
+            vec = plan.half or xs[i].shape[3] % 4 == 0  # the streaming fuse-sum kernel moves 16 B per lane
             acc = xs[0] if i == 0 else None
             ybuf = None
             # (a) down-sampling terms j < i: 3x3 s2 chains whose last conv accumulates into ybuf in its epilogue;

@@ -61,32 +61,42 @@ class BatchNorm2d(nn.Module):
 _TUNE_CACHE: Dict[Tuple, int] = {}
 
 
-def tune_conv_variant(lib, d, x, packed, scale, shift, res1, res2, out) -> int:
-    """Pick the tile variant for one conv launch shape by timing the candidates once (HIP events, 3 launches each) on
-    the layer's real buffers; -1 = library heuristic when tuning is off (MINDPOSE_AUTOTUNE=0) or pointless (tiny
-    layers).  Results are cached per shape, so a network's ~40 distinct shapes are tuned once per process."""
+class ActC8:
+    """fp16 activation in the channel-blocked layout of the fp16 matrix-core path: physical tensor
+    ``[N][ceil(C/8)][H][W][8]`` halfs (padding channels zero), ``shape`` = the logical NCHW shape."""
+
+    def __init__(self, n: int, c: int, h: int, w: int, device) -> None:
+        self.shape = torch.Size((n, c, h, w))
+        self.c8_tensor = torch.zeros(n, (c + 7) // 8, h, w, 8, device=device, dtype=torch.float16)
+        self.device = self.c8_tensor.device
+
+    def data_ptr(self) -> int:
+        return self.c8_tensor.data_ptr()
+
+    def to_nchw(self) -> torch.Tensor:
+        """fp32 NCHW copy (tests / debugging)."""
+        n, c, h, w = self.shape
+        return self.c8_tensor.permute(0, 1, 4, 2, 3).reshape(n, -1, h, w)[:, :c].float().contiguous()
+
+
+def _autotune(key, macs, n_variants, launch) -> int:
+    """Time ``launch(v)`` for every tile variant once (HIP events, 3 launches each; a non-zero return code = variant not
+    available) and cache the winner per launch shape; -1 = library heuristic when tuning is off (MINDPOSE_AUTOTUNE=0) or
+    pointless (tiny layers)."""
     if os.environ.get("MINDPOSE_AUTOTUNE", "1") == "0":
         return -1
-    key = tuple(getattr(d, f) for f, _ in d._fields_) + (res1 is not None, res2 is not None, str(out.device))
     hit = _TUNE_CACHE.get(key)
     if hit is not None:
         return hit
-    macs = d.n * d.conv_h * d.conv_w * d.cout * d.cin * d.kh * d.kw
     best, best_t = -1, None
     if macs >= (1 << 26):
-        stream = _lib.stream()
-        # in-place accumulation (out aliases res1) must not be disturbed by trial launches: tune into a scratch copy
-        alias = res1 is not None and res1.data_ptr() == out.data_ptr()
-        trial_out = torch.empty_like(out) if alias else out
-        for v in range(8):
-            args = (ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(res1),
-                    _lib.ptr(res2), _lib.ptr(trial_out), stream)
-            if lib.mp_conv2d_fwd_variant(*args) != 0:
+        for v in range(n_variants):
+            if launch(v) != 0:
                 continue
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(3):
-                lib.mp_conv2d_fwd_variant(*args)
+                launch(v)
             e1.record()
             e1.synchronize()
             t = e0.elapsed_time(e1)
@@ -96,12 +106,33 @@ def tune_conv_variant(lib, d, x, packed, scale, shift, res1, res2, out) -> int:
     return best
 
 
+def tune_conv_variant(lib, d, x, packed, scale, shift, res1, res2, out, half: bool = False) -> int:
+    """Pick the tile variant for one conv launch shape by timing the candidates on the layer's real buffers.  Results
+    are cached per shape, so a network's ~40 distinct shapes are tuned once per process."""
+    key = tuple(getattr(d, f) for f, _ in d._fields_) + (res1 is not None, res2 is not None, str(out.device), half)
+    macs = d.n * d.conv_h * d.conv_w * d.cout * d.cin * d.kh * d.kw
+    stream = _lib.stream()
+    # in-place accumulation (out aliases res1) must not be disturbed by trial launches: tune into a scratch copy
+    alias = res1 is not None and res1.data_ptr() == out.data_ptr()
+    trial_out = out
+    if alias:
+        trial_out = ActC8(*out.shape, out.device) if half else torch.empty_like(out)
+    fn = lib.mp_f16_conv2d_fwd if half else lib.mp_conv2d_fwd_variant
+
+    def launch(v):
+        return fn(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(res1),
+                  _lib.ptr(res2), _lib.ptr(trial_out), stream)
+
+    return _autotune(key, macs, 5 if half else 8, launch)
+
+
 class Plan:
     """A recorded forward: native ``mp_plan`` + the tensors it points into."""
 
-    def __init__(self, device: torch.device) -> None:
+    def __init__(self, device: torch.device, half: bool = False) -> None:
         self.lib = _lib.load()
         self.device = device
+        self.half = half  # amp O2/O3: fp16 matrix-core kernels over channel-blocked fp16 activations
         self.handle = ctypes.c_void_p(self.lib.mp_plan_create())
         if not self.handle:
             raise _lib.MindposeHipError("mp_plan_create failed")
@@ -123,10 +154,34 @@ class Plan:
         except Exception:
             pass
 
-    def alloc(self, *shape: int) -> torch.Tensor:
+    def alloc(self, *shape: int):
+        """Activation buffer of the plan's compute type (fp32 NCHW tensor, or ActC8 in fp16 mode)."""
+        if self.half:
+            t = ActC8(*shape, self.device)
+            self.keep.append(t.c8_tensor)
+            return t
+        return self.alloc_f32(*shape)
+
+    def alloc_f32(self, *shape: int) -> torch.Tensor:
         t = torch.empty(shape, device=self.device, dtype=torch.float32)
         self.keep.append(t)
         return t
+
+    def to_c8(self, x: torch.Tensor) -> "ActC8":
+        """NCHW fp32 -> channel-blocked fp16 (first entry of an fp16 plan)."""
+        n, c, h, w = x.shape
+        out = self.alloc(n, c, h, w)
+        _lib.check(self.lib.mp_plan_add_layout_f16(self.handle, 1, _lib.ptr(x), _lib.ptr(out), n, c, h, w), "mp_plan_add_layout_f16")
+        self.layer_info.append(dict(kind="to_c8", n=n, c=c, h=h, w=w, macs=0))
+        return out
+
+    def from_c8(self, x: "ActC8") -> torch.Tensor:
+        """channel-blocked fp16 -> NCHW fp32 (the network output handed to the decoder / loss)."""
+        n, c, h, w = x.shape
+        out = self.alloc_f32(n, c, h, w)
+        _lib.check(self.lib.mp_plan_add_layout_f16(self.handle, 0, _lib.ptr(x), _lib.ptr(out), n, c, h, w), "mp_plan_add_layout_f16")
+        self.layer_info.append(dict(kind="from_c8", n=n, c=c, h=h, w=w, macs=0))
+        return out
 
     def run(self) -> None:
         """Replay the recorded forward: as one hipGraph launch once captured (MINDPOSE_HIP_GRAPH=0 disables it),
@@ -177,6 +232,16 @@ class Plan:
         if key in self._packed:
             return self._packed[key]
         w = weight.detach().to(self.device, torch.float32).contiguous()
+        if self.half:
+            if transposed:
+                raise NotImplementedError("the fp16 path has no transposed-convolution kernels yet (amp_level O0 has)")
+            nbytes = self.lib.mp_f16_packed_weight_bytes(cout, cin, k, k)
+            packed = torch.empty(nbytes // 2, device=self.device, dtype=torch.float16)
+            _lib.check(self.lib.mp_f16_pack_weight(_lib.ptr(w), _lib.ptr(packed), cout, cin, k, k, _lib.stream()),
+                       "mp_f16_pack_weight")
+            self.keep += [w, packed]
+            self._packed[key] = packed
+            return packed
         nbytes = self.lib.mp_conv_packed_weight_bytes(cout, cin, k, k)
         packed = torch.empty(nbytes // 4, device=self.device, dtype=torch.float32)
         _lib.check(self.lib.mp_conv_pack_weight(_lib.ptr(w), _lib.ptr(packed), cout, cin, k, k, int(transposed), py, px,
@@ -195,6 +260,10 @@ class Plan:
         else:
             scale = torch.ones(cout, device=self.device)
             shift = bias.detach().float().to(self.device).contiguous() if bias is not None else torch.zeros(cout, device=self.device)
+        if self.half:  # the fp16 kernel reads 4 couts per lane: arrays padded to Cout_pad16 with zeros
+            pad = (-cout) % 16
+            scale = torch.cat([scale, scale.new_zeros(pad)]).contiguous()
+            shift = torch.cat([shift, shift.new_zeros(pad)]).contiguous()
         self.keep += [scale, shift]
         self._folded[key] = (scale, shift)
         return scale, shift
@@ -224,19 +293,23 @@ class Plan:
         d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=conv.out_channels, kh=k, kw=k, stride=s, pad_top=pad,
                           pad_left=pad, conv_h=ho, conv_w=wo, out_h=oh, out_w=ow, out_mul=upsample, out_rep=upsample,
                           out_off_y=0, out_off_x=0, relu=int(relu), tap_dilation_unused=0)
+        if self.half and upsample != 1:
+            raise NotImplementedError("fp16 plans add up-sampled terms with fuse_sum, not through the conv epilogue")
         variant = self._tune(d, x, packed, scale, shift, res1, res2, out)
-        _lib.check(self.lib.mp_plan_add_conv_variant(self.handle, ctypes.byref(d), variant, _lib.ptr(x), _lib.ptr(packed),
-                                                     _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(res1), _lib.ptr(res2),
-                                                     _lib.ptr(out)), "mp_plan_add_conv_variant")
-        self.layer_info.append(dict(kind="conv", k=k, stride=s, cin=cin, cout=conv.out_channels, h=h, w=w, n=n,
-                                    macs=n * ho * wo * conv.out_channels * cin * k * k))
+        add = self.lib.mp_plan_add_conv_f16 if self.half else self.lib.mp_plan_add_conv_variant
+        _lib.check(add(self.handle, ctypes.byref(d), variant, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift),
+                       _lib.ptr(res1), _lib.ptr(res2), _lib.ptr(out)), "mp_plan_add_conv")
+        self.layer_info.append(dict(kind="conv_f16" if self.half else "conv", k=k, stride=s, cin=cin, cout=conv.out_channels,
+                                    h=h, w=w, n=n, macs=n * ho * wo * conv.out_channels * cin * k * k))
         return out
 
     def _tune(self, d, x, packed, scale, shift, res1, res2, out) -> int:
-        return tune_conv_variant(self.lib, d, x, packed, scale, shift, res1, res2, out)
+        return tune_conv_variant(self.lib, d, x, packed, scale, shift, res1, res2, out, half=self.half)
 
     def deconv4x4s2(self, x: torch.Tensor, deconv: Conv2dTranspose, bn: BatchNorm2d, relu: bool = True) -> torch.Tensor:
         """Conv2dTranspose(k=4, s=2, p=1) + BN + ReLU as four 2x2 sub-pixel phase convolutions."""
+        if self.half:
+            raise NotImplementedError("the fp16 path has no transposed-convolution kernels yet (amp_level O0 has)")
         n, cin, h, w = x.shape
         cout = deconv.out_channels
         out = self.alloc(n, cout, 2 * h, 2 * w)
@@ -264,12 +337,14 @@ class Plan:
             if t is not None and tuple(t.shape) != (n, c, h // sc, w // sc):
                 raise ValueError(f"fuse term shape {tuple(t.shape)} does not match {(n, c, h // sc, w // sc)}")
             args += [_lib.ptr(t), int(sc)]
-        _lib.check(self.lib.mp_plan_add_fuse_sum(self.handle, _lib.ptr(base), *args, _lib.ptr(out), n, c, h, w, int(relu)),
-                   "mp_plan_add_fuse_sum")
+        add = self.lib.mp_plan_add_fuse_sum_f16 if self.half else self.lib.mp_plan_add_fuse_sum
+        _lib.check(add(self.handle, _lib.ptr(base), *args, _lib.ptr(out), n, c, h, w, int(relu)), "mp_plan_add_fuse_sum")
         self.layer_info.append(dict(kind="fuse_sum", n=n, c=c, h=h, w=w, terms=len(terms), macs=0))
         return out
 
     def maxpool3x3s2_same(self, x: torch.Tensor) -> torch.Tensor:
+        if self.half:
+            raise NotImplementedError("the fp16 path has no max-pool kernel yet (amp_level O0 has)")
         n, c, h, w = x.shape
         out = self.alloc(n, c, (h + 1) // 2, (w + 1) // 2)
         _lib.check(self.lib.mp_plan_add_maxpool(self.handle, _lib.ptr(x), _lib.ptr(out), n, c, h, w), "mp_plan_add_maxpool")
@@ -290,6 +365,7 @@ class PlannedModule(nn.Module):
         super().__init__()
         self._plans: Dict[Tuple, Plan] = {}
         self.training = False  # like mindspore.nn.Cell: inference mode until .train() / set_train(True)
+        self.amp_level = "O0"  # see auto_mixed_precision()
 
     def set_train(self, mode: bool = True):
         """mindspore.nn.Cell.set_train alias."""
@@ -313,7 +389,8 @@ class PlannedModule(nn.Module):
         return super()._load_from_state_dict(*args, **kwargs)
 
     def get_plan(self, shape, device) -> Plan:
-        key = (tuple(shape), str(device))
+        half = self.amp_level in ("O2", "O3")
+        key = (tuple(shape), str(device), half)
         plan = self._plans.get(key)
         if plan is None:
             if device.type != "cuda":
@@ -321,9 +398,10 @@ class PlannedModule(nn.Module):
                     "mindpose_amd networks run on the MI355X HIP path only (no CPU fallback): move the module and "
                     "its inputs to a CUDA device")
             with torch.no_grad():
-                plan = Plan(device)
-                plan.input = plan.alloc(*shape)
-                plan.output = self.emit(plan, plan.input)
+                plan = Plan(device, half=half)
+                plan.input = plan.alloc_f32(*shape)
+                out = self.emit(plan, plan.to_c8(plan.input) if half else plan.input)
+                plan.output = plan.from_c8(out) if isinstance(out, ActC8) else out
             self._plans[key] = plan
         return plan
 
@@ -341,3 +419,19 @@ class PlannedModule(nn.Module):
             plan.input.copy_(x)
         plan.run()
         return plan.output
+
+
+def auto_mixed_precision(network: nn.Module, amp_level: str = "O0") -> nn.Module:
+    """``mindspore.amp.auto_mixed_precision(network, amp_level)`` for the planned networks (what
+    ``mindspore.Model(amp_level=...)`` applies in the reference's tools/train.py:176-181).
+
+    O0: fp32 everywhere (fp32 MFMA kernels).  O2 / O3: inference runs the fp16 matrix-core kernels - fp16 conv operands
+    and activations, fp32 accumulation, BatchNorm folded in fp32 - and hands fp32 heat maps to the decoder.  (O1 is not
+    offered: its white-list casts are a graph rewrite of the MindSpore cells with no counterpart here.)"""
+    if amp_level not in ("O0", "O2", "O3"):
+        raise ValueError(f"amp_level must be one of O0, O2, O3, got {amp_level!r}")
+    for m in network.modules():
+        if isinstance(m, PlannedModule):
+            m.amp_level = amp_level
+            m._plans.clear()
+    return network

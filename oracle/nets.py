@@ -45,11 +45,11 @@ class _P:
     statistics updated in place with momentum 0.9, mindspore.nn.BatchNorm2d training) and keeps the autograd graph
     of the parameter tensors (used to check the HIP backward kernels)."""
 
-    def __init__(self, params, prefix="", train=False):
-        self.params, self.prefix, self.train = params, prefix, train
+    def __init__(self, params, prefix="", train=False, amp=False):
+        self.params, self.prefix, self.train, self.amp = params, prefix, train, amp
 
     def sub(self, name):
-        return _P(self.params, f"{self.prefix}{name}.", self.train)
+        return _P(self.params, f"{self.prefix}{name}.", self.train, self.amp)
 
     def __getitem__(self, name):
         t = self.params[self.prefix + name]
@@ -63,12 +63,22 @@ class _P:
         return (self.prefix + name) in self.params
 
 
+def _r(p, x):
+    """amp O2 emulation: every cell output is an fp16 tensor (mindspore.amp.auto_mixed_precision casts the cells to
+    fp16 and keeps BatchNorm in fp32 with an fp16 output) - round to nearest-even fp16, keep computing in fp32."""
+    return x.half().float() if p.amp else x
+
+
 def _conv(p, x, stride=1, padding=0):
     bias = p["bias"] if p.has("bias") else None
+    if p.amp:  # fp16 operands, fp32 accumulation (cube unit), fp16 output
+        return _r(p, F.conv2d(x, _r(p, p["weight"]), None if bias is None else _r(p, bias), stride=stride, padding=padding))
     return F.conv2d(x, p["weight"], bias, stride=stride, padding=padding)
 
 
 def _bn(p, x):
+    if p.amp and not p.train:
+        return _r(p, F.batch_norm(x, p["moving_mean"], p["moving_variance"], p["gamma"], p["beta"], training=False, eps=BN_EPS))
     if p.train:  # torch momentum 0.1 == MindSpore momentum 0.9 (weight of the OLD moving value)
         return F.batch_norm(x, p["moving_mean"], p["moving_variance"], p["gamma"], p["beta"],
                             training=True, momentum=0.1, eps=BN_EPS)
@@ -80,7 +90,7 @@ def _basic_block(p, x):
     """hrnet.py:66-83: relu(bn2(conv2(relu(bn1(conv1 x)))) + identity)."""
     out = F.relu(_bn(p.sub("bn1"), _conv(p.sub("conv1"), x, 1, 1)))
     out = _bn(p.sub("bn2"), _conv(p.sub("conv2"), out, 1, 1))
-    return F.relu(out + x)
+    return F.relu(_r(p, out + x))
 
 
 def _bottleneck(p, x, stride=1):
@@ -92,7 +102,7 @@ def _bottleneck(p, x, stride=1):
     if p.has("down_sample.0.weight"):
         ds = p.sub("down_sample")
         identity = _bn(ds.sub("1"), _conv(ds.sub("0"), x, stride, 0))
-    return F.relu(out + identity)
+    return F.relu(_r(p, out + identity))
 
 
 def _hr_module(p, xs, num_branches, num_blocks, multi_scale_output):
@@ -120,16 +130,17 @@ def _hr_module(p, xs, num_branches, num_blocks, multi_scale_output):
                     t = _bn(s.sub("1"), _conv(s.sub("0"), t, 2, 1))
                     if k != i - j - 1:
                         t = F.relu(t)
-            y = t if y is None else y + t
+            y = t if y is None else _r(p, y + t)
         outs.append(F.relu(y))
     return outs
 
 
-def hrnet_forward(params, x, name="hrnet_w32", prefix="", train=False):
-    """HRNet.forward_feature hrnet.py:559-605."""
+def hrnet_forward(params, x, name="hrnet_w32", prefix="", train=False, amp=False):
+    """HRNet.forward_feature hrnet.py:559-605.  ``amp``: op-by-op fp16 emulation of amp level O2 (eval only)."""
     cfg = HRNET_CFG[name]
-    p = _P(params, prefix, train)
+    p = _P(params, prefix, train, amp)
     x = torch.as_tensor(x) if train else torch.as_tensor(x, dtype=torch.float32)  # train: keep dtype (fp64 oracle runs)
+    x = _r(p, x)
     x = F.relu(_bn(p.sub("bn1"), _conv(p.sub("conv1"), x, 2, 1)))
     x = F.relu(_bn(p.sub("bn2"), _conv(p.sub("conv2"), x, 2, 1)))
     for b in range(cfg["stage1"]["num_blocks"][0]):
@@ -189,9 +200,9 @@ def resnet_forward(params, x, name="resnet50", prefix=""):
     return x
 
 
-def hrnet_head_forward(params, x, prefix="", train=False):
+def hrnet_head_forward(params, x, prefix="", train=False, amp=False):
     """HRNetHead.construct hrnet_head.py:47-49: 1x1 conv + bias."""
-    return _conv(_P(params, prefix, train).sub("head"), x)
+    return _conv(_P(params, prefix, train, amp).sub("head"), x)
 
 
 def simple_baseline_head_forward(params, x, prefix="", num_deconv_layers=3):
@@ -212,9 +223,13 @@ def net_forward_train(params, x, backbone="hrnet_w32", head="hrnet_head"):
     return hrnet_head_forward(params, f, prefix="head.", train=True)
 
 
-def net_forward(params, x, backbone="hrnet_w32", head="hrnet_head"):
-    """Net.construct networks.py:39-44 (no neck exists in the reference)."""
+def net_forward(params, x, backbone="hrnet_w32", head="hrnet_head", amp=False):
+    """Net.construct networks.py:39-44 (no neck exists in the reference).  ``amp=True``: HRNet + HRNetHead under the
+    op-by-op fp16 emulation of amp level O2 (every cell output rounded to fp16, BatchNorm computed in fp32)."""
     with torch.no_grad():
+        if amp:
+            f = hrnet_forward(params, x, backbone, prefix="backbone.", amp=True)
+            return hrnet_head_forward(params, f, prefix="head.", amp=True)
         if backbone.startswith("hrnet"):
             f = hrnet_forward(params, x, backbone, prefix="backbone.")
         else:
