@@ -28,6 +28,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_FP16_MFMA_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense" (--amp O2 runs only)
+F16_VARIANT_TEMPLATE = {0: "3,2,4,1", 1: "3,4,4,1", 2: "3,3,4,1", 3: "3,2,2,2", 4: "3,1,2,2", 5: "3,2,4,1", 6: "3,4,4,1",
+                        7: "3,3,4,1", 8: "3,2,2,2", 9: "3,1,2,2"}
 VARIANT_TEMPLATE = {0: "3,2,4,1", 1: "3,4,4,1", 2: "3,3,4,1", 3: "3,2,2,2", 4: "3,1,2,2", 5: "3,2,2,2", 6: "3,2,4,1",
                     7: "3,1,2,2"}  # PS,CS,WAVES_P,WAVES_C
 
@@ -54,6 +57,8 @@ def log(msg):
 def kernel_name(info):
     """Template head <KS,S,PS,CS,WAVES_P,WAVES_C> of the instantiation; '/occ3' marks the light build (rocprof shows it as
     the trailing template argument OCC = 3)."""
+    if info["kind_id"] == 3:
+        return f"conv_f16_kernel<{info['ks']},{info['stride']},{F16_VARIANT_TEMPLATE[info['variant']]}>" + ("/occ3" if info.get("light") else "")
     return f"conv_mfma_kernel<{info['ks']},{info['stride']},{VARIANT_TEMPLATE[info['variant']]}>" + ("/occ3" if info.get("light") else "")
 
 
@@ -91,13 +96,14 @@ def pmc_traffic(kernel):
 
 
 def roofline_report(plan, reps=5, layers_csv=""):
+    peak = PEAK_FP16_MFMA_TFLOPS if plan.half else PEAK_FP32_MFMA_TFLOPS
     per_entry = time_plan_entries(plan, reps)
     if layers_csv:
         with open(layers_csv, "w") as f:
             f.write("index,kind,kernel,us,tflops,n,cin,cout,k,stride,h,w,workgroups,lds_bytes,cin_chunk,images_per_tile,rows_per_tile\n")
             for i, t in enumerate(per_entry):
                 e = plan.entry_info(i)
-                name = kernel_name(e) if e["kind_id"] == 0 else e["kind"]
+                name = kernel_name(e) if e["kind_id"] in (0, 3) else e["kind"]
                 tf = 2.0 * e.get("macs", 0) / t / 1e12 if t > 0 else 0.0
                 f.write(f"{i},{e['kind']},\"{name}\",{t * 1e6:.2f},{tf:.2f},{e.get('n', '')},{e.get('cin', e.get('c', ''))},"
                         f"{e.get('cout', '')},{e.get('k', '')},{e.get('stride', '')},{e.get('h', '')},{e.get('w', '')},"
@@ -105,7 +111,7 @@ def roofline_report(plan, reps=5, layers_csv=""):
     groups = {}
     for i, t in enumerate(per_entry):
         info = plan.entry_info(i)
-        if info["kind_id"] != 0:
+        if info["kind_id"] not in (0, 3):
             continue
         g = groups.setdefault(kernel_name(info), dict(time=0.0, flops=0.0, launches=0))
         g["time"] += t
@@ -117,13 +123,13 @@ def roofline_report(plan, reps=5, layers_csv=""):
     fam_f = sum(v["flops"] for v in groups.values())
     achieved = g["flops"] / g["time"] / 1e12
     return {
-        "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(dom),
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+        "frac": round(achieved / peak, 4), "traffic": pmc_traffic(dom),
         "kernel": dom, "launches_per_step": g["launches"],
         "flop_per_launch": round(g["flops"] / g["launches"]), "avg_launch_us": round(g["time"] / g["launches"] * 1e6, 2),
         "share_of_conv_time": round(g["time"] / fam_t, 3),
         "all_conv_launches": {"launches_per_step": sum(v["launches"] for v in groups.values()),
-                              "achieved": round(fam_f / fam_t / 1e12, 2), "frac": round(fam_f / fam_t / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                              "achieved": round(fam_f / fam_t / 1e12, 2), "frac": round(fam_f / fam_t / 1e12 / peak, 4),
                               "sum_launch_ms": round(fam_t * 1e3, 3)},
         "per_kernel": {k: {"launches": v["launches"], "ms": round(v["time"] * 1e3, 3),
                            "tflops": round(v["flops"] / v["time"] / 1e12, 2)} for k, v in sorted(groups.items())},
@@ -245,6 +251,8 @@ def main():
     ap.add_argument("--workload", default="hrnet_w32", choices=list(WORKLOADS) + ["hrnet_w32_train"],
                     help="hrnet_w32 = BASELINE.json metric / configs[2] (default); the others are extra measurements")
     ap.add_argument("--layers", default="", help="write a per-launch timing table (CSV) to this path")
+    ap.add_argument("--amp", default="O0", choices=["O0", "O2"],
+                    help="O0 = fp32 (the reference's eval precision, the headline); O2 = fp16 matrix-core kernels (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -271,6 +279,9 @@ def main():
         return train_bench(args, mp, dev, dist, world, rank)
     backbone, head, (ih, iw), dec_kw, flip, workload_desc = WORKLOADS[args.workload]
     net = mp.init_synthetic(mp.create_network(backbone, head), seed=0).to(dev).eval()
+    if args.amp != "O0":
+        mp.models.auto_mixed_precision(net, args.amp)
+        workload_desc += f" [amp {args.amp}: fp16 MFMA kernels, fp32 accumulate]"
     decoder = mp.create_decoder("topdown_heatmap", **dec_kw).to(dev)
     eval_net = mp.create_eval_network(net, decoder, output_raw=True)
     multi_run = None
@@ -325,7 +336,7 @@ def main():
                        else f"images/sec, {args.workload} top-down inference (backbone+head+decode)"),
             "value": round(world * n * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.amp == "O0" else "f16", "data": "synthetic",
             "config": {"workload": workload_desc,
                        "per_gpu_batch": n, "global_batch": n * world, "image": f"{ih}x{iw}", "heatmap": f"{ih // 4}x{iw // 4}x17",
                        "sharding": "crops split over ranks, no data-path collective",

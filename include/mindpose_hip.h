@@ -237,7 +237,8 @@ int mp_conv_wgrad(const mp_conv_desc* desc, const float* x_dev, const float* dz_
  * Activations are CHANNEL-BLOCKED fp16, [N][ceil(C/8)][H][W][8] ("c8"; padding channels zero), weights are packed
  * [ceil(Cin/32)][kh*kw][4][Cout_pad16][8] fp16; scale / shift are fp32 arrays of Cout_pad16 entries (zero beyond Cout).
  * Only the plain output mapping is supported (desc->out_* must equal the conv output, kernel 1x1 or 3x3); the
- * exchange-unit up-sampling runs in mp_f16_fuse_upsample_sum.  variant -1 = heuristic, 0..4 = forced tile shape. */
+ * exchange-unit up-sampling runs in mp_f16_fuse_upsample_sum.  variant -1 = heuristic, 0..9 = forced tile shape
+ * (5..9 = the light builds of 0..4: small chunks, three workgroups per CU). */
 size_t mp_f16_packed_weight_bytes(int cout, int cin, int kh, int kw);
 size_t mp_f16_activation_bytes(int n, int c, int h, int w);
 int mp_f16_pack_weight(const float* w_dev, void* packed_dev, int cout, int cin, int kh, int kw, mp_stream_t stream);

@@ -441,6 +441,7 @@ int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]) {
         info[1] = e.conv16.ks; info[2] = e.conv16.stride; info[3] = e.conv16.variant; info[4] = e.conv16.p.total_blocks;
         info[5] = (int64_t)e.conv16.lds_bytes; info[6] = ct; info[7] = pt; info[8] = e.conv16.p.PK * 8; info[9] = e.conv16.p.G;
         info[10] = e.conv16.p.R;
+        info[11] = f16_variant_light(e.conv16.variant) ? 1 : 0;
     }
     return MP_OK;
 }

@@ -40,8 +40,9 @@ struct ConvF16Launch {
     size_t lds_bytes;
 };
 
-enum ConvF16Variant { F_CT32_PT192 = 0, F_CT64_PT192 = 1, F_CT48_PT192 = 2, F_CT64_PT96 = 3, F_CT32_PT96 = 4, F_CT64_PT384 = 5,
-                      F_CT32_PT384 = 6, F_COUNT = 7 };
+enum ConvF16Variant { F_CT32_PT192 = 0, F_CT64_PT192 = 1, F_CT48_PT192 = 2, F_CT64_PT96 = 3, F_CT32_PT96 = 4,
+                      F_CT32_PT192_L = 5, F_CT64_PT192_L = 6, F_CT48_PT192_L = 7, F_CT64_PT96_L = 8, F_CT32_PT96_L = 9, F_COUNT = 10 };
+bool f16_variant_light(int v);
 
 int f16_build_launch(const mp_conv_desc* desc, int variant, const void* x, const void* w, const float* scale,
                      const float* shift, const void* res1, const void* res2, void* out, ConvF16Launch& L);

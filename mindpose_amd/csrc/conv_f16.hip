@@ -33,8 +33,8 @@ __device__ __forceinline__ unsigned fastdiv(unsigned e, unsigned d, unsigned mag
 inline unsigned magic_of(unsigned d) { return d <= 1 ? 0u : (unsigned)(0x100000000ULL / d) + 1u; }
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, int NI, int NW>
-__global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvF16Params p) {
+template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, int NI, int NW, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params p) {
     static_assert(WAVES_P * WAVES_C == 4, "4 waves per workgroup");
     constexpr int T = KS * KS;
     constexpr int CT = 16 * CS * WAVES_C;
@@ -155,10 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvF16Params p)
     __syncthreads();
 
     const int nq = p.PK >> 2;
-    for (int ch = 0; ch < p.n_chunks; ++ch) {
-        const int buf = p.nbuf == 2 ? (ch & 1) : 0;
-        const bool more = ch + 1 < p.n_chunks;
-        if (more) stage_load(ch + 1);
+    auto compute = [&](int buf) {
         const u32x4* __restrict__ lin = lds_in + buf * p.in_buf;
         const u32x4* __restrict__ lw = lds_w + buf * p.w_buf;
         u32x4 bv[PS], av[CS];
@@ -202,13 +199,18 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvF16Params p)
                 for (int cs = 0; cs < CS; ++cs) av[cs] = an[cs];
             }
         }
-        if (more) {
-            stage_store(buf ^ 1);
-            __syncthreads();
-        }
+    };
+    // all chunks but the last: fetch chunk c+1 into registers while chunk c computes
+    for (int ch = 0; ch + 1 < p.n_chunks; ++ch) {
+        const int buf = ch & 1;
+        stage_load(ch + 1);
+        compute(buf);
+        stage_store(buf ^ 1);
+        __syncthreads();
     }
-
-    // ---- epilogue: lane = (pixel lr of tile ps) x (couts 4*lq .. +3 of tile cs) -> one 8-byte store
+    // ---- output addressing, lane = (pixel lr of tile ps) x (couts 4*lq .. +3 of tile cs) -> one 8-byte store; the
+    //      residual tensors are fetched before the LAST chunk computes (the staging registers are free by then), so
+    //      their latency hides under that chunk's MFMA phase
     const int plane_o = p.Ho * p.Wo;
     const size_t grp = (size_t)n0 * p.C8out * plane_o * 16;
     const size_t grp_bytes = (size_t)n_img * p.C8out * plane_o * 16;
@@ -254,6 +256,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvF16Params p)
             for (int ps = 0; ps < PS; ++ps)
                 r2[cs][ps] = __builtin_amdgcn_raw_buffer_load_b64(rs, ((co_off[cs] | pix_off[ps]) & kOob) ? kOob : co_off[cs] + pix_off[ps], 0, 0);
     }
+    compute(p.nbuf == 2 ? ((p.n_chunks - 1) & 1) : 0);
+
+    // ---- epilogue: scale/shift, residuals (fetched before the MFMA loop), ReLU, one rounding, 8-byte stores
 #pragma unroll
     for (int cs = 0; cs < CS; ++cs)
 #pragma unroll
@@ -274,12 +279,14 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvF16Params p)
         }
 }
 
-constexpr int f16_ni(int ks) { return 10; }
-constexpr int f16_nw(int ks) { return ks == 3 ? 9 : 8; }
+// regular: big chunks, two workgroups per CU; light: small chunks / few staging registers, three per CU (<= 52 KiB LDS)
+constexpr int f16_ni(int ks, bool light) { return light ? 5 : 10; }
+constexpr int f16_nw(int ks, bool light) { return light ? 5 : (ks == 3 ? 9 : 8); }
+constexpr int f16_occ(bool light) { return light ? 3 : 2; }
 
-template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C>
+template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, bool LIGHT>
 int launch_f16_variant(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
-    auto kern = conv_f16_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, f16_ni(KS), f16_nw(KS)>;
+    auto kern = conv_f16_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, f16_ni(KS, LIGHT), f16_nw(KS, LIGHT), f16_occ(LIGHT)>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -293,11 +300,16 @@ int launch_f16_variant(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) 
 template <int KS, int S>
 int launch_f16_ks(const ConvF16Params& p, int variant, size_t lds_bytes, hipStream_t s) {
     switch (variant) {
-        case F_CT32_PT192: return launch_f16_variant<KS, S, 3, 2, 4, 1>(p, lds_bytes, s);
-        case F_CT64_PT192: return launch_f16_variant<KS, S, 3, 4, 4, 1>(p, lds_bytes, s);
-        case F_CT48_PT192: return launch_f16_variant<KS, S, 3, 3, 4, 1>(p, lds_bytes, s);
-        case F_CT64_PT96: return launch_f16_variant<KS, S, 3, 2, 2, 2>(p, lds_bytes, s);
-        case F_CT32_PT96: return launch_f16_variant<KS, S, 3, 1, 2, 2>(p, lds_bytes, s);
+        case F_CT32_PT192: return launch_f16_variant<KS, S, 3, 2, 4, 1, false>(p, lds_bytes, s);
+        case F_CT64_PT192: return launch_f16_variant<KS, S, 3, 4, 4, 1, false>(p, lds_bytes, s);
+        case F_CT48_PT192: return launch_f16_variant<KS, S, 3, 3, 4, 1, false>(p, lds_bytes, s);
+        case F_CT64_PT96: return launch_f16_variant<KS, S, 3, 2, 2, 2, false>(p, lds_bytes, s);
+        case F_CT32_PT96: return launch_f16_variant<KS, S, 3, 1, 2, 2, false>(p, lds_bytes, s);
+        case F_CT32_PT192_L: return launch_f16_variant<KS, S, 3, 2, 4, 1, true>(p, lds_bytes, s);
+        case F_CT64_PT192_L: return launch_f16_variant<KS, S, 3, 4, 4, 1, true>(p, lds_bytes, s);
+        case F_CT48_PT192_L: return launch_f16_variant<KS, S, 3, 3, 4, 1, true>(p, lds_bytes, s);
+        case F_CT64_PT96_L: return launch_f16_variant<KS, S, 3, 2, 2, 2, true>(p, lds_bytes, s);
+        case F_CT32_PT96_L: return launch_f16_variant<KS, S, 3, 1, 2, 2, true>(p, lds_bytes, s);
         default: return MP_ERR_UNSUPPORTED;
     }
 }
@@ -317,12 +329,14 @@ bool f16_configure(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
     p.Ho = d.conv_h; p.Wo = d.conv_w; p.pad_t = d.pad_top; p.pad_l = d.pad_left;
     const int planes_total = round_up(d.cin, 32) / 8;
     if (p.Wo > PT) return false;
-    const int ni = f16_ni(KS), nw = f16_nw(KS);
+    const bool light = f16_variant_light(variant);
+    const int ni = f16_ni(KS, light), nw = f16_nw(KS, light);
     int rows_fit = PT / p.Wo;
     if (rows_fit > p.Ho) rows_fit = p.Ho;
     bool found = false;
     for (int pass = 0; pass < 2 && !found; ++pass) {  // pass 0: two workgroups per CU, pass 1: whatever fits
-        const long long budget = pass == 0 ? kLdsBudget : kLdsMax;
+        const long long budget = pass == 0 ? (light ? 52 * 1024 : kLdsBudget) : kLdsMax;
+        if (pass == 1 && light) break;  // a light build that cannot run three per CU has no point
         for (int R = rows_fit; R >= 1 && !found; --R) {
             p.R = R;
             p.G = 1;
@@ -487,11 +501,12 @@ int grid_for(size_t total) {
 }  // namespace
 
 void f16_variant_dims(int v, int& ct, int& pt) {
-    static const int cts[F_COUNT] = {32, 64, 48, 64, 32, 64, 32};
-    static const int pts[F_COUNT] = {192, 192, 192, 96, 96, 384, 384};
+    static const int cts[F_COUNT] = {32, 64, 48, 64, 32, 32, 64, 48, 64, 32};
+    static const int pts[F_COUNT] = {192, 192, 192, 96, 96, 192, 192, 192, 96, 96};
     ct = cts[v];
     pt = pts[v];
 }
+bool f16_variant_light(int v) { return v >= F_CT32_PT192_L; }
 
 int f16_build_launch(const mp_conv_desc* desc, int variant, const void* x, const void* w, const float* scale,
                      const float* shift, const void* res1, const void* res2, void* out, ConvF16Launch& L) {
@@ -501,7 +516,7 @@ int f16_build_launch(const mp_conv_desc* desc, int variant, const void* x, const
     if (variant >= F_COUNT) return MP_ERR_UNSUPPORTED;
     bool ok = false;
     if (variant >= 0) {
-        ok = variant <= F_CT32_PT96 && f16_configure(*desc, variant, L);
+        ok = f16_configure(*desc, variant, L);
     } else {
         // heuristic: widest cout tile that divides the padded couts, 192-pixel tiles unless the grid would not fill the chip
         const int c16 = round_up(desc->cout, 16);
