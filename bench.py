@@ -58,7 +58,10 @@ def kernel_name(info):
     """Template head <KS,S,PS,CS,WAVES_P,WAVES_C> of the instantiation; '/occ3' marks the light build (rocprof shows it as
     the trailing template argument OCC = 3)."""
     if info["kind_id"] == 3:
-        return f"conv_f16_kernel<{info['ks']},{info['stride']},{F16_VARIANT_TEMPLATE[info['variant']]}>" + ("/occ3" if info.get("light") else "")
+        v = info["variant"]
+        if v >= 10:
+            return f"conv_f16_mt_kernel<{info['ks']},{info['stride']},{F16_VARIANT_TEMPLATE[v % 5]}>/occ{1 if v >= 15 else 2}"
+        return f"conv_f16_kernel<{info['ks']},{info['stride']},{F16_VARIANT_TEMPLATE[v]}>" + ("/occ3" if info.get("light") else "")
     return f"conv_mfma_kernel<{info['ks']},{info['stride']},{VARIANT_TEMPLATE[info['variant']]}>" + ("/occ3" if info.get("light") else "")
 
 

@@ -32,6 +32,8 @@ struct ConvF16Params {
     int relu;
     unsigned magic_upc, magic_ncols, magic_rin, magic_rwo, magic_wo;
     int RWo, total_blocks;
+    // persistent multi-tile kernel only: a workgroup keeps its weight slice in LDS and walks tiles_per_wg pixel tiles
+    int tiles_total, tiles_per_wg, n_groups;
 };
 
 struct ConvF16Launch {
@@ -40,13 +42,20 @@ struct ConvF16Launch {
     size_t lds_bytes;
 };
 
+// 0..4 tile shapes (cout tile x pixel tile), 5..9 their light builds, 10..14 / 15..19 the persistent multi-tile kernel
+// (weights resident in LDS, input tiles double-buffered) compiled for two / one workgroup per CU
 enum ConvF16Variant { F_CT32_PT192 = 0, F_CT64_PT192 = 1, F_CT48_PT192 = 2, F_CT64_PT96 = 3, F_CT32_PT96 = 4,
-                      F_CT32_PT192_L = 5, F_CT64_PT192_L = 6, F_CT48_PT192_L = 7, F_CT64_PT96_L = 8, F_CT32_PT96_L = 9, F_COUNT = 10 };
+                      F_CT32_PT192_L = 5, F_CT64_PT192_L = 6, F_CT48_PT192_L = 7, F_CT64_PT96_L = 8, F_CT32_PT96_L = 9,
+                      F_MT2_BASE = 10, F_MT1_BASE = 15, F_COUNT = 20 };
+inline bool f16_variant_mt(int v) { return v >= F_MT2_BASE; }
+inline int f16_variant_mt_occ(int v) { return v >= F_MT1_BASE ? 1 : 2; }
 bool f16_variant_light(int v);
 
 int f16_build_launch(const mp_conv_desc* desc, int variant, const void* x, const void* w, const float* scale,
                      const float* shift, const void* res1, const void* res2, void* out, ConvF16Launch& L);
 int f16_launch(const ConvF16Launch& L, hipStream_t s);
 void f16_variant_dims(int v, int& ct, int& pt);
+int f16_mt_launch(const ConvF16Launch& L, hipStream_t s);
+int f16_mt_ni(int occ);
 
 }  // namespace mp

@@ -11,27 +11,14 @@
 //   pipeline:       as the fp32 kernel: chunk c+1 is fetched into registers (range-checked buffer loads) while chunk c
 //                   computes, operand fragments are read one k-step ahead, one barrier per chunk.
 //   epilogue:       fp32 scale/shift (folded BatchNorm or bias), up to two residual tensors, ReLU, one rounding to fp16.
+#include <stdlib.h>
+
 #include "conv_f16.h"
+#include "conv_f16_dev.h"
 
 namespace mp {
 
 namespace {
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-
-constexpr unsigned kOob = 0x80000000u;
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, size_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes < 0x7FFFFFF0u ? bytes : 0x7FFFFFF0u), 0x00020000);
-}
-__device__ __forceinline__ unsigned fastdiv(unsigned e, unsigned d, unsigned magic) { return d == 1 ? e : __umulhi(e, magic); }
-
-inline unsigned magic_of(unsigned d) { return d <= 1 ? 0u : (unsigned)(0x100000000ULL / d) + 1u; }
-inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, int NI, int NW, int OCC>
 __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params p) {
@@ -317,7 +304,82 @@ int launch_f16_ks(const ConvF16Params& p, int variant, size_t lds_bytes, hipStre
 const int kLdsMax = 150 * 1024;
 const int kLdsBudget = 78 * 1024;  // two workgroups per CU
 
+// persistent multi-tile geometry: whole K in one "chunk", weights resident, two input buffers
+bool f16_configure_mt(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
+    int CT, PT;
+    f16_variant_dims(variant, CT, PT);
+    ConvF16Params& p = L.p;
+    const int S = d.stride, KS = d.kh, T = KS * KS;
+    if (!(KS == 3 || (KS == 1 && S == 1))) return false;
+    const int occ = f16_variant_mt_occ(variant);
+    p.N = d.n; p.H = d.h; p.W = d.w; p.Cout = d.cout;
+    p.C8in = (d.cin + 7) / 8;
+    p.Cout_pad16 = round_up(d.cout, 16);
+    p.C8out = (d.cout + 7) / 8;
+    p.Ho = d.conv_h; p.Wo = d.conv_w; p.pad_t = d.pad_top; p.pad_l = d.pad_left;
+    // 32-bit byte offsets over the whole tensors
+    if ((long long)d.n * p.C8in * d.h * d.w * 16 >= 0x7FFFFFF0LL || (long long)d.n * p.C8out * p.Ho * p.Wo * 16 >= 0x7FFFFFF0LL) return false;
+    p.PK = round_up(d.cin, 32) / 8;
+    p.PKs = p.C8in < p.PK ? p.C8in : p.PK;
+    p.n_chunks = 1; p.nbuf = 2;
+    if (p.Wo > PT) return false;
+    const int ni = f16_mt_ni(occ);
+    const long long budget = occ == 2 ? kLdsBudget : kLdsMax;
+    int rows_fit = PT / p.Wo;
+    if (rows_fit > p.Ho) rows_fit = p.Ho;
+    bool found = false;
+    for (int R = rows_fit; R >= 1 && !found; --R) {
+        p.R = R;
+        p.G = 1;
+        if (R == p.Ho) {
+            p.G = PT / (p.Ho * p.Wo);
+            if (p.G > p.N) p.G = p.N;
+            if (p.G < 1) p.G = 1;
+        }
+        p.RWo = p.R * p.Wo;
+        p.Rin = (p.R - 1) * S + KS;
+        p.Wp = (p.Wo - 1) * S + KS;
+        if (p.Wp < p.pad_l + p.W && p.pad_l + p.W - p.Wp <= 2) p.Wp = p.pad_l + p.W;
+        p.img_plane = p.Rin * p.Wp;
+        p.plane = S == 1 ? round_up(p.G * p.img_plane, 16) : ((p.G * p.img_plane) | 1);
+        p.ncols = p.W < p.Wp - p.pad_l ? p.W : p.Wp - p.pad_l;
+        if (p.ncols < 1) return false;
+        p.upc = p.G * p.Rin * p.ncols;
+        if ((long long)p.PKs * p.upc > (long long)ni * 256) continue;
+        const long long bytes = ((long long)p.PK * T * CT + 2LL * p.PK * p.plane) * 16;
+        if (bytes > budget) continue;
+        found = true;
+    }
+    if (!found) return false;
+    p.in_buf = p.PK * p.plane;
+    p.w_buf = p.PK * T * CT;
+    p.n_ct = (p.Cout_pad16 + CT - 1) / CT;
+    p.tiles_y = (p.G > 1 || p.R >= p.Ho) ? 1 : (p.Ho + p.R - 1) / p.R;
+    p.tiles_n = (p.N + p.G - 1) / p.G;
+    p.tiles_total = p.tiles_y * p.tiles_n;
+    int max_groups = occ * 256 / p.n_ct;
+    if (const char* e = getenv("MP_F16_MT_GROUPS")) {  // tests: force long tile runs on small problems
+        const int v = atoi(e);
+        if (v >= 1) max_groups = v;
+    }
+    if (max_groups < 1) max_groups = 1;
+    p.tiles_per_wg = (p.tiles_total + max_groups - 1) / max_groups;
+    if (p.tiles_per_wg < 2) return false;  // nothing to amortise: the one-tile kernel does the same work with less LDS
+    p.n_groups = (p.tiles_total + p.tiles_per_wg - 1) / p.tiles_per_wg;
+    p.relu = d.relu;
+    p.magic_upc = magic_of(p.upc);
+    p.magic_ncols = magic_of(p.ncols);
+    p.magic_rin = magic_of(p.Rin);
+    p.magic_rwo = magic_of(p.RWo);
+    p.magic_wo = magic_of(p.Wo);
+    p.total_blocks = p.n_ct * p.n_groups;
+    L.ks = KS; L.stride = S; L.variant = variant;
+    L.lds_bytes = (size_t)(p.w_buf + 2 * p.in_buf) * 16;
+    return L.lds_bytes <= (size_t)kLdsMax;
+}
+
 bool f16_configure(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
+    if (f16_variant_mt(variant)) return f16_configure_mt(d, variant, L);
     int CT, PT;
     f16_variant_dims(variant, CT, PT);
     ConvF16Params& p = L.p;
@@ -501,12 +563,12 @@ int grid_for(size_t total) {
 }  // namespace
 
 void f16_variant_dims(int v, int& ct, int& pt) {
-    static const int cts[F_COUNT] = {32, 64, 48, 64, 32, 32, 64, 48, 64, 32};
-    static const int pts[F_COUNT] = {192, 192, 192, 96, 96, 192, 192, 192, 96, 96};
-    ct = cts[v];
-    pt = pts[v];
+    static const int cts[5] = {32, 64, 48, 64, 32};
+    static const int pts[5] = {192, 192, 192, 96, 96};
+    ct = cts[v % 5];
+    pt = pts[v % 5];
 }
-bool f16_variant_light(int v) { return v >= F_CT32_PT192_L; }
+bool f16_variant_light(int v) { return v >= F_CT32_PT192_L && v < F_MT2_BASE; }
 
 int f16_build_launch(const mp_conv_desc* desc, int variant, const void* x, const void* w, const float* scale,
                      const float* shift, const void* res1, const void* res2, void* out, ConvF16Launch& L) {
@@ -544,6 +606,7 @@ int f16_build_launch(const mp_conv_desc* desc, int variant, const void* x, const
 }
 
 int f16_launch(const ConvF16Launch& L, hipStream_t s) {
+    if (f16_variant_mt(L.variant)) return f16_mt_launch(L, s);
     if (L.ks == 1) return L.stride == 1 ? launch_f16_ks<1, 1>(L.p, L.variant, L.lds_bytes, s) : launch_f16_ks<1, 2>(L.p, L.variant, L.lds_bytes, s);
     if (L.ks == 3) return L.stride == 1 ? launch_f16_ks<3, 1>(L.p, L.variant, L.lds_bytes, s) : launch_f16_ks<3, 2>(L.p, L.variant, L.lds_bytes, s);
     return MP_ERR_UNSUPPORTED;

@@ -1,0 +1,300 @@
+// Persistent multi-tile form of the fp16-MFMA convolution: a workgroup loads its weight slice (all input channels x
+// taps x CT couts) into LDS ONCE and then walks a run of pixel tiles, double-buffering the input tiles - tile t+1 is
+// fetched into registers while tile t runs on the matrix cores, its residuals are fetched before its MFMA loop, its
+// results leave as 8-byte stores while the next tile's data lands in LDS; one barrier per tile.
+// Compared with conv_f16_kernel (one tile per workgroup) the weight traffic from L2 drops by the run length and the
+// load / MFMA / store phases overlap inside a workgroup instead of only across co-resident ones.
+#include "conv_f16.h"
+#include "conv_f16_dev.h"
+
+namespace mp {
+
+namespace {
+
+template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, int NI, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Params p) {
+    static_assert(WAVES_P * WAVES_C == 4, "4 waves per workgroup");
+    constexpr int T = KS * KS;
+    constexpr int CT = 16 * CS * WAVES_C;
+    extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
+    u32x4* __restrict__ lds_w = smem16;             // [PK/4][T][4][CT]
+    u32x4* __restrict__ lds_in = smem16 + p.w_buf;  // [2][in_buf]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp_i = wave % WAVES_P, wc_i = wave / WAVES_P;
+    const int lq = lane >> 4, lr = lane & 15;
+
+    int b = blockIdx.x;
+    {
+        const int nb = p.total_blocks, q8 = nb >> 3, r8 = nb & 7, xcd = b & 7, j = b >> 3;
+        b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
+    }
+    const int ct = b % p.n_ct;
+    const int grp = b / p.n_ct;
+    const int t_begin = grp * p.tiles_per_wg;
+    const int t_end = min(t_begin + p.tiles_per_wg, p.tiles_total);
+    const int HW = p.H * p.W;
+    const int plane_o = p.Ho * p.Wo;
+
+    // ---- weights: the whole K x CT slice, once
+    {
+        const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.wp, (size_t)p.PK * T * p.Cout_pad16 * 16);
+        const int w_units = p.PK * T * CT;
+        for (int u0 = 0; u0 < w_units; u0 += 256 * 8) {
+            u32x4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int u = u0 + tid + 256 * i;
+                const int row = u / CT, c = u - row * CT;
+                const bool ok = u < w_units && ct * CT + c < p.Cout_pad16;
+                v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, ok ? (unsigned)(row * p.Cout_pad16 + ct * CT + c) * 16u : kOob, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int u = u0 + tid + 256 * i;
+                if (u < w_units) lds_w[u] = v[i];
+            }
+        }
+    }
+    {
+        const int n16 = 2 * p.in_buf;
+        const u32x4 zero = (u32x4){0u, 0u, 0u, 0u};
+        for (int i = tid; i < n16; i += 256) lds_in[i] = zero;
+    }
+
+    // ---- tile-independent staging tables: source offset relative to the tile's first row of its first image, LDS
+    //      destination, and (image, row) inside the tile for the per-tile range check
+    int uoff[NI], udst[NI], ugr[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const unsigned u = tid + 256 * i;
+        uoff[i] = 0;
+        udst[i] = -1;
+        ugr[i] = 0;
+        if (u < (unsigned)(p.PKs * p.upc)) {
+            const unsigned pl = fastdiv(u, p.upc, p.magic_upc);
+            const unsigned rem = u - pl * p.upc;
+            const unsigned gr = fastdiv(rem, p.ncols, p.magic_ncols);
+            const unsigned xu = rem - gr * p.ncols;
+            const unsigned g = p.G > 1 ? fastdiv(gr, p.Rin, p.magic_rin) : 0u;
+            const unsigned r = gr - g * p.Rin;
+            uoff[i] = (int)(((g * p.C8in + pl) * HW + r * p.W + xu) * 16u);
+            udst[i] = (int)(pl * p.plane + g * p.img_plane + r * p.Wp + p.pad_l + xu);
+            ugr[i] = (int)((g << 16) | r);
+        }
+    }
+
+    int b_off[PS];
+    int pix_rel[PS], pix_gy[PS];  // output offset of the lane's pixel relative to the tile origin; (image << 16 | row), -1 = padding lane
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps) {
+        const unsigned pl0 = (unsigned)((wp_i * PS + ps) * 16 + lr);
+        const unsigned pl = pl0 < (unsigned)(p.G * p.RWo) ? pl0 : 0u;
+        const unsigned g = fastdiv(pl, p.RWo, p.magic_rwo);
+        const unsigned rem = pl - g * p.RWo;
+        const unsigned y = fastdiv(rem, p.Wo, p.magic_wo);
+        const unsigned xx = rem - y * p.Wo;
+        b_off[ps] = lq * p.plane + g * p.img_plane + (y * S) * p.Wp + xx * S;
+        pix_rel[ps] = (int)((g * p.C8out * plane_o + y * p.Wo + xx) * 16u);
+        pix_gy[ps] = pl0 < (unsigned)(p.G * p.RWo) ? (int)((g << 16) | y) : -1;
+    }
+    int a_off[CS];
+#pragma unroll
+    for (int cs = 0; cs < CS; ++cs) a_off[cs] = lq * CT + (wc_i * CS + cs) * 16 + lr;
+
+    f32x4 sc[CS], sh[CS];
+    unsigned co_off[CS];
+#pragma unroll
+    for (int cs = 0; cs < CS; ++cs) {
+        const int co = ct * CT + (wc_i * CS + cs) * 16 + 4 * lq;
+        const bool ok = co < p.C8out * 8;
+        const int cc = co < p.Cout_pad16 ? co : 0;
+        sc[cs] = *reinterpret_cast<const f32x4*>(p.scale + cc);
+        sh[cs] = *reinterpret_cast<const f32x4*>(p.shift + cc);
+        co_off[cs] = ok ? (unsigned)(co >> 3) * plane_o * 16u + ((co >> 2) & 1) * 8u : kOob;
+    }
+
+    const size_t x_bytes = (size_t)p.N * p.C8in * HW * 16, o_bytes = (size_t)p.N * p.C8out * plane_o * 16;
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x, x_bytes);
+    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(p.out, o_bytes);
+    const __amdgpu_buffer_rsrc_t rs_r1 = make_rsrc(p.res1 ? p.res1 : p.out, o_bytes);
+    const __amdgpu_buffer_rsrc_t rs_r2 = make_rsrc(p.res2 ? p.res2 : p.out, o_bytes);
+
+    u32x4 vin[NI];
+    auto stage_load = [&](int t) {
+        const int ty = t % p.tiles_y, tn = t / p.tiles_y;
+        const int n0 = tn * p.G, y_in0 = ty * p.R * S - p.pad_t;
+        const int base = (n0 * p.C8in * HW + y_in0 * p.W) * 16;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int yin = y_in0 + (ugr[i] & 0xFFFF), n = n0 + (ugr[i] >> 16);
+            const bool ok = udst[i] >= 0 && yin >= 0 && yin < p.H && n < p.N;
+            vin[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? (unsigned)(base + uoff[i]) : kOob, 0, 0);
+        }
+    };
+    auto stage_store = [&](int buf) {  // rows / images outside the tensor arrive as zeros and overwrite the last tile's data
+        u32x4* __restrict__ din = lds_in + buf * p.in_buf;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (udst[i] >= 0) din[udst[i]] = vin[i];
+    };
+
+    stage_load(t_begin);
+    __syncthreads();  // weights + zero fill complete
+    stage_store(0);
+    __syncthreads();
+
+    const int nq = p.PK >> 2;
+    for (int t = t_begin; t < t_end; ++t) {
+        const int buf = (t - t_begin) & 1;
+        const bool more = t + 1 < t_end;
+        if (more) stage_load(t + 1);
+
+        // output addresses of this tile, residuals fetched now (their latency hides under the MFMA loop)
+        const int ty = t % p.tiles_y, tn = t / p.tiles_y;
+        const int n0 = tn * p.G, y0 = ty * p.R;
+        const int obase = (n0 * p.C8out * plane_o + y0 * p.Wo) * 16;
+        unsigned pix_off[PS];
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps) {
+            const bool ok = pix_gy[ps] >= 0 && n0 + (pix_gy[ps] >> 16) < p.N && y0 + (pix_gy[ps] & 0xFFFF) < p.Ho;
+            pix_off[ps] = ok ? (unsigned)(obase + pix_rel[ps]) : kOob;
+        }
+        u32x2 r1[CS][PS], r2[CS][PS];
+        if (p.res1) {
+#pragma unroll
+            for (int cs = 0; cs < CS; ++cs)
+#pragma unroll
+                for (int ps = 0; ps < PS; ++ps)
+                    r1[cs][ps] = __builtin_amdgcn_raw_buffer_load_b64(rs_r1, ((co_off[cs] | pix_off[ps]) & kOob) ? kOob : co_off[cs] + pix_off[ps], 0, 0);
+        }
+        if (p.res2) {
+#pragma unroll
+            for (int cs = 0; cs < CS; ++cs)
+#pragma unroll
+                for (int ps = 0; ps < PS; ++ps)
+                    r2[cs][ps] = __builtin_amdgcn_raw_buffer_load_b64(rs_r2, ((co_off[cs] | pix_off[ps]) & kOob) ? kOob : co_off[cs] + pix_off[ps], 0, 0);
+        }
+
+        f32x4 acc[PS][CS];
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps)
+#pragma unroll
+            for (int cs = 0; cs < CS; ++cs) acc[ps][cs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            const u32x4* __restrict__ lin = lds_in + buf * p.in_buf;
+            const u32x4* __restrict__ lw = lds_w;
+            u32x4 bv[PS], av[CS];
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps) bv[ps] = lin[b_off[ps]];
+#pragma unroll
+            for (int cs = 0; cs < CS; ++cs) av[cs] = lw[a_off[cs]];
+            for (int q = 0; q < nq; ++q) {
+                const int in_q = q * 4 * p.plane;
+                const int w_q = q * T * 4 * CT;
+                const int qn = min(q + 1, nq - 1);
+#pragma unroll
+                for (int tp = 0; tp < T; ++tp) {
+                    const int tn2 = (tp + 1 < T) ? tp + 1 : 0;
+                    const int in_off = ((tp + 1 < T) ? in_q : qn * 4 * p.plane) + (tn2 / KS) * p.Wp + (tn2 % KS);
+                    const int w_off = ((tp + 1 < T) ? w_q : qn * T * 4 * CT) + tn2 * 4 * CT;
+                    u32x4 bn[PS], an[CS];
+#pragma unroll
+                    for (int ps = 0; ps < PS; ++ps) bn[ps] = lin[b_off[ps] + in_off];
+#pragma unroll
+                    for (int cs = 0; cs < CS; ++cs) an[cs] = lw[a_off[cs] + w_off];
+#pragma unroll
+                    for (int ps = 0; ps < PS; ++ps)
+#pragma unroll
+                        for (int cs = 0; cs < CS; ++cs)
+                            acc[ps][cs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[cs]),
+                                                                                  __builtin_bit_cast(f16x8, bv[ps]), acc[ps][cs], 0, 0, 0);
+                    {
+                        constexpr int NR = PS + CS, NM = PS * CS, NPAIR = NR < NM ? NR : NM;
+#pragma unroll
+                        for (int i = 0; i < NPAIR; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+                        if (NM > NPAIR) __builtin_amdgcn_sched_group_barrier(0x008, NM - NPAIR, 0);
+                        if (NR > NPAIR) __builtin_amdgcn_sched_group_barrier(0x100, NR - NPAIR, 0);
+                    }
+#pragma unroll
+                    for (int ps = 0; ps < PS; ++ps) bv[ps] = bn[ps];
+#pragma unroll
+                    for (int cs = 0; cs < CS; ++cs) av[cs] = an[cs];
+                }
+            }
+        }
+
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs)
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps) {
+                f32x4 v = acc[ps][cs] * sc[cs] + sh[cs];
+                if (p.res1) {
+                    const f16x4 h = __builtin_bit_cast(f16x4, r1[cs][ps]);
+                    v += (f32x4){(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+                }
+                if (p.res2) {
+                    const f16x4 h = __builtin_bit_cast(f16x4, r2[cs][ps]);
+                    v += (f32x4){(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+                }
+                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                const f16x4 o = (f16x4){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs_o,
+                                                      ((co_off[cs] | pix_off[ps]) & kOob) ? kOob : co_off[cs] + pix_off[ps], 0, 0);
+            }
+
+        if (more) {
+            stage_store(buf ^ 1);
+            __syncthreads();
+        }
+    }
+}
+
+constexpr int mt_ni(int occ) { return occ == 1 ? 12 : 8; }
+
+template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, int OCC>
+int launch_mt_variant(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
+    auto kern = conv_f16_mt_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, mt_ni(OCC), OCC>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(256), lds_bytes, s, p);
+    return check_launch();
+}
+
+template <int KS, int S, int OCC>
+int launch_mt_shape(const ConvF16Params& p, int shape, size_t lds_bytes, hipStream_t s) {
+    switch (shape) {
+        case F_CT32_PT192: return launch_mt_variant<KS, S, 3, 2, 4, 1, OCC>(p, lds_bytes, s);
+        case F_CT64_PT192: return launch_mt_variant<KS, S, 3, 4, 4, 1, OCC>(p, lds_bytes, s);
+        case F_CT48_PT192: return launch_mt_variant<KS, S, 3, 3, 4, 1, OCC>(p, lds_bytes, s);
+        case F_CT64_PT96: return launch_mt_variant<KS, S, 3, 2, 2, 2, OCC>(p, lds_bytes, s);
+        case F_CT32_PT96: return launch_mt_variant<KS, S, 3, 1, 2, 2, OCC>(p, lds_bytes, s);
+        default: return MP_ERR_UNSUPPORTED;
+    }
+}
+
+template <int KS, int S>
+int launch_mt_ks(const ConvF16Params& p, int variant, size_t lds_bytes, hipStream_t s) {
+    const int shape = (variant - F_MT2_BASE) % 5;
+    return f16_variant_mt_occ(variant) == 1 ? launch_mt_shape<KS, S, 1>(p, shape, lds_bytes, s)
+                                            : launch_mt_shape<KS, S, 2>(p, shape, lds_bytes, s);
+}
+
+}  // namespace
+
+int f16_mt_ni(int occ) { return mt_ni(occ); }
+
+int f16_mt_launch(const ConvF16Launch& L, hipStream_t s) {
+    if (L.ks == 3) return L.stride == 1 ? launch_mt_ks<3, 1>(L.p, L.variant, L.lds_bytes, s) : launch_mt_ks<3, 2>(L.p, L.variant, L.lds_bytes, s);
+    if (L.ks == 1 && L.stride == 1) return launch_mt_ks<1, 1>(L.p, L.variant, L.lds_bytes, s);
+    return MP_ERR_UNSUPPORTED;
+}
+
+}  // namespace mp

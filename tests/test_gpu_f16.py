@@ -75,7 +75,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [-1] + list(range(20)))
 def test_conv_f16_vs_oracle(case, variant):
     n, cin, cout, k, s, h, w, relu, n_res = case
     g = torch.Generator().manual_seed(hash(case) % 1000)
@@ -118,6 +118,17 @@ def test_conv_f16_vs_oracle(case, variant):
     # padding channels stay zero (the next layer's MFMA reads them)
     blk = out.c8_tensor.cpu().permute(0, 1, 4, 2, 3).reshape(n, -1, ho, wo)
     assert torch.all(blk[:, cout:] == 0)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("variant", list(range(10, 20)))
+@pytest.mark.parametrize("groups", ["1", "3"])
+def test_conv_f16_multi_tile_vs_oracle(case, variant, groups, monkeypatch):
+    # the persistent multi-tile kernel only engages when a workgroup gets >= 2 tiles; MP_F16_MT_GROUPS caps the number of
+    # workgroups per cout tile so that small problems exercise long tile runs (1 group = every tile in one workgroup,
+    # 3 groups = ragged last run)
+    monkeypatch.setenv("MP_F16_MT_GROUPS", groups)
+    test_conv_f16_vs_oracle(case, variant)
 
 
 def test_conv_f16_rejects_unsupported():
