@@ -59,6 +59,40 @@ class BatchNorm2d(nn.Module):
 
 
 _TUNE_CACHE: Dict[Tuple, int] = {}
+_TUNE_FILE_LOADED = False
+
+
+def _tune_file() -> Optional[str]:
+    """MINDPOSE_TUNE_CACHE=<path>: persist the autotuner's choices (JSON, keyed by launch shape) so that a later process
+    - a profiling run, a production worker - replays them without timing trial launches."""
+    return os.environ.get("MINDPOSE_TUNE_CACHE") or None
+
+
+def _tune_load() -> None:
+    global _TUNE_FILE_LOADED
+    path = _tune_file()
+    if _TUNE_FILE_LOADED or not path:
+        return
+    _TUNE_FILE_LOADED = True
+    try:
+        import json
+        with open(path) as f:
+            for k, v in json.load(f).items():
+                _TUNE_CACHE.setdefault(k, int(v))
+    except (OSError, ValueError):
+        pass
+
+
+def _tune_save() -> None:
+    path = _tune_file()
+    if not path:
+        return
+    try:
+        import json
+        with open(path, "w") as f:
+            json.dump({k: v for k, v in _TUNE_CACHE.items() if isinstance(k, str)}, f)
+    except OSError:
+        pass
 
 
 class ActC8:
@@ -85,6 +119,8 @@ def _autotune(key, macs, n_variants, launch) -> int:
     pointless (tiny layers)."""
     if os.environ.get("MINDPOSE_AUTOTUNE", "1") == "0":
         return -1
+    _tune_load()
+    key = repr(key)
     hit = _TUNE_CACHE.get(key)
     if hit is not None:
         return hit
@@ -103,6 +139,8 @@ def _autotune(key, macs, n_variants, launch) -> int:
             if best_t is None or t < best_t:
                 best, best_t = v, t
     _TUNE_CACHE[key] = best
+    if macs >= (1 << 26):
+        _tune_save()
     return best
 
 
