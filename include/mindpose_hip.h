@@ -257,6 +257,22 @@ int mp_plan_add_fuse_sum_f16(mp_plan* plan, const void* base_dev, const void* t1
 /* to_c8 != 0: NCHW fp32 -> c8 fp16, else c8 fp16 -> NCHW fp32 */
 int mp_plan_add_layout_f16(mp_plan* plan, int to_c8, const void* x_dev, void* out_dev, int n, int c, int h, int w);
 
+/* ---- loader side: the crop that feeds the network -----------------------------------------------------
+ * cv2.warpAffine(image, trans, (out_w, out_h), flags=cv2.INTER_LINEAR) of TopDownAffine._affine / _udp_affine
+ * (mindpose/data/transform/topdown_transform.py:198-262), optionally fused with vision.Normalize(mean, std) +
+ * vision.HWC2CHW (mindpose/data/data_factory.py:129-133).
+ *   src          device buffer holding the source images, HWC uint8, 3 channels
+ *   src_offsets  [n] int64 (device): byte offset of crop i's source image inside src
+ *   src_hw       [n][2] int32 (device): height, width of crop i's source image
+ *   trans        [n][6] fp64 (device): the 2x3 FORWARD matrices (source -> crop) exactly as get_affine_transform /
+ *                get_warp_matrix return them; the kernel inverts them as cv2.warpAffine does
+ *   normalize=1: out = fp32 [n][3][out_h][out_w], (pixel - mean[c]) / stddev[c]   (mean/std already times 255, host arrays)
+ *   normalize=0: out = uint8 [n][out_h][out_w][3], the warped image only
+ * Border mode BORDER_CONSTANT(0); OpenCV's fixed-point bilinear arithmetic restated (parity unpinned: no cv2 here). */
+int mp_warp_affine(const uint8_t* src_dev, const long long* src_offsets_dev, const int* src_hw_dev, const double* trans_dev,
+                   void* out_dev, int n, int out_h, int out_w, int normalize, const float mean[3], const float stddev[3],
+                   mp_stream_t stream);
+
 /* Diagnostics: only a library built with -DMP_CONV_STAMPS=1 (never the product build) records per-workgroup
  * phase cycle counters (8 x uint64 per workgroup) of each conv launch into this device buffer; the product
  * build returns MP_ERR_UNSUPPORTED. */

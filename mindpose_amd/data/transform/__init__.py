@@ -1,3 +1,4 @@
-from .topdown_transform import TopDownGenerateTarget  # noqa: F401
+from .topdown_transform import (TopDownAffine, TopDownBoxToCenterScale, TopDownGenerateTarget,  # noqa: F401
+                                get_affine_transform, get_warp_matrix)
 
-__all__ = ["TopDownGenerateTarget"]
+__all__ = ["TopDownGenerateTarget", "TopDownBoxToCenterScale", "TopDownAffine", "get_affine_transform", "get_warp_matrix"]

@@ -172,8 +172,45 @@ def gen_loss():
     print("loss done")
 
 
+def gen_geometry():
+    """Loader geometry computed by the REFERENCE's own numpy code (no cv2 call on these paths):
+    TopDownBoxToCenterScale._xywh2cs in eval mode (topdown_transform.py:131-154) and get_warp_matrix (utils.py:150-181)."""
+    load_reference_target_class()
+    tt = sys.modules["mindpose.data.transform.topdown_transform"]
+    ut = sys.modules["mindpose.data.transform.utils"]
+    rng = np.random.RandomState(77)
+    out = {}
+    for name, image_size in (("256x192", [192, 256]), ("384x288", [288, 384])):
+        cfg = dict(image_size=image_size, heatmap_size=[image_size[0] // 4, image_size[1] // 4], flip_pairs=recipes.FLIP_PAIRS,
+                   upper_body_ids=list(range(11)), pixel_std=200.0, scale_padding=1.25)
+        t = tt.TopDownBoxToCenterScale(is_train=False, config=cfg)
+        boxes = np.concatenate([rng.uniform(0, 500, (40, 2)), rng.uniform(5, 400, (40, 2))], axis=1).astype(np.float32)
+        boxes[0] = [10, 20, 96, 128]   # exactly the aspect ratio
+        boxes[1] = [0, 0, 300, 10]     # very wide
+        boxes[2] = [5.5, 7.25, 3, 400]  # very tall
+        cs = [t.transform(dict(boxes=b)) for b in boxes]
+        out[f"boxes_{name}"] = boxes
+        out[f"center_{name}"] = np.stack([c["center"] for c in cs])
+        out[f"scale_{name}"] = np.stack([c["scale"] for c in cs])
+        mats = []
+        args = []
+        for i in range(24):
+            theta = float(rng.uniform(-45, 45)) if i % 3 else 0.0
+            center = rng.uniform(50, 400, 2).astype(np.float32)
+            scale = rng.uniform(0.3, 3.0, 2).astype(np.float32)
+            size = np.array(image_size)
+            mats.append(ut.get_warp_matrix(theta, center * 2.0, size - 1.0, scale * 200.0))
+            args.append([theta, *center, *scale])
+        out[f"warp_args_{name}"] = np.array(args, np.float64)
+        out[f"warp_matrix_{name}"] = np.stack(mats)
+    np.savez_compressed(os.path.join(HERE, "geometry.npz"), **out)
+    print("geometry.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["targets", "decoder", "flip", "loss"]
+    which = sys.argv[1:] or ["targets", "decoder", "flip", "loss", "geometry"]
+    if "geometry" in which:
+        gen_geometry()
     if "targets" in which:
         gen_targets()
     if "decoder" in which:

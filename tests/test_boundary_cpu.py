@@ -44,7 +44,8 @@ def test_registry_names_resolve():
         "head": ["HRNetHead", "hrnet_head", "SimpleBaselineHead", "simple_baseline_head"],
         "decoder": ["TopDownHeatMapDecoder", "topdown_heatmap"],
         "loss": ["JointsMSELoss", "joint_mse"],
-        "transform": ["TopDownGenerateTarget", "topdown_generate_target"],
+        "transform": ["TopDownGenerateTarget", "topdown_generate_target", "TopDownBoxToCenterScale",
+                      "topdown_box_to_center_scale", "TopDownAffine", "topdown_affine"],
         "inferencer": ["TopDownHeatMapInferencer", "topdown_heatmap"],
     }
     for module, comps in names.items():

@@ -1,0 +1,95 @@
+"""Fused crop kernel (warpAffine + Normalize + HWC2CHW) against the CPU oracle, through the C ABI.
+Integer pixel values are compared bit-exact; the normalised fp32 output is the same IEEE expression on both sides, so it
+is compared bit-exact too."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs an MI355X", allow_module_level=True)
+
+import mindpose_amd as mp  # noqa: E402
+from oracle import loader as ol  # noqa: E402
+from tests.golden import recipes  # noqa: E402
+
+DEV = torch.device("cuda:0")
+CFG = dict(heatmap_size=[48, 64], flip_pairs=recipes.FLIP_PAIRS, upper_body_ids=list(range(11)), pixel_std=200.0,
+           scale_padding=1.25)
+
+
+def _images(rng):
+    return [rng.randint(0, 256, s).astype(np.uint8) for s in ((480, 640, 3), (333, 500, 3), (97, 61, 3))]
+
+
+@pytest.mark.parametrize("use_udp", [False, True])
+@pytest.mark.parametrize("image_size", [[192, 256], [288, 384]])
+def test_crop_batch_bit_exact_vs_oracle(use_udp, image_size):
+    rng = np.random.RandomState(11 + use_udp)
+    imgs = _images(rng)
+    dimgs = [torch.from_numpy(i).to(DEV) for i in imgs]
+    n = 24
+    index = rng.randint(0, len(imgs), n)
+    boxes = []
+    for i in range(n):
+        h, w, _ = imgs[index[i]].shape
+        bw, bh = rng.uniform(10, w * 1.2), rng.uniform(10, h * 1.2)
+        boxes.append([rng.uniform(-0.3 * w, w), rng.uniform(-0.3 * h, h), bw, bh])  # partly / mostly outside included
+    boxes = np.array(boxes, np.float32)
+    b2cs = mp.TopDownBoxToCenterScale(is_train=False, config=dict(CFG, image_size=image_size))
+    centers, scales = b2cs.transform_batch(boxes)
+    rot = np.where(np.arange(n) % 3 == 0, 0.0, rng.uniform(-40, 40, n))
+    aff = mp.TopDownAffine(is_train=False, config=dict(CFG, image_size=image_size), use_udp=use_udp)
+    crops, mats = aff.crop_batch(dimgs, centers, scales, rot, image_index=index)
+    assert crops.shape == (n, 3, image_size[1], image_size[0]) and crops.dtype == torch.float32
+    got = crops.cpu().numpy()
+    for i in range(n):
+        ref, trans = ol.crop(imgs[index[i]], centers[i], scales[i], float(rot[i]), image_size, use_udp=use_udp)
+        assert np.array_equal(np.asarray(mats[i], np.float64), np.asarray(trans, np.float64))
+        assert np.array_equal(got[i], ref), f"crop {i}: {np.abs(got[i] - ref).max()}"
+
+
+def test_transform_per_sample_contract_and_errors():
+    rng = np.random.RandomState(5)
+    img = rng.randint(0, 256, (200, 300, 3)).astype(np.uint8)
+    aff = mp.TopDownAffine(is_train=False, config=dict(CFG, image_size=[192, 256]))
+    kp = np.concatenate([rng.uniform(0, 200, (17, 2)), (rng.rand(17, 1) > 0.3)], axis=1).astype(np.float32)
+    center, scale = np.array([150.0, 100.0], np.float32), np.array([0.9, 1.2], np.float32)
+    out = aff.transform(dict(image=torch.from_numpy(img).to(DEV), center=center, scale=scale, rotation=15.0, keypoints=kp.copy()))
+    trans = ol.get_affine_transform(center, scale, 15.0, np.array([192, 256]))
+    assert out["image"].dtype == torch.uint8 and tuple(out["image"].shape) == (256, 192, 3)
+    assert np.array_equal(out["image"].cpu().numpy(), ol.warp_affine(img, trans, 192, 256))
+    want = kp.copy()
+    for i in range(17):
+        if want[i, 2] > 0:
+            want[i, :2] = trans @ np.array([want[i, 0], want[i, 1], 1.0])
+    assert np.array_equal(out["keypoints"], want)
+    with pytest.raises(mp._lib.MindposeHipError):
+        aff.transform(dict(image=img, center=center, scale=scale, rotation=0.0))  # numpy image: no CPU fallback
+    with pytest.raises(mp._lib.MindposeHipError):
+        aff.crop_batch(torch.from_numpy(img), center[None], scale[None])  # CPU tensor
+
+
+def test_boxes_to_keypoints_end_to_end():
+    # detector boxes -> centre/scale -> fused crop written straight into the plan's input buffer -> network -> decode
+    from oracle import decoder as od
+    from oracle import nets as onets
+    rng = np.random.RandomState(9)
+    img = rng.randint(0, 256, (360, 480, 3)).astype(np.uint8)
+    boxes = np.array([[40, 30, 120, 260], [200, 50, 180, 200], [10, 10, 400, 300]], np.float32)
+    cfg = dict(CFG, image_size=[192, 256])
+    centers, scales = mp.TopDownBoxToCenterScale(is_train=False, config=cfg).transform_batch(boxes)
+    net = mp.init_synthetic(mp.create_network("hrnet_w32", "hrnet_head"), seed=0).to(DEV).eval()
+    dec = mp.create_decoder("topdown_heatmap", shift_coordinate=True).to(DEV)
+    ev = mp.create_eval_network(net, dec, output_raw=True)
+    buf = net.input_buffer((3, 3, 256, 192), DEV)
+    crops, _ = mp.TopDownAffine(is_train=False, config=cfg).crop_batch(torch.from_numpy(img).to(DEV), centers, scales, out=buf)
+    assert crops.data_ptr() == buf.data_ptr()
+    score = torch.ones(3, device=DEV)
+    (preds, pboxes), hm = ev(buf, torch.from_numpy(centers).to(DEV), torch.from_numpy(scales).to(DEV), score)
+    x = np.stack([ol.crop(img, centers[i], scales[i], 0.0, [192, 256])[0] for i in range(3)])
+    ref_hm = onets.net_forward({k: v.cpu() for k, v in net.state_dict().items()}, torch.from_numpy(x), "hrnet_w32", "hrnet_head")
+    assert float((hm.cpu() - ref_hm).abs().max() / ref_hm.abs().max()) < 1e-3
+    rp, rb, _ = od.decode(hm.cpu().numpy(), centers, scales, np.ones(3, np.float32), shift_coord=True)
+    assert np.array_equal(preds.cpu().numpy(), rp) and np.array_equal(pboxes.cpu().numpy(), rb)
