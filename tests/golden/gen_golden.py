@@ -207,8 +207,52 @@ def gen_geometry():
     print("geometry.npz", {k: v.shape for k, v in out.items()})
 
 
+def nms_cases():
+    """Seeded person lists: clusters of near-duplicate poses (so that NMS has something to suppress) + distinct ones."""
+    rng = np.random.RandomState(2024)
+    cases = []
+    for n_people, dup in ((1, 0), (6, 3), (12, 8), (25, 10), (40, 30)):
+        people = []
+        base = rng.uniform(50, 400, (n_people, 17, 2))
+        for p in range(n_people):
+            kp = np.concatenate([base[p], rng.uniform(0.05, 1.0, (17, 1))], axis=1)
+            people.append(dict(keypoints=kp.astype(np.float32), score=float(rng.uniform(0.1, 1.0)), area=float(rng.uniform(2e3, 6e4))))
+        for _ in range(dup):
+            src = people[rng.randint(0, n_people)]
+            kp = src["keypoints"].copy()
+            kp[:, :2] += rng.normal(0, rng.choice([1.0, 4.0, 12.0]), (17, 2)).astype(np.float32)
+            people.append(dict(keypoints=kp, score=float(rng.uniform(0.1, 1.0)), area=src["area"] * float(rng.uniform(0.8, 1.2))))
+        cases.append(people)
+    return cases
+
+
+def gen_nms():
+    """OKS NMS outputs of the REFERENCE's own numpy module (mindpose/utils/nms.py, no MindSpore / cv2 import)."""
+    spec = importlib.util.spec_from_file_location("ref_nms", REF + "/utils/nms.py")
+    nms = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(nms)
+    out = {}
+    for ci, people in enumerate(nms_cases()):
+        out[f"c{ci}_keypoints"] = np.stack([p["keypoints"] for p in people])
+        out[f"c{ci}_score"] = np.array([p["score"] for p in people])
+        out[f"c{ci}_area"] = np.array([p["area"] for p in people])
+        kpts = np.array([p["keypoints"].flatten() for p in people])
+        areas = out[f"c{ci}_area"]
+        out[f"c{ci}_iou0"] = nms.oks_iou(kpts[0], kpts[1:], areas[0], areas[1:])
+        out[f"c{ci}_iou0_vis"] = nms.oks_iou(kpts[0], kpts[1:], areas[0], areas[1:], None, 0.4)
+        for thr in (0.5, 0.9):
+            tag = str(thr).replace(".", "")
+            out[f"c{ci}_keep_{tag}"] = np.asarray(nms.oks_nms(people, thr), dtype=np.int64)
+            out[f"c{ci}_keep_vis_{tag}"] = np.asarray(nms.oks_nms(people, thr, None, 0.4), dtype=np.int64)
+            out[f"c{ci}_soft_{tag}"] = np.asarray(nms.soft_oks_nms(people, thr), dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "nms.npz"), **out)
+    print("nms.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["targets", "decoder", "flip", "loss", "geometry"]
+    which = sys.argv[1:] or ["targets", "decoder", "flip", "loss", "geometry", "nms"]
+    if "nms" in which:
+        gen_nms()
     if "geometry" in which:
         gen_geometry()
     if "targets" in which:
