@@ -128,6 +128,8 @@ def roofline_report(plan, reps=5, layers_csv=""):
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
         "frac": round(achieved / peak, 4), "traffic": pmc_traffic(dom),
+        "timing": "HIP events around each launch replayed alone on one stream (mp_plan_run_range); the timed region of "
+                  "`value` overlaps the four HRNet branch lanes, which stretches individual kernels but shortens the step",
         "kernel": dom, "launches_per_step": g["launches"],
         "flop_per_launch": round(g["flops"] / g["launches"]), "avg_launch_us": round(g["time"] / g["launches"] * 1e6, 2),
         "share_of_conv_time": round(g["time"] / fam_t, 3),
@@ -344,7 +346,8 @@ def main():
                        "per_gpu_batch": n, "global_batch": n * world, "image": f"{ih}x{iw}", "heatmap": f"{ih // 4}x{iw // 4}x17",
                        "sharding": "crops split over ranks, no data-path collective",
                        "gflop_per_image": round(2e-9 * plan.total_macs / n * (2 if flip else 1), 3),
-                       "launches_per_step": (len(plan) + 1) * (2 if flip else 1)},
+                       "launches_per_step": (sum(1 for e in plan.layer_info if e["kind"] != "barrier") + 1) * (2 if flip else 1),
+                       "execution_lanes": 4 if any(e["kind"] == "barrier" for e in plan.layer_info) else 1},
         }
         if not args.no_roofline:
             result["roofline"] = roofline_report(plan, layers_csv=args.layers)

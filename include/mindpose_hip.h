@@ -179,6 +179,13 @@ int mp_plan_add_conv_variant(mp_plan* plan, const mp_conv_desc* desc, int varian
 int mp_plan_add_maxpool(mp_plan* plan, const float* x_dev, float* out_dev, int n, int c, int h, int w);
 int mp_plan_add_fuse_sum(mp_plan* plan, const float* base_dev, const float* t1_dev, int s1, const float* t2_dev, int s2,
                          const float* t3_dev, int s3, float* out_dev, int n, int c, int h, int w, int relu);
+/* Execution lanes: entries added after mp_plan_set_lane(plan, l) (l in 0..3) replay on lane l - lane 0 is the stream
+ * passed to mp_plan_run, lanes 1..3 are side streams the plan owns - so independent sub-graphs (the HRNet branches, the
+ * rows of an exchange unit) overlap on the chip.  mp_plan_add_barrier orders every lane after everything recorded so far
+ * on every other lane; mp_plan_run forks the side lanes from the caller's stream and joins them before returning control
+ * to it (event fork/join: also valid under stream capture).  mp_plan_run_range always replays sequentially on one stream. */
+int mp_plan_set_lane(mp_plan* plan, int lane);
+int mp_plan_add_barrier(mp_plan* plan);
 int mp_plan_size(const mp_plan* plan);
 int mp_plan_run(const mp_plan* plan, mp_stream_t stream);
 /* run entries [first, first+count) only (profiling / per-layer timing) */

@@ -244,7 +244,9 @@ using namespace mp;
 
 struct mp_plan {
     struct Entry {
-        int kind;  // 0 conv, 1 maxpool, 2 fuse-sum; fp16 layout: 3 conv, 4 fuse-sum, 5 NCHW fp32 -> c8, 6 c8 -> NCHW fp32
+        int kind;  // 0 conv, 1 maxpool, 2 fuse-sum; fp16 layout: 3 conv, 4 fuse-sum, 5 NCHW fp32 -> c8, 6 c8 -> NCHW fp32;
+                   // 7 = all-lane barrier (no launch)
+        int lane;  // execution lane: 0 = the caller's stream, 1..3 = the plan's own side streams
         ConvLaunch conv;
         ConvF16Launch conv16;
         const void* t16[3];
@@ -258,7 +260,85 @@ struct mp_plan {
         int relu;
     };
     std::vector<Entry> entries;
+    int cur_lane = 0;
+    int max_lane = 0;
+    // side streams / events of the multi-lane replay, created on first use (one plan = one device)
+    mutable hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    mutable hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    mutable hipEvent_t ev_fork = nullptr;
+    ~mp_plan() {
+        for (auto& st : side)
+            if (st) (void)hipStreamDestroy(st);
+        for (auto& e : ev)
+            if (e) (void)hipEventDestroy(e);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+    }
 };
+
+static const int kPlanLanes = 4;
+
+static int run_entry(const mp_plan::Entry& e, mp_stream_t stream) {
+    switch (e.kind) {
+        case 0: return launch(e.conv, as_stream(stream));
+        case 1: return mp_maxpool3x3s2_same(e.x, e.out, e.n, e.c, e.h, e.w, stream);
+        case 2: return mp_fuse_upsample_sum(e.x, e.t[0], e.s[0], e.t[1], e.s[1], e.t[2], e.s[2], e.out, e.n, e.c, e.h, e.w, e.relu, stream);
+        case 3: return f16_launch(e.conv16, as_stream(stream));
+        case 4:
+            return mp_f16_fuse_upsample_sum(e.x16, e.t16[0], e.s[0], e.t16[1], e.s[1], e.t16[2], e.s[2], e.out16, e.n, e.c, e.h, e.w,
+                                            e.relu, stream);
+        case 5: return mp_f16_to_c8(e.x, e.out16, e.n, e.c, e.h, e.w, stream);
+        case 6: return mp_f16_from_c8(e.x16, e.out, e.n, e.c, e.h, e.w, stream);
+        case 7: return MP_OK;
+        default: return MP_ERR_UNSUPPORTED;
+    }
+}
+
+static int hip_rc(hipError_t e) {
+    if (e == hipSuccess) return MP_OK;
+    g_last_hip_error = (int)e;
+    return MP_ERR_HIP;
+}
+
+// Multi-lane replay: independent sub-graphs (the HRNet branches, the rows of an exchange unit) are enqueued on different
+// HIP streams so that their kernels overlap on the chip; "barrier" entries order every lane after every other one.  Works
+// under stream capture too (fork / join through events), so a captured hipGraph keeps the parallel structure.
+static int run_multi_lane(const mp_plan* plan, hipStream_t main_stream) {
+    for (int i = 0; i < 3; ++i)
+        if (!plan->side[i]) {
+            int rc = hip_rc(hipStreamCreateWithFlags(&plan->side[i], hipStreamNonBlocking));
+            if (rc != MP_OK) return rc;
+        }
+    for (int i = 0; i < kPlanLanes; ++i)
+        if (!plan->ev[i]) {
+            int rc = hip_rc(hipEventCreateWithFlags(&plan->ev[i], hipEventDisableTiming));
+            if (rc != MP_OK) return rc;
+        }
+    if (!plan->ev_fork) {
+        int rc = hip_rc(hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming));
+        if (rc != MP_OK) return rc;
+    }
+    hipStream_t lanes[kPlanLanes] = {main_stream, plan->side[0], plan->side[1], plan->side[2]};
+    const int nl = plan->max_lane + 1;
+    int rc = hip_rc(hipEventRecord(plan->ev_fork, main_stream));
+    for (int l = 1; l < nl && rc == MP_OK; ++l) rc = hip_rc(hipStreamWaitEvent(lanes[l], plan->ev_fork, 0));
+    for (size_t i = 0; i < plan->entries.size() && rc == MP_OK; ++i) {
+        const mp_plan::Entry& e = plan->entries[i];
+        if (e.kind == 7) {
+            for (int l = 0; l < nl && rc == MP_OK; ++l) rc = hip_rc(hipEventRecord(plan->ev[l], lanes[l]));
+            for (int l = 0; l < nl && rc == MP_OK; ++l)
+                for (int m = 0; m < nl && rc == MP_OK; ++m)
+                    if (m != l) rc = hip_rc(hipStreamWaitEvent(lanes[l], plan->ev[m], 0));
+        } else {
+            rc = run_entry(e, reinterpret_cast<mp_stream_t>(lanes[e.lane]));
+        }
+    }
+    // join: the caller's stream continues only after every side lane has drained
+    for (int l = 1; l < nl && rc == MP_OK; ++l) {
+        rc = hip_rc(hipEventRecord(plan->ev[l], lanes[l]));
+        if (rc == MP_OK) rc = hip_rc(hipStreamWaitEvent(main_stream, plan->ev[l], 0));
+    }
+    return rc;
+}
 
 extern "C" {
 
@@ -317,6 +397,7 @@ int mp_plan_add_conv_variant(mp_plan* plan, const mp_conv_desc* desc, int varian
     e.kind = 0;
     int rc = build_launch(desc, x, packed_w, scale, shift, res1, res2, out, e.conv, variant);
     if (rc != MP_OK) return rc;
+    e.lane = plan->cur_lane;
     plan->entries.push_back(e);
     return MP_OK;
 }
@@ -332,6 +413,7 @@ int mp_plan_add_conv(mp_plan* plan, const mp_conv_desc* desc, const float* x, co
     e.kind = 0;
     int rc = build_launch(desc, x, packed_w, scale, shift, res1, res2, out, e.conv);
     if (rc != MP_OK) return rc;
+    e.lane = plan->cur_lane;
     plan->entries.push_back(e);
     return MP_OK;
 }
@@ -342,6 +424,7 @@ int mp_plan_add_maxpool(mp_plan* plan, const float* x, float* out, int n, int c,
     mp_plan::Entry e{};
     e.kind = 1;
     e.x = x; e.out = out; e.n = n; e.c = c; e.h = h; e.w = w;
+    e.lane = plan->cur_lane;
     plan->entries.push_back(e);
     return MP_OK;
 }
@@ -354,6 +437,7 @@ int mp_plan_add_fuse_sum(mp_plan* plan, const float* base, const float* t1, int 
     e.kind = 2;
     e.x = base; e.out = out; e.n = n; e.c = c; e.h = h; e.w = w; e.relu = relu;
     e.t[0] = t1; e.t[1] = t2; e.t[2] = t3; e.s[0] = s1; e.s[1] = s2; e.s[2] = s3;
+    e.lane = plan->cur_lane;
     plan->entries.push_back(e);
     return MP_OK;
 }
@@ -365,6 +449,7 @@ int mp_plan_add_conv_f16(mp_plan* plan, const mp_conv_desc* desc, int variant, c
     e.kind = 3;
     int rc = f16_build_launch(desc, variant, x, packed_w, scale, shift, res1, res2, out, e.conv16);
     if (rc != MP_OK) return rc;
+    e.lane = plan->cur_lane;
     plan->entries.push_back(e);
     return MP_OK;
 }
@@ -377,6 +462,7 @@ int mp_plan_add_fuse_sum_f16(mp_plan* plan, const void* base, const void* t1, in
     e.kind = 4;
     e.x16 = base; e.out16 = out; e.n = n; e.c = c; e.h = h; e.w = w; e.relu = relu;
     e.t16[0] = t1; e.t16[1] = t2; e.t16[2] = t3; e.s[0] = s1; e.s[1] = s2; e.s[2] = s3;
+    e.lane = plan->cur_lane;
     plan->entries.push_back(e);
     return MP_OK;
 }
@@ -389,6 +475,7 @@ int mp_plan_add_layout_f16(mp_plan* plan, int to_c8, const void* x, void* out, i
     if (to_c8) { e.x = reinterpret_cast<const float*>(x); e.out16 = out; }
     else { e.x16 = x; e.out = reinterpret_cast<float*>(out); }
     e.n = n; e.c = c; e.h = h; e.w = w;
+    e.lane = plan->cur_lane;
     plan->entries.push_back(e);
     return MP_OK;
 }
@@ -399,24 +486,7 @@ int mp_plan_run_range(const mp_plan* plan, int first, int count, mp_stream_t str
     if (!plan) return MP_ERR_NULL;
     if (first < 0 || count < 0 || (size_t)first + count > plan->entries.size()) return MP_ERR_SHAPE;
     for (int i = first; i < first + count; ++i) {
-        const mp_plan::Entry& e = plan->entries[i];
-        int rc;
-        switch (e.kind) {
-            case 0: rc = launch(e.conv, as_stream(stream)); break;
-            case 1: rc = mp_maxpool3x3s2_same(e.x, e.out, e.n, e.c, e.h, e.w, stream); break;
-            case 2:
-                rc = mp_fuse_upsample_sum(e.x, e.t[0], e.s[0], e.t[1], e.s[1], e.t[2], e.s[2], e.out, e.n, e.c, e.h, e.w, e.relu,
-                                          stream);
-                break;
-            case 3: rc = f16_launch(e.conv16, as_stream(stream)); break;
-            case 4:
-                rc = mp_f16_fuse_upsample_sum(e.x16, e.t16[0], e.s[0], e.t16[1], e.s[1], e.t16[2], e.s[2], e.out16, e.n, e.c, e.h,
-                                              e.w, e.relu, stream);
-                break;
-            case 5: rc = mp_f16_to_c8(e.x, e.out16, e.n, e.c, e.h, e.w, stream); break;
-            case 6: rc = mp_f16_from_c8(e.x16, e.out, e.n, e.c, e.h, e.w, stream); break;
-            default: rc = MP_ERR_UNSUPPORTED;
-        }
+        int rc = run_entry(plan->entries[i], stream);  // one stream, in order: per-entry timing / profiling
         if (rc != MP_OK) return rc;
     }
     return MP_OK;
@@ -448,7 +518,25 @@ int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]) {
 
 int mp_plan_run(const mp_plan* plan, mp_stream_t stream) {
     if (!plan) return MP_ERR_NULL;
+    if (plan->max_lane > 0) return run_multi_lane(plan, as_stream(stream));
     return mp_plan_run_range(plan, 0, (int)plan->entries.size(), stream);
+}
+
+int mp_plan_set_lane(mp_plan* plan, int lane) {
+    if (!plan) return MP_ERR_NULL;
+    if (lane < 0 || lane >= kPlanLanes) return MP_ERR_SHAPE;
+    plan->cur_lane = lane;
+    if (lane > plan->max_lane) plan->max_lane = lane;
+    return MP_OK;
+}
+
+int mp_plan_add_barrier(mp_plan* plan) {
+    if (!plan) return MP_ERR_NULL;
+    mp_plan::Entry e{};
+    e.kind = 7;
+    e.lane = 0;
+    plan->entries.push_back(e);
+    return MP_OK;
 }
 
 }  // extern "C"

@@ -152,14 +152,19 @@ class HRModule(nn.Module):
 
     def emit(self, plan: Plan, xs: List[torch.Tensor]) -> List[torch.Tensor]:
         xs = list(xs)
+        # branch i runs on execution lane i: the four resolutions are independent until the exchange unit, and the deep
+        # branches (few workgroups per launch) fill the chip while the wide ones run
         for i in range(self.num_branches):
+            plan.set_lane(i)
             for blk in self.branches[i]:
                 xs[i] = blk.emit(plan, xs[i])
         if self.num_branches == 1:
             return xs
+        plan.barrier()  # every row of the exchange unit reads every branch
         outs = []
         nb = self.num_branches
         for i in range(len(self.fuse_layers)):
+            plan.set_lane(i)  # row i feeds branch i of the next module: no barrier needed after the exchange unit
             # reference order (hrnet.py:327-339): y = t_0; y = y + t_1; ... ; relu(y).  Every term except
             # the identity x_i is a conv launch whose epilogue adds the running sum (res1); the identity
             # rides as res2 on the launch that precedes it (or as res1 of the first launch when i == 0).
@@ -317,6 +322,7 @@ class HRNet(Backbone):
             cfg = getattr(self, f"stage{idx}_cfg")
             xs = []
             for i in range(cfg["num_branches"]):
+                plan.set_lane(min(i, len(ys) - 1))  # a transition runs on the lane that produced its input
                 if not flags[i]:
                     xs.append(ys[i])
                 elif i < len(ys):
@@ -326,9 +332,11 @@ class HRNet(Backbone):
                     for seq in trans[i]:
                         t = _emit_conv_bn(plan, seq, t)
                     xs.append(t)
+            plan.barrier()  # the new branch's lane consumes what another lane just produced
             for mod in getattr(self, f"stage{idx}"):
                 xs = mod.emit(plan, xs)
             ys = xs
+        plan.set_lane(0)  # the last exchange unit has a single row (lane 0); the head continues there
         return ys[0]
 
     def train_forward(self, x: torch.Tensor) -> torch.Tensor:

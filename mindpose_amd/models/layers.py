@@ -171,6 +171,7 @@ class Plan:
         self.lib = _lib.load()
         self.device = device
         self.half = half  # amp O2/O3: fp16 matrix-core kernels over channel-blocked fp16 activations
+        self.lanes = os.environ.get("MINDPOSE_PLAN_LANES", "1") != "0"
         self.handle = ctypes.c_void_p(self.lib.mp_plan_create())
         if not self.handle:
             raise _lib.MindposeHipError("mp_plan_create failed")
@@ -220,6 +221,24 @@ class Plan:
         _lib.check(self.lib.mp_plan_add_layout_f16(self.handle, 0, _lib.ptr(x), _lib.ptr(out), n, c, h, w), "mp_plan_add_layout_f16")
         self.layer_info.append(dict(kind="from_c8", n=n, c=c, h=h, w=w, macs=0))
         return out
+
+    # -- execution lanes ----------------------------------------------------------------------
+    def set_lane(self, lane: int) -> None:
+        """Entries recorded from now on replay on execution lane ``lane`` (0 = the caller's stream, 1..3 = side streams of
+        the plan): independent sub-graphs overlap on the chip.  No-op when lanes are disabled (MINDPOSE_PLAN_LANES=0)."""
+        if self.lanes:
+            _lib.check(self.lib.mp_plan_set_lane(self.handle, int(lane) % 4), "mp_plan_set_lane")
+            if lane:
+                # a multi-lane replay is not captured into a hipGraph: ROCm 7.2's capture_end faults on the event fork/join
+                # of the side streams, and capture never bought anything here (the replay is one native call that
+                # enqueues back to back; measured no gain at N = 1 ... 128)
+                self._graph_ok = False
+
+    def barrier(self) -> None:
+        """Every lane waits for everything recorded so far on every other lane."""
+        if self.lanes:
+            _lib.check(self.lib.mp_plan_add_barrier(self.handle), "mp_plan_add_barrier")
+            self.layer_info.append(dict(kind="barrier", macs=0))
 
     def run(self) -> None:
         """Replay the recorded forward: as one hipGraph launch once captured (MINDPOSE_HIP_GRAPH=0 disables it),
