@@ -269,13 +269,20 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    # rehearsal on a one-GPU box (never the measured configuration): every rank on device 0, gloo for the barrier / MAX
+    rehearsal = os.environ.get("MINDPOSE_BENCH_SHARED_GPU_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group(backend="nccl", device_id=dev)  # RCCL; only the timing barrier / MAX uses it
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)  # RCCL; only the timing barrier / MAX uses it
 
     import mindpose_amd as mp
 
