@@ -243,12 +243,15 @@ int mp_conv_wgrad(const mp_conv_desc* desc, const float* x_dev, const float* dz_
  * when they run on the Ascend cube unit: fp16 conv operands, fp32 accumulation, BatchNorm in fp32, fp16 activations.
  * Activations are CHANNEL-BLOCKED fp16, [N][ceil(C/8)][H][W][8] ("c8"; padding channels zero), weights are packed
  * [ceil(Cin/32)][kh*kw][4][Cout_pad16][8] fp16; scale / shift are fp32 arrays of Cout_pad16 entries (zero beyond Cout).
- * Only the plain output mapping is supported (desc->out_* must equal the conv output, kernel 1x1 or 3x3); the
- * exchange-unit up-sampling runs in mp_f16_fuse_upsample_sum.  variant -1 = heuristic, 0..9 = forced tile shape
+ * Kernel 1x1, 2x2 (stride 1) or 3x3; output mapping plain or strided scatter (out_mul, out_off_*: the sub-pixel phases of
+ * the transposed convolution), out_rep must be 1: the exchange-unit up-sampling runs in mp_f16_fuse_upsample_sum.  variant -1 = heuristic, 0..9 = forced tile shape
  * (5..9 = the light builds of 0..4: small chunks, three workgroups per CU). */
 size_t mp_f16_packed_weight_bytes(int cout, int cin, int kh, int kw);
 size_t mp_f16_activation_bytes(int n, int c, int h, int w);
-int mp_f16_pack_weight(const float* w_dev, void* packed_dev, int cout, int cin, int kh, int kw, mp_stream_t stream);
+/* transposed = 0: Conv2d weight [Cout,Cin,kh,kw]; 1: the (phase_y, phase_x) 2x2 sub-pixel phase of a
+ * Conv2dTranspose(k=4, s=2, pad=1) weight [Cin,Cout,4,4] (kh = kw = 2), as mp_conv_pack_weight mode 1 */
+int mp_f16_pack_weight(const float* w_dev, void* packed_dev, int cout, int cin, int kh, int kw, int transposed, int phase_y,
+                       int phase_x, mp_stream_t stream);
 int mp_f16_to_c8(const float* x_nchw_dev, void* out_c8_dev, int n, int c, int h, int w, mp_stream_t stream);
 int mp_f16_from_c8(const void* x_c8_dev, float* out_nchw_dev, int n, int c, int h, int w, mp_stream_t stream);
 int mp_f16_conv2d_fwd(const mp_conv_desc* desc, int variant, const void* x_c8_dev, const void* packed_w_dev,

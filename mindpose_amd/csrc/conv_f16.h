@@ -30,6 +30,7 @@ struct ConvF16Params {
     int w_buf;       // LDS elements per weight buffer (PK * T * CT)
     int nbuf;
     int relu;
+    int out_h, out_w, out_mul, off_y, off_x;  // output mapping: conv pixel (y, x) -> (y*out_mul + off_y, x*out_mul + off_x)
     unsigned magic_upc, magic_ncols, magic_rin, magic_rwo, magic_wo;
     int RWo, total_blocks;
     // persistent multi-tile kernel only: a workgroup keeps its weight slice in LDS and walks tiles_per_wg pixel tiles

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
     // ---- output addressing, lane = (pixel lr of tile ps) x (couts 4*lq .. +3 of tile cs) -> one 8-byte store; the
     //      residual tensors are fetched before the LAST chunk computes (the staging registers are free by then), so
     //      their latency hides under that chunk's MFMA phase
-    const int plane_o = p.Ho * p.Wo;
+    const int plane_o = p.out_h * p.out_w;
     const size_t grp = (size_t)n0 * p.C8out * plane_o * 16;
     const size_t grp_bytes = (size_t)n_img * p.C8out * plane_o * 16;
     const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(reinterpret_cast<char*>(p.out) + grp, grp_bytes);
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
         const unsigned xx = rem - y * p.Wo;
         const int yy = y0 + y;
         const bool ok = pl < (unsigned)(p.G * p.RWo) && n0 + (int)g < p.N && yy < p.Ho;
-        pix_off[ps] = ok ? (g * p.C8out * plane_o + yy * p.Wo + xx) * 16u : kOob;
+        pix_off[ps] = ok ? (g * p.C8out * plane_o + (yy * p.out_mul + p.off_y) * p.out_w + xx * p.out_mul + p.off_x) * 16u : kOob;
     }
     f32x4 sc[CS], sh[CS];
     unsigned co_off[CS];
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
 
 // regular: big chunks, two workgroups per CU; light: small chunks / few staging registers, three per CU (<= 52 KiB LDS)
 constexpr int f16_ni(int ks, bool light) { return light ? 5 : 10; }
-constexpr int f16_nw(int ks, bool light) { return light ? 5 : (ks == 3 ? 9 : 8); }
+constexpr int f16_nw(int ks, bool light) { return light ? 5 : (ks == 3 ? 9 : 8); }  // ks 2 (deconv phases): 8
 constexpr int f16_occ(bool light) { return light ? 3 : 2; }
 
 template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, bool LIGHT>
@@ -310,7 +310,7 @@ bool f16_configure_mt(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
     f16_variant_dims(variant, CT, PT);
     ConvF16Params& p = L.p;
     const int S = d.stride, KS = d.kh, T = KS * KS;
-    if (!(KS == 3 || (KS == 1 && S == 1))) return false;
+    if (!(KS == 3 || ((KS == 1 || KS == 2) && S == 1))) return false;
     const int occ = f16_variant_mt_occ(variant);
     p.N = d.n; p.H = d.h; p.W = d.w; p.Cout = d.cout;
     p.C8in = (d.cin + 7) / 8;
@@ -318,7 +318,7 @@ bool f16_configure_mt(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
     p.C8out = (d.cout + 7) / 8;
     p.Ho = d.conv_h; p.Wo = d.conv_w; p.pad_t = d.pad_top; p.pad_l = d.pad_left;
     // 32-bit byte offsets over the whole tensors
-    if ((long long)d.n * p.C8in * d.h * d.w * 16 >= 0x7FFFFFF0LL || (long long)d.n * p.C8out * p.Ho * p.Wo * 16 >= 0x7FFFFFF0LL) return false;
+    if ((long long)d.n * p.C8in * d.h * d.w * 16 >= 0x7FFFFFF0LL || (long long)d.n * p.C8out * d.out_h * d.out_w * 16 >= 0x7FFFFFF0LL) return false;
     p.PK = round_up(d.cin, 32) / 8;
     p.PKs = p.C8in < p.PK ? p.C8in : p.PK;
     p.n_chunks = 1; p.nbuf = 2;
@@ -367,6 +367,7 @@ bool f16_configure_mt(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
     if (p.tiles_per_wg < 2) return false;  // nothing to amortise: the one-tile kernel does the same work with less LDS
     p.n_groups = (p.tiles_total + p.tiles_per_wg - 1) / p.tiles_per_wg;
     p.relu = d.relu;
+    p.out_h = d.out_h; p.out_w = d.out_w; p.out_mul = d.out_mul; p.off_y = d.out_off_y; p.off_x = d.out_off_x;
     p.magic_upc = magic_of(p.upc);
     p.magic_ncols = magic_of(p.ncols);
     p.magic_rin = magic_of(p.Rin);
@@ -438,6 +439,7 @@ bool f16_configure(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
     p.tiles_y = (p.G > 1 || p.R >= p.Ho) ? 1 : (p.Ho + p.R - 1) / p.R;
     p.tiles_n = (p.N + p.G - 1) / p.G;
     p.relu = d.relu;
+    p.out_h = d.out_h; p.out_w = d.out_w; p.out_mul = d.out_mul; p.off_y = d.out_off_y; p.off_x = d.out_off_x;
     p.magic_upc = magic_of(p.upc);
     p.magic_ncols = magic_of(p.ncols);
     p.magic_rin = magic_of(p.Rin);
@@ -452,23 +454,26 @@ bool f16_configure(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
 int f16_validate(const mp_conv_desc* d) {
     if (!d) return MP_ERR_NULL;
     if (d->n <= 0 || d->cin <= 0 || d->h <= 0 || d->w <= 0 || d->cout <= 0) return MP_ERR_SHAPE;
-    if (d->kh != d->kw || !(d->kh == 1 || d->kh == 3)) return MP_ERR_UNSUPPORTED;
-    if (!(d->stride == 1 || d->stride == 2)) return MP_ERR_UNSUPPORTED;
+    if (d->kh != d->kw || !(d->kh == 1 || d->kh == 2 || d->kh == 3)) return MP_ERR_UNSUPPORTED;
+    if (!(d->stride == 1 || d->stride == 2) || (d->kh == 2 && d->stride != 1)) return MP_ERR_UNSUPPORTED;
     if (d->pad_top < 0 || d->pad_left < 0 || d->pad_top > d->kh || d->pad_left > d->kw) return MP_ERR_SHAPE;
     if (d->conv_h <= 0 || d->conv_w <= 0) return MP_ERR_SHAPE;
-    // plain output mapping only: the exchange-unit up-sampling has its own streaming kernel in this layout
-    if (d->out_h != d->conv_h || d->out_w != d->conv_w || d->out_mul != 1 || d->out_rep != 1 || d->out_off_y != 0 ||
-        d->out_off_x != 0 || d->tap_dilation_unused != 0)
-        return MP_ERR_UNSUPPORTED;
+    // plain or strided-scatter output mapping (sub-pixel phases of the transposed convolution); replication (nearest
+    // up-sampling) is not part of this kernel: the exchange unit has its own streaming kernel in this layout
+    if (d->out_rep != 1 || d->out_mul < 1 || d->out_off_y < 0 || d->out_off_x < 0 || d->tap_dilation_unused != 0) return MP_ERR_UNSUPPORTED;
+    if (d->out_h <= 0 || d->out_w <= 0) return MP_ERR_SHAPE;
+    if ((d->conv_h - 1) * d->out_mul + d->out_off_y >= d->out_h || (d->conv_w - 1) * d->out_mul + d->out_off_x >= d->out_w) return MP_ERR_SHAPE;
     // every input row / column a tap reads must exist or be zero padding on the top / left only up to pad; the bottom /
     // right overhang is covered by the LDS halo, as in the fp32 kernel
-    if ((long long)d->n * ((d->cout + 7) / 8) * d->conv_h * d->conv_w * 16 >= (1LL << 40)) return MP_ERR_UNSUPPORTED;
+    if ((long long)d->n * ((d->cout + 7) / 8) * d->out_h * d->out_w * 16 >= (1LL << 40)) return MP_ERR_UNSUPPORTED;
     return MP_OK;
 }
 
 // [Cout,Cin,kh,kw] fp32 -> [Cin_pad32/32][T][4][Cout_pad16][8] fp16 (round to nearest even), zero padded
+// transposed = 1: the (py, px) 2x2 sub-pixel phase of a Conv2dTranspose(k=4, s=2, p=1) weight [Cin,Cout,4,4]
 __global__ __launch_bounds__(256) void pack_weight_f16_kernel(const float* __restrict__ w, _Float16* __restrict__ out,
-                                                              int cout, int cin, int kh, int kw, int kq, int cout_pad16) {
+                                                              int cout, int cin, int kh, int kw, int kq, int cout_pad16,
+                                                              int transposed, int py, int px) {
     const int T = kh * kw;
     const size_t total = (size_t)kq * T * 4 * cout_pad16 * 8;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -482,7 +487,16 @@ __global__ __launch_bounds__(256) void pack_weight_f16_kernel(const float* __res
         const int q = (int)(r / T);
         const int ci = q * 32 + g * 8 + j;
         float v = 0.f;
-        if (co < cout && ci < cin) v = w[(((size_t)co * cin + ci) * kh + t / kw) * kw + t % kw];
+        if (co < cout && ci < cin) {
+            const int ty = t / kw, tx = t % kw;
+            if (!transposed) {
+                v = w[(((size_t)co * cin + ci) * kh + ty) * kw + tx];
+            } else {  // out row 2m+py reads in row m-1+py+ty with kernel row 3-2*ty (py=0) or 2-2*ty (py=1); same along x
+                const int ky = py == 0 ? 3 - 2 * ty : 2 - 2 * ty;
+                const int kx = px == 0 ? 3 - 2 * tx : 2 - 2 * tx;
+                v = w[(((size_t)ci * cout + co) * 4 + ky) * 4 + kx];
+            }
+        }
         out[i] = (_Float16)v;
     }
 }
@@ -608,6 +622,7 @@ int f16_build_launch(const mp_conv_desc* desc, int variant, const void* x, const
 int f16_launch(const ConvF16Launch& L, hipStream_t s) {
     if (f16_variant_mt(L.variant)) return f16_mt_launch(L, s);
     if (L.ks == 1) return L.stride == 1 ? launch_f16_ks<1, 1>(L.p, L.variant, L.lds_bytes, s) : launch_f16_ks<1, 2>(L.p, L.variant, L.lds_bytes, s);
+    if (L.ks == 2) return launch_f16_ks<2, 1>(L.p, L.variant, L.lds_bytes, s);
     if (L.ks == 3) return L.stride == 1 ? launch_f16_ks<3, 1>(L.p, L.variant, L.lds_bytes, s) : launch_f16_ks<3, 2>(L.p, L.variant, L.lds_bytes, s);
     return MP_ERR_UNSUPPORTED;
 }
@@ -628,13 +643,16 @@ size_t mp_f16_activation_bytes(int n, int c, int h, int w) {
     return (size_t)n * ((c + 7) / 8) * h * w * 16;
 }
 
-int mp_f16_pack_weight(const float* w, void* packed, int cout, int cin, int kh, int kw, mp_stream_t stream) {
+int mp_f16_pack_weight(const float* w, void* packed, int cout, int cin, int kh, int kw, int transposed, int phase_y, int phase_x,
+                       mp_stream_t stream) {
     if (!w || !packed) return MP_ERR_NULL;
     if (cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0) return MP_ERR_SHAPE;
+    if (transposed < 0 || transposed > 1) return MP_ERR_UNSUPPORTED;
+    if (transposed && (kh != 2 || kw != 2 || phase_y < 0 || phase_y > 1 || phase_x < 0 || phase_x > 1)) return MP_ERR_UNSUPPORTED;
     const int kq = round_up(cin, 32) / 32, cp = round_up(cout, 16);
     const size_t total = (size_t)kq * kh * kw * 4 * cp * 8;
     hipLaunchKernelGGL(pack_weight_f16_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), w,
-                       reinterpret_cast<_Float16*>(packed), cout, cin, kh, kw, kq, cp);
+                       reinterpret_cast<_Float16*>(packed), cout, cin, kh, kw, kq, cp, transposed, phase_y, phase_x);
     return check_launch();
 }
 

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Para
     const int t_begin = grp * p.tiles_per_wg;
     const int t_end = min(t_begin + p.tiles_per_wg, p.tiles_total);
     const int HW = p.H * p.W;
-    const int plane_o = p.Ho * p.Wo;
+    const int plane_o = p.out_h * p.out_w;
 
     // ---- weights: the whole K x CT slice, once
     {
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Para
         const unsigned y = fastdiv(rem, p.Wo, p.magic_wo);
         const unsigned xx = rem - y * p.Wo;
         b_off[ps] = lq * p.plane + g * p.img_plane + (y * S) * p.Wp + xx * S;
-        pix_rel[ps] = (int)((g * p.C8out * plane_o + y * p.Wo + xx) * 16u);
+        pix_rel[ps] = (int)((g * p.C8out * plane_o + (y * p.out_mul + p.off_y) * p.out_w + xx * p.out_mul + p.off_x) * 16u);
         pix_gy[ps] = pl0 < (unsigned)(p.G * p.RWo) ? (int)((g << 16) | y) : -1;
     }
     int a_off[CS];
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Para
         // output addresses of this tile, residuals fetched now (their latency hides under the MFMA loop)
         const int ty = t % p.tiles_y, tn = t / p.tiles_y;
         const int n0 = tn * p.G, y0 = ty * p.R;
-        const int obase = (n0 * p.C8out * plane_o + y0 * p.Wo) * 16;
+        const int obase = (n0 * p.C8out * plane_o + y0 * p.out_mul * p.out_w) * 16;
         unsigned pix_off[PS];
 #pragma unroll
         for (int ps = 0; ps < PS; ++ps) {
@@ -294,6 +294,7 @@ int f16_mt_ni(int occ) { return mt_ni(occ); }
 int f16_mt_launch(const ConvF16Launch& L, hipStream_t s) {
     if (L.ks == 3) return L.stride == 1 ? launch_mt_ks<3, 1>(L.p, L.variant, L.lds_bytes, s) : launch_mt_ks<3, 2>(L.p, L.variant, L.lds_bytes, s);
     if (L.ks == 1 && L.stride == 1) return launch_mt_ks<1, 1>(L.p, L.variant, L.lds_bytes, s);
+    if (L.ks == 2 && L.stride == 1) return launch_mt_ks<2, 1>(L.p, L.variant, L.lds_bytes, s);
     return MP_ERR_UNSUPPORTED;
 }
 

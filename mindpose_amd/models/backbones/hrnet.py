@@ -311,6 +311,7 @@ class HRNet(Backbone):
 
     def emit(self, plan: Plan, x: torch.Tensor) -> torch.Tensor:
         """Recorded form of ``forward_feature`` hrnet.py:559-605."""
+        x = plan.enter(x)
         x = plan.conv(x, self.conv1, self.bn1, relu=True)
         x = plan.conv(x, self.conv2, self.bn2, relu=True)
         for blk in self.layer1:

@@ -48,8 +48,9 @@ class ResNet(Backbone):
 
     def emit(self, plan: Plan, x: torch.Tensor) -> torch.Tensor:
         """Recorded form of ``forward_feature`` resnet.py:247-264."""
-        x = plan.conv(x, self.conv1, self.bn1, relu=True)
+        x = plan.conv(x, self.conv1, self.bn1, relu=True)  # 7x7 stem + max-pool stay fp32 NCHW under amp O2 too
         x = plan.maxpool3x3s2_same(x)
+        x = plan.enter(x)
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in layer:
                 x = blk.emit(plan, x)

@@ -214,6 +214,13 @@ class Plan:
         self.layer_info.append(dict(kind="to_c8", n=n, c=c, h=h, w=w, macs=0))
         return out
 
+    def enter(self, x):
+        """Switch to the plan's compute type: in an fp16 plan an fp32 NCHW tensor is converted to channel-blocked fp16 here
+        (HRNet: the input image; ResNet: after the fp32 7x7 stem and max-pool); otherwise ``x`` is returned unchanged."""
+        if self.half and not isinstance(x, ActC8):
+            return self.to_c8(x)
+        return x
+
     def from_c8(self, x: "ActC8") -> torch.Tensor:
         """channel-blocked fp16 -> NCHW fp32 (the network output handed to the decoder / loss)."""
         n, c, h, w = x.shape
@@ -284,18 +291,17 @@ class Plan:
         return sum(e.get("macs", 0) for e in self.layer_info)
 
     # -- weights ------------------------------------------------------------------------------
-    def _pack(self, weight: torch.Tensor, cout: int, cin: int, k: int, transposed: bool, py: int, px: int) -> torch.Tensor:
-        key = (id(weight), py if transposed else -1, px if transposed else -1)
+    def _pack(self, weight: torch.Tensor, cout: int, cin: int, k: int, transposed: bool, py: int, px: int,
+              half: bool = False) -> torch.Tensor:
+        key = (id(weight), py if transposed else -1, px if transposed else -1, half)
         if key in self._packed:
             return self._packed[key]
         w = weight.detach().to(self.device, torch.float32).contiguous()
-        if self.half:
-            if transposed:
-                raise NotImplementedError("the fp16 path has no transposed-convolution kernels yet (amp_level O0 has)")
+        if half:
             nbytes = self.lib.mp_f16_packed_weight_bytes(cout, cin, k, k)
             packed = torch.empty(nbytes // 2, device=self.device, dtype=torch.float16)
-            _lib.check(self.lib.mp_f16_pack_weight(_lib.ptr(w), _lib.ptr(packed), cout, cin, k, k, _lib.stream()),
-                       "mp_f16_pack_weight")
+            _lib.check(self.lib.mp_f16_pack_weight(_lib.ptr(w), _lib.ptr(packed), cout, cin, k, k, int(transposed), py, px,
+                                                   _lib.stream()), "mp_f16_pack_weight")
             self.keep += [w, packed]
             self._packed[key] = packed
             return packed
@@ -307,8 +313,8 @@ class Plan:
         self._packed[key] = packed
         return packed
 
-    def _affine(self, cout: int, bn: Optional[BatchNorm2d], bias: Optional[torch.Tensor]):
-        key = id(bn) if bn is not None else id(bias)
+    def _affine(self, cout: int, bn: Optional[BatchNorm2d], bias: Optional[torch.Tensor], half: bool = False):
+        key = (id(bn) if bn is not None else id(bias), half)
         if key in self._folded:
             return self._folded[key]
         if bn is not None:
@@ -317,7 +323,7 @@ class Plan:
         else:
             scale = torch.ones(cout, device=self.device)
             shift = bias.detach().float().to(self.device).contiguous() if bias is not None else torch.zeros(cout, device=self.device)
-        if self.half:  # the fp16 kernel reads 4 couts per lane: arrays padded to Cout_pad16 with zeros
+        if half:  # the fp16 kernel reads 4 couts per lane: arrays padded to Cout_pad16 with zeros
             pad = (-cout) % 16
             scale = torch.cat([scale, scale.new_zeros(pad)]).contiguous()
             shift = torch.cat([shift, shift.new_zeros(pad)]).contiguous()
@@ -335,52 +341,55 @@ class Plan:
         k, s, pad = conv.kernel_size, conv.stride, conv.padding
         if cin != conv.in_channels:
             raise ValueError(f"conv expects {conv.in_channels} input channels, got {cin}")
+        half = isinstance(x, ActC8)  # the kernel family follows the activation: fp32 NCHW tensors take the fp32 kernels
         ho = (h + 2 * pad - k) // s + 1
         wo = (w + 2 * pad - k) // s + 1
         oh, ow = ho * upsample, wo * upsample
         if out is None:
-            out = self.alloc(n, conv.out_channels, oh, ow)
+            out = self.alloc(n, conv.out_channels, oh, ow) if half else self.alloc_f32(n, conv.out_channels, oh, ow)
         if tuple(out.shape) != (n, conv.out_channels, oh, ow):
             raise ValueError(f"bad out shape {tuple(out.shape)}")
         for r in (res1, res2):
             if r is not None and tuple(r.shape) != tuple(out.shape):
                 raise ValueError(f"residual shape {tuple(r.shape)} != out shape {tuple(out.shape)}")
-        packed = self._pack(conv.weight, conv.out_channels, cin, k, False, 0, 0)
-        scale, shift = self._affine(conv.out_channels, bn, conv.bias)
+        packed = self._pack(conv.weight, conv.out_channels, cin, k, False, 0, 0, half)
+        scale, shift = self._affine(conv.out_channels, bn, conv.bias, half)
         d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=conv.out_channels, kh=k, kw=k, stride=s, pad_top=pad,
                           pad_left=pad, conv_h=ho, conv_w=wo, out_h=oh, out_w=ow, out_mul=upsample, out_rep=upsample,
                           out_off_y=0, out_off_x=0, relu=int(relu), tap_dilation_unused=0)
-        if self.half and upsample != 1:
+        if half and upsample != 1:
             raise NotImplementedError("fp16 plans add up-sampled terms with fuse_sum, not through the conv epilogue")
-        variant = self._tune(d, x, packed, scale, shift, res1, res2, out)
-        add = self.lib.mp_plan_add_conv_f16 if self.half else self.lib.mp_plan_add_conv_variant
+        variant = tune_conv_variant(self.lib, d, x, packed, scale, shift, res1, res2, out, half=half)
+        add = self.lib.mp_plan_add_conv_f16 if half else self.lib.mp_plan_add_conv_variant
         _lib.check(add(self.handle, ctypes.byref(d), variant, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift),
                        _lib.ptr(res1), _lib.ptr(res2), _lib.ptr(out)), "mp_plan_add_conv")
-        self.layer_info.append(dict(kind="conv_f16" if self.half else "conv", k=k, stride=s, cin=cin, cout=conv.out_channels,
+        self.layer_info.append(dict(kind="conv_f16" if half else "conv", k=k, stride=s, cin=cin, cout=conv.out_channels,
                                     h=h, w=w, n=n, macs=n * ho * wo * conv.out_channels * cin * k * k))
         return out
 
-    def _tune(self, d, x, packed, scale, shift, res1, res2, out) -> int:
-        return tune_conv_variant(self.lib, d, x, packed, scale, shift, res1, res2, out, half=self.half)
-
     def deconv4x4s2(self, x: torch.Tensor, deconv: Conv2dTranspose, bn: BatchNorm2d, relu: bool = True) -> torch.Tensor:
         """Conv2dTranspose(k=4, s=2, p=1) + BN + ReLU as four 2x2 sub-pixel phase convolutions."""
-        if self.half:
-            raise NotImplementedError("the fp16 path has no transposed-convolution kernels yet (amp_level O0 has)")
+        half = isinstance(x, ActC8)
         n, cin, h, w = x.shape
         cout = deconv.out_channels
-        out = self.alloc(n, cout, 2 * h, 2 * w)
-        scale, shift = self._affine(cout, bn, None)
+        out = self.alloc(n, cout, 2 * h, 2 * w) if half else self.alloc_f32(n, cout, 2 * h, 2 * w)
+        scale, shift = self._affine(cout, bn, None, half)
         for py in (0, 1):
             for px in (0, 1):
-                packed = self._pack(deconv.weight, cout, cin, 2, True, py, px)
+                packed = self._pack(deconv.weight, cout, cin, 2, True, py, px, half)
                 d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=2, kw=2, stride=1, pad_top=1 - py,
                                   pad_left=1 - px, conv_h=h, conv_w=w, out_h=2 * h, out_w=2 * w, out_mul=2, out_rep=1,
                                   out_off_y=py, out_off_x=px, relu=int(relu), tap_dilation_unused=0)
-                _lib.check(self.lib.mp_plan_add_conv(self.handle, ctypes.byref(d), _lib.ptr(x), _lib.ptr(packed),
-                                                     _lib.ptr(scale), _lib.ptr(shift), None, None, _lib.ptr(out)),
-                           "mp_plan_add_conv(deconv phase)")
-                self.layer_info.append(dict(kind="deconv_phase", k=2, stride=1, cin=cin, cout=cout, h=h, w=w, n=n,
+                if half:
+                    v = tune_conv_variant(self.lib, d, x, packed, scale, shift, None, None, out, half=True)
+                    _lib.check(self.lib.mp_plan_add_conv_f16(self.handle, ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed),
+                                                             _lib.ptr(scale), _lib.ptr(shift), None, None, _lib.ptr(out)),
+                               "mp_plan_add_conv_f16(deconv phase)")
+                else:
+                    _lib.check(self.lib.mp_plan_add_conv(self.handle, ctypes.byref(d), _lib.ptr(x), _lib.ptr(packed),
+                                                         _lib.ptr(scale), _lib.ptr(shift), None, None, _lib.ptr(out)),
+                               "mp_plan_add_conv(deconv phase)")
+                self.layer_info.append(dict(kind="deconv_phase_f16" if half else "deconv_phase", k=2, stride=1, cin=cin, cout=cout, h=h, w=w, n=n,
                                             macs=n * h * w * cout * cin * 4))
         return out
 
@@ -394,16 +403,16 @@ class Plan:
             if t is not None and tuple(t.shape) != (n, c, h // sc, w // sc):
                 raise ValueError(f"fuse term shape {tuple(t.shape)} does not match {(n, c, h // sc, w // sc)}")
             args += [_lib.ptr(t), int(sc)]
-        add = self.lib.mp_plan_add_fuse_sum_f16 if self.half else self.lib.mp_plan_add_fuse_sum
+        add = self.lib.mp_plan_add_fuse_sum_f16 if isinstance(base, ActC8) else self.lib.mp_plan_add_fuse_sum
         _lib.check(add(self.handle, _lib.ptr(base), *args, _lib.ptr(out), n, c, h, w, int(relu)), "mp_plan_add_fuse_sum")
         self.layer_info.append(dict(kind="fuse_sum", n=n, c=c, h=h, w=w, terms=len(terms), macs=0))
         return out
 
     def maxpool3x3s2_same(self, x: torch.Tensor) -> torch.Tensor:
-        if self.half:
-            raise NotImplementedError("the fp16 path has no max-pool kernel yet (amp_level O0 has)")
+        if isinstance(x, ActC8):
+            raise NotImplementedError("max-pool runs on fp32 NCHW activations (the ResNet stem stays fp32 under amp O2)")
         n, c, h, w = x.shape
-        out = self.alloc(n, c, (h + 1) // 2, (w + 1) // 2)
+        out = self.alloc_f32(n, c, (h + 1) // 2, (w + 1) // 2)
         _lib.check(self.lib.mp_plan_add_maxpool(self.handle, _lib.ptr(x), _lib.ptr(out), n, c, h, w), "mp_plan_add_maxpool")
         self.layer_info.append(dict(kind="maxpool", n=n, c=c, h=h, w=w, macs=0))
         return out
@@ -457,7 +466,7 @@ class PlannedModule(nn.Module):
             with torch.no_grad():
                 plan = Plan(device, half=half)
                 plan.input = plan.alloc_f32(*shape)
-                out = self.emit(plan, plan.to_c8(plan.input) if half else plan.input)
+                out = self.emit(plan, plan.input)  # backbones switch to the fp16 layout themselves (plan.enter)
                 plan.output = plan.from_c8(out) if isinstance(out, ActC8) else out
             self._plans[key] = plan
         return plan

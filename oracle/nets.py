@@ -187,10 +187,10 @@ def maxpool3x3s2_same(x):
     return F.max_pool2d(x, 3, 2)
 
 
-def resnet_forward(params, x, name="resnet50", prefix=""):
+def resnet_forward(params, x, name="resnet50", prefix="", amp=False):
     """ResNet.forward_feature resnet.py:247-264."""
-    p = _P(params, prefix)
-    x = torch.as_tensor(x, dtype=torch.float32)
+    p = _P(params, prefix, False, amp)
+    x = _r(p, torch.as_tensor(x, dtype=torch.float32))
     x = F.relu(_bn(p.sub("bn1"), _conv(p.sub("conv1"), x, 2, 3)))
     x = maxpool3x3s2_same(x)
     for li, nblocks in enumerate(RESNET_LAYERS[name], start=1):
@@ -205,13 +205,13 @@ def hrnet_head_forward(params, x, prefix="", train=False, amp=False):
     return _conv(_P(params, prefix, train, amp).sub("head"), x)
 
 
-def simple_baseline_head_forward(params, x, prefix="", num_deconv_layers=3):
+def simple_baseline_head_forward(params, x, prefix="", num_deconv_layers=3, amp=False):
     """SimpleBaselineHead.construct simple_baseline_head.py:95-98.
     deconv_layer = SequentialCell(deconv, bn, relu, deconv, bn, relu, ...) -> indices 3i, 3i+1."""
-    p = _P(params, prefix)
+    p = _P(params, prefix, False, amp)
     for i in range(num_deconv_layers):
         w = p[f"deconv_layer.{3 * i}.weight"]
-        x = F.conv_transpose2d(x, w, None, stride=2, padding=1)
+        x = _r(p, F.conv_transpose2d(x, _r(p, w), None, stride=2, padding=1))
         x = F.relu(_bn(p.sub(f"deconv_layer.{3 * i + 1}"), x))
     return _conv(p.sub("final_layer"), x)
 
@@ -227,9 +227,12 @@ def net_forward(params, x, backbone="hrnet_w32", head="hrnet_head", amp=False):
     """Net.construct networks.py:39-44 (no neck exists in the reference).  ``amp=True``: HRNet + HRNetHead under the
     op-by-op fp16 emulation of amp level O2 (every cell output rounded to fp16, BatchNorm computed in fp32)."""
     with torch.no_grad():
-        if amp:
+        if amp and backbone.startswith("hrnet"):
             f = hrnet_forward(params, x, backbone, prefix="backbone.", amp=True)
             return hrnet_head_forward(params, f, prefix="head.", amp=True)
+        if amp:
+            f = resnet_forward(params, x, backbone, prefix="backbone.", amp=True)
+            return simple_baseline_head_forward(params, f, prefix="head.", amp=True)
         if backbone.startswith("hrnet"):
             f = hrnet_forward(params, x, backbone, prefix="backbone.")
         else:

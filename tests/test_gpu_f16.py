@@ -99,7 +99,7 @@ def test_conv_f16_vs_oracle(case, variant):
     out = ActC8(n, cout, ho, wo, DEV)
     nb = LIB.mp_f16_packed_weight_bytes(cout, cin, k, k)
     packed = torch.empty(nb // 2, device=DEV, dtype=torch.float16)
-    _lib.check(LIB.mp_f16_pack_weight(_lib.ptr(wt.to(DEV)), _lib.ptr(packed), cout, cin, k, k, _lib.stream()), "pack")
+    _lib.check(LIB.mp_f16_pack_weight(_lib.ptr(wt.to(DEV)), _lib.ptr(packed), cout, cin, k, k, 0, 0, 0, _lib.stream()), "pack")
     padc = (-cout) % 16
     sc = torch.cat([scale, torch.zeros(padc)]).to(DEV)
     sh = torch.cat([shift, torch.zeros(padc)]).to(DEV)
@@ -129,6 +129,42 @@ def test_conv_f16_multi_tile_vs_oracle(case, variant, groups, monkeypatch):
     # 3 groups = ragged last run)
     monkeypatch.setenv("MP_F16_MT_GROUPS", groups)
     test_conv_f16_vs_oracle(case, variant)
+
+
+@pytest.mark.parametrize("variant", [-1, 1, 3, 11, 16])
+def test_deconv_phases_f16_vs_oracle(variant, monkeypatch):
+    # Conv2dTranspose(k=4, s=2, p=1) + BN + ReLU as four 2x2 sub-pixel phase convs with the strided-scatter output mapping
+    monkeypatch.setenv("MP_F16_MT_GROUPS", "2")
+    g = torch.Generator().manual_seed(4)
+    n, cin, cout, h, w = 3, 64, 48, 16, 12
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cin, cout, 4, 4, generator=g) / (cin * 4) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ref = F.conv_transpose2d(_h(x), _h(wt), None, stride=2, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    ref = _h(F.relu(ref))
+    xa = _to_c8(x)
+    out = ActC8(n, cout, 2 * h, 2 * w, DEV)
+    padc = (-cout) % 16
+    sc, sh = torch.cat([scale, torch.zeros(padc)]).to(DEV), torch.cat([shift, torch.zeros(padc)]).to(DEV)
+    nb = LIB.mp_f16_packed_weight_bytes(cout, cin, 2, 2)
+    ran = False
+    for py in (0, 1):
+        for px in (0, 1):
+            packed = torch.empty(nb // 2, device=DEV, dtype=torch.float16)
+            _lib.check(LIB.mp_f16_pack_weight(_lib.ptr(wt.to(DEV)), _lib.ptr(packed), cout, cin, 2, 2, 1, py, px, _lib.stream()), "pack")
+            d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=2, kw=2, stride=1, pad_top=1 - py, pad_left=1 - px, conv_h=h,
+                              conv_w=w, out_h=2 * h, out_w=2 * w, out_mul=2, out_rep=1, out_off_y=py, out_off_x=px, relu=1,
+                              tap_dilation_unused=0)
+            rc = LIB.mp_f16_conv2d_fwd(ctypes.byref(d), variant, _lib.ptr(xa), _lib.ptr(packed), _lib.ptr(sc), _lib.ptr(sh), None,
+                                       None, _lib.ptr(out), _lib.stream())
+            if rc != 0 and variant >= 0:
+                pytest.skip("tile variant not available for this shape")
+            _lib.check(rc, "deconv phase")
+            ran = True
+    assert ran
+    got = _from_c8(out)
+    tol = ref.abs() * 2.0 ** -9 + 1e-4 * ref.abs().max()
+    assert not ((got - ref).abs() > tol).any(), float((got - ref).abs().max())
 
 
 def test_conv_f16_rejects_unsupported():
@@ -166,22 +202,24 @@ def test_fuse_sum_f16(c, h, w, scales):
     assert torch.equal(_from_c8(out), ref)  # same fp32 sums in the same order, one rounding: bit-exact
 
 
-def _net(backbone):
-    return mp.init_synthetic(mp.create_network(backbone, "hrnet_head"), seed=0).to(DEV).eval()
+def _net(backbone, head="hrnet_head"):
+    return mp.init_synthetic(mp.create_network(backbone, head), seed=0).to(DEV).eval()
 
 
 def _nerr(a, b):
     return float((a - b).abs().max() / b.abs().max())
 
 
-@pytest.mark.parametrize("backbone,shape", [("hrnet_w32", (2, 3, 256, 192)), ("hrnet_w48", (1, 3, 128, 96)),
-                                            ("hrnet_w32", (3, 3, 96, 64))])
-def test_network_o2_vs_amp_oracle(backbone, shape):
-    net = _net(backbone)
+@pytest.mark.parametrize("backbone,head,shape", [("hrnet_w32", "hrnet_head", (2, 3, 256, 192)),
+                                                 ("hrnet_w48", "hrnet_head", (1, 3, 128, 96)),
+                                                 ("hrnet_w32", "hrnet_head", (3, 3, 96, 64)),
+                                                 ("resnet50", "simple_baseline_head", (2, 3, 256, 192))])
+def test_network_o2_vs_amp_oracle(backbone, head, shape):
+    net = _net(backbone, head)
     x = torch.randn(*shape, generator=torch.Generator().manual_seed(1))
     params = {k: v.cpu() for k, v in net.state_dict().items()}
-    ref32 = onets.net_forward(params, x, backbone, "hrnet_head")
-    ref16 = onets.net_forward(params, x, backbone, "hrnet_head", amp=True)
+    ref32 = onets.net_forward(params, x, backbone, head)
+    ref16 = onets.net_forward(params, x, backbone, head, amp=True)
     got32 = net(x.to(DEV)).cpu().clone()
     mp.models.auto_mixed_precision(net, "O2")
     got = net(x.to(DEV)).cpu().clone()
