@@ -249,7 +249,8 @@ int mp_conv_wgrad(const mp_conv_desc* desc, const float* x_dev, const float* dz_
 size_t mp_f16_packed_weight_bytes(int cout, int cin, int kh, int kw);
 size_t mp_f16_activation_bytes(int n, int c, int h, int w);
 /* transposed = 0: Conv2d weight [Cout,Cin,kh,kw]; 1: the (phase_y, phase_x) 2x2 sub-pixel phase of a
- * Conv2dTranspose(k=4, s=2, pad=1) weight [Cin,Cout,4,4] (kh = kw = 2), as mp_conv_pack_weight mode 1 */
+ * Conv2dTranspose(k=4, s=2, pad=1) weight [Cin,Cout,4,4] (kh = kw = 2); 2 / 3: the data-gradient packings of
+ * mp_conv_pack_weight (stride-1 conv: roles swapped + taps mirrored; 3x3 stride-2 conv: 2x2 parity phases) */
 int mp_f16_pack_weight(const float* w_dev, void* packed_dev, int cout, int cin, int kh, int kw, int transposed, int phase_y,
                        int phase_x, mp_stream_t stream);
 int mp_f16_to_c8(const float* x_nchw_dev, void* out_c8_dev, int n, int c, int h, int w, mp_stream_t stream);
@@ -282,6 +283,23 @@ int mp_plan_add_layout_f16(mp_plan* plan, int to_c8, const void* x_dev, void* ou
 int mp_warp_affine(const uint8_t* src_dev, const long long* src_offsets_dev, const int* src_hw_dev, const double* trans_dev,
                    void* out_dev, int n, int out_h, int out_w, int normalize, const float mean[3], const float stddev[3],
                    mp_stream_t stream);
+
+/* fp16 (amp O2) training passes over channel-blocked fp16 activations; same contracts as mp_bn_train_fwd / _bwd and
+ * mp_fuse_upsample_sum_bwd (statistics, gamma / beta gradients and the workspace stay fp32 / fp64; mp_bn_workspace_bytes) */
+int mp_f16_bn_train_fwd(const void* z_dev, const float* gamma_dev, const float* beta_dev, const void* res_dev, void* y_dev,
+                        float* save_mean_dev, float* save_invstd_dev, float* moving_mean_dev, float* moving_var_dev, int n, int c,
+                        int hw, float eps, float momentum, int relu, void* workspace_dev, size_t workspace_bytes, mp_stream_t stream);
+int mp_f16_bn_train_bwd(const void* dy_dev, const void* z_dev, const void* y_dev, const float* gamma_dev, const float* save_mean_dev,
+                        const float* save_invstd_dev, void* dz_dev, void* dres_dev, float* dgamma_dev, float* dbeta_dev, int n, int c,
+                        int hw, int relu, void* workspace_dev, size_t workspace_bytes, mp_stream_t stream);
+int mp_f16_fuse_upsample_sum_bwd(const void* dy_dev, const void* out_dev, void* dbase_dev, void* dt1_dev, int s1, void* dt2_dev,
+                                 int s2, void* dt3_dev, int s3, int n, int c, int h, int w, int relu, mp_stream_t stream);
+/* weight gradient of a conv (kernel 1x1 or 3x3, stride 1 or 2, padding k/2) from channel-blocked fp16 x and dz on the fp16
+ * matrix cores, fp32 accumulation and fp32 result dw [Cout,Cin,kh,kw] (times `scale`: pass 1 / loss_scale); workspace from
+ * mp_f16_conv_wgrad_workspace_bytes */
+size_t mp_f16_conv_wgrad_workspace_bytes(const mp_conv_desc* desc);
+int mp_f16_conv_wgrad(const mp_conv_desc* desc, const void* x_c8_dev, const void* dz_c8_dev, float* dw_dev, float scale,
+                      void* workspace_dev, size_t workspace_bytes, mp_stream_t stream);
 
 /* Diagnostics: only a library built with -DMP_CONV_STAMPS=1 (never the product build) records per-workgroup
  * phase cycle counters (8 x uint64 per workgroup) of each conv launch into this device buffer; the product

@@ -491,6 +491,16 @@ __global__ __launch_bounds__(256) void pack_weight_f16_kernel(const float* __res
             const int ty = t / kw, tx = t % kw;
             if (!transposed) {
                 v = w[(((size_t)co * cin + ci) * kh + ty) * kw + tx];
+            } else if (transposed == 2) {
+                // data gradient of a stride-1 conv whose weight is [cin, cout, kh, kw] in forward terms (this packed conv's
+                // cout = forward cin): roles swapped, taps mirrored
+                v = w[(((size_t)ci * cout + co) * kh + (kh - 1 - ty)) * kw + (kw - 1 - tx)];
+            } else if (transposed == 3) {
+                // data gradient of a 3x3 stride-2 pad-1 conv, output parity phase (py, px), as a 2x2 conv over dy:
+                // dx[2a+p] = sum_t dy[a+t] * w[k(p,t)],  k(0,0)=1, k(0,1)=none, k(1,0)=2, k(1,1)=0
+                const int ky = py == 0 ? (ty == 0 ? 1 : -1) : (ty == 0 ? 2 : 0);
+                const int kx = px == 0 ? (tx == 0 ? 1 : -1) : (tx == 0 ? 2 : 0);
+                v = (ky < 0 || kx < 0) ? 0.f : w[(((size_t)ci * cout + co) * 3 + ky) * 3 + kx];
             } else {  // out row 2m+py reads in row m-1+py+ty with kernel row 3-2*ty (py=0) or 2-2*ty (py=1); same along x
                 const int ky = py == 0 ? 3 - 2 * ty : 2 - 2 * ty;
                 const int kx = px == 0 ? 3 - 2 * tx : 2 - 2 * tx;
@@ -647,8 +657,9 @@ int mp_f16_pack_weight(const float* w, void* packed, int cout, int cin, int kh, 
                        mp_stream_t stream) {
     if (!w || !packed) return MP_ERR_NULL;
     if (cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0) return MP_ERR_SHAPE;
-    if (transposed < 0 || transposed > 1) return MP_ERR_UNSUPPORTED;
-    if (transposed && (kh != 2 || kw != 2 || phase_y < 0 || phase_y > 1 || phase_x < 0 || phase_x > 1)) return MP_ERR_UNSUPPORTED;
+    if (transposed < 0 || transposed > 3) return MP_ERR_UNSUPPORTED;
+    if ((transposed == 1 || transposed == 3) && (kh != 2 || kw != 2 || phase_y < 0 || phase_y > 1 || phase_x < 0 || phase_x > 1))
+        return MP_ERR_UNSUPPORTED;
     const int kq = round_up(cin, 32) / 32, cp = round_up(cout, 16);
     const size_t total = (size_t)kq * kh * kw * 4 * cp * 8;
     hipLaunchKernelGGL(pack_weight_f16_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), w,

@@ -196,6 +196,173 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
+// ---- fp16 (amp O2) training: the same BatchNorm passes over channel-blocked fp16 activations [N][C8][HW][8] ------------
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+// fixed-order block reduction of 16 doubles per thread (wave shuffles, then the four waves through LDS)
+__device__ __forceinline__ void block_sum16_256(double (&v)[16], double (*sm)[16]) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        double x = v[j];
+        for (int off = 32; off >= 1; off >>= 1) x += __shfl_down(x, off, 64);
+        v[j] = x;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sm[wave][j] = v[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) v[0] = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+    __syncthreads();
+}
+
+// grid (C8, kBnSplit): block (blk, sp) reduces images sp, sp + kBnSplit, ... of the 8 channels of block blk; partials in the
+// fp32 kernels' layout part[(ch * kBnSplit + sp) * 2 + {0,1}] so that the finalize kernels are shared
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn16_reduce_kernel(const u32x4_t* __restrict__ a_in, const u32x4_t* __restrict__ z,
+                                                          const u32x4_t* __restrict__ y, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, double* __restrict__ part, int n,
+                                                          int c, int c8, int hw, int relu) {
+    const int blk = blockIdx.x, sp = blockIdx.y;
+    float mu[8], is[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ch = blk * 8 + j;
+        mu[j] = (BWD && ch < c) ? mean[ch] : 0.f;
+        is[j] = (BWD && ch < c) ? invstd[ch] : 0.f;
+    }
+    double acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0;
+    for (int img = sp; img < n; img += kBnSplit) {
+        const size_t base = ((size_t)img * c8 + blk) * hw;
+        float f[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) f[j] = 0.f;
+        for (int i = threadIdx.x; i < hw; i += 256) {
+            const h16x8 zv = __builtin_bit_cast(h16x8, z[base + i]);
+            if (BWD) {
+                const h16x8 gv = __builtin_bit_cast(h16x8, a_in[base + i]);
+                h16x8 yv = zv;
+                if (relu) yv = __builtin_bit_cast(h16x8, y[base + i]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float g = (float)gv[j];
+                    if (relu && !((float)yv[j] > 0.f)) g = 0.f;
+                    const float xh = ((float)zv[j] - mu[j]) * is[j];
+                    f[2 * j] += g;
+                    f[2 * j + 1] += g * xh;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = (float)zv[j];
+                    f[2 * j] += v;
+                    f[2 * j + 1] += v * v;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] += (double)f[j];
+    }
+    __shared__ double sm[4][16];
+    block_sum16_256(acc, sm);
+    if (threadIdx.x < 16) {
+        const int ch = blk * 8 + (threadIdx.x >> 1);
+        if (ch < c) part[((size_t)ch * kBnSplit + sp) * 2 + (threadIdx.x & 1)] = acc[0];
+    }
+}
+
+// y = act(z * scale[c] + shift[c] (+ res)) over c8 elements; padding channels stay zero
+__global__ __launch_bounds__(256) void bn16_apply_kernel(const u32x4_t* __restrict__ z, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const u32x4_t* __restrict__ res,
+                                                         u32x4_t* __restrict__ y, int c, int c8, int hw, size_t total, int relu) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int blk = (int)((i / hw) % c8);
+        const h16x8 zv = __builtin_bit_cast(h16x8, z[i]);
+        h16x8 rv = zv;
+        if (res) rv = __builtin_bit_cast(h16x8, res[i]);
+        h16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ch = blk * 8 + j;
+            float v = 0.f;
+            if (ch < c) {
+                v = (float)zv[j] * scale[ch] + shift[ch];
+                if (res) v += (float)rv[j];
+                if (relu) v = fmaxf(v, 0.f);
+            }
+            o[j] = (_Float16)v;
+        }
+        y[i] = __builtin_bit_cast(u32x4_t, o);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn16_bwd_apply_kernel(const u32x4_t* __restrict__ dy, const u32x4_t* __restrict__ z,
+                                                             const u32x4_t* __restrict__ y, const float* __restrict__ gamma,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                             u32x4_t* __restrict__ dz, u32x4_t* __restrict__ dres, int c, int c8,
+                                                             int hw, size_t total, int relu, float inv_count) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int blk = (int)((i / hw) % c8);
+        const h16x8 gv = __builtin_bit_cast(h16x8, dy[i]);
+        const h16x8 zv = __builtin_bit_cast(h16x8, z[i]);
+        h16x8 yv = zv;
+        if (relu) yv = __builtin_bit_cast(h16x8, y[i]);
+        h16x8 oz, og;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ch = blk * 8 + j;
+            float g = 0.f, d = 0.f;
+            if (ch < c) {
+                g = (float)gv[j];
+                if (relu && !((float)yv[j] > 0.f)) g = 0.f;
+                const float is = invstd[ch];
+                const float xh = ((float)zv[j] - mean[ch]) * is;
+                d = gamma[ch] * is * (g - dbeta[ch] * inv_count - xh * dgamma[ch] * inv_count);
+            }
+            oz[j] = (_Float16)d;
+            og[j] = (_Float16)g;
+        }
+        dz[i] = __builtin_bit_cast(u32x4_t, oz);
+        if (dres) dres[i] = __builtin_bit_cast(u32x4_t, og);
+    }
+}
+
+// backward of the exchange-unit sum in the c8 layout: g = dy * (out > 0); term k gets the s_k x s_k block sums of g
+__global__ __launch_bounds__(256) void fuse_sum16_bwd_kernel(const u32x4_t* __restrict__ dy, const u32x4_t* __restrict__ out,
+                                                             u32x4_t* __restrict__ dt, int planes, int h, int w, int sh, int relu) {
+    const int lh = h >> sh, lw = w >> sh, s = 1 << sh;
+    const size_t total = (size_t)planes * lh * lw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int lx = (int)(i % lw);
+        const size_t r = i / lw;
+        const int ly = (int)(r % lh);
+        const size_t plane = r / lh;
+        const size_t o = (plane * h + (size_t)ly * s) * w + (size_t)lx * s;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < s; ++a)
+            for (int b = 0; b < s; ++b) {
+                const h16x8 gv = __builtin_bit_cast(h16x8, dy[o + (size_t)a * w + b]);
+                h16x8 ov = gv;
+                if (relu) ov = __builtin_bit_cast(h16x8, out[o + (size_t)a * w + b]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float g = (float)gv[j];
+                    if (relu && !((float)ov[j] > 0.f)) g = 0.f;
+                    acc[j] += g;
+                }
+            }
+        h16x8 res;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) res[j] = (_Float16)acc[j];
+        dt[i] = __builtin_bit_cast(u32x4_t, res);
+    }
+}
+
 static int log2_exact_t(int v) {
     for (int i = 0; i < 16; ++i)
         if ((1 << i) == v) return i;
@@ -289,6 +456,86 @@ int mp_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq,
                        count, lr, beta1, beta2, eps, weight_decay);
     return check_launch();
+}
+
+
+int mp_f16_bn_train_fwd(const void* z, const float* gamma, const float* beta, const void* res, void* y, float* save_mean,
+                        float* save_invstd, float* moving_mean, float* moving_var, int n, int c, int hw, float eps, float momentum,
+                        int relu, void* workspace, size_t workspace_bytes, mp_stream_t stream) {
+    if (!z || !gamma || !beta || !y || !save_mean || !save_invstd) return MP_ERR_NULL;
+    if ((moving_mean == nullptr) != (moving_var == nullptr)) return MP_ERR_NULL;
+    if (n <= 0 || c <= 0 || hw <= 0) return MP_ERR_SHAPE;
+    if (!workspace || workspace_bytes < mp_bn_workspace_bytes(c)) return MP_ERR_WORKSPACE;
+    double* part = reinterpret_cast<double*>(workspace);
+    float* scale = reinterpret_cast<float*>(part + (size_t)c * kBnSplit * 2);
+    float* shift = scale + c;
+    const int c8 = (c + 7) / 8;
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(bn16_reduce_kernel<false>, dim3(c8, kBnSplit), dim3(256), 0, s, nullptr, reinterpret_cast<const u32x4_t*>(z),
+                       nullptr, nullptr, nullptr, part, n, c, c8, hw, 0);
+    int rc = check_launch();
+    if (rc != MP_OK) return rc;
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((c + 63) / 64), dim3(64), 0, s, part, gamma, beta, save_mean, save_invstd,
+                       scale, shift, moving_mean, moving_var, c, (double)n * hw, eps, momentum);
+    rc = check_launch();
+    if (rc != MP_OK) return rc;
+    const size_t total = (size_t)n * c8 * hw;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bn16_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const u32x4_t*>(z), scale, shift,
+                       reinterpret_cast<const u32x4_t*>(res), reinterpret_cast<u32x4_t*>(y), c, c8, hw, total, relu ? 1 : 0);
+    return check_launch();
+}
+
+int mp_f16_bn_train_bwd(const void* dy, const void* z, const void* y, const float* gamma, const float* save_mean,
+                        const float* save_invstd, void* dz, void* dres, float* dgamma, float* dbeta, int n, int c, int hw, int relu,
+                        void* workspace, size_t workspace_bytes, mp_stream_t stream) {
+    if (!dy || !z || !gamma || !save_mean || !save_invstd || !dz || !dgamma || !dbeta) return MP_ERR_NULL;
+    if (relu && !y) return MP_ERR_NULL;
+    if (n <= 0 || c <= 0 || hw <= 0) return MP_ERR_SHAPE;
+    if (!workspace || workspace_bytes < mp_bn_workspace_bytes(c)) return MP_ERR_WORKSPACE;
+    double* part = reinterpret_cast<double*>(workspace);
+    const int c8 = (c + 7) / 8;
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(bn16_reduce_kernel<true>, dim3(c8, kBnSplit), dim3(256), 0, s, reinterpret_cast<const u32x4_t*>(dy),
+                       reinterpret_cast<const u32x4_t*>(z), reinterpret_cast<const u32x4_t*>(y), save_mean, save_invstd, part, n, c,
+                       c8, hw, relu ? 1 : 0);
+    int rc = check_launch();
+    if (rc != MP_OK) return rc;
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((c + 63) / 64), dim3(64), 0, s, part, dgamma, dbeta, c);
+    rc = check_launch();
+    if (rc != MP_OK) return rc;
+    const size_t total = (size_t)n * c8 * hw;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bn16_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const u32x4_t*>(dy),
+                       reinterpret_cast<const u32x4_t*>(z), reinterpret_cast<const u32x4_t*>(y), gamma, save_mean, save_invstd, dgamma,
+                       dbeta, reinterpret_cast<u32x4_t*>(dz), reinterpret_cast<u32x4_t*>(dres), c, c8, hw, total, relu ? 1 : 0,
+                       (float)(1.0 / ((double)n * hw)));
+    return check_launch();
+}
+
+int mp_f16_fuse_upsample_sum_bwd(const void* dy, const void* out, void* dbase, void* dt1, int s1, void* dt2, int s2, void* dt3,
+                                 int s3, int n, int c, int h, int w, int relu, mp_stream_t stream) {
+    if (!dy || (relu && !out)) return MP_ERR_NULL;
+    if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return MP_ERR_SHAPE;
+    hipStream_t s = as_stream(stream);
+    void* dts[4] = {dbase, dt1, dt2, dt3};
+    const int ss[4] = {1, s1, s2, s3};
+    const int planes = n * ((c + 7) / 8);
+    for (int k = 0; k < 4; ++k) {
+        if (!dts[k]) continue;
+        const int sh = log2_exact_t(ss[k]);
+        if (sh < 0 || (h % ss[k]) || (w % ss[k])) return MP_ERR_UNSUPPORTED;
+        const size_t total = (size_t)planes * (h >> sh) * (w >> sh);
+        size_t blocks = (total + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(fuse_sum16_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const u32x4_t*>(dy),
+                           reinterpret_cast<const u32x4_t*>(out), reinterpret_cast<u32x4_t*>(dts[k]), planes, h, w, sh, relu ? 1 : 0);
+        int rc = check_launch();
+        if (rc != MP_OK) return rc;
+    }
+    return MP_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,292 @@
+// Weight gradient of a convolution on the fp16 matrix cores (amp O2 training), channel-blocked fp16 operands.
+//
+//   dW[co][ci][t] = sum over pixels p of dz[p][co] * x[p*S + tap t][ci]        (fp32 accumulation, fp32 result)
+//
+// Per tap this is a GEMM with the PIXEL axis as K.  Both operands live in HBM channel-blocked (8 channels of one pixel =
+// 16 B), i.e. K-strided for the MFMA, so the tiles are staged pixel-major in LDS - row = one position, 32 channels per row -
+// and read with the gfx950 transposing LDS read ds_read_b64_tr_b16: a 16-lane group fetches 4 positions x 16 channels and
+// every lane receives ITS channel at the 4 positions, exactly the k-contiguous fragment v_mfma_f32_16x16x32_f16 wants.
+//
+// Position trick: the dz tile is stored with the SAME row pitch P as the (halo-padded) x tile, its padding columns zero,
+// so that for stride S the x position of tap (ty, tx) is  S*k + ty*P + tx  - linear in the dz position k = y*P + x
+// ((S*y + ty)*P + S*x + tx).  The padding columns cost MFMA work on zeros (a few per cent at stride 1, half of the
+// k-steps at stride 2, which only the rare down-sampling convs use) and remove all index arithmetic from the loop.
+//
+// Workgroup = 32 couts x 32 cins x all taps (wave = one 16x16 sub-tile, T accumulators); the pixel axis is split over
+// gridDim.y slabs that a fixed-order reduce sums (deterministic, no atomics).  Tiles are double-buffered in LDS with the
+// next tile's 16-byte range-checked buffer loads in flight during the MFMA loop.
+#include "common.h"
+#include "conv_f16_dev.h"
+
+namespace mp {
+
+namespace {
+
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+struct frag8 {
+    s16x4 lo, hi;
+};
+
+constexpr int kRowHalfs = 40;  // LDS row = 32 channels (64 B) + 16 B pad: rows stay 16-byte aligned, banks spread
+
+struct Wgrad16Params {
+    const void* x;
+    const void* dz;
+    float* slabs;
+    int N, Cin, C8in, H, W, Cout, C8out, Ho, Wo, pad;
+    int R, P, Px, Rin, K, xrows;
+    int tiles_y, tiles, splits, tiles_per_split, ci_tiles;
+    unsigned magic_wo, magic_w;
+};
+
+__device__ __forceinline__ s16x4 tr_read(const _Float16* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+
+template <int KS, int S, int NZ, int NX>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16_kernel(const Wgrad16Params p) {
+    constexpr int T = KS * KS;
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];
+    const int zbuf = p.K * kRowHalfs, xbuf = p.xrows * kRowHalfs;  // halfs per buffer
+    _Float16* lds_z = smem_h;             // [2][zbuf]
+    _Float16* lds_x = smem_h + 2 * zbuf;  // [2][xbuf]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co_sub = wave & 1, ci_sub = wave >> 1;
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int co_tile = blockIdx.x / p.ci_tiles, ci_tile = blockIdx.x % p.ci_tiles;
+    const int t_begin = blockIdx.y * p.tiles_per_split;
+    const int t_end = min(t_begin + p.tiles_per_split, p.tiles);
+
+    {
+        u32x4* z = reinterpret_cast<u32x4*>(smem_h);
+        const int n16 = (2 * (zbuf + xbuf)) >> 3;
+        const u32x4 zero = (u32x4){0u, 0u, 0u, 0u};
+        for (int i = tid; i < n16; i += 256) z[i] = zero;
+    }
+
+    // staging tables (tile independent): 16-byte units = (position, 8-channel block)
+    int zoff[NZ], zdst[NZ], zrow[NZ];
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+        const unsigned u = tid + 256 * i;
+        zdst[i] = -1; zoff[i] = 0; zrow[i] = 0;
+        if (u < (unsigned)(p.R * p.Wo * 4)) {
+            const unsigned blk = u & 3, pos = u >> 2;
+            const unsigned r = fastdiv(pos, p.Wo, p.magic_wo), xx = pos - r * p.Wo;
+            const int cb = co_tile * 4 + (int)blk;
+            if (cb < p.C8out) {
+                zoff[i] = (int)(((unsigned)cb * p.Ho * p.Wo + r * p.Wo + xx) * 16u);
+                zdst[i] = (int)((r * p.P + xx) * kRowHalfs + blk * 8);
+                zrow[i] = (int)r;
+            }
+        }
+    }
+    int xoff[NX], xdst[NX], xrow[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const unsigned u = tid + 256 * i;
+        xdst[i] = -1; xoff[i] = 0; xrow[i] = 0;
+        if (u < (unsigned)(p.Rin * p.W * 4)) {
+            const unsigned blk = u & 3, pos = u >> 2;
+            const unsigned r = fastdiv(pos, p.W, p.magic_w), xx = pos - r * p.W;
+            const int cb = ci_tile * 4 + (int)blk;
+            if (cb < p.C8in) {
+                xoff[i] = (int)(((unsigned)cb * p.H * p.W + r * p.W + xx) * 16u);
+                xdst[i] = (int)((r * p.Px + xx + p.pad) * kRowHalfs + blk * 8);
+                xrow[i] = (int)r;
+            }
+        }
+    }
+
+    const __amdgpu_buffer_rsrc_t rs_z = make_rsrc(p.dz, (size_t)p.N * p.C8out * p.Ho * p.Wo * 16);
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x, (size_t)p.N * p.C8in * p.H * p.W * 16);
+    u32x4 vz[NZ], vx[NX];
+    auto stage_load = [&](int t) {
+        const int n = t / p.tiles_y, ty = t - n * p.tiles_y;
+        const int y0 = ty * p.R, yin0 = y0 * S - p.pad;
+        const int zb = (n * p.C8out * p.Ho * p.Wo + y0 * p.Wo) * 16;
+        const int xb = (n * p.C8in * p.H * p.W + yin0 * p.W) * 16;
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) {
+            const bool ok = zdst[i] >= 0 && y0 + zrow[i] < p.Ho;
+            vz[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_z, ok ? (unsigned)(zb + zoff[i]) : kOob, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int yin = yin0 + xrow[i];
+            const bool ok = xdst[i] >= 0 && yin >= 0 && yin < p.H;
+            vx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? (unsigned)(xb + xoff[i]) : kOob, 0, 0);
+        }
+    };
+    auto stage_store = [&](int buf) {  // rows outside the tensor arrive as zeros and overwrite the previous tile's data
+        _Float16* dzp = lds_z + buf * zbuf;
+        _Float16* dxp = lds_x + buf * xbuf;
+#pragma unroll
+        for (int i = 0; i < NZ; ++i)
+            if (zdst[i] >= 0) *reinterpret_cast<u32x4*>(dzp + zdst[i]) = vz[i];
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+            if (xdst[i] >= 0) *reinterpret_cast<u32x4*>(dxp + xdst[i]) = vx[i];
+    };
+
+    f32x4 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // lane-constant operand offsets (halfs): row (8g + q) of a k-step, this wave's 16 channels, 4 halfs per lane
+    const int a_base = (8 * g + q) * kRowHalfs + co_sub * 16 + 4 * pp;
+    const int b_base = S * (8 * g + q) * kRowHalfs + ci_sub * 16 + 4 * pp;
+
+    if (t_begin < t_end) {
+        stage_load(t_begin);
+        __syncthreads();  // zero fill complete
+        stage_store(0);
+        __syncthreads();
+    }
+    const int ksteps = p.K >> 5;
+    for (int t = t_begin; t < t_end; ++t) {
+        const int buf = (t - t_begin) & 1;
+        const bool more = t + 1 < t_end;
+        if (more) stage_load(t + 1);
+        const _Float16* zt = lds_z + buf * zbuf + a_base;
+        const _Float16* xt = lds_x + buf * xbuf + b_base;
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const _Float16* za = zt + ks * 32 * kRowHalfs;
+            const _Float16* xb = xt + ks * 32 * S * kRowHalfs;
+            frag8 a;
+            a.lo = tr_read(za);
+            a.hi = tr_read(za + 4 * kRowHalfs);
+            const f16x8 af = __builtin_bit_cast(f16x8, a);
+#pragma unroll
+            for (int tp = 0; tp < T; ++tp) {
+                const int off = ((tp / KS) * p.Px + (tp % KS)) * kRowHalfs;
+                frag8 b;
+                b.lo = tr_read(xb + off);
+                b.hi = tr_read(xb + off + 4 * S * kRowHalfs);
+                acc[tp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, __builtin_bit_cast(f16x8, b), acc[tp], 0, 0, 0);
+            }
+        }
+        if (more) {
+            stage_store(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // D: lane holds couts 4g .. 4g+3 (rows) of cin (lane & 15) (column) -> slab [Cout][Cin][T]
+    float* slab = p.slabs + (size_t)blockIdx.y * p.Cout * p.Cin * T;
+    const int ci = ci_tile * 32 + ci_sub * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = co_tile * 32 + co_sub * 16 + 4 * g + r;
+        if (co < p.Cout && ci < p.Cin) {
+#pragma unroll
+            for (int tp = 0; tp < T; ++tp) slab[((size_t)co * p.Cin + ci) * T + tp] = acc[tp][r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad16_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, size_t count,
+                                                             int splits, float scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 8 <= splits; k += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part[j] += slabs[(size_t)(k + j) * count + i];
+        }
+        for (int j = 0; k < splits; ++k, ++j) part[j] += slabs[(size_t)k * count + i];
+        dw[i] = (((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]))) * scale;
+    }
+}
+
+constexpr int kNZ = 4, kNX = 8;
+
+int geometry(const mp_conv_desc* d, Wgrad16Params& p, size_t& lds_bytes) {
+    if (!d) return MP_ERR_NULL;
+    if (d->n <= 0 || d->cin <= 0 || d->cout <= 0 || d->h <= 0 || d->w <= 0 || d->conv_h <= 0 || d->conv_w <= 0) return MP_ERR_SHAPE;
+    if (d->kh != d->kw || !(d->kh == 1 || d->kh == 3)) return MP_ERR_UNSUPPORTED;
+    if (!(d->stride == 1 || d->stride == 2)) return MP_ERR_UNSUPPORTED;
+    if (d->pad_top != d->pad_left || d->pad_top != d->kh / 2) return MP_ERR_UNSUPPORTED;
+    const int S = d->stride, KS = d->kh;
+    p.N = d->n; p.Cin = d->cin; p.C8in = (d->cin + 7) / 8; p.H = d->h; p.W = d->w;
+    p.Cout = d->cout; p.C8out = (d->cout + 7) / 8; p.Ho = d->conv_h; p.Wo = d->conv_w; p.pad = d->pad_top;
+    if ((long long)p.N * p.C8in * p.H * p.W * 16 >= 0x7FFFFFF0LL || (long long)p.N * p.C8out * p.Ho * p.Wo * 16 >= 0x7FFFFFF0LL)
+        return MP_ERR_UNSUPPORTED;
+    // common pitch: a row holds the Wo gradient columns and the W + 2*pad input columns
+    p.P = p.W + 2 * p.pad > p.Wo ? p.W + 2 * p.pad : p.Wo;
+    p.Px = p.P;
+    bool found = false;
+    for (int R = p.Ho < 16 ? p.Ho : 16; R >= 1; --R) {
+        p.R = R;
+        p.Rin = (R - 1) * S + KS;
+        p.K = (R * p.P + 31) / 32 * 32;
+        p.xrows = S * (p.K - 1) + (KS - 1) * p.Px + (KS - 1) + 1;
+        if (p.xrows < p.Rin * p.Px) p.xrows = p.Rin * p.Px;
+        lds_bytes = (size_t)2 * (p.K + p.xrows) * kRowHalfs * 2;
+        if (R * p.Wo * 4 <= kNZ * 256 && p.Rin * p.W * 4 <= kNX * 256 && lds_bytes <= 78 * 1024) { found = true; break; }
+    }
+    if (!found) return MP_ERR_UNSUPPORTED;
+    p.tiles_y = (p.Ho + p.R - 1) / p.R;
+    p.tiles = p.N * p.tiles_y;
+    p.ci_tiles = (p.Cin + 31) / 32;
+    const int ct = ((p.Cout + 31) / 32) * p.ci_tiles;
+    int splits = 1024 / ct;
+    if (splits < 1) splits = 1;
+    if (splits > 64) splits = 64;
+    if (splits > p.tiles) splits = p.tiles;
+    p.tiles_per_split = (p.tiles + splits - 1) / splits;
+    p.splits = (p.tiles + p.tiles_per_split - 1) / p.tiles_per_split;
+    p.magic_wo = magic_of(p.Wo);
+    p.magic_w = magic_of(p.W);
+    return MP_OK;
+}
+
+template <int KS, int S>
+int launch_wgrad16(const Wgrad16Params& p, size_t lds, hipStream_t s) {
+    auto kern = conv_wgrad_f16_kernel<KS, S, kNZ, kNX>;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(((p.Cout + 31) / 32) * p.ci_tiles, p.splits), dim3(256), lds, s, p);
+    return check_launch();
+}
+
+}  // namespace
+}  // namespace mp
+
+using namespace mp;
+
+extern "C" {
+
+size_t mp_f16_conv_wgrad_workspace_bytes(const mp_conv_desc* desc) {
+    Wgrad16Params p{};
+    size_t lds = 0;
+    if (geometry(desc, p, lds) != MP_OK) return 0;
+    return (size_t)p.splits * p.Cout * p.Cin * desc->kh * desc->kw * sizeof(float);
+}
+
+int mp_f16_conv_wgrad(const mp_conv_desc* desc, const void* x, const void* dz, float* dw, float scale, void* workspace,
+                      size_t workspace_bytes, mp_stream_t stream) {
+    if (!x || !dz || !dw) return MP_ERR_NULL;
+    Wgrad16Params p{};
+    size_t lds = 0;
+    int rc = geometry(desc, p, lds);
+    if (rc != MP_OK) return rc;
+    const size_t count = (size_t)p.Cout * p.Cin * desc->kh * desc->kw;
+    if (!workspace || workspace_bytes < (size_t)p.splits * count * sizeof(float)) return MP_ERR_WORKSPACE;
+    p.x = x; p.dz = dz; p.slabs = reinterpret_cast<float*>(workspace);
+    hipStream_t s = as_stream(stream);
+    if (desc->kh == 3) rc = desc->stride == 1 ? launch_wgrad16<3, 1>(p, lds, s) : launch_wgrad16<3, 2>(p, lds, s);
+    else rc = desc->stride == 1 ? launch_wgrad16<1, 1>(p, lds, s) : launch_wgrad16<1, 2>(p, lds, s);
+    if (rc != MP_OK) return rc;
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad16_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p.slabs, dw, count, p.splits, scale);
+    return check_launch();
+}
+
+}  // extern "C"

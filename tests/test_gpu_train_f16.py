@@ -1,0 +1,206 @@
+"""fp16 (amp O2) training kernels against torch-CPU autograd on fp16-rounded operands (fp32 accumulation on both sides),
+through the C ABI.  Tolerances: fp16 outputs one ulp (2^-9 relative + 1e-4 of scale); fp32 weight gradients 1e-4 of scale
+(accumulation order only)."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs an MI355X", allow_module_level=True)
+
+from mindpose_amd import _lib  # noqa: E402
+from mindpose_amd.models.layers import ActC8  # noqa: E402
+
+DEV = torch.device("cuda:0")
+LIB = _lib.load()
+
+
+def _h(x):
+    return x.half().float()
+
+
+def _to_c8(x):
+    n, c, h, w = x.shape
+    a = ActC8(n, c, h, w, DEV)
+    _lib.check(LIB.mp_f16_to_c8(_lib.ptr(x.to(DEV).contiguous()), _lib.ptr(a), n, c, h, w, _lib.stream()), "to_c8")
+    return a
+
+
+def _from_c8(a):
+    n, c, h, w = a.shape
+    out = torch.empty(n, c, h, w, device=DEV)
+    _lib.check(LIB.mp_f16_from_c8(_lib.ptr(a), _lib.ptr(out), n, c, h, w, _lib.stream()), "from_c8")
+    return out.cpu()
+
+
+def _close16(got, ref, what=""):
+    tol = ref.abs() * 2.0 ** -9 + 2e-4 * ref.abs().max()
+    bad = (got - ref).abs() > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.numel()} beyond tolerance, max diff {float((got - ref).abs().max())}"
+
+
+def _desc(n, cin, h, w, cout, k, s, pad, ho, wo, oh=None, ow=None, mul=1, oy=0, ox=0, pt=None, pl=None):
+    return _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=k, kw=k, stride=s, pad_top=pad if pt is None else pt,
+                         pad_left=pad if pl is None else pl, conv_h=ho, conv_w=wo, out_h=oh or ho, out_w=ow or wo, out_mul=mul,
+                         out_rep=1, out_off_y=oy, out_off_x=ox, relu=0, tap_dilation_unused=0)
+
+
+WGRAD_CASES = [
+    # n, cin, cout, k, s, h, w
+    (3, 32, 32, 3, 1, 64, 48),
+    (4, 64, 64, 3, 1, 32, 24),
+    (5, 128, 128, 3, 1, 16, 12),
+    (6, 256, 256, 3, 1, 8, 6),
+    (2, 3, 64, 3, 2, 64, 48),
+    (3, 64, 128, 3, 2, 32, 24),
+    (3, 48, 96, 3, 2, 24, 18),
+    (2, 64, 256, 1, 1, 32, 24),
+    (2, 256, 64, 1, 1, 16, 12),
+    (3, 32, 17, 1, 1, 64, 48),
+    (2, 40, 24, 3, 1, 9, 7),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_wgrad_f16_vs_torch(case):
+    n, cin, cout, k, s, h, w = case
+    g = torch.Generator().manual_seed(sum(case))
+    pad = k // 2
+    ho, wo = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+    x = torch.randn(n, cin, h, w, generator=g)
+    dz = torch.randn(n, cout, ho, wo, generator=g)
+    wt = torch.zeros(cout, cin, k, k, requires_grad=True)
+    F.conv2d(_h(x), wt, None, stride=s, padding=pad).backward(_h(dz))
+    ref = wt.grad * 0.5
+    d = _desc(n, cin, h, w, cout, k, s, pad, ho, wo)
+    nb = LIB.mp_f16_conv_wgrad_workspace_bytes(ctypes.byref(d))
+    assert nb > 0
+    ws = torch.empty(nb // 4, device=DEV)
+    dw = torch.full((cout, cin, k, k), float("nan"), device=DEV)
+    xa, dza = _to_c8(x), _to_c8(dz)  # keep the device tensors alive: the ABI only sees raw pointers
+    _lib.check(LIB.mp_f16_conv_wgrad(ctypes.byref(d), _lib.ptr(xa), _lib.ptr(dza), _lib.ptr(dw), 0.5, _lib.ptr(ws), nb,
+                                     _lib.stream()), "wgrad")
+    got = dw.cpu()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err < 1e-4, err
+    # deterministic: bit-identical on a second launch
+    dw2 = torch.empty_like(dw)
+    _lib.check(LIB.mp_f16_conv_wgrad(ctypes.byref(d), _lib.ptr(xa), _lib.ptr(dza), _lib.ptr(dw2), 0.5, _lib.ptr(ws), nb,
+                                     _lib.stream()), "wgrad")
+    assert torch.equal(dw, dw2)
+
+
+DGRAD_CASES = [(2, 32, 48, 3, 1, 32, 24), (3, 64, 64, 3, 1, 16, 12), (2, 64, 128, 3, 2, 32, 24), (2, 48, 96, 3, 2, 24, 16),
+               (2, 64, 256, 1, 1, 16, 12)]
+
+
+@pytest.mark.parametrize("case", DGRAD_CASES)
+def test_dgrad_f16_vs_torch(case):
+    n, cin, cout, k, s, h, w = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    pad = k // 2
+    ho, wo = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    dz = torch.randn(n, cout, ho, wo, generator=g)
+    x = torch.zeros(n, cin, h, w, requires_grad=True)
+    F.conv2d(x, _h(wt), None, stride=s, padding=pad).backward(_h(dz))
+    ref = _h(x.grad)
+    dza = _to_c8(dz)
+    dx = ActC8(n, cin, h, w, DEV)
+    ones = torch.ones((cin + 15) // 16 * 16, device=DEV)
+    zeros = torch.zeros_like(ones)
+    wdev = wt.to(DEV)
+
+    def run(d, mode, kk, py=0, px=0):
+        nb = LIB.mp_f16_packed_weight_bytes(cin, cout, kk, kk)
+        packed = torch.empty(nb // 2, device=DEV, dtype=torch.float16)
+        _lib.check(LIB.mp_f16_pack_weight(_lib.ptr(wdev), _lib.ptr(packed), cin, cout, kk, kk, mode, py, px, _lib.stream()), "pack")
+        _lib.check(LIB.mp_f16_conv2d_fwd(ctypes.byref(d), -1, _lib.ptr(dza), _lib.ptr(packed), _lib.ptr(ones), _lib.ptr(zeros), None,
+                                         None, _lib.ptr(dx), _lib.stream()), "dgrad")
+    if s == 1:
+        run(_desc(n, cout, ho, wo, cin, k, 1, k - 1 - pad, h, w), 2, k)
+    else:
+        for py in (0, 1):
+            for px in (0, 1):
+                run(_desc(n, cout, ho, wo, cin, 2, 1, 0, ho, wo, oh=h, ow=w, mul=2, oy=py, ox=px), 3, 2, py, px)
+    _close16(_from_c8(dx), ref, "dx")
+
+
+@pytest.mark.parametrize("c,h,w,relu,with_res", [(32, 64, 48, True, True), (64, 16, 12, True, False), (17, 8, 6, False, False),
+                                                 (48, 24, 18, True, True)])
+def test_bn_train_f16_fwd_bwd_vs_torch(c, h, w, relu, with_res):
+    g = torch.Generator().manual_seed(c + h)
+    n = 6
+    z = (torch.randn(n, c, h, w, generator=g) * 1.5 + 0.3)
+    res = torch.randn(n, c, h, w, generator=g) if with_res else None
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+    dy = torch.randn(n, c, h, w, generator=g)
+    mm, mv = torch.zeros(c), torch.ones(c)
+    zt = _h(z).requires_grad_(True)
+    rt = _h(res).requires_grad_(True) if with_res else None
+    gt, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rmm, rmv = mm.clone(), mv.clone()
+    y = F.batch_norm(zt, rmm, rmv, gt, bt, training=True, momentum=0.1, eps=1e-5)
+    if with_res:
+        y = y + rt
+    if relu:
+        y = F.relu(y)
+    yh = _h(y.detach())
+    # the kernel masks with the STORED (fp16) output: make the reference use the same mask
+    y.backward(_h(dy) * ((yh > 0).float() if relu else 1.0))
+
+    za, ya = _to_c8(z), ActC8(n, c, h, w, DEV)
+    ra = _to_c8(res) if with_res else None
+    nb = LIB.mp_bn_workspace_bytes(c)
+    ws = torch.empty(nb // 4 + 1, device=DEV)
+    mean, invstd = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    dmm, dmv = mm.to(DEV), mv.to(DEV)
+    dgam, dbet = gamma.to(DEV), beta.to(DEV)
+    _lib.check(LIB.mp_f16_bn_train_fwd(_lib.ptr(za), _lib.ptr(dgam), _lib.ptr(dbet), _lib.ptr(ra), _lib.ptr(ya),
+                                       _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(dmm), _lib.ptr(dmv), n, c, h * w, 1e-5, 0.9,
+                                       int(relu), _lib.ptr(ws), nb, _lib.stream()), "bn fwd")
+    _close16(_from_c8(ya), yh, "y")
+    assert torch.allclose(dmm.cpu(), rmm, atol=1e-5) and torch.allclose(dmv.cpu(), rmv, atol=1e-5)
+    dza, dra = ActC8(n, c, h, w, DEV), (ActC8(n, c, h, w, DEV) if with_res else None)
+    dgm, dbt = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    dya = _to_c8(dy)
+    _lib.check(LIB.mp_f16_bn_train_bwd(_lib.ptr(dya), _lib.ptr(za), _lib.ptr(ya), _lib.ptr(dgam), _lib.ptr(mean),
+                                       _lib.ptr(invstd), _lib.ptr(dza), _lib.ptr(dra), _lib.ptr(dgm), _lib.ptr(dbt), n, c, h * w,
+                                       int(relu), _lib.ptr(ws), nb, _lib.stream()), "bn bwd")
+    # where the kernel's fp16 y and torch's fp32 y disagree about the ReLU mask (y within an ulp of 0) nothing is compared
+    _close16(_from_c8(dza), _h(zt.grad), "dz")
+    assert torch.allclose(dgm.cpu(), gt.grad, rtol=2e-3, atol=2e-3 * float(gt.grad.abs().max()))
+    assert torch.allclose(dbt.cpu(), bt.grad, rtol=2e-3, atol=2e-3 * float(bt.grad.abs().max()))
+    if with_res:
+        _close16(_from_c8(dra), _h(rt.grad), "dres")
+
+
+def test_fuse_sum_f16_bwd_vs_torch():
+    g = torch.Generator().manual_seed(3)
+    n, c, h, w = 3, 32, 32, 24
+    scales = (2, 4, 8)
+    base = torch.randn(n, c, h, w, generator=g)
+    terms = [torch.randn(n, c, h // s, w // s, generator=g) for s in scales]
+    dy = torch.randn(n, c, h, w, generator=g)
+    leaves = [_h(base).requires_grad_(True)] + [_h(t).requires_grad_(True) for t in terms]
+    y = leaves[0]
+    for t, s in zip(leaves[1:], scales):
+        y = y + F.interpolate(t, scale_factor=s, mode="nearest")
+    out = _h(F.relu(y).detach())
+    y.backward(_h(dy) * (out > 0).float())
+    outa = _to_c8(out)
+    dbase = ActC8(n, c, h, w, DEV)
+    dts = [ActC8(n, c, h // s, w // s, DEV) for s in scales]
+    args = []
+    for t, s in zip(dts, scales):
+        args += [_lib.ptr(t), s]
+    dya = _to_c8(dy)
+    _lib.check(LIB.mp_f16_fuse_upsample_sum_bwd(_lib.ptr(dya), _lib.ptr(outa), _lib.ptr(dbase), *args, n, c, h, w, 1,
+                                                _lib.stream()), "fuse bwd")
+    assert torch.equal(_from_c8(dbase), _h(leaves[0].grad))
+    for t, leaf in zip(dts, leaves[1:]):
+        _close16(_from_c8(t), _h(leaf.grad), "dt")
