@@ -193,9 +193,13 @@ def train_bench(args, mp, dev, dist, world, rank):
     """configs[3] in fp32: HRNet-W32 256x192 training step, data parallel - Gaussian targets on the device, forward
     with batch-statistics BatchNorm, JointsMSELoss, backward (MFMA dgrad/wgrad), bucketed RCCL gradient mean
     overlapped with backward, AdamWeightDecay.  Extra measurement (the contract metric is inference)."""
-    from mindpose_amd.utils import AdamWeightDecay
+    from mindpose_amd.utils import AdamWeightDecay, DynamicLossScaleManager
     n = args.batch
     net = mp.init_synthetic(mp.create_network("hrnet_w32", "hrnet_head"), seed=0).to(dev).train()
+    scaler = None
+    if args.amp != "O0":  # the reference's recipe: amp O2 + DynamicLossScaleManager (tools/train.py:170-181)
+        mp.models.auto_mixed_precision(net, args.amp)
+        scaler = DynamicLossScaleManager()
     nwl = mp.create_network_with_loss(net, mp.create_loss("joint_mse", use_target_weight=True), has_extra_inputs=True)
     opt = AdamWeightDecay(net, lr=1e-3, weight_decay=0.05, filter_bias_and_bn=True)
     tgt = mp.TopDownGenerateTarget(config=dict(image_size=[192, 256], heatmap_size=[48, 64]), sigma=2.0)
@@ -211,8 +215,12 @@ def train_bench(args, mp, dev, dist, world, rank):
         opt.zero_grad()
         target, weight = tgt(kp)
         loss = nwl(image, target, weight)
-        loss.backward()
-        opt.step()
+        if scaler is not None:
+            scaler.scale(loss).backward()
+            opt.step(loss_scale_manager=scaler)
+        else:
+            loss.backward()
+            opt.step()
         return loss
 
     def sync_all():
@@ -240,10 +248,14 @@ def train_bench(args, mp, dev, dist, world, rank):
             "metric": "images/sec, HRNet-W32 256x192 training step (targets+fwd+loss+bwd+grad mean+AdamWeightDecay)",
             "value": round(world * n * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[3] in fp32: HRNet-W32 256x192 training, DP, Gaussian targets + JointsMSE + "
-                                   "bucketed RCCL gradient mean (114 MB/step) + AdamWeightDecay",
-                       "per_gpu_batch": n, "global_batch": n * world, "final_loss": float(loss.detach())},
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if scaler is None else "f16", "data": "synthetic",
+            "config": {"workload": ("configs[3] in fp32" if scaler is None else "configs[3] as the reference trains it (amp O2: fp16 "
+                                    "matrix-core convs / activations, fp32 statistics + master weights, dynamic loss scale)") +
+                                   ": HRNet-W32 256x192 training, DP, Gaussian targets + JointsMSE + bucketed RCCL gradient mean "
+                                   "(114 MB/step) + AdamWeightDecay",
+                       "per_gpu_batch": n, "global_batch": n * world, "final_loss": float(loss.detach()),
+                       "loss_scale": None if scaler is None else scaler.loss_scale,
+                       "skipped_steps": None if scaler is None else scaler.skipped_steps},
             "roofline": None, "cpu_baseline": None}))
 
 

@@ -36,6 +36,7 @@ struct Wgrad16Params {
     int N, Cin, C8in, H, W, Cout, C8out, Ho, Wo, pad;
     int R, P, Px, Rin, K, xrows;
     int tiles_y, tiles, splits, tiles_per_split, ci_tiles;
+    int nbuf;  // 2 = double-buffered tiles; 1 = one LDS buffer (wide stride-2 layers whose tiles do not fit twice)
     unsigned magic_wo, magic_w;
 };
 
@@ -48,8 +49,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16_kernel(const Wgrad16Par
     constexpr int T = KS * KS;
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];
     const int zbuf = p.K * kRowHalfs, xbuf = p.xrows * kRowHalfs;  // halfs per buffer
-    _Float16* lds_z = smem_h;             // [2][zbuf]
-    _Float16* lds_x = smem_h + 2 * zbuf;  // [2][xbuf]
+    _Float16* lds_z = smem_h;                  // [nbuf][zbuf]
+    _Float16* lds_x = smem_h + p.nbuf * zbuf;  // [nbuf][xbuf]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int co_sub = wave & 1, ci_sub = wave >> 1;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16_kernel(const Wgrad16Par
 
     {
         u32x4* z = reinterpret_cast<u32x4*>(smem_h);
-        const int n16 = (2 * (zbuf + xbuf)) >> 3;
+        const int n16 = (p.nbuf * (zbuf + xbuf)) >> 3;
         const u32x4 zero = (u32x4){0u, 0u, 0u, 0u};
         for (int i = tid; i < n16; i += 256) z[i] = zero;
     }
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16_kernel(const Wgrad16Par
     }
     const int ksteps = p.K >> 5;
     for (int t = t_begin; t < t_end; ++t) {
-        const int buf = (t - t_begin) & 1;
+        const int buf = p.nbuf == 2 ? ((t - t_begin) & 1) : 0;
         const bool more = t + 1 < t_end;
         if (more) stage_load(t + 1);
         const _Float16* zt = lds_z + buf * zbuf + a_base;
@@ -168,7 +169,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16_kernel(const Wgrad16Par
             }
         }
         if (more) {
-            stage_store(buf ^ 1);
+            if (p.nbuf == 1) __syncthreads();  // every wave is done reading the only buffer
+            stage_store(p.nbuf == 2 ? (buf ^ 1) : 0);
             __syncthreads();
         }
     }
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(256) void wgrad16_reduce_kernel(const float* __rest
     }
 }
 
-constexpr int kNZ = 4, kNX = 8;
+constexpr int kNZ = 4, kNX = 10;
 
 int geometry(const mp_conv_desc* d, Wgrad16Params& p, size_t& lds_bytes) {
     if (!d) return MP_ERR_NULL;
@@ -216,15 +218,20 @@ int geometry(const mp_conv_desc* d, Wgrad16Params& p, size_t& lds_bytes) {
     // common pitch: a row holds the Wo gradient columns and the W + 2*pad input columns
     p.P = p.W + 2 * p.pad > p.Wo ? p.W + 2 * p.pad : p.Wo;
     p.Px = p.P;
+    // pass 0: double-buffered, two workgroups per CU; pass 1: double-buffered, whatever fits; pass 2: single buffer
     bool found = false;
-    for (int R = p.Ho < 16 ? p.Ho : 16; R >= 1; --R) {
-        p.R = R;
-        p.Rin = (R - 1) * S + KS;
-        p.K = (R * p.P + 31) / 32 * 32;
-        p.xrows = S * (p.K - 1) + (KS - 1) * p.Px + (KS - 1) + 1;
-        if (p.xrows < p.Rin * p.Px) p.xrows = p.Rin * p.Px;
-        lds_bytes = (size_t)2 * (p.K + p.xrows) * kRowHalfs * 2;
-        if (R * p.Wo * 4 <= kNZ * 256 && p.Rin * p.W * 4 <= kNX * 256 && lds_bytes <= 78 * 1024) { found = true; break; }
+    for (int pass = 0; pass < 3 && !found; ++pass) {
+        p.nbuf = pass < 2 ? 2 : 1;
+        const size_t budget = pass == 0 ? 78 * 1024 : 150 * 1024;
+        for (int R = p.Ho < 16 ? p.Ho : 16; R >= 1; --R) {
+            p.R = R;
+            p.Rin = (R - 1) * S + KS;
+            p.K = (R * p.P + 31) / 32 * 32;
+            p.xrows = S * (p.K - 1) + (KS - 1) * p.Px + (KS - 1) + 1;
+            if (p.xrows < p.Rin * p.Px) p.xrows = p.Rin * p.Px;
+            lds_bytes = (size_t)p.nbuf * (p.K + p.xrows) * kRowHalfs * 2;
+            if (R * p.Wo * 4 <= kNZ * 256 && p.Rin * p.W * 4 <= kNX * 256 && lds_bytes <= budget) { found = true; break; }
+        }
     }
     if (!found) return MP_ERR_UNSUPPORTED;
     p.tiles_y = (p.Ho + p.R - 1) / p.R;

@@ -31,6 +31,10 @@ class Net(PlannedModule):
     def train_forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.has_neck:
             raise NotImplementedError("no concrete neck exists in the reference")
+        if self.amp_level in ("O2", "O3"):  # fp16 matrix-core training graph; fp32 images in, fp32 heat-maps out
+            from . import train_ops as T
+            y = self.head.train_forward(self.backbone.train_forward(T.to_c8(x)))
+            return T.from_c8(y, self.head.head.out_channels)
         return self.head.train_forward(self.backbone.train_forward(x))
 
 

@@ -195,8 +195,225 @@ class FuseSumFn(torch.autograd.Function):
         return (dbase, None, *dts)
 
 
+# ---- amp O2: the same graph on channel-blocked fp16 activations ([N, ceil(C/8), H, W, 8] half tensors) -------------------
+# fp16 conv operands / activations / activation gradients, fp32 accumulation, BatchNorm statistics and every PARAMETER
+# gradient in fp32 (the parameters themselves stay fp32 "master" weights: the pack kernel rounds them to fp16 per step).
+
+
+def _c8_shape(n, c, h, w):
+    return (n, (c + 7) // 8, h, w, 8)
+
+
+def _pack16(lib, w, cout, cin, k, mode, py=0, px=0):
+    nbytes = lib.mp_f16_packed_weight_bytes(cout, cin, k, k)
+    packed = torch.empty(nbytes // 2, device=w.device, dtype=torch.float16)
+    _lib.check(lib.mp_f16_pack_weight(_lib.ptr(w), _lib.ptr(packed), cout, cin, k, k, mode, py, px, _lib.stream()),
+               "mp_f16_pack_weight")
+    return packed
+
+
+def _ones_zeros16(c: int, device):
+    return _ones_zeros((c + 15) // 16 * 16, device)
+
+
+def _conv16_launch(lib, d, x, packed, scale, shift, out, what):
+    _lib.check(lib.mp_f16_conv2d_fwd(ctypes.byref(d), -1, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift), None, None,
+                                     _lib.ptr(out), _lib.stream()), what)
+
+
+class ToC8Fn(torch.autograd.Function):
+    """fp32 NCHW -> channel-blocked fp16 (network input: no gradient flows back)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _lib.require_cuda_f32(x, "x")
+        n, c, h, w = x.shape
+        out = torch.zeros(_c8_shape(n, c, h, w), device=x.device, dtype=torch.float16)
+        _lib.check(lib.mp_f16_to_c8(_lib.ptr(x), _lib.ptr(out), n, c, h, w, _lib.stream()), "mp_f16_to_c8")
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return None
+
+
+class FromC8Fn(torch.autograd.Function):
+    """channel-blocked fp16 -> fp32 NCHW (network output handed to the fp32 loss); backward rounds the loss gradient to fp16."""
+
+    @staticmethod
+    def forward(ctx, x, c):
+        lib = _lib.load()
+        n, _, h, w, _ = x.shape
+        out = torch.empty(n, c, h, w, device=x.device, dtype=torch.float32)
+        _lib.check(lib.mp_f16_from_c8(_lib.ptr(x), _lib.ptr(out), n, c, h, w, _lib.stream()), "mp_f16_from_c8")
+        ctx.c = c
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        dy = dy.contiguous()
+        n, c, h, w = dy.shape
+        out = torch.zeros(_c8_shape(n, c, h, w), device=dy.device, dtype=torch.float16)
+        _lib.check(lib.mp_f16_to_c8(_lib.ptr(dy), _lib.ptr(out), n, c, h, w, _lib.stream()), "mp_f16_to_c8")
+        return out, None
+
+
+class Conv16Fn(torch.autograd.Function):
+    """z = conv2d(x, fp16(weight)) (+ bias) on the fp16 matrix cores; k in {1, 3}, stride in {1, 2}, padding = k // 2."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding):
+        lib = _lib.load()
+        w = weight.detach().contiguous()
+        n, _, h, wd, _ = x.shape
+        cout, cin, k, _ = w.shape
+        if padding != k // 2 or k not in (1, 3) or stride not in (1, 2):
+            raise NotImplementedError("training path covers k in {1,3}, stride in {1,2}, padding = k//2")
+        ho, wo = (h + 2 * padding - k) // stride + 1, (wd + 2 * padding - k) // stride + 1
+        ones, zeros = _ones_zeros16(cout, x.device)
+        shift = zeros
+        if bias is not None:
+            shift = torch.zeros_like(zeros)
+            shift[:cout] = bias.detach()
+        z = torch.zeros(_c8_shape(n, cout, ho, wo), device=x.device, dtype=torch.float16)
+        d = _desc(n, cin, h, wd, cout, k, stride, padding, padding, ho, wo, ho, wo)
+        packed = _pack16(lib, w, cout, cin, k, 0)
+        _conv16_launch(lib, d, x, packed, ones, shift, z, "mp_f16_conv2d_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.stride, ctx.padding, ctx.has_bias = stride, padding, bias is not None
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        dz = dz.contiguous()
+        n, _, h, wd, _ = x.shape
+        cout, cin, k, _ = w.shape
+        s, pad = ctx.stride, ctx.padding
+        ho, wo = dz.shape[2], dz.shape[3]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            ones, zeros = _ones_zeros16(cin, x.device)
+            dx = torch.zeros_like(x)
+            if s == 1:
+                d = _desc(n, cout, ho, wo, cin, k, 1, k - 1 - pad, k - 1 - pad, h, wd, h, wd)
+                _conv16_launch(lib, d, dz, _pack16(lib, w, cin, cout, k, 2), ones, zeros, dx, "conv dgrad")
+            else:
+                if h != 2 * ho or wd != 2 * wo or k != 3:
+                    raise NotImplementedError("stride-2 data gradient: 3x3 kernels on even input extents")
+                for py in (0, 1):
+                    for px in (0, 1):
+                        d = _desc(n, cout, ho, wo, cin, 2, 1, 0, 0, ho, wo, h, wd, out_mul=2, off_y=py, off_x=px)
+                        _conv16_launch(lib, d, dz, _pack16(lib, w, cin, cout, 2, 3, py, px), ones, zeros, dx, "conv dgrad phase")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            d = _desc(n, cin, h, wd, cout, k, s, pad, pad, ho, wo, ho, wo)
+            ws_bytes = lib.mp_f16_conv_wgrad_workspace_bytes(ctypes.byref(d))
+            ws = torch.empty(max(ws_bytes // 4, 1), device=x.device, dtype=torch.float32)
+            _lib.check(lib.mp_f16_conv_wgrad(ctypes.byref(d), _lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), 1.0, _lib.ptr(ws), ws_bytes,
+                                             _lib.stream()), "mp_f16_conv_wgrad")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dz.float().sum(dim=(0, 2, 3)).reshape(-1)[:cout]  # head conv bias (17 values)
+        return dx, dw, db, None, None
+
+
+class BatchNormAct16Fn(torch.autograd.Function):
+    """y = act(BN_train(z) (+ res)) on channel-blocked fp16; statistics / gamma / beta (and their gradients) in fp32."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, res, moving_mean, moving_var, relu):
+        lib = _lib.load()
+        n, _, h, w, _ = z.shape
+        c = gamma.numel()
+        y = torch.empty_like(z)
+        mean = torch.empty(c, device=z.device)
+        invstd = torch.empty(c, device=z.device)
+        ws_bytes = lib.mp_bn_workspace_bytes(c)
+        ws = torch.empty(ws_bytes // 4 + 1, device=z.device, dtype=torch.float32)
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        r = res.contiguous() if res is not None else None
+        _lib.check(lib.mp_f16_bn_train_fwd(_lib.ptr(z), _lib.ptr(g), _lib.ptr(b), _lib.ptr(r), _lib.ptr(y), _lib.ptr(mean),
+                                           _lib.ptr(invstd), _lib.ptr(moving_mean), _lib.ptr(moving_var), n, c, h * w, BN_EPS,
+                                           BN_MOMENTUM, int(relu), _lib.ptr(ws), ws_bytes, _lib.stream()), "mp_f16_bn_train_fwd")
+        ctx.save_for_backward(z, y, g, mean, invstd)
+        ctx.relu, ctx.has_res = relu, res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        z, y, g, mean, invstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, _, h, w, _ = z.shape
+        c = g.numel()
+        dz = torch.empty_like(z)
+        dres = torch.empty_like(z) if ctx.has_res else None
+        dgamma = torch.empty(c, device=z.device)
+        dbeta = torch.empty(c, device=z.device)
+        ws_bytes = lib.mp_bn_workspace_bytes(c)
+        ws = torch.empty(ws_bytes // 4 + 1, device=z.device, dtype=torch.float32)
+        _lib.check(lib.mp_f16_bn_train_bwd(_lib.ptr(dy), _lib.ptr(z), _lib.ptr(y), _lib.ptr(g), _lib.ptr(mean), _lib.ptr(invstd),
+                                           _lib.ptr(dz), _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta), n, c, h * w,
+                                           int(ctx.relu), _lib.ptr(ws), ws_bytes, _lib.stream()), "mp_f16_bn_train_bwd")
+        return dz, dgamma, dbeta, dres, None, None, None
+
+
+class FuseSum16Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, base, scales, *terms):
+        lib = _lib.load()
+        n, c8, h, w, _ = base.shape
+        base = base.contiguous()
+        ts = [t.contiguous() for t in terms]
+        out = torch.empty_like(base)
+        args = []
+        for i in range(3):
+            args += [_lib.ptr(ts[i]), int(scales[i])] if i < len(ts) else [None, 1]
+        _lib.check(lib.mp_f16_fuse_upsample_sum(_lib.ptr(base), *args, _lib.ptr(out), n, c8 * 8, h, w, 1, _lib.stream()),
+                   "mp_f16_fuse_upsample_sum")
+        ctx.save_for_backward(out)
+        ctx.scales = [int(s) for s in scales[:len(ts)]]
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (out,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, c8, h, w, _ = out.shape
+        dbase = torch.empty_like(out)
+        dts = [torch.empty(n, c8, h // s, w // s, 8, device=out.device, dtype=torch.float16) for s in ctx.scales]
+        args = []
+        for i in range(3):
+            args += [_lib.ptr(dts[i]), ctx.scales[i]] if i < len(dts) else [None, 1]
+        _lib.check(lib.mp_f16_fuse_upsample_sum_bwd(_lib.ptr(dy), _lib.ptr(out), _lib.ptr(dbase), *args, n, c8 * 8, h, w, 1,
+                                                    _lib.stream()), "mp_f16_fuse_upsample_sum_bwd")
+        return (dbase, None, *dts)
+
+
+def to_c8(x: torch.Tensor) -> torch.Tensor:
+    return ToC8Fn.apply(x)
+
+
+def from_c8(x: torch.Tensor, channels: int) -> torch.Tensor:
+    return FromC8Fn.apply(x, channels)
+
+
+def _is_c8(x) -> bool:
+    return x.dtype == torch.float16 and x.dim() == 5
+
+
 def conv_bn_act(x, conv, bn, relu: bool, res: Optional[torch.Tensor] = None):
-    """One conv + BatchNorm(train) (+ residual) (+ ReLU) group of the reference's cells."""
+    """One conv + BatchNorm(train) (+ residual) (+ ReLU) group of the reference's cells; the kernel family follows the
+    activation type (fp32 NCHW, or channel-blocked fp16 under amp O2)."""
+    if _is_c8(x):
+        z = Conv16Fn.apply(x, conv.weight, conv.bias, conv.stride, conv.padding)
+        if bn is None:
+            return z
+        return BatchNormAct16Fn.apply(z, bn.gamma, bn.beta, res, bn.moving_mean, bn.moving_variance, relu)
     z = Conv2dFn.apply(x, conv.weight, conv.bias, conv.stride, conv.padding)
     if bn is None:
         return z
@@ -205,4 +422,5 @@ def conv_bn_act(x, conv, bn, relu: bool, res: Optional[torch.Tensor] = None):
 
 def fuse_sum(base, terms):
     """terms = [(tensor, integer scale), ...] (1-3 entries)."""
-    return FuseSumFn.apply(base, [s for _, s in terms], *[t for t, _ in terms])
+    fn = FuseSum16Fn if _is_c8(base) else FuseSumFn
+    return fn.apply(base, [s for _, s in terms], *[t for t, _ in terms])

@@ -55,10 +55,20 @@ class AdamWeightDecay:
     def zero_grad(self) -> None:
         self.grads.begin_step()
 
-    def step(self) -> None:
-        """All-reduce (mean) the gradients, then one fused update per decay group."""
+    def step(self, loss_scale_manager=None) -> bool:
+        """All-reduce (mean) the gradients, then one fused update per decay group.
+
+        With a ``DynamicLossScaleManager`` (amp O2, tools/train.py:170-181) the gradients are first divided by the loss
+        scale and checked: on overflow (inf / nan anywhere) the update is skipped and the scale halves, exactly one
+        host read-back per step; returns whether the parameters were updated."""
         lib = _lib.load()
         self.grads.finish()
+        if loss_scale_manager is not None:
+            self._grad_flat.mul_(1.0 / loss_scale_manager.loss_scale)
+            finite = bool(torch.isfinite(self._grad_flat).all())
+            loss_scale_manager.update_loss_scale(not finite)
+            if not finite:
+                return False
         s = _lib.stream()
         for start, count, wd in ((0, self.n_decay, self.weight_decay), (self.n_decay, self.flat.numel() - self.n_decay, 0.0)):
             if count == 0:
@@ -68,3 +78,4 @@ class AdamWeightDecay:
                                          float(self.lr), float(self.beta1), float(self.beta2), float(self.eps), float(wd), s),
                        "mp_adamw_step")
         self.global_step += 1
+        return True
