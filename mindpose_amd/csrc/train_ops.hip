@@ -8,6 +8,7 @@
 namespace mp {
 
 constexpr int kBnSplit = 32;  // per-channel partial reductions (fixed: determinism)
+constexpr int kBn16MaxSplit = 256;
 
 __device__ __forceinline__ double block_sum_256(double v, double* sm) {
     sm[threadIdx.x] = v;
@@ -69,14 +70,20 @@ __global__ void bn_finalize_fwd_kernel(const double* __restrict__ part, const fl
                                        const float* __restrict__ beta, float* __restrict__ save_mean,
                                        float* __restrict__ save_invstd, float* __restrict__ scale,
                                        float* __restrict__ shift, float* __restrict__ moving_mean,
-                                       float* __restrict__ moving_var, int c, double count, float eps, float momentum) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
+                                       float* __restrict__ moving_var, int c, double count, float eps, float momentum,
+                                       int nsplit) {
+    // one wave per channel: lane l sums splits l, l + 64, ... then a fixed-order shuffle tree (deterministic)
+    const int ch = blockIdx.x;
     double s0 = 0.0, s1 = 0.0;
-    for (int sp = 0; sp < kBnSplit; ++sp) {
-        s0 += part[((size_t)ch * kBnSplit + sp) * 2 + 0];
-        s1 += part[((size_t)ch * kBnSplit + sp) * 2 + 1];
+    for (int sp = threadIdx.x; sp < nsplit; sp += 64) {
+        s0 += part[((size_t)ch * nsplit + sp) * 2 + 0];
+        s1 += part[((size_t)ch * nsplit + sp) * 2 + 1];
     }
+    for (int off = 32; off >= 1; off >>= 1) {
+        s0 += __shfl_down(s0, off, 64);
+        s1 += __shfl_down(s1, off, 64);
+    }
+    if (threadIdx.x != 0) return;
     const double mean = s0 / count;
     double var = s1 / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -121,14 +128,18 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 
 // stage 2 (backward): dgamma = sum g*xhat, dbeta = sum g
 __global__ void bn_finalize_bwd_kernel(const double* __restrict__ part, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, int c) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
+                                       float* __restrict__ dbeta, int c, int nsplit) {
+    const int ch = blockIdx.x;
     double s0 = 0.0, s1 = 0.0;
-    for (int sp = 0; sp < kBnSplit; ++sp) {
-        s0 += part[((size_t)ch * kBnSplit + sp) * 2 + 0];
-        s1 += part[((size_t)ch * kBnSplit + sp) * 2 + 1];
+    for (int sp = threadIdx.x; sp < nsplit; sp += 64) {
+        s0 += part[((size_t)ch * nsplit + sp) * 2 + 0];
+        s1 += part[((size_t)ch * nsplit + sp) * 2 + 1];
     }
+    for (int off = 32; off >= 1; off >>= 1) {
+        s0 += __shfl_down(s0, off, 64);
+        s1 += __shfl_down(s1, off, 64);
+    }
+    if (threadIdx.x != 0) return;
     dbeta[ch] = (float)s0;
     dgamma[ch] = (float)s1;
 }
@@ -224,8 +235,11 @@ template <bool BWD>
 __global__ __launch_bounds__(256) void bn16_reduce_kernel(const u32x4_t* __restrict__ a_in, const u32x4_t* __restrict__ z,
                                                           const u32x4_t* __restrict__ y, const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, double* __restrict__ part, int n,
-                                                          int c, int c8, int hw, int relu) {
-    const int blk = blockIdx.x, sp = blockIdx.y;
+                                                          int c, int c8, int hw, int relu, int gi, int gp) {
+    // split sp = (image group sp % gi, pixel chunk sp / gi): enough blocks to fill the chip even for 4 channel blocks
+    const int blk = blockIdx.x, sp = blockIdx.y, nsplit = gi * gp;
+    const int ig = sp % gi, pc = sp / gi;
+    const int chunk = (hw + gp - 1) / gp, p0 = pc * chunk, p1 = min(p0 + chunk, hw);
     float mu[8], is[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -236,12 +250,12 @@ __global__ __launch_bounds__(256) void bn16_reduce_kernel(const u32x4_t* __restr
     double acc[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.0;
-    for (int img = sp; img < n; img += kBnSplit) {
+    for (int img = ig; img < n; img += gi) {
         const size_t base = ((size_t)img * c8 + blk) * hw;
         float f[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) f[j] = 0.f;
-        for (int i = threadIdx.x; i < hw; i += 256) {
+        for (int i = p0 + threadIdx.x; i < p1; i += 256) {
             const h16x8 zv = __builtin_bit_cast(h16x8, z[base + i]);
             if (BWD) {
                 const h16x8 gv = __builtin_bit_cast(h16x8, a_in[base + i]);
@@ -271,7 +285,7 @@ __global__ __launch_bounds__(256) void bn16_reduce_kernel(const u32x4_t* __restr
     block_sum16_256(acc, sm);
     if (threadIdx.x < 16) {
         const int ch = blk * 8 + (threadIdx.x >> 1);
-        if (ch < c) part[((size_t)ch * kBnSplit + sp) * 2 + (threadIdx.x & 1)] = acc[0];
+        if (ch < c) part[((size_t)ch * nsplit + sp) * 2 + (threadIdx.x & 1)] = acc[0];
     }
 }
 
@@ -363,6 +377,17 @@ __global__ __launch_bounds__(256) void fuse_sum16_bwd_kernel(const u32x4_t* __re
     }
 }
 
+// image groups x pixel chunks of the fp16 reductions: about 512+ blocks, fixed by the shape (deterministic)
+static void bn16_split(int n, int c8, int hw, int& gi, int& gp) {
+    int want = 512 / c8;  // a block should stream >= ~50 KB to amortise its reduction tail
+    if (want < 32) want = 32;
+    if (want > kBn16MaxSplit) want = kBn16MaxSplit;
+    gi = n < want ? n : want;
+    gp = want / gi;
+    if (gp < 1) gp = 1;
+    while (gp > 1 && (hw + gp - 1) / gp < 256) --gp;  // at least one element per thread
+}
+
 static int log2_exact_t(int v) {
     for (int i = 0; i < 16; ++i)
         if ((1 << i) == v) return i;
@@ -377,8 +402,8 @@ extern "C" {
 
 size_t mp_bn_workspace_bytes(int c) {
     if (c <= 0) return 0;
-    // fp64 partials [C][kBnSplit][2] + scale/shift (fwd) or nothing extra (bwd)
-    return (size_t)c * kBnSplit * 2 * sizeof(double) + (size_t)c * 2 * sizeof(float) + 256;
+    // fp64 partials [C][splits][2] (32 splits in the fp32 passes, up to kBn16MaxSplit in the fp16 ones) + scale/shift
+    return (size_t)c * kBn16MaxSplit * 2 * sizeof(double) + (size_t)c * 2 * sizeof(float) + 256;
 }
 
 int mp_bn_train_fwd(const float* z, const float* gamma, const float* beta, const float* res, float* y, float* save_mean,
@@ -396,8 +421,8 @@ int mp_bn_train_fwd(const float* z, const float* gamma, const float* beta, const
                        n, c, hw, 0);
     int rc = check_launch();
     if (rc != MP_OK) return rc;
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((c + 63) / 64), dim3(64), 0, s, part, gamma, beta, save_mean, save_invstd,
-                       scale, shift, moving_mean, moving_var, c, (double)n * hw, eps, momentum);
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(c), dim3(64), 0, s, part, gamma, beta, save_mean, save_invstd,
+                       scale, shift, moving_mean, moving_var, c, (double)n * hw, eps, momentum, kBnSplit);
     rc = check_launch();
     if (rc != MP_OK) return rc;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(n * c), dim3(256), 0, s, z, scale, shift, res, y, c, hw, relu ? 1 : 0);
@@ -417,7 +442,7 @@ int mp_bn_train_bwd(const float* dy, const float* z, const float* y, const float
                        hw, relu ? 1 : 0);
     int rc = check_launch();
     if (rc != MP_OK) return rc;
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((c + 63) / 64), dim3(64), 0, s, part, dgamma, dbeta, c);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(c), dim3(64), 0, s, part, dgamma, dbeta, c, kBnSplit);
     rc = check_launch();
     if (rc != MP_OK) return rc;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(n * c), dim3(256), 0, s, dy, z, y, gamma, save_mean, save_invstd, dgamma, dbeta,
@@ -467,16 +492,18 @@ int mp_f16_bn_train_fwd(const void* z, const float* gamma, const float* beta, co
     if (n <= 0 || c <= 0 || hw <= 0) return MP_ERR_SHAPE;
     if (!workspace || workspace_bytes < mp_bn_workspace_bytes(c)) return MP_ERR_WORKSPACE;
     double* part = reinterpret_cast<double*>(workspace);
-    float* scale = reinterpret_cast<float*>(part + (size_t)c * kBnSplit * 2);
-    float* shift = scale + c;
     const int c8 = (c + 7) / 8;
+    int gi, gp;
+    bn16_split(n, c8, hw, gi, gp);
+    float* scale = reinterpret_cast<float*>(part + (size_t)c * kBn16MaxSplit * 2);
+    float* shift = scale + c;
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(bn16_reduce_kernel<false>, dim3(c8, kBnSplit), dim3(256), 0, s, nullptr, reinterpret_cast<const u32x4_t*>(z),
-                       nullptr, nullptr, nullptr, part, n, c, c8, hw, 0);
+    hipLaunchKernelGGL(bn16_reduce_kernel<false>, dim3(c8, gi * gp), dim3(256), 0, s, nullptr, reinterpret_cast<const u32x4_t*>(z),
+                       nullptr, nullptr, nullptr, part, n, c, c8, hw, 0, gi, gp);
     int rc = check_launch();
     if (rc != MP_OK) return rc;
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((c + 63) / 64), dim3(64), 0, s, part, gamma, beta, save_mean, save_invstd,
-                       scale, shift, moving_mean, moving_var, c, (double)n * hw, eps, momentum);
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(c), dim3(64), 0, s, part, gamma, beta, save_mean, save_invstd,
+                       scale, shift, moving_mean, moving_var, c, (double)n * hw, eps, momentum, gi * gp);
     rc = check_launch();
     if (rc != MP_OK) return rc;
     const size_t total = (size_t)n * c8 * hw;
@@ -496,13 +523,15 @@ int mp_f16_bn_train_bwd(const void* dy, const void* z, const void* y, const floa
     if (!workspace || workspace_bytes < mp_bn_workspace_bytes(c)) return MP_ERR_WORKSPACE;
     double* part = reinterpret_cast<double*>(workspace);
     const int c8 = (c + 7) / 8;
+    int gi, gp;
+    bn16_split(n, c8, hw, gi, gp);
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(bn16_reduce_kernel<true>, dim3(c8, kBnSplit), dim3(256), 0, s, reinterpret_cast<const u32x4_t*>(dy),
+    hipLaunchKernelGGL(bn16_reduce_kernel<true>, dim3(c8, gi * gp), dim3(256), 0, s, reinterpret_cast<const u32x4_t*>(dy),
                        reinterpret_cast<const u32x4_t*>(z), reinterpret_cast<const u32x4_t*>(y), save_mean, save_invstd, part, n, c,
-                       c8, hw, relu ? 1 : 0);
+                       c8, hw, relu ? 1 : 0, gi, gp);
     int rc = check_launch();
     if (rc != MP_OK) return rc;
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((c + 63) / 64), dim3(64), 0, s, part, dgamma, dbeta, c);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(c), dim3(64), 0, s, part, dgamma, dbeta, c, gi * gp);
     rc = check_launch();
     if (rc != MP_OK) return rc;
     const size_t total = (size_t)n * c8 * hw;

@@ -204,6 +204,13 @@ def _c8_shape(n, c, h, w):
     return (n, (c + 7) // 8, h, w, 8)
 
 
+def _c8_alloc(n, c, h, w, device):
+    """Uninitialised when every channel block is full; zero-filled when the last block has padding channels (the kernels
+    keep them zero, but a fresh buffer must start that way)."""
+    make = torch.empty if c % 8 == 0 else torch.zeros
+    return make(_c8_shape(n, c, h, w), device=device, dtype=torch.float16)
+
+
 def _pack16(lib, w, cout, cin, k, mode, py=0, px=0):
     nbytes = lib.mp_f16_packed_weight_bytes(cout, cin, k, k)
     packed = torch.empty(nbytes // 2, device=w.device, dtype=torch.float16)
@@ -217,7 +224,8 @@ def _ones_zeros16(c: int, device):
 
 
 def _conv16_launch(lib, d, x, packed, scale, shift, out, what):
-    _lib.check(lib.mp_f16_conv2d_fwd(ctypes.byref(d), -1, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift), None, None,
+    v = tune_conv_variant(lib, d, x, packed, scale, shift, None, None, out, half=True)  # one-tile / multi-tile, cached per shape
+    _lib.check(lib.mp_f16_conv2d_fwd(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift), None, None,
                                      _lib.ptr(out), _lib.stream()), what)
 
 
@@ -229,7 +237,7 @@ class ToC8Fn(torch.autograd.Function):
         lib = _lib.load()
         x = _lib.require_cuda_f32(x, "x")
         n, c, h, w = x.shape
-        out = torch.zeros(_c8_shape(n, c, h, w), device=x.device, dtype=torch.float16)
+        out = _c8_alloc(n, c, h, w, x.device)
         _lib.check(lib.mp_f16_to_c8(_lib.ptr(x), _lib.ptr(out), n, c, h, w, _lib.stream()), "mp_f16_to_c8")
         return out
 
@@ -255,7 +263,7 @@ class FromC8Fn(torch.autograd.Function):
         lib = _lib.load()
         dy = dy.contiguous()
         n, c, h, w = dy.shape
-        out = torch.zeros(_c8_shape(n, c, h, w), device=dy.device, dtype=torch.float16)
+        out = _c8_alloc(n, c, h, w, dy.device)
         _lib.check(lib.mp_f16_to_c8(_lib.ptr(dy), _lib.ptr(out), n, c, h, w, _lib.stream()), "mp_f16_to_c8")
         return out, None
 
@@ -277,7 +285,7 @@ class Conv16Fn(torch.autograd.Function):
         if bias is not None:
             shift = torch.zeros_like(zeros)
             shift[:cout] = bias.detach()
-        z = torch.zeros(_c8_shape(n, cout, ho, wo), device=x.device, dtype=torch.float16)
+        z = _c8_alloc(n, cout, ho, wo, x.device)
         d = _desc(n, cin, h, wd, cout, k, stride, padding, padding, ho, wo, ho, wo)
         packed = _pack16(lib, w, cout, cin, k, 0)
         _conv16_launch(lib, d, x, packed, ones, shift, z, "mp_f16_conv2d_fwd")
@@ -297,7 +305,7 @@ class Conv16Fn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             ones, zeros = _ones_zeros16(cin, x.device)
-            dx = torch.zeros_like(x)
+            dx = _c8_alloc(n, cin, h, wd, x.device)
             if s == 1:
                 d = _desc(n, cout, ho, wo, cin, k, 1, k - 1 - pad, k - 1 - pad, h, wd, h, wd)
                 _conv16_launch(lib, d, dz, _pack16(lib, w, cin, cout, k, 2), ones, zeros, dx, "conv dgrad")

@@ -213,7 +213,7 @@ def test_hrnet_w32_o2_training_step_vs_fp32_path():
     against the fp32 HIP training path, which tests/test_gpu_train.py pins to an fp64 oracle.  fp16 activations and
     activation gradients perturb every ReLU mask and batch statistic a little, so tensor-wise equality is not the bar:
     the loss must agree to 1e-2, every parameter gradient must point the same way (cosine > 0.95 per tensor, > 0.98 over
-    all 28.5 M values), the well-conditioned ones must agree to 3e-2."""
+    all 28.5 M values), the head's must agree to 5e-3."""
     import numpy as np
     import mindpose_amd as mp
     torch.manual_seed(0)
@@ -249,8 +249,8 @@ def test_hrnet_w32_o2_training_step_vs_fp32_path():
           f"rel err median {float(np.median(list(rel.values()))):.3e}; loss {float(loss16.detach())} vs {float(loss32.detach())}")
     print({n: rel[n] for n in ("head.head.weight", "head.head.bias", "backbone.stage4.2.fuse_layers.0.3.0.weight")})
     assert gcos > 0.98 and med > 0.99 and min(cos.values()) > 0.95
-    for name in ("head.head.weight", "head.head.bias", "backbone.stage4.2.fuse_layers.0.3.0.weight"):
-        assert rel[name] < 3e-2, (name, rel[name])
+    assert rel["head.head.weight"] < 5e-3 and rel["head.head.bias"] < 5e-3  # one layer from the loss: tight
+    assert rel["backbone.stage4.2.fuse_layers.0.3.0.weight"] < 6e-2        # a few fp16 layers deep
 
 
 def test_o2_optimizer_steps_with_dynamic_loss_scale():
