@@ -201,7 +201,10 @@ def train_bench(args, mp, dev, dist, world, rank):
         mp.models.auto_mixed_precision(net, args.amp)
         scaler = DynamicLossScaleManager()
     nwl = mp.create_network_with_loss(net, mp.create_loss("joint_mse", use_target_weight=True), has_extra_inputs=True)
-    opt = AdamWeightDecay(net, lr=1e-3, weight_decay=0.05, filter_bias_and_bn=True)
+    # amp O2 is launch-bound from Python (64 ms per step at any batch): its step is captured into a hipGraph.  The fp32
+    # step is GPU-bound and measured eager (capture made it 8 % slower: the graph's private pool defeats the allocator reuse)
+    graphed = os.environ.get("MINDPOSE_TRAIN_GRAPH", "1" if args.amp != "O0" else "0") != "0"
+    opt = AdamWeightDecay(net, lr=1e-3, weight_decay=0.05, filter_bias_and_bn=True, overlap=not graphed)
     tgt = mp.TopDownGenerateTarget(config=dict(image_size=[192, 256], heatmap_size=[48, 64]), sigma=2.0)
     gen = torch.Generator(device="cpu").manual_seed(1000 + rank)
     image = torch.randn(n, 3, 256, 192, generator=gen).to(dev)
@@ -211,7 +214,16 @@ def train_bench(args, mp, dev, dist, world, rank):
     kp[..., 2] = (torch.rand(n, 17, generator=gen) < 0.7).float()
     kp = kp.to(dev)
 
+    gstep = None
+    if graphed:  # forward + loss + backward captured once into a hipGraph, replayed per step (utils/graph_step.py)
+        from mindpose_amd.utils import GraphedTrainStep
+        t0, w0 = tgt(kp)
+        gstep = GraphedTrainStep(nwl, opt, (image, t0, w0), loss_scale_manager=scaler)
+
     def step():
+        if gstep is not None:
+            target, weight = tgt(kp)
+            return gstep(image, target, weight)
         opt.zero_grad()
         target, weight = tgt(kp)
         loss = nwl(image, target, weight)
@@ -254,6 +266,7 @@ def train_bench(args, mp, dev, dist, world, rank):
                                    ": HRNet-W32 256x192 training, DP, Gaussian targets + JointsMSE + bucketed RCCL gradient mean "
                                    "(114 MB/step) + AdamWeightDecay",
                        "per_gpu_batch": n, "global_batch": n * world, "final_loss": float(loss.detach()),
+                       "step": "one hipGraph replay (forward+loss+backward) + optimizer" if graphed else "eager autograd",
                        "loss_scale": None if scaler is None else scaler.loss_scale,
                        "skipped_steps": None if scaler is None else scaler.skipped_steps},
             "roofline": None, "cpu_baseline": None}))

@@ -238,9 +238,8 @@ int geometry(const mp_conv_desc* d, Wgrad16Params& p, size_t& lds_bytes) {
     p.tiles = p.N * p.tiles_y;
     p.ci_tiles = (p.Cin + 31) / 32;
     const int ct = ((p.Cout + 31) / 32) * p.ci_tiles;
-    int splits = 1024 / ct;
+    int splits = 512 / ct;  // two workgroups per CU; the slab reduce reads splits x |dW| floats, so no finer than that
     if (splits < 1) splits = 1;
-    if (splits > 64) splits = 64;
     if (splits > p.tiles) splits = p.tiles;
     p.tiles_per_split = (p.tiles + splits - 1) / splits;
     p.splits = (p.tiles + p.tiles_per_split - 1) / p.tiles_per_split;

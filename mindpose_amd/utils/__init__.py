@@ -1,6 +1,7 @@
 from .adamw import AdamWeightDecay, split_decay  # noqa: F401
 from .grad_allreduce import GradientAverager  # noqa: F401
 from .ckpt import load_checkpoint, load_param_into_net, save_checkpoint  # noqa: F401
+from .graph_step import GraphedTrainStep  # noqa: F401
 from .loss_scale import DynamicLossScaleManager  # noqa: F401
 from .lr import WarmupMultiStepDecayLR  # noqa: F401
 from .sharding import shard_range  # noqa: F401

@@ -278,3 +278,41 @@ def test_o2_optimizer_steps_with_dynamic_loss_scale():
     assert updated >= 8 and mgr.skipped_steps == 16 - updated and mgr.loss_scale == 2.0 ** 24 / 2 ** mgr.skipped_steps
     assert losses[-1] < losses[0], losses
     assert all(torch.isfinite(p).all() for p in net.parameters())
+
+
+def test_graphed_o2_step_equals_eager():
+    """forward + loss + backward replayed from one hipGraph: same loss and bit-identical gradients as the eager step
+    (same kernels, same order), then the optimizer update and the loss-scale bookkeeping run outside the graph."""
+    import mindpose_amd as mp
+    from mindpose_amd.utils import AdamWeightDecay, DynamicLossScaleManager, GraphedTrainStep
+
+    def build():
+        torch.manual_seed(0)
+        net = mp.init_synthetic(mp.create_network("hrnet_w32", "hrnet_head"), seed=0).to(DEV).train()
+        mp.models.auto_mixed_precision(net, "O2")
+        nwl = mp.create_network_with_loss(net, mp.create_loss("joint_mse", use_target_weight=True), has_extra_inputs=True)
+        opt = AdamWeightDecay(net, lr=1e-3, weight_decay=0.05, filter_bias_and_bn=True, overlap=False)
+        return net, nwl, opt
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 3, 64, 64, generator=g).to(DEV)
+    kp = (torch.rand(4, 17, 3, generator=g) * torch.tensor([64.0, 64.0, 2.0])).to(DEV)
+    tgt = mp.TopDownGenerateTarget(config=dict(image_size=[64, 64], heatmap_size=[16, 16]), sigma=2.0)
+    target, weight = tgt(kp)
+    net_e, nwl_e, opt_e = build()
+    opt_e.zero_grad()
+    loss_e = nwl_e(x, target, weight)
+    (loss_e * 4096.0).backward()
+    grads_e = opt_e.grads.arena.clone()
+    net_g, nwl_g, opt_g = build()
+    mgr = DynamicLossScaleManager(init_loss_scale=4096.0)
+    step = GraphedTrainStep(nwl_g, opt_g, (x, target, weight), loss_scale_manager=mgr, warmup=2)
+    before = opt_g.flat.clone()
+    loss_g = step(x, target, weight)
+    assert float(loss_g.detach()) == float(loss_e.detach())
+    assert step.updated and mgr.skipped_steps == 0
+    # the optimizer divided the arena by the loss scale in place; the parameters moved
+    assert torch.equal(opt_g.grads.arena * 4096.0, grads_e)
+    assert not torch.equal(opt_g.flat, before)
+    losses = [float(step(x, target, weight).detach()) for _ in range(6)]
+    assert losses[-1] < float(loss_e.detach())
