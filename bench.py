@@ -202,7 +202,8 @@ def train_bench(args, mp, dev, dist, world, rank):
         scaler = DynamicLossScaleManager()
     nwl = mp.create_network_with_loss(net, mp.create_loss("joint_mse", use_target_weight=True), has_extra_inputs=True)
     # amp O2 is launch-bound from Python (64 ms per step at any batch): its step is captured into a hipGraph.  The fp32
-    # step is GPU-bound and measured eager (capture made it 8 % slower: the graph's private pool defeats the allocator reuse)
+    # step is GPU-bound (capture changes nothing: 122.8 ms either way) and stays eager, with the bucket all-reduces
+    # overlapping backward under data parallelism
     graphed = os.environ.get("MINDPOSE_TRAIN_GRAPH", "1" if args.amp != "O0" else "0") != "0"
     opt = AdamWeightDecay(net, lr=1e-3, weight_decay=0.05, filter_bias_and_bn=True, overlap=not graphed)
     tgt = mp.TopDownGenerateTarget(config=dict(image_size=[192, 256], heatmap_size=[48, 64]), sigma=2.0)
