@@ -204,7 +204,10 @@ def train_bench(args, mp, dev, dist, world, rank):
     # amp O2 is launch-bound from Python (64 ms per step at any batch): its step is captured into a hipGraph.  The fp32
     # step is GPU-bound (capture changes nothing: 122.8 ms either way) and stays eager, with the bucket all-reduces
     # overlapping backward under data parallelism
-    graphed = os.environ.get("MINDPOSE_TRAIN_GRAPH", "1" if args.amp != "O0" else "0") != "0"
+    # Multi-rank runs default to the eager step (overlapped bucket all-reduces): the graphed step + all-reduce after the
+    # replay is covered by tests on one GPU only (a two-rank rehearsal SHARING one GPU serialises graph replays badly, which
+    # says nothing about one GPU per rank); MINDPOSE_TRAIN_GRAPH=1 forces it.
+    graphed = os.environ.get("MINDPOSE_TRAIN_GRAPH", "1" if (args.amp != "O0" and world == 1) else "0") != "0"
     opt = AdamWeightDecay(net, lr=1e-3, weight_decay=0.05, filter_bias_and_bn=True, overlap=not graphed)
     tgt = mp.TopDownGenerateTarget(config=dict(image_size=[192, 256], heatmap_size=[48, 64]), sigma=2.0)
     gen = torch.Generator(device="cpu").manual_seed(1000 + rank)
