@@ -275,13 +275,15 @@ int mp_plan_add_layout_f16(mp_plan* plan, int to_c8, const void* x_dev, void* ou
  *   src          device buffer holding the source images, HWC uint8, 3 channels
  *   src_offsets  [n] int64 (device): byte offset of crop i's source image inside src
  *   src_hw       [n][2] int32 (device): height, width of crop i's source image
+ *   flip         NULL or [n] int32 (device): non-zero = crop i is taken from the horizontally flipped source image
+ *                (cv2.flip(image, 1) of TopDownHorizontalRandomFlip :481, applied while sampling: no flipped copy is made)
  *   trans        [n][6] fp64 (device): the 2x3 FORWARD matrices (source -> crop) exactly as get_affine_transform /
  *                get_warp_matrix return them; the kernel inverts them as cv2.warpAffine does
  *   normalize=1: out = fp32 [n][3][out_h][out_w], (pixel - mean[c]) / stddev[c]   (mean/std already times 255, host arrays)
  *   normalize=0: out = uint8 [n][out_h][out_w][3], the warped image only
  * Border mode BORDER_CONSTANT(0); OpenCV's fixed-point bilinear arithmetic restated (parity unpinned: no cv2 here). */
-int mp_warp_affine(const uint8_t* src_dev, const long long* src_offsets_dev, const int* src_hw_dev, const double* trans_dev,
-                   void* out_dev, int n, int out_h, int out_w, int normalize, const float mean[3], const float stddev[3],
+int mp_warp_affine(const uint8_t* src_dev, const long long* src_offsets_dev, const int* src_hw_dev, const int* flip_dev,
+                   const double* trans_dev, void* out_dev, int n, int out_h, int out_w, int normalize, const float mean[3], const float stddev[3],
                    mp_stream_t stream);
 
 /* fp16 (amp O2) training passes over channel-blocked fp16 activations; same contracts as mp_bn_train_fwd / _bwd and

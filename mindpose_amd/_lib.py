@@ -73,7 +73,7 @@ _PROTOTYPES = {
     "mp_f16_conv_wgrad": (c_int, [ctypes.POINTER(ConvDesc), c_f32p, c_f32p, c_f32p, ctypes.c_float, c_f32p, c_size_t, ctypes.c_void_p]),
     "mp_plan_set_lane": (c_int, [ctypes.c_void_p, c_int]),
     "mp_plan_add_barrier": (c_int, [ctypes.c_void_p]),
-    "mp_warp_affine": (c_int, [c_f32p] * 5 + [c_int] * 4 + [ctypes.POINTER(ctypes.c_float)] * 2 + [ctypes.c_void_p]),
+    "mp_warp_affine": (c_int, [c_f32p] * 6 + [c_int] * 4 + [ctypes.POINTER(ctypes.c_float)] * 2 + [ctypes.c_void_p]),
     # fp16 matrix-core inference path (channel-blocked activations)
     "mp_f16_packed_weight_bytes": (c_size_t, [c_int] * 4),
     "mp_f16_activation_bytes": (c_size_t, [c_int] * 4),

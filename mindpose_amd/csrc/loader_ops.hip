@@ -21,8 +21,8 @@ __device__ __forceinline__ int cv_round(double v) { return (int)rint(v); }  // c
 
 template <bool NORMALIZE>
 __global__ __launch_bounds__(256) void warp_affine_kernel(const uint8_t* __restrict__ src, const long long* __restrict__ src_off,
-                                                          const int* __restrict__ src_hw, const double* __restrict__ trans,
-                                                          void* __restrict__ out, int out_h, int out_w, float m0, float m1,
+                                                          const int* __restrict__ src_hw, const int* __restrict__ flip,
+                                                          const double* __restrict__ trans, void* __restrict__ out, int out_h, int out_w, float m0, float m1,
                                                           float m2, float s0, float s1, float s2) {
     const int n = blockIdx.y;
     __shared__ double inv[6];
@@ -39,6 +39,9 @@ __global__ __launch_bounds__(256) void warp_affine_kernel(const uint8_t* __restr
     }
     __syncthreads();
     const int H = src_hw[2 * n], W = src_hw[2 * n + 1];
+    // cv2.flip(image, 1) before the warp (TopDownHorizontalRandomFlip) = sampling the original at the mirrored column:
+    // the fixed-point coordinates and the bilinear weights are symmetric, so the result is bit-identical
+    const bool mirror = flip && flip[n] != 0;
     const uint8_t* __restrict__ img = src + src_off[n];
     const int total = out_h * out_w;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256) void warp_affine_kernel(const uint8_t* __restr
         int acc[3] = {0, 0, 0};
         auto tap = [&](int yy, int xx, int w) {
             if (w != 0 && yy >= 0 && yy < H && xx >= 0 && xx < W) {
-                const uint8_t* px = img + ((size_t)yy * W + xx) * 3;
+                const uint8_t* px = img + ((size_t)yy * W + (mirror ? W - 1 - xx : xx)) * 3;
                 acc[0] += w * px[0]; acc[1] += w * px[1]; acc[2] += w * px[2];
             }
         };
@@ -82,8 +85,8 @@ __global__ __launch_bounds__(256) void warp_affine_kernel(const uint8_t* __restr
 
 using namespace mp;
 
-extern "C" int mp_warp_affine(const uint8_t* src, const long long* src_offsets, const int* src_hw, const double* trans, void* out,
-                              int n, int out_h, int out_w, int normalize, const float mean[3], const float stddev[3],
+extern "C" int mp_warp_affine(const uint8_t* src, const long long* src_offsets, const int* src_hw, const int* flip,
+                              const double* trans, void* out, int n, int out_h, int out_w, int normalize, const float mean[3], const float stddev[3],
                               mp_stream_t stream) {
     if (!src || !src_offsets || !src_hw || !trans || !out) return MP_ERR_NULL;
     if (n <= 0 || out_h <= 0 || out_w <= 0 || n > 65535) return MP_ERR_SHAPE;
@@ -93,10 +96,10 @@ extern "C" int mp_warp_affine(const uint8_t* src, const long long* src_offsets, 
     int bx = (total + 255) / 256;
     if (bx > 1024) bx = 1024;
     if (normalize)
-        hipLaunchKernelGGL(warp_affine_kernel<true>, dim3(bx, n), dim3(256), 0, as_stream(stream), src, src_offsets, src_hw, trans, out,
+        hipLaunchKernelGGL(warp_affine_kernel<true>, dim3(bx, n), dim3(256), 0, as_stream(stream), src, src_offsets, src_hw, flip, trans, out,
                            out_h, out_w, mean[0], mean[1], mean[2], stddev[0], stddev[1], stddev[2]);
     else
-        hipLaunchKernelGGL(warp_affine_kernel<false>, dim3(bx, n), dim3(256), 0, as_stream(stream), src, src_offsets, src_hw, trans, out,
+        hipLaunchKernelGGL(warp_affine_kernel<false>, dim3(bx, n), dim3(256), 0, as_stream(stream), src, src_offsets, src_hw, flip, trans, out,
                            out_h, out_w, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f);
     return check_launch();
 }

@@ -1,4 +1,6 @@
 from .topdown_transform import (TopDownAffine, TopDownBoxToCenterScale, TopDownGenerateTarget,  # noqa: F401
-                                get_affine_transform, get_warp_matrix)
+                                TopDownHalfBodyTransform, TopDownHorizontalRandomFlip, TopDownRandomScaleRotation,
+                                fliplr_joints, get_affine_transform, get_warp_matrix)
 
-__all__ = ["TopDownGenerateTarget", "TopDownBoxToCenterScale", "TopDownAffine", "get_affine_transform", "get_warp_matrix"]
+__all__ = ["TopDownGenerateTarget", "TopDownBoxToCenterScale", "TopDownAffine", "TopDownHorizontalRandomFlip",
+           "TopDownHalfBodyTransform", "TopDownRandomScaleRotation", "fliplr_joints", "get_affine_transform", "get_warp_matrix"]

@@ -246,7 +246,7 @@ class TopDownAffine:
         return get_affine_transform(center, scale, rotation, image_size, pixel_std=pixel_std)
 
     def _launch(self, images: Sequence[torch.Tensor], index: Sequence[int], mats: np.ndarray, normalize: bool,
-                out: Optional[torch.Tensor], mean, std) -> torch.Tensor:
+                out: Optional[torch.Tensor], mean, std, flips=None) -> torch.Tensor:
         lib = _lib.load()
         w, h = (int(v) for v in self._transform_cfg["image_size"])
         n = len(index)
@@ -258,6 +258,7 @@ class TopDownAffine:
         offs = torch.tensor([images[i].data_ptr() - base for i in index], dtype=torch.int64, device=dev)
         hw = torch.tensor([[images[i].shape[0], images[i].shape[1]] for i in index], dtype=torch.int32, device=dev)
         tr = torch.from_numpy(np.ascontiguousarray(mats, dtype=np.float64).reshape(n, 6)).to(dev)
+        fl = None if flips is None else torch.tensor([int(bool(f)) for f in flips], dtype=torch.int32, device=dev)
         if out is None:
             out = (torch.empty(n, 3, h, w, device=dev, dtype=torch.float32) if normalize
                    else torch.empty(n, h, w, 3, device=dev, dtype=torch.uint8))
@@ -266,17 +267,19 @@ class TopDownAffine:
             raise ValueError(f"out must be a contiguous {want} tensor")
         m3 = (ctypes.c_float * 3)(*[float(np.float32(v * 255.0)) for v in mean])
         s3 = (ctypes.c_float * 3)(*[float(np.float32(v * 255.0)) for v in std])
-        _lib.check(lib.mp_warp_affine(base, _lib.ptr(offs), _lib.ptr(hw), _lib.ptr(tr), _lib.ptr(out), n, h, w, int(normalize),
+        _lib.check(lib.mp_warp_affine(base, _lib.ptr(offs), _lib.ptr(hw), _lib.ptr(fl), _lib.ptr(tr), _lib.ptr(out), n, h, w, int(normalize),
                                       m3, s3, _lib.stream()), "mp_warp_affine")
         return out
 
     def crop_batch(self, images: Union[torch.Tensor, Sequence[torch.Tensor]], centers: np.ndarray, scales: np.ndarray,
                    rotations: Optional[np.ndarray] = None, image_index: Optional[Sequence[int]] = None,
-                   out: Optional[torch.Tensor] = None, normalize_mean=NORMALIZE_MEAN, normalize_std=NORMALIZE_STD
-                   ) -> Tuple[torch.Tensor, np.ndarray]:
+                   out: Optional[torch.Tensor] = None, normalize_mean=NORMALIZE_MEAN, normalize_std=NORMALIZE_STD,
+                   flips: Optional[Sequence[bool]] = None) -> Tuple[torch.Tensor, np.ndarray]:
         """warpAffine + Normalize + HWC2CHW for N boxes in one launch.
 
         images: one CUDA uint8 [H,W,3] tensor or a list of them; ``image_index[i]`` = the image box i lives in.
+        ``flips[i]``: box i is cropped from the horizontally flipped image (training augmentation; ``centers`` are then
+        the already mirrored centres, as TopDownHorizontalRandomFlip returns them) - applied while sampling.
         Returns (crops [N,3,h,w] fp32 CUDA - ``out`` when given, e.g. the network's input buffer -, matrices [N,2,3])."""
         if torch.is_tensor(images):
             images = [images]
@@ -284,7 +287,7 @@ class TopDownAffine:
         index = list(image_index) if image_index is not None else [0] * n
         rot = np.zeros(n) if rotations is None else np.asarray(rotations)
         mats = np.stack([self.get_matrix(np.asarray(centers[i]), np.asarray(scales[i]), float(rot[i])) for i in range(n)])
-        return self._launch(images, index, mats, True, out, normalize_mean, normalize_std), mats
+        return self._launch(images, index, mats, True, out, normalize_mean, normalize_std, flips), mats
 
     def transform(self, state: Dict[str, Any]) -> Dict[str, Any]:
         """Per-sample contract of the reference (:183-262): required keys image, center, scale, rotation, keypoints
@@ -305,3 +308,108 @@ class TopDownAffine:
                         kp[i, 0:2] = np.array(trans) @ np.array([kp[i, 0], kp[i, 1], 1.0])
             out["keypoints"] = kp
         return out
+
+
+def fliplr_joints(keypoints: np.ndarray, img_width: int, flip_pairs=None, flip_index: Optional[np.ndarray] = None) -> np.ndarray:
+    """Mirror key points horizontally and swap left / right joints (transform/utils.py:7-41)."""
+    assert img_width > 0
+    assert flip_pairs is not None or flip_index is not None
+    if flip_pairs is not None:
+        flipped = keypoints.copy()
+        for left, right in flip_pairs:
+            flipped[..., left, :] = keypoints[..., right, :]
+            flipped[..., right, :] = keypoints[..., left, :]
+    else:
+        flipped = keypoints[..., flip_index, :]
+    flipped[..., 0] = img_width - 1 - flipped[..., 0]
+    return flipped
+
+
+@register("transform", extra_name="topdown_horizontal_random_flip")
+class TopDownHorizontalRandomFlip:
+    """Random horizontal flip of image, key points and box centre (topdown_transform.py:433-488).  The image may be a
+    numpy HWC array or a CUDA tensor (flipped on the device); the random draw and the label arithmetic are the reference's."""
+
+    def __init__(self, is_train: bool = True, config: Optional[Dict[str, Any]] = None, flip_prob: float = 0.5) -> None:
+        self.is_train = is_train
+        self.config = config if config else dict()
+        self._transform_cfg = _load_full_cfg(self.config)
+        self.flip_prob = flip_prob
+
+    def transform(self, state: Dict[str, Any]) -> Dict[str, Any]:
+        image, keypoints, center = state["image"], state["keypoints"], state["center"]
+        if np.random.rand() <= self.flip_prob:
+            image = torch.flip(image, dims=[1]) if torch.is_tensor(image) else image[:, ::-1]
+            keypoints = fliplr_joints(keypoints, image.shape[1], flip_index=self._transform_cfg["flip_index"])
+            center[0] = image.shape[1] - center[0]
+        return dict(image=image, keypoints=keypoints, center=center)
+
+
+@register("transform", extra_name="topdown_halfbody_transform")
+class TopDownHalfBodyTransform:
+    """Keep only the upper or the lower body at random (topdown_transform.py:490-606); host numpy, same random draws."""
+
+    def __init__(self, is_train: bool = True, config: Optional[Dict[str, Any]] = None, num_joints_half_body: int = 8,
+                 prob_half_body: float = 0.3, scale_padding: float = 1.5) -> None:
+        self.is_train = is_train
+        self.config = config if config else dict()
+        self._transform_cfg = _load_full_cfg(self.config)
+        self.num_joints_half_body = num_joints_half_body
+        self.prob_half_body = prob_half_body
+        self.scale_padding = scale_padding
+
+    def half_body_transform(self, keypoints: np.ndarray, num_joints: int = 17):
+        upper, lower = [], []
+        for joint_id in range(num_joints):
+            if keypoints[joint_id][2] > 0:
+                (upper if joint_id in self._transform_cfg["upper_body_ids"] else lower).append(keypoints[joint_id])
+        if np.random.randn() < 0.5 and len(upper) > 2:  # (the reference really draws from randn here)
+            selected = upper
+        elif len(lower) > 2:
+            selected = lower
+        else:
+            selected = upper
+        if len(selected) < 2:
+            return None, None
+        selected = np.array(selected, dtype=np.float32)
+        center = selected.mean(axis=0)[:2]
+        left_top = np.amin(selected, axis=0)
+        right_bottom = np.amax(selected, axis=0)
+        w = right_bottom[0] - left_top[0]
+        h = right_bottom[1] - left_top[1]
+        aspect_ratio = self._transform_cfg["image_size"][0] / self._transform_cfg["image_size"][1]
+        if w > aspect_ratio * h:
+            h = w * 1.0 / aspect_ratio
+        elif w < aspect_ratio * h:
+            w = h * aspect_ratio
+        scale = np.array([w / self._transform_cfg["pixel_std"], h / self._transform_cfg["pixel_std"]], dtype=np.float32)
+        return center, scale * self.scale_padding
+
+    def transform(self, state: Dict[str, Any]) -> Dict[str, Any]:
+        keypoints = state["keypoints"]
+        if np.sum(keypoints[:, 2]) > self.num_joints_half_body and np.random.rand() < self.prob_half_body:
+            c, s = self.half_body_transform(keypoints, num_joints=keypoints.shape[0])
+            if c is not None and s is not None:
+                return dict(center=c, scale=s)
+        return dict()
+
+
+@register("transform", extra_name="topdown_randomscale_rotation")
+class TopDownRandomScaleRotation:
+    """Random scale and rotation of the box (topdown_transform.py:608-667); host numpy, same random draws."""
+
+    def __init__(self, is_train: bool = True, config: Optional[Dict[str, Any]] = None, rot_factor: float = 40.0,
+                 scale_factor: float = 0.5, rot_prob: float = 0.6) -> None:
+        self.is_train = is_train
+        self.config = config if config else dict()
+        self._transform_cfg = _load_full_cfg(self.config)
+        self.rot_factor, self.scale_factor, self.rot_prob = rot_factor, scale_factor, rot_prob
+
+    def transform(self, state: Dict[str, Any]) -> Dict[str, Any]:
+        s = state["scale"]
+        sf, rf = self.scale_factor, self.rot_factor
+        s_factor = np.clip(np.random.randn() * sf + 1, 1 - sf, 1 + sf, dtype=np.float32)
+        s = s * s_factor
+        r_factor = np.clip(np.random.randn() * rf, -rf * 2, rf * 2, dtype=np.float32)
+        r = r_factor if np.random.rand() <= self.rot_prob else np.float32(0.0)
+        return dict(scale=s, rotation=r)

@@ -203,6 +203,32 @@ def gen_geometry():
             args.append([theta, *center, *scale])
         out[f"warp_args_{name}"] = np.array(args, np.float64)
         out[f"warp_matrix_{name}"] = np.stack(mats)
+    # training-time augmentations (numpy + np.random only): seeded runs of the reference classes
+    cfg = dict(image_size=[192, 256], heatmap_size=[48, 64], flip_pairs=recipes.FLIP_PAIRS, upper_body_ids=list(range(11)),
+               pixel_std=200.0, scale_padding=1.25)
+    kps = rng.uniform(0, 300, (30, 17, 3)).astype(np.float32)
+    kps[..., 2] = (rng.rand(30, 17) > 0.25).astype(np.float32)
+    kps[3, :, 2] = 0
+    kps[4, 6:, 2] = 0  # upper body only
+    scales = rng.uniform(0.4, 2.5, (30, 2)).astype(np.float32)
+    out["aug_keypoints"], out["aug_scales"] = kps, scales
+    hb = tt.TopDownHalfBodyTransform(is_train=True, config=cfg)
+    rs = tt.TopDownRandomScaleRotation(is_train=True, config=cfg)
+    np.random.seed(4321)
+    hb_c, hb_s, hb_hit, rs_s, rs_r = [], [], [], [], []
+    for i in range(30):
+        o = hb.transform(dict(keypoints=kps[i].copy()))
+        hb_hit.append(1 if o else 0)
+        hb_c.append(o.get("center", np.zeros(2, np.float32)))
+        hb_s.append(o.get("scale", np.zeros(2, np.float32)))
+        o = rs.transform(dict(scale=scales[i].copy()))
+        rs_s.append(o["scale"])
+        rs_r.append(o["rotation"])
+    out["aug_halfbody_hit"] = np.array(hb_hit)
+    out["aug_halfbody_center"], out["aug_halfbody_scale"] = np.stack(hb_c), np.stack(hb_s)
+    out["aug_rs_scale"], out["aug_rs_rotation"] = np.stack(rs_s), np.array(rs_r, np.float32)
+    out["aug_fliplr_index"] = ut.fliplr_joints(kps, 192, flip_index=hb._transform_cfg["flip_index"])
+    out["aug_fliplr_pairs"] = ut.fliplr_joints(kps, 192, flip_pairs=recipes.FLIP_PAIRS)
     np.savez_compressed(os.path.join(HERE, "geometry.npz"), **out)
     print("geometry.npz", {k: v.shape for k, v in out.items()})
 

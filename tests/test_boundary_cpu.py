@@ -45,7 +45,8 @@ def test_registry_names_resolve():
         "decoder": ["TopDownHeatMapDecoder", "topdown_heatmap"],
         "loss": ["JointsMSELoss", "joint_mse"],
         "transform": ["TopDownGenerateTarget", "topdown_generate_target", "TopDownBoxToCenterScale",
-                      "topdown_box_to_center_scale", "TopDownAffine", "topdown_affine"],
+                      "topdown_box_to_center_scale", "TopDownAffine", "topdown_affine", "topdown_horizontal_random_flip",
+                      "topdown_halfbody_transform", "topdown_randomscale_rotation"],
         "inferencer": ["TopDownHeatMapInferencer", "topdown_heatmap"],
     }
     for module, comps in names.items():

@@ -93,3 +93,30 @@ def test_boxes_to_keypoints_end_to_end():
     assert float((hm.cpu() - ref_hm).abs().max() / ref_hm.abs().max()) < 1e-3
     rp, rb, _ = od.decode(hm.cpu().numpy(), centers, scales, np.ones(3, np.float32), shift_coord=True)
     assert np.array_equal(preds.cpu().numpy(), rp) and np.array_equal(pboxes.cpu().numpy(), rb)
+
+
+def test_training_augmentation_chain_flip_in_kernel():
+    # flip -> half-body / random scale-rotation -> fused crop with the flip applied while sampling == crop of a flipped copy
+    rng = np.random.RandomState(21)
+    img = rng.randint(0, 256, (240, 320, 3)).astype(np.uint8)
+    cfg = dict(CFG, image_size=[192, 256])
+    np.random.seed(99)
+    fl = mp.TopDownHorizontalRandomFlip(True, cfg, flip_prob=0.5)
+    rs = mp.TopDownRandomScaleRotation(True, cfg)
+    aff = mp.TopDownAffine(True, cfg)
+    centers, scales, rots, flips = [], [], [], []
+    for i in range(12):
+        kp = np.concatenate([rng.uniform(0, 240, (17, 2)), np.ones((17, 1))], axis=1).astype(np.float32)
+        c0 = np.array([rng.uniform(60, 260), rng.uniform(60, 180)], np.float32)
+        st = fl.transform(dict(image=img, keypoints=kp, center=c0.copy()))
+        flips.append(st["image"] is not img)
+        o = rs.transform(dict(scale=np.array([0.8, 1.1], np.float32)))
+        centers.append(st["center"]); scales.append(o["scale"]); rots.append(float(o["rotation"]))
+    assert any(flips) and not all(flips)
+    dimg = torch.from_numpy(img).to(DEV)
+    crops, _ = aff.crop_batch(dimg, np.stack(centers), np.stack(scales), np.array(rots), flips=flips)
+    got = crops.cpu().numpy()
+    for i in range(12):
+        src = np.ascontiguousarray(img[:, ::-1]) if flips[i] else img
+        ref, _ = ol.crop(src, centers[i], scales[i], rots[i], [192, 256])
+        assert np.array_equal(got[i], ref), i

@@ -86,3 +86,34 @@ def test_warp_affine_oracle_properties():
     chw = ol.normalize_chw(img, [100.0, 110.0, 120.0], [50.0, 60.0, 70.0])
     assert chw.shape == (3, 60, 80) and chw.dtype == np.float32
     assert chw[1, 7, 9] == (np.float32(img[7, 9, 1]) - np.float32(110.0)) / np.float32(60.0)
+
+
+def test_training_augmentations_bit_exact_vs_reference():
+    """Half-body, random scale / rotation (same np.random draws in the same order) and fliplr_joints against seeded runs of
+    the reference's own classes."""
+    cfg = dict(CFG, image_size=[192, 256])
+    kps, scales = G["aug_keypoints"], G["aug_scales"]
+    hb = mp.TopDownHalfBodyTransform(is_train=True, config=cfg)
+    rs = mp.TopDownRandomScaleRotation(is_train=True, config=cfg)
+    np.random.seed(4321)
+    hits = 0
+    for i in range(30):
+        o = hb.transform(dict(keypoints=kps[i].copy()))
+        assert (1 if o else 0) == int(G["aug_halfbody_hit"][i])
+        if o:
+            hits += 1
+            assert np.array_equal(o["center"], G["aug_halfbody_center"][i]) and np.array_equal(o["scale"], G["aug_halfbody_scale"][i])
+        o = rs.transform(dict(scale=scales[i].copy()))
+        assert np.array_equal(o["scale"], G["aug_rs_scale"][i]) and o["rotation"] == G["aug_rs_rotation"][i]
+        assert o["scale"].dtype == np.float32 and np.asarray(o["rotation"]).dtype == np.float32
+    assert 3 <= hits <= 20 and (G["aug_rs_rotation"] == 0).any() and (G["aug_rs_rotation"] != 0).any()
+    fi = hb._transform_cfg["flip_index"]
+    assert np.array_equal(mp.fliplr_joints(kps, 192, flip_index=fi), G["aug_fliplr_index"])
+    assert np.array_equal(mp.fliplr_joints(kps, 192, flip_pairs=recipes.FLIP_PAIRS), G["aug_fliplr_pairs"])
+    # the flip transform: label arithmetic as the reference (centre mirrored about the image WIDTH, key points about W - 1)
+    fl = mp.TopDownHorizontalRandomFlip(is_train=True, config=cfg, flip_prob=1.0)
+    img = np.arange(4 * 6 * 3, dtype=np.uint8).reshape(4, 6, 3)
+    o = fl.transform(dict(image=img, keypoints=kps[0, :, :].copy(), center=np.array([2.0, 1.0], np.float32)))
+    assert np.array_equal(o["image"], img[:, ::-1]) and o["center"][0] == 4.0
+    assert np.array_equal(o["keypoints"], mp.fliplr_joints(kps[0], 6, flip_index=fi))
+    assert mp.entrypoint("transform", "topdown_halfbody_transform") is mp.TopDownHalfBodyTransform
