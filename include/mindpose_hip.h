@@ -291,17 +291,20 @@ int mp_warp_affine(const uint8_t* src_dev, const long long* src_offsets_dev, con
 int mp_f16_bn_train_fwd(const void* z_dev, const float* gamma_dev, const float* beta_dev, const void* res_dev, void* y_dev,
                         float* save_mean_dev, float* save_invstd_dev, float* moving_mean_dev, float* moving_var_dev, int n, int c,
                         int hw, float eps, float momentum, int relu, void* workspace_dev, size_t workspace_bytes, mp_stream_t stream);
+/* dgamma_acc / dbeta_acc (both or neither, may be NULL): the gamma / beta gradients are ALSO added into these buffers (the
+ * caller's gradient arena), which saves the framework's separate accumulate launch */
 int mp_f16_bn_train_bwd(const void* dy_dev, const void* z_dev, const void* y_dev, const float* gamma_dev, const float* save_mean_dev,
-                        const float* save_invstd_dev, void* dz_dev, void* dres_dev, float* dgamma_dev, float* dbeta_dev, int n, int c,
-                        int hw, int relu, void* workspace_dev, size_t workspace_bytes, mp_stream_t stream);
+                        const float* save_invstd_dev, void* dz_dev, void* dres_dev, float* dgamma_dev, float* dbeta_dev,
+                        float* dgamma_acc_dev, float* dbeta_acc_dev, int n, int c, int hw, int relu, void* workspace_dev,
+                        size_t workspace_bytes, mp_stream_t stream);
 int mp_f16_fuse_upsample_sum_bwd(const void* dy_dev, const void* out_dev, void* dbase_dev, void* dt1_dev, int s1, void* dt2_dev,
                                  int s2, void* dt3_dev, int s3, int n, int c, int h, int w, int relu, mp_stream_t stream);
 /* weight gradient of a conv (kernel 1x1 or 3x3, stride 1 or 2, padding k/2) from channel-blocked fp16 x and dz on the fp16
- * matrix cores, fp32 accumulation and fp32 result dw [Cout,Cin,kh,kw] (times `scale`: pass 1 / loss_scale); workspace from
- * mp_f16_conv_wgrad_workspace_bytes */
+ * matrix cores, fp32 accumulation and fp32 result dw [Cout,Cin,kh,kw] (times `scale`: pass 1 / loss_scale); accumulate != 0
+ * adds into dw (the caller's gradient arena) instead of overwriting; workspace from mp_f16_conv_wgrad_workspace_bytes */
 size_t mp_f16_conv_wgrad_workspace_bytes(const mp_conv_desc* desc);
 int mp_f16_conv_wgrad(const mp_conv_desc* desc, const void* x_c8_dev, const void* dz_c8_dev, float* dw_dev, float scale,
-                      void* workspace_dev, size_t workspace_bytes, mp_stream_t stream);
+                      int accumulate, void* workspace_dev, size_t workspace_bytes, mp_stream_t stream);
 
 /* Diagnostics: only a library built with -DMP_CONV_STAMPS=1 (never the product build) records per-workgroup
  * phase cycle counters (8 x uint64 per workgroup) of each conv launch into this device buffer; the product

@@ -67,10 +67,10 @@ _PROTOTYPES = {
     "mp_conv_wgrad": (c_int, [ctypes.POINTER(ConvDesc), c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_size_t, ctypes.c_void_p]),
     "mp_adamw_step": (c_int, [c_f32p] * 4 + [c_size_t] + [ctypes.c_float] * 5 + [ctypes.c_void_p]),
     "mp_f16_bn_train_fwd": (c_int, [c_f32p] * 9 + [c_int] * 3 + [ctypes.c_float, ctypes.c_float, c_int, c_f32p, c_size_t, ctypes.c_void_p]),
-    "mp_f16_bn_train_bwd": (c_int, [c_f32p] * 10 + [c_int] * 4 + [c_f32p, c_size_t, ctypes.c_void_p]),
+    "mp_f16_bn_train_bwd": (c_int, [c_f32p] * 12 + [c_int] * 4 + [c_f32p, c_size_t, ctypes.c_void_p]),
     "mp_f16_fuse_upsample_sum_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_int, c_f32p, c_int] + [c_int] * 5 + [ctypes.c_void_p]),
     "mp_f16_conv_wgrad_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),
-    "mp_f16_conv_wgrad": (c_int, [ctypes.POINTER(ConvDesc), c_f32p, c_f32p, c_f32p, ctypes.c_float, c_f32p, c_size_t, ctypes.c_void_p]),
+    "mp_f16_conv_wgrad": (c_int, [ctypes.POINTER(ConvDesc), c_f32p, c_f32p, c_f32p, ctypes.c_float, c_int, c_f32p, c_size_t, ctypes.c_void_p]),
     "mp_plan_set_lane": (c_int, [ctypes.c_void_p, c_int]),
     "mp_plan_add_barrier": (c_int, [ctypes.c_void_p]),
     "mp_warp_affine": (c_int, [c_f32p] * 6 + [c_int] * 4 + [ctypes.POINTER(ctypes.c_float)] * 2 + [ctypes.c_void_p]),

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 
 // stage 2 (backward): dgamma = sum g*xhat, dbeta = sum g
 __global__ void bn_finalize_bwd_kernel(const double* __restrict__ part, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, int c, int nsplit) {
+                                       float* __restrict__ dbeta, int c, int nsplit, int accumulate) {
     const int ch = blockIdx.x;
     double s0 = 0.0, s1 = 0.0;
     for (int sp = threadIdx.x; sp < nsplit; sp += 64) {
@@ -140,8 +140,8 @@ __global__ void bn_finalize_bwd_kernel(const double* __restrict__ part, float* _
         s1 += __shfl_down(s1, off, 64);
     }
     if (threadIdx.x != 0) return;
-    dbeta[ch] = (float)s0;
-    dgamma[ch] = (float)s1;
+    dbeta[ch] = accumulate ? dbeta[ch] + (float)s0 : (float)s0;
+    dgamma[ch] = accumulate ? dgamma[ch] + (float)s1 : (float)s1;
 }
 
 // dz = gamma*invstd * (g - dbeta/M - xhat*dgamma/M), dres = g  (g = dy masked by the ReLU of the forward output)
@@ -442,7 +442,7 @@ int mp_bn_train_bwd(const float* dy, const float* z, const float* y, const float
                        hw, relu ? 1 : 0);
     int rc = check_launch();
     if (rc != MP_OK) return rc;
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(c), dim3(64), 0, s, part, dgamma, dbeta, c, kBnSplit);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(c), dim3(64), 0, s, part, dgamma, dbeta, c, kBnSplit, 0);
     rc = check_launch();
     if (rc != MP_OK) return rc;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(n * c), dim3(256), 0, s, dy, z, y, gamma, save_mean, save_invstd, dgamma, dbeta,
@@ -515,8 +515,8 @@ int mp_f16_bn_train_fwd(const void* z, const float* gamma, const float* beta, co
 }
 
 int mp_f16_bn_train_bwd(const void* dy, const void* z, const void* y, const float* gamma, const float* save_mean,
-                        const float* save_invstd, void* dz, void* dres, float* dgamma, float* dbeta, int n, int c, int hw, int relu,
-                        void* workspace, size_t workspace_bytes, mp_stream_t stream) {
+                        const float* save_invstd, void* dz, void* dres, float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc,
+                        int n, int c, int hw, int relu, void* workspace, size_t workspace_bytes, mp_stream_t stream) {
     if (!dy || !z || !gamma || !save_mean || !save_invstd || !dz || !dgamma || !dbeta) return MP_ERR_NULL;
     if (relu && !y) return MP_ERR_NULL;
     if (n <= 0 || c <= 0 || hw <= 0) return MP_ERR_SHAPE;
@@ -531,8 +531,12 @@ int mp_f16_bn_train_bwd(const void* dy, const void* z, const void* y, const floa
                        c8, hw, relu ? 1 : 0, gi, gp);
     int rc = check_launch();
     if (rc != MP_OK) return rc;
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(c), dim3(64), 0, s, part, dgamma, dbeta, c, gi * gp);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(c), dim3(64), 0, s, part, dgamma, dbeta, c, gi * gp, 0);
     rc = check_launch();
+    if (rc == MP_OK && dgamma_acc && dbeta_acc) {  // + straight into the caller's gradient buffers (no separate add launch)
+        hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(c), dim3(64), 0, s, part, dgamma_acc, dbeta_acc, c, gi * gp, 1);
+        rc = check_launch();
+    }
     if (rc != MP_OK) return rc;
     const size_t total = (size_t)n * c8 * hw;
     size_t blocks = (total + 255) / 256;

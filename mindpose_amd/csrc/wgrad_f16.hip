@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16_kernel(const Wgrad16Par
 }
 
 __global__ __launch_bounds__(256) void wgrad16_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, size_t count,
-                                                             int splits, float scale) {
+                                                             int splits, float scale, int accumulate) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
         float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         int k = 0;
@@ -198,7 +198,8 @@ __global__ __launch_bounds__(256) void wgrad16_reduce_kernel(const float* __rest
             for (int j = 0; j < 8; ++j) part[j] += slabs[(size_t)(k + j) * count + i];
         }
         for (int j = 0; k < splits; ++k, ++j) part[j] += slabs[(size_t)k * count + i];
-        dw[i] = (((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]))) * scale;
+        const float v = (((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]))) * scale;
+        dw[i] = accumulate ? dw[i] + v : v;
     }
 }
 
@@ -275,8 +276,8 @@ size_t mp_f16_conv_wgrad_workspace_bytes(const mp_conv_desc* desc) {
     return (size_t)p.splits * p.Cout * p.Cin * desc->kh * desc->kw * sizeof(float);
 }
 
-int mp_f16_conv_wgrad(const mp_conv_desc* desc, const void* x, const void* dz, float* dw, float scale, void* workspace,
-                      size_t workspace_bytes, mp_stream_t stream) {
+int mp_f16_conv_wgrad(const mp_conv_desc* desc, const void* x, const void* dz, float* dw, float scale, int accumulate,
+                      void* workspace, size_t workspace_bytes, mp_stream_t stream) {
     if (!x || !dz || !dw) return MP_ERR_NULL;
     Wgrad16Params p{};
     size_t lds = 0;
@@ -291,7 +292,7 @@ int mp_f16_conv_wgrad(const mp_conv_desc* desc, const void* x, const void* dz, f
     if (rc != MP_OK) return rc;
     size_t blocks = (count + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(wgrad16_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p.slabs, dw, count, p.splits, scale);
+    hipLaunchKernelGGL(wgrad16_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p.slabs, dw, count, p.splits, scale, accumulate ? 1 : 0);
     return check_launch();
 }
 

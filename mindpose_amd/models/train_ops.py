@@ -200,6 +200,15 @@ class FuseSumFn(torch.autograd.Function):
 # gradient in fp32 (the parameters themselves stay fp32 "master" weights: the pack kernel rounds them to fp16 per step).
 
 
+def _direct_grad(param):
+    """The parameter's slot in a flat gradient arena when the owner allows kernels to accumulate into it directly
+    (``GradientAverager`` without overlap hooks sets ``_mp_grad_direct``): saves one AccumulateGrad add launch per parameter
+    (878 per HRNet-W32 step, 8 % of the graphed O2 step)."""
+    if getattr(param, "_mp_grad_direct", False) and param.grad is not None and param.grad.is_contiguous():
+        return param.grad
+    return None
+
+
 def _c8_shape(n, c, h, w):
     return (n, (c + 7) // 8, h, w, 8)
 
@@ -291,6 +300,7 @@ class Conv16Fn(torch.autograd.Function):
         _conv16_launch(lib, d, x, packed, ones, shift, z, "mp_f16_conv2d_fwd")
         ctx.save_for_backward(x, w)
         ctx.stride, ctx.padding, ctx.has_bias = stride, padding, bias is not None
+        ctx.weight_param = weight
         return z
 
     @staticmethod
@@ -317,12 +327,15 @@ class Conv16Fn(torch.autograd.Function):
                         d = _desc(n, cout, ho, wo, cin, 2, 1, 0, 0, ho, wo, h, wd, out_mul=2, off_y=py, off_x=px)
                         _conv16_launch(lib, d, dz, _pack16(lib, w, cin, cout, 2, 3, py, px), ones, zeros, dx, "conv dgrad phase")
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
+            direct = _direct_grad(ctx.weight_param)  # add straight into the gradient arena: no AccumulateGrad launch
+            dw = direct if direct is not None else torch.empty_like(w)
             d = _desc(n, cin, h, wd, cout, k, s, pad, pad, ho, wo, ho, wo)
             ws_bytes = lib.mp_f16_conv_wgrad_workspace_bytes(ctypes.byref(d))
             ws = torch.empty(max(ws_bytes // 4, 1), device=x.device, dtype=torch.float32)
-            _lib.check(lib.mp_f16_conv_wgrad(ctypes.byref(d), _lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), 1.0, _lib.ptr(ws), ws_bytes,
-                                             _lib.stream()), "mp_f16_conv_wgrad")
+            _lib.check(lib.mp_f16_conv_wgrad(ctypes.byref(d), _lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), 1.0, int(direct is not None),
+                                             _lib.ptr(ws), ws_bytes, _lib.stream()), "mp_f16_conv_wgrad")
+            if direct is not None:
+                dw = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dz.float().sum(dim=(0, 2, 3)).reshape(-1)[:cout]  # head conv bias (17 values)
         return dx, dw, db, None, None
@@ -348,6 +361,7 @@ class BatchNormAct16Fn(torch.autograd.Function):
                                            BN_MOMENTUM, int(relu), _lib.ptr(ws), ws_bytes, _lib.stream()), "mp_f16_bn_train_fwd")
         ctx.save_for_backward(z, y, g, mean, invstd)
         ctx.relu, ctx.has_res = relu, res is not None
+        ctx.gamma_param, ctx.beta_param = gamma, beta
         return y
 
     @staticmethod
@@ -363,9 +377,14 @@ class BatchNormAct16Fn(torch.autograd.Function):
         dbeta = torch.empty(c, device=z.device)
         ws_bytes = lib.mp_bn_workspace_bytes(c)
         ws = torch.empty(ws_bytes // 4 + 1, device=z.device, dtype=torch.float32)
+        ga, ba = _direct_grad(ctx.gamma_param), _direct_grad(ctx.beta_param)
+        if ga is None or ba is None:
+            ga = ba = None
         _lib.check(lib.mp_f16_bn_train_bwd(_lib.ptr(dy), _lib.ptr(z), _lib.ptr(y), _lib.ptr(g), _lib.ptr(mean), _lib.ptr(invstd),
-                                           _lib.ptr(dz), _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta), n, c, h * w,
-                                           int(ctx.relu), _lib.ptr(ws), ws_bytes, _lib.stream()), "mp_f16_bn_train_bwd")
+                                           _lib.ptr(dz), _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ga), _lib.ptr(ba),
+                                           n, c, h * w, int(ctx.relu), _lib.ptr(ws), ws_bytes, _lib.stream()), "mp_f16_bn_train_bwd")
+        if ga is not None:
+            return dz, None, None, dres, None, None, None
         return dz, dgamma, dbeta, dres, None, None, None
 
 

@@ -53,6 +53,10 @@ class GradientAverager:
         if self.overlap:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
+        for p in self.params:
+            # without overlap hooks nothing needs to observe the accumulation: backward kernels may add into the arena slot
+            # themselves (train_ops._direct_grad) instead of returning a tensor for autograd's AccumulateGrad to add
+            p._mp_grad_direct = not self.overlap
         self.begin_step()
 
     # -- per step ---------------------------------------------------------------------------------

@@ -84,16 +84,20 @@ def test_wgrad_f16_vs_torch(case):
     ws = torch.empty(nb // 4, device=DEV)
     dw = torch.full((cout, cin, k, k), float("nan"), device=DEV)
     xa, dza = _to_c8(x), _to_c8(dz)  # keep the device tensors alive: the ABI only sees raw pointers
-    _lib.check(LIB.mp_f16_conv_wgrad(ctypes.byref(d), _lib.ptr(xa), _lib.ptr(dza), _lib.ptr(dw), 0.5, _lib.ptr(ws), nb,
+    _lib.check(LIB.mp_f16_conv_wgrad(ctypes.byref(d), _lib.ptr(xa), _lib.ptr(dza), _lib.ptr(dw), 0.5, 0, _lib.ptr(ws), nb,
                                      _lib.stream()), "wgrad")
     got = dw.cpu()
     err = float((got - ref).abs().max() / ref.abs().max())
     assert err < 1e-4, err
     # deterministic: bit-identical on a second launch
     dw2 = torch.empty_like(dw)
-    _lib.check(LIB.mp_f16_conv_wgrad(ctypes.byref(d), _lib.ptr(xa), _lib.ptr(dza), _lib.ptr(dw2), 0.5, _lib.ptr(ws), nb,
+    _lib.check(LIB.mp_f16_conv_wgrad(ctypes.byref(d), _lib.ptr(xa), _lib.ptr(dza), _lib.ptr(dw2), 0.5, 0, _lib.ptr(ws), nb,
                                      _lib.stream()), "wgrad")
     assert torch.equal(dw, dw2)
+    # accumulate mode adds into the destination (gradient arena slot)
+    _lib.check(LIB.mp_f16_conv_wgrad(ctypes.byref(d), _lib.ptr(xa), _lib.ptr(dza), _lib.ptr(dw2), 0.5, 1, _lib.ptr(ws), nb,
+                                     _lib.stream()), "wgrad")
+    assert torch.equal(dw2, dw + dw)
 
 
 DGRAD_CASES = [(2, 32, 48, 3, 1, 32, 24), (3, 64, 64, 3, 1, 16, 12), (2, 64, 128, 3, 2, 32, 24), (2, 48, 96, 3, 2, 24, 16),
@@ -169,10 +173,12 @@ def test_bn_train_f16_fwd_bwd_vs_torch(c, h, w, relu, with_res):
     assert torch.allclose(dmm.cpu(), rmm, atol=1e-5) and torch.allclose(dmv.cpu(), rmv, atol=1e-5)
     dza, dra = ActC8(n, c, h, w, DEV), (ActC8(n, c, h, w, DEV) if with_res else None)
     dgm, dbt = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    acc_g, acc_b = torch.full((c,), 1.0, device=DEV), torch.full((c,), 2.0, device=DEV)
     dya = _to_c8(dy)
     _lib.check(LIB.mp_f16_bn_train_bwd(_lib.ptr(dya), _lib.ptr(za), _lib.ptr(ya), _lib.ptr(dgam), _lib.ptr(mean),
-                                       _lib.ptr(invstd), _lib.ptr(dza), _lib.ptr(dra), _lib.ptr(dgm), _lib.ptr(dbt), n, c, h * w,
-                                       int(relu), _lib.ptr(ws), nb, _lib.stream()), "bn bwd")
+                                       _lib.ptr(invstd), _lib.ptr(dza), _lib.ptr(dra), _lib.ptr(dgm), _lib.ptr(dbt), _lib.ptr(acc_g),
+                                       _lib.ptr(acc_b), n, c, h * w, int(relu), _lib.ptr(ws), nb, _lib.stream()), "bn bwd")
+    assert torch.equal(acc_g, dgm + 1.0) and torch.equal(acc_b, dbt + 2.0)  # also added into the caller's buffers
     # where the kernel's fp16 y and torch's fp32 y disagree about the ReLU mask (y within an ulp of 0) nothing is compared
     _close16(_from_c8(dza), _h(zt.grad), "dz")
     assert torch.allclose(dgm.cpu(), gt.grad, rtol=2e-3, atol=2e-3 * float(gt.grad.abs().max()))

@@ -70,3 +70,22 @@ def test_warmup_multistep_lr_schedule():
     assert sched(0) == 0.0 and abs(sched(250) - 5e-4) < 1e-12 and sched(500) == 1e-3
     assert sched(169 * 100 - 1) == 1e-3 and abs(sched(169 * 100) - 1e-4) < 1e-15
     assert abs(sched(199 * 100) - 1e-5) < 1e-15 and abs(sched(10 ** 6) - 1e-5) < 1e-15
+
+
+def test_dynamic_loss_scale_manager_semantics():
+    from mindpose_amd.utils import DynamicLossScaleManager
+    m = DynamicLossScaleManager(init_loss_scale=2.0 ** 10, scale_factor=2.0, scale_window=3)
+    assert m.get_loss_scale() == 1024.0 and m.scale(0.5) == 512.0
+    m.update_loss_scale(True)                       # overflow: halve, remember the iteration
+    assert m.loss_scale == 512.0 and m.skipped_steps == 1
+    for _ in range(2):
+        m.update_loss_scale(False)
+    assert m.loss_scale == 512.0                    # window not reached yet
+    m.update_loss_scale(False)                      # 3 clean steps since the overflow: double
+    assert m.loss_scale == 1024.0
+    for _ in range(40):                             # never below 1
+        m.update_loss_scale(True)
+    assert m.loss_scale == 1.0
+    import pytest
+    with pytest.raises(ValueError):
+        DynamicLossScaleManager(init_loss_scale=0.5)
