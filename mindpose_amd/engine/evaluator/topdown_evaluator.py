@@ -59,66 +59,66 @@ class TopDownEvaluator:
         return self.eval(inference_result)
 
     def eval(self, inference_result: List[Dict[str, Any]]) -> Dict[str, Any]:
-        kpts = defaultdict(list)
-        for record in inference_result:
-            image_id = self.name2id[os.path.basename(record["image_path"])]
-            kpts[image_id].append({"keypoints": record["pred"], "center": record["box"][0:2], "scale": record["box"][2:4],
-                                   "area": record["box"][4], "score": record["box"][5], "image_id": image_id,
-                                   "bbox_id": record["bbox_id"]})
-        kpts = self._sort_and_unique_bboxes(kpts)
-        vis_thr, oks_thr = self._evaluation_cfg["vis_thr"], self._evaluation_cfg["oks_thr"]
-        valid_kpts = []
-        for image_id in kpts.keys():
-            img_kpts = kpts[image_id]
-            for n_p in img_kpts:  # rescoring: box score x mean score of the key points above vis_thr (:101-113)
-                box_score = n_p["score"]
-                kpt_score, valid_num = 0, 0
-                for n_jt in range(0, self.num_joints):
-                    t_s = n_p["keypoints"][n_jt][2]
-                    if t_s > vis_thr:
-                        kpt_score = kpt_score + t_s
-                        valid_num = valid_num + 1
-                if valid_num != 0:
-                    kpt_score = kpt_score / valid_num
-                n_p["score"] = kpt_score * box_score
-            if self._evaluation_cfg["use_nms"]:
-                nms = soft_oks_nms if self._evaluation_cfg["soft_nms"] else oks_nms
-                keep = nms(img_kpts, oks_thr, sigmas=np.asarray(self._evaluation_cfg["sigmas"]))
-                valid_kpts.append([img_kpts[_keep] for _keep in keep])
-            else:
-                valid_kpts.append(img_kpts)
-        results = self._write_coco_keypoint_results(valid_kpts, self.result_path)
-        name_value = dict(self._do_python_keypoint_eval(results))
-        for name in self.metrics:
-            if name not in name_value:
-                raise ValueError(f"`{name}` is not in the returned result `{name_value.keys()}`")
+        """records -> per-image person lists -> rescoring -> (soft) OKS NMS -> result file -> the ten COCO statistics."""
+        people = self._group_by_image(inference_result)
+        survivors = [self._suppress(self._rescore(persons)) for persons in people.values()]
+        results = self._dump_results(survivors, self.result_path)
+        stats = dict(self._do_python_keypoint_eval(results))
+        missing = [m for m in self.metrics if m not in stats]
+        if missing:
+            raise ValueError(f"`{missing[0]}` is not in the returned result `{stats.keys()}`")
         if self.remove_result_file:
             os.remove(self.result_path)
-        return name_value
+        return stats
 
-    def _sort_and_unique_bboxes(self, kpts, key: str = "bbox_id"):
-        for img_id, persons in kpts.items():
-            num = len(persons)
-            kpts[img_id] = sorted(kpts[img_id], key=lambda x: x[key])
-            for i in range(num - 1, 0, -1):
-                if kpts[img_id][i][key] == kpts[img_id][i - 1][key]:
-                    del kpts[img_id][i]
-        return kpts
+    def _group_by_image(self, records) -> Dict[int, List[Dict[str, Any]]]:
+        """One list per image id, sorted by bbox_id with repeated boxes removed (:77-94, :134-148)."""
+        people: Dict[int, List[Dict[str, Any]]] = defaultdict(list)
+        for rec in records:
+            image_id = self.name2id[os.path.basename(rec["image_path"])]
+            box = rec["box"]
+            people[image_id].append(dict(keypoints=rec["pred"], center=box[0:2], scale=box[2:4], area=box[4], score=box[5],
+                                         image_id=image_id, bbox_id=rec["bbox_id"]))
+        for image_id, persons in people.items():
+            persons = sorted(persons, key=lambda person: person["bbox_id"])
+            people[image_id] = [q for k, q in enumerate(persons) if k == 0 or q["bbox_id"] != persons[k - 1]["bbox_id"]]
+        return people
 
-    def _write_coco_keypoint_results(self, keypoints, res_file: str) -> List[Dict[str, Any]]:
-        cls = self.classes[1]
-        cat_id = self._class_to_coco_ind[cls]
-        cat_results = []
-        for img_kpts in keypoints:
-            if not img_kpts:
+    def _rescore(self, persons: List[Dict[str, Any]]) -> List[Dict[str, Any]]:
+        """score = box score x mean confidence of the key points above ``vis_thr`` (:101-113); a python-float running sum in
+        joint order, as the reference accumulates it."""
+        vis_thr = self._evaluation_cfg["vis_thr"]
+        for person in persons:
+            total, count = 0, 0
+            for joint in range(self.num_joints):
+                conf = person["keypoints"][joint][2]
+                if conf > vis_thr:
+                    total, count = total + conf, count + 1
+            person["score"] = (total / count if count else total) * person["score"]
+        return persons
+
+    def _suppress(self, persons: List[Dict[str, Any]]) -> List[Dict[str, Any]]:
+        cfg = self._evaluation_cfg
+        if not cfg["use_nms"]:
+            return persons
+        pick = (soft_oks_nms if cfg["soft_nms"] else oks_nms)(persons, cfg["oks_thr"], sigmas=np.asarray(cfg["sigmas"]))
+        return [persons[k] for k in pick]
+
+    def _dump_results(self, keypoints, res_file: str) -> List[Dict[str, Any]]:
+        """COCO result entries of the (single) person category, written like evaluator.py:89-131 does."""
+        cat_id = self._class_to_coco_ind[self.classes[1]]
+        entries: List[Dict[str, Any]] = []
+        for persons in keypoints:
+            if not persons:
                 continue
-            key_points = np.array([k["keypoints"] for k in img_kpts]).reshape(-1, self.num_joints * 3)
-            cat_results.extend({"image_id": k["image_id"], "category_id": cat_id, "keypoints": kp.tolist(),
-                                "score": float(k["score"]), "center": np.asarray(k.get("center", -1)).tolist(),
-                                "scale": np.asarray(k.get("scale", -1)).tolist()} for k, kp in zip(img_kpts, key_points))
+            flat = np.array([person["keypoints"] for person in persons]).reshape(-1, self.num_joints * 3)
+            for person, row in zip(persons, flat):
+                entries.append({"image_id": person["image_id"], "category_id": cat_id, "keypoints": row.tolist(),
+                                "score": float(person["score"]), "center": np.asarray(person.get("center", -1)).tolist(),
+                                "scale": np.asarray(person.get("scale", -1)).tolist()})
         with open(res_file, "w") as f:
-            json.dump(cat_results, f, sort_keys=True, indent=4)
-        return cat_results
+            json.dump(entries, f, sort_keys=True, indent=4)
+        return entries
 
     def _do_python_keypoint_eval(self, results):
         cat_id = self._class_to_coco_ind[self.classes[1]]

@@ -39,36 +39,30 @@ class Net(PlannedModule):
 
 
 class EvalNet(nn.Module):
-    """net + decoder (networks.py:47-76): returns ``(result, raw)`` when ``output_raw``."""
+    """Inference wrapper with the reference's call contract (networks.py:47-76): ``eval_net(image, *decoder_inputs)`` runs the
+    network plan, hands the heat-maps plus the remaining inputs (box centre, scale, score) to the decoder and returns
+    ``(decoded, heat-maps)`` - or just ``decoded`` when ``output_raw`` is off.  Both children are put in eval mode."""
 
     def __init__(self, net: Net, decoder: Decoder, output_raw: bool = True) -> None:
         super().__init__()
-        self.net = net
-        self.decoder = decoder
-        self.output_raw = output_raw
-        self.net.eval()
-        self.decoder.eval()
+        self.net, self.decoder, self.output_raw = net.eval(), decoder.eval(), output_raw
 
     @torch.no_grad()
     def forward(self, *inputs: torch.Tensor) -> Tuple[torch.Tensor, ...]:
-        x = self.net(inputs[0])
-        result = self.decoder(x, *inputs[1:])
-        if self.output_raw:
-            return result, x
-        return result
+        image, *box_inputs = inputs
+        heatmap = self.net(image)
+        decoded = self.decoder(heatmap, *box_inputs)
+        return (decoded, heatmap) if self.output_raw else decoded
 
 
 class NetWithLoss(nn.Module):
-    """net + loss (networks.py:79-106)."""
+    """Training wrapper (networks.py:79-106): ``loss(net(data), label[, *extra_inputs])``; the extra inputs (e.g. the
+    per-joint target weights of JointsMSELoss) are forwarded only when ``has_extra_inputs`` says the loss takes them."""
 
     def __init__(self, net: Net, loss: Loss, has_extra_inputs: bool = False) -> None:
         super().__init__()
-        self.net = net
-        self.loss = loss
-        self.has_extra_inputs = has_extra_inputs
+        self.net, self.loss, self.has_extra_inputs = net, loss, has_extra_inputs
 
     def forward(self, data: torch.Tensor, label: torch.Tensor, *extra_inputs: torch.Tensor) -> torch.Tensor:
-        out = self.net(data)
-        if self.has_extra_inputs:
-            return self.loss(out, label, *extra_inputs)
-        return self.loss(out, label)
+        loss_inputs = (label, *extra_inputs) if self.has_extra_inputs else (label,)
+        return self.loss(self.net(data), *loss_inputs)

@@ -39,59 +39,59 @@ def oks_iou(g: np.ndarray, d: np.ndarray, a_g: float, a_d: np.ndarray, sigmas: O
     return ious
 
 
-def _gather(kpts_db: List[Dict[str, Any]]):
-    scores = np.array([k["score"] for k in kpts_db])
-    kpts = np.array([np.asarray(k["keypoints"]).flatten() for k in kpts_db])
-    areas = np.array([k["area"] for k in kpts_db])
-    return scores, kpts, areas
+def _columns(kpts_db: List[Dict[str, Any]]):
+    """Person list -> (scores [N], flattened key points [N, 3K], areas [N])."""
+    score = np.array([person["score"] for person in kpts_db])
+    flat = np.array([np.asarray(person["keypoints"]).flatten() for person in kpts_db])
+    area = np.array([person["area"] for person in kpts_db])
+    return score, flat, area
 
 
 def oks_nms(kpts_db: List[Dict[str, Any]], thr: float, sigmas: Optional[np.ndarray] = None,
             vis_thr: Optional[float] = None) -> np.ndarray:
-    """Greedy OKS NMS: keep the best-scored instance, drop the ones whose OKS with it exceeds ``thr`` (nms.py:71-108)."""
+    """Greedy OKS NMS (nms.py:71-108): walk the instances by descending score, keep the head of the queue and drop every
+    queued instance whose OKS with it exceeds ``thr``.  Returns the kept indices in that order."""
     if not kpts_db:
         return []
-    scores, kpts, areas = _gather(kpts_db)
-    order = scores.argsort()[::-1]
-    keep = []
-    while order.size > 0:
-        i = order[0]
-        keep.append(i)
-        rest = order[1:]
-        ovr = oks_iou(kpts[i], kpts[rest], areas[i], areas[rest], sigmas, vis_thr)
-        order = rest[np.where(ovr <= thr)[0]]
-    return np.array(keep)
+    score, flat, area = _columns(kpts_db)
+    queue = score.argsort()[::-1]
+    kept = []
+    while queue.size > 0:
+        head, queue = queue[0], queue[1:]
+        kept.append(head)
+        overlap = oks_iou(flat[head], flat[queue], area[head], area[queue], sigmas, vis_thr)
+        queue = queue[np.where(overlap <= thr)[0]]
+    return np.array(kept)
 
 
-def _rescore(overlap: np.ndarray, scores: np.ndarray, thr: float, key_type: str = "gaussian") -> np.ndarray:
+def _decay(overlap: np.ndarray, scores: np.ndarray, thr: float, key_type: str = "gaussian") -> np.ndarray:
+    """Soft-NMS score decay (nms.py:111-136): gaussian exp(-oks^2 / thr), or linear (1 - oks) above the threshold."""
     assert len(overlap) == len(scores)
     assert key_type in ["gaussian", "linear"]
-    if key_type == "linear":
-        inds = np.where(overlap >= thr)[0]
-        scores[inds] = scores[inds] * (1 - overlap[inds])
-    else:
-        scores = scores * np.exp(-(overlap ** 2) / thr)
+    if key_type == "gaussian":
+        return scores * np.exp(-(overlap ** 2) / thr)
+    hit = np.where(overlap >= thr)[0]
+    scores[hit] = scores[hit] * (1 - overlap[hit])
     return scores
 
 
 def soft_oks_nms(kpts_db: List[Dict[str, Any]], thr: float, max_dets: int = 20, sigmas: Optional[np.ndarray] = None,
                  vis_thr: Optional[float] = None) -> np.ndarray:
-    """Soft OKS NMS: Gaussian score decay instead of removal, at most ``max_dets`` kept (nms.py:139-190)."""
+    """Soft OKS NMS (nms.py:139-190): nothing is removed; after each pick the remaining scores decay with their OKS to the
+    pick and the queue is re-sorted; at most ``max_dets`` picks."""
     if not kpts_db:
         return []
-    scores, kpts, areas = _gather(kpts_db)
-    order = scores.argsort()[::-1]
-    scores = scores[order]
-    keep = np.zeros(max_dets, dtype=np.intp)
-    cnt = 0
-    while order.size > 0 and cnt < max_dets:
-        i = order[0]
-        rest = order[1:]
-        ovr = oks_iou(kpts[i], kpts[rest], areas[i], areas[rest], sigmas, vis_thr)
-        scores = _rescore(ovr, scores[1:], thr)
-        tmp = scores.argsort()[::-1]
-        order = rest[tmp]
-        scores = scores[tmp]
-        keep[cnt] = i
-        cnt += 1
-    return keep[:cnt]
+    score, flat, area = _columns(kpts_db)
+    queue = score.argsort()[::-1]
+    live = score[queue]
+    picked = np.zeros(max_dets, dtype=np.intp)
+    n = 0
+    while queue.size > 0 and n < max_dets:
+        head, queue = queue[0], queue[1:]
+        overlap = oks_iou(flat[head], flat[queue], area[head], area[queue], sigmas, vis_thr)
+        live = _decay(overlap, live[1:], thr)
+        resort = live.argsort()[::-1]
+        queue, live = queue[resort], live[resort]
+        picked[n] = head
+        n += 1
+    return picked[:n]
