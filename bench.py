@@ -92,10 +92,10 @@ def pmc_traffic(kernel):
             with open(path) as f:
                 k = json.load(f)["kernels"].get(kernel)
             if k:
-                return {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "source": os.path.relpath(path, ROOT)}
+                return k["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
         except (OSError, ValueError, KeyError):
             continue
-    return None
+    return None, None
 
 
 def roofline_report(plan, reps=5, layers_csv=""):
@@ -125,9 +125,13 @@ def roofline_report(plan, reps=5, layers_csv=""):
     fam_t = sum(v["time"] for v in groups.values())
     fam_f = sum(v["flops"] for v in groups.values())
     achieved = g["flops"] / g["time"] / 1e12
+    traffic, traffic_source = pmc_traffic(dom)
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-        "frac": round(achieved / peak, 4), "traffic": pmc_traffic(dom),
+        "frac": round(achieved / peak, 4),
+        # HBM bytes per launch of the dominant kernel (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes; the committed
+        # summary named in traffic_source - bench.py cannot collect PMC counters itself); null when no summary names the kernel
+        "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_source,
         "timing": "HIP events around each launch replayed alone on one stream (mp_plan_run_range); the timed region of "
                   "`value` overlaps the four HRNet branch lanes, which stretches individual kernels but shortens the step",
         "kernel": dom, "launches_per_step": g["launches"],
