@@ -199,7 +199,8 @@ def train_bench(args, mp, dev, dist, world, rank):
     overlapped with backward, AdamWeightDecay.  Extra measurement (the contract metric is inference)."""
     from mindpose_amd.utils import AdamWeightDecay, DynamicLossScaleManager
     n = args.batch
-    net = mp.init_synthetic(mp.create_network("hrnet_w32", "hrnet_head"), seed=0).to(dev).train()
+    bb, hd = ("resnet50", "simple_baseline_head") if args.workload == "simplebaseline_r50_train" else ("hrnet_w32", "hrnet_head")
+    net = mp.init_synthetic(mp.create_network(bb, hd), seed=0).to(dev).train()
     scaler = None
     if args.amp != "O0":  # the reference's recipe: amp O2 + DynamicLossScaleManager (tools/train.py:170-181)
         mp.models.auto_mixed_precision(net, args.amp)
@@ -265,14 +266,14 @@ def train_bench(args, mp, dev, dist, world, rank):
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({
-            "metric": "images/sec, HRNet-W32 256x192 training step (targets+fwd+loss+bwd+grad mean+AdamWeightDecay)",
+            "metric": f"images/sec, {args.workload} 256x192 training step (targets+fwd+loss+bwd+grad mean+AdamWeightDecay)",
             "value": round(world * n * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32" if scaler is None else "f16", "data": "synthetic",
             "config": {"workload": ("configs[3] in fp32" if scaler is None else "configs[3] as the reference trains it (amp O2: fp16 "
                                     "matrix-core convs / activations, fp32 statistics + master weights, dynamic loss scale)") +
-                                   ": HRNet-W32 256x192 training, DP, Gaussian targets + JointsMSE + bucketed RCCL gradient mean "
-                                   "(114 MB/step) + AdamWeightDecay",
+                                   f": {bb} + {hd} 256x192 training, DP, Gaussian targets + JointsMSE + bucketed RCCL gradient "
+                                   "mean + AdamWeightDecay",
                        "per_gpu_batch": n, "global_batch": n * world, "final_loss": float(loss.detach()),
                        "step": "one hipGraph replay (forward+loss+backward) + optimizer" if graphed else "eager autograd",
                        "loss_scale": None if scaler is None else scaler.loss_scale,
@@ -286,7 +287,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="crops per GPU per step (reference per-device batch_size)")
-    ap.add_argument("--workload", default="hrnet_w32", choices=list(WORKLOADS) + ["hrnet_w32_train"],
+    ap.add_argument("--workload", default="hrnet_w32", choices=list(WORKLOADS) + ["hrnet_w32_train", "simplebaseline_r50_train"],
                     help="hrnet_w32 = BASELINE.json metric / configs[2] (default); the others are extra measurements")
     ap.add_argument("--layers", default="", help="write a per-launch timing table (CSV) to this path")
     ap.add_argument("--amp", default="O0", choices=["O0", "O2"],
@@ -320,7 +321,7 @@ def main():
     import mindpose_amd as mp
 
     torch.manual_seed(0)
-    if args.workload == "hrnet_w32_train":
+    if args.workload in ("hrnet_w32_train", "simplebaseline_r50_train"):
         return train_bench(args, mp, dev, dist, world, rank)
     backbone, head, (ih, iw), dec_kw, flip, workload_desc = WORKLOADS[args.workload]
     net = mp.init_synthetic(mp.create_network(backbone, head), seed=0).to(dev).eval()

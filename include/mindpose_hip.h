@@ -250,7 +250,8 @@ size_t mp_f16_packed_weight_bytes(int cout, int cin, int kh, int kw);
 size_t mp_f16_activation_bytes(int n, int c, int h, int w);
 /* transposed = 0: Conv2d weight [Cout,Cin,kh,kw]; 1: the (phase_y, phase_x) 2x2 sub-pixel phase of a
  * Conv2dTranspose(k=4, s=2, pad=1) weight [Cin,Cout,4,4] (kh = kw = 2); 2 / 3: the data-gradient packings of
- * mp_conv_pack_weight (stride-1 conv: roles swapped + taps mirrored; 3x3 stride-2 conv: 2x2 parity phases) */
+ * mp_conv_pack_weight (stride-1 conv: roles swapped + taps mirrored; 3x3 stride-2 conv: 2x2 parity phases); 4: the data
+ * gradient of transposed-conv phase (phase_y, phase_x) (w = the [Cin_t,Cout_t,4,4] weight, cout := Cin_t, cin := Cout_t) */
 int mp_f16_pack_weight(const float* w_dev, void* packed_dev, int cout, int cin, int kh, int kw, int transposed, int phase_y,
                        int phase_x, mp_stream_t stream);
 int mp_f16_to_c8(const float* x_nchw_dev, void* out_c8_dev, int n, int c, int h, int w, mp_stream_t stream);
@@ -305,6 +306,21 @@ int mp_f16_fuse_upsample_sum_bwd(const void* dy_dev, const void* out_dev, void* 
 size_t mp_f16_conv_wgrad_workspace_bytes(const mp_conv_desc* desc);
 int mp_f16_conv_wgrad(const mp_conv_desc* desc, const void* x_c8_dev, const void* dz_c8_dev, float* dw_dev, float scale,
                       int accumulate, void* workspace_dev, size_t workspace_bytes, mp_stream_t stream);
+
+/* ---- training kernels of the SimpleBaseline-ResNet family ---------------------------------------------------------------
+ * mp_maxpool3x3s2_same_bwd: backward of nn.MaxPool2d(3, 2, pad_mode="same") (resnet.py:190), gradient to the first maximum of
+ *   each window in scan order; fp32 NCHW.
+ * mp_stem_conv_wgrad: weight gradient of the k x k (k = 7 or 3) stride-2 padding-k/2 stem conv with <= 4 input channels
+ *   (resnet.py:180-188), fp32 NCHW x [n,cin,h,w], dz [n,cout,ho,wo] -> dw [cout,cin,k,k].
+ * mp_f16_gather_phase: out[n,c,m,k] = x[n,c,2m+phase_y,2k+phase_x] on channel-blocked fp16 (x is [n,c,2h,2w]): the sub-pixel
+ *   phase of a gradient that the 2x2 phase kernels of the transposed convolution (mp_f16_pack_weight mode 4) consume.
+ * The transposed convolution's weight gradient is mp_f16_conv_wgrad on a 4x4 stride-2 padding-1 descriptor with the roles
+ *   (x := dy at the up-sampled resolution, dz := the layer input): dW[cin_t][cout_t][ky][kx] = sum x_t[m] * dy[2m+ky-1]. */
+int mp_maxpool3x3s2_same_bwd(const float* x_dev, const float* dy_dev, float* dx_dev, int n, int c, int h, int w, mp_stream_t stream);
+int mp_stem_conv_wgrad(const float* x_dev, const float* dz_dev, float* dw_dev, int n, int cin, int h, int w, int cout, int k,
+                       mp_stream_t stream);
+int mp_f16_gather_phase(const void* x_c8_dev, void* out_c8_dev, int n, int c, int h, int w, int phase_y, int phase_x,
+                        mp_stream_t stream);
 
 /* Diagnostics: only a library built with -DMP_CONV_STAMPS=1 (never the product build) records per-workgroup
  * phase cycle counters (8 x uint64 per workgroup) of each conv launch into this device buffer; the product

@@ -208,9 +208,11 @@ constexpr int kNZ = 4, kNX = 10;
 int geometry(const mp_conv_desc* d, Wgrad16Params& p, size_t& lds_bytes) {
     if (!d) return MP_ERR_NULL;
     if (d->n <= 0 || d->cin <= 0 || d->cout <= 0 || d->h <= 0 || d->w <= 0 || d->conv_h <= 0 || d->conv_w <= 0) return MP_ERR_SHAPE;
-    if (d->kh != d->kw || !(d->kh == 1 || d->kh == 3)) return MP_ERR_UNSUPPORTED;
+    // 1x1 / 3x3 with padding k/2, or the 4x4 stride-2 padding-1 form (the transposed convolution's weight gradient)
+    if (d->kh != d->kw || !(d->kh == 1 || d->kh == 3 || d->kh == 4)) return MP_ERR_UNSUPPORTED;
     if (!(d->stride == 1 || d->stride == 2)) return MP_ERR_UNSUPPORTED;
-    if (d->pad_top != d->pad_left || d->pad_top != d->kh / 2) return MP_ERR_UNSUPPORTED;
+    if (d->pad_top != d->pad_left) return MP_ERR_UNSUPPORTED;
+    if (d->kh == 4 ? (d->stride != 2 || d->pad_top != 1) : (d->pad_top != d->kh / 2)) return MP_ERR_UNSUPPORTED;
     const int S = d->stride, KS = d->kh;
     p.N = d->n; p.Cin = d->cin; p.C8in = (d->cin + 7) / 8; p.H = d->h; p.W = d->w;
     p.Cout = d->cout; p.C8out = (d->cout + 7) / 8; p.Ho = d->conv_h; p.Wo = d->conv_w; p.pad = d->pad_top;
@@ -287,7 +289,8 @@ int mp_f16_conv_wgrad(const mp_conv_desc* desc, const void* x, const void* dz, f
     if (!workspace || workspace_bytes < (size_t)p.splits * count * sizeof(float)) return MP_ERR_WORKSPACE;
     p.x = x; p.dz = dz; p.slabs = reinterpret_cast<float*>(workspace);
     hipStream_t s = as_stream(stream);
-    if (desc->kh == 3) rc = desc->stride == 1 ? launch_wgrad16<3, 1>(p, lds, s) : launch_wgrad16<3, 2>(p, lds, s);
+    if (desc->kh == 4) rc = launch_wgrad16<4, 2>(p, lds, s);
+    else if (desc->kh == 3) rc = desc->stride == 1 ? launch_wgrad16<3, 1>(p, lds, s) : launch_wgrad16<3, 2>(p, lds, s);
     else rc = desc->stride == 1 ? launch_wgrad16<1, 1>(p, lds, s) : launch_wgrad16<1, 2>(p, lds, s);
     if (rc != MP_OK) return rc;
     size_t blocks = (count + 255) / 256;

@@ -342,6 +342,8 @@ class HRNet(Backbone):
 
     def train_forward(self, x: torch.Tensor) -> torch.Tensor:
         """Training form of ``forward_feature`` hrnet.py:559-605 (batch-statistics BatchNorm, autograd)."""
+        if self.amp_level in ("O2", "O3") and not T._is_c8(x):
+            x = T.to_c8(x)
         x = T.conv_bn_act(x, self.conv1, self.bn1, relu=True)
         x = T.conv_bn_act(x, self.conv2, self.bn2, relu=True)
         for blk in self.layer1:

@@ -56,6 +56,18 @@ class ResNet(Backbone):
                 x = blk.emit(plan, x)
         return x
 
+    def train_forward(self, x: torch.Tensor) -> torch.Tensor:
+        """Training form of ``forward_feature`` resnet.py:247-264: fp32 stem + max-pool, then the bottleneck stages in the
+        network's precision (channel-blocked fp16 under amp O2)."""
+        from .. import train_ops as T
+        x = T.maxpool3x3s2_same(T.stem_conv_bn_relu(x, self.conv1, self.bn1))
+        if self.amp_level in ("O2", "O3"):
+            x = T.to_c8(x)
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in layer:
+                x = blk.train_forward(x)
+        return x
+
     @property
     def out_channels(self) -> int:
         return 512 * Bottleneck.expansion

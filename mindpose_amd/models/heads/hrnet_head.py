@@ -16,6 +16,10 @@ class HRNetHead(Head):
             raise ValueError("final_conv_kernel_size must be 1 or 3")
         self.head = Conv2d(in_channels, num_joints, k, padding=k // 2, has_bias=True)
 
+    @property
+    def out_joints(self):
+        return self.head.out_channels
+
     def emit(self, plan: Plan, x):
         return plan.conv(x, self.head)
 

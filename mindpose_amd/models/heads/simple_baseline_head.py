@@ -37,6 +37,17 @@ class SimpleBaselineHead(Head):
         self.final_layer = Conv2d(width, num_joints, final_conv_kernel_size, padding=final_conv_kernel_size // 2,
                                   has_bias=True)
 
+    @property
+    def out_joints(self) -> int:
+        return self.final_layer.out_channels
+
+    def train_forward(self, x: torch.Tensor) -> torch.Tensor:
+        from .. import train_ops as T
+        cells = list(self.deconv_layer)
+        for deconv, bn in zip(cells[0::3], cells[1::3]):
+            x = T.deconv_bn_relu(x, deconv, bn)
+        return T.conv_bn_act(x, self.final_layer, None, relu=False)
+
     def emit(self, plan: Plan, x: torch.Tensor) -> torch.Tensor:
         cells = list(self.deconv_layer)
         for deconv, bn in zip(cells[0::3], cells[1::3]):

@@ -154,7 +154,7 @@ def tune_conv_variant(lib, d, x, packed, scale, shift, res1, res2, out, half: bo
     alias = res1 is not None and res1.data_ptr() == out.data_ptr()
     trial_out = out
     if alias:
-        trial_out = ActC8(*out.shape, out.device) if half else torch.empty_like(out)
+        trial_out = torch.empty_like(out) if torch.is_tensor(out) else ActC8(*out.shape, out.device)
     fn = lib.mp_f16_conv2d_fwd if half else lib.mp_conv2d_fwd_variant
 
     def launch(v):

@@ -31,11 +31,11 @@ class Net(PlannedModule):
     def train_forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.has_neck:
             raise NotImplementedError("no concrete neck exists in the reference")
-        if self.amp_level in ("O2", "O3"):  # fp16 matrix-core training graph; fp32 images in, fp32 heat-maps out
-            from . import train_ops as T
-            y = self.head.train_forward(self.backbone.train_forward(T.to_c8(x)))
-            return T.from_c8(y, self.head.head.out_channels)
-        return self.head.train_forward(self.backbone.train_forward(x))
+        # under amp O2 the backbone switches to channel-blocked fp16 itself (HRNet at the image, ResNet after its fp32 stem);
+        # fp32 images in, fp32 heat-maps out either way
+        from . import train_ops as T
+        y = self.head.train_forward(self.backbone.train_forward(x))
+        return T.from_c8(y, self.head.out_joints) if T._is_c8(y) else y
 
 
 class EvalNet(nn.Module):

@@ -239,7 +239,8 @@ def _conv16_launch(lib, d, x, packed, scale, shift, out, what):
 
 
 class ToC8Fn(torch.autograd.Function):
-    """fp32 NCHW -> channel-blocked fp16 (network input: no gradient flows back)."""
+    """fp32 NCHW -> channel-blocked fp16 (the network input, or the output of ResNet's fp32 stem: then the gradient flows back
+    as fp32 NCHW)."""
 
     @staticmethod
     def forward(ctx, x):
@@ -248,11 +249,19 @@ class ToC8Fn(torch.autograd.Function):
         n, c, h, w = x.shape
         out = _c8_alloc(n, c, h, w, x.device)
         _lib.check(lib.mp_f16_to_c8(_lib.ptr(x), _lib.ptr(out), n, c, h, w, _lib.stream()), "mp_f16_to_c8")
+        ctx.c = c
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        return None
+        if not ctx.needs_input_grad[0]:
+            return None
+        lib = _lib.load()
+        dy = dy.contiguous()
+        n, _, h, w, _ = dy.shape
+        dx = torch.empty(n, ctx.c, h, w, device=dy.device, dtype=torch.float32)
+        _lib.check(lib.mp_f16_from_c8(_lib.ptr(dy), _lib.ptr(dx), n, ctx.c, h, w, _lib.stream()), "mp_f16_from_c8")
+        return dx
 
 
 class FromC8Fn(torch.autograd.Function):
@@ -320,12 +329,17 @@ class Conv16Fn(torch.autograd.Function):
                 d = _desc(n, cout, ho, wo, cin, k, 1, k - 1 - pad, k - 1 - pad, h, wd, h, wd)
                 _conv16_launch(lib, d, dz, _pack16(lib, w, cin, cout, k, 2), ones, zeros, dx, "conv dgrad")
             else:
-                if h != 2 * ho or wd != 2 * wo or k != 3:
-                    raise NotImplementedError("stride-2 data gradient: 3x3 kernels on even input extents")
-                for py in (0, 1):
-                    for px in (0, 1):
-                        d = _desc(n, cout, ho, wo, cin, 2, 1, 0, 0, ho, wo, h, wd, out_mul=2, off_y=py, off_x=px)
-                        _conv16_launch(lib, d, dz, _pack16(lib, w, cin, cout, 2, 3, py, px), ones, zeros, dx, "conv dgrad phase")
+                if h != 2 * ho or wd != 2 * wo:
+                    raise NotImplementedError("stride-2 data gradient needs even input extents")
+                if k == 3:
+                    for py in (0, 1):
+                        for px in (0, 1):
+                            d = _desc(n, cout, ho, wo, cin, 2, 1, 0, 0, ho, wo, h, wd, out_mul=2, off_y=py, off_x=px)
+                            _conv16_launch(lib, d, dz, _pack16(lib, w, cin, cout, 2, 3, py, px), ones, zeros, dx, "conv dgrad phase")
+                else:  # 1x1 stride 2 (ResNet down-sample): only the even positions receive gradient
+                    dx.zero_()
+                    d = _desc(n, cout, ho, wo, cin, 1, 1, 0, 0, ho, wo, h, wd, out_mul=2)
+                    _conv16_launch(lib, d, dz, _pack16(lib, w, cin, cout, 1, 2), ones, zeros, dx, "conv dgrad 1x1s2")
         if ctx.needs_input_grad[1]:
             direct = _direct_grad(ctx.weight_param)  # add straight into the gradient arena: no AccumulateGrad launch
             dw = direct if direct is not None else torch.empty_like(w)
@@ -419,6 +433,149 @@ class FuseSum16Fn(torch.autograd.Function):
         _lib.check(lib.mp_f16_fuse_upsample_sum_bwd(_lib.ptr(dy), _lib.ptr(out), _lib.ptr(dbase), *args, n, c8 * 8, h, w, 1,
                                                     _lib.stream()), "mp_f16_fuse_upsample_sum_bwd")
         return (dbase, None, *dts)
+
+
+class StemConvFn(torch.autograd.Function):
+    """ResNet stem: 7x7 stride-2 conv of the (3-channel, fp32 NCHW) image - forward on the fp32 MFMA kernel, weight gradient by
+    the direct-reduction kernel (3 input channels leave the matrix cores nothing to do); the image gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, padding):
+        lib = _lib.load()
+        x = _lib.require_cuda_f32(x, "x")
+        w = weight.detach().contiguous()
+        n, cin, h, wd = x.shape
+        cout, _, k, _ = w.shape
+        if stride != 2 or padding != k // 2 or cin > 4:
+            raise NotImplementedError("stem conv: stride 2, padding k//2, <= 4 input channels")
+        ho, wo = (h + 2 * padding - k) // 2 + 1, (wd + 2 * padding - k) // 2 + 1
+        ones, zeros = _ones_zeros(cout, x.device)
+        z = torch.empty(n, cout, ho, wo, device=x.device, dtype=torch.float32)
+        d = _desc(n, cin, h, wd, cout, k, 2, padding, padding, ho, wo, ho, wo)
+        _conv_launch(lib, d, x, _pack(lib, w, cout, cin, k, 0), ones, zeros, z, "stem conv")
+        ctx.save_for_backward(x, w)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        dz = dz.contiguous()
+        n, cin, h, wd = x.shape
+        cout, _, k, _ = w.shape
+        dw = torch.empty_like(w)
+        _lib.check(lib.mp_stem_conv_wgrad(_lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), n, cin, h, wd, cout, k, _lib.stream()),
+                   "mp_stem_conv_wgrad")
+        return None, dw, None, None
+
+
+class MaxPoolFn(torch.autograd.Function):
+    """nn.MaxPool2d(3, 2, pad_mode="same") on fp32 NCHW (resnet.py:190)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _lib.require_cuda_f32(x, "x")
+        n, c, h, w = x.shape
+        out = torch.empty(n, c, (h + 1) // 2, (w + 1) // 2, device=x.device, dtype=torch.float32)
+        _lib.check(lib.mp_maxpool3x3s2_same(_lib.ptr(x), _lib.ptr(out), n, c, h, w, _lib.stream()), "mp_maxpool3x3s2_same")
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, c, h, w = x.shape
+        dx = torch.empty_like(x)
+        _lib.check(lib.mp_maxpool3x3s2_same_bwd(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dx), n, c, h, w, _lib.stream()),
+                   "mp_maxpool3x3s2_same_bwd")
+        return dx
+
+
+class Deconv16Fn(torch.autograd.Function):
+    """Conv2dTranspose(k=4, s=2, p=1) on channel-blocked fp16 (simple_baseline_head.py:80-88), weight [Cin, Cout, 4, 4].
+    Forward: four 2x2 sub-pixel phase convs.  Data gradient: per phase, the strided gather of dy followed by the 2x2 conv with
+    roles swapped (running sum through the epilogue).  Weight gradient: the 4x4 stride-2 weight-gradient GEMM with the roles of
+    input and output gradient exchanged."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        lib = _lib.load()
+        w = weight.detach().contiguous()
+        n, _, h, wd, _ = x.shape
+        cin, cout = w.shape[0], w.shape[1]
+        ones, zeros = _ones_zeros16(cout, x.device)
+        y = _c8_alloc(n, cout, 2 * h, 2 * wd, x.device)
+        for py in (0, 1):
+            for px in (0, 1):
+                d = _desc(n, cin, h, wd, cout, 2, 1, 1 - py, 1 - px, h, wd, 2 * h, 2 * wd, out_mul=2, off_y=py, off_x=px)
+                _conv16_launch(lib, d, x, _pack16(lib, w, cout, cin, 2, 1, py, px), ones, zeros, y, "deconv phase")
+        ctx.save_for_backward(x, w)
+        ctx.weight_param = weight
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, _, h, wd, _ = x.shape
+        cin, cout = w.shape[0], w.shape[1]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            ones, zeros = _ones_zeros16(cin, x.device)
+            dx = _c8_alloc(n, cin, h, wd, x.device)
+            phase = _c8_alloc(n, cout, h, wd, x.device)
+            first = True
+            for py in (0, 1):
+                for px in (0, 1):
+                    _lib.check(lib.mp_f16_gather_phase(_lib.ptr(dy), _lib.ptr(phase), n, cout, h, wd, py, px, _lib.stream()),
+                               "mp_f16_gather_phase")
+                    # y_phase[m] = sum_t x[m - (1-p) + t] wp[t]  =>  dx[j] = sum_t dy_phase[j + (1-p) - t] wp[t]:
+                    # a 2x2 conv over dy_phase with mirrored taps and padding p
+                    d = _desc(n, cout, h, wd, cin, 2, 1, py, px, h, wd, h, wd)
+                    packed = _pack16(lib, w, cin, cout, 2, 4, py, px)
+                    v = tune_conv_variant(lib, d, phase, packed, ones, zeros, None if first else dx, None, dx, half=True)
+                    _lib.check(lib.mp_f16_conv2d_fwd(ctypes.byref(d), v, _lib.ptr(phase), _lib.ptr(packed), _lib.ptr(ones),
+                                                     _lib.ptr(zeros), None if first else _lib.ptr(dx), None, _lib.ptr(dx),
+                                                     _lib.stream()), "deconv dgrad phase")
+                    first = False
+        if ctx.needs_input_grad[1]:
+            # dW[ci][co][ky][kx] = sum_m x[m][ci] * dy[2m + ky - 1][co]: weight gradient of a 4x4 s2 p1 conv whose input is dy
+            # and whose output gradient is x -> result laid out [ci][co][4][4] = the transposed conv's own weight layout
+            direct = _direct_grad(ctx.weight_param)
+            dw = direct if direct is not None else torch.empty_like(w)
+            d = _desc(n, cout, 2 * h, 2 * wd, cin, 4, 2, 1, 1, h, wd, h, wd)
+            ws_bytes = lib.mp_f16_conv_wgrad_workspace_bytes(ctypes.byref(d))
+            if ws_bytes == 0:
+                raise _lib.MindposeHipError("transposed-conv weight gradient: unsupported shape")
+            ws = torch.empty(ws_bytes // 4, device=x.device, dtype=torch.float32)
+            _lib.check(lib.mp_f16_conv_wgrad(ctypes.byref(d), _lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), 1.0, int(direct is not None),
+                                             _lib.ptr(ws), ws_bytes, _lib.stream()), "deconv wgrad")
+            if direct is not None:
+                dw = None
+        return dx, dw
+
+
+def stem_conv_bn_relu(x, conv, bn):
+    """ResNet stem group conv7x7 s2 + BatchNorm(train) + ReLU on the fp32 image."""
+    z = StemConvFn.apply(x, conv.weight, conv.stride, conv.padding)
+    return BatchNormActFn.apply(z, bn.gamma, bn.beta, None, bn.moving_mean, bn.moving_variance, True)
+
+
+def maxpool3x3s2_same(x):
+    return MaxPoolFn.apply(x)
+
+
+def deconv_bn_relu(x, deconv, bn):
+    """Conv2dTranspose(4, 2, 1) + BatchNorm(train) + ReLU of the SimpleBaseline head (amp O2 only)."""
+    if not _is_c8(x):
+        raise NotImplementedError("the SimpleBaseline head trains under amp O2 (auto_mixed_precision(net, 'O2')): the "
+                                  "transposed-convolution gradients exist for the fp16 matrix-core kernels only")
+    y = Deconv16Fn.apply(x, deconv.weight)
+    return BatchNormAct16Fn.apply(y, bn.gamma, bn.beta, None, bn.moving_mean, bn.moving_variance, True)
 
 
 def to_c8(x: torch.Tensor) -> torch.Tensor:

@@ -187,10 +187,10 @@ def maxpool3x3s2_same(x):
     return F.max_pool2d(x, 3, 2)
 
 
-def resnet_forward(params, x, name="resnet50", prefix="", amp=False):
+def resnet_forward(params, x, name="resnet50", prefix="", amp=False, train=False):
     """ResNet.forward_feature resnet.py:247-264."""
-    p = _P(params, prefix, False, amp)
-    x = _r(p, torch.as_tensor(x, dtype=torch.float32))
+    p = _P(params, prefix, train, amp)
+    x = torch.as_tensor(x) if train else _r(p, torch.as_tensor(x, dtype=torch.float32))
     x = F.relu(_bn(p.sub("bn1"), _conv(p.sub("conv1"), x, 2, 3)))
     x = maxpool3x3s2_same(x)
     for li, nblocks in enumerate(RESNET_LAYERS[name], start=1):
@@ -205,10 +205,10 @@ def hrnet_head_forward(params, x, prefix="", train=False, amp=False):
     return _conv(_P(params, prefix, train, amp).sub("head"), x)
 
 
-def simple_baseline_head_forward(params, x, prefix="", num_deconv_layers=3, amp=False):
+def simple_baseline_head_forward(params, x, prefix="", num_deconv_layers=3, amp=False, train=False):
     """SimpleBaselineHead.construct simple_baseline_head.py:95-98.
     deconv_layer = SequentialCell(deconv, bn, relu, deconv, bn, relu, ...) -> indices 3i, 3i+1."""
-    p = _P(params, prefix, False, amp)
+    p = _P(params, prefix, train, amp)
     for i in range(num_deconv_layers):
         w = p[f"deconv_layer.{3 * i}.weight"]
         x = _r(p, F.conv_transpose2d(x, _r(p, w), None, stride=2, padding=1))
@@ -217,10 +217,13 @@ def simple_baseline_head_forward(params, x, prefix="", num_deconv_layers=3, amp=
 
 
 def net_forward_train(params, x, backbone="hrnet_w32", head="hrnet_head"):
-    """Net.construct in training mode (HRNet + HRNetHead): batch-statistics BatchNorm, autograd graph kept.
+    """Net.construct in training mode: batch-statistics BatchNorm, autograd graph kept.
     ``params`` must hold torch tensors (leaf tensors with requires_grad for the trainable ones)."""
-    f = hrnet_forward(params, x, backbone, prefix="backbone.", train=True)
-    return hrnet_head_forward(params, f, prefix="head.", train=True)
+    if backbone.startswith("hrnet"):
+        f = hrnet_forward(params, x, backbone, prefix="backbone.", train=True)
+        return hrnet_head_forward(params, f, prefix="head.", train=True)
+    f = resnet_forward(params, x, backbone, prefix="backbone.", train=True)
+    return simple_baseline_head_forward(params, f, prefix="head.", train=True)
 
 
 def net_forward(params, x, backbone="hrnet_w32", head="hrnet_head", amp=False):
