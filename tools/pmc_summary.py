@@ -51,14 +51,25 @@ def collect(d, counter):
 
 def main():
     tag, d_fetch, d_write = sys.argv[1:4]
+    d_mfma = sys.argv[4] if len(sys.argv) > 4 else None
     fetch, nf = collect(d_fetch, "FETCH_SIZE")
     write, _ = collect(d_write, "WRITE_SIZE")
+    mfma, gui = {}, {}
+    if d_mfma:
+        # SQ_VALU_MFMA_BUSY_CYCLES: MFMA-pipe busy cycles summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE: active cycles
+        # summed over the 8 XCDs (MI355X_MICROARCH.md).  busy fraction = busy / (1024 * active / 8)
+        mfma, _ = collect(d_mfma, "SQ_VALU_MFMA_BUSY_CYCLES")
+        gui, _ = collect(d_mfma, "GRBM_GUI_ACTIVE")
     kernels = {}
     for k in sorted(set(fetch) | set(write)):
         fb = fetch.get(k, 0.0) * 1024 * 2
         wb = write.get(k, 0.0) * 1024
         kernels[k] = {"fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
                       "hbm_bytes_per_launch": round(fb + wb), "dispatches": nf.get(k, 0)}
+        if k in mfma and gui.get(k):
+            kernels[k]["mfma_busy_cycles_per_launch"] = round(mfma[k])
+            kernels[k]["gui_active_cycles_per_launch_per_xcd"] = round(gui[k] / 8)
+            kernels[k]["mfma_busy_fraction_of_active_cycles"] = round(mfma[k] / (1024 * gui[k] / 8), 4)
     out = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over bench.py (autotuner choices replayed "
                     "from MINDPOSE_TUNE_CACHE, so no trial launches are mixed in). KiB per dispatch; FETCH_SIZE doubled per "
                     "MI355X_MICROARCH.md, WRITE_SIZE as reported. Average HBM-side bytes per launch of each instantiation.",

@@ -30,8 +30,9 @@ export MINDPOSE_PLAN_LANES=0
 # 3. HBM traffic counters, one pass each
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmc_fetch -o ${tag} -- python3 $root/bench.py "$@" --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2> $out/${tag}_pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/${tag}_pmc_write -o ${tag} -- python3 $root/bench.py "$@" --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2> $out/${tag}_pmc_write.err
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/${tag}_pmc_mfma -o ${tag} -- python3 $root/bench.py "$@" --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2> $out/${tag}_pmc_mfma.err || true
 cd $root
-python3 tools/pmc_summary.py ${tag} $out/${tag}_pmc_fetch $out/${tag}_pmc_write
+python3 tools/pmc_summary.py ${tag} $out/${tag}_pmc_fetch $out/${tag}_pmc_write $out/${tag}_pmc_mfma
 cp profiles/${tag}_pmc_traffic.json $out/
 # keep the merge-back small
-rm -rf $out/${tag}_prof $out/${tag}_prof_lanes $out/${tag}_pmc_fetch $out/${tag}_pmc_write
+rm -rf $out/${tag}_prof $out/${tag}_prof_lanes $out/${tag}_pmc_fetch $out/${tag}_pmc_write $out/${tag}_pmc_mfma
