@@ -59,6 +59,9 @@ def kernel_name(info):
     the trailing template argument OCC = 3)."""
     if info["kind_id"] == 3:
         v = info["variant"]
+        if v >= 20:  # 16-cout tiles: regular, light, multi-tile (2 / 1 workgroups per CU)
+            head = f"<{info['ks']},{info['stride']},3,1,4,1>"
+            return (f"conv_f16_kernel{head}" + ("/occ3" if v == 21 else "")) if v < 22 else f"conv_f16_mt_kernel{head}/occ{24 - v}"
         if v >= 10:
             return f"conv_f16_mt_kernel<{info['ks']},{info['stride']},{F16_VARIANT_TEMPLATE[v % 5]}>/occ{1 if v >= 15 else 2}"
         return f"conv_f16_kernel<{info['ks']},{info['stride']},{F16_VARIANT_TEMPLATE[v]}>" + ("/occ3" if info.get("light") else "")

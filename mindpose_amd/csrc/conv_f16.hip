@@ -297,6 +297,8 @@ int launch_f16_ks(const ConvF16Params& p, int variant, size_t lds_bytes, hipStre
         case F_CT48_PT192_L: return launch_f16_variant<KS, S, 3, 3, 4, 1, true>(p, lds_bytes, s);
         case F_CT64_PT96_L: return launch_f16_variant<KS, S, 3, 2, 2, 2, true>(p, lds_bytes, s);
         case F_CT32_PT96_L: return launch_f16_variant<KS, S, 3, 1, 2, 2, true>(p, lds_bytes, s);
+        case F_CT16_PT192: return launch_f16_variant<KS, S, 3, 1, 4, 1, false>(p, lds_bytes, s);
+        case F_CT16_PT192_L: return launch_f16_variant<KS, S, 3, 1, 4, 1, true>(p, lds_bytes, s);
         default: return MP_ERR_UNSUPPORTED;
     }
 }
@@ -321,14 +323,18 @@ bool f16_configure_mt(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
     if ((long long)d.n * p.C8in * d.h * d.w * 16 >= 0x7FFFFFF0LL || (long long)d.n * p.C8out * d.out_h * d.out_w * 16 >= 0x7FFFFFF0LL) return false;
     p.PK = round_up(d.cin, 32) / 8;
     p.PKs = p.C8in < p.PK ? p.C8in : p.PK;
-    p.n_chunks = 1; p.nbuf = 2;
+    p.n_chunks = 1;
     if (p.Wo > PT) return false;
     const int ni = f16_mt_ni(occ);
     const long long budget = occ == 2 ? kLdsBudget : kLdsMax;
     int rows_fit = PT / p.Wo;
     if (rows_fit > p.Ho) rows_fit = p.Ho;
     bool found = false;
+    // double-buffered input tiles first; the one-workgroup-per-CU build may fall back to ONE input buffer for large-K layers
+    // (weights + one tile fill LDS): the next tile still flies into registers under the MFMA loop, only its LDS write waits
+    for (int nbuf = 2; nbuf >= (occ == 1 ? 1 : 2) && !found; --nbuf)
     for (int R = rows_fit; R >= 1 && !found; --R) {
+        p.nbuf = nbuf;
         p.R = R;
         p.G = 1;
         if (R == p.Ho) {
@@ -346,7 +352,7 @@ bool f16_configure_mt(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
         if (p.ncols < 1) return false;
         p.upc = p.G * p.Rin * p.ncols;
         if ((long long)p.PKs * p.upc > (long long)ni * 256) continue;
-        const long long bytes = ((long long)p.PK * T * CT + 2LL * p.PK * p.plane) * 16;
+        const long long bytes = ((long long)p.PK * T * CT + (long long)nbuf * p.PK * p.plane) * 16;
         if (bytes > budget) continue;
         found = true;
     }
@@ -375,7 +381,7 @@ bool f16_configure_mt(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
     p.magic_wo = magic_of(p.Wo);
     p.total_blocks = p.n_ct * p.n_groups;
     L.ks = KS; L.stride = S; L.variant = variant;
-    L.lds_bytes = (size_t)(p.w_buf + 2 * p.in_buf) * 16;
+    L.lds_bytes = (size_t)(p.w_buf + p.nbuf * p.in_buf) * 16;
     return L.lds_bytes <= (size_t)kLdsMax;
 }
 
@@ -597,10 +603,11 @@ int grid_for(size_t total) {
 void f16_variant_dims(int v, int& ct, int& pt) {
     static const int cts[5] = {32, 64, 48, 64, 32};
     static const int pts[5] = {192, 192, 192, 96, 96};
+    if (v >= F_CT16_PT192) { ct = 16; pt = 192; return; }
     ct = cts[v % 5];
     pt = pts[v % 5];
 }
-bool f16_variant_light(int v) { return v >= F_CT32_PT192_L && v < F_MT2_BASE; }
+bool f16_variant_light(int v) { return (v >= F_CT32_PT192_L && v < F_MT2_BASE) || v == F_CT16_PT192_L; }
 
 int f16_build_launch(const mp_conv_desc* desc, int variant, const void* x, const void* w, const float* scale,
                      const float* shift, const void* res1, const void* res2, void* out, ConvF16Launch& L) {

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Para
     constexpr int CT = 16 * CS * WAVES_C;
     extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
     u32x4* __restrict__ lds_w = smem16;             // [PK/4][T][4][CT]
-    u32x4* __restrict__ lds_in = smem16 + p.w_buf;  // [2][in_buf]
+    u32x4* __restrict__ lds_in = smem16 + p.w_buf;  // [nbuf][in_buf]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp_i = wave % WAVES_P, wc_i = wave / WAVES_P;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Para
         }
     }
     {
-        const int n16 = 2 * p.in_buf;
+        const int n16 = p.nbuf * p.in_buf;
         const u32x4 zero = (u32x4){0u, 0u, 0u, 0u};
         for (int i = tid; i < n16; i += 256) lds_in[i] = zero;
     }
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Para
 
     const int nq = p.PK >> 2;
     for (int t = t_begin; t < t_end; ++t) {
-        const int buf = (t - t_begin) & 1;
+        const int buf = p.nbuf == 2 ? ((t - t_begin) & 1) : 0;
         const bool more = t + 1 < t_end;
         if (more) stage_load(t + 1);
 
@@ -247,7 +247,8 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Para
             }
 
         if (more) {
-            stage_store(buf ^ 1);
+            if (p.nbuf == 1) __syncthreads();  // single input buffer (big tiles): every wave is done reading it
+            stage_store(p.nbuf == 2 ? (buf ^ 1) : 0);
             __syncthreads();
         }
     }
@@ -276,13 +277,14 @@ int launch_mt_shape(const ConvF16Params& p, int shape, size_t lds_bytes, hipStre
         case F_CT48_PT192: return launch_mt_variant<KS, S, 3, 3, 4, 1, OCC>(p, lds_bytes, s);
         case F_CT64_PT96: return launch_mt_variant<KS, S, 3, 2, 2, 2, OCC>(p, lds_bytes, s);
         case F_CT32_PT96: return launch_mt_variant<KS, S, 3, 1, 2, 2, OCC>(p, lds_bytes, s);
+        case 5: return launch_mt_variant<KS, S, 3, 1, 4, 1, OCC>(p, lds_bytes, s);  // 16 couts x 192 pixels
         default: return MP_ERR_UNSUPPORTED;
     }
 }
 
 template <int KS, int S>
 int launch_mt_ks(const ConvF16Params& p, int variant, size_t lds_bytes, hipStream_t s) {
-    const int shape = (variant - F_MT2_BASE) % 5;
+    const int shape = variant >= F_CT16_PT192_MT2 ? 5 : (variant - F_MT2_BASE) % 5;
     return f16_variant_mt_occ(variant) == 1 ? launch_mt_shape<KS, S, 1>(p, shape, lds_bytes, s)
                                             : launch_mt_shape<KS, S, 2>(p, shape, lds_bytes, s);
 }
