@@ -342,7 +342,11 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(const ConvKParams p
 
     // ---- epilogue: BN scale/shift (+res1) (+res2) (+ReLU) -> NCHW, with the output mapping
     const int plane_o = p.out_h * p.out_w;
-    const bool vec_ok = ((p.Wo & 3) == 0);
+    // 4 consecutive flattened tile pixels are 16 contiguous, aligned bytes of an NCHW plane when rows are a multiple of 4
+    // wide - or when the tile holds whole images whose plane is (8x6 maps: 48 floats) and the mapping is the plain one
+    const bool vec_ok = ((p.Wo & 3) == 0) ||
+                        (p.R == p.Ho && ((p.Ho * p.Wo) & 3) == 0 && p.out_mul == 1 && p.out_rep == 1 && p.out_w == p.Wo &&
+                         p.out_h == p.Ho && p.off_x == 0 && p.off_y == 0);
     if (vec_ok && p.out_mul == 1 && p.out_rep == 1) {
         // plain mapping: 16 B per lane.  All residual loads are issued first (clamped address + select, no
         // branches), then combined and stored, so their latencies overlap instead of adding up.
