@@ -98,3 +98,20 @@ def test_topdown_evaluator_end_to_end(tmp_path):
     assert len(res) == 3 and all(abs(r["score"] - 0.8 * 0.95) < 1e-6 for r in res)  # rescoring = mean kpt score x box score
     with pytest.raises(KeyError):
         mp.TopDownEvaluator(str(ann_file), metric="PCK", config=cfg)
+
+
+def test_engine_factories_merge_configs(tmp_path, caplog):
+    import inspect
+    images = [dict(id=1, file_name="a.jpg")]
+    ann_file = tmp_path / "ann.json"
+    ann_file.write_text(json.dumps(dict(images=images, annotations=[], categories=[dict(id=1, name="person")])))
+    ev = mp.create_evaluator(str(ann_file), name="topdown", metric="AP", config=dict(vis_thr=0.2, oks_thr=0.9, use_nms=True),
+                             dataset_config=dict(soft_nms=False, sigmas=COCO_SIGMAS.tolist(), vis_thr=0.3))
+    assert isinstance(ev, mp.TopDownEvaluator) and ev._evaluation_cfg["vis_thr"] == 0.3  # dataset config wins, with a warning
+    assert any("Duplicated keys" in r.message for r in caplog.records)
+    inf = mp.create_inferencer(net=object(), name="topdown_heatmap", config=dict(has_heatmap_output=True, hflip_tta=False, shift_heatmap=False),
+                               dataset_config=dict(flip_pairs=[[1, 2]]))
+    assert isinstance(inf, mp.TopDownHeatMapInferencer)
+    assert list(inspect.signature(mp.create_inferencer).parameters) == ["net", "name", "config", "dataset_config", "kwargs"]
+    assert list(inspect.signature(mp.create_evaluator).parameters) == ["annotation_file", "name", "metric", "config",
+                                                                         "dataset_config", "kwargs"]
