@@ -233,3 +233,26 @@ def test_optimizer_step_reduces_loss_and_matches_reference_update():
         losses.append(float(loss.detach()))
     assert losses[-1] < losses[0], losses
     assert opt.global_step == 4
+
+
+def test_create_optimizer_and_scheduler_drive_the_native_adamw():
+    from mindpose_amd.optim import create_optimizer
+    from mindpose_amd.scheduler import create_lr_scheduler
+    net = mp.init_synthetic(mp.create_network("hrnet_w32", "hrnet_head"), seed=0).to(DEV).train()
+    sched = create_lr_scheduler("warmup_multi_step_decay", lr=1e-3, total_epochs=2, steps_per_epoch=4, warmup=2, milestones=[2])
+    opt = create_optimizer(net, name="adamw", learning_rate=sched, weight_decay=0.05, filter_bias_and_bn=True)
+    nwl = mp.create_network_with_loss(net, mp.create_loss("joint_mse", use_target_weight=True), has_extra_inputs=True)
+    x = torch.randn(2, 3, 64, 64, device=DEV)
+    tgt = mp.TopDownGenerateTarget(config=dict(image_size=[64, 64], heatmap_size=[16, 16]), sigma=2.0)
+    target, weight = tgt(torch.rand(2, 17, 3, device=DEV) * 60)
+    lrs = []
+    for _ in range(6):
+        opt.zero_grad()
+        nwl(x, target, weight).backward()
+        opt.step()
+        lrs.append(opt.lr)
+    assert lrs == [sched(i) for i in range(6)] and lrs[0] == 0.0 and lrs[2] == 1e-3 and lrs[4] == 1e-3 * 0.1
+    # weight decay only through the decay / no-decay grouping, as the reference wires it
+    assert create_optimizer(net, "adamw", 1e-3, weight_decay=0.05, filter_bias_and_bn=False).weight_decay == 0.0
+    with pytest.raises(NotImplementedError):
+        create_optimizer(net, name="sgd")

@@ -63,13 +63,25 @@ def test_world_size_2_gloo_sharded_decode(tmp_path):
     assert np.load(tmp_path / "tmax.npy")[0] == 0.2
 
 
-def test_warmup_multistep_lr_schedule():
-    from mindpose_amd.utils import WarmupMultiStepDecayLR
-    # reference recipe: lr 1e-3, warm-up 500 steps, milestones [170, 200] epochs (configs/hrnet/hrnet_w32_ascend.yaml:75-88)
-    sched = WarmupMultiStepDecayLR(1e-3, warmup=500, milestones=[170, 200], decay_rate=0.1, steps_per_epoch=100)
-    assert sched(0) == 0.0 and abs(sched(250) - 5e-4) < 1e-12 and sched(500) == 1e-3
-    assert sched(169 * 100 - 1) == 1e-3 and abs(sched(169 * 100) - 1e-4) < 1e-15
-    assert abs(sched(199 * 100) - 1e-5) < 1e-15 and abs(sched(10 ** 6) - 1e-5) < 1e-15
+def test_lr_schedules_match_reference_formulas():
+    import math
+    from mindpose_amd.utils import WarmupCosineDecayLR, WarmupMultiStepDecayLR, create_lr_scheduler
+    # reference recipe: lr 1e-3, warm-up 500 steps, milestones [170, 200] of 210 epochs (configs/hrnet/hrnet_w32_ascend.yaml:75-88)
+    sched = create_lr_scheduler("warmup_multi_step_decay", lr=1e-3, total_epochs=210, steps_per_epoch=100, warmup=500,
+                                milestones=[170, 200], decay_rate=0.1)
+    assert isinstance(sched, WarmupMultiStepDecayLR)
+    assert sched(0) == 0.0 and abs(sched(250) - 5e-4) < 1e-12 and sched(500) == 1e-3 and sched(501) == 1e-3
+    assert sched(169 * 100 - 1) == 1e-3 and sched(169 * 100) == 1e-3 * 0.1
+    assert sched(199 * 100 - 1) == 1e-3 * 0.1 and sched(199 * 100) == 1e-3 * 0.1 * 0.1 and sched(210 * 100 - 1) == 1e-3 * 0.1 * 0.1
+    # fractional warm-up = fraction of the total steps; cosine decay over the rest, never below min_lr
+    cos = create_lr_scheduler("warmup_cosine_decay", lr=2e-3, total_epochs=10, steps_per_epoch=100, warmup=0.1, min_lr=1e-5)
+    assert isinstance(cos, WarmupCosineDecayLR) and cos.warmup_steps == 100 and cos.decay_steps == 900
+    assert abs(cos(50) - 1e-3) < 1e-15 and cos(100) == 2e-3
+    want = 1e-5 + 0.5 * (2e-3 - 1e-5) * (1 + math.cos(math.pi * 450 / 900))
+    assert abs(cos(550) - want) < 1e-15 and abs(cos(1000) - 1e-5) < 1e-12
+    import pytest
+    with pytest.raises(ValueError, match="Warmup steps"):
+        WarmupMultiStepDecayLR(1e-3, 1, 10, [1], warmup=11)
 
 
 def test_dynamic_loss_scale_manager_semantics():
