@@ -253,3 +253,20 @@ def test_fuse_upsample_sum_vs_torch(terms):
     plan.run()
     torch.cuda.synchronize()
     assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("amp", ["O0", "O2"])
+def test_execution_lanes_are_bit_identical_to_single_stream(amp, monkeypatch):
+    # the four-lane replay (branches / exchange-unit rows on side streams, event fork / barriers / join) must produce exactly
+    # the single-stream result, run after run: a missing ordering edge would show up as a difference at a filling batch size
+    x = torch.randn(48, 3, 256, 192, generator=torch.Generator().manual_seed(7)).to(DEV)
+    outs = {}
+    for lanes in ("1", "0"):
+        monkeypatch.setenv("MINDPOSE_PLAN_LANES", lanes)
+        net = _net("hrnet_w32", "hrnet_head")
+        mp.models.auto_mixed_precision(net, amp)
+        outs[lanes] = [net(x).clone() for _ in range(4)]
+        torch.cuda.synchronize()
+    for o in outs["1"]:
+        assert torch.equal(o, outs["0"][0])
+    assert all(torch.equal(o, outs["0"][0]) for o in outs["0"])
