@@ -322,6 +322,9 @@ int mp_stem_conv_wgrad(const float* x_dev, const float* dz_dev, float* dw_dev, i
                        mp_stream_t stream);
 int mp_f16_gather_phase(const void* x_c8_dev, void* out_c8_dev, int n, int c, int h, int w, int phase_y, int phase_x,
                         mp_stream_t stream);
+/* the same gather on fp32 NCHW; the fp32 transposed-conv gradients use it with mp_conv_pack_weight mode 4 (data gradient of
+ * phase (phase_y, phase_x)) and mp_conv_wgrad on a 4x4 stride-2 padding-1 descriptor with the roles exchanged */
+int mp_gather_phase(const float* x_dev, float* out_dev, int n, int c, int h, int w, int phase_y, int phase_x, mp_stream_t stream);
 
 /* Diagnostics: only a library built with -DMP_CONV_STAMPS=1 (never the product build) records per-workgroup
  * phase cycle counters (8 x uint64 per workgroup) of each conv launch into this device buffer; the product

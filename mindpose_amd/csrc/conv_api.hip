@@ -43,6 +43,13 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
                 const int ky = py == 0 ? (ty == 0 ? 1 : -1) : (ty == 0 ? 2 : 0);
                 const int kx = px == 0 ? (tx == 0 ? 1 : -1) : (tx == 0 ? 2 : 0);
                 v = (ky < 0 || kx < 0) ? 0.f : w[(((size_t)ci * cout + co) * 3 + ky) * 3 + kx];
+            } else if (transposed == 4) {
+                // data gradient of sub-pixel phase (py, px) of Conv2dTranspose k=4 s=2 p=1: roles swapped (this packed conv's
+                // cout = the transposed conv's cin), the 2x2 phase taps mirrored; w = [cout, cin, 4, 4] in packed terms
+                const int my = 1 - ty, mx = 1 - tx;
+                const int ky = py == 0 ? 3 - 2 * my : 2 - 2 * my;
+                const int kx = px == 0 ? 3 - 2 * mx : 2 - 2 * mx;
+                v = w[(((size_t)co * cin + ci) * 4 + ky) * 4 + kx];
             } else {
                 // Conv2dTranspose k=4 s=2 p=1: out row 2m+py reads in row m-1+py+ty with kernel row
                 // ky = 3-2*ty (py=0) or 2-2*ty (py=1); same along x.
@@ -351,8 +358,8 @@ int mp_conv_pack_weight(const float* w, float* packed, int cout, int cin, int kh
                         int phase_x, mp_stream_t stream) {
     if (!w || !packed) return MP_ERR_NULL;
     if (cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0) return MP_ERR_SHAPE;
-    if (transposed < 0 || transposed > 3) return MP_ERR_UNSUPPORTED;
-    if ((transposed == 1 || transposed == 3) && (kh != 2 || kw != 2 || phase_y < 0 || phase_y > 1 || phase_x < 0 || phase_x > 1))
+    if (transposed < 0 || transposed > 4) return MP_ERR_UNSUPPORTED;
+    if ((transposed == 1 || transposed == 3 || transposed == 4) && (kh != 2 || kw != 2 || phase_y < 0 || phase_y > 1 || phase_x < 0 || phase_x > 1))
         return MP_ERR_UNSUPPORTED;
     const int cin_pad4 = round_up(cin, 4), cout_pad16 = round_up(cout, 16);
     const size_t total = (size_t)cin_pad4 * kh * kw * cout_pad16;

@@ -270,15 +270,18 @@ static int odd_up(int v) { return v | 1; }
 static int wgrad_geometry(const mp_conv_desc* d, WgradParams& p, size_t& lds_bytes) {
     if (!d) return MP_ERR_NULL;
     if (d->n <= 0 || d->cin <= 0 || d->cout <= 0 || d->h <= 0 || d->w <= 0 || d->conv_h <= 0 || d->conv_w <= 0) return MP_ERR_SHAPE;
-    if (d->kh != d->kw || !(d->kh == 1 || d->kh == 3)) return MP_ERR_UNSUPPORTED;
+    // 1x1 / 3x3 with padding k/2, or the 4x4 stride-2 padding-1 form (the transposed convolution's weight gradient, roles of
+    // input and output gradient exchanged by the caller; simple kernel only)
+    if (d->kh != d->kw || !(d->kh == 1 || d->kh == 3 || d->kh == 4)) return MP_ERR_UNSUPPORTED;
     if (!(d->stride == 1 || d->stride == 2)) return MP_ERR_UNSUPPORTED;
-    if (d->pad_top != d->pad_left || d->pad_top != d->kh / 2) return MP_ERR_UNSUPPORTED;
+    if (d->pad_top != d->pad_left) return MP_ERR_UNSUPPORTED;
+    if (d->kh == 4 ? (d->stride != 2 || d->pad_top != 1) : (d->pad_top != d->kh / 2)) return MP_ERR_UNSUPPORTED;
     p.N = d->n; p.Cin = d->cin; p.H = d->h; p.W = d->w; p.Cout = d->cout; p.Ho = d->conv_h; p.Wo = d->conv_w; p.pad = d->pad_top;
     const int S = d->stride, KS = d->kh;
     int R = 192 / p.Wo;
     if (R < 1) R = 1;
     if (R > p.Ho) R = p.Ho;
-    p.vec = ((p.W & 3) == 0 && (p.Wo & 3) == 0 && !getenv("MP_WGRAD_SIMPLE")) ? 1 : 0;
+    p.vec = ((p.W & 3) == 0 && (p.Wo & 3) == 0 && d->kh != 4 && !getenv("MP_WGRAD_SIMPLE")) ? 1 : 0;
     if (p.vec) {
         // pipelined kernel: double-buffered tiles; R limited by the per-thread staging registers (NZ = 6, NX = 9
         // 16-B units) and by 2 workgroups per CU (<= 78 KiB LDS)
@@ -379,7 +382,8 @@ int mp_conv_wgrad(const mp_conv_desc* desc, const float* x, const float* dz, flo
         else if (desc->kh == 1 && desc->stride == 1) MP_WGRAD_LAUNCH_PIPE(1, 1);
         else MP_WGRAD_LAUNCH_PIPE(1, 2);
     } else {
-        if (desc->kh == 3 && desc->stride == 1) MP_WGRAD_LAUNCH(3, 1);
+        if (desc->kh == 4) MP_WGRAD_LAUNCH(4, 2);
+        else if (desc->kh == 3 && desc->stride == 1) MP_WGRAD_LAUNCH(3, 1);
         else if (desc->kh == 3 && desc->stride == 2) MP_WGRAD_LAUNCH(3, 2);
         else if (desc->kh == 1 && desc->stride == 1) MP_WGRAD_LAUNCH(1, 1);
         else MP_WGRAD_LAUNCH(1, 2);

@@ -103,6 +103,19 @@ __global__ __launch_bounds__(256) void gather_phase_c8_kernel(const u32x4s* __re
     }
 }
 
+// fp32 NCHW form of the phase gather: out[pl, m, k] = x[pl, 2m + py, 2k + px]
+__global__ __launch_bounds__(256) void gather_phase_f32_kernel(const float* __restrict__ x, float* __restrict__ out, int planes, int h,
+                                                               int w, int py, int px) {
+    const size_t total = (size_t)planes * h * w;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % w);
+        const size_t t = i / w;
+        const int m = (int)(t % h);
+        const size_t pl = t / h;
+        out[i] = x[(pl * (2 * h) + 2 * m + py) * (size_t)(2 * w) + 2 * k + px];
+    }
+}
+
 }  // namespace
 }  // namespace mp
 
@@ -132,6 +145,17 @@ int mp_stem_conv_wgrad(const float* x, const float* dz, float* dw, int n, int ci
     const dim3 grid(cout * cin * k);
     if (k == 7) hipLaunchKernelGGL(stem_wgrad_kernel<7>, grid, dim3(256), 0, as_stream(stream), x, dz, dw, n, cin, h, w, cout, ho, wo);
     else hipLaunchKernelGGL(stem_wgrad_kernel<3>, grid, dim3(256), 0, as_stream(stream), x, dz, dw, n, cin, h, w, cout, ho, wo);
+    return check_launch();
+}
+
+int mp_gather_phase(const float* x, float* out, int n, int c, int h, int w, int phase_y, int phase_x, mp_stream_t stream) {
+    if (!x || !out) return MP_ERR_NULL;
+    if (n <= 0 || c <= 0 || h <= 0 || w <= 0 || phase_y < 0 || phase_y > 1 || phase_x < 0 || phase_x > 1) return MP_ERR_SHAPE;
+    const size_t total = (size_t)n * c * h * w;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(gather_phase_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, out, n * c, h, w, phase_y,
+                       phase_x);
     return check_launch();
 }
 

@@ -569,13 +569,66 @@ def maxpool3x3s2_same(x):
     return MaxPoolFn.apply(x)
 
 
+class DeconvFn(torch.autograd.Function):
+    """fp32 NCHW form of ``Deconv16Fn``: four 2x2 phase convs forward, gathered-phase 2x2 convs for the data gradient, the 4x4
+    stride-2 weight-gradient GEMM (roles exchanged) for the weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        lib = _lib.load()
+        x = _lib.require_cuda_f32(x, "x")
+        w = weight.detach().contiguous()
+        n, cin, h, wd = x.shape
+        cout = w.shape[1]
+        ones, zeros = _ones_zeros(cout, x.device)
+        y = torch.empty(n, cout, 2 * h, 2 * wd, device=x.device, dtype=torch.float32)
+        for py in (0, 1):
+            for px in (0, 1):
+                d = _desc(n, cin, h, wd, cout, 2, 1, 1 - py, 1 - px, h, wd, 2 * h, 2 * wd, out_mul=2, off_y=py, off_x=px)
+                _conv_launch(lib, d, x, _pack(lib, w, cout, cin, 2, 1, py, px), ones, zeros, y, "deconv phase")
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, cin, h, wd = x.shape
+        cout = w.shape[1]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            ones, zeros = _ones_zeros(cin, x.device)
+            dx = torch.empty_like(x)
+            phase = torch.empty(n, cout, h, wd, device=x.device, dtype=torch.float32)
+            first = True
+            for py in (0, 1):
+                for px in (0, 1):
+                    _lib.check(lib.mp_gather_phase(_lib.ptr(dy), _lib.ptr(phase), n, cout, h, wd, py, px, _lib.stream()), "mp_gather_phase")
+                    d = _desc(n, cout, h, wd, cin, 2, 1, py, px, h, wd, h, wd)
+                    packed = _pack(lib, w, cin, cout, 2, 4, py, px)
+                    _lib.check(lib.mp_conv2d_fwd(ctypes.byref(d), _lib.ptr(phase), _lib.ptr(packed), _lib.ptr(ones), _lib.ptr(zeros),
+                                                 None if first else _lib.ptr(dx), None, _lib.ptr(dx), _lib.stream()), "deconv dgrad phase")
+                    first = False
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            d = _desc(n, cout, 2 * h, 2 * wd, cin, 4, 2, 1, 1, h, wd, h, wd)
+            ws_bytes = lib.mp_conv_wgrad_workspace_bytes(ctypes.byref(d))
+            if ws_bytes == 0:
+                raise _lib.MindposeHipError("transposed-conv weight gradient: unsupported shape")
+            ws = torch.empty(ws_bytes // 4, device=x.device, dtype=torch.float32)
+            _lib.check(lib.mp_conv_wgrad(ctypes.byref(d), _lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), 0, _lib.ptr(ws), ws_bytes,
+                                         _lib.stream()), "deconv wgrad")
+        return dx, dw
+
+
 def deconv_bn_relu(x, deconv, bn):
-    """Conv2dTranspose(4, 2, 1) + BatchNorm(train) + ReLU of the SimpleBaseline head (amp O2 only)."""
-    if not _is_c8(x):
-        raise NotImplementedError("the SimpleBaseline head trains under amp O2 (auto_mixed_precision(net, 'O2')): the "
-                                  "transposed-convolution gradients exist for the fp16 matrix-core kernels only")
-    y = Deconv16Fn.apply(x, deconv.weight)
-    return BatchNormAct16Fn.apply(y, bn.gamma, bn.beta, None, bn.moving_mean, bn.moving_variance, True)
+    """Conv2dTranspose(4, 2, 1) + BatchNorm(train) + ReLU of the SimpleBaseline head."""
+    if _is_c8(x):
+        y = Deconv16Fn.apply(x, deconv.weight)
+        return BatchNormAct16Fn.apply(y, bn.gamma, bn.beta, None, bn.moving_mean, bn.moving_variance, True)
+    y = DeconvFn.apply(x, deconv.weight)
+    return BatchNormActFn.apply(y, bn.gamma, bn.beta, None, bn.moving_mean, bn.moving_variance, True)
 
 
 def to_c8(x: torch.Tensor) -> torch.Tensor:
