@@ -35,6 +35,7 @@ struct ConvF16Params {
     int RWo, total_blocks;
     // persistent multi-tile kernel only: a workgroup keeps its weight slice in LDS and walks tiles_per_wg pixel tiles
     int tiles_total, tiles_per_wg, n_groups;
+    int ni_used, nw_used;  // staging slots (of the kernel's NI / NW) that carry data for this shape: the rest are skipped
 };
 
 struct ConvF16Launch {

@@ -115,22 +115,29 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
         const unsigned xo = (unsigned)c0 * HW * 16u;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
+            if (i >= p.ni_used) break;  // uniform: slots beyond this shape's unit count issue nothing
             unsigned off = isrc[i] + xo;
             if (idst[i] >= 0 && c0 + (idst[i] >> 20) >= p.C8in) off = kOob;  // zero planes beyond the real channels
             vin[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
         }
         const unsigned wo = (unsigned)ch * p.PK * T * p.Cout_pad16 * 16u;
 #pragma unroll
-        for (int i = 0; i < NW; ++i) vw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wsrc[i] == kOob ? kOob : wsrc[i] + wo, 0, 0);
+        for (int i = 0; i < NW; ++i) {
+            if (i >= p.nw_used) break;
+            vw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wsrc[i] == kOob ? kOob : wsrc[i] + wo, 0, 0);
+        }
     };
     auto stage_store = [&](int buf) {
         u32x4* __restrict__ din = lds_in + buf * p.in_buf;
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
+        for (int i = 0; i < NI; ++i) {
+            if (i >= p.ni_used) break;
             if (idst[i] >= 0) din[idst[i] & 0xFFFFF] = vin[i];
+        }
         u32x4* __restrict__ dw = lds_w + buf * p.w_buf;
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
+            if (i >= p.nw_used) break;
             const int u = tid + 256 * i;
             if (u < w_units) dw[u] = vw[i];
         }
@@ -380,6 +387,8 @@ bool f16_configure_mt(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
     p.magic_rwo = magic_of(p.RWo);
     p.magic_wo = magic_of(p.Wo);
     p.total_blocks = p.n_ct * p.n_groups;
+    p.ni_used = (p.PKs * p.upc + 255) / 256;
+    p.nw_used = 0;  // this kernel loads its weights once, outside the staging slots
     L.ks = KS; L.stride = S; L.variant = variant;
     L.lds_bytes = (size_t)(p.w_buf + p.nbuf * p.in_buf) * 16;
     return L.lds_bytes <= (size_t)kLdsMax;
@@ -452,6 +461,8 @@ bool f16_configure(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
     p.magic_rwo = magic_of(p.RWo);
     p.magic_wo = magic_of(p.Wo);
     p.total_blocks = p.n_ct * p.tiles_y * p.tiles_n;
+    p.ni_used = (p.PKs * p.upc + 255) / 256;
+    p.nw_used = (p.PK * T * CT + 255) / 256;
     L.ks = KS; L.stride = S; L.variant = variant;
     L.lds_bytes = (size_t)p.nbuf * (p.in_buf + p.w_buf) * 16;
     return L.lds_bytes <= (size_t)kLdsMax;

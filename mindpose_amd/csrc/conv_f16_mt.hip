@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Para
         const int base = (n0 * p.C8in * HW + y_in0 * p.W) * 16;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
+            if (i >= p.ni_used) break;  // uniform: slots beyond this shape's unit count issue nothing
             const int yin = y_in0 + (ugr[i] & 0xFFFF), n = n0 + (ugr[i] >> 16);
             const bool ok = udst[i] >= 0 && yin >= 0 && yin < p.H && n < p.N;
             vin[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? (unsigned)(base + uoff[i]) : kOob, 0, 0);
@@ -135,8 +136,10 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Para
     auto stage_store = [&](int buf) {  // rows / images outside the tensor arrive as zeros and overwrite the last tile's data
         u32x4* __restrict__ din = lds_in + buf * p.in_buf;
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
+        for (int i = 0; i < NI; ++i) {
+            if (i >= p.ni_used) break;
             if (udst[i] >= 0) din[udst[i]] = vin[i];
+        }
     };
 
     stage_load(t_begin);
