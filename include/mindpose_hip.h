@@ -255,6 +255,18 @@ size_t mp_f16_activation_bytes(int n, int c, int h, int w);
  * gradient of transposed-conv phase (phase_y, phase_x) (w = the [Cin_t,Cout_t,4,4] weight, cout := Cin_t, cin := Cout_t) */
 int mp_f16_pack_weight(const float* w_dev, void* packed_dev, int cout, int cin, int kh, int kw, int transposed, int phase_y,
                        int phase_x, mp_stream_t stream);
+/* All weight packings of one training step in ONE launch (the fp32 master weights change every step, and an HRNet-W32 step
+ * needs 700 packings: forward + data-gradient forms).  jobs_dev: device array of n_jobs descriptors with the arguments of
+ * mp_f16_pack_weight (same validity rules, checked by the caller); first_block_dev: device array of n_jobs + 1 prefix sums of
+ * ceil(units_j / 256), units_j = ceil(cin/32) * kh * kw * 4 * Cout_pad16 (the job's 16-byte groups); total_blocks = its last
+ * entry.  Both tables are caller-owned and must stay alive until the launch has run. */
+typedef struct mp_f16_pack_job {
+    const float* w;
+    void* packed;
+    int cout, cin, kh, kw, transposed, phase_y, phase_x, reserved;
+} mp_f16_pack_job;
+int mp_f16_pack_weight_batch(const mp_f16_pack_job* jobs_dev, const unsigned* first_block_dev, int n_jobs, unsigned total_blocks,
+                             mp_stream_t stream);
 int mp_f16_to_c8(const float* x_nchw_dev, void* out_c8_dev, int n, int c, int h, int w, mp_stream_t stream);
 int mp_f16_from_c8(const void* x_c8_dev, float* out_nchw_dev, int n, int c, int h, int w, mp_stream_t stream);
 int mp_f16_conv2d_fwd(const mp_conv_desc* desc, int variant, const void* x_c8_dev, const void* packed_w_dev,

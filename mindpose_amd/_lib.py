@@ -82,6 +82,7 @@ _PROTOTYPES = {
     "mp_f16_packed_weight_bytes": (c_size_t, [c_int] * 4),
     "mp_f16_activation_bytes": (c_size_t, [c_int] * 4),
     "mp_f16_pack_weight": (c_int, [c_f32p, c_f32p] + [c_int] * 7 + [ctypes.c_void_p]),
+    "mp_f16_pack_weight_batch": (c_int, [c_f32p, c_f32p, c_int, ctypes.c_uint, ctypes.c_void_p]),
     "mp_f16_to_c8": (c_int, [c_f32p, c_f32p] + [c_int] * 4 + [ctypes.c_void_p]),
     "mp_f16_from_c8": (c_int, [c_f32p, c_f32p] + [c_int] * 4 + [ctypes.c_void_p]),
     "mp_f16_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_int] + [c_f32p] * 7 + [ctypes.c_void_p]),

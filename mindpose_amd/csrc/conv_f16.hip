@@ -488,6 +488,38 @@ int f16_validate(const mp_conv_desc* d) {
 
 // [Cout,Cin,kh,kw] fp32 -> [Cin_pad32/32][T][4][Cout_pad16][8] fp16 (round to nearest even), zero padded
 // transposed = 1: the (py, px) 2x2 sub-pixel phase of a Conv2dTranspose(k=4, s=2, p=1) weight [Cin,Cout,4,4]
+// source value of packed element (cout co, cin ci, tap t) - callers have checked co < cout && ci < cin
+__device__ __forceinline__ float pack_f16_source(const float* __restrict__ w, int cout, int cin, int kh, int kw, int transposed,
+                                                 int py, int px, int co, int ci, int t) {
+    const int ty = t / kw, tx = t % kw;
+    if (!transposed) return w[(((size_t)co * cin + ci) * kh + ty) * kw + tx];
+    if (transposed == 2) {
+        // data gradient of a stride-1 conv whose weight is [cin, cout, kh, kw] in forward terms (this packed conv's
+        // cout = forward cin): roles swapped, taps mirrored
+        return w[(((size_t)ci * cout + co) * kh + (kh - 1 - ty)) * kw + (kw - 1 - tx)];
+    }
+    if (transposed == 3) {
+        // data gradient of a 3x3 stride-2 pad-1 conv, output parity phase (py, px), as a 2x2 conv over dy:
+        // dx[2a+p] = sum_t dy[a+t] * w[k(p,t)],  k(0,0)=1, k(0,1)=none, k(1,0)=2, k(1,1)=0
+        const int ky = py == 0 ? (ty == 0 ? 1 : -1) : (ty == 0 ? 2 : 0);
+        const int kx = px == 0 ? (tx == 0 ? 1 : -1) : (tx == 0 ? 2 : 0);
+        return (ky < 0 || kx < 0) ? 0.f : w[(((size_t)ci * cout + co) * 3 + ky) * 3 + kx];
+    }
+    if (transposed == 4) {
+        // data gradient of the (py, px) sub-pixel phase of Conv2dTranspose(k=4, s=2, p=1): roles swapped (this packed
+        // conv's cout = the transposed conv's cin) and the 2x2 phase taps mirrored; w is [cout, cin, 4, 4] in
+        // this packed conv's terms
+        const int my = 1 - ty, mx = 1 - tx;
+        const int ky = py == 0 ? 3 - 2 * my : 2 - 2 * my;
+        const int kx = px == 0 ? 3 - 2 * mx : 2 - 2 * mx;
+        return w[(((size_t)co * cin + ci) * 4 + ky) * 4 + kx];
+    }
+    // out row 2m+py reads in row m-1+py+ty with kernel row 3-2*ty (py=0) or 2-2*ty (py=1); same along x
+    const int ky = py == 0 ? 3 - 2 * ty : 2 - 2 * ty;
+    const int kx = px == 0 ? 3 - 2 * tx : 2 - 2 * tx;
+    return w[(((size_t)ci * cout + co) * 4 + ky) * 4 + kx];
+}
+
 __global__ __launch_bounds__(256) void pack_weight_f16_kernel(const float* __restrict__ w, _Float16* __restrict__ out,
                                                               int cout, int cin, int kh, int kw, int kq, int cout_pad16,
                                                               int transposed, int py, int px) {
@@ -504,36 +536,41 @@ __global__ __launch_bounds__(256) void pack_weight_f16_kernel(const float* __res
         const int q = (int)(r / T);
         const int ci = q * 32 + g * 8 + j;
         float v = 0.f;
-        if (co < cout && ci < cin) {
-            const int ty = t / kw, tx = t % kw;
-            if (!transposed) {
-                v = w[(((size_t)co * cin + ci) * kh + ty) * kw + tx];
-            } else if (transposed == 2) {
-                // data gradient of a stride-1 conv whose weight is [cin, cout, kh, kw] in forward terms (this packed conv's
-                // cout = forward cin): roles swapped, taps mirrored
-                v = w[(((size_t)ci * cout + co) * kh + (kh - 1 - ty)) * kw + (kw - 1 - tx)];
-            } else if (transposed == 3) {
-                // data gradient of a 3x3 stride-2 pad-1 conv, output parity phase (py, px), as a 2x2 conv over dy:
-                // dx[2a+p] = sum_t dy[a+t] * w[k(p,t)],  k(0,0)=1, k(0,1)=none, k(1,0)=2, k(1,1)=0
-                const int ky = py == 0 ? (ty == 0 ? 1 : -1) : (ty == 0 ? 2 : 0);
-                const int kx = px == 0 ? (tx == 0 ? 1 : -1) : (tx == 0 ? 2 : 0);
-                v = (ky < 0 || kx < 0) ? 0.f : w[(((size_t)ci * cout + co) * 3 + ky) * 3 + kx];
-            } else if (transposed == 4) {
-                // data gradient of the (py, px) sub-pixel phase of Conv2dTranspose(k=4, s=2, p=1): roles swapped (this packed
-                // conv's cout = the transposed conv's cin) and the 2x2 phase taps mirrored; w is [cout, cin, 4, 4] in
-                // this packed conv's terms
-                const int my = 1 - ty, mx = 1 - tx;
-                const int ky = py == 0 ? 3 - 2 * my : 2 - 2 * my;
-                const int kx = px == 0 ? 3 - 2 * mx : 2 - 2 * mx;
-                v = w[(((size_t)co * cin + ci) * 4 + ky) * 4 + kx];
-            } else {  // out row 2m+py reads in row m-1+py+ty with kernel row 3-2*ty (py=0) or 2-2*ty (py=1); same along x
-                const int ky = py == 0 ? 3 - 2 * ty : 2 - 2 * ty;
-                const int kx = px == 0 ? 3 - 2 * tx : 2 - 2 * tx;
-                v = w[(((size_t)ci * cout + co) * 4 + ky) * 4 + kx];
-            }
-        }
+        if (co < cout && ci < cin) v = pack_f16_source(w, cout, cin, kh, kw, transposed, py, px, co, ci, t);
         out[i] = (_Float16)v;
     }
+}
+
+// every weight of a training step in ONE launch: block b serves job j with first_block[j] <= b < first_block[j + 1] (binary
+// search over the prefix table), a thread writes one 16-byte group of 8 input channels
+__global__ __launch_bounds__(256) void pack_weight_f16_batch_kernel(const mp_f16_pack_job* __restrict__ jobs,
+                                                                    const unsigned* __restrict__ first_block, int n_jobs) {
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (first_block[mid] <= blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const mp_f16_pack_job jb = jobs[lo];
+    const int T = jb.kh * jb.kw, cp = (jb.cout + 15) / 16 * 16, kq = (jb.cin + 31) / 32;
+    const unsigned units = (unsigned)kq * T * 4 * cp;
+    const unsigned u = (blockIdx.x - first_block[lo]) * 256u + threadIdx.x;
+    if (u >= units) return;
+    const int co = (int)(u % cp);
+    unsigned r = u / cp;
+    const int g = (int)(r & 3);
+    r >>= 2;
+    const int t = (int)(r % T);
+    const int q = (int)(r / T);
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ci = q * 32 + g * 8 + j;
+        float v = 0.f;
+        if (co < jb.cout && ci < jb.cin)
+            v = pack_f16_source(jb.w, jb.cout, jb.cin, jb.kh, jb.kw, jb.transposed, jb.phase_y, jb.phase_x, co, ci, t);
+        o[j] = (_Float16)v;
+    }
+    reinterpret_cast<u32x4*>(jb.packed)[u] = __builtin_bit_cast(u32x4, o);
 }
 
 // NCHW fp32 -> c8 fp16: one thread per (n, block, pixel): 8 strided plane reads (coalesced across lanes), one 16-B store
@@ -690,6 +727,16 @@ int mp_f16_pack_weight(const float* w, void* packed, int cout, int cin, int kh, 
     const size_t total = (size_t)kq * kh * kw * 4 * cp * 8;
     hipLaunchKernelGGL(pack_weight_f16_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), w,
                        reinterpret_cast<_Float16*>(packed), cout, cin, kh, kw, kq, cp, transposed, phase_y, phase_x);
+    return check_launch();
+}
+
+int mp_f16_pack_weight_batch(const mp_f16_pack_job* jobs_dev, const unsigned* first_block_dev, int n_jobs, unsigned total_blocks,
+                             mp_stream_t stream) {
+    if (n_jobs == 0) return MP_OK;
+    if (!jobs_dev || !first_block_dev) return MP_ERR_NULL;
+    if (n_jobs < 0 || total_blocks == 0) return MP_ERR_SHAPE;
+    hipLaunchKernelGGL(pack_weight_f16_batch_kernel, dim3(total_blocks), dim3(256), 0, as_stream(stream), jobs_dev, first_block_dev,
+                       n_jobs);
     return check_launch();
 }
 

@@ -128,7 +128,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 
 // stage 2 (backward): dgamma = sum g*xhat, dbeta = sum g
 __global__ void bn_finalize_bwd_kernel(const double* __restrict__ part, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, int c, int nsplit, int accumulate) {
+                                       float* __restrict__ dbeta, float* __restrict__ dgamma_acc,
+                                       float* __restrict__ dbeta_acc, int c, int nsplit) {
     const int ch = blockIdx.x;
     double s0 = 0.0, s1 = 0.0;
     for (int sp = threadIdx.x; sp < nsplit; sp += 64) {
@@ -140,8 +141,12 @@ __global__ void bn_finalize_bwd_kernel(const double* __restrict__ part, float* _
         s1 += __shfl_down(s1, off, 64);
     }
     if (threadIdx.x != 0) return;
-    dbeta[ch] = accumulate ? dbeta[ch] + (float)s0 : (float)s0;
-    dgamma[ch] = accumulate ? dgamma[ch] + (float)s1 : (float)s1;
+    dbeta[ch] = (float)s0;
+    dgamma[ch] = (float)s1;
+    if (dgamma_acc && dbeta_acc) {  // + straight into the caller's gradient buffers (no separate add launch)
+        dbeta_acc[ch] += (float)s0;
+        dgamma_acc[ch] += (float)s1;
+    }
 }
 
 // dz = gamma*invstd * (g - dbeta/M - xhat*dgamma/M), dres = g  (g = dy masked by the ReLU of the forward output)
@@ -442,7 +447,7 @@ int mp_bn_train_bwd(const float* dy, const float* z, const float* y, const float
                        hw, relu ? 1 : 0);
     int rc = check_launch();
     if (rc != MP_OK) return rc;
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(c), dim3(64), 0, s, part, dgamma, dbeta, c, kBnSplit, 0);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(c), dim3(64), 0, s, part, dgamma, dbeta, nullptr, nullptr, c, kBnSplit);
     rc = check_launch();
     if (rc != MP_OK) return rc;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(n * c), dim3(256), 0, s, dy, z, y, gamma, save_mean, save_invstd, dgamma, dbeta,
@@ -531,12 +536,9 @@ int mp_f16_bn_train_bwd(const void* dy, const void* z, const void* y, const floa
                        c8, hw, relu ? 1 : 0, gi, gp);
     int rc = check_launch();
     if (rc != MP_OK) return rc;
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(c), dim3(64), 0, s, part, dgamma, dbeta, c, gi * gp, 0);
+    // one stage-2 launch writes dgamma / dbeta and, when given, also adds them into the caller's gradient buffers
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(c), dim3(64), 0, s, part, dgamma, dbeta, dgamma_acc, dbeta_acc, c, gi * gp);
     rc = check_launch();
-    if (rc == MP_OK && dgamma_acc && dbeta_acc) {  // + straight into the caller's gradient buffers (no separate add launch)
-        hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(c), dim3(64), 0, s, part, dgamma_acc, dbeta_acc, c, gi * gp, 1);
-        rc = check_launch();
-    }
     if (rc != MP_OK) return rc;
     const size_t total = (size_t)n * c8 * hw;
     size_t blocks = (total + 255) / 256;

@@ -34,6 +34,7 @@ class Net(PlannedModule):
         # under amp O2 the backbone switches to channel-blocked fp16 itself (HRNet at the image, ResNet after its fp32 stem);
         # fp32 images in, fp32 heat-maps out either way
         from . import train_ops as T
+        T.repack_weights(self)  # amp O2: every fp16 weight packing of the step in one launch (no-op in fp32 / on step one)
         y = self.head.train_forward(self.backbone.train_forward(x))
         return T.from_c8(y, self.head.out_joints) if T._is_c8(y) else y
 

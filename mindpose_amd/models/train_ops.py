@@ -8,6 +8,7 @@ Reference semantics: the cells of mindpose/models/backbones/hrnet.py run by mind
 import ctypes
 from typing import Optional
 
+import numpy as np
 import torch
 
 from .. import _lib
@@ -220,12 +221,98 @@ def _c8_alloc(n, c, h, w, device):
     return make(_c8_shape(n, c, h, w), device=device, dtype=torch.float16)
 
 
-def _pack16(lib, w, cout, cin, k, mode, py=0, px=0):
+_BN16_WS = {}
+
+
+def _bn16_workspace(lib, c, device):
+    """ONE persistent BatchNorm workspace per device (all calls are ordered on the current stream): no allocation per layer."""
+    need = lib.mp_bn_workspace_bytes(c)
+    ws = _BN16_WS.get(device)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.zeros(max(need, lib.mp_bn_workspace_bytes(2048)) // 4 + 1, device=device, dtype=torch.float32)
+        _BN16_WS[device] = ws
+    return ws, ws.numel() * 4
+
+
+# ---- fp16 weight packings ------------------------------------------------------------------------------------------------
+# The fp32 master weights change every step, so every step re-packs them (forward form + data-gradient forms: 700 packings
+# per HRNet-W32 step).  Each parameter remembers its packed buffers (``param._mp_packs``); ``repack_weights(net)`` - called
+# by ``Net.train_forward`` - refreshes ALL of them with ONE launch (mp_f16_pack_weight_batch) and the per-layer code then
+# finds its packing fresh.  A packing is used once per refresh; anything else (first step, direct calls of the functions,
+# a weight changed since the refresh) packs individually, as before.
+_PACK_GEN = [0]
+
+
+def invalidate_packs():
+    """Master weights were written behind torch's back (optimizer kernels update through raw pointers): nothing packed
+    before this call may be reused."""
+    _PACK_GEN[0] += 1
+
+
+class _PackEntry:
+    __slots__ = ("buf", "fresh", "gen", "ptr", "version")
+
+    def __init__(self, buf):
+        self.buf, self.fresh, self.gen, self.ptr, self.version = buf, False, -1, 0, -1
+
+
+class _PackJob(ctypes.Structure):  # mp_f16_pack_job
+    _fields_ = [("w", ctypes.c_void_p), ("packed", ctypes.c_void_p)] + [(k, ctypes.c_int) for k in
+                ("cout", "cin", "kh", "kw", "transposed", "phase_y", "phase_x", "reserved")]
+
+
+def _pack16(lib, w, cout, cin, k, mode, py=0, px=0, owner=None):
+    """Packed fp16 form of ``w``; with ``owner`` (the Parameter ``w`` was detached from) the buffer is persistent and a
+    packing refreshed by ``repack_weights`` is handed out without a launch."""
     nbytes = lib.mp_f16_packed_weight_bytes(cout, cin, k, k)
-    packed = torch.empty(nbytes // 2, device=w.device, dtype=torch.float16)
+    entry = None
+    if owner is not None:
+        packs = owner.__dict__.setdefault("_mp_packs", {})
+        key = (cout, cin, k, mode, py, px)
+        entry = packs.get(key)
+        if entry is None:
+            entry = packs[key] = _PackEntry(torch.empty(nbytes // 2, device=w.device, dtype=torch.float16))
+        if (entry.fresh and entry.gen == _PACK_GEN[0] and entry.ptr == w.data_ptr() and entry.version == owner._version):
+            entry.fresh = False
+            return entry.buf
+        entry.fresh = False
+    packed = entry.buf if entry is not None else torch.empty(nbytes // 2, device=w.device, dtype=torch.float16)
     _lib.check(lib.mp_f16_pack_weight(_lib.ptr(w), _lib.ptr(packed), cout, cin, k, k, mode, py, px, _lib.stream()),
                "mp_f16_pack_weight")
     return packed
+
+
+def repack_weights(module):
+    """Refresh every remembered fp16 packing of ``module``'s parameters in one launch (no-op until a first step has run)."""
+    jobs = []
+    for prm in module.parameters():
+        packs = prm.__dict__.get("_mp_packs")
+        if packs and prm.is_cuda and prm.dtype == torch.float32 and prm.is_contiguous():
+            jobs.extend((prm, key, entry) for key, entry in packs.items())
+    if not jobs:
+        return 0
+    lib = _lib.load()
+    sig = tuple((prm.data_ptr(), entry.buf.data_ptr()) for prm, _, entry in jobs)
+    table = module.__dict__.get("_mp_pack_table")
+    if table is None or table[0] != sig:
+        arr = (_PackJob * len(jobs))()
+        first = np.zeros(len(jobs) + 1, dtype=np.uint32)
+        for i, (prm, (cout, cin, k, mode, py, px), entry) in enumerate(jobs):
+            arr[i] = _PackJob(prm.data_ptr(), entry.buf.data_ptr(), cout, cin, k, k, mode, py, px, 0)
+            units = (cin + 31) // 32 * k * k * 4 * ((cout + 15) // 16 * 16)
+            first[i + 1] = first[i] + (units + 255) // 256
+        dev = jobs[0][0].device
+        jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        first_dev = torch.from_numpy(first.view(np.int32)).to(dev)
+        table = (sig, jobs_dev, first_dev, int(first[-1]))
+        module.__dict__["_mp_pack_table"] = table
+    _, jobs_dev, first_dev, blocks = table
+    _lib.check(lib.mp_f16_pack_weight_batch(_lib.ptr(jobs_dev), _lib.ptr(first_dev), len(jobs), blocks, _lib.stream()),
+               "mp_f16_pack_weight_batch")
+    gen = _PACK_GEN[0]
+    for prm, _, entry in jobs:
+        entry.fresh, entry.gen, entry.ptr, entry.version = True, gen, prm.data_ptr(), prm._version
+    return len(jobs)
 
 
 def _ones_zeros16(c: int, device):
@@ -305,7 +392,7 @@ class Conv16Fn(torch.autograd.Function):
             shift[:cout] = bias.detach()
         z = _c8_alloc(n, cout, ho, wo, x.device)
         d = _desc(n, cin, h, wd, cout, k, stride, padding, padding, ho, wo, ho, wo)
-        packed = _pack16(lib, w, cout, cin, k, 0)
+        packed = _pack16(lib, w, cout, cin, k, 0, owner=weight)
         _conv16_launch(lib, d, x, packed, ones, shift, z, "mp_f16_conv2d_fwd")
         ctx.save_for_backward(x, w)
         ctx.stride, ctx.padding, ctx.has_bias = stride, padding, bias is not None
@@ -327,7 +414,7 @@ class Conv16Fn(torch.autograd.Function):
             dx = _c8_alloc(n, cin, h, wd, x.device)
             if s == 1:
                 d = _desc(n, cout, ho, wo, cin, k, 1, k - 1 - pad, k - 1 - pad, h, wd, h, wd)
-                _conv16_launch(lib, d, dz, _pack16(lib, w, cin, cout, k, 2), ones, zeros, dx, "conv dgrad")
+                _conv16_launch(lib, d, dz, _pack16(lib, w, cin, cout, k, 2, owner=ctx.weight_param), ones, zeros, dx, "conv dgrad")
             else:
                 if h != 2 * ho or wd != 2 * wo:
                     raise NotImplementedError("stride-2 data gradient needs even input extents")
@@ -335,11 +422,12 @@ class Conv16Fn(torch.autograd.Function):
                     for py in (0, 1):
                         for px in (0, 1):
                             d = _desc(n, cout, ho, wo, cin, 2, 1, 0, 0, ho, wo, h, wd, out_mul=2, off_y=py, off_x=px)
-                            _conv16_launch(lib, d, dz, _pack16(lib, w, cin, cout, 2, 3, py, px), ones, zeros, dx, "conv dgrad phase")
+                            _conv16_launch(lib, d, dz, _pack16(lib, w, cin, cout, 2, 3, py, px, owner=ctx.weight_param), ones, zeros, dx,
+                                           "conv dgrad phase")
                 else:  # 1x1 stride 2 (ResNet down-sample): only the even positions receive gradient
                     dx.zero_()
                     d = _desc(n, cout, ho, wo, cin, 1, 1, 0, 0, ho, wo, h, wd, out_mul=2)
-                    _conv16_launch(lib, d, dz, _pack16(lib, w, cin, cout, 1, 2), ones, zeros, dx, "conv dgrad 1x1s2")
+                    _conv16_launch(lib, d, dz, _pack16(lib, w, cin, cout, 1, 2, owner=ctx.weight_param), ones, zeros, dx, "conv dgrad 1x1s2")
         if ctx.needs_input_grad[1]:
             direct = _direct_grad(ctx.weight_param)  # add straight into the gradient arena: no AccumulateGrad launch
             dw = direct if direct is not None else torch.empty_like(w)
@@ -366,8 +454,7 @@ class BatchNormAct16Fn(torch.autograd.Function):
         y = torch.empty_like(z)
         mean = torch.empty(c, device=z.device)
         invstd = torch.empty(c, device=z.device)
-        ws_bytes = lib.mp_bn_workspace_bytes(c)
-        ws = torch.empty(ws_bytes // 4 + 1, device=z.device, dtype=torch.float32)
+        ws, ws_bytes = _bn16_workspace(lib, c, z.device)
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
         r = res.contiguous() if res is not None else None
         _lib.check(lib.mp_f16_bn_train_fwd(_lib.ptr(z), _lib.ptr(g), _lib.ptr(b), _lib.ptr(r), _lib.ptr(y), _lib.ptr(mean),
@@ -389,8 +476,7 @@ class BatchNormAct16Fn(torch.autograd.Function):
         dres = torch.empty_like(z) if ctx.has_res else None
         dgamma = torch.empty(c, device=z.device)
         dbeta = torch.empty(c, device=z.device)
-        ws_bytes = lib.mp_bn_workspace_bytes(c)
-        ws = torch.empty(ws_bytes // 4 + 1, device=z.device, dtype=torch.float32)
+        ws, ws_bytes = _bn16_workspace(lib, c, z.device)
         ga, ba = _direct_grad(ctx.gamma_param), _direct_grad(ctx.beta_param)
         if ga is None or ba is None:
             ga = ba = None
@@ -511,7 +597,7 @@ class Deconv16Fn(torch.autograd.Function):
         for py in (0, 1):
             for px in (0, 1):
                 d = _desc(n, cin, h, wd, cout, 2, 1, 1 - py, 1 - px, h, wd, 2 * h, 2 * wd, out_mul=2, off_y=py, off_x=px)
-                _conv16_launch(lib, d, x, _pack16(lib, w, cout, cin, 2, 1, py, px), ones, zeros, y, "deconv phase")
+                _conv16_launch(lib, d, x, _pack16(lib, w, cout, cin, 2, 1, py, px, owner=weight), ones, zeros, y, "deconv phase")
         ctx.save_for_backward(x, w)
         ctx.weight_param = weight
         return y
@@ -536,7 +622,7 @@ class Deconv16Fn(torch.autograd.Function):
                     # y_phase[m] = sum_t x[m - (1-p) + t] wp[t]  =>  dx[j] = sum_t dy_phase[j + (1-p) - t] wp[t]:
                     # a 2x2 conv over dy_phase with mirrored taps and padding p
                     d = _desc(n, cout, h, wd, cin, 2, 1, py, px, h, wd, h, wd)
-                    packed = _pack16(lib, w, cin, cout, 2, 4, py, px)
+                    packed = _pack16(lib, w, cin, cout, 2, 4, py, px, owner=ctx.weight_param)
                     v = tune_conv_variant(lib, d, phase, packed, ones, zeros, None if first else dx, None, dx, half=True)
                     _lib.check(lib.mp_f16_conv2d_fwd(ctypes.byref(d), v, _lib.ptr(phase), _lib.ptr(packed), _lib.ptr(ones),
                                                      _lib.ptr(zeros), None if first else _lib.ptr(dx), None, _lib.ptr(dx),

@@ -77,5 +77,7 @@ class AdamWeightDecay:
                                          self.exp_avg[start:].data_ptr(), self.exp_avg_sq[start:].data_ptr(), count,
                                          float(self.lr), float(self.beta1), float(self.beta2), float(self.eps), float(wd), s),
                        "mp_adamw_step")
+        from ..models.train_ops import invalidate_packs
+        invalidate_packs()  # the kernel wrote the master weights through raw pointers: fp16 packings made before are stale
         self.global_step += 1
         return True

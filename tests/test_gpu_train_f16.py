@@ -324,6 +324,73 @@ def test_graphed_o2_step_equals_eager():
     assert losses[-1] < float(loss_e.detach())
 
 
+def test_batched_weight_pack_equals_individual_packs():
+    """mp_f16_pack_weight_batch == one mp_f16_pack_weight per job, bit for bit, over every packing mode; then three optimizer
+    steps of a network whose packings are refreshed by the batched launch equal three steps with per-layer packing."""
+    import ctypes
+    import numpy as np
+    from mindpose_amd.models import train_ops as T
+
+    g = torch.Generator().manual_seed(21)
+    specs = [  # (weight shape, cout, cin, k, mode, py, px)
+        ((40, 24, 3, 3), 40, 24, 3, 0, 0, 0), ((17, 32, 1, 1), 17, 32, 1, 0, 0, 0), ((40, 24, 3, 3), 24, 40, 3, 2, 0, 0),
+        ((40, 24, 3, 3), 24, 40, 2, 3, 1, 0), ((24, 40, 4, 4), 40, 24, 2, 1, 0, 1), ((24, 40, 4, 4), 24, 40, 2, 4, 1, 1),
+        ((64, 64, 1, 1), 64, 64, 1, 2, 0, 0)]
+    ws = [torch.randn(sh, generator=g).to(DEV) for sh, *_ in specs]
+    single, batch = [], []
+    arr = (T._PackJob * len(specs))()
+    first = np.zeros(len(specs) + 1, dtype=np.uint32)
+    for i, (w, (_, cout, cin, k, mode, py, px)) in enumerate(zip(ws, specs)):
+        nb = LIB.mp_f16_packed_weight_bytes(cout, cin, k, k)
+        a, b = torch.full((nb // 2,), 7.0, device=DEV, dtype=torch.float16), torch.full((nb // 2,), 9.0, device=DEV, dtype=torch.float16)
+        _lib.check(LIB.mp_f16_pack_weight(_lib.ptr(w), _lib.ptr(a), cout, cin, k, k, mode, py, px, _lib.stream()), "pack")
+        arr[i] = T._PackJob(w.data_ptr(), b.data_ptr(), cout, cin, k, k, mode, py, px, 0)
+        first[i + 1] = first[i] + ((cin + 31) // 32 * k * k * 4 * ((cout + 15) // 16 * 16) + 255) // 256
+        single.append(a)
+        batch.append(b)
+    jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+    first_dev = torch.from_numpy(first.view(np.int32)).to(DEV)
+    _lib.check(LIB.mp_f16_pack_weight_batch(_lib.ptr(jobs_dev), _lib.ptr(first_dev), len(specs), int(first[-1]), _lib.stream()), "batch")
+    torch.cuda.synchronize()
+    for a, b, sp in zip(single, batch, specs):
+        assert torch.equal(a, b), sp
+
+    import mindpose_amd as mp
+    from mindpose_amd.utils import AdamWeightDecay
+
+    def run(batched):
+        torch.manual_seed(0)
+        net = mp.init_synthetic(mp.create_network("hrnet_w32", "hrnet_head"), seed=0).to(DEV).train()
+        mp.models.auto_mixed_precision(net, "O2")
+        nwl = mp.create_network_with_loss(net, mp.create_loss("joint_mse", use_target_weight=True), has_extra_inputs=True)
+        opt = AdamWeightDecay(net, lr=1e-3, weight_decay=0.05, filter_bias_and_bn=True, overlap=False)
+        gg = torch.Generator().manual_seed(3)
+        x = torch.randn(2, 3, 64, 64, generator=gg).to(DEV)
+        kp = (torch.rand(2, 17, 3, generator=gg) * torch.tensor([64.0, 64.0, 2.0])).to(DEV)
+        target, weight = mp.TopDownGenerateTarget(config=dict(image_size=[64, 64], heatmap_size=[16, 16]), sigma=2.0)(kp)
+        losses, refreshed = [], []
+        real = T.repack_weights
+        if not batched:
+            T.repack_weights = lambda module: 0
+        try:
+            for _ in range(3):
+                refreshed.append(T.repack_weights(net) if batched else 0)  # what Net.train_forward is about to do again
+                opt.zero_grad()
+                loss = nwl(x, target, weight)
+                (loss * 1024.0).backward()
+                opt.grads.arena.mul_(1.0 / 1024.0)
+                opt.step()
+                losses.append(float(loss.detach()))
+        finally:
+            T.repack_weights = real
+        return losses, opt.flat.clone(), refreshed
+
+    la, pa, ra = run(True)
+    lb, pb, _ = run(False)
+    assert ra[0] == 0 and ra[1] > 500 and ra[2] == ra[1]  # step one packs per layer, later steps refresh all at once
+    assert la == lb and torch.equal(pa, pb)
+
+
 def test_maxpool_bwd_and_stem_wgrad_vs_torch():
     g = torch.Generator().manual_seed(8)
     x = torch.randn(3, 5, 18, 14, generator=g)

@@ -14,7 +14,7 @@ for c, h, w in ((32, 64, 48), (64, 32, 24), (128, 16, 12), (256, 8, 6), (64, 64,
     g, b = torch.ones(c, device=dev), torch.zeros(c, device=dev)
     mean, invstd, dg, db = (torch.empty(c, device=dev) for _ in range(4))
     mm, mv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
-    nb = lib.mp_bn_workspace_bytes(c); ws = torch.empty(nb // 4 + 1, device=dev)
+    nb = lib.mp_bn_workspace_bytes(c); ws = torch.zeros(nb // 4 + 1, device=dev)
     def fwd():
         _lib.check(lib.mp_f16_bn_train_fwd(_lib.ptr(z), _lib.ptr(g), _lib.ptr(b), _lib.ptr(res), _lib.ptr(y), _lib.ptr(mean), _lib.ptr(invstd),
                                            _lib.ptr(mm), _lib.ptr(mv), n, c, h * w, 1e-5, 0.9, 1, _lib.ptr(ws), nb, _lib.stream()), "f")
