@@ -1,0 +1,357 @@
+// Fused BasicBlock (hrnet.py:30-83 in eval mode) on the fp16 matrix cores for the 32-channel high-resolution branch:
+//
+//     out = relu(bn2(conv3x3(relu(bn1(conv3x3(x))))) + x)          x, out: channel-blocked fp16 [N][4][H][W][8]
+//
+// One workgroup owns R output rows of one image.  It stages rows y0-2 .. y0+R+1 of x (zero halo) and the first weight set in
+// LDS, computes the R+2 intermediate rows y0-1 .. y0+R straight into a second LDS tile (fp32 accumulate, folded BatchNorm,
+// ReLU, ONE rounding to fp16 - exactly what the two-launch path stores to HBM), swaps the second weight set in (fetched into
+// registers under the first MFMA loop) and computes the R output rows, taking the identity from the staged input tile.
+// The intermediate tensor never leaves the CU: per block 1 read + 1 write of the activation instead of 3 reads + 2 writes,
+// which is what bounds this branch in fp16 (arithmetic intensity 144 FLOP/B unfused vs a ridge of ~310).
+// Same MFMA operand mapping, k order and epilogue arithmetic as conv_f16_kernel, so the result is bit-identical to
+// mp_f16_conv2d_fwd x 2.  Wider blocks do not fit: two resident weight sets + both tiles exceed the LDS of two workgroups
+// per CU from C = 64 on, and those branches sit at or above the ridge anyway.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "conv_f16.h"
+#include "conv_f16_dev.h"
+
+namespace mp {
+
+namespace {
+
+constexpr int kBlkCT = 32;              // output channels = one cout tile of two 16-row MFMA tiles per wave
+constexpr int kBlkWUnits = 9 * 4 * kBlkCT;  // 16-byte units of one packed 32x32x3x3 weight set
+constexpr int kBlkNI = 8, kBlkNW = 5;
+
+template <int PS1, int PS2>
+__global__ __launch_bounds__(256, 2) void basicblock_f16_kernel(const BlockF16Params p) {
+    constexpr int CS = 2, CT = kBlkCT;
+    extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
+    u32x4* __restrict__ lds_in = smem16;
+    u32x4* __restrict__ lds_mid = smem16 + 4 * p.plane_in;
+    u32x4* __restrict__ lds_w = lds_mid + 4 * p.plane_mid;
+    // [scale1 | shift1 | scale2 | shift2] x 32 fp32 (the epilogues read them back with one ds_read_b128 each: no global
+    // latency inside the tile loop, no registers held across it), then one unit that masked LDS writes land in (branch-free)
+    f32x4* __restrict__ lds_bn = reinterpret_cast<f32x4*>(lds_w + kBlkWUnits);
+    const int dummy = 4 * (p.plane_in + p.plane_mid) + kBlkWUnits + 32;  // unit index from lds_in
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane >> 4, lr = lane & 15;
+
+    int b = blockIdx.x;  // XCD-aware workgroup id: every XCD walks a contiguous run of tiles
+    {
+        const int nb = p.total_blocks, q8 = nb >> 3, r8 = nb & 7, xcd = b & 7, j = b >> 3;
+        b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
+    }
+    const int t_begin = b * p.tiles_per_wg, t_end = min(t_begin + p.tiles_per_wg, p.tiles_total);
+    const int HW = p.H * p.W;
+
+    {
+        const int n16 = 4 * (p.plane_in + p.plane_mid);
+        const u32x4 zero = (u32x4){0u, 0u, 0u, 0u};
+        for (int i = tid; i < n16; i += 256) lds_in[i] = zero;  // halo columns stay zero for the whole run
+        if (tid < 32) {
+            const float* src = tid < 8 ? p.scale1 : tid < 16 ? p.shift1 : tid < 24 ? p.scale2 : p.shift2;
+            lds_bn[tid] = *reinterpret_cast<const f32x4*>(src + 4 * (tid & 7));
+        }
+    }
+
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x, (size_t)p.N * 4 * HW * 16);
+    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(p.out, (size_t)p.N * 4 * HW * 16);
+    const __amdgpu_buffer_rsrc_t rs_w1 = make_rsrc(p.w1, (size_t)kBlkWUnits * 16);
+    const __amdgpu_buffer_rsrc_t rs_w2 = make_rsrc(p.w2, (size_t)kBlkWUnits * 16);
+
+    // ---- tile-independent addressing
+    // input staging unit i of this thread: LDS slot, source row within the tile, source offset without the tile's origin
+    int idst[kBlkNI];
+    unsigned isrc[kBlkNI];  // (row within the tile) << 28 | 16-byte unit offset of (plane, column)
+    const int rows_in = p.R + 4;
+#pragma unroll
+    for (int i = 0; i < kBlkNI; ++i) {
+        const unsigned u = tid + 256 * i;
+        idst[i] = dummy;
+        isrc[i] = 0;
+        if (u < (unsigned)p.in_units) {
+            const unsigned pl = fastdiv(u, rows_in * p.W, p.magic_rw);
+            const unsigned rem = u - pl * rows_in * p.W;
+            const unsigned r = fastdiv(rem, p.W, p.magic_w);
+            const unsigned xu = rem - r * p.W;
+            idst[i] = (int)(pl * p.plane_in + r * p.Wp + 1 + xu);
+            isrc[i] = (r << 28) | (pl * HW + xu);
+        }
+    }
+    int a_off[CS];
+#pragma unroll
+    for (int cs = 0; cs < CS; ++cs) a_off[cs] = lq * CT + cs * 16 + lr;
+    // few persistent registers per pixel tile (the run keeps the next tile's rows in registers too): everything else is
+    // re-derived at its single use
+    int m_pack[PS1];  // conv1 pixel: (row << 16) | slot in a padded tile plane (row * Wp + col + 1); -1 = beyond the tile
+#pragma unroll
+    for (int ps = 0; ps < PS1; ++ps) {
+        const unsigned pl = (unsigned)((wave * PS1 + ps) * 16 + lr);
+        const unsigned r = fastdiv(pl, p.W, p.magic_w);
+        const unsigned col = pl - r * p.W;
+        m_pack[ps] = pl < (unsigned)p.M1 ? (int)((r << 16) | (r * p.Wp + col + 1)) : -1;
+    }
+    int o_pack[PS2];  // conv2 pixel: (row << 16) | col; -1 = beyond the tile
+#pragma unroll
+    for (int ps = 0; ps < PS2; ++ps) {
+        const unsigned pl = (unsigned)((wave * PS2 + ps) * 16 + lr);
+        const unsigned r = fastdiv(pl, p.W, p.magic_w);
+        const unsigned col = pl - r * p.W;
+        o_pack[ps] = pl < (unsigned)p.M2 ? (int)((r << 16) | col) : -1;
+    }
+
+    u32x4 vin[kBlkNI], vw[kBlkNW];
+    auto load_input = [&](int t) {  // rows outside the image / tiles beyond the run arrive as zeros and are stored as such
+        const int ty = t % p.tiles_y, n = t / p.tiles_y;
+        const int yb = ty * p.R - 2;
+        const unsigned base = ((unsigned)n * 4 * HW + yb * p.W) * 16u;
+#pragma unroll
+        for (int i = 0; i < kBlkNI; ++i) {
+            if (i >= p.ni_used) break;
+            const int row = (int)(isrc[i] >> 28), yin = yb + row;
+            const bool ok = idst[i] != dummy && yin >= 0 && yin < p.H && t < t_end;
+            vin[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? base + ((isrc[i] & 0x0FFFFFFFu) + (unsigned)row * p.W) * 16u : kOob, 0, 0);
+        }
+    };
+    auto store_input = [&]() {
+#pragma unroll
+        for (int i = 0; i < kBlkNI; ++i) {
+            if (i >= p.ni_used) break;
+            lds_in[idst[i]] = vin[i];
+        }
+    };
+    auto load_weights = [&](const __amdgpu_buffer_rsrc_t rs) {
+#pragma unroll
+        for (int i = 0; i < kBlkNW; ++i) {
+            const int u = tid + 256 * i;
+            vw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, u < kBlkWUnits ? (unsigned)u * 16u : kOob, 0, 0);
+        }
+    };
+    auto store_weights = [&]() {
+#pragma unroll
+        for (int i = 0; i < kBlkNW; ++i) {
+            const int u = tid + 256 * i;
+            if (u < kBlkWUnits) lds_w[u] = vw[i];
+        }
+    };
+
+    // one 3x3 conv over an LDS tile: 9 k-steps of 32 channels, operands fetched one k-step ahead
+    auto mma9 = [&](const u32x4* __restrict__ lin, auto& acc, const auto& b_off, auto ps_tag) {
+        constexpr int PS = decltype(ps_tag)::value;
+        u32x4 bv[PS], av[CS];
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps) bv[ps] = lin[b_off[ps]];
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs) av[cs] = lds_w[a_off[cs]];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int tn = (t + 1 < 9) ? t + 1 : 0;  // the final prefetch re-reads a valid k-step (discarded)
+            const int in_off = (tn / 3) * p.Wp + (tn % 3);
+            const int w_off = tn * 4 * CT;
+            u32x4 bn[PS], an[CS];
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps) bn[ps] = lin[b_off[ps] + in_off];
+#pragma unroll
+            for (int cs = 0; cs < CS; ++cs) an[cs] = lds_w[a_off[cs] + w_off];
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps)
+#pragma unroll
+                for (int cs = 0; cs < CS; ++cs)
+                    acc[ps][cs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[cs]),
+                                                                          __builtin_bit_cast(f16x8, bv[ps]), acc[ps][cs], 0, 0, 0);
+            {
+                constexpr int NR = PS + CS, NM = PS * CS, NPAIR = NR < NM ? NR : NM;
+#pragma unroll
+                for (int i = 0; i < NPAIR; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+                }
+                if (NM > NPAIR) __builtin_amdgcn_sched_group_barrier(0x008, NM - NPAIR, 0);
+                if (NR > NPAIR) __builtin_amdgcn_sched_group_barrier(0x100, NR - NPAIR, 0);
+            }
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps) bv[ps] = bn[ps];
+#pragma unroll
+            for (int cs = 0; cs < CS; ++cs) av[cs] = an[cs];
+        }
+    };
+
+    load_input(t_begin);
+    load_weights(rs_w1);
+    __syncthreads();  // zero fill complete before the copies land
+    store_input();
+    store_weights();
+    __syncthreads();
+
+    u32x2* __restrict__ mid8 = reinterpret_cast<u32x2*>(lds_mid);
+    const u32x2* __restrict__ in8 = reinterpret_cast<const u32x2*>(lds_in);
+    for (int t = t_begin; t < t_end; ++t) {
+        const int ty = t % p.tiles_y, n = t / p.tiles_y;
+        const int y0 = ty * p.R;
+        load_weights(rs_w2);  // in flight under the first MFMA loop
+
+        // ---- conv1 + bn1 + relu over the R+2 intermediate rows -> lds_mid; rows outside the image are conv2's zero padding
+        {
+            f32x4 acc[PS1][CS];
+#pragma unroll
+            for (int ps = 0; ps < PS1; ++ps)
+#pragma unroll
+                for (int cs = 0; cs < CS; ++cs) acc[ps][cs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            int b1_off[PS1];
+#pragma unroll
+            for (int ps = 0; ps < PS1; ++ps) b1_off[ps] = lq * p.plane_in + (m_pack[ps] >= 0 ? (m_pack[ps] & 0xFFFF) - 1 : 0);
+            mma9(lds_in, acc, b1_off, std::integral_constant<int, PS1>{});
+#pragma unroll
+            for (int cs = 0; cs < CS; ++cs) {
+                const int plane = cs * 2 + (lq >> 1);
+                const f32x4 sc = lds_bn[cs * 4 + lq], sh = lds_bn[8 + cs * 4 + lq];
+#pragma unroll
+                for (int ps = 0; ps < PS1; ++ps) {
+                    f32x4 v = acc[ps][cs] * sc + sh;
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    f16x4 o = (f16x4){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                    const int ym = y0 - 1 + (m_pack[ps] >> 16);
+                    if (ym < 0 || ym >= p.H) o = (f16x4){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                    const int slot = m_pack[ps] >= 0 ? plane * p.plane_mid + (m_pack[ps] & 0xFFFF) : dummy - 4 * p.plane_in;
+                    mid8[slot * 2 + (lq & 1)] = __builtin_bit_cast(u32x2, o);
+                }
+            }
+        }
+        __syncthreads();  // every wave is done with the first weight set; the intermediate tile is complete
+        store_weights();
+        __syncthreads();
+        if (t + 1 < t_end) {  // in flight under the second MFMA loop: the next tile's rows and the first weight set again
+            load_input(t + 1);
+            load_weights(rs_w1);
+        }
+
+        // ---- conv2 + bn2 + identity + relu over the R output rows -> HBM
+        {
+            f32x4 acc[PS2][CS];
+#pragma unroll
+            for (int ps = 0; ps < PS2; ++ps)
+#pragma unroll
+                for (int cs = 0; cs < CS; ++cs) acc[ps][cs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            int b2_off[PS2];
+#pragma unroll
+            for (int ps = 0; ps < PS2; ++ps)
+                b2_off[ps] = lq * p.plane_mid + (o_pack[ps] >= 0 ? (o_pack[ps] >> 16) * p.Wp + (o_pack[ps] & 0xFFFF) : 0);
+            mma9(lds_mid, acc, b2_off, std::integral_constant<int, PS2>{});
+            const unsigned img = (unsigned)n * 4 * HW * 16u;
+#pragma unroll
+            for (int cs = 0; cs < CS; ++cs) {
+                const int plane = cs * 2 + (lq >> 1);
+                const f32x4 sc = lds_bn[16 + cs * 4 + lq], sh = lds_bn[24 + cs * 4 + lq];
+#pragma unroll
+                for (int ps = 0; ps < PS2; ++ps) {
+                    f32x4 v = acc[ps][cs] * sc + sh;
+                    const int orow = o_pack[ps] >= 0 ? (o_pack[ps] >> 16) : 0, ocol = o_pack[ps] >= 0 ? (o_pack[ps] & 0xFFFF) : 0;
+                    const f16x4 h = __builtin_bit_cast(f16x4, in8[(plane * p.plane_in + (orow + 2) * p.Wp + ocol + 1) * 2 + (lq & 1)]);
+                    v += (f32x4){(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    const f16x4 o = (f16x4){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                    const int yo = y0 + orow;
+                    const unsigned off = (o_pack[ps] >= 0 && yo < p.H) ? img + ((unsigned)plane * HW + yo * p.W + ocol) * 16u + (lq & 1) * 8u : kOob;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs_o, off, 0, 0);
+                }
+            }
+        }
+        if (t + 1 < t_end) {
+            __syncthreads();  // input tile (identity reads), intermediate tile and second weight set are free
+            store_input();
+            store_weights();
+            __syncthreads();
+        }
+    }
+}
+
+template <int PS1, int PS2>
+int launch_block(const BlockF16Params& p, size_t lds_bytes, hipStream_t s) {
+    auto kern = basicblock_f16_kernel<PS1, PS2>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(256), lds_bytes, s, p);
+    return check_launch();
+}
+
+}  // namespace
+
+int blockf16_build(const void* x, const void* w1, const float* scale1, const float* shift1, const void* w2, const float* scale2,
+                   const float* shift2, void* out, int n, int c, int h, int w, int rows, BlockF16Launch& L) {
+    if (!x || !w1 || !w2 || !scale1 || !shift1 || !scale2 || !shift2 || !out) return MP_ERR_NULL;
+    if (n <= 0 || h <= 0 || w <= 0) return MP_ERR_SHAPE;
+    if (c <= 24 || c > 32) return MP_ERR_UNSUPPORTED;  // exactly four 8-channel blocks (channels beyond c are zero padding)
+    if (rows < 0) return MP_ERR_SHAPE;
+    if (x == out) return MP_ERR_UNSUPPORTED;  // neighbouring tiles read the halo rows this tile would overwrite
+    BlockF16Params p{};
+    p.x = x; p.w1 = w1; p.w2 = w2; p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2; p.out = out;
+    p.N = n; p.H = h; p.W = w;
+    p.Wp = w + 2;
+    int best = 0, ps1 = 0, ps2 = 0;
+    for (int R = (rows > 0 ? rows : 6); R >= 1; --R) {
+        if (R > h && R > 1) continue;
+        const int m1 = (R + 2) * w, m2 = R * w;
+        const int t1 = ((m1 + 15) / 16 + 3) / 4, t2 = ((m2 + 15) / 16 + 3) / 4;
+        if (t1 > 6 || t2 > 5) continue;
+        if (4 * (R + 4) * w > kBlkNI * 256) continue;
+        const size_t bytes = ((size_t)4 * (round_up((R + 4) * p.Wp, 16) + round_up((R + 2) * p.Wp, 16)) + kBlkWUnits + 33) * 16;
+        if (bytes > 80 * 1024) continue;
+        best = R; ps1 = t1; ps2 = t2;
+        break;
+    }
+    if (best == 0) return MP_ERR_UNSUPPORTED;
+    p.R = best;
+    p.plane_in = round_up((best + 4) * p.Wp, 16);
+    p.plane_mid = round_up((best + 2) * p.Wp, 16);
+    p.M1 = (best + 2) * w;
+    p.M2 = best * w;
+    p.in_units = 4 * (best + 4) * w;
+    p.tiles_y = (h + best - 1) / best;
+    p.tiles_total = p.tiles_y * n;
+    // persistent workgroups: two per CU walk runs of tiles, the next tile's rows in flight under the current MFMA loops
+    int groups = 512;
+    if (const char* e = getenv("MP_F16_BLOCK_GROUPS")) {  // tests: force long tile runs on small problems
+        const int v = atoi(e);
+        if (v >= 1) groups = v;
+    }
+    p.tiles_per_wg = (p.tiles_total + groups - 1) / groups;
+    p.total_blocks = (p.tiles_total + p.tiles_per_wg - 1) / p.tiles_per_wg;
+    p.ni_used = (p.in_units + 255) / 256;
+    if ((size_t)n * 4 * h * w * 16 > 0x7FFFFFF0u) return MP_ERR_UNSUPPORTED;  // 32-bit buffer offsets
+    p.magic_w = magic_of((unsigned)w);
+    p.magic_rw = magic_of((unsigned)((best + 4) * w));
+    L.p = p;
+    L.small = (ps1 <= 5 && ps2 <= 3) ? 1 : 0;
+    L.lds_bytes = ((size_t)4 * (p.plane_in + p.plane_mid) + kBlkWUnits + 32 + 1) * 16;
+    return MP_OK;
+}
+
+int blockf16_launch(const BlockF16Launch& L, hipStream_t s) {
+    return L.small ? launch_block<5, 3>(L.p, L.lds_bytes, s) : launch_block<6, 5>(L.p, L.lds_bytes, s);
+}
+
+}  // namespace mp
+
+using namespace mp;
+
+extern "C" {
+
+int mp_f16_basicblock_fwd(const void* x, const void* packed_w1, const float* scale1, const float* shift1, const void* packed_w2,
+                          const float* scale2, const float* shift2, void* out, int n, int c, int h, int w, int rows,
+                          mp_stream_t stream) {
+    BlockF16Launch L{};
+    const int rc = blockf16_build(x, packed_w1, scale1, shift1, packed_w2, scale2, shift2, out, n, c, h, w, rows, L);
+    if (rc != MP_OK) return rc;
+    return blockf16_launch(L, as_stream(stream));
+}
+
+}  // extern "C"

@@ -55,6 +55,33 @@ inline bool f16_variant_mt(int v) { return (v >= F_MT2_BASE && v < F_CT16_PT192)
 inline int f16_variant_mt_occ(int v) { return (v >= F_MT1_BASE && v < F_CT16_PT192) || v == F_CT16_PT192_MT1 ? 1 : 2; }
 bool f16_variant_light(int v);
 
+// fused BasicBlock of the 32-channel branch (basicblock_f16.hip)
+struct BlockF16Params {
+    const void* x;
+    const void* w1;
+    const void* w2;
+    const float* scale1;
+    const float* shift1;
+    const float* scale2;
+    const float* shift2;
+    void* out;
+    int N, H, W;
+    int R, Wp, plane_in, plane_mid;  // LDS planes in 16-byte units (multiples of 16: conflict-free ds_read_b128)
+    int M1, M2;                      // intermediate / output pixels of a tile
+    int in_units;                    // staged 16-byte units of the input tile (4 planes x (R+4) rows x W)
+    int tiles_y, tiles_total, tiles_per_wg, total_blocks, ni_used;
+    unsigned magic_w, magic_rw;      // / W, / ((R+4) * W)
+};
+
+struct BlockF16Launch {
+    BlockF16Params p;
+    int small;  // 1: the <5,3> pixel-tile build suffices, 0: <6,5>
+    size_t lds_bytes;
+};
+int blockf16_build(const void* x, const void* w1, const float* scale1, const float* shift1, const void* w2, const float* scale2,
+                   const float* shift2, void* out, int n, int c, int h, int w, int rows, BlockF16Launch& L);
+int blockf16_launch(const BlockF16Launch& L, hipStream_t s);
+
 int f16_build_launch(const mp_conv_desc* desc, int variant, const void* x, const void* w, const float* scale,
                      const float* shift, const void* res1, const void* res2, void* out, ConvF16Launch& L);
 int f16_launch(const ConvF16Launch& L, hipStream_t s);

@@ -367,6 +367,29 @@ class Plan:
                                     h=h, w=w, n=n, macs=n * ho * wo * conv.out_channels * cin * k * k))
         return out
 
+    def fuses_basic_block(self, x: torch.Tensor, conv1: Conv2d, conv2: Conv2d) -> bool:
+        """The fused fp16 BasicBlock kernel covers the 32-channel branch (four 8-channel blocks, 3x3 stride 1 both convs);
+        ``MINDPOSE_FUSE_BLOCK=0`` keeps the two-launch path."""
+        if not isinstance(x, ActC8) or os.environ.get("MINDPOSE_FUSE_BLOCK", "1") == "0":
+            return False
+        c = x.shape[1]
+        return (24 < c <= 32 and all(cv.in_channels == c and cv.out_channels == c and cv.kernel_size == 3 and cv.stride == 1
+                                     and cv.padding == 1 and cv.bias is None for cv in (conv1, conv2)))
+
+    def basic_block(self, x: torch.Tensor, conv1: Conv2d, bn1: BatchNorm2d, conv2: Conv2d, bn2: BatchNorm2d) -> torch.Tensor:
+        """relu(bn2(conv2(relu(bn1(conv1 x)))) + x) in ONE launch (mp_f16_basicblock_fwd): the intermediate tensor stays in LDS;
+        bit-identical to the two conv launches."""
+        n, c, h, w = x.shape
+        out = self.alloc(n, c, h, w)
+        p1, p2 = (self._pack(cv.weight, c, c, 3, False, 0, 0, True) for cv in (conv1, conv2))
+        (s1, b1), (s2, b2) = self._affine(c, bn1, None, True), self._affine(c, bn2, None, True)
+        _lib.check(self.lib.mp_plan_add_basicblock_f16(self.handle, _lib.ptr(x), _lib.ptr(p1), _lib.ptr(s1), _lib.ptr(b1),
+                                                       _lib.ptr(p2), _lib.ptr(s2), _lib.ptr(b2), _lib.ptr(out), n, c, h, w, 0),
+                   "mp_plan_add_basicblock_f16")
+        self.layer_info.append(dict(kind="basicblock_f16", k=3, stride=1, cin=c, cout=c, h=h, w=w, n=n,
+                                    macs=2 * n * h * w * c * c * 9))
+        return out
+
     def deconv4x4s2(self, x: torch.Tensor, deconv: Conv2dTranspose, bn: BatchNorm2d, relu: bool = True) -> torch.Tensor:
         """Conv2dTranspose(k=4, s=2, p=1) + BN + ReLU as four 2x2 sub-pixel phase convolutions."""
         half = isinstance(x, ActC8)

@@ -266,3 +266,54 @@ def test_config5_w48_384x288_udp_dark_flip_fp16():
     px = float(scale.max()) * 200.0 / 72.0  # image pixels per heat-map pixel (UDP, 96x72 maps)
     dd = np.abs(preds.cpu().numpy()[..., :2] - p32.cpu().numpy()[..., :2])
     assert np.mean(dd < 0.25 * px) > 0.9
+
+
+def _block_pair(n, c, h, w, seed):
+    """Inputs of one BasicBlock plus the two-launch result (mp_f16_conv2d_fwd x 2, heuristic variant)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, c, h, w, generator=g)
+    ws = [torch.randn(c, c, 3, 3, generator=g) / (c * 9) ** 0.5 for _ in range(2)]
+    affine = [(torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1) for _ in range(2)]
+    xa = _to_c8(x)
+    packed, scs, shs = [], [], []
+    for wt, (scale, shift) in zip(ws, affine):
+        nb = LIB.mp_f16_packed_weight_bytes(c, c, 3, 3)
+        pk = torch.empty(nb // 2, device=DEV, dtype=torch.float16)
+        _lib.check(LIB.mp_f16_pack_weight(_lib.ptr(wt.to(DEV)), _lib.ptr(pk), c, c, 3, 3, 0, 0, 0, _lib.stream()), "pack")
+        packed.append(pk)
+        padc = (-c) % 16
+        scs.append(torch.cat([scale, torch.zeros(padc)]).to(DEV))
+        shs.append(torch.cat([shift, torch.zeros(padc)]).to(DEV))
+    d = _lib.ConvDesc(n=n, cin=c, h=h, w=w, cout=c, kh=3, kw=3, stride=1, pad_top=1, pad_left=1, conv_h=h, conv_w=w, out_h=h,
+                      out_w=w, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=1, tap_dilation_unused=0)
+    mid, two = ActC8(n, c, h, w, DEV), ActC8(n, c, h, w, DEV)
+    _lib.check(LIB.mp_f16_conv2d_fwd(ctypes.byref(d), -1, _lib.ptr(xa), _lib.ptr(packed[0]), _lib.ptr(scs[0]), _lib.ptr(shs[0]),
+                                     None, None, _lib.ptr(mid), _lib.stream()), "conv1")
+    _lib.check(LIB.mp_f16_conv2d_fwd(ctypes.byref(d), -1, _lib.ptr(mid), _lib.ptr(packed[1]), _lib.ptr(scs[1]), _lib.ptr(shs[1]),
+                                     _lib.ptr(xa), None, _lib.ptr(two), _lib.stream()), "conv2")
+    return xa, packed, scs, shs, two
+
+
+@pytest.mark.parametrize("shape", [(3, 32, 64, 48), (2, 32, 16, 12), (2, 30, 21, 17), (1, 32, 5, 40), (5, 32, 7, 8)])
+@pytest.mark.parametrize("rows", [0, 4, 1])
+def test_fused_basicblock_equals_two_convs(shape, rows):
+    """mp_f16_basicblock_fwd keeps the intermediate tile in LDS; same operands, k order and rounding points as the two-launch
+    path, so the result is bit-identical - at the HRNet branch shape, on ragged extents (partial last row band, pixel counts
+    that do not fill the 16-wide MFMA tiles) and with padding channels."""
+    n, c, h, w = shape
+    xa, packed, scs, shs, two = _block_pair(n, c, h, w, seed=h * w + rows)
+    fused = ActC8(n, c, h, w, DEV)
+    fused.c8_tensor.fill_(7.0)
+    _lib.check(LIB.mp_f16_basicblock_fwd(_lib.ptr(xa), _lib.ptr(packed[0]), _lib.ptr(scs[0]), _lib.ptr(shs[0]), _lib.ptr(packed[1]),
+                                         _lib.ptr(scs[1]), _lib.ptr(shs[1]), _lib.ptr(fused), n, c, h, w, rows, _lib.stream()),
+               "mp_f16_basicblock_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(fused.c8_tensor, two.c8_tensor)
+
+
+def test_fused_basicblock_rejects_other_widths():
+    xa, packed, scs, shs, two = _block_pair(1, 32, 8, 8, seed=1)
+    args = (_lib.ptr(packed[0]), _lib.ptr(scs[0]), _lib.ptr(shs[0]), _lib.ptr(packed[1]), _lib.ptr(scs[1]), _lib.ptr(shs[1]))
+    assert LIB.mp_f16_basicblock_fwd(_lib.ptr(xa), *args, _lib.ptr(two), 1, 64, 8, 8, 0, _lib.stream()) == -3  # MP_ERR_UNSUPPORTED
+    assert LIB.mp_f16_basicblock_fwd(_lib.ptr(xa), *args, _lib.ptr(xa), 1, 32, 8, 8, 0, _lib.stream()) == -3  # MP_ERR_UNSUPPORTED
+    assert LIB.mp_f16_basicblock_fwd(None, *args, _lib.ptr(two), 1, 32, 8, 8, 0, _lib.stream()) == -1  # MP_ERR_NULL
