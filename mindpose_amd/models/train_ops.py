@@ -225,12 +225,13 @@ _BN16_WS = {}
 
 
 def _bn16_workspace(lib, c, device):
-    """ONE persistent BatchNorm workspace per device (all calls are ordered on the current stream): no allocation per layer."""
+    """ONE persistent BatchNorm workspace per (device, stream): no allocation per layer."""
     need = lib.mp_bn_workspace_bytes(c)
-    ws = _BN16_WS.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)  # calls on one stream are ordered; streams do not share
+    ws = _BN16_WS.get(key)
     if ws is None or ws.numel() * 4 < need:
         ws = torch.zeros(max(need, lib.mp_bn_workspace_bytes(2048)) // 4 + 1, device=device, dtype=torch.float32)
-        _BN16_WS[device] = ws
+        _BN16_WS[key] = ws
     return ws, ws.numel() * 4
 
 
