@@ -148,6 +148,9 @@ __global__ __launch_bounds__(256, 2) void basicblock_f16_kernel(const BlockF16Pa
         for (int ps = 0; ps < PS; ++ps) bv[ps] = lin[b_off[ps]];
 #pragma unroll
         for (int cs = 0; cs < CS; ++cs) av[cs] = lds_w[a_off[cs]];
+        // the nine k-steps are one straight-line block: without this fence the scheduler fills step 0's "DS read" slots with
+        // the reads above and every later read lands right before its consumer (no prefetch distance at all)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int tn = (t + 1 < 9) ? t + 1 : 0;  // the final prefetch re-reads a valid k-step (discarded)
@@ -155,9 +158,9 @@ __global__ __launch_bounds__(256, 2) void basicblock_f16_kernel(const BlockF16Pa
             const int w_off = tn * 4 * CT;
             u32x4 bn[PS], an[CS];
 #pragma unroll
-            for (int ps = 0; ps < PS; ++ps) bn[ps] = lin[b_off[ps] + in_off];
+            for (int cs = 0; cs < CS; ++cs) an[cs] = lds_w[a_off[cs] + w_off];  // weights first: the next step's first MFMA needs them
 #pragma unroll
-            for (int cs = 0; cs < CS; ++cs) an[cs] = lds_w[a_off[cs] + w_off];
+            for (int ps = 0; ps < PS; ++ps) bn[ps] = lin[b_off[ps] + in_off];
 #pragma unroll
             for (int ps = 0; ps < PS; ++ps)
 #pragma unroll

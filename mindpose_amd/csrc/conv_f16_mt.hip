@@ -203,9 +203,9 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Para
                     const int w_off = ((tp + 1 < T) ? w_q : qn * T * 4 * CT) + tn2 * 4 * CT;
                     u32x4 bn[PS], an[CS];
 #pragma unroll
-                    for (int ps = 0; ps < PS; ++ps) bn[ps] = lin[b_off[ps] + in_off];
+                    for (int cs = 0; cs < CS; ++cs) an[cs] = lw[a_off[cs] + w_off];  // weights first: the next step's first MFMA needs them
 #pragma unroll
-                    for (int cs = 0; cs < CS; ++cs) an[cs] = lw[a_off[cs] + w_off];
+                    for (int ps = 0; ps < PS; ++ps) bn[ps] = lin[b_off[ps] + in_off];
 #pragma unroll
                     for (int ps = 0; ps < PS; ++ps)
 #pragma unroll
