@@ -230,6 +230,15 @@ int mp_fuse_upsample_sum_bwd(const float* dy_dev, const float* out_dev, float* d
 int mp_adamw_step(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, size_t count,
                   float lr, float beta1, float beta2, float eps, float weight_decay, mp_stream_t stream);
 
+/* The other optimizers registered by mindpose/optim/optim_factory.py:9-14, on the same flat fp32 arenas.
+ * kind 1 = mindspore.nn.Adam (bias-corrected; hyper = {beta1, beta2, eps, beta1^t, beta2^t}; state1 = m, state2 = v),
+ * 2 = nn.SGD (hyper = {momentum, dampening, nesterov, first_step}; state1 = momentum buffer, may be NULL when momentum == 0),
+ * 3 = nn.Momentum (hyper = {momentum, use_nesterov}; state1 = accumulator), 4 = nn.Adagrad (state1 = accumulator, initialised
+ * by the caller).  The gradient enters as g * grad_scale + weight_decay * p (static loss scale and L2 decay of those cells).
+ * Update rules from the MindSpore documentation [MS-knowledge; no reference test pins them]. */
+int mp_optimizer_step(int kind, float* param_dev, const float* grad_dev, float* state1_dev, float* state2_dev, size_t count,
+                      float lr, float grad_scale, float weight_decay, const float hyper[5], mp_stream_t stream);
+
 /* Conv2d weight gradient (training backward of every conv of hrnet.py): dW[co,ci,ky,kx] = sum_{n,y,x}
  * dz[n,co,y,x] * x[n,ci,y*s+ky-p,x*s+kx-p] for k in {1,3}, s in {1,2}, p = k/2 (desc as for the forward conv; its
  * output-mapping fields are ignored).  fp32 MFMA, pixel axis split over workgroups into slabs that are summed in a

@@ -212,6 +212,49 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
+// The other optimizers the reference registers (mindpose/optim/optim_factory.py:9-14), same flat-arena form.  Update rules as
+// documented for mindspore.nn.{Adam, SGD, Momentum, Adagrad} [MS-knowledge: no reference test pins them]; the gradient is
+// first divided by the static loss scale and given the L2 term (g = g * grad_scale + wd * p), as those optimizers do.
+//   kind 1 Adam:     m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps)
+//        (h: b1, b2, eps, b1^t, b2^t)
+//   kind 2 SGD:      buf = g on the first step, else mom buf + (1-damp) g; d = nesterov ? g + mom buf : buf (d = g when
+//        mom == 0); p -= lr d      (h: mom, damp, nesterov, first_step)
+//   kind 3 Momentum: acc = mom acc + g; p -= lr (nesterov ? g + mom acc : acc)      (h: mom, nesterov)
+//   kind 4 Adagrad:  acc += g^2; p -= lr g / sqrt(acc)      (accumulator initialised by the caller, 0.1 in MindSpore)
+template <int KIND>
+__global__ __launch_bounds__(256) void optimizer_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ s1,
+                                                        float* __restrict__ s2, size_t n, float lr, float grad_scale, float wd,
+                                                        float h0, float h1, float h2, float h3, float h4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float w = p[i];
+        const float gi = g[i] * grad_scale + wd * w;
+        if (KIND == 1) {
+            const float mi = h0 * s1[i] + (1.f - h0) * gi;
+            const float vi = h1 * s2[i] + (1.f - h1) * gi * gi;
+            s1[i] = mi;
+            s2[i] = vi;
+            const float lr_t = lr * sqrtf(1.f - h4) / (1.f - h3);
+            p[i] = w - lr_t * mi / (sqrtf(vi) + h2);
+        } else if (KIND == 2) {
+            float d = gi;
+            if (h0 != 0.f) {
+                const float buf = h3 != 0.f ? gi : h0 * s1[i] + (1.f - h1) * gi;
+                s1[i] = buf;
+                d = h2 != 0.f ? gi + h0 * buf : buf;
+            }
+            p[i] = w - lr * d;
+        } else if (KIND == 3) {
+            const float acc = h0 * s1[i] + gi;
+            s1[i] = acc;
+            p[i] = w - lr * (h1 != 0.f ? gi + h0 * acc : acc);
+        } else {
+            const float acc = s1[i] + gi * gi;
+            s1[i] = acc;
+            p[i] = w - lr * gi / sqrtf(acc);
+        }
+    }
+}
+
 // ---- fp16 (amp O2) training: the same BatchNorm passes over channel-blocked fp16 activations [N][C8][HW][8] ------------
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -488,6 +531,26 @@ int mp_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
     return check_launch();
 }
 
+int mp_optimizer_step(int kind, float* param, const float* grad, float* state1, float* state2, size_t count, float lr,
+                      float grad_scale, float weight_decay, const float hyper[5], mp_stream_t stream) {
+    if (!param || !grad || !hyper) return MP_ERR_NULL;
+    if (kind < 1 || kind > 4) return MP_ERR_UNSUPPORTED;
+    if (!state1 && !(kind == 2 && hyper[0] == 0.f)) return MP_ERR_NULL;
+    if (kind == 1 && !state2) return MP_ERR_NULL;
+    if (count == 0) return MP_OK;
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    const dim3 grid((unsigned)blocks), block(256);
+    hipStream_t s = as_stream(stream);
+    const float h0 = hyper[0], h1 = hyper[1], h2 = hyper[2], h3 = hyper[3], h4 = hyper[4];
+    switch (kind) {
+        case 1: hipLaunchKernelGGL(optimizer_kernel<1>, grid, block, 0, s, param, grad, state1, state2, count, lr, grad_scale, weight_decay, h0, h1, h2, h3, h4); break;
+        case 2: hipLaunchKernelGGL(optimizer_kernel<2>, grid, block, 0, s, param, grad, state1, state2, count, lr, grad_scale, weight_decay, h0, h1, h2, h3, h4); break;
+        case 3: hipLaunchKernelGGL(optimizer_kernel<3>, grid, block, 0, s, param, grad, state1, state2, count, lr, grad_scale, weight_decay, h0, h1, h2, h3, h4); break;
+        default: hipLaunchKernelGGL(optimizer_kernel<4>, grid, block, 0, s, param, grad, state1, state2, count, lr, grad_scale, weight_decay, h0, h1, h2, h3, h4); break;
+    }
+    return check_launch();
+}
 
 int mp_f16_bn_train_fwd(const void* z, const float* gamma, const float* beta, const void* res, void* y, float* save_mean,
                         float* save_invstd, float* moving_mean, float* moving_var, int n, int c, int hw, float eps, float momentum,

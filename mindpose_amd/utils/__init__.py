@@ -1,4 +1,4 @@
-from .adamw import AdamWeightDecay, split_decay  # noqa: F401
+from .adamw import SGD, Adagrad, Adam, AdamWeightDecay, Momentum, split_decay  # noqa: F401
 from .grad_allreduce import GradientAverager  # noqa: F401
 from .ckpt import load_checkpoint, load_param_into_net, save_checkpoint  # noqa: F401
 from .graph_step import GraphedTrainStep  # noqa: F401

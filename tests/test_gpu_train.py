@@ -254,8 +254,60 @@ def test_create_optimizer_and_scheduler_drive_the_native_adamw():
     assert lrs == [sched(i) for i in range(6)] and lrs[0] == 0.0 and lrs[2] == 1e-3 and lrs[4] == 1e-3 * 0.1
     # weight decay only through the decay / no-decay grouping, as the reference wires it
     assert create_optimizer(net, "adamw", 1e-3, weight_decay=0.05, filter_bias_and_bn=False).weight_decay == 0.0
-    with pytest.raises(NotImplementedError):
-        create_optimizer(net, name="sgd")
+    with pytest.raises(ValueError, match="Unkown components"):
+        create_optimizer(net, name="lamb")
+
+
+class _TwoParam(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(5)
+        self.weight = torch.nn.Parameter(torch.randn(37, 5, generator=g))
+        self.bias = torch.nn.Parameter(torch.randn(19, generator=g))
+
+
+@pytest.mark.parametrize("name,kwargs", [("adam", {}), ("sgd", dict(momentum=0.9, dampening=0.1)), ("sgd", dict(momentum=0.9, nesterov=True)),
+                                         ("sgd", {}), ("momentum", dict(momentum=0.9)), ("momentum", dict(momentum=0.8, use_nesterov=True)),
+                                         ("adagrad", {})])
+def test_other_registered_optimizers_vs_their_documented_update_rules(name, kwargs):
+    """create_optimizer resolves every name the reference registers (optim_factory.py:9-14); four steps of each on a tiny
+    module against the documented update rule evaluated in fp64 (static loss scale 8, L2 decay on the weight only)."""
+    from mindpose_amd.optim import create_optimizer
+    net = _TwoParam().to(DEV)
+    lr, wd, ls = 0.05, 0.01, 8.0
+    opt = create_optimizer(net, name=name, learning_rate=lr, weight_decay=wd, filter_bias_and_bn=True, loss_scale=ls, overlap=False, **kwargs)
+    ref = {k: v.detach().double().cpu() for k, v in net.named_parameters()}
+    st = {k: [torch.full_like(v, 0.1 if name == "adagrad" else 0.0), torch.zeros_like(v)] for k, v in ref.items()}
+    g = torch.Generator().manual_seed(9)
+    for t in range(1, 5):
+        grads = {k: torch.randn(v.shape, generator=g) for k, v in ref.items()}
+        opt.zero_grad()
+        for k, prm in net.named_parameters():
+            prm.grad.copy_(grads[k].to(DEV))  # p.grad are views of the optimizer's gradient arena
+        opt.step()
+        for k in ref:
+            gi = grads[k].double() / ls + (wd if k == "weight" else 0.0) * ref[k]
+            s1, s2 = st[k]
+            if name == "adam":
+                s1.mul_(0.9).add_(0.1 * gi)
+                s2.mul_(0.999).add_(0.001 * gi * gi)
+                ref[k] = ref[k] - lr * (1 - 0.999 ** t) ** 0.5 / (1 - 0.9 ** t) * s1 / (s2.sqrt() + 1e-8)
+            elif name == "sgd":
+                mom, damp, nest = kwargs.get("momentum", 0.0), kwargs.get("dampening", 0.0), kwargs.get("nesterov", False)
+                d = gi
+                if mom:
+                    s1.copy_(gi if t == 1 else mom * s1 + (1 - damp) * gi)
+                    d = gi + mom * s1 if nest else s1
+                ref[k] = ref[k] - lr * d
+            elif name == "momentum":
+                mom = kwargs["momentum"]
+                s1.mul_(mom).add_(gi)
+                ref[k] = ref[k] - lr * (gi + mom * s1 if kwargs.get("use_nesterov") else s1)
+            else:
+                s1.add_(gi * gi)
+                ref[k] = ref[k] - lr * gi / s1.sqrt()
+    for k, prm in net.named_parameters():
+        assert torch.allclose(prm.detach().cpu().double(), ref[k], rtol=2e-5, atol=2e-6), (name, k)
 
 
 def test_deconv_fp32_autograd_vs_torch():
