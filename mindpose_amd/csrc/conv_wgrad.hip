@@ -285,7 +285,10 @@ static int wgrad_geometry(const mp_conv_desc* d, WgradParams& p, size_t& lds_byt
     if (p.vec) {
         // pipelined kernel: double-buffered tiles; R limited by the per-thread staging registers (NZ = 6, NX = 9
         // 16-B units) and by 2 workgroups per CU (<= 78 KiB LDS)
-        for (;; --R) {
+        // (wide stride-2 layers - the stem's 64->64 conv on 128x96 maps - need 99 KB even for one output row: they run one
+        // workgroup per CU rather than fall back to the scalar-staging kernel, which is 6x slower there)
+        const int r_first = R;
+        for (int budget_kb = 78;; --R) {
             p.R = R;
             p.Rin = (R - 1) * S + KS;
             p.Wp = (p.Wo - 1) * S + KS;
@@ -295,10 +298,14 @@ static int wgrad_geometry(const mp_conv_desc* d, WgradParams& p, size_t& lds_byt
             p.xplane = ((p.Rin * p.Wp + 31) / 32) * 32 + 2;
             p.zpitch = ((R * p.Wo + 31) / 32) * 32 + 2;
             lds_bytes = (size_t)2 * 32 * (p.xplane + p.zpitch) * 4;
-            const bool fits = 32 * p.zq <= 6 * 256 && 32 * p.Rin * p.xw4 <= 9 * 256 && lds_bytes <= 78 * 1024 &&
+            const bool fits = 32 * p.zq <= 6 * 256 && 32 * p.Rin * p.xw4 <= 9 * 256 && lds_bytes <= (size_t)budget_kb * 1024 &&
                               p.zpitch < 65536 && 32 * p.xplane < 65536;
             if (fits) break;
-            if (R == 1) { p.vec = 0; break; }
+            if (R == 1) {
+                if (budget_kb == 78) { budget_kb = 150; R = r_first + 1; continue; }
+                p.vec = 0;
+                break;
+            }
         }
     }
     if (!p.vec) {

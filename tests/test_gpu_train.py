@@ -69,6 +69,7 @@ CONV_TRAIN_CASES = [
     (1, 5, 7, 3, 1, 9, 7, False),
     (2, 256, 256, 3, 1, 8, 6, False),
     (8, 32, 32, 3, 1, 64, 48, False),
+    (2, 64, 64, 3, 2, 128, 96, False),   # stem conv2: the wide stride-2 layer (pipelined wgrad with one workgroup per CU)
 ]
 
 
