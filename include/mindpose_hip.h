@@ -224,6 +224,12 @@ int mp_fuse_upsample_sum_bwd(const float* dy_dev, const float* out_dev, float* d
                              float* dt2_dev, int s2, float* dt3_dev, int s3, int n, int c, int h, int w, int relu,
                              mp_stream_t stream);
 
+/* mp_bn_train_bwd that ALSO adds dgamma / dbeta into dgamma_acc / dbeta_acc (both or neither; the caller's gradient arena) */
+int mp_bn_train_bwd_acc(const float* dy_dev, const float* z_dev, const float* y_dev, const float* gamma_dev,
+                        const float* save_mean_dev, const float* save_invstd_dev, float* dz_dev, float* dres_dev,
+                        float* dgamma_dev, float* dbeta_dev, float* dgamma_acc_dev, float* dbeta_acc_dev, int n, int c, int hw,
+                        int relu, void* workspace_dev, size_t workspace_bytes, mp_stream_t stream);
+
 /* mindspore.nn.AdamWeightDecay (selected by mindpose/optim/optim_factory.py:69-72 for "adamw"): Adam WITHOUT bias
  * correction, eps added to sqrt(v), decoupled weight decay:  m=b1*m+(1-b1)*g; v=b2*v+(1-b2)*g*g;
  * p -= lr*(m/(sqrt(v)+eps) + wd*p).  Operates on one flat fp32 arena (params, grads, moments). */
@@ -276,6 +282,10 @@ typedef struct mp_f16_pack_job {
 } mp_f16_pack_job;
 int mp_f16_pack_weight_batch(const mp_f16_pack_job* jobs_dev, const unsigned* first_block_dev, int n_jobs, unsigned total_blocks,
                              mp_stream_t stream);
+/* the fp32 form (mp_conv_pack_weight per job; packed = fp32 [Cin_pad4/4][kh*kw][4][Cout_pad16]): same job descriptor,
+ * units_j = Cin_pad4 * kh * kw * Cout_pad16 / 4 (a thread writes four output channels) */
+int mp_conv_pack_weight_batch(const mp_f16_pack_job* jobs_dev, const unsigned* first_block_dev, int n_jobs, unsigned total_blocks,
+                              mp_stream_t stream);
 int mp_f16_to_c8(const float* x_nchw_dev, void* out_c8_dev, int n, int c, int h, int w, mp_stream_t stream);
 int mp_f16_from_c8(const void* x_c8_dev, float* out_nchw_dev, int n, int c, int h, int w, mp_stream_t stream);
 int mp_f16_conv2d_fwd(const mp_conv_desc* desc, int variant, const void* x_c8_dev, const void* packed_w_dev,

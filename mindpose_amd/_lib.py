@@ -62,6 +62,7 @@ _PROTOTYPES = {
     "mp_bn_workspace_bytes": (c_size_t, [c_int]),
     "mp_bn_train_fwd": (c_int, [c_f32p] * 9 + [c_int] * 3 + [ctypes.c_float, ctypes.c_float, c_int, c_f32p, c_size_t, ctypes.c_void_p]),
     "mp_bn_train_bwd": (c_int, [c_f32p] * 10 + [c_int] * 4 + [c_f32p, c_size_t, ctypes.c_void_p]),
+    "mp_bn_train_bwd_acc": (c_int, [c_f32p] * 12 + [c_int] * 4 + [c_f32p, c_size_t, ctypes.c_void_p]),
     "mp_fuse_upsample_sum_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_int, c_f32p, c_int] + [c_int] * 5 + [ctypes.c_void_p]),
     "mp_conv_wgrad_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "mp_conv_wgrad": (c_int, [ctypes.POINTER(ConvDesc), c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_size_t, ctypes.c_void_p]),
@@ -83,6 +84,7 @@ _PROTOTYPES = {
     "mp_f16_activation_bytes": (c_size_t, [c_int] * 4),
     "mp_f16_pack_weight": (c_int, [c_f32p, c_f32p] + [c_int] * 7 + [ctypes.c_void_p]),
     "mp_f16_pack_weight_batch": (c_int, [c_f32p, c_f32p, c_int, ctypes.c_uint, ctypes.c_void_p]),
+    "mp_conv_pack_weight_batch": (c_int, [c_f32p, c_f32p, c_int, ctypes.c_uint, ctypes.c_void_p]),
     "mp_f16_to_c8": (c_int, [c_f32p, c_f32p] + [c_int] * 4 + [ctypes.c_void_p]),
     "mp_f16_from_c8": (c_int, [c_f32p, c_f32p] + [c_int] * 4 + [ctypes.c_void_p]),
     "mp_f16_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_int] + [c_f32p] * 7 + [ctypes.c_void_p]),

@@ -15,6 +15,38 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // [Cout,Cin,kh,kw] (or the (py,px) 2x2 phase of a [Cin,Cout,4,4] transposed-conv weight)
 //   -> [Cin_pad4/4][T][4][Cout_pad16], zero padded.
+// source value of packed element (cout co, cin ci, tap t); callers have checked co < cout && ci < cin
+__device__ __forceinline__ float pack_source(const float* __restrict__ w, int cout, int cin, int kh, int kw, int transposed,
+                                             int py, int px, int co, int ci, int t) {
+    const int ty = t / kw, tx = t % kw;
+    if (transposed == 0) return w[(((size_t)co * cin + ci) * kh + ty) * kw + tx];
+    if (transposed == 2) {
+        // data gradient of a stride-1 conv whose weight is [cin, cout, kh, kw] in forward terms (this packed
+        // conv's cout = forward cin): roles swapped, taps mirrored
+        return w[(((size_t)ci * cout + co) * kh + (kh - 1 - ty)) * kw + (kw - 1 - tx)];
+    }
+    if (transposed == 3) {
+        // data gradient of a 3x3 stride-2 pad-1 conv, output parity phase (py, px), as a 2x2 conv over dy:
+        // dx[2a+p] = sum_t dy[a+t] * w[k(p,t)],  k(0,0)=1, k(0,1)=none, k(1,0)=2, k(1,1)=0
+        const int ky = py == 0 ? (ty == 0 ? 1 : -1) : (ty == 0 ? 2 : 0);
+        const int kx = px == 0 ? (tx == 0 ? 1 : -1) : (tx == 0 ? 2 : 0);
+        return (ky < 0 || kx < 0) ? 0.f : w[(((size_t)ci * cout + co) * 3 + ky) * 3 + kx];
+    }
+    if (transposed == 4) {
+        // data gradient of sub-pixel phase (py, px) of Conv2dTranspose k=4 s=2 p=1: roles swapped (this packed conv's
+        // cout = the transposed conv's cin), the 2x2 phase taps mirrored; w = [cout, cin, 4, 4] in packed terms
+        const int my = 1 - ty, mx = 1 - tx;
+        const int ky = py == 0 ? 3 - 2 * my : 2 - 2 * my;
+        const int kx = px == 0 ? 3 - 2 * mx : 2 - 2 * mx;
+        return w[(((size_t)co * cin + ci) * 4 + ky) * 4 + kx];
+    }
+    // Conv2dTranspose k=4 s=2 p=1: out row 2m+py reads in row m-1+py+ty with kernel row
+    // ky = 3-2*ty (py=0) or 2-2*ty (py=1); same along x.
+    const int ky = py == 0 ? 3 - 2 * ty : 2 - 2 * ty;
+    const int kx = px == 0 ? 3 - 2 * tx : 2 - 2 * tx;
+    return w[(((size_t)ci * cout + co) * 4 + ky) * 4 + kx];
+}
+
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int cout,
                                                           int cin, int kh, int kw, int cin_pad4, int cout_pad16,
                                                           int transposed, int py, int px) {
@@ -29,37 +61,39 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
         const int q = (int)(r / T);
         const int ci = q * 4 + kq;
         float v = 0.f;
-        if (co < cout && ci < cin) {
-            const int ty = t / kw, tx = t % kw;
-            if (transposed == 0) {
-                v = w[(((size_t)co * cin + ci) * kh + ty) * kw + tx];
-            } else if (transposed == 2) {
-                // data gradient of a stride-1 conv whose weight is [cin, cout, kh, kw] in forward terms (this packed
-                // conv's cout = forward cin): roles swapped, taps mirrored
-                v = w[(((size_t)ci * cout + co) * kh + (kh - 1 - ty)) * kw + (kw - 1 - tx)];
-            } else if (transposed == 3) {
-                // data gradient of a 3x3 stride-2 pad-1 conv, output parity phase (py, px), as a 2x2 conv over dy:
-                // dx[2a+p] = sum_t dy[a+t] * w[k(p,t)],  k(0,0)=1, k(0,1)=none, k(1,0)=2, k(1,1)=0
-                const int ky = py == 0 ? (ty == 0 ? 1 : -1) : (ty == 0 ? 2 : 0);
-                const int kx = px == 0 ? (tx == 0 ? 1 : -1) : (tx == 0 ? 2 : 0);
-                v = (ky < 0 || kx < 0) ? 0.f : w[(((size_t)ci * cout + co) * 3 + ky) * 3 + kx];
-            } else if (transposed == 4) {
-                // data gradient of sub-pixel phase (py, px) of Conv2dTranspose k=4 s=2 p=1: roles swapped (this packed conv's
-                // cout = the transposed conv's cin), the 2x2 phase taps mirrored; w = [cout, cin, 4, 4] in packed terms
-                const int my = 1 - ty, mx = 1 - tx;
-                const int ky = py == 0 ? 3 - 2 * my : 2 - 2 * my;
-                const int kx = px == 0 ? 3 - 2 * mx : 2 - 2 * mx;
-                v = w[(((size_t)co * cin + ci) * 4 + ky) * 4 + kx];
-            } else {
-                // Conv2dTranspose k=4 s=2 p=1: out row 2m+py reads in row m-1+py+ty with kernel row
-                // ky = 3-2*ty (py=0) or 2-2*ty (py=1); same along x.
-                const int ky = py == 0 ? 3 - 2 * ty : 2 - 2 * ty;
-                const int kx = px == 0 ? 3 - 2 * tx : 2 - 2 * tx;
-                v = w[(((size_t)ci * cout + co) * 4 + ky) * 4 + kx];
-            }
-        }
+        if (co < cout && ci < cin) v = pack_source(w, cout, cin, kh, kw, transposed, py, px, co, ci, t);
         out[i] = v;
     }
+}
+
+// every fp32 weight packing of a training step in ONE launch (same job table as mp_f16_pack_weight_batch): block b serves the
+// job whose block range holds it, a thread writes four consecutive output channels (one 16-byte store)
+__global__ __launch_bounds__(256) void pack_weight_batch_kernel(const mp_f16_pack_job* __restrict__ jobs,
+                                                                const unsigned* __restrict__ first_block, int n_jobs) {
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (first_block[mid] <= blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const mp_f16_pack_job jb = jobs[lo];
+    const int T = jb.kh * jb.kw, cp = (jb.cout + 15) / 16 * 16, cin_pad4 = (jb.cin + 3) / 4 * 4;
+    const unsigned units = (unsigned)cin_pad4 * T * (cp / 4);
+    const unsigned u = (blockIdx.x - first_block[lo]) * 256u + threadIdx.x;
+    if (u >= units) return;
+    const int c4 = (int)(u % (cp / 4)) * 4;
+    unsigned r = u / (cp / 4);
+    const int kq = (int)(r & 3);
+    r >>= 2;
+    const int t = (int)(r % T);
+    const int ci = (int)(r / T) * 4 + kq;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int co = c4 + j;
+        v[j] = (co < jb.cout && ci < jb.cin) ? pack_source(jb.w, jb.cout, jb.cin, jb.kh, jb.kw, jb.transposed, jb.phase_y, jb.phase_x, co, ci, t)
+                                             : 0.f;
+    }
+    reinterpret_cast<float4*>(jb.packed)[u] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 static unsigned long long* g_stamp_buf = nullptr;
@@ -369,6 +403,16 @@ int mp_conv_pack_weight(const float* w, float* packed, int cout, int cin, int kh
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, packed, cout, cin, kh, kw,
                        cin_pad4, cout_pad16, transposed, phase_y, phase_x);
+    return check_launch();
+}
+
+int mp_conv_pack_weight_batch(const mp_f16_pack_job* jobs_dev, const unsigned* first_block_dev, int n_jobs, unsigned total_blocks,
+                              mp_stream_t stream) {
+    if (n_jobs == 0) return MP_OK;
+    if (!jobs_dev || !first_block_dev) return MP_ERR_NULL;
+    if (n_jobs < 0 || total_blocks == 0) return MP_ERR_SHAPE;
+    hipLaunchKernelGGL(pack_weight_batch_kernel, dim3(total_blocks), dim3(256), 0, as_stream(stream), jobs_dev, first_block_dev,
+                       n_jobs);
     return check_launch();
 }
 

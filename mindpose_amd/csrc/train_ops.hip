@@ -480,6 +480,14 @@ int mp_bn_train_fwd(const float* z, const float* gamma, const float* beta, const
 int mp_bn_train_bwd(const float* dy, const float* z, const float* y, const float* gamma, const float* save_mean,
                     const float* save_invstd, float* dz, float* dres, float* dgamma, float* dbeta, int n, int c, int hw,
                     int relu, void* workspace, size_t workspace_bytes, mp_stream_t stream) {
+    return mp_bn_train_bwd_acc(dy, z, y, gamma, save_mean, save_invstd, dz, dres, dgamma, dbeta, nullptr, nullptr, n, c, hw, relu,
+                               workspace, workspace_bytes, stream);
+}
+
+int mp_bn_train_bwd_acc(const float* dy, const float* z, const float* y, const float* gamma, const float* save_mean,
+                        const float* save_invstd, float* dz, float* dres, float* dgamma, float* dbeta, float* dgamma_acc,
+                        float* dbeta_acc, int n, int c, int hw, int relu, void* workspace, size_t workspace_bytes,
+                        mp_stream_t stream) {
     if (!dy || !z || !gamma || !save_mean || !save_invstd || !dz || !dgamma || !dbeta) return MP_ERR_NULL;
     if (relu && !y) return MP_ERR_NULL;
     if (n <= 0 || c <= 0 || hw <= 0) return MP_ERR_SHAPE;
@@ -490,7 +498,9 @@ int mp_bn_train_bwd(const float* dy, const float* z, const float* y, const float
                        hw, relu ? 1 : 0);
     int rc = check_launch();
     if (rc != MP_OK) return rc;
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(c), dim3(64), 0, s, part, dgamma, dbeta, nullptr, nullptr, c, kBnSplit);
+    const bool acc = dgamma_acc && dbeta_acc;
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(c), dim3(64), 0, s, part, dgamma, dbeta, acc ? dgamma_acc : nullptr,
+                       acc ? dbeta_acc : nullptr, c, kBnSplit);
     rc = check_launch();
     if (rc != MP_OK) return rc;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(n * c), dim3(256), 0, s, dy, z, y, gamma, save_mean, save_invstd, dgamma, dbeta,

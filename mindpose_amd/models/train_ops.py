@@ -40,12 +40,8 @@ def _conv_launch(lib, d, x, packed, scale, shift, out, what):
                                          None, None, _lib.ptr(out), _lib.stream()), what)
 
 
-def _pack(lib, w, cout, cin, k, mode, py=0, px=0):
-    nbytes = lib.mp_conv_packed_weight_bytes(cout, cin, k, k)
-    packed = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
-    _lib.check(lib.mp_conv_pack_weight(_lib.ptr(w), _lib.ptr(packed), cout, cin, k, k, mode, py, px, _lib.stream()),
-               "mp_conv_pack_weight")
-    return packed
+def _pack(lib, w, cout, cin, k, mode, py=0, px=0, owner=None):
+    return _cached_pack(lib, w, owner, False, cout, cin, k, mode, py, px)
 
 
 class Conv2dFn(torch.autograd.Function):
@@ -65,10 +61,11 @@ class Conv2dFn(torch.autograd.Function):
         shift = bias.detach().contiguous() if bias is not None else zeros
         z = torch.empty(n, cout, ho, wo, device=x.device, dtype=torch.float32)
         d = _desc(n, cin, h, wd, cout, k, stride, padding, padding, ho, wo, ho, wo)
-        packed = _pack(lib, w, cout, cin, k, 0)
+        packed = _pack(lib, w, cout, cin, k, 0, owner=weight)
         _conv_launch(lib, d, x, packed, ones, shift, z, "mp_conv2d_fwd")
         ctx.save_for_backward(x, w)
         ctx.stride, ctx.padding, ctx.has_bias = stride, padding, bias is not None
+        ctx.weight_param = weight
         return z
 
     @staticmethod
@@ -86,7 +83,7 @@ class Conv2dFn(torch.autograd.Function):
             if s == 1:
                 dx = torch.empty_like(x)
                 d = _desc(n, cout, ho, wo, cin, k, 1, k - 1 - pad, k - 1 - pad, h, wd, h, wd)
-                packed = _pack(lib, w, cin, cout, k, 2)
+                packed = _pack(lib, w, cin, cout, k, 2, owner=ctx.weight_param)
                 _conv_launch(lib, d, dz, packed, ones, zeros, dx, "conv dgrad")
             else:
                 if h != 2 * ho or wd != 2 * wo:
@@ -96,20 +93,23 @@ class Conv2dFn(torch.autograd.Function):
                     for py in (0, 1):
                         for px in (0, 1):
                             d = _desc(n, cout, ho, wo, cin, 2, 1, 0, 0, ho, wo, h, wd, out_mul=2, off_y=py, off_x=px)
-                            packed = _pack(lib, w, cin, cout, 2, 3, py, px)
+                            packed = _pack(lib, w, cin, cout, 2, 3, py, px, owner=ctx.weight_param)
                             _conv_launch(lib, d, dz, packed, ones, zeros, dx, "conv dgrad phase")
                 else:  # 1x1 stride 2: only even positions receive gradient
                     dx = torch.zeros_like(x)
                     d = _desc(n, cout, ho, wo, cin, 1, 1, 0, 0, ho, wo, h, wd, out_mul=2)
-                    packed = _pack(lib, w, cin, cout, 1, 2)
+                    packed = _pack(lib, w, cin, cout, 1, 2, owner=ctx.weight_param)
                     _conv_launch(lib, d, dz, packed, ones, zeros, dx, "conv dgrad 1x1s2")
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
+            direct = _direct_grad(ctx.weight_param)  # add straight into the gradient arena: no AccumulateGrad launch
+            dw = direct if direct is not None else torch.empty_like(w)
             d = _desc(n, cin, h, wd, cout, k, s, pad, pad, ho, wo, ho, wo)
             ws_bytes = lib.mp_conv_wgrad_workspace_bytes(ctypes.byref(d))
             ws = torch.empty(max(ws_bytes // 4, 1), device=x.device, dtype=torch.float32)
-            _lib.check(lib.mp_conv_wgrad(ctypes.byref(d), _lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), 0, _lib.ptr(ws), ws_bytes,
-                                         _lib.stream()), "mp_conv_wgrad")
+            _lib.check(lib.mp_conv_wgrad(ctypes.byref(d), _lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), int(direct is not None), _lib.ptr(ws),
+                                         ws_bytes, _lib.stream()), "mp_conv_wgrad")
+            if direct is not None:
+                dw = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dz.sum(dim=(0, 2, 3))  # [Cout] reduction of the head conv's bias gradient (17 values)
         return dx, dw, db, None, None
@@ -135,6 +135,7 @@ class BatchNormActFn(torch.autograd.Function):
                                        BN_MOMENTUM, int(relu), _lib.ptr(ws), ws_bytes, _lib.stream()), "mp_bn_train_fwd")
         ctx.save_for_backward(z, y, g, mean, invstd)
         ctx.relu, ctx.has_res = relu, res is not None
+        ctx.gamma_param, ctx.beta_param = gamma, beta
         return y
 
     @staticmethod
@@ -149,9 +150,14 @@ class BatchNormActFn(torch.autograd.Function):
         dbeta = torch.empty(c, device=z.device)
         ws_bytes = lib.mp_bn_workspace_bytes(c)
         ws = torch.empty(ws_bytes // 4 + 1, device=z.device, dtype=torch.float32)
-        _lib.check(lib.mp_bn_train_bwd(_lib.ptr(dy), _lib.ptr(z), _lib.ptr(y), _lib.ptr(g), _lib.ptr(mean), _lib.ptr(invstd),
-                                       _lib.ptr(dz), _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta), n, c, h * w,
-                                       int(ctx.relu), _lib.ptr(ws), ws_bytes, _lib.stream()), "mp_bn_train_bwd")
+        ga, ba = _direct_grad(ctx.gamma_param), _direct_grad(ctx.beta_param)  # + straight into the gradient arena
+        if ga is None or ba is None:
+            ga = ba = None
+        _lib.check(lib.mp_bn_train_bwd_acc(_lib.ptr(dy), _lib.ptr(z), _lib.ptr(y), _lib.ptr(g), _lib.ptr(mean), _lib.ptr(invstd),
+                                           _lib.ptr(dz), _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ga), _lib.ptr(ba),
+                                           n, c, h * w, int(ctx.relu), _lib.ptr(ws), ws_bytes, _lib.stream()), "mp_bn_train_bwd")
+        if ga is not None:
+            return dz, None, None, dres, None, None, None
         return dz, dgamma, dbeta, dres, None, None, None
 
 
@@ -262,58 +268,71 @@ class _PackJob(ctypes.Structure):  # mp_f16_pack_job
                 ("cout", "cin", "kh", "kw", "transposed", "phase_y", "phase_x", "reserved")]
 
 
-def _pack16(lib, w, cout, cin, k, mode, py=0, px=0, owner=None):
-    """Packed fp16 form of ``w``; with ``owner`` (the Parameter ``w`` was detached from) the buffer is persistent and a
-    packing refreshed by ``repack_weights`` is handed out without a launch."""
-    nbytes = lib.mp_f16_packed_weight_bytes(cout, cin, k, k)
+def _cached_pack(lib, w, owner, half, cout, cin, k, mode, py, px):
+    """Packed form of ``w`` (fp16 or fp32 kernels); with ``owner`` (the Parameter ``w`` was detached from) the buffer is
+    persistent and a packing refreshed by ``repack_weights`` is handed out without a launch."""
+    if half:
+        numel, dtype = lib.mp_f16_packed_weight_bytes(cout, cin, k, k) // 2, torch.float16
+    else:
+        numel, dtype = lib.mp_conv_packed_weight_bytes(cout, cin, k, k) // 4, torch.float32
     entry = None
     if owner is not None:
         packs = owner.__dict__.setdefault("_mp_packs", {})
-        key = (cout, cin, k, mode, py, px)
+        key = (half, cout, cin, k, mode, py, px)
         entry = packs.get(key)
         if entry is None:
-            entry = packs[key] = _PackEntry(torch.empty(nbytes // 2, device=w.device, dtype=torch.float16))
+            entry = packs[key] = _PackEntry(torch.empty(numel, device=w.device, dtype=dtype))
         if (entry.fresh and entry.gen == _PACK_GEN[0] and entry.ptr == w.data_ptr() and entry.version == owner._version):
             entry.fresh = False
             return entry.buf
         entry.fresh = False
-    packed = entry.buf if entry is not None else torch.empty(nbytes // 2, device=w.device, dtype=torch.float16)
-    _lib.check(lib.mp_f16_pack_weight(_lib.ptr(w), _lib.ptr(packed), cout, cin, k, k, mode, py, px, _lib.stream()),
-               "mp_f16_pack_weight")
+    packed = entry.buf if entry is not None else torch.empty(numel, device=w.device, dtype=dtype)
+    fn = lib.mp_f16_pack_weight if half else lib.mp_conv_pack_weight
+    _lib.check(fn(_lib.ptr(w), _lib.ptr(packed), cout, cin, k, k, mode, py, px, _lib.stream()), "pack_weight")
     return packed
 
 
+def _pack16(lib, w, cout, cin, k, mode, py=0, px=0, owner=None):
+    return _cached_pack(lib, w, owner, True, cout, cin, k, mode, py, px)
+
+
 def repack_weights(module):
-    """Refresh every remembered fp16 packing of ``module``'s parameters in one launch (no-op until a first step has run)."""
-    jobs = []
+    """Refresh every remembered packing of ``module``'s parameters: one launch for the fp16 forms, one for the fp32 forms
+    (no-op until a first step has run)."""
+    jobs = {True: [], False: []}
     for prm in module.parameters():
         packs = prm.__dict__.get("_mp_packs")
         if packs and prm.is_cuda and prm.dtype == torch.float32 and prm.is_contiguous():
-            jobs.extend((prm, key, entry) for key, entry in packs.items())
-    if not jobs:
-        return 0
-    lib = _lib.load()
-    sig = tuple((prm.data_ptr(), entry.buf.data_ptr()) for prm, _, entry in jobs)
-    table = module.__dict__.get("_mp_pack_table")
-    if table is None or table[0] != sig:
-        arr = (_PackJob * len(jobs))()
-        first = np.zeros(len(jobs) + 1, dtype=np.uint32)
-        for i, (prm, (cout, cin, k, mode, py, px), entry) in enumerate(jobs):
-            arr[i] = _PackJob(prm.data_ptr(), entry.buf.data_ptr(), cout, cin, k, k, mode, py, px, 0)
-            units = (cin + 31) // 32 * k * k * 4 * ((cout + 15) // 16 * 16)
-            first[i + 1] = first[i] + (units + 255) // 256
-        dev = jobs[0][0].device
-        jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
-        first_dev = torch.from_numpy(first.view(np.int32)).to(dev)
-        table = (sig, jobs_dev, first_dev, int(first[-1]))
-        module.__dict__["_mp_pack_table"] = table
-    _, jobs_dev, first_dev, blocks = table
-    _lib.check(lib.mp_f16_pack_weight_batch(_lib.ptr(jobs_dev), _lib.ptr(first_dev), len(jobs), blocks, _lib.stream()),
-               "mp_f16_pack_weight_batch")
-    gen = _PACK_GEN[0]
-    for prm, _, entry in jobs:
-        entry.fresh, entry.gen, entry.ptr, entry.version = True, gen, prm.data_ptr(), prm._version
-    return len(jobs)
+            for key, entry in packs.items():
+                jobs[key[0]].append((prm, key, entry))
+    total = 0
+    for half, group in jobs.items():
+        if not group:
+            continue
+        lib = _lib.load()
+        sig = tuple((prm.data_ptr(), entry.buf.data_ptr()) for prm, _, entry in group)
+        tables = module.__dict__.setdefault("_mp_pack_tables", {})
+        table = tables.get(half)
+        if table is None or table[0] != sig:
+            arr = (_PackJob * len(group))()
+            first = np.zeros(len(group) + 1, dtype=np.uint32)
+            for i, (prm, (_, cout, cin, k, mode, py, px), entry) in enumerate(group):
+                arr[i] = _PackJob(prm.data_ptr(), entry.buf.data_ptr(), cout, cin, k, k, mode, py, px, 0)
+                cp = (cout + 15) // 16 * 16
+                units = (cin + 31) // 32 * k * k * 4 * cp if half else (cin + 3) // 4 * 4 * k * k * (cp // 4)
+                first[i + 1] = first[i] + (units + 255) // 256
+            dev = group[0][0].device
+            jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+            first_dev = torch.from_numpy(first.view(np.int32)).to(dev)
+            table = tables[half] = (sig, jobs_dev, first_dev, int(first[-1]))
+        _, jobs_dev, first_dev, blocks = table
+        fn = lib.mp_f16_pack_weight_batch if half else lib.mp_conv_pack_weight_batch
+        _lib.check(fn(_lib.ptr(jobs_dev), _lib.ptr(first_dev), len(group), blocks, _lib.stream()), "pack_weight_batch")
+        gen = _PACK_GEN[0]
+        for prm, _, entry in group:
+            entry.fresh, entry.gen, entry.ptr, entry.version = True, gen, prm.data_ptr(), prm._version
+        total += len(group)
+    return total
 
 
 def _ones_zeros16(c: int, device):

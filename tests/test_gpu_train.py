@@ -377,3 +377,32 @@ def test_simplebaseline_r50_fp32_training_step_vs_oracle():
     assert med_hip < max(2 * med_cpu, 1e-4) and worst_hip < max(2 * worst_cpu, 0.1)
     for name in ("head.final_layer.weight", "head.final_layer.bias"):
         assert e_hip[name] < 5e-5, (name, e_hip[name])
+
+
+def test_batched_fp32_weight_pack_equals_individual_packs():
+    """mp_conv_pack_weight_batch == one mp_conv_pack_weight per job, bit for bit, over every packing mode."""
+    import numpy as np
+    from mindpose_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(22)
+    specs = [((40, 24, 3, 3), 40, 24, 3, 0, 0, 0), ((17, 32, 1, 1), 17, 32, 1, 0, 0, 0), ((40, 24, 3, 3), 24, 40, 3, 2, 0, 0),
+             ((40, 24, 3, 3), 24, 40, 2, 3, 1, 0), ((24, 40, 4, 4), 40, 24, 2, 1, 0, 1), ((24, 40, 4, 4), 24, 40, 2, 4, 1, 1),
+             ((64, 3, 7, 7), 64, 3, 7, 0, 0, 0)]
+    ws = [torch.randn(sh, generator=g).to(DEV) for sh, *_ in specs]
+    single, batch = [], []
+    arr = (T._PackJob * len(specs))()
+    first = np.zeros(len(specs) + 1, dtype=np.uint32)
+    for i, (w, (_, cout, cin, k, mode, py, px)) in enumerate(zip(ws, specs)):
+        nb = lib.mp_conv_packed_weight_bytes(cout, cin, k, k)
+        a, b = torch.full((nb // 4,), 7.0, device=DEV), torch.full((nb // 4,), 9.0, device=DEV)
+        _lib.check(lib.mp_conv_pack_weight(_lib.ptr(w), _lib.ptr(a), cout, cin, k, k, mode, py, px, _lib.stream()), "pack")
+        arr[i] = T._PackJob(w.data_ptr(), b.data_ptr(), cout, cin, k, k, mode, py, px, 0)
+        first[i + 1] = first[i] + ((cin + 3) // 4 * 4 * k * k * ((cout + 15) // 16 * 4) + 255) // 256
+        single.append(a)
+        batch.append(b)
+    jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+    first_dev = torch.from_numpy(first.view(np.int32)).to(DEV)
+    _lib.check(lib.mp_conv_pack_weight_batch(_lib.ptr(jobs_dev), _lib.ptr(first_dev), len(specs), int(first[-1]), _lib.stream()), "batch")
+    torch.cuda.synchronize()
+    for a, b, sp in zip(single, batch, specs):
+        assert torch.equal(a, b), sp
