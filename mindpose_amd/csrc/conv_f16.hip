@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
         const unsigned xx = rem - y * p.Wo;
         const int yy = y0 + y;
         const bool ok = pl < (unsigned)(p.G * p.RWo) && n0 + (int)g < p.N && yy < p.Ho;
-        pix_off[ps] = ok ? (g * p.C8out * plane_o + (yy * p.out_mul + p.off_y) * p.out_w + xx * p.out_mul + p.off_x) * 16u : kOob;
+        pix_off[ps] = ok ? (g * p.C8out * plane_o + (yy * p.out_mul + p.off_y) * p.out_w + xx * p.out_mul + p.off_x) * 16u : kInv;
     }
     f32x4 sc[CS], sh[CS];
     unsigned co_off[CS];
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
         const int cc = co < p.Cout_pad16 ? co : 0;
         sc[cs] = *reinterpret_cast<const f32x4*>(p.scale + cc);
         sh[cs] = *reinterpret_cast<const f32x4*>(p.shift + cc);
-        co_off[cs] = ok ? (unsigned)(co >> 3) * plane_o * 16u + ((co >> 2) & 1) * 8u : kOob;
+        co_off[cs] = ok ? (unsigned)(co >> 3) * plane_o * 16u + ((co >> 2) & 1) * 8u : kInv;
     }
     u32x2 r1[CS][PS], r2[CS][PS];
     if (p.res1) {
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
         for (int cs = 0; cs < CS; ++cs)
 #pragma unroll
             for (int ps = 0; ps < PS; ++ps)
-                r1[cs][ps] = __builtin_amdgcn_raw_buffer_load_b64(rs, ((co_off[cs] | pix_off[ps]) & kOob) ? kOob : co_off[cs] + pix_off[ps], 0, 0);
+                r1[cs][ps] = __builtin_amdgcn_raw_buffer_load_b64(rs, co_off[cs] + pix_off[ps], 0, 0);
     }
     if (p.res2) {
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const char*>(p.res2) + grp, grp_bytes);
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
         for (int cs = 0; cs < CS; ++cs)
 #pragma unroll
             for (int ps = 0; ps < PS; ++ps)
-                r2[cs][ps] = __builtin_amdgcn_raw_buffer_load_b64(rs, ((co_off[cs] | pix_off[ps]) & kOob) ? kOob : co_off[cs] + pix_off[ps], 0, 0);
+                r2[cs][ps] = __builtin_amdgcn_raw_buffer_load_b64(rs, co_off[cs] + pix_off[ps], 0, 0);
     }
     compute(p.nbuf == 2 ? ((p.n_chunks - 1) & 1) : 0);
 
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
             if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             const f16x4 o = (f16x4){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs_o,
-                                                  ((co_off[cs] | pix_off[ps]) & kOob) ? kOob : co_off[cs] + pix_off[ps], 0, 0);
+                                                  co_off[cs] + pix_off[ps], 0, 0);
         }
 }
 
@@ -663,6 +663,8 @@ int f16_build_launch(const mp_conv_desc* desc, int variant, const void* x, const
     if (rc != MP_OK) return rc;
     if (!x || !w || !scale || !shift || !out) return MP_ERR_NULL;
     if (variant >= F_COUNT) return MP_ERR_UNSUPPORTED;
+    // output offsets are 32-bit sums of masked parts (kInv in conv_f16_dev.h)
+    if ((size_t)desc->n * ((desc->cout + 7) / 8) * desc->out_h * desc->out_w * 16 >= 0x60000000u) return MP_ERR_UNSUPPORTED;
     bool ok = false;
     if (variant >= 0) {
         ok = f16_configure(*desc, variant, L);

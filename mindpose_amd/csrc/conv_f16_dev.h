@@ -12,6 +12,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr unsigned kOob = 0x80000000u;
+// "masked" marker for the two ADDENDS of an output offset (cout part + pixel part): marker + marker, marker + any valid part
+// and a valid sum are all told apart by the buffer range check alone as long as the tensor is smaller than the marker, so the
+// epilogue adds the parts without a select per store (tensors >= 1.5 GB are refused at plan time)
+constexpr unsigned kInv = 0x60000000u;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, size_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes < 0x7FFFFFF0u ? bytes : 0x7FFFFFF0u), 0x00020000);

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Para
         const int cc = co < p.Cout_pad16 ? co : 0;
         sc[cs] = *reinterpret_cast<const f32x4*>(p.scale + cc);
         sh[cs] = *reinterpret_cast<const f32x4*>(p.shift + cc);
-        co_off[cs] = ok ? (unsigned)(co >> 3) * plane_o * 16u + ((co >> 2) & 1) * 8u : kOob;
+        co_off[cs] = ok ? (unsigned)(co >> 3) * plane_o * 16u + ((co >> 2) & 1) * 8u : kInv;
     }
 
     const size_t x_bytes = (size_t)p.N * p.C8in * HW * 16, o_bytes = (size_t)p.N * p.C8out * plane_o * 16;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Para
 #pragma unroll
         for (int ps = 0; ps < PS; ++ps) {
             const bool ok = pix_gy[ps] >= 0 && n0 + (pix_gy[ps] >> 16) < p.N && y0 + (pix_gy[ps] & 0xFFFF) < p.Ho;
-            pix_off[ps] = ok ? (unsigned)(obase + pix_rel[ps]) : kOob;
+            pix_off[ps] = ok ? (unsigned)(obase + pix_rel[ps]) : kInv;
         }
         u32x2 r1[CS][PS], r2[CS][PS];
         if (p.res1) {
@@ -169,14 +169,14 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Para
             for (int cs = 0; cs < CS; ++cs)
 #pragma unroll
                 for (int ps = 0; ps < PS; ++ps)
-                    r1[cs][ps] = __builtin_amdgcn_raw_buffer_load_b64(rs_r1, ((co_off[cs] | pix_off[ps]) & kOob) ? kOob : co_off[cs] + pix_off[ps], 0, 0);
+                    r1[cs][ps] = __builtin_amdgcn_raw_buffer_load_b64(rs_r1, co_off[cs] + pix_off[ps], 0, 0);
         }
         if (p.res2) {
 #pragma unroll
             for (int cs = 0; cs < CS; ++cs)
 #pragma unroll
                 for (int ps = 0; ps < PS; ++ps)
-                    r2[cs][ps] = __builtin_amdgcn_raw_buffer_load_b64(rs_r2, ((co_off[cs] | pix_off[ps]) & kOob) ? kOob : co_off[cs] + pix_off[ps], 0, 0);
+                    r2[cs][ps] = __builtin_amdgcn_raw_buffer_load_b64(rs_r2, co_off[cs] + pix_off[ps], 0, 0);
         }
 
         f32x4 acc[PS][CS];
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Para
                 if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 const f16x4 o = (f16x4){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs_o,
-                                                      ((co_off[cs] | pix_off[ps]) & kOob) ? kOob : co_off[cs] + pix_off[ps], 0, 0);
+                                                      co_off[cs] + pix_off[ps], 0, 0);
             }
 
         if (more) {
