@@ -36,6 +36,8 @@ struct ConvF16Params {
     // persistent multi-tile kernel only: a workgroup keeps its weight slice in LDS and walks tiles_per_wg pixel tiles
     int tiles_total, tiles_per_wg, n_groups;
     int ni_used, nw_used;  // staging slots (of the kernel's NI / NW) that carry data for this shape: the rest are skipped
+    unsigned magic_rows;       // / (G * Rin)
+    int step_rows, step_cols;  // 256 staging units = step_rows whole rows + step_cols columns (slot-to-slot stepping)
 };
 
 struct ConvF16Launch {

@@ -47,43 +47,61 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
     const int HW = p.H * p.W;
 
     {
-        const int n16 = p.nbuf * p.in_buf;
+        const int n16 = (p.n_chunks > 1 ? p.nbuf : 1) * p.in_buf;  // a single-chunk launch only ever touches buffer 0
         const u32x4 zero = (u32x4){0u, 0u, 0u, 0u};
         for (int i = tid; i < n16; i += 256) lds_in[i] = zero;
     }
 
+    // Staging tables.  A workgroup of the small-K layers lives ~12 k cycles, of which this integer set-up used to be a
+    // quarter (in-kernel cycle stamps): only the slots the shape uses are filled, and slot i+1 is derived from slot i by
+    // stepping 256 units forward (row / plane carries) instead of three magic-number divisions per slot.
     unsigned isrc[NI];
     int idst[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-        const unsigned u = tid + 256 * i;
         isrc[i] = kOob;
         idst[i] = -1;
-        if (u < (unsigned)(p.PKs * p.upc)) {
-            const unsigned pl = fastdiv(u, p.upc, p.magic_upc);
-            const unsigned rem = u - pl * p.upc;
-            const unsigned gr = fastdiv(rem, p.ncols, p.magic_ncols);
-            const unsigned xu = rem - gr * p.ncols;
-            const unsigned g = p.G > 1 ? fastdiv(gr, p.Rin, p.magic_rin) : 0u;
-            const unsigned r = gr - g * p.Rin;
-            const int yin = y_in0 + (int)r;
-            if (yin >= 0 && yin < p.H && n0 + (int)g < p.N) {
-                isrc[i] = ((g * p.C8in + pl) * HW + yin * p.W + xu) * 16u;
-                idst[i] = (int)((pl << 20) | (pl * p.plane + g * p.img_plane + r * p.Wp + p.pad_l + xu));
+    }
+    {
+        const int rows = p.G * p.Rin;  // staged rows per channel-block plane
+        unsigned pl = fastdiv((unsigned)tid, p.upc, p.magic_upc);
+        const unsigned rem0 = tid - pl * p.upc;
+        unsigned gr = fastdiv(rem0, p.ncols, p.magic_ncols);
+        unsigned xu = rem0 - gr * p.ncols;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (i < p.ni_used && pl < (unsigned)p.PKs) {
+                const unsigned g = p.G > 1 ? fastdiv(gr, p.Rin, p.magic_rin) : 0u;
+                const unsigned r = gr - g * p.Rin;
+                const int yin = y_in0 + (int)r;
+                if (yin >= 0 && yin < p.H && n0 + (int)g < p.N) {
+                    isrc[i] = ((g * p.C8in + pl) * HW + yin * p.W + xu) * 16u;
+                    idst[i] = (int)((pl << 20) | (pl * p.plane + g * p.img_plane + r * p.Wp + p.pad_l + xu));
+                }
+            }
+            xu += p.step_cols;  // 256 units further: 256 = step_rows * ncols + step_cols
+            gr += p.step_rows;
+            if (xu >= (unsigned)p.ncols) { xu -= p.ncols; ++gr; }
+            if (gr >= (unsigned)rows) {  // plane carry (several planes at once on the small maps)
+                const unsigned k = fastdiv(gr, rows, p.magic_rows);
+                gr -= k * rows;
+                pl += k;
             }
         }
     }
 
     int b_off[PS];  // pixel operand
+    int pix_gyx[PS];  // the lane's pixel of tile ps as (image << 24 | row << 12 | col), -1 = padding lane: reused by the epilogue
 #pragma unroll
     for (int ps = 0; ps < PS; ++ps) {
-        unsigned pl = (unsigned)((wp_i * PS + ps) * 16 + lr);
-        if (pl >= (unsigned)(p.G * p.RWo)) pl = 0;
+        const unsigned pl0 = (unsigned)((wp_i * PS + ps) * 16 + lr);
+        const unsigned pl = pl0 < (unsigned)(p.G * p.RWo) ? pl0 : 0u;
         const unsigned g = fastdiv(pl, p.RWo, p.magic_rwo);
         const unsigned rem = pl - g * p.RWo;
         const unsigned y = fastdiv(rem, p.Wo, p.magic_wo);
         const unsigned xx = rem - y * p.Wo;
         b_off[ps] = lq * p.plane + g * p.img_plane + (y * S) * p.Wp + xx * S;
+        pix_gyx[ps] = pl0 < (unsigned)(p.G * p.RWo) ? (int)((g << 24) | (y << 12) | xx) : -1;
     }
     int a_off[CS];  // weight operand
 #pragma unroll
@@ -104,9 +122,11 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
     unsigned wsrc[NW];
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
+        wsrc[i] = kOob;
+        if (i >= p.nw_used) continue;
         const int u = tid + 256 * i;
         const int row = u / CT, c = u - row * CT;
-        wsrc[i] = (u < w_units && ct * CT + c < p.Cout_pad16) ? (unsigned)(row * p.Cout_pad16 + ct * CT + c) * 16u : kOob;
+        if (u < w_units && ct * CT + c < p.Cout_pad16) wsrc[i] = (unsigned)(row * p.Cout_pad16 + ct * CT + c) * 16u;
     }
 
     u32x4 vin[NI], vw[NW];
@@ -212,14 +232,9 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
     unsigned pix_off[PS];
 #pragma unroll
     for (int ps = 0; ps < PS; ++ps) {
-        const unsigned pl = (unsigned)((wp_i * PS + ps) * 16 + lr);
-        const unsigned pc = pl < (unsigned)(p.G * p.RWo) ? pl : 0u;
-        const unsigned g = fastdiv(pc, p.RWo, p.magic_rwo);
-        const unsigned rem = pc - g * p.RWo;
-        const unsigned y = fastdiv(rem, p.Wo, p.magic_wo);
-        const unsigned xx = rem - y * p.Wo;
+        const unsigned g = (unsigned)pix_gyx[ps] >> 24, y = ((unsigned)pix_gyx[ps] >> 12) & 0xFFFu, xx = (unsigned)pix_gyx[ps] & 0xFFFu;
         const int yy = y0 + y;
-        const bool ok = pl < (unsigned)(p.G * p.RWo) && n0 + (int)g < p.N && yy < p.Ho;
+        const bool ok = pix_gyx[ps] >= 0 && n0 + (int)g < p.N && yy < p.Ho;
         pix_off[ps] = ok ? (g * p.C8out * plane_o + (yy * p.out_mul + p.off_y) * p.out_w + xx * p.out_mul + p.off_x) * 16u : kInv;
     }
     f32x4 sc[CS], sh[CS];
@@ -463,6 +478,9 @@ bool f16_configure(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
     p.total_blocks = p.n_ct * p.tiles_y * p.tiles_n;
     p.ni_used = (p.PKs * p.upc + 255) / 256;
     p.nw_used = (p.PK * T * CT + 255) / 256;
+    p.step_rows = 256 / p.ncols;
+    p.step_cols = 256 % p.ncols;
+    p.magic_rows = magic_of((unsigned)(p.G * p.Rin));
     L.ks = KS; L.stride = S; L.variant = variant;
     L.lds_bytes = (size_t)p.nbuf * (p.in_buf + p.w_buf) * 16;
     return L.lds_bytes <= (size_t)kLdsMax;
