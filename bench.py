@@ -61,6 +61,8 @@ def kernel_name(info):
         return "basicblock_f16_kernel<5,3>" if info["variant"] else "basicblock_f16_kernel<6,5>"
     if info["kind_id"] == 3:
         v = info["variant"]
+        if v == 24:  # 32 couts x 384 pixels, single-chunk build
+            return f"conv_f16_kernel<{info['ks']},{info['stride']},6,2,4,1>"
         if v >= 20:  # 16-cout tiles: regular, light, multi-tile (2 / 1 workgroups per CU)
             head = f"<{info['ks']},{info['stride']},3,1,4,1>"
             return (f"conv_f16_kernel{head}" + ("/occ3" if v == 21 else "")) if v < 22 else f"conv_f16_mt_kernel{head}/occ{24 - v}"

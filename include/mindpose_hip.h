@@ -261,7 +261,8 @@ int mp_conv_wgrad(const mp_conv_desc* desc, const float* x_dev, const float* dz_
  * Kernel 1x1, 2x2 (stride 1) or 3x3; output mapping plain or strided scatter (out_mul, out_off_*: the sub-pixel phases of
  * the transposed convolution), out_rep must be 1: the exchange-unit up-sampling runs in mp_f16_fuse_upsample_sum.  variant -1 = heuristic, 0..9 = forced tile shape
  * (5..9 = the light builds of 0..4: small chunks, three workgroups per CU), 10..19 = the persistent multi-tile kernel in
- * those shapes (two / one workgroup per CU), 20..23 = the 16-cout x 192-pixel shape (regular, light, multi-tile x2). */
+ * those shapes (two / one workgroup per CU), 20..23 = the 16-cout x 192-pixel shape (regular, light, multi-tile x2),
+ * 24 = 32 couts x 384 pixels for layers whose K fits one chunk (Cin <= 32 at 3x3). */
 size_t mp_f16_packed_weight_bytes(int cout, int cin, int kh, int kw);
 size_t mp_f16_activation_bytes(int n, int c, int h, int w);
 /* transposed = 0: Conv2d weight [Cout,Cin,kh,kw]; 1: the (phase_y, phase_x) 2x2 sub-pixel phase of a

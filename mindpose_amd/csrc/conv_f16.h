@@ -52,8 +52,11 @@ enum ConvF16Variant { F_CT32_PT192 = 0, F_CT64_PT192 = 1, F_CT48_PT192 = 2, F_CT
                       F_CT32_PT192_L = 5, F_CT64_PT192_L = 6, F_CT48_PT192_L = 7, F_CT64_PT96_L = 8, F_CT32_PT96_L = 9,
                       F_MT2_BASE = 10, F_MT1_BASE = 15,
                       // 16-cout tiles (twice the workgroups: latency hiding for the large-K small-map layers)
-                      F_CT16_PT192 = 20, F_CT16_PT192_L = 21, F_CT16_PT192_MT2 = 22, F_CT16_PT192_MT1 = 23, F_COUNT = 24 };
-inline bool f16_variant_mt(int v) { return (v >= F_MT2_BASE && v < F_CT16_PT192) || v >= F_CT16_PT192_MT2; }
+                      F_CT16_PT192 = 20, F_CT16_PT192_L = 21, F_CT16_PT192_MT2 = 22, F_CT16_PT192_MT1 = 23,
+                      // 384-pixel tiles for the small-K layers: a workgroup's fixed set-up (a third of its life at K = 288)
+                      // and its weight loads are spread over twice the MFMA work
+                      F_CT32_PT384 = 24, F_COUNT = 25 };
+inline bool f16_variant_mt(int v) { return (v >= F_MT2_BASE && v < F_CT16_PT192) || v == F_CT16_PT192_MT2 || v == F_CT16_PT192_MT1; }
 inline int f16_variant_mt_occ(int v) { return (v >= F_MT1_BASE && v < F_CT16_PT192) || v == F_CT16_PT192_MT1 ? 1 : 2; }
 bool f16_variant_light(int v);
 

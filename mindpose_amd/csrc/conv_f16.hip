@@ -20,7 +20,9 @@ namespace mp {
 
 namespace {
 
-template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, int NI, int NW, int OCC>
+// ONE_CHUNK: the build for layers whose whole K fits one chunk (the 32-channel layers): no chunk loop, so the staging
+// registers are dead before the MFMA loop and a wave can own six pixel tiles instead of three
+template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, int NI, int NW, int OCC, bool ONE_CHUNK = false>
 __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params p) {
     static_assert(WAVES_P * WAVES_C == 4, "4 waves per workgroup");
     constexpr int T = KS * KS;
@@ -215,12 +217,14 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
         }
     };
     // all chunks but the last: fetch chunk c+1 into registers while chunk c computes
-    for (int ch = 0; ch + 1 < p.n_chunks; ++ch) {
-        const int buf = ch & 1;
-        stage_load(ch + 1);
-        compute(buf);
-        stage_store(buf ^ 1);
-        __syncthreads();
+    if constexpr (!ONE_CHUNK) {
+        for (int ch = 0; ch + 1 < p.n_chunks; ++ch) {
+            const int buf = ch & 1;
+            stage_load(ch + 1);
+            compute(buf);
+            stage_store(buf ^ 1);
+            __syncthreads();
+        }
     }
     // ---- output addressing, lane = (pixel lr of tile ps) x (couts 4*lq .. +3 of tile cs) -> one 8-byte store; the
     //      residual tensors are fetched before the LAST chunk computes (the staging registers are free by then), so
@@ -321,6 +325,18 @@ int launch_f16_ks(const ConvF16Params& p, int variant, size_t lds_bytes, hipStre
         case F_CT32_PT96_L: return launch_f16_variant<KS, S, 3, 1, 2, 2, true>(p, lds_bytes, s);
         case F_CT16_PT192: return launch_f16_variant<KS, S, 3, 1, 4, 1, false>(p, lds_bytes, s);
         case F_CT16_PT192_L: return launch_f16_variant<KS, S, 3, 1, 4, 1, true>(p, lds_bytes, s);
+        case F_CT32_PT384: {
+            if (p.n_chunks != 1) return MP_ERR_UNSUPPORTED;
+            auto kern = conv_f16_kernel<KS, S, 6, 2, 4, 1, f16_ni(KS, false), f16_nw(KS, false), 2, true>;
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipGetLastError();
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(256), lds_bytes, s, p);
+            return check_launch();
+        }
         default: return MP_ERR_UNSUPPORTED;
     }
 }
@@ -463,6 +479,7 @@ bool f16_configure(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
         }
     }
     if (!found) return false;
+    if (variant == F_CT32_PT384 && p.n_chunks != 1) return false;  // single-chunk build
     p.in_buf = p.PK * p.plane;
     p.w_buf = p.PK * T * CT;
     p.n_ct = (p.Cout_pad16 + CT - 1) / CT;
@@ -669,6 +686,7 @@ int grid_for(size_t total) {
 void f16_variant_dims(int v, int& ct, int& pt) {
     static const int cts[5] = {32, 64, 48, 64, 32};
     static const int pts[5] = {192, 192, 192, 96, 96};
+    if (v == F_CT32_PT384) { ct = 32; pt = 384; return; }
     if (v >= F_CT16_PT192) { ct = 16; pt = 192; return; }
     ct = cts[v % 5];
     pt = pts[v % 5];

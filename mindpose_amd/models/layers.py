@@ -161,7 +161,7 @@ def tune_conv_variant(lib, d, x, packed, scale, shift, res1, res2, out, half: bo
         return fn(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(res1),
                   _lib.ptr(res2), _lib.ptr(trial_out), stream)
 
-    return _autotune(key, macs, 24 if half else 8, launch)
+    return _autotune(key, macs, 25 if half else 8, launch)
 
 
 class Plan:

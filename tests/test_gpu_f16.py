@@ -75,7 +75,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("variant", [-1] + list(range(10)) + [20, 21])
+@pytest.mark.parametrize("variant", [-1] + list(range(10)) + [20, 21, 24])
 def test_conv_f16_vs_oracle(case, variant):
     n, cin, cout, k, s, h, w, relu, n_res = case
     g = torch.Generator().manual_seed(hash(case) % 1000)
