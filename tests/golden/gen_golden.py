@@ -275,8 +275,41 @@ def gen_nms():
     print("nms.npz", len(out), "arrays")
 
 
+def gen_helpers():
+    """Point helpers of the REFERENCE's mindpose/data/transform/utils.py (numpy only): affine_transform, rotate_point,
+    warp_affine_joints, pad_to_same, transform_keypoints on seeded inputs."""
+    load_reference_target_class()
+    ut = sys.modules["mindpose.data.transform.utils"]
+    rng = np.random.RandomState(31)
+    out = {}
+    mats = rng.uniform(-2, 2, (12, 2, 3))
+    pts = rng.uniform(-100, 400, (12, 2)).astype(np.float32)
+    angles = rng.uniform(-3.2, 3.2, 12)
+    out["mats"], out["pts"], out["angles"] = mats, pts, angles
+    out["affine"] = np.stack([ut.affine_transform(tuple(p), m) for p, m in zip(pts, mats)])
+    out["rotated"] = np.array([ut.rotate_point(tuple(p), a) for p, a in zip(pts, angles)])
+    joints = rng.uniform(0, 300, (5, 17, 2)).astype(np.float32)
+    out["joints"] = joints
+    out["warped_joints"] = ut.warp_affine_joints(joints, mats[0])
+    ragged = [rng.uniform(0, 1, sh).astype(np.float32) for sh in ((3, 5), (1, 7), (4, 2))]
+    for i, (a, b) in enumerate(zip(ragged, ut.pad_to_same(ragged))):
+        out[f"ragged_{i}"], out[f"padded_{i}"] = a, b
+    coords = [rng.uniform(0, 64, (17, 3, 3)).astype(np.float32), np.zeros((17, 0, 3), np.float32), rng.uniform(0, 64, (17, 1, 3)).astype(np.float32)]
+    center = rng.uniform(50, 300, (3, 2)).astype(np.float32)
+    scale = rng.uniform(0.5, 2.0, (3, 2)).astype(np.float32)
+    hm = np.array([[48, 64], [48, 64], [72, 96]], np.float32)
+    res = ut.transform_keypoints(coords, center, scale, hm)
+    out["tk_center"], out["tk_scale"], out["tk_heatmap_shape"] = center, scale, hm
+    for i, (a, b) in enumerate(zip(coords, res)):
+        out[f"tk_in_{i}"], out[f"tk_out_{i}"] = a, b
+    np.savez_compressed(os.path.join(HERE, "helpers.npz"), **out)
+    print("helpers.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["targets", "decoder", "flip", "loss", "geometry", "nms"]
+    which = sys.argv[1:] or ["targets", "decoder", "flip", "loss", "geometry", "nms", "helpers"]
+    if "helpers" in which:
+        gen_helpers()
     if "nms" in which:
         gen_nms()
     if "geometry" in which:

@@ -117,3 +117,25 @@ def test_training_augmentations_bit_exact_vs_reference():
     assert np.array_equal(o["image"], img[:, ::-1]) and o["center"][0] == 4.0
     assert np.array_equal(o["keypoints"], mp.fliplr_joints(kps[0], 6, flip_index=fi))
     assert mp.entrypoint("transform", "topdown_halfbody_transform") is mp.TopDownHalfBodyTransform
+
+
+def test_point_helpers_match_reference_goldens():
+    """affine_transform / rotate_point / warp_affine_joints / pad_to_same / transform_keypoints against outputs of the reference's
+    own mindpose/data/transform/utils.py (tests/golden/helpers.npz, made by gen_golden.py helpers)."""
+    import os
+    from mindpose_amd.data.transform import utils as U
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "helpers.npz"))
+    for p, m, want in zip(g["pts"], g["mats"], g["affine"]):
+        assert np.array_equal(U.affine_transform(tuple(p), m), want)
+    for p, a, want in zip(g["pts"], g["angles"], g["rotated"]):
+        assert np.array_equal(np.array(U.rotate_point(tuple(p), a)), want)
+    got = U.warp_affine_joints(g["joints"], g["mats"][0])
+    assert got.dtype == g["warped_joints"].dtype and np.array_equal(got, g["warped_joints"])
+    padded = U.pad_to_same([g[f"ragged_{i}"] for i in range(3)])
+    for i, b in enumerate(padded):
+        assert np.array_equal(b, g[f"padded_{i}"])
+    res = U.transform_keypoints([g[f"tk_in_{i}"] for i in range(3)], g["tk_center"], g["tk_scale"], g["tk_heatmap_shape"])
+    for i, b in enumerate(res):
+        assert b.dtype == g[f"tk_out_{i}"].dtype and np.array_equal(b, g[f"tk_out_{i}"])
+    with np.testing.assert_raises(AssertionError):
+        U.affine_transform((1.0, 2.0, 3.0), g["mats"][0])
