@@ -337,22 +337,82 @@ __global__ __launch_bounds__(256) void bn16_reduce_kernel(const u32x4_t* __restr
     }
 }
 
+// Stage 2 folded into the consumers: a block of the apply kernels serves ONE 8-channel block (grid = (C8, chunks of the
+// image x pixel range)) and first reduces that block's partial sums itself - thread t: channel t >> 5, splits t & 31, + 32, ...
+// then a 32-lane shuffle tree; every block computes the same values in the same order (deterministic) - which removes the
+// ~5 us stage-2 launch between the two passes of every BatchNorm in both directions (6 % of the amp-O2 step).  Chunk 0 of a
+// channel block also writes the per-channel results (saved statistics / moving averages, or dgamma / dbeta).
+__device__ __forceinline__ void bn16_channel_sums(const double* __restrict__ part, int ch, int c, int nsplit, double& s0, double& s1) {
+    s0 = 0.0;
+    s1 = 0.0;
+    if (ch < c) {
+        for (int sp = threadIdx.x & 31; sp < nsplit; sp += 32) {
+            s0 += part[((size_t)ch * nsplit + sp) * 2 + 0];
+            s1 += part[((size_t)ch * nsplit + sp) * 2 + 1];
+        }
+    }
+    for (int off = 16; off >= 1; off >>= 1) {  // xor tree inside each 32-lane half: every lane ends with the total
+        s0 += __shfl_xor(s0, off, 64);
+        s1 += __shfl_xor(s1, off, 64);
+    }
+}
+
 // y = act(z * scale[c] + shift[c] (+ res)) over c8 elements; padding channels stay zero
-__global__ __launch_bounds__(256) void bn16_apply_kernel(const u32x4_t* __restrict__ z, const float* __restrict__ scale,
-                                                         const float* __restrict__ shift, const u32x4_t* __restrict__ res,
-                                                         u32x4_t* __restrict__ y, int c, int c8, int hw, size_t total, int relu) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int blk = (int)((i / hw) % c8);
+__global__ __launch_bounds__(256) void bn16_apply_kernel(const u32x4_t* __restrict__ z, const double* __restrict__ part,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                         float* __restrict__ moving_mean, float* __restrict__ moving_var,
+                                                         const u32x4_t* __restrict__ res, u32x4_t* __restrict__ y, int n, int c,
+                                                         int c8, int hw, int nsplit, double count, float eps, float momentum,
+                                                         int relu) {
+    const int blk = blockIdx.x;
+    __shared__ float s_scale[8], s_shift[8];
+    {
+        const int j = threadIdx.x >> 5, ch = blk * 8 + j;
+        double s0, s1;
+        bn16_channel_sums(part, ch, c, nsplit, s0, s1);
+        if ((threadIdx.x & 31) == 0) {
+            float sc = 0.f, sh = 0.f;
+            if (ch < c) {
+                const double mean = s0 / count;
+                double var = s1 / count - mean * mean;
+                if (var < 0.0) var = 0.0;
+                const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+                sc = gamma[ch] * invstd;
+                sh = beta[ch] - (float)mean * sc;
+                if (blockIdx.y == 0) {
+                    save_mean[ch] = (float)mean;
+                    save_invstd[ch] = invstd;
+                    if (moving_mean) {
+                        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                        moving_mean[ch] = momentum * moving_mean[ch] + (1.f - momentum) * (float)mean;
+                        moving_var[ch] = momentum * moving_var[ch] + (1.f - momentum) * (float)unbiased;
+                    }
+                }
+            }
+            s_scale[j] = sc;
+            s_shift[j] = sh;
+        }
+    }
+    __syncthreads();
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = s_scale[j]; sh[j] = s_shift[j]; }
+    const size_t per_blk = (size_t)n * hw;
+    const size_t len = (per_blk + gridDim.y - 1) / gridDim.y;
+    const size_t e0 = (size_t)blockIdx.y * len, e1 = e0 + len < per_blk ? e0 + len : per_blk;
+    for (size_t e = e0 + threadIdx.x; e < e1; e += 256) {
+        const size_t img = e / hw;
+        const size_t i = (img * c8 + blk) * hw + (e - img * hw);
         const h16x8 zv = __builtin_bit_cast(h16x8, z[i]);
         h16x8 rv = zv;
         if (res) rv = __builtin_bit_cast(h16x8, res[i]);
         h16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int ch = blk * 8 + j;
             float v = 0.f;
-            if (ch < c) {
-                v = (float)zv[j] * scale[ch] + shift[ch];
+            if (blk * 8 + j < c) {
+                v = (float)zv[j] * sc[j] + sh[j];
                 if (res) v += (float)rv[j];
                 if (relu) v = fmaxf(v, 0.f);
             }
@@ -363,13 +423,50 @@ __global__ __launch_bounds__(256) void bn16_apply_kernel(const u32x4_t* __restri
 }
 
 __global__ __launch_bounds__(256) void bn16_bwd_apply_kernel(const u32x4_t* __restrict__ dy, const u32x4_t* __restrict__ z,
-                                                             const u32x4_t* __restrict__ y, const float* __restrict__ gamma,
-                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                             const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                             u32x4_t* __restrict__ dz, u32x4_t* __restrict__ dres, int c, int c8,
-                                                             int hw, size_t total, int relu, float inv_count) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int blk = (int)((i / hw) % c8);
+                                                             const u32x4_t* __restrict__ y, const double* __restrict__ part,
+                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, float* __restrict__ dgamma_acc,
+                                                             float* __restrict__ dbeta_acc, u32x4_t* __restrict__ dz,
+                                                             u32x4_t* __restrict__ dres, int n, int c, int c8, int hw, int nsplit,
+                                                             int relu, float inv_count) {
+    const int blk = blockIdx.x;
+    __shared__ float s_k[8], s_mu[8], s_is[8], s_mb[8], s_mg[8];
+    {
+        const int j = threadIdx.x >> 5, ch = blk * 8 + j;
+        double s0, s1;
+        bn16_channel_sums(part, ch, c, nsplit, s0, s1);
+        if ((threadIdx.x & 31) == 0) {
+            float k = 0.f, mu = 0.f, is = 0.f, mb = 0.f, mg = 0.f;
+            if (ch < c) {
+                const float db = (float)s0, dg = (float)s1;
+                mu = mean[ch];
+                is = invstd[ch];
+                k = gamma[ch] * is;
+                mb = db * inv_count;
+                mg = dg * inv_count;
+                if (blockIdx.y == 0) {
+                    dbeta[ch] = db;
+                    dgamma[ch] = dg;
+                    if (dgamma_acc && dbeta_acc) {  // + straight into the caller's gradient buffers (no separate add launch)
+                        dbeta_acc[ch] += db;
+                        dgamma_acc[ch] += dg;
+                    }
+                }
+            }
+            s_k[j] = k; s_mu[j] = mu; s_is[j] = is; s_mb[j] = mb; s_mg[j] = mg;
+        }
+    }
+    __syncthreads();
+    float k[8], mu[8], is[8], mb[8], mg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { k[j] = s_k[j]; mu[j] = s_mu[j]; is[j] = s_is[j]; mb[j] = s_mb[j]; mg[j] = s_mg[j]; }
+    const size_t per_blk = (size_t)n * hw;
+    const size_t len = (per_blk + gridDim.y - 1) / gridDim.y;
+    const size_t e0 = (size_t)blockIdx.y * len, e1 = e0 + len < per_blk ? e0 + len : per_blk;
+    for (size_t e = e0 + threadIdx.x; e < e1; e += 256) {
+        const size_t img = e / hw;
+        const size_t i = (img * c8 + blk) * hw + (e - img * hw);
         const h16x8 gv = __builtin_bit_cast(h16x8, dy[i]);
         const h16x8 zv = __builtin_bit_cast(h16x8, z[i]);
         h16x8 yv = zv;
@@ -377,14 +474,12 @@ __global__ __launch_bounds__(256) void bn16_bwd_apply_kernel(const u32x4_t* __re
         h16x8 oz, og;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int ch = blk * 8 + j;
             float g = 0.f, d = 0.f;
-            if (ch < c) {
+            if (blk * 8 + j < c) {
                 g = (float)gv[j];
                 if (relu && !((float)yv[j] > 0.f)) g = 0.f;
-                const float is = invstd[ch];
-                const float xh = ((float)zv[j] - mean[ch]) * is;
-                d = gamma[ch] * is * (g - dbeta[ch] * inv_count - xh * dgamma[ch] * inv_count);
+                const float xh = ((float)zv[j] - mu[j]) * is[j];
+                d = k[j] * (g - mb[j] - xh * mg[j]);
             }
             oz[j] = (_Float16)d;
             og[j] = (_Float16)g;
@@ -434,6 +529,14 @@ static void bn16_split(int n, int c8, int hw, int& gi, int& gp) {
     gp = want / gi;
     if (gp < 1) gp = 1;
     while (gp > 1 && (hw + gp - 1) / gp < 256) --gp;  // at least one element per thread
+}
+
+// pixel-range chunks per channel block of the apply kernels: ~768 blocks in all, each streaming at least 1024 elements
+static unsigned bn16_apply_chunks(int n, int c8, int hw) {
+    size_t chunks = (768 + c8 - 1) / c8;
+    const size_t per_blk = (size_t)n * hw;
+    while (chunks > 1 && per_blk / chunks < 1024) --chunks;
+    return (unsigned)chunks;
 }
 
 static int log2_exact_t(int v) {
@@ -580,15 +683,10 @@ int mp_f16_bn_train_fwd(const void* z, const float* gamma, const float* beta, co
                        nullptr, nullptr, nullptr, part, n, c, c8, hw, 0, gi, gp);
     int rc = check_launch();
     if (rc != MP_OK) return rc;
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(c), dim3(64), 0, s, part, gamma, beta, save_mean, save_invstd,
-                       scale, shift, moving_mean, moving_var, c, (double)n * hw, eps, momentum, gi * gp);
-    rc = check_launch();
-    if (rc != MP_OK) return rc;
-    const size_t total = (size_t)n * c8 * hw;
-    size_t blocks = (total + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(bn16_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const u32x4_t*>(z), scale, shift,
-                       reinterpret_cast<const u32x4_t*>(res), reinterpret_cast<u32x4_t*>(y), c, c8, hw, total, relu ? 1 : 0);
+    (void)scale; (void)shift;
+    hipLaunchKernelGGL(bn16_apply_kernel, dim3(c8, bn16_apply_chunks(n, c8, hw)), dim3(256), 0, s, reinterpret_cast<const u32x4_t*>(z),
+                       part, gamma, beta, save_mean, save_invstd, moving_mean, moving_var, reinterpret_cast<const u32x4_t*>(res),
+                       reinterpret_cast<u32x4_t*>(y), n, c, c8, hw, gi * gp, (double)n * hw, eps, momentum, relu ? 1 : 0);
     return check_launch();
 }
 
@@ -609,16 +707,11 @@ int mp_f16_bn_train_bwd(const void* dy, const void* z, const void* y, const floa
                        c8, hw, relu ? 1 : 0, gi, gp);
     int rc = check_launch();
     if (rc != MP_OK) return rc;
-    // one stage-2 launch writes dgamma / dbeta and, when given, also adds them into the caller's gradient buffers
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(c), dim3(64), 0, s, part, dgamma, dbeta, dgamma_acc, dbeta_acc, c, gi * gp);
-    rc = check_launch();
-    if (rc != MP_OK) return rc;
-    const size_t total = (size_t)n * c8 * hw;
-    size_t blocks = (total + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(bn16_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const u32x4_t*>(dy),
-                       reinterpret_cast<const u32x4_t*>(z), reinterpret_cast<const u32x4_t*>(y), gamma, save_mean, save_invstd, dgamma,
-                       dbeta, reinterpret_cast<u32x4_t*>(dz), reinterpret_cast<u32x4_t*>(dres), c, c8, hw, total, relu ? 1 : 0,
+    const bool acc = dgamma_acc && dbeta_acc;
+    hipLaunchKernelGGL(bn16_bwd_apply_kernel, dim3(c8, bn16_apply_chunks(n, c8, hw)), dim3(256), 0, s,
+                       reinterpret_cast<const u32x4_t*>(dy), reinterpret_cast<const u32x4_t*>(z), reinterpret_cast<const u32x4_t*>(y),
+                       part, gamma, save_mean, save_invstd, dgamma, dbeta, acc ? dgamma_acc : nullptr, acc ? dbeta_acc : nullptr,
+                       reinterpret_cast<u32x4_t*>(dz), reinterpret_cast<u32x4_t*>(dres), n, c, c8, hw, gi * gp, relu ? 1 : 0,
                        (float)(1.0 / ((double)n * hw)));
     return check_launch();
 }
