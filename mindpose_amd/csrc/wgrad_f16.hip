@@ -241,7 +241,12 @@ int geometry(const mp_conv_desc* d, Wgrad16Params& p, size_t& lds_bytes) {
     p.tiles = p.N * p.tiles_y;
     p.ci_tiles = (p.Cin + 31) / 32;
     const int ct = ((p.Cout + 31) / 32) * p.ci_tiles;
-    int splits = 512 / ct;  // two workgroups per CU; the slab reduce reads splits x |dW| floats, so no finer than that
+    int target = 512;  // two workgroups per CU; the slab reduce reads splits x |dW| floats, so no finer than that
+    if (const char* e = getenv("MP_WGRAD16_WGS")) {  // experiments: total workgroups per launch
+        const int v = atoi(e);
+        if (v >= 1) target = v;
+    }
+    int splits = target / ct;
     if (splits < 1) splits = 1;
     if (splits > p.tiles) splits = p.tiles;
     p.tiles_per_split = (p.tiles + splits - 1) / splits;
