@@ -265,6 +265,34 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// Small weights (the 32- / 64-channel layers): G threads per element share the walk over the slabs - see the fp16 twin in
+// wgrad_f16.hip; fixed-order combine through LDS, deterministic.
+template <int G>
+__global__ __launch_bounds__(256) void wgrad_reduce_grouped_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                                   size_t count, int splits, int accumulate) {
+    constexpr int E = 256 / G;
+    __shared__ float sm[G][E];
+    const int e = threadIdx.x % E, g = threadIdx.x / E;
+    const size_t i = (size_t)blockIdx.x * E + e;
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i < count) {
+        int k = g, j = 0;
+        for (; k + 3 * G < splits; k += 4 * G) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) part[u] += slabs[(size_t)(k + u * G) * count + i];
+        }
+        for (; k < splits; k += G, ++j) part[j] += slabs[(size_t)k * count + i];
+    }
+    sm[g][e] = (part[0] + part[1]) + (part[2] + part[3]);
+    __syncthreads();
+    if (g == 0 && i < count) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < G; ++q) v += sm[q][e];
+        dw[i] = accumulate ? dw[i] + v : v;
+    }
+}
+
 static int odd_up(int v) { return v | 1; }
 
 static int wgrad_geometry(const mp_conv_desc* d, WgradParams& p, size_t& lds_bytes) {
@@ -399,9 +427,17 @@ int mp_conv_wgrad(const mp_conv_desc* desc, const float* x, const float* dz, flo
 #undef MP_WGRAD_LAUNCH
     rc = check_launch();
     if (rc != MP_OK) return rc;
-    size_t blocks = (count + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p.slabs, dw, count, p.splits, accumulate ? 1 : 0);
+    if (count <= 18432 && p.splits >= 64) {
+        hipLaunchKernelGGL(wgrad_reduce_grouped_kernel<16>, dim3((unsigned)((count + 15) / 16)), dim3(256), 0, s, p.slabs, dw, count,
+                           p.splits, accumulate ? 1 : 0);
+    } else if (count <= 73728 && p.splits >= 16) {
+        hipLaunchKernelGGL(wgrad_reduce_grouped_kernel<4>, dim3((unsigned)((count + 63) / 64)), dim3(256), 0, s, p.slabs, dw, count,
+                           p.splits, accumulate ? 1 : 0);
+    } else {
+        size_t blocks = (count + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p.slabs, dw, count, p.splits, accumulate ? 1 : 0);
+    }
     return check_launch();
 }
 

@@ -203,6 +203,37 @@ __global__ __launch_bounds__(256) void wgrad16_reduce_kernel(const float* __rest
     }
 }
 
+// The same reduction for SMALL weights: with |dW| = 9 K floats (the 32-channel layers) the kernel above is 36 blocks of
+// threads that each walk 512 slabs serially - latency-bound at ~25 us.  Here a block serves 256 / G elements with G threads
+// per element, thread g summing slabs g, g + G, ... (four interleaved partial sums), then a fixed-order combine through LDS
+// (deterministic): G times the blocks, 1 / G of the serial depth.
+template <int G>
+__global__ __launch_bounds__(256) void wgrad16_reduce_grouped_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                                     size_t count, int splits, float scale, int accumulate) {
+    constexpr int E = 256 / G;
+    __shared__ float sm[G][E];
+    const int e = threadIdx.x % E, g = threadIdx.x / E;
+    const size_t i = (size_t)blockIdx.x * E + e;
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i < count) {
+        int k = g, j = 0;
+        for (; k + 3 * G < splits; k += 4 * G) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) part[u] += slabs[(size_t)(k + u * G) * count + i];
+        }
+        for (; k < splits; k += G, ++j) part[j] += slabs[(size_t)k * count + i];
+    }
+    sm[g][e] = (part[0] + part[1]) + (part[2] + part[3]);
+    __syncthreads();
+    if (g == 0 && i < count) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < G; ++q) v += sm[q][e];
+        v *= scale;
+        dw[i] = accumulate ? dw[i] + v : v;
+    }
+}
+
 constexpr int kNZ = 4, kNX = 10;
 
 int geometry(const mp_conv_desc* d, Wgrad16Params& p, size_t& lds_bytes) {
@@ -298,9 +329,18 @@ int mp_f16_conv_wgrad(const mp_conv_desc* desc, const void* x, const void* dz, f
     else if (desc->kh == 3) rc = desc->stride == 1 ? launch_wgrad16<3, 1>(p, lds, s) : launch_wgrad16<3, 2>(p, lds, s);
     else rc = desc->stride == 1 ? launch_wgrad16<1, 1>(p, lds, s) : launch_wgrad16<1, 2>(p, lds, s);
     if (rc != MP_OK) return rc;
-    size_t blocks = (count + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(wgrad16_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p.slabs, dw, count, p.splits, scale, accumulate ? 1 : 0);
+    if (count * 16 <= 147456 * 2 && p.splits >= 64) {  // <= 18 K weights (32-channel 3x3): 16 threads per element
+        hipLaunchKernelGGL(wgrad16_reduce_grouped_kernel<16>, dim3((unsigned)((count + 15) / 16)), dim3(256), 0, s, p.slabs, dw, count,
+                           p.splits, scale, accumulate ? 1 : 0);
+    } else if (count * 4 <= 147456 * 2 && p.splits >= 16) {  // <= 74 K weights (64-channel 3x3, the 1x1 convs): 4 per element
+        hipLaunchKernelGGL(wgrad16_reduce_grouped_kernel<4>, dim3((unsigned)((count + 63) / 64)), dim3(256), 0, s, p.slabs, dw, count,
+                           p.splits, scale, accumulate ? 1 : 0);
+    } else {
+        size_t blocks = (count + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(wgrad16_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p.slabs, dw, count, p.splits, scale,
+                           accumulate ? 1 : 0);
+    }
     return check_launch();
 }
 
