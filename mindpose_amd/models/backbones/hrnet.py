@@ -42,9 +42,9 @@ class BasicBlock(nn.Module):
         return plan.conv(out, self.conv2, self.bn2, relu=True, res1=identity)
 
     def train_forward(self, x: torch.Tensor) -> torch.Tensor:
-        identity = x
-        if self.down_sample is not None:
-            identity = T.conv_bn_act(x, self.down_sample[0], self.down_sample[1], relu=False)
+        if self.down_sample is None:
+            return T.residual_block(x, [(self.conv1, self.bn1), (self.conv2, self.bn2)])
+        identity = T.conv_bn_act(x, self.down_sample[0], self.down_sample[1], relu=False)
         out = T.conv_bn_act(x, self.conv1, self.bn1, relu=True)
         return T.conv_bn_act(out, self.conv2, self.bn2, relu=True, res=identity)
 
@@ -77,6 +77,8 @@ class Bottleneck(nn.Module):
         identity = x
         if self.down_sample is not None:
             identity = T.conv_bn_act(x, self.down_sample[0], self.down_sample[1], relu=False)
+        if self.down_sample is None:
+            return T.residual_block(x, [(self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)])
         out = T.conv_bn_act(x, self.conv1, self.bn1, relu=True)
         out = T.conv_bn_act(out, self.conv2, self.bn2, relu=True)
         return T.conv_bn_act(out, self.conv3, self.bn3, relu=True, res=identity)

@@ -6,6 +6,7 @@ Reference semantics: the cells of mindpose/models/backbones/hrnet.py run by mind
 (tools/train.py:176-233); amp aside, everything here computes in fp32.
 """
 import ctypes
+import os
 from typing import Optional
 
 import numpy as np
@@ -339,10 +340,10 @@ def _ones_zeros16(c: int, device):
     return _ones_zeros((c + 15) // 16 * 16, device)
 
 
-def _conv16_launch(lib, d, x, packed, scale, shift, out, what):
-    v = tune_conv_variant(lib, d, x, packed, scale, shift, None, None, out, half=True)  # one-tile / multi-tile, cached per shape
-    _lib.check(lib.mp_f16_conv2d_fwd(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift), None, None,
-                                     _lib.ptr(out), _lib.stream()), what)
+def _conv16_launch(lib, d, x, packed, scale, shift, out, what, res1=None):
+    v = tune_conv_variant(lib, d, x, packed, scale, shift, res1, None, out, half=True)  # one-tile / multi-tile, cached per shape
+    _lib.check(lib.mp_f16_conv2d_fwd(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(res1),
+                                     None, _lib.ptr(out), _lib.stream()), what)
 
 
 class ToC8Fn(torch.autograd.Function):
@@ -434,7 +435,9 @@ class Conv16Fn(torch.autograd.Function):
             dx = _c8_alloc(n, cin, h, wd, x.device)
             if s == 1:
                 d = _desc(n, cout, ho, wo, cin, k, 1, k - 1 - pad, k - 1 - pad, h, wd, h, wd)
-                _conv16_launch(lib, d, dz, _pack16(lib, w, cin, cout, k, 2, owner=ctx.weight_param), ones, zeros, dx, "conv dgrad")
+                # ResidualBlock16Fn: the gradient that reaches x through the identity is added in this launch's epilogue
+                _conv16_launch(lib, d, dz, _pack16(lib, w, cin, cout, k, 2, owner=ctx.weight_param), ones, zeros, dx, "conv dgrad",
+                               res1=getattr(ctx, "dx_residual", None))
             else:
                 if h != 2 * ho or wd != 2 * wo:
                     raise NotImplementedError("stride-2 data gradient needs even input extents")
@@ -747,6 +750,72 @@ def from_c8(x: torch.Tensor, channels: int) -> torch.Tensor:
 
 def _is_c8(x) -> bool:
     return x.dtype == torch.float16 and x.dim() == 5
+
+
+class _SubCtx:
+    """The slice of an autograd context the per-cell Functions use, so that a composite Function can drive their static
+    forward / backward methods itself."""
+
+    def __init__(self, n_inputs):
+        self.needs_input_grad = (True,) * n_inputs
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+class ResidualBlock16Fn(torch.autograd.Function):
+    """A whole residual block on channel-blocked fp16 - conv+BN+ReLU groups whose last BatchNorm adds the block input and applies
+    the ReLU (BasicBlock: two groups, Bottleneck without down-sample: three) - as ONE autograd node.  Same kernels as the
+    per-cell Functions; what it saves is autograd's separate launch that sums the two gradients reaching the block input:
+    the identity's gradient is added in the epilogue of the first conv's data-gradient launch (160 launches per HRNet-W32
+    step)."""
+
+    @staticmethod
+    def forward(ctx, x, meta, *params):
+        groups = []
+        y = x
+        n_groups = len(meta)
+        for gi, (stride, padding, mm, mv) in enumerate(meta):
+            w, gamma, beta = params[3 * gi: 3 * gi + 3]
+            cc, bc = _SubCtx(5), _SubCtx(7)
+            z = Conv16Fn.forward(cc, y, w, None, stride, padding)
+            last = gi == n_groups - 1
+            y = BatchNormAct16Fn.forward(bc, z, gamma, beta, x if last else None, mm, mv, True)
+            groups.append((cc, bc))
+        ctx.groups = groups
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        grads = []
+        g = dy
+        dres = None
+        for gi in range(len(ctx.groups) - 1, -1, -1):
+            cc, bc = ctx.groups[gi]
+            dz, dgamma, dbeta, dr, _, _, _ = BatchNormAct16Fn.backward(bc, g)
+            if dr is not None:
+                dres = dr
+            if gi == 0:
+                cc.dx_residual = dres
+            g, dw, _, _, _ = Conv16Fn.backward(cc, dz)
+            grads = [dw, dgamma, dbeta] + grads
+        ctx.groups = None
+        return (g, None, *grads)
+
+
+def residual_block(x, groups):
+    """``groups`` = [(conv, bn), ...]; relu(bn_k(conv_k(... relu(bn_1(conv_1 x)) ...)) + x).  Channel-blocked fp16 activations with
+    stride-1 first conv take the one-node form above; anything else composes the per-cell functions."""
+    first = groups[0][0]
+    if _is_c8(x) and first.stride == 1 and all(cv.bias is None for cv, _ in groups) and os.environ.get("MINDPOSE_FUSE_RESIDUAL", "1") != "0":
+        meta = tuple((cv.stride, cv.padding, bn.moving_mean, bn.moving_variance) for cv, bn in groups)
+        params = [t for cv, bn in groups for t in (cv.weight, bn.gamma, bn.beta)]
+        return ResidualBlock16Fn.apply(x, meta, *params)
+    y = x
+    for i, (cv, bn) in enumerate(groups):
+        y = conv_bn_act(y, cv, bn, relu=True, res=x if i == len(groups) - 1 else None)
+    return y
 
 
 def conv_bn_act(x, conv, bn, relu: bool, res: Optional[torch.Tensor] = None):

@@ -391,6 +391,36 @@ def test_batched_weight_pack_equals_individual_packs():
     assert la == lb and torch.equal(pa, pb)
 
 
+def test_residual_block_as_one_autograd_node_matches_per_cell_functions(monkeypatch):
+    """ResidualBlock16Fn (identity gradient added in the first conv's data-gradient epilogue, one rounding) against the per-cell
+    composition (autograd's separate fp16 add): same loss bit for bit, gradients equal up to that one extra fp16 rounding."""
+    import mindpose_amd as mp
+    from mindpose_amd.utils import AdamWeightDecay
+
+    def run(fused):
+        monkeypatch.setenv("MINDPOSE_FUSE_RESIDUAL", "1" if fused else "0")
+        torch.manual_seed(0)
+        net = mp.init_synthetic(mp.create_network("hrnet_w32", "hrnet_head"), seed=0).to(DEV).train()
+        mp.models.auto_mixed_precision(net, "O2")
+        nwl = mp.create_network_with_loss(net, mp.create_loss("joint_mse", use_target_weight=True), has_extra_inputs=True)
+        opt = AdamWeightDecay(net, lr=1e-3, weight_decay=0.05, filter_bias_and_bn=True, overlap=False)
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(2, 3, 64, 64, generator=g).to(DEV)
+        kp = (torch.rand(2, 17, 3, generator=g) * torch.tensor([64.0, 64.0, 2.0])).to(DEV)
+        target, weight = mp.TopDownGenerateTarget(config=dict(image_size=[64, 64], heatmap_size=[16, 16]), sigma=2.0)(kp)
+        opt.zero_grad()
+        loss = nwl(x, target, weight)
+        (loss * 1024.0).backward()
+        return float(loss.detach()), opt.grads.arena.clone()
+
+    l1, g1 = run(True)
+    l0, g0 = run(False)
+    assert l1 == l0
+    cos = torch.nn.functional.cosine_similarity(g1.double(), g0.double(), dim=0)
+    assert float(cos) > 0.9995, float(cos)
+    assert float((g1 - g0).norm() / g0.norm()) < 3e-2
+
+
 def test_maxpool_bwd_and_stem_wgrad_vs_torch():
     g = torch.Generator().manual_seed(8)
     x = torch.randn(3, 5, 18, 14, generator=g)
