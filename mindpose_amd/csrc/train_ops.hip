@@ -303,6 +303,7 @@ __global__ __launch_bounds__(256) void bn16_reduce_kernel(const u32x4_t* __restr
         float f[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) f[j] = 0.f;
+#pragma unroll 4
         for (int i = p0 + threadIdx.x; i < p1; i += 256) {
             const h16x8 zv = __builtin_bit_cast(h16x8, z[base + i]);
             if (BWD) {
@@ -401,6 +402,7 @@ __global__ __launch_bounds__(256) void bn16_apply_kernel(const u32x4_t* __restri
     const size_t per_blk = (size_t)n * hw;
     const size_t len = (per_blk + gridDim.y - 1) / gridDim.y;
     const size_t e0 = (size_t)blockIdx.y * len, e1 = e0 + len < per_blk ? e0 + len : per_blk;
+#pragma unroll 4
     for (size_t e = e0 + threadIdx.x; e < e1; e += 256) {
         const size_t img = e / hw;
         const size_t i = (img * c8 + blk) * hw + (e - img * hw);
@@ -464,6 +466,7 @@ __global__ __launch_bounds__(256) void bn16_bwd_apply_kernel(const u32x4_t* __re
     const size_t per_blk = (size_t)n * hw;
     const size_t len = (per_blk + gridDim.y - 1) / gridDim.y;
     const size_t e0 = (size_t)blockIdx.y * len, e1 = e0 + len < per_blk ? e0 + len : per_blk;
+#pragma unroll 4
     for (size_t e = e0 + threadIdx.x; e < e1; e += 256) {
         const size_t img = e / hw;
         const size_t i = (img * c8 + blk) * hw + (e - img * hw);
