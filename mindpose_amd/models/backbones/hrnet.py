@@ -5,6 +5,7 @@ Same graph, constructor arguments, registry names and parameter names as the ref
 direct fp32-MFMA convolution, and the HRModule fuse rows (:318-344) accumulate in place through the
 conv epilogue (nearest up-sampling happens while storing; nothing is materialised).
 """
+import os
 from typing import Dict, List, Tuple, Type, Union
 
 import torch
@@ -98,6 +99,32 @@ def _emit_conv_bn(plan: Plan, seq: nn.Sequential, x: torch.Tensor, **kw) -> torc
 
 def _train_conv_bn(seq: nn.Sequential, x: torch.Tensor, relu=None) -> torch.Tensor:
     return T.conv_bn_act(x, seq[0], seq[1], relu=(len(seq) > 2) if relu is None else relu)
+
+
+_BRANCH_STREAMS = {}
+_BRANCH_STREAMS_ON = [False]
+
+
+def set_branch_streams(on: bool) -> bool:
+    """Run the branches of every HRModule on side streams in ``train_forward`` (``GraphedTrainStep`` turns this on around its
+    warm-up and capture: inside a hipGraph the fork / join become graph dependencies, so the replay overlaps the small launches
+    of the deep branches with the large ones).  Returns the previous setting.  ``MINDPOSE_TRAIN_BRANCH_STREAMS=0/1`` overrides."""
+    prev = _BRANCH_STREAMS_ON[0]
+    _BRANCH_STREAMS_ON[0] = bool(on)
+    return prev
+
+
+def branch_streams_enabled() -> bool:
+    env = os.environ.get("MINDPOSE_TRAIN_BRANCH_STREAMS")
+    return _BRANCH_STREAMS_ON[0] if env is None else env == "1"
+
+
+
+def _branch_streams(device, n):
+    have = _BRANCH_STREAMS.setdefault(device, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device=device))
+    return have[:n]
 
 
 class HRModule(nn.Module):
@@ -217,9 +244,25 @@ class HRModule(nn.Module):
     def train_forward(self, xs: List[torch.Tensor]) -> List[torch.Tensor]:
         """Training form of hrnet.py:318-344: same term order; one exchange-unit sum kernel per row."""
         xs = list(xs)
-        for i in range(self.num_branches):
-            for blk in self.branches[i]:
-                xs[i] = blk.train_forward(xs[i])
+        if self.num_branches > 1 and xs[0].is_cuda and branch_streams_enabled():
+            # the branches are independent until the exchange unit: branch i > 0 on side stream i (forked from / joined to the
+            # current stream), so the small launches of the deep branches overlap the large ones; autograd replays each node on
+            # its forward stream, which parallelises the backward the same way
+            cur = torch.cuda.current_stream(xs[0].device)
+            side = _branch_streams(xs[0].device, self.num_branches - 1)
+            for i in range(1, self.num_branches):
+                side[i - 1].wait_stream(cur)
+                with torch.cuda.stream(side[i - 1]):
+                    for blk in self.branches[i]:
+                        xs[i] = blk.train_forward(xs[i])
+            for blk in self.branches[0]:
+                xs[0] = blk.train_forward(xs[0])
+            for st in side:
+                cur.wait_stream(st)
+        else:
+            for i in range(self.num_branches):
+                for blk in self.branches[i]:
+                    xs[i] = blk.train_forward(xs[i])
         if self.num_branches == 1:
             return xs
         outs = []
