@@ -213,13 +213,13 @@ def train_bench(args, mp, dev, dist, world, rank):
         mp.models.auto_mixed_precision(net, args.amp)
         scaler = DynamicLossScaleManager()
     nwl = mp.create_network_with_loss(net, mp.create_loss("joint_mse", use_target_weight=True), has_extra_inputs=True)
-    # amp O2 is launch-bound from Python (64 ms per step at any batch): its step is captured into a hipGraph.  The fp32
-    # step is GPU-bound (capture changes nothing: 122.8 ms either way) and stays eager, with the bucket all-reduces
-    # overlapping backward under data parallelism
+    # The step is captured into a hipGraph on one rank: amp O2 is launch-bound from Python (eager ~2450 img/s), and inside the
+    # graph the HRModule branches run on side streams (graph dependencies), which also pays for the GPU-bound fp32 step
+    # (1096 eager -> 1169 img/s).
     # Multi-rank runs default to the eager step (overlapped bucket all-reduces): the graphed step + all-reduce after the
     # replay is covered by tests on one GPU only (a two-rank rehearsal SHARING one GPU serialises graph replays badly, which
     # says nothing about one GPU per rank); MINDPOSE_TRAIN_GRAPH=1 forces it.
-    graphed = os.environ.get("MINDPOSE_TRAIN_GRAPH", "1" if (args.amp != "O0" and world == 1) else "0") != "0"
+    graphed = os.environ.get("MINDPOSE_TRAIN_GRAPH", "1" if world == 1 else "0") != "0"
     opt = AdamWeightDecay(net, lr=1e-3, weight_decay=0.05, filter_bias_and_bn=True, overlap=not graphed)
     tgt = mp.TopDownGenerateTarget(config=dict(image_size=[192, 256], heatmap_size=[48, 64]), sigma=2.0)
     gen = torch.Generator(device="cpu").manual_seed(1000 + rank)
