@@ -339,9 +339,8 @@ def main():
     eval_net = mp.create_eval_network(net, decoder, output_raw=True)
     multi_run = None
     if flip:
-        from mindpose_amd.engine.inferencer.topdown_inferencer import _MultiRunNet
-        from tests.golden.recipes import FLIP_INDEX
-        multi_run = _MultiRunNet(eval_net, decoder, np.array(FLIP_INDEX), shift_heatmap=False).to(dev)
+        from mindpose_amd.engine.inferencer.topdown_inferencer import COCO_FLIP_INDEX, _MultiRunNet
+        multi_run = _MultiRunNet(eval_net, decoder, np.array(COCO_FLIP_INDEX), shift_heatmap=False).to(dev)
 
     n = args.batch
     # synthetic crops written straight into the plan's resident input buffer (inputs in HBM before timing)

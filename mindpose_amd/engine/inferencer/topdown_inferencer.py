@@ -16,6 +16,12 @@ from ...models.decoders import TopDownHeatMapDecoder
 from ...register import register
 
 
+# COCO person key points: mirrored pairs as the reference's configs give them (configs/hrnet/hrnet_w32_ascend.yaml
+# `flip_pairs`) and the channel permutation load_inference_cfg derives from them (topdown_inferencer.py:78-80)
+COCO_FLIP_PAIRS = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]
+COCO_FLIP_INDEX = [0, 2, 1, 4, 3, 6, 5, 8, 7, 10, 9, 12, 11, 14, 13, 16, 15]
+
+
 class _MultiRunNet(nn.Module):
     """Running the inference twice with horizontal-flip TTA (topdown_inferencer.py:146-187)."""
 

@@ -68,6 +68,11 @@ def _tune_file() -> Optional[str]:
     return os.environ.get("MINDPOSE_TUNE_CACHE") or None
 
 
+def _tune_stamp() -> str:
+    """Variant indices only mean something for one build of the kernels on one architecture."""
+    return f"{_lib.load().mp_version().decode()}|gfx950"
+
+
 def _tune_load() -> None:
     global _TUNE_FILE_LOADED
     path = _tune_file()
@@ -77,20 +82,26 @@ def _tune_load() -> None:
     try:
         import json
         with open(path) as f:
-            for k, v in json.load(f).items():
-                _TUNE_CACHE.setdefault(k, int(v))
-    except (OSError, ValueError):
+            doc = json.load(f)
+        if doc.get("stamp") != _tune_stamp():  # written by another library version: variant indices may have moved
+            return
+        for k, v in doc.get("choices", {}).items():
+            _TUNE_CACHE.setdefault(k, int(v))
+    except (OSError, ValueError, AttributeError):
         pass
 
 
 def _tune_save() -> None:
+    """Whole-file replace through a temporary (ranks of one job share the path; a torn file would silently drop the cache)."""
     path = _tune_file()
     if not path:
         return
     try:
         import json
-        with open(path, "w") as f:
-            json.dump({k: v for k, v in _TUNE_CACHE.items() if isinstance(k, str)}, f)
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "w") as f:
+            json.dump({"stamp": _tune_stamp(), "choices": {k: v for k, v in _TUNE_CACHE.items() if isinstance(k, str)}}, f)
+        os.replace(tmp, path)
     except OSError:
         pass
 
@@ -317,7 +328,9 @@ class Plan:
         return packed
 
     def _affine(self, cout: int, bn: Optional[BatchNorm2d], bias: Optional[torch.Tensor], half: bool = False):
-        key = (id(bn) if bn is not None else id(bias), half)
+        # keyed on both parameter holders and the width: a conv with neither BatchNorm nor bias must not share the
+        # ones / zeros pair of another width (the kernel reads cout entries)
+        key = (id(bn) if bn is not None else None, id(bias) if bias is not None else None, cout, half)
         if key in self._folded:
             return self._folded[key]
         if bn is not None:

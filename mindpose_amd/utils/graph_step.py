@@ -58,4 +58,11 @@ class GraphedTrainStep:
             b["pending"] = b["count"]
         self.graph.replay()
         self.updated = self.opt.step(loss_scale_manager=self.mgr)
+        if self.updated:
+            # a replay never passes through PlannedModule.forward, which is what drops recorded inference plans in training
+            # mode: without this an evaluation between graphed steps would replay packed weights / folded BatchNorm of an
+            # earlier parameter state
+            for m in self.nwl.modules():
+                if hasattr(m, "_plans"):
+                    m._plans.clear()
         return self.static_loss

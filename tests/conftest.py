@@ -12,6 +12,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """`gpu` tests are skipped (not failed) on a machine without a HIP device or without the built extension."""
+    import torch
+    reason = None
+    if not torch.cuda.is_available():
+        reason = "no HIP device (run on the GPU box: pytest -m gpu)"
+    elif not os.path.exists(os.path.join(ROOT, "mindpose_amd", "csrc", "libmindpose_hip.so")):
+        reason = "libmindpose_hip.so not built"
+    if reason:
+        skip = pytest.mark.skip(reason=reason)
+        for item in items:
+            if "gpu" in item.keywords:
+                item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
