@@ -1,6 +1,9 @@
 """Benchmark of the hot path: HRNet-W32 256x192 top-down inference (BASELINE.json metric / configs[2]).
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+        N > 1: one rank per GPU over RCCL.  Either the driver launches the ranks itself (torch.distributed.run: RANK /
+        WORLD_SIZE in the environment), or - when no WORLD_SIZE is set - this process starts them as children through
+        torch.distributed.run BEFORE it makes any GPU call and exits with their status.
 
 A step = one pass of the hot path over one per-GPU batch of synthetic 256x192 crops that is already
 resident in HBM: HRNet-W32 backbone + HRNetHead (direct fp32-MFMA conv plan) + TopDownHeatMapDecoder
@@ -12,12 +15,18 @@ Prints ONE JSON line (rank 0) with the contract fields plus
                  algorithmic FLOP per launch / its average launch duration, measured live with HIP
                  events on the launch stream; peak = fp32 matrix-core rate of MI355X_MICROARCH.md.
   cpu_baseline - the CPU oracle (torch-CPU fp32 restatement; the literal MindSpore-CPU path cannot run:
-                 MindSpore is not installable here or on the GPU box) timed on a bounded sample on the
-                 host cores, rank 0 at N=1 only.
+                 MindSpore is not installable here or on the GPU box) timed per SURVEY.md 8(d) on the host cores
+                 (3 warm-up + 10 timed iterations at N=1 and N=32, threads = the process's CPU affinity), plus the reference's
+                 own single-core numpy target loop next to mp_gaussian_target; rank 0 at N=1 only.
+  extra_workloads (N=1, after the headline's timed region) - short legs, each in a child process with its own timed region and
+                 roofline: HRNet-W32 under amp O2, BASELINE configs[4] (W48 384x288 UDP/DARK + flip test, fp16), configs[1]
+                 (SimpleBaseline-R50), and the configs[3] training step in fp32 and in the reference's amp-O2 recipe.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,6 +38,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_FP16_MFMA_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense" (--amp O2 runs only)
+PEAK_HBM_GBPS = 8000.0  # same guide, "HBM3E peak BW 8.0 TB/s spec" (6.29 TB/s measured copy)
 F16_VARIANT_TEMPLATE = {0: "3,2,4,1", 1: "3,4,4,1", 2: "3,3,4,1", 3: "3,2,2,2", 4: "3,1,2,2", 5: "3,2,4,1", 6: "3,4,4,1",
                         7: "3,3,4,1", 8: "3,2,2,2", 9: "3,1,2,2"}
 VARIANT_TEMPLATE = {0: "3,2,4,1", 1: "3,4,4,1", 2: "3,3,4,1", 3: "3,2,2,2", 4: "3,1,2,2", 5: "3,2,2,2", 6: "3,2,4,1",
@@ -152,58 +162,233 @@ def roofline_report(plan, reps=5, layers_csv=""):
     }
 
 
-def cpu_baseline(state_dict, batch, budget_s=20.0):
-    """CPU oracle on the host cores: HRNet-W32 forward + decode on `batch` crops, repeated until ~budget."""
-    from oracle import decoder as od
-    from oracle import nets as onets
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))  # the GPU box grants ~16 host cores per GPU; more threads only thrash
-    torch.set_num_threads(cores)
-    sd = {k: v.detach().cpu() for k, v in state_dict.items()}
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(batch, 3, 256, 192, generator=g)
-    center = np.full((batch, 2), [96.0, 128.0], dtype=np.float32)
-    scale = np.full((batch, 2), [0.96, 1.28], dtype=np.float32)
-    score = np.ones(batch, dtype=np.float32)
-
-    def one():
-        hm = onets.net_forward(sd, x, "hrnet_w32", "hrnet_head").numpy()
-        od.decode(hm, center, scale, score, shift_coord=True)
-
-    t0 = time.perf_counter()
-    one()  # warm-up, also sizes the sample
-    warm = time.perf_counter() - t0
-    log(f"cpu_baseline: warm-up iteration {warm:.1f}s on {cores} threads")
-    max_iters = max(1, min(20, int(budget_s / max(warm, 1e-3))))
-    t0 = time.perf_counter()
-    iters = 0
-    while iters < max_iters:
-        one()
-        iters += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    model = "unknown"
+def _cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
             for line in f:
                 if line.startswith("model name"):
-                    model = line.split(":", 1)[1].strip()
-                    break
+                    return line.split(":", 1)[1].strip()
     except OSError:
         pass
-    return {"value": round(batch * iters / dt, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{iters} x batch {batch} HRNet-W32 256x192 forward+decode, torch-CPU fp32 oracle "
-                      f"(MindSpore-CPU reference path not installable), os.cpu_count={os.cpu_count()}, cpu='{model}'"}
+    return "unknown"
+
+
+def cpu_baseline(state_dict, mp, dev):
+    """the CPU oracle (same graph, torch-CPU fp32) on the host cores of this box - threads = the CPU affinity
+    of the process, 3 warm-up + 10 timed iterations at N=1 and N=32 (HRNet-W32 256x192 forward + decode) - and the reference's
+    own target loop (numpy, 17 joints x N samples, ONE core: topdown_transform.py:346-369) beside mp_gaussian_target."""
+    from oracle import decoder as od
+    from oracle import nets as onets
+    from oracle import target as otarget
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, cores)
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().cpu() for k, v in state_dict.items()}
+    g = torch.Generator().manual_seed(0)
+    rates = {}
+    budget_left = 45.0  # hard bound on the whole leg; the protocol's 13 iterations fit it on the 16-core share of a GPU box
+    for batch in (1, 32):
+        x = torch.randn(batch, 3, 256, 192, generator=g)
+        center = np.full((batch, 2), [96.0, 128.0], dtype=np.float32)
+        scale = np.full((batch, 2), [0.96, 1.28], dtype=np.float32)
+        score = np.ones(batch, dtype=np.float32)
+
+        def one():
+            hm = onets.net_forward(sd, x, "hrnet_w32", "hrnet_head").numpy()
+            od.decode(hm, center, scale, score, shift_coord=True)
+
+        t0 = time.perf_counter()
+        for _ in range(3):
+            one()
+        warm = (time.perf_counter() - t0) / 3
+        iters = 10 if warm * 10 <= budget_left else max(1, int(budget_left / max(warm, 1e-3)))
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            one()
+        dt = time.perf_counter() - t0
+        budget_left -= dt + 3 * warm
+        rates[batch] = dict(images_per_s=round(batch * iters / dt, 2), ms_per_iter=round(dt / iters * 1e3, 2), timed_iters=iters)
+        log(f"cpu_baseline: N={batch}: {rates[batch]['images_per_s']} img/s on {cores} threads ({iters} timed iterations)")
+    # the reference's target generation IS numpy on one core: time the pinned restatement next to the HIP kernel
+    torch.set_num_threads(1)
+    rng = np.random.default_rng(0)
+    n_t = 128
+    kp = np.empty((n_t, 17, 3), dtype=np.float32)
+    kp[..., 0] = rng.uniform(-20, 212, size=(n_t, 17))
+    kp[..., 1] = rng.uniform(-20, 276, size=(n_t, 17))
+    kp[..., 2] = (rng.uniform(size=(n_t, 17)) < 0.7)
+    otarget.generate_target(kp[:8], (192, 256), (48, 64), sigma=2.0)
+    t0 = time.perf_counter()
+    otarget.generate_target(kp, (192, 256), (48, 64), sigma=2.0)
+    cpu_t = time.perf_counter() - t0
+    torch.set_num_threads(cores)
+    tgt = mp.TopDownGenerateTarget(config=dict(image_size=[192, 256], heatmap_size=[48, 64]), sigma=2.0)
+    kpd = torch.from_numpy(kp).to(dev)
+    tgt(kpd)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        tgt(kpd)
+    e1.record()
+    e1.synchronize()
+    gpu_t = e0.elapsed_time(e1) * 1e-3 / 20
+    target_bytes = n_t * 17 * 64 * 48 * 4
+    return {"value": rates[32]["images_per_s"], "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"SURVEY 8(d) protocol: 3 warm-up + {rates[32]['timed_iters']} timed iterations of batch 32 (and batch 1) HRNet-W32 "
+                      f"256x192 forward+decode, torch-CPU fp32 oracle (MindSpore-CPU reference path not installable); "
+                      f"threads=len(os.sched_getaffinity(0))={cores}, torch.get_num_threads()={torch.get_num_threads()}, "
+                      f"os.cpu_count()={os.cpu_count()}, cpu='{_cpu_model()}'",
+            "batch_1": rates[1], "batch_32": rates[32],
+            "target_generation": {"cpu_samples_per_s": round(n_t / cpu_t, 1), "cpu_cores": 1,
+                                  "cpu_what": "numpy restatement of TopDownGenerateTarget._encoding (17 joints x 128 samples, one core; "
+                                              "pinned bit-exact to the reference's own output)",
+                                  "gpu_samples_per_s": round(n_t / gpu_t, 1), "gpu_us_per_batch_128": round(gpu_t * 1e6, 2),
+                                  "gpu_write_GBps": round(target_bytes / gpu_t / 1e9, 1),
+                                  "gpu_what": "mp_gaussian_target, 128 x 17 x 64x48 fp32 heat-maps written once (HBM-bound, 8 TB/s peak)"}}
+
+
+class CallTimer:
+    """HIP events around every call of the named C-ABI entries (recorded on the launch stream, read once at the end): the
+    per-kernel-family device time of an eager training step.  The entries are wrapped on the loaded library object, which is
+    what the host mirror calls through, and restored afterwards."""
+
+    CONV = ("mp_f16_conv2d_fwd", "mp_conv2d_fwd_variant", "mp_conv2d_fwd")
+    WGRAD = ("mp_f16_conv_wgrad", "mp_conv_wgrad")
+    BN = ("mp_f16_bn_train_fwd", "mp_f16_bn_train_bwd", "mp_bn_train_fwd", "mp_bn_train_bwd_acc", "mp_bn_train_bwd")
+    OTHER = ("mp_f16_fuse_upsample_sum", "mp_f16_fuse_upsample_sum_bwd", "mp_fuse_upsample_sum", "mp_fuse_upsample_sum_bwd",
+             "mp_f16_to_c8", "mp_f16_from_c8", "mp_f16_pack_weight_batch", "mp_conv_pack_weight_batch", "mp_f16_pack_weight",
+             "mp_conv_pack_weight", "mp_joints_mse_fwd", "mp_joints_mse_bwd", "mp_gaussian_target", "mp_adamw_step_scaled",
+             "mp_grad_finite_check")
+
+    def __init__(self, lib):
+        self.lib, self.records, self._orig = lib, [], {}
+
+    def __enter__(self):
+        for name in self.CONV + self.WGRAD + self.BN + self.OTHER:
+            orig = getattr(self.lib, name)
+            self._orig[name] = orig
+            setattr(self.lib, name, self._wrap(name, orig))
+        return self
+
+    def __exit__(self, *exc):
+        for name, orig in self._orig.items():
+            setattr(self.lib, name, orig)
+
+    def _wrap(self, name, orig):
+        def call(*args):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = orig(*args)
+            e1.record()
+            self.records.append((name, self._describe(name, args), e0, e1))
+            return rc
+        return call
+
+    @staticmethod
+    def _describe(name, args):
+        if name in CallTimer.CONV + CallTimer.WGRAD:
+            d = args[0]._obj  # ctypes.byref(mp_conv_desc)
+            flops = 2.0 * d.n * d.conv_h * d.conv_w * d.cout * d.cin * d.kh * d.kw
+            variant = args[1] if name in ("mp_f16_conv2d_fwd", "mp_conv2d_fwd_variant") else None
+            return dict(flops=flops, shape=f"{d.kh}x{d.kw} s{d.stride} {d.cin}->{d.cout} @{d.h}x{d.w} N={d.n}", variant=variant,
+                        ks=d.kh, stride=d.stride)
+        if name in CallTimer.BN:
+            fwd = name.endswith("fwd")
+            half = "f16" in name
+            # positional layout of the BatchNorm entries (include/mindpose_hip.h): fwd (z,g,b,res,y,...,n,c,hw at 9..11);
+            # bwd (dy,z,y,g,mean,invstd,dz,dres,...) with n,c,hw after the pointer block
+            if fwd:
+                n, c, hw = args[9:12]
+                tensors = 2 + (args[3] is not None)            # read z, write y (+ read res)
+            else:
+                k = 12 if name in ("mp_f16_bn_train_bwd", "mp_bn_train_bwd_acc") else 10
+                n, c, hw = args[k:k + 3]
+                tensors = 4 + (args[7] is not None)            # read dy, z, y; write dz (+ dres)
+            return dict(bytes=float(tensors) * n * c * hw * (2 if half else 4), shape=f"C={c} HW={hw} N={n}")
+        return {}
+
+    def summary(self):
+        torch.cuda.synchronize()
+        fam = {}
+        for name, info, e0, e1 in self.records:
+            t = e0.elapsed_time(e1) * 1e-3
+            key = name
+            f = fam.setdefault(key, dict(time=0.0, launches=0, flops=0.0, bytes=0.0, shapes={}))
+            f["time"] += t
+            f["launches"] += 1
+            f["flops"] += info.get("flops", 0.0)
+            f["bytes"] += info.get("bytes", 0.0)
+            if "shape" in info:
+                sh = f["shapes"].setdefault((info["shape"], info.get("variant"), info.get("ks"), info.get("stride")),
+                                            dict(time=0.0, launches=0, flops=0.0))
+                sh["time"] += t
+                sh["launches"] += 1
+                sh["flops"] += info.get("flops", 0.0)
+        return fam
+
+
+def f16_kernel_for(ks, stride, variant):
+    return kernel_name(dict(kind_id=3, ks=ks, stride=stride, variant=variant, light=5 <= variant <= 9)) if variant is not None and variant >= 0 else "library heuristic"
+
+
+def f32_kernel_for(ks, stride, variant):
+    light = variant in (0, 5, 7)  # conv_mfma.h variant_light
+    return kernel_name(dict(kind_id=0, ks=ks, stride=stride, variant=variant, light=light)) if variant is not None and variant >= 0 else "library heuristic"
+
+
+def train_roofline(eager_step, half):
+    """Roofline of the training step's dominant kernel family: one eager step (same kernels as the graph replay, one stream) with
+    HIP events around every C-ABI call.  Conv / weight-gradient entries are priced in algorithmic FLOP (2 x MACs), the BatchNorm
+    passes in algorithmic bytes (each operand tensor once)."""
+    from mindpose_amd import _lib
+    lib = _lib.load()
+    eager_step()  # warm (allocator, tuner)
+    with CallTimer(lib) as ct:
+        eager_step()
+        fam = ct.summary()
+    total = sum(f["time"] for f in fam.values())
+    mfma_peak = PEAK_FP16_MFMA_TFLOPS if half else PEAK_FP32_MFMA_TFLOPS
+    dom = max(fam, key=lambda k: fam[k]["time"])
+    d = fam[dom]
+    per_entry = {}
+    for k, f in sorted(fam.items(), key=lambda kv: -kv[1]["time"]):
+        e = {"launches": f["launches"], "ms": round(f["time"] * 1e3, 3), "share": round(f["time"] / total, 3)}
+        if f["flops"]:
+            e["tflops"] = round(f["flops"] / f["time"] / 1e12, 2)
+        if f["bytes"]:
+            e["GBps"] = round(f["bytes"] / f["time"] / 1e9, 1)
+        per_entry[k] = e
+    out = {"timing": "HIP events around each C-ABI call of one eager step on one stream (the timed region replays the same kernels "
+                     "from a hipGraph with the HRModule branches on side streams)",
+           "entry": dom, "launches_per_step": d["launches"], "share_of_step_kernel_time": round(d["time"] / total, 3),
+           "sum_kernel_ms": round(total * 1e3, 3), "per_entry": per_entry, "traffic": None}
+    if d["flops"]:
+        shapes = d["shapes"]
+        top = max(shapes, key=lambda k: shapes[k]["time"])
+        name = (f16_kernel_for if "f16" in dom else f32_kernel_for)(top[2], top[3], top[1]) if dom in CallTimer.CONV else (
+            f"conv_wgrad_f16_kernel<{top[2]},{top[3]}>" if "f16" in dom else f"conv_wgrad_pipe_kernel<{top[2]},{top[3]}>")
+        t = shapes[top]
+        ach = t["flops"] / t["time"] / 1e12
+        out.update({"bound": "mfma", "achieved": round(ach, 2), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(ach / mfma_peak, 4),
+                    "kernel": name, "shape": top[0], "kernel_launches_per_step": t["launches"],
+                    "flop_per_launch": round(t["flops"] / t["launches"]), "avg_launch_us": round(t["time"] / t["launches"] * 1e6, 2),
+                    "all_launches_of_entry": {"achieved": round(d["flops"] / d["time"] / 1e12, 2),
+                                              "frac": round(d["flops"] / d["time"] / 1e12 / mfma_peak, 4)}})
+    else:
+        ach = d["bytes"] / d["time"] / 1e9
+        out.update({"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBPS, 4),
+                    "kernel": dom, "bytes_per_launch": round(d["bytes"] / d["launches"]),
+                    "avg_launch_us": round(d["time"] / d["launches"] * 1e6, 2)})
+    return out
 
 
 def train_bench(args, mp, dev, dist, world, rank):
-    """configs[3] in fp32: HRNet-W32 256x192 training step, data parallel - Gaussian targets on the device, forward
-    with batch-statistics BatchNorm, JointsMSELoss, backward (MFMA dgrad/wgrad), bucketed RCCL gradient mean
-    overlapped with backward, AdamWeightDecay.  Extra measurement (the contract metric is inference)."""
+    """configs[3]: HRNet-W32 256x192 training step, data parallel - Gaussian targets on the device, forward with
+    batch-statistics BatchNorm, JointsMSELoss, backward (MFMA dgrad/wgrad), RCCL gradient mean, AdamWeightDecay.
+    Extra measurement (the contract metric is inference)."""
     from mindpose_amd.utils import AdamWeightDecay, DynamicLossScaleManager
     n = args.batch
     bb, hd = ("resnet50", "simple_baseline_head") if args.workload == "simplebaseline_r50_train" else ("hrnet_w32", "hrnet_head")
@@ -213,13 +398,11 @@ def train_bench(args, mp, dev, dist, world, rank):
         mp.models.auto_mixed_precision(net, args.amp)
         scaler = DynamicLossScaleManager()
     nwl = mp.create_network_with_loss(net, mp.create_loss("joint_mse", use_target_weight=True), has_extra_inputs=True)
-    # The step is captured into a hipGraph on one rank: amp O2 is launch-bound from Python (eager ~2450 img/s), and inside the
-    # graph the HRModule branches run on side streams (graph dependencies), which also pays for the GPU-bound fp32 step
-    # (1096 eager -> 1169 img/s).
-    # Multi-rank runs default to the eager step (overlapped bucket all-reduces): the graphed step + all-reduce after the
-    # replay is covered by tests on one GPU only (a two-rank rehearsal SHARING one GPU serialises graph replays badly, which
-    # says nothing about one GPU per rank); MINDPOSE_TRAIN_GRAPH=1 forces it.
-    graphed = os.environ.get("MINDPOSE_TRAIN_GRAPH", "1" if world == 1 else "0") != "0"
+    # The step (forward + loss + backward) is captured into a hipGraph on every rank: amp O2 is launch-bound from Python
+    # (eager ~2450 img/s) and inside the graph the HRModule branches run on side streams.  Under DP the bucket all-reduces of
+    # the gradient arena are issued right after the replay (RCCL, asynchronous) and the update kernel folds the 1/world in.
+    # MINDPOSE_TRAIN_GRAPH=0: the eager step with the bucket all-reduces launched from backward hooks (overlapped).
+    graphed = os.environ.get("MINDPOSE_TRAIN_GRAPH", "1") != "0"
     opt = AdamWeightDecay(net, lr=1e-3, weight_decay=0.05, filter_bias_and_bn=True, overlap=not graphed)
     tgt = mp.TopDownGenerateTarget(config=dict(image_size=[192, 256], heatmap_size=[48, 64]), sigma=2.0)
     gen = torch.Generator(device="cpu").manual_seed(1000 + rank)
@@ -236,20 +419,23 @@ def train_bench(args, mp, dev, dist, world, rank):
         t0, w0 = tgt(kp)
         gstep = GraphedTrainStep(nwl, opt, (image, t0, w0), loss_scale_manager=scaler)
 
-    def step():
-        if gstep is not None:
-            target, weight = tgt(kp)
-            return gstep(image, target, weight)
+    def eager_step(update=True):
         opt.zero_grad()
         target, weight = tgt(kp)
         loss = nwl(image, target, weight)
         if scaler is not None:
             scaler.scale(loss).backward()
-            opt.step(loss_scale_manager=scaler)
         else:
             loss.backward()
-            opt.step()
+        if update:
+            opt.step(loss_scale_manager=scaler)
         return loss
+
+    def step():
+        if gstep is not None:
+            target, weight = tgt(kp)
+            return gstep(image, target, weight)
+        return eager_step()
 
     def sync_all():
         torch.cuda.synchronize()
@@ -265,13 +451,19 @@ def train_bench(args, mp, dev, dist, world, rank):
         loss = step()
     sync_all()
     elapsed = time.perf_counter() - t0
+    final_loss = float(loss.detach())
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    roofline = None
+    if world == 1 and not args.no_roofline:  # one rank only: an extra instrumented step on rank 0 alone would strand its collectives
+        roofline = train_roofline(lambda: eager_step(update=False), half=scaler is not None)
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        gflop = 45.9 if bb == "hrnet_w32" else None  # ~3x the forward's 15.29 GFLOP
         print(json.dumps({
             "metric": f"images/sec, {args.workload} 256x192 training step (targets+fwd+loss+bwd+grad mean+AdamWeightDecay)",
             "value": round(world * n * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
@@ -281,11 +473,77 @@ def train_bench(args, mp, dev, dist, world, rank):
                                     "matrix-core convs / activations, fp32 statistics + master weights, dynamic loss scale)") +
                                    f": {bb} + {hd} 256x192 training, DP, Gaussian targets + JointsMSE + bucketed RCCL gradient "
                                    "mean + AdamWeightDecay",
-                       "per_gpu_batch": n, "global_batch": n * world, "final_loss": float(loss.detach()),
-                       "step": "one hipGraph replay (forward+loss+backward) + optimizer" if graphed else "eager autograd",
+                       "per_gpu_batch": n, "global_batch": n * world, "final_loss": final_loss,
+                       "gflop_per_image": gflop,
+                       "step_tflops": None if gflop is None else round(gflop * world * n * args.steps / elapsed / 1e3, 2),
+                       "step": ("one hipGraph replay (forward+loss+backward), then bucket all-reduces + overflow check + update"
+                                if graphed else "eager autograd, bucket all-reduces overlapped with backward"),
                        "loss_scale": None if scaler is None else scaler.loss_scale,
                        "skipped_steps": None if scaler is None else scaler.skipped_steps},
-            "roofline": None, "cpu_baseline": None}))
+            "roofline": roofline, "cpu_baseline": None}))
+
+
+# name -> bench.py arguments of the extra legs run after the headline (N=1 only); steps / warm-up are short on purpose
+EXTRA_LEGS = {
+    "hrnet_w32_256x192_infer_ampO2": ["--workload", "hrnet_w32", "--amp", "O2", "--batch", "128", "--steps", "10", "--warmup", "3"],
+    "config5_hrnet_w48_384x288_udp_dark_flip_ampO2": ["--workload", "hrnet_w48_384_udp_flip", "--amp", "O2", "--batch", "64",
+                                                      "--steps", "5", "--warmup", "2"],
+    "config1_simplebaseline_r50_256x192_infer_f32": ["--workload", "simplebaseline_r50", "--batch", "64", "--steps", "5", "--warmup", "2"],
+    "config3_hrnet_w32_train_f32": ["--workload", "hrnet_w32_train", "--batch", "128", "--steps", "5", "--warmup", "2"],
+    "config3_hrnet_w32_train_ampO2": ["--workload", "hrnet_w32_train", "--amp", "O2", "--batch", "128", "--steps", "5", "--warmup", "2"],
+}
+
+
+def run_extra_legs(selected=None, timeout_s=240):
+    """Each leg = this script in a fresh child process (own timed region, own roofline), started AFTER the headline's timed
+    region; a leg that fails or exceeds its limit is reported as such and never takes the headline line down."""
+    out = {}
+    env = dict(os.environ)
+    env.setdefault("MINDPOSE_TUNE_CACHE", os.path.join("/tmp", f"mindpose_tune_{os.getuid()}.json"))
+    for name, leg_args in EXTRA_LEGS.items():
+        if selected and name not in selected:
+            continue
+        t0 = time.perf_counter()
+        log(f"extra leg {name}: {' '.join(leg_args)}")
+        try:
+            proc = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--leg", *leg_args], env=env,
+                                  capture_output=True, text=True, timeout=timeout_s)
+            line = next((ln for ln in reversed(proc.stdout.splitlines()) if ln.startswith("{")), None)
+            if proc.returncode != 0 or line is None:
+                out[name] = {"error": f"rc {proc.returncode}", "stderr_tail": proc.stderr[-400:]}
+                continue
+            r = json.loads(line)
+            rl = r.get("roofline") or {}
+            out[name] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+                         "warmup": r["warmup"], "dtype": r["dtype"], "per_gpu_batch": r["config"].get("per_gpu_batch"),
+                         "workload": r["config"]["workload"],
+                         "roofline": {k: rl.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_us",
+                                                             "launches_per_step", "all_conv_launches", "all_launches_of_entry",
+                                                             "per_entry", "share_of_step_kernel_time") if k in rl},
+                         "leg_wall_s": round(time.perf_counter() - t0, 1)}
+            for k in ("gflop_per_image", "step_tflops", "final_loss", "step", "loss_scale", "skipped_steps"):
+                if k in r["config"]:
+                    out[name][k] = r["config"][k]
+        except subprocess.TimeoutExpired:
+            out[name] = {"error": f"timeout after {timeout_s}s"}
+        except (ValueError, KeyError) as exc:
+            out[name] = {"error": f"unparsable leg output: {exc}"}
+    return out
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks through torch.distributed.run as ONE child process tree.
+    Nothing in this process has touched the GPU yet (importing torch does not), so no GPU-initialised process is replaced."""
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    log(f"no WORLD_SIZE in the environment: launching {n} ranks: {' '.join(cmd)}")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -301,14 +559,17 @@ def main():
                     help="O0 = fp32 (the reference's eval precision, the headline); O2 = fp16 matrix-core kernels (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_workloads legs (N=1 headline runs only)")
+    ap.add_argument("--extra", default="", help="comma-separated subset of the extra legs to run (default: all)")
+    ap.add_argument("--leg", action="store_true", help="this process IS an extra leg: no CPU baseline, no further legs")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     # rehearsal on a one-GPU box (never the measured configuration): every rank on device 0, gloo for the barrier / MAX
     rehearsal = os.environ.get("MINDPOSE_BENCH_SHARED_GPU_REHEARSAL") == "1"
@@ -399,8 +660,11 @@ def main():
         if not args.no_roofline:
             result["roofline"] = roofline_report(plan, layers_csv=args.layers)
             log("roofline done")
-        if world == 1 and not args.no_cpu_baseline and args.workload == "hrnet_w32":
-            result["cpu_baseline"] = cpu_baseline(net.state_dict(), batch=8)
+        headline = world == 1 and args.workload == "hrnet_w32" and args.amp == "O0" and not args.leg
+        if headline and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(net.state_dict(), mp, dev)
+        if headline and not args.no_extra:
+            result["extra_workloads"] = run_extra_legs([x for x in args.extra.split(",") if x] or None)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

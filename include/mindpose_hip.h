@@ -236,6 +236,34 @@ int mp_bn_train_bwd_acc(const float* dy_dev, const float* z_dev, const float* y_
 int mp_adamw_step(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, size_t count,
                   float lr, float beta1, float beta2, float eps, float weight_decay, mp_stream_t stream);
 
+/* mp_adamw_step with the gradient read as g * grad_scale (fold 1 / (loss_scale * world_size) here instead of a separate pass over
+ * the arena) and an optional device flag: when *skip_flag_dev != 0 the launch leaves parameters and moments untouched (the
+ * overflow step of DynamicLossScaleManager, tools/train.py:170-173). */
+int mp_adamw_step_scaled(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, size_t count,
+                         float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                         const int* skip_flag_dev, mp_stream_t stream);
+/* Overflow check of the dynamic loss scale: *flag_dev |= 1 when any of grad_dev[0..count) is inf / nan (one read of the
+ * arena; the caller zeroes the flag).  grad_dev must be 16-byte aligned. */
+int mp_grad_finite_check(const float* grad_dev, size_t count, int* flag_dev, mp_stream_t stream);
+
+/* ---- data-parallel gradient mean over RCCL/xGMI (tools/train.py:43-49: parallel_mode=data_parallel, gradients_mean=True) ----
+ * A thin layer over the process's RCCL (bound at run time; mp_comm_available() == 0 when no RCCL can be found).
+ *   mp_comm_get_unique_id  rank 0 fills 128 bytes (ncclUniqueId) that the host code broadcasts to the other ranks
+ *   mp_comm_init_rank      every rank, after hipSetDevice: creates the communicator (collective call)
+ *   mp_allreduce_grads     in-place all-reduce of count fp32 values on `stream` (average != 0: mean over ranks, ncclAvg);
+ *                          asynchronous, capturable into a hipGraph like any RCCL call
+ *   mp_reduce_scatter_allgather_grads   the same result as reduce-scatter + all-gather of count / nranks shards (count must be a
+ *                          multiple of nranks): every xGMI link carries 1/nranks of the arena in each phase
+ * Errors: MP_ERR_UNSUPPORTED (no RCCL), MP_ERR_HIP with the ncclResult_t in mp_comm_last_error(). */
+int mp_comm_available(void);
+int mp_comm_last_error(void);
+int mp_comm_get_unique_id(void* id128_host);
+int mp_comm_init_rank(void** comm_out, int nranks, const void* id128_host, int rank);
+int mp_comm_destroy(void* comm);
+int mp_allreduce_grads(void* comm, float* arena_dev, size_t count, int average, mp_stream_t stream);
+int mp_reduce_scatter_allgather_grads(void* comm, float* arena_dev, size_t count, int nranks, int rank, int average,
+                                      mp_stream_t stream);
+
 /* The other optimizers registered by mindpose/optim/optim_factory.py:9-14, on the same flat fp32 arenas.
  * kind 1 = mindspore.nn.Adam (bias-corrected; hyper = {beta1, beta2, eps, beta1^t, beta2^t}; state1 = m, state2 = v),
  * 2 = nn.SGD (hyper = {momentum, dampening, nesterov, first_step}; state1 = momentum buffer, may be NULL when momentum == 0),

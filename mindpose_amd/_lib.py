@@ -67,6 +67,15 @@ _PROTOTYPES = {
     "mp_conv_wgrad_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "mp_conv_wgrad": (c_int, [ctypes.POINTER(ConvDesc), c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_size_t, ctypes.c_void_p]),
     "mp_adamw_step": (c_int, [c_f32p] * 4 + [c_size_t] + [ctypes.c_float] * 5 + [ctypes.c_void_p]),
+    "mp_adamw_step_scaled": (c_int, [c_f32p] * 4 + [c_size_t] + [ctypes.c_float] * 6 + [c_f32p, ctypes.c_void_p]),
+    "mp_grad_finite_check": (c_int, [c_f32p, c_size_t, c_f32p, ctypes.c_void_p]),
+    "mp_comm_available": (c_int, []),
+    "mp_comm_last_error": (c_int, []),
+    "mp_comm_get_unique_id": (c_int, [ctypes.c_void_p]),
+    "mp_comm_init_rank": (c_int, [ctypes.POINTER(ctypes.c_void_p), c_int, ctypes.c_void_p, c_int]),
+    "mp_comm_destroy": (c_int, [ctypes.c_void_p]),
+    "mp_allreduce_grads": (c_int, [ctypes.c_void_p, c_f32p, c_size_t, c_int, ctypes.c_void_p]),
+    "mp_reduce_scatter_allgather_grads": (c_int, [ctypes.c_void_p, c_f32p, c_size_t, c_int, c_int, c_int, ctypes.c_void_p]),
     "mp_f16_bn_train_fwd": (c_int, [c_f32p] * 9 + [c_int] * 3 + [ctypes.c_float, ctypes.c_float, c_int, c_f32p, c_size_t, ctypes.c_void_p]),
     "mp_f16_bn_train_bwd": (c_int, [c_f32p] * 12 + [c_int] * 4 + [c_f32p, c_size_t, ctypes.c_void_p]),
     "mp_f16_fuse_upsample_sum_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_int, c_f32p, c_int] + [c_int] * 5 + [ctypes.c_void_p]),

@@ -36,7 +36,8 @@ class _ArenaOptimizer:
     n_states = 2
 
     def __init__(self, net: torch.nn.Module, lr: float, weight_decay: float = 0.0, filter_bias_and_bn: bool = True,
-                 bucket_mb: float = 32.0, process_group=None, overlap: bool = True, state_init: float = 0.0) -> None:
+                 bucket_mb: float = 32.0, process_group=None, overlap: bool = True, state_init: float = 0.0,
+                 transport=None, force_collectives: bool = False) -> None:
         decay, no_decay = split_decay(net.named_parameters(), filter_bias_and_bn)
         self.params = decay + no_decay
         self.n_decay = sum(p.numel() for p in decay)
@@ -54,9 +55,12 @@ class _ArenaOptimizer:
         self.lr, self.weight_decay = lr, weight_decay
         # gradients: one arena in the SAME order as the parameter arena (no gather before the update), bucketed
         # all-reduce overlapped with backward
+        # the 1/world of the gradient mean is folded into the update kernels' gradient scale (mean="consumer"): no extra pass
         self.grads = GradientAverager(self.params, bucket_mb=bucket_mb, process_group=process_group, overlap=overlap,
-                                      arena_order="given")
+                                      arena_order="given", mean="consumer", transport=transport,
+                                      force_collectives=force_collectives)
         self._grad_flat = self.grads.arena
+        self._overflow = torch.zeros(1, device=dev, dtype=torch.int32)  # device flag of the loss-scale overflow check
         self.global_step = 0
 
     def zero_grad(self) -> None:
@@ -70,9 +74,15 @@ class _ArenaOptimizer:
         host read-back per step; returns whether the parameters were updated."""
         lib = _lib.load()
         self.grads.finish()
+        # gradient scale the update kernels apply while reading the arena: 1 / loss_scale (amp O2) x 1 / world (gradient mean)
+        self.grad_scale = self.grads.mean_scale
         if loss_scale_manager is not None:
-            self._grad_flat.mul_(1.0 / loss_scale_manager.loss_scale)
-            finite = bool(torch.isfinite(self._grad_flat).all())
+            self.grad_scale /= loss_scale_manager.loss_scale
+            # overflow check on the (still scaled) sums: inf / nan survive the scaling, so one read-only pass decides
+            self._overflow.zero_()
+            _lib.check(lib.mp_grad_finite_check(self._grad_flat.data_ptr(), self._grad_flat.numel(), self._overflow.data_ptr(),
+                                                _lib.stream()), "mp_grad_finite_check")
+            finite = int(self._overflow.item()) == 0
             loss_scale_manager.update_loss_scale(not finite)
             if not finite:
                 return False
@@ -95,10 +105,10 @@ class AdamWeightDecay(_ArenaOptimizer):
         self.exp_avg, self.exp_avg_sq = self.states
 
     def _update(self, lib, start, count, wd, stream):
-        _lib.check(lib.mp_adamw_step(self.flat[start:].data_ptr(), self._grad_flat[start:].data_ptr(),
-                                     self.exp_avg[start:].data_ptr(), self.exp_avg_sq[start:].data_ptr(), count,
-                                     float(self.lr), float(self.beta1), float(self.beta2), float(self.eps), wd, stream),
-                   "mp_adamw_step")
+        _lib.check(lib.mp_adamw_step_scaled(self.flat[start:].data_ptr(), self._grad_flat[start:].data_ptr(),
+                                            self.exp_avg[start:].data_ptr(), self.exp_avg_sq[start:].data_ptr(), count,
+                                            float(self.lr), float(self.beta1), float(self.beta2), float(self.eps), wd,
+                                            float(self.grad_scale), None, stream), "mp_adamw_step_scaled")
 
 
 class _KernelOptimizer(_ArenaOptimizer):
@@ -119,7 +129,7 @@ class _KernelOptimizer(_ArenaOptimizer):
         hyper = (ctypes.c_float * 5)(*[float(v) for v in self._hyper()])
         st = [s_[start:].data_ptr() for s_ in self.states] + [None, None]
         _lib.check(lib.mp_optimizer_step(self.kind, self.flat[start:].data_ptr(), self._grad_flat[start:].data_ptr(), st[0], st[1],
-                                         count, float(self.lr), 1.0 / float(self.loss_scale), wd, ctypes.byref(hyper), stream),
+                                         count, float(self.lr), float(self.grad_scale) / float(self.loss_scale), wd, ctypes.byref(hyper), stream),
                    "mp_optimizer_step")
 
 

@@ -4,28 +4,108 @@ gradients_mean=True)``, tools/train.py:43-49 - MindSpore all-reduces every gradi
 MI355X-first shape of the same exchange: all gradients live in ONE flat fp32 arena (``p.grad`` are views into it), the
 arena is cut into a few large buckets in reverse parameter order (the order backward produces them), and each bucket's
 all-reduce is launched asynchronously the moment its last gradient has been accumulated, so communication overlaps the
-rest of backward.  HRNet-W32 = 114 MB of fp32 gradients per step = 4 buckets of 32 MB.  ``torch.distributed`` backend
-"nccl" is RCCL on ROCm; "gloo" runs the identical logic on CPU (tests).  BatchNorm statistics stay per device
+rest of backward.  HRNet-W32 = 114 MB of fp32 gradients per step = 4 buckets of 32 MB.  BatchNorm statistics stay per device
 (no SyncBN in the reference).
+
+Where the mean's 1/world goes (``mean``):
+  "collective"  ``ReduceOp.AVG`` inside RCCL (backend "nccl"): no extra pass over the arena
+  "consumer"    the collective SUMs and the consumer folds ``mean_scale`` (= 1/world) into its own read of the arena - what the
+                arena optimizers do (``mp_adamw_step_scaled`` multiplies it into the loss-scale factor)
+  "pass"        SUM, then one ``arena *= 1/world`` pass (backend "gloo" has no AVG; CPU tests)
+
+Transport (``transport``): "torch" = ``torch.distributed`` (backend "nccl" IS RCCL on ROCm; "gloo" runs the identical logic on
+CPU), "native" = the library's own communicator (``mp_comm_init_rank`` / ``mp_allreduce_grads``, include/mindpose_hip.h) on a
+dedicated HIP stream; its unique id travels through the ``torch.distributed`` store.
 """
+import ctypes
+import os
 from typing import Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
 
 
+class NativeComm:
+    """``mp_comm_*``: an RCCL communicator owned by libmindpose_hip.so, one per process group."""
+
+    def __init__(self, device: torch.device, process_group=None) -> None:
+        from .. import _lib
+        self.lib = _lib.load()
+        if not self.lib.mp_comm_available():
+            raise _lib.MindposeHipError("no RCCL found in this process (mp_comm_available() == 0)")
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        ident = (ctypes.c_char * 128)()
+        if self.rank == 0:
+            _lib.check(self.lib.mp_comm_get_unique_id(ident), "mp_comm_get_unique_id")
+        if self.world > 1:
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
+                                       group=process_group)
+            ident = (ctypes.c_char * 128).from_buffer_copy(box[0])
+        self.handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(self.lib.mp_comm_init_rank(ctypes.byref(self.handle), self.world, ident, self.rank), "mp_comm_init_rank")
+        self.stream = torch.cuda.Stream(device=device)
+        self._check = _lib.check
+
+    def all_reduce(self, view: torch.Tensor, average: bool, split: bool = False) -> torch.cuda.Event:
+        """In-place all-reduce of ``view`` on the communicator's stream, ordered after everything already enqueued on the
+        caller's current stream; returns the event the consumer waits for.  ``split``: reduce-scatter + all-gather."""
+        self.stream.wait_stream(torch.cuda.current_stream(view.device))
+        if split and view.numel() % self.world == 0:
+            rc = self.lib.mp_reduce_scatter_allgather_grads(self.handle, view.data_ptr(), view.numel(), self.world, self.rank,
+                                                            int(average), self.stream.cuda_stream)
+        else:
+            rc = self.lib.mp_allreduce_grads(self.handle, view.data_ptr(), view.numel(), int(average), self.stream.cuda_stream)
+        self._check(rc, "mp_allreduce_grads")
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        return ev
+
+    def close(self) -> None:
+        if self.handle:
+            self.lib.mp_comm_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+
+class _EventHandle:
+    def __init__(self, ev: torch.cuda.Event) -> None:
+        self.ev = ev
+
+    def wait(self) -> None:
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
 class GradientAverager:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 32.0, process_group=None,
-                 overlap: bool = True, arena_order: str = "reverse") -> None:
+                 overlap: bool = True, arena_order: str = "reverse", mean: Optional[str] = None,
+                 transport: Optional[str] = None, force_collectives: bool = False) -> None:
         """``arena_order``: "reverse" lays the arena out last-parameter-first (buckets fill front to back during
         backward); "given" keeps the caller's order, e.g. to alias an optimizer's flat parameter layout (buckets then
-        complete back to front - the overlap is the same, every bucket still launches when its last gradient lands)."""
+        complete back to front - the overlap is the same, every bucket still launches when its last gradient lands).
+        ``force_collectives``: issue the collectives on a one-rank group too (exercises the RCCL path on a one-GPU box)."""
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
         dev, dtype = self.params[0].device, torch.float32
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        backend = dist.get_backend(process_group) if dist.is_initialized() else None
+        transport = transport or os.environ.get("MINDPOSE_DP_TRANSPORT", "torch")
+        if transport not in ("torch", "native"):
+            raise ValueError("transport must be 'torch' or 'native'")
+        if transport == "native" and dev.type != "cuda":
+            raise ValueError("the native RCCL transport needs the arena on a GPU")
+        self.native = NativeComm(dev, process_group) if (transport == "native" and dist.is_initialized()) else None
+        has_avg = self.native is not None or backend == "nccl"
+        if mean is None:
+            mean = "collective" if has_avg else "pass"
+        if mean not in ("collective", "consumer", "pass"):
+            raise ValueError("mean must be 'collective', 'consumer' or 'pass'")
+        if mean == "collective" and not has_avg:
+            raise ValueError(f"backend {backend!r} has no averaging all-reduce: use mean='pass' or 'consumer'")
+        self.mean = mean
         total = sum(p.numel() for p in self.params)
         self.arena = torch.zeros(total, device=dev, dtype=dtype)
         if arena_order not in ("reverse", "given"):
@@ -49,7 +129,8 @@ class GradientAverager:
         self.buckets.append(cur)
         self._handles: List = []
         self._hooks = []
-        self.overlap = overlap and self.world > 1
+        self.active = self.world > 1 or (force_collectives and dist.is_initialized())
+        self.overlap = overlap and self.active
         if self.overlap:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
@@ -59,17 +140,30 @@ class GradientAverager:
             p._mp_grad_direct = not self.overlap
         self.begin_step()
 
+    @property
+    def mean_scale(self) -> float:
+        """Factor the consumer of the arena still has to apply after ``finish()`` (1 unless mean == "consumer")."""
+        return 1.0 / self.world if (self.mean == "consumer" and self.world > 1) else 1.0
+
     # -- per step ---------------------------------------------------------------------------------
     def begin_step(self) -> None:
         """Zero the arena and re-arm the buckets (call before forward/backward)."""
         self.arena.zero_()
+        self.rearm()
+
+    def rearm(self) -> None:
+        """Re-arm the buckets without touching the arena (a captured step zeroes it inside its hipGraph)."""
         for b in self.buckets:
             b["pending"] = b["count"]
         self._handles = []
 
     def _launch(self, b: dict) -> None:
         view = self.arena[b["start"]:b["end"]]
-        self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.native is not None:
+            self._handles.append(_EventHandle(self.native.all_reduce(view, average=self.mean == "collective")))
+            return
+        op = dist.ReduceOp.AVG if self.mean == "collective" else dist.ReduceOp.SUM
+        self._handles.append(dist.all_reduce(view, op=op, group=self.group, async_op=True))
 
     def _on_grad_ready(self, p: torch.nn.Parameter) -> None:
         if p.grad is None or p.grad.data_ptr() < self.arena.data_ptr():
@@ -80,8 +174,9 @@ class GradientAverager:
             self._launch(b)
 
     def finish(self) -> None:
-        """Wait for the bucket all-reduces (launching any that did not overlap) and turn sums into means."""
-        if self.world > 1:
+        """Wait for the bucket all-reduces (launching any that did not overlap); afterwards the arena holds the mean over ranks,
+        up to ``mean_scale``."""
+        if self.active:
             if not self.overlap:
                 for b in self.buckets:
                     self._launch(b)
@@ -92,7 +187,8 @@ class GradientAverager:
                         b["pending"] = 0
             for h in self._handles:
                 h.wait()
-            self.arena.mul_(1.0 / self.world)
+            if self.mean == "pass" and self.world > 1:
+                self.arena.mul_(1.0 / self.world)
         self._handles = []
 
     def remove_hooks(self) -> None:

@@ -54,8 +54,7 @@ class GraphedTrainStep:
                 dst.copy_(src)
         if self.mgr is not None:
             self.scale_t.fill_(self.mgr.loss_scale)
-        for b in self.opt.grads.buckets:
-            b["pending"] = b["count"]
+        self.opt.grads.rearm()  # the graph zeroes and fills the arena; under DP opt.step() launches the bucket all-reduces after it
         self.graph.replay()
         self.updated = self.opt.step(loss_scale_manager=self.mgr)
         if self.updated:

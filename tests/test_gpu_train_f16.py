@@ -317,8 +317,8 @@ def test_graphed_o2_step_equals_eager():
     loss_g = step(x, target, weight)
     assert float(loss_g.detach()) == float(loss_e.detach())
     assert step.updated and mgr.skipped_steps == 0
-    # the optimizer divided the arena by the loss scale in place; the parameters moved
-    assert torch.equal(opt_g.grads.arena * 4096.0, grads_e)
+    # the arena keeps the loss-scaled sums (the 1 / loss_scale is folded into the update kernel's read); the parameters moved
+    assert torch.equal(opt_g.grads.arena, grads_e) and opt_g.grad_scale == 1.0 / 4096.0
     assert not torch.equal(opt_g.flat, before)
     losses = [float(step(x, target, weight).detach()) for _ in range(6)]
     assert losses[-1] < float(loss_e.detach())

@@ -24,12 +24,13 @@ def _model():
                                torch.nn.Linear(64, 8))
 
 
-def _worker(rank, world, port, out_dir, overlap):
+def _worker(rank, world, port, out_dir, overlap, mean="pass"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     net = _model()
-    avg = GradientAverager(net.parameters(), bucket_mb=0.01, overlap=overlap)  # tiny buckets -> several of them
+    avg = GradientAverager(net.parameters(), bucket_mb=0.01, overlap=overlap, mean=mean)  # tiny buckets -> several of them
     assert len(avg.buckets) >= 3
+    assert avg.mean_scale == (0.5 if mean == "consumer" else 1.0)
     g = torch.Generator().manual_seed(5)
     x, y = torch.randn(8, 16, generator=g), torch.randn(8, 8, generator=g)
     xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
@@ -39,7 +40,8 @@ def _worker(rank, world, port, out_dir, overlap):
         loss.backward()
         avg.finish()
     if rank == 0:
-        torch.save([p.grad.clone() for p in net.parameters()], os.path.join(out_dir, f"grads_{int(overlap)}.pt"))
+        # what the consumer sees: the arena times the factor it still has to fold in
+        torch.save([p.grad.clone() * avg.mean_scale for p in net.parameters()], os.path.join(out_dir, f"grads_{int(overlap)}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -55,6 +57,20 @@ def test_bucketed_overlapped_allreduce_matches_full_batch(tmp_path):
         got = torch.load(os.path.join(tmp_path, f"grads_{int(overlap)}.pt"))
         for a, b in zip(got, ref):
             torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
+    # mean="consumer": the collective sums and the optimizer folds 1/world into its gradient scale
+    mp_.spawn(_worker, args=(2, _free_port(), str(tmp_path), True, "consumer"), nprocs=2, join=True)
+    for a, b in zip(torch.load(os.path.join(tmp_path, "grads_1.pt")), ref):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
+
+
+def test_mean_modes_are_validated():
+    import pytest
+    net = _model()
+    with pytest.raises(ValueError):
+        GradientAverager(net.parameters(), mean="collective")  # no process group: nothing offers an averaging all-reduce
+    with pytest.raises(ValueError):
+        GradientAverager(net.parameters(), mean="bogus")
+    assert GradientAverager(net.parameters(), mean="consumer").mean_scale == 1.0  # world 1
 
 
 def test_single_process_arena_views():

@@ -101,3 +101,29 @@ def test_dynamic_loss_scale_manager_semantics():
     import pytest
     with pytest.raises(ValueError):
         DynamicLossScaleManager(init_loss_scale=0.5)
+
+
+def test_bench_spawns_its_own_ranks_without_a_launcher(monkeypatch):
+    """`python bench.py --gpus N` with no WORLD_SIZE starts the ranks itself through torch.distributed.run (before any GPU call);
+    with WORLD_SIZE set it is a rank and must not spawn."""
+    import importlib
+    import sys
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    import pytest
+    with pytest.raises(SystemExit) as exc:
+        bench.main()
+    assert exc.value.code == 7  # the children's status is the parent's
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
