@@ -55,6 +55,16 @@ int mp_decode_topdown(const float* heatmap_dev, const float* center_dev, const f
                       int n, int k, int h, int w, int refine_mode, int use_udp, int to_original,
                       float pixel_std, const float* blur_kernel_dev, int kernel_size, mp_stream_t stream);
 
+/* mp_decode_topdown in MP_REFINE_DARK mode that ALSO writes the intermediates of the refinement (top_down_decoder.py:176-204)
+ * for parity tests: dark_terms_dev [N*K][16] = the 3x3 neighbourhood of log(clip(blur(heatmap))) around the arg-max, row-major
+ * (rows y-1, y, y+1; zero outside the map = the reference's zero pad in log space) [0..8], dx, dy [9,10], dxx, dyy, dxy [11..13],
+ * det(Hessian + 1e-7 I) [14], 0 [15].  Same kernel, same arithmetic; the product path passes no such pointer. */
+int mp_decode_topdown_debug(const float* heatmap_dev, const float* center_dev, const float* scale_dev,
+                            const float* score_dev, float* preds_dev, float* boxes_dev, int32_t* argmax_idx_dev,
+                            int n, int k, int h, int w, int refine_mode, int use_udp, int to_original,
+                            float pixel_std, const float* blur_kernel_dev, int kernel_size, float* dark_terms_dev,
+                            mp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Flip-test aggregation: _MultiRunNet.construct, mindpose/engine/inferencer/topdown_inferencer.py:165-187
  *   avg = (heatmap + flip_back(flipped)[shifted]) * 0.5 ; decoder(avg, ...)

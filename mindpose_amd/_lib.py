@@ -34,6 +34,7 @@ _PROTOTYPES = {
     "mp_error_string": (ctypes.c_char_p, [c_int]),
     "mp_last_hip_error": (c_int, []),
     "mp_decode_topdown": (c_int, [c_f32p] * 7 + [c_int] * 7 + [ctypes.c_float, c_f32p, c_int, ctypes.c_void_p]),
+    "mp_decode_topdown_debug": (c_int, [c_f32p] * 7 + [c_int] * 7 + [ctypes.c_float, c_f32p, c_int, c_f32p, ctypes.c_void_p]),
     "mp_flip_aggregate": (c_int, [c_f32p] * 4 + [c_int] * 5 + [ctypes.c_void_p]),
     "mp_flip_aggregate_decode": (c_int, [c_f32p] * 3 + [c_int] + [c_f32p] * 7 + [c_int] * 7
                                  + [ctypes.c_float, c_f32p, c_int, ctypes.c_void_p]),

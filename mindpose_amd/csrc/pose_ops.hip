@@ -27,6 +27,7 @@ struct DecodeParams {
     float* boxes;
     int32_t* argmax;
     const float* blur;
+    float* dark_terms;        // optional debug output [N*K][16] (mp_decode_topdown_debug), else nullptr
     int n, k, h, w;
     int refine, use_udp, to_original, ks, shift_heatmap;
     float pixel_std;
@@ -153,6 +154,12 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeParams p) {
         const float dxy = 0.5f * (ix1y1 - ix1 - iy1 + i_ + i_ - ix1_ - iy1_ + ix1_y1_);
         const float ha = dxx + 1e-7f, hd = dyy + 1e-7f;  // Hessian + 1e-7 I
         const float det = ha * hd - dxy * dxy;
+        if (p.dark_terms && lane == 0) {  // intermediates of the refinement for the parity tests (uniform branch)
+            float* t = p.dark_terms + (size_t)row * 16;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) t[i] = L[i / 3][i % 3];
+            t[9] = dx; t[10] = dy; t[11] = dxx; t[12] = dyy; t[13] = dxy; t[14] = det; t[15] = 0.f;
+        }
         cx = cx - (hd * dx - dxy * dy) / det;
         cy = cy - (ha * dy - dxy * dx) / det;
     }
@@ -501,6 +508,23 @@ int mp_decode_topdown(const float* heatmap, const float* center, const float* sc
     p.center = center; p.scale = scale; p.score = score; p.preds = preds; p.boxes = boxes; p.argmax = argmax_idx;
     p.blur = blur_kernel; p.n = n; p.k = k; p.h = h; p.w = w; p.refine = refine_mode; p.use_udp = use_udp;
     p.to_original = to_original; p.ks = kernel_size; p.shift_heatmap = 0; p.pixel_std = pixel_std;
+    return launch_decode(p, as_stream(stream));
+}
+
+int mp_decode_topdown_debug(const float* heatmap, const float* center, const float* scale, const float* score, float* preds,
+                            float* boxes, int32_t* argmax_idx, int n, int k, int h, int w, int refine_mode, int use_udp,
+                            int to_original, float pixel_std, const float* blur_kernel, int kernel_size, float* dark_terms,
+                            mp_stream_t stream) {
+    int rc = validate_decode(heatmap, center, scale, score, preds, boxes, n, k, h, w, refine_mode, blur_kernel,
+                             kernel_size);
+    if (rc != MP_OK) return rc;
+    if (refine_mode != MP_REFINE_DARK) return MP_ERR_UNSUPPORTED;
+    if (!dark_terms) return MP_ERR_NULL;
+    DecodeParams p{};
+    p.hm = heatmap; p.hf = nullptr; p.flip_index = nullptr; p.avg_out = nullptr;
+    p.center = center; p.scale = scale; p.score = score; p.preds = preds; p.boxes = boxes; p.argmax = argmax_idx;
+    p.blur = blur_kernel; p.dark_terms = dark_terms; p.n = n; p.k = k; p.h = h; p.w = w; p.refine = refine_mode;
+    p.use_udp = use_udp; p.to_original = to_original; p.ks = kernel_size; p.shift_heatmap = 0; p.pixel_std = pixel_std;
     return launch_decode(p, as_stream(stream));
 }
 

@@ -72,7 +72,7 @@ def _depthwise_blur_same(heatmap, kernel):
     return out
 
 
-def dark_udp_refine_coords(coords, heatmap, kernel_size):
+def dark_udp_refine_coords(coords, heatmap, kernel_size, terms=None):
     """top_down_decoder.py:171-205 - DARK / UDP second-order Taylor refinement.
 
     blur -> clip[1e-3, 50] -> log -> zero-pad by 1 (value 0 in log space) -> 7 gathers ->
@@ -108,6 +108,12 @@ def dark_udp_refine_coords(coords, heatmap, kernel_size):
     dxx = ix1 - 2 * i_ + ix1_
     dyy = iy1 - 2 * i_ + iy1_
     dxy = F32(0.5) * (ix1y1 - ix1 - iy1 + i_ + i_ - ix1_ - iy1_ + ix1_y1_)
+    if terms is not None:
+        # the intermediates, for the kernel's debug output (mp_decode_topdown_debug): 3x3 log-blur neighbourhood row-major
+        # (the two corners the reference never gathers are filled in too), gradient, Hessian entries
+        nb = np.stack([hm[index + oy * (w + 2) + ox] for oy in (-1, 0, 1) for ox in (-1, 0, 1)], axis=-1).reshape(n, k, 9)
+        terms.update(neighbourhood=nb.astype(F32), dx=dx.reshape(n, k), dy=dy.reshape(n, k), dxx=dxx.reshape(n, k),
+                     dyy=dyy.reshape(n, k), dxy=dxy.reshape(n, k))
     hessian = np.concatenate([dxx, dxy, dxy, dyy], axis=1).reshape(n, k, 2, 2).astype(F32)
     hessian = np.linalg.inv(hessian + np.eye(2, dtype=F32) * F32(1e-7)).astype(F32)
     delta = np.matmul(hessian, derivative.astype(F32))[..., 0]

@@ -80,8 +80,9 @@ def _bn(p, x):
     if p.amp and not p.train:
         return _r(p, F.batch_norm(x, p["moving_mean"], p["moving_variance"], p["gamma"], p["beta"], training=False, eps=BN_EPS))
     if p.train:  # torch momentum 0.1 == MindSpore momentum 0.9 (weight of the OLD moving value)
-        return F.batch_norm(x, p["moving_mean"], p["moving_variance"], p["gamma"], p["beta"],
-                            training=True, momentum=0.1, eps=BN_EPS)
+        # amp O2 keeps BatchNorm in fp32 (statistics, gamma / beta) and hands an fp16 tensor on: one rounding of the output
+        return _r(p, F.batch_norm(x, p["moving_mean"], p["moving_variance"], p["gamma"], p["beta"],
+                                  training=True, momentum=0.1, eps=BN_EPS))
     return F.batch_norm(x, p["moving_mean"], p["moving_variance"], p["gamma"], p["beta"],
                         training=False, eps=BN_EPS)
 
@@ -136,7 +137,7 @@ def _hr_module(p, xs, num_branches, num_blocks, multi_scale_output):
 
 
 def hrnet_forward(params, x, name="hrnet_w32", prefix="", train=False, amp=False):
-    """HRNet.forward_feature hrnet.py:559-605.  ``amp``: op-by-op fp16 emulation of amp level O2 (eval only)."""
+    """HRNet.forward_feature hrnet.py:559-605.  ``amp``: op-by-op fp16 emulation of amp level O2."""
     cfg = HRNET_CFG[name]
     p = _P(params, prefix, train, amp)
     x = torch.as_tensor(x) if train else torch.as_tensor(x, dtype=torch.float32)  # train: keep dtype (fp64 oracle runs)
@@ -216,14 +217,17 @@ def simple_baseline_head_forward(params, x, prefix="", num_deconv_layers=3, amp=
     return _conv(p.sub("final_layer"), x)
 
 
-def net_forward_train(params, x, backbone="hrnet_w32", head="hrnet_head"):
+def net_forward_train(params, x, backbone="hrnet_w32", head="hrnet_head", amp=False):
     """Net.construct in training mode: batch-statistics BatchNorm, autograd graph kept.
-    ``params`` must hold torch tensors (leaf tensors with requires_grad for the trainable ones)."""
+    ``params`` must hold torch tensors (leaf tensors with requires_grad for the trainable ones).
+    ``amp=True``: the reference's training recipe (amp_level O2, tools/train.py:176-181) emulated op by op - fp16 conv operands
+    and cell outputs (round-to-nearest fp16 through a differentiable cast, so the activation gradients are rounded to fp16 at
+    the same points on the way back), fp32 accumulation, BatchNorm statistics / affine in fp32."""
     if backbone.startswith("hrnet"):
-        f = hrnet_forward(params, x, backbone, prefix="backbone.", train=True)
-        return hrnet_head_forward(params, f, prefix="head.", train=True)
-    f = resnet_forward(params, x, backbone, prefix="backbone.", train=True)
-    return simple_baseline_head_forward(params, f, prefix="head.", train=True)
+        f = hrnet_forward(params, x, backbone, prefix="backbone.", train=True, amp=amp)
+        return hrnet_head_forward(params, f, prefix="head.", train=True, amp=amp)
+    f = resnet_forward(params, x, backbone, prefix="backbone.", train=True, amp=amp)
+    return simple_baseline_head_forward(params, f, prefix="head.", train=True, amp=amp)
 
 
 def net_forward(params, x, backbone="hrnet_w32", head="hrnet_head", amp=False):

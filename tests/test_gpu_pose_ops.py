@@ -204,3 +204,60 @@ def test_maxpool_same():
     xd = x.to(DEV)
     mp._lib.check(lib.mp_maxpool3x3s2_same(xd.data_ptr(), out.data_ptr(), 2, 5, 12, 10, None), "maxpool")
     assert torch.equal(out.cpu(), onets.maxpool3x3s2_same(x))
+
+
+@pytest.mark.parametrize("case", [c for c in DECODER_CASES if c[4].get("dark_udp_refine")], ids=lambda c: c[0])
+def test_dark_refine_intermediates_vs_oracle(case):
+    """top_down_decoder.py:171-205 term by term, on EVERY map (noise maps and singular joints included): the 3x3 neighbourhood
+    of log(clip(blur(h))), the gradient and the Hessian entries of the kernel (mp_decode_topdown_debug: same kernel, extra output)
+    against the oracle at 1e-5; the final 2x2 solve is checked as a solve (residual of (H + 1e-7 I) delta = g on the kernel's own
+    terms), which holds however ill-conditioned H is - so a wrong tap, pad rule or clip bound cannot hide behind conditioning."""
+    import ctypes
+    name, kind, shape, seed, kw = case
+    hm, center, scale, score = decoder_inputs(kind, shape, seed)
+    n, k, h, w = shape
+    lib = mp._lib.load()
+    dec = _dec(kw)
+    thm, tc, ts, tsc = _cuda(hm, center, scale, score)
+    preds = torch.empty(n, k, 3, device=DEV)
+    boxes = torch.empty(n, 6, device=DEV)
+    idx = torch.empty(n, k, dtype=torch.int32, device=DEV)
+    terms = torch.full((n, k, 16), float("nan"), device=DEV)
+    blur = dec._blur_on(torch.device(DEV))
+    # to_original=0: coordinates stay in heat-map pixels, so the refinement offset itself is visible
+    mp._lib.check(lib.mp_decode_topdown_debug(thm.data_ptr(), tc.data_ptr(), ts.data_ptr(), tsc.data_ptr(), preds.data_ptr(),
+                                              boxes.data_ptr(), idx.data_ptr(), n, k, h, w, mp._lib.MP_REFINE_DARK,
+                                              int(dec.use_udp), 0, float(dec.pixel_std), blur.data_ptr(), int(dec.kernel_size),
+                                              terms.data_ptr(), mp._lib.stream()), "mp_decode_topdown_debug")
+    t = terms.cpu().numpy()
+    coords, _, ref_idx = od.get_max_preds(hm)
+    assert np.array_equal(idx.cpu().numpy(), ref_idx.astype(np.int32))
+    ref = {}
+    od.dark_udp_refine_coords(coords, hm, dec.kernel_size, terms=ref)
+    nb = ref["neighbourhood"]
+    # the reference gathers 7 of the 9 positions (not the two anti-diagonal corners); all 9 are compared
+    np.testing.assert_allclose(t[..., :9], nb, rtol=1e-5, atol=2e-6)
+    mag = np.abs(nb).max(axis=-1) + 1e-30  # derivatives are differences of these values: tolerance relative to their size
+    for j, key in ((9, "dx"), (10, "dy"), (11, "dxx"), (12, "dyy"), (13, "dxy")):
+        err = np.abs(t[..., j] - ref[key]) / mag
+        assert err.max() < 1e-5, (key, float(err.max()))
+    # the solve, on the kernel's own terms, in fp64: (H + 1e-7 I) delta = g  with  delta = arg-max - refined
+    dx, dy, dxx, dyy, dxy = (t[..., j].astype(np.float64) for j in (9, 10, 11, 12, 13))
+    delta = coords.astype(np.float64) - preds.cpu().numpy()[..., :2].astype(np.float64)
+    ha, hd = dxx + np.float64(np.float32(1e-7)), dyy + np.float64(np.float32(1e-7))
+    rx = ha * delta[..., 0] + dxy * delta[..., 1] - dx
+    ry = dxy * delta[..., 0] + hd * delta[..., 1] - dy
+    # fp32 adjugate solve + the subtraction from the arg-max coordinate (ulp of a coordinate up to 64 ~ 4e-6 per unit of H)
+    bound = (1e-4 * (np.abs(ha) * np.abs(delta[..., 0]) + np.abs(dxy) * (np.abs(delta[..., 0]) + np.abs(delta[..., 1]))
+                     + np.abs(hd) * np.abs(delta[..., 1]) + np.abs(dx) + np.abs(dy))
+             + 8e-6 * (np.abs(ha) + np.abs(hd) + 2 * np.abs(dxy)) * 64 + 1e-12)
+    finite = np.isfinite(delta).all(axis=-1)
+    assert (np.abs(rx)[finite] <= bound[finite]).all() and (np.abs(ry)[finite] <= bound[finite]).all()
+    # where the determinant vanishes exactly the reference's inv() is singular too; everything else is finite
+    assert (finite | (t[..., 14] == 0)).all()
+    # and the product entry point returns exactly the same coordinates as the debug entry
+    preds2 = torch.empty_like(preds)
+    mp._lib.check(lib.mp_decode_topdown(thm.data_ptr(), tc.data_ptr(), ts.data_ptr(), tsc.data_ptr(), preds2.data_ptr(),
+                                        boxes.data_ptr(), idx.data_ptr(), n, k, h, w, mp._lib.MP_REFINE_DARK, int(dec.use_udp), 0,
+                                        float(dec.pixel_std), blur.data_ptr(), int(dec.kernel_size), mp._lib.stream()), "decode")
+    assert torch.equal(preds2.nan_to_num(123.0), preds.nan_to_num(123.0))
