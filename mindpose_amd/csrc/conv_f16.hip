@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
     }
     int a_off[CS];  // weight operand
 #pragma unroll
-    for (int cs = 0; cs < CS; ++cs) a_off[cs] = lq * CT + (wc_i * CS + cs) * 16 + lr;
+    for (int cs = 0; cs < CS; ++cs) a_off[cs] = lq * CT + wc_i * CS * 16 + f16_a_row<CS>(cs, lr);
 
     f32x4 acc[PS][CS];
 #pragma unroll
@@ -245,51 +245,60 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
     unsigned co_off[CS];
 #pragma unroll
     for (int cs = 0; cs < CS; ++cs) {
-        const int co = ct * CT + (wc_i * CS + cs) * 16 + 4 * lq;
+        const int co = ct * CT + wc_i * CS * 16 + f16_d_cout<CS>(cs, lq);
         const bool ok = co < p.C8out * 8;
         const int cc = co < p.Cout_pad16 ? co : 0;
         sc[cs] = *reinterpret_cast<const f32x4*>(p.scale + cc);
         sh[cs] = *reinterpret_cast<const f32x4*>(p.shift + cc);
         co_off[cs] = ok ? (unsigned)(co >> 3) * plane_o * 16u + ((co >> 2) & 1) * 8u : kInv;
     }
-    u32x2 r1[CS][PS], r2[CS][PS];
+    // cout tiles 2j, 2j+1 share a 16-byte channel block per pixel (conv_f16_dev.h): 16-byte residual loads and stores
+    constexpr int NP = CS / 2, NS = CS - 2 * NP;
+    u32x4 r1p[NP ? NP : 1][PS], r2p[NP ? NP : 1][PS];
+    u32x2 r1s[PS], r2s[PS];
     if (p.res1) {
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const char*>(p.res1) + grp, grp_bytes);
 #pragma unroll
-        for (int cs = 0; cs < CS; ++cs)
+        for (int j = 0; j < NP; ++j)
 #pragma unroll
-            for (int ps = 0; ps < PS; ++ps)
-                r1[cs][ps] = __builtin_amdgcn_raw_buffer_load_b64(rs, co_off[cs] + pix_off[ps], 0, 0);
+            for (int ps = 0; ps < PS; ++ps) r1p[j][ps] = __builtin_amdgcn_raw_buffer_load_b128(rs, co_off[2 * j] + pix_off[ps], 0, 0);
+        if (NS) {
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps) r1s[ps] = __builtin_amdgcn_raw_buffer_load_b64(rs, co_off[CS - 1] + pix_off[ps], 0, 0);
+        }
     }
     if (p.res2) {
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const char*>(p.res2) + grp, grp_bytes);
 #pragma unroll
-        for (int cs = 0; cs < CS; ++cs)
+        for (int j = 0; j < NP; ++j)
 #pragma unroll
-            for (int ps = 0; ps < PS; ++ps)
-                r2[cs][ps] = __builtin_amdgcn_raw_buffer_load_b64(rs, co_off[cs] + pix_off[ps], 0, 0);
+            for (int ps = 0; ps < PS; ++ps) r2p[j][ps] = __builtin_amdgcn_raw_buffer_load_b128(rs, co_off[2 * j] + pix_off[ps], 0, 0);
+        if (NS) {
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps) r2s[ps] = __builtin_amdgcn_raw_buffer_load_b64(rs, co_off[CS - 1] + pix_off[ps], 0, 0);
+        }
     }
     compute(p.nbuf == 2 ? ((p.n_chunks - 1) & 1) : 0);
 
-    // ---- epilogue: scale/shift, residuals (fetched before the MFMA loop), ReLU, one rounding, 8-byte stores
+    // ---- epilogue: scale/shift, residuals (fetched before the MFMA loop), ReLU, one rounding, 16-byte stores per tile pair
+    const bool has1 = p.res1 != nullptr, has2 = p.res2 != nullptr;
 #pragma unroll
-    for (int cs = 0; cs < CS; ++cs)
+    for (int j = 0; j < NP; ++j)
 #pragma unroll
         for (int ps = 0; ps < PS; ++ps) {
-            f32x4 v = acc[ps][cs] * sc[cs] + sh[cs];
-            if (p.res1) {
-                const f16x4 h = __builtin_bit_cast(f16x4, r1[cs][ps]);
-                v += (f32x4){(float)h.x, (float)h.y, (float)h.z, (float)h.w};
-            }
-            if (p.res2) {
-                const f16x4 h = __builtin_bit_cast(f16x4, r2[cs][ps]);
-                v += (f32x4){(float)h.x, (float)h.y, (float)h.z, (float)h.w};
-            }
-            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            const f16x4 o = (f16x4){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs_o,
-                                                  co_off[cs] + pix_off[ps], 0, 0);
+            const u32x4 a1 = has1 ? r1p[j][ps] : (u32x4){0u, 0u, 0u, 0u}, a2 = has2 ? r2p[j][ps] : (u32x4){0u, 0u, 0u, 0u};
+            const u32x2 lo = f16_pack4(f16_epi4(acc[ps][2 * j], sc[2 * j], sh[2 * j], has1, (u32x2){a1.x, a1.y}, has2, (u32x2){a2.x, a2.y}, p.relu));
+            const u32x2 hi = f16_pack4(f16_epi4(acc[ps][2 * j + 1], sc[2 * j + 1], sh[2 * j + 1], has1, (u32x2){a1.z, a1.w}, has2, (u32x2){a2.z, a2.w}, p.relu));
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){lo.x, lo.y, hi.x, hi.y}, rs_o, co_off[2 * j] + pix_off[ps], 0, 0);
         }
+    if (NS) {
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps) {
+            const u32x2 o = f16_pack4(f16_epi4(acc[ps][CS - 1], sc[CS - 1], sh[CS - 1], has1, has1 ? r1s[ps] : (u32x2){0u, 0u}, has2,
+                                               has2 ? r2s[ps] : (u32x2){0u, 0u}, p.relu));
+            __builtin_amdgcn_raw_buffer_store_b64(o, rs_o, co_off[CS - 1] + pix_off[ps], 0, 0);
+        }
+    }
 }
 
 // regular: big chunks, two workgroups per CU; light: small chunks / few staging registers, three per CU (<= 52 KiB LDS)
@@ -426,6 +435,7 @@ bool f16_configure_mt(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
 }
 
 bool f16_configure(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
+    if (f16_variant_wreg(variant)) return f16_configure_wreg(d, variant, L);
     if (f16_variant_mt(variant)) return f16_configure_mt(d, variant, L);
     int CT, PT;
     f16_variant_dims(variant, CT, PT);
@@ -686,6 +696,13 @@ int grid_for(size_t total) {
 void f16_variant_dims(int v, int& ct, int& pt) {
     static const int cts[5] = {32, 64, 48, 64, 32};
     static const int pts[5] = {192, 192, 192, 96, 96};
+    if (f16_variant_wreg(v)) {
+        int ps, csw;
+        f16_wreg_dims(v, ps, csw);
+        ct = 64 * csw;
+        pt = 16 * ps;
+        return;
+    }
     if (v == F_CT32_PT384) { ct = 32; pt = 384; return; }
     if (v >= F_CT16_PT192) { ct = 16; pt = 192; return; }
     ct = cts[v % 5];
@@ -703,6 +720,7 @@ int f16_build_launch(const mp_conv_desc* desc, int variant, const void* x, const
     if ((size_t)desc->n * ((desc->cout + 7) / 8) * desc->out_h * desc->out_w * 16 >= 0x60000000u) return MP_ERR_UNSUPPORTED;
     bool ok = false;
     if (variant >= 0) {
+        if (f16_variant_wreg(variant) && res2) return MP_ERR_UNSUPPORTED;  // one residual tensor in that kernel
         ok = f16_configure(*desc, variant, L);
     } else {
         // heuristic: widest cout tile that divides the padded couts, 192-pixel tiles unless the grid would not fill the chip
@@ -731,6 +749,7 @@ int f16_build_launch(const mp_conv_desc* desc, int variant, const void* x, const
 }
 
 int f16_launch(const ConvF16Launch& L, hipStream_t s) {
+    if (f16_variant_wreg(L.variant)) return f16_wreg_launch(L, s);
     if (f16_variant_mt(L.variant)) return f16_mt_launch(L, s);
     if (L.ks == 1) return L.stride == 1 ? launch_f16_ks<1, 1>(L.p, L.variant, L.lds_bytes, s) : launch_f16_ks<1, 2>(L.p, L.variant, L.lds_bytes, s);
     if (L.ks == 2) return launch_f16_ks<2, 1>(L.p, L.variant, L.lds_bytes, s);

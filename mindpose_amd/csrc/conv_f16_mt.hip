@@ -100,13 +100,13 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Para
     }
     int a_off[CS];
 #pragma unroll
-    for (int cs = 0; cs < CS; ++cs) a_off[cs] = lq * CT + (wc_i * CS + cs) * 16 + lr;
+    for (int cs = 0; cs < CS; ++cs) a_off[cs] = lq * CT + wc_i * CS * 16 + f16_a_row<CS>(cs, lr);
 
     f32x4 sc[CS], sh[CS];
     unsigned co_off[CS];
 #pragma unroll
     for (int cs = 0; cs < CS; ++cs) {
-        const int co = ct * CT + (wc_i * CS + cs) * 16 + 4 * lq;
+        const int co = ct * CT + wc_i * CS * 16 + f16_d_cout<CS>(cs, lq);
         const bool ok = co < p.C8out * 8;
         const int cc = co < p.Cout_pad16 ? co : 0;
         sc[cs] = *reinterpret_cast<const f32x4*>(p.scale + cc);
@@ -163,20 +163,29 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Para
             const bool ok = pix_gy[ps] >= 0 && n0 + (pix_gy[ps] >> 16) < p.N && y0 + (pix_gy[ps] & 0xFFFF) < p.Ho;
             pix_off[ps] = ok ? (unsigned)(obase + pix_rel[ps]) : kInv;
         }
-        u32x2 r1[CS][PS], r2[CS][PS];
+        // cout tiles 2j, 2j+1 share a 16-byte channel block per pixel (conv_f16_dev.h): 16-byte residual loads and stores
+        constexpr int NP = CS / 2, NS = CS - 2 * NP;
+        u32x4 r1p[NP ? NP : 1][PS], r2p[NP ? NP : 1][PS];
+        u32x2 r1s[PS], r2s[PS];
         if (p.res1) {
 #pragma unroll
-            for (int cs = 0; cs < CS; ++cs)
+            for (int j = 0; j < NP; ++j)
 #pragma unroll
-                for (int ps = 0; ps < PS; ++ps)
-                    r1[cs][ps] = __builtin_amdgcn_raw_buffer_load_b64(rs_r1, co_off[cs] + pix_off[ps], 0, 0);
+                for (int ps = 0; ps < PS; ++ps) r1p[j][ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_r1, co_off[2 * j] + pix_off[ps], 0, 0);
+            if (NS) {
+#pragma unroll
+                for (int ps = 0; ps < PS; ++ps) r1s[ps] = __builtin_amdgcn_raw_buffer_load_b64(rs_r1, co_off[CS - 1] + pix_off[ps], 0, 0);
+            }
         }
         if (p.res2) {
 #pragma unroll
-            for (int cs = 0; cs < CS; ++cs)
+            for (int j = 0; j < NP; ++j)
 #pragma unroll
-                for (int ps = 0; ps < PS; ++ps)
-                    r2[cs][ps] = __builtin_amdgcn_raw_buffer_load_b64(rs_r2, co_off[cs] + pix_off[ps], 0, 0);
+                for (int ps = 0; ps < PS; ++ps) r2p[j][ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_r2, co_off[2 * j] + pix_off[ps], 0, 0);
+            if (NS) {
+#pragma unroll
+                for (int ps = 0; ps < PS; ++ps) r2s[ps] = __builtin_amdgcn_raw_buffer_load_b64(rs_r2, co_off[CS - 1] + pix_off[ps], 0, 0);
+            }
         }
 
         f32x4 acc[PS][CS];
@@ -230,24 +239,24 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Para
             }
         }
 
+        const bool has1 = p.res1 != nullptr, has2 = p.res2 != nullptr;
 #pragma unroll
-        for (int cs = 0; cs < CS; ++cs)
+        for (int j = 0; j < NP; ++j)
 #pragma unroll
             for (int ps = 0; ps < PS; ++ps) {
-                f32x4 v = acc[ps][cs] * sc[cs] + sh[cs];
-                if (p.res1) {
-                    const f16x4 h = __builtin_bit_cast(f16x4, r1[cs][ps]);
-                    v += (f32x4){(float)h.x, (float)h.y, (float)h.z, (float)h.w};
-                }
-                if (p.res2) {
-                    const f16x4 h = __builtin_bit_cast(f16x4, r2[cs][ps]);
-                    v += (f32x4){(float)h.x, (float)h.y, (float)h.z, (float)h.w};
-                }
-                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                const f16x4 o = (f16x4){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs_o,
-                                                      co_off[cs] + pix_off[ps], 0, 0);
+                const u32x4 a1 = has1 ? r1p[j][ps] : (u32x4){0u, 0u, 0u, 0u}, a2 = has2 ? r2p[j][ps] : (u32x4){0u, 0u, 0u, 0u};
+                const u32x2 lo = f16_pack4(f16_epi4(acc[ps][2 * j], sc[2 * j], sh[2 * j], has1, (u32x2){a1.x, a1.y}, has2, (u32x2){a2.x, a2.y}, p.relu));
+                const u32x2 hi = f16_pack4(f16_epi4(acc[ps][2 * j + 1], sc[2 * j + 1], sh[2 * j + 1], has1, (u32x2){a1.z, a1.w}, has2, (u32x2){a2.z, a2.w}, p.relu));
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){lo.x, lo.y, hi.x, hi.y}, rs_o, co_off[2 * j] + pix_off[ps], 0, 0);
             }
+        if (NS) {
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps) {
+                const u32x2 o = f16_pack4(f16_epi4(acc[ps][CS - 1], sc[CS - 1], sh[CS - 1], has1, has1 ? r1s[ps] : (u32x2){0u, 0u}, has2,
+                                                   has2 ? r2s[ps] : (u32x2){0u, 0u}, p.relu));
+                __builtin_amdgcn_raw_buffer_store_b64(o, rs_o, co_off[CS - 1] + pix_off[ps], 0, 0);
+            }
+        }
 
         if (more) {
             if (p.nbuf == 1) __syncthreads();  // single input buffer (big tiles): every wave is done reading it

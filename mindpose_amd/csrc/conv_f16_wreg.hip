@@ -1,0 +1,309 @@
+// fp16-MFMA convolution, "weights in registers" form, for the large-K stride-1 layers (HRNet branches with 64 - 384 channels).
+//
+// Why another structure (DESIGN 4.4, round-1 phase stamps): at fp16 MFMA rates the one-tile / multi-tile kernels are paced by
+// everything AROUND the matrix pipe - both operands go global -> VGPR -> ds_write -> barrier -> ds_read, one barrier per 54 MFMAs,
+// and a workgroup's life is a serial chain of those phases (pipe 25 % busy).  Here
+//   * the weight operand never touches LDS: the four waves of a workgroup own disjoint output channels, so each wave streams ITS
+//     A fragments straight from global memory (L2-resident, packed lane-linear) into a register ring one k-step (KS*KS taps)
+//     ahead of their use - no staging registers, no ds_write, no sharing, no barrier;
+//   * the input tile of ALL input channels is brought into LDS ONCE by LDS-DMA (buffer_load_dwordx4 ... lds: no VGPR round trip;
+//     rows / images outside the tensor and the halo column arrive as zeros through the buffer range check, so there is no zero
+//     fill pass either), then read by every wave as the B operand: ONE barrier per workgroup;
+//   * the k loop is therefore a pure ds_read_b128 + global A prefetch + MFMA stream in the SAME k order as the other kernels
+//     (k-steps ascending, taps ascending): outputs are bit-identical to conv_f16_kernel / conv_f16_mt_kernel.
+// LDS image: [plane][image][row][W + h] 16-byte elements + one trailing element, h = KS / 2: ONE zero column between rows serves
+// as the right halo of row r and the left halo of row r + 1 (pixel (r, x) at r * (W + h) + x + h).
+// Per-CU budget at (6 pixel tiles x 2 cout tiles per wave): LDS reads 128 B/clk of 256, weight stream 43 B/clk of the 64 B/clk
+// vector-memory path, 12 MFMAs per tap per wave.
+#include "conv_f16.h"
+#include "conv_f16_dev.h"
+
+namespace mp {
+
+namespace {
+
+template <int KS, int PS, int CSW, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Params p) {
+    constexpr int T = KS * KS;
+    constexpr int HALO = KS / 2;
+    constexpr int CT = 64 * CSW;  // couts per workgroup: 4 waves x CSW tiles of 16
+    extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
+    u32x4* __restrict__ lds_in = smem16;  // [PK][plane]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane >> 4, lr = lane & 15;
+
+    int b = blockIdx.x;
+    {
+        const int nb = p.total_blocks, q8 = nb >> 3, r8 = nb & 7, xcd = b & 7, j = b >> 3;
+        b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
+    }
+    const int ct = b % p.n_ct;
+    b /= p.n_ct;
+    const int ty = b % p.tiles_y, tn = b / p.tiles_y;
+    const int n0 = tn * p.G, y0 = ty * p.R;
+    const int HW = p.H * p.W;
+    const int P = p.Wp;  // row pitch W + HALO
+
+    // ---- weight operand: this wave's couts, straight from the packed weights [kq][T][4][Cout_pad16] x 16 B
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.wp, (size_t)(p.PK >> 2) * T * 4 * p.Cout_pad16 * 16);
+    unsigned a_goff[CSW];
+#pragma unroll
+    for (int cs = 0; cs < CSW; ++cs) {
+        const int co = ct * CT + wave * CSW * 16 + f16_a_row<CSW>(cs, lr);
+        a_goff[cs] = co < p.Cout_pad16 ? (unsigned)(lq * p.Cout_pad16 + co) * 16u : kOob;
+    }
+    const unsigned tap_bytes = 4u * p.Cout_pad16 * 16u;  // one (k-step, tap): 4 planes x Cout_pad16 x 16 B
+    u32x4 A[T][CSW];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int cs = 0; cs < CSW; ++cs)
+            A[t][cs] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, a_goff[cs] == kOob ? kOob : a_goff[cs] + t * tap_bytes, 0, 0);
+
+    // ---- input tile: every 16-byte slot of the LDS image is written by LDS-DMA, data or (out of range) zero
+    {
+        const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x, (size_t)p.N * p.C8in * HW * 16);
+        const int total = p.PK * p.plane;  // multiple of 64
+        const int img_slots = p.G * p.img_plane;
+        for (int s0 = wave * 64; s0 < total; s0 += 256) {
+            const unsigned s = (unsigned)(s0 + lane);
+            const unsigned pl = fastdiv(s, p.plane, p.magic_upc);
+            const unsigned rem = s - pl * p.plane;
+            const unsigned g = p.G > 1 ? fastdiv(rem, p.img_plane, p.magic_rin) : 0u;
+            const unsigned rr = rem - g * p.img_plane;
+            const unsigned r = fastdiv(rr, P, p.magic_ncols);
+            const int c = (int)(rr - r * P) - HALO;
+            const int yin = y0 - HALO + (int)r;
+            const bool ok = rem < (unsigned)img_slots && c >= 0 && yin >= 0 && yin < p.H && n0 + (int)g < p.N && pl < (unsigned)p.C8in;
+            const unsigned off = ok ? ((((unsigned)(n0 + g) * p.C8in + pl) * HW + yin * p.W + c) * 16u) : kOob;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(lds_in + s0), 16, off, 0, 0, 0);
+        }
+    }
+
+    // ---- pixel operand addresses and the epilogue's pixel offsets (overlap the DMA's flight)
+    int b_off[PS];
+    unsigned pix_off[PS];
+    const int plane_o = p.out_h * p.out_w;
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps) {
+        const unsigned pl0 = (unsigned)(ps * 16 + lr);
+        const bool in_tile = pl0 < (unsigned)(p.G * p.RWo);
+        const unsigned pl = in_tile ? pl0 : 0u;
+        const unsigned g = fastdiv(pl, p.RWo, p.magic_rwo);
+        const unsigned rem = pl - g * p.RWo;
+        const unsigned y = fastdiv(rem, p.Wo, p.magic_wo);
+        const unsigned xx = rem - y * p.Wo;
+        b_off[ps] = lq * p.plane + g * p.img_plane + y * P + xx;
+        const int yy = y0 + (int)y;
+        const bool ok = in_tile && n0 + (int)g < p.N && yy < p.Ho;
+        pix_off[ps] = ok ? (((unsigned)(n0 + g) * p.C8out * plane_o + (yy * p.out_mul + p.off_y) * p.out_w + xx * p.out_mul + p.off_x) * 16u) : kInv;
+    }
+    f32x4 sc[CSW], sh[CSW];
+    unsigned co_off[CSW];
+#pragma unroll
+    for (int cs = 0; cs < CSW; ++cs) {
+        const int co = ct * CT + wave * CSW * 16 + f16_d_cout<CSW>(cs, lq);
+        const bool ok = co < p.C8out * 8;
+        const int cc = co < p.Cout_pad16 ? co : 0;
+        sc[cs] = *reinterpret_cast<const f32x4*>(p.scale + cc);
+        sh[cs] = *reinterpret_cast<const f32x4*>(p.shift + cc);
+        co_off[cs] = ok ? (unsigned)(co >> 3) * plane_o * 16u + ((co >> 2) & 1) * 8u : kInv;
+    }
+
+    f32x4 acc[PS][CSW];
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps)
+#pragma unroll
+        for (int cs = 0; cs < CSW; ++cs) acc[ps][cs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces (and its first weight fragments) have landed
+    __syncthreads();                                  // ... and every other wave's: the only barrier of the workgroup
+
+    constexpr int NP = CSW / 2, NS = CSW - 2 * NP;
+    const size_t o_bytes = (size_t)p.N * p.C8out * plane_o * 16;
+    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(p.out, o_bytes);
+    u32x4 r1p[NP ? NP : 1][PS];  // one residual tensor (the BasicBlock identity); launches with two go to the tile kernels
+    u32x2 r1s[PS];
+
+    const int nq = p.PK >> 2;
+    u32x4 bv[PS];
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps) bv[ps] = lds_in[b_off[ps]];
+    for (int q = 0; q < nq; ++q) {
+        const bool more = q + 1 < nq;
+        if (!more) {
+            // residual tensors: fetched ahead of the last k-step, so their latency hides under its MFMAs
+            if (p.res1) {
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.res1, o_bytes);
+#pragma unroll
+                for (int j = 0; j < NP; ++j)
+#pragma unroll
+                    for (int ps = 0; ps < PS; ++ps) r1p[j][ps] = __builtin_amdgcn_raw_buffer_load_b128(rs, co_off[2 * j] + pix_off[ps], 0, 0);
+                if (NS) {
+#pragma unroll
+                    for (int ps = 0; ps < PS; ++ps) r1s[ps] = __builtin_amdgcn_raw_buffer_load_b64(rs, co_off[CSW - 1] + pix_off[ps], 0, 0);
+                }
+            }
+        }
+        const int in_q = q * 4 * p.plane;
+        const int qn = more ? q + 1 : q;  // the final prefetch re-reads a valid position (discarded)
+        const unsigned wq_next = (unsigned)(q + 1) * T * tap_bytes;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int tn2 = (t + 1 < T) ? t + 1 : 0;
+            const int in_off = ((t + 1 < T) ? in_q : qn * 4 * p.plane) + (tn2 / KS) * P + (tn2 % KS);
+            u32x4 bn[PS];
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps) bn[ps] = lds_in[b_off[ps] + in_off];
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps)
+#pragma unroll
+                for (int cs = 0; cs < CSW; ++cs)
+                    acc[ps][cs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A[t][cs]),
+                                                                          __builtin_bit_cast(f16x8, bv[ps]), acc[ps][cs], 0, 0, 0);
+            {
+                constexpr int NM = PS * CSW, NPAIR = PS < NM ? PS : NM;
+#pragma unroll
+                for (int i = 0; i < NPAIR; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+                }
+                if (NM > NPAIR) __builtin_amdgcn_sched_group_barrier(0x008, NM - NPAIR, 0);
+            }
+            // this tap's weight registers are free: refill them for the next k-step (one k-step = T taps of prefetch distance)
+            if (more) {
+#pragma unroll
+                for (int cs = 0; cs < CSW; ++cs)
+                    A[t][cs] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, a_goff[cs] == kOob ? kOob : a_goff[cs] + wq_next + t * tap_bytes, 0, 0);
+            }
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps) bv[ps] = bn[ps];
+        }
+    }
+
+    // ---- epilogue: scale/shift, residuals, ReLU, one rounding, 16-byte stores per cout-tile pair
+    const bool has1 = p.res1 != nullptr;
+    const u32x2 none = (u32x2){0u, 0u};
+#pragma unroll
+    for (int j = 0; j < NP; ++j)
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps) {
+            const u32x4 a1 = has1 ? r1p[j][ps] : (u32x4){0u, 0u, 0u, 0u};
+            const u32x2 lo = f16_pack4(f16_epi4(acc[ps][2 * j], sc[2 * j], sh[2 * j], has1, (u32x2){a1.x, a1.y}, false, none, p.relu));
+            const u32x2 hi = f16_pack4(f16_epi4(acc[ps][2 * j + 1], sc[2 * j + 1], sh[2 * j + 1], has1, (u32x2){a1.z, a1.w}, false, none, p.relu));
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){lo.x, lo.y, hi.x, hi.y}, rs_o, co_off[2 * j] + pix_off[ps], 0, 0);
+        }
+    if (NS) {
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps) {
+            const u32x2 o = f16_pack4(f16_epi4(acc[ps][CSW - 1], sc[CSW - 1], sh[CSW - 1], has1, has1 ? r1s[ps] : none, false, none, p.relu));
+            __builtin_amdgcn_raw_buffer_store_b64(o, rs_o, co_off[CSW - 1] + pix_off[ps], 0, 0);
+        }
+    }
+}
+
+template <int KS, int PS, int CSW, int OCC>
+int launch_wreg(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
+    auto kern = conv_f16_wreg_kernel<KS, PS, CSW, OCC>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(256), lds_bytes, s, p);
+    return check_launch();
+}
+
+template <int KS>
+int launch_wreg_ks(const ConvF16Params& p, int variant, size_t lds_bytes, hipStream_t s) {
+    switch (variant) {
+        case F_WREG_P6C2: return launch_wreg<KS, 6, 2, 1>(p, lds_bytes, s);
+        case F_WREG_P3C2: return launch_wreg<KS, 3, 2, 2>(p, lds_bytes, s);
+        case F_WREG_P6C1: return launch_wreg<KS, 6, 1, 2>(p, lds_bytes, s);
+        case F_WREG_P6C3: return launch_wreg<KS, 6, 3, 1>(p, lds_bytes, s);
+        case F_WREG_P3C3: return launch_wreg<KS, 3, 3, 1>(p, lds_bytes, s);
+        case F_WREG_P3C4: return launch_wreg<KS, 3, 4, 1>(p, lds_bytes, s);
+        default: return MP_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace
+
+void f16_wreg_dims(int v, int& ps, int& csw) {
+    static const int pss[6] = {6, 3, 6, 6, 3, 3};
+    static const int css[6] = {2, 2, 1, 3, 3, 4};
+    ps = pss[v - F_WREG_P6C2];
+    csw = css[v - F_WREG_P6C2];
+}
+
+// geometry: stride-1 "same" convolutions (3x3 pad 1, 1x1 pad 0) whose output rows tile the pixel tile
+bool f16_configure_wreg(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
+    int PS, CSW;
+    f16_wreg_dims(variant, PS, CSW);
+    const int KS = d.kh, halo = KS / 2, T = KS * KS;
+    if (d.stride != 1 || !(KS == 3 || KS == 1)) return false;
+    if (d.pad_top != halo || d.pad_left != halo || d.conv_h != d.h || d.conv_w != d.w) return false;
+    ConvF16Params& p = L.p;
+    const int PT = 16 * PS, CT = 64 * CSW;
+    p.N = d.n; p.H = d.h; p.W = d.w; p.Cout = d.cout;
+    p.C8in = (d.cin + 7) / 8;
+    p.Cout_pad16 = round_up(d.cout, 16);
+    p.C8out = (d.cout + 7) / 8;
+    p.Ho = d.conv_h; p.Wo = d.conv_w; p.pad_t = halo; p.pad_l = halo;
+    if ((long long)d.n * p.C8in * d.h * d.w * 16 >= 0x7FFFFFF0LL || (long long)d.n * p.C8out * d.out_h * d.out_w * 16 >= 0x60000000LL) return false;
+    p.PK = round_up(d.cin, 32) / 8;
+    p.PKs = p.C8in < p.PK ? p.C8in : p.PK;
+    p.n_chunks = 1;
+    if (p.Wo > PT) return false;
+    // the structure pays when the weight stream per pixel tile is substantial: large K (the small-K layers are HBM-bound and served
+    // by the tile kernels), and when a wave's cout tiles are all real
+    if (d.cin < 64 || (p.Cout_pad16 / 16) % (4 * CSW) != 0) return false;  // every wave of every workgroup owns CSW real cout tiles
+    int R = PT / p.Wo;
+    if (R > p.Ho) R = p.Ho;
+    p.R = R;
+    p.G = 1;
+    if (R == p.Ho) {
+        p.G = PT / (p.Ho * p.Wo);
+        if (p.G > p.N) p.G = p.N;
+        if (p.G < 1) p.G = 1;
+    }
+    p.RWo = p.R * p.Wo;
+    if (p.G * p.RWo * 10 < PT * 7) return false;  // more than 30 % padding lanes: another tile shape fits better
+    p.Rin = p.R + 2 * halo;
+    p.Wp = p.W + halo;  // row pitch: one shared zero column
+    p.img_plane = p.Rin * p.Wp;
+    p.plane = round_up(p.G * p.img_plane + halo, 16);
+    p.ncols = p.W;
+    p.upc = 0;
+    p.in_buf = p.PK * p.plane;
+    p.w_buf = 0;
+    p.nbuf = 1;
+    p.n_ct = (p.Cout_pad16 + CT - 1) / CT;
+    p.tiles_y = (p.G > 1 || p.R >= p.Ho) ? 1 : (p.Ho + p.R - 1) / p.R;
+    p.tiles_n = (p.N + p.G - 1) / p.G;
+    p.tiles_total = p.tiles_y * p.tiles_n;
+    p.relu = d.relu;
+    p.out_h = d.out_h; p.out_w = d.out_w; p.out_mul = d.out_mul; p.off_y = d.out_off_y; p.off_x = d.out_off_x;
+    p.magic_upc = magic_of(p.plane);       // slot -> plane
+    p.magic_rin = magic_of(p.img_plane);   // slot -> image
+    p.magic_ncols = magic_of(p.Wp);        // slot -> row
+    p.magic_rwo = magic_of(p.RWo);
+    p.magic_wo = magic_of(p.Wo);
+    p.total_blocks = p.n_ct * p.tiles_y * p.tiles_n;
+    p.ni_used = p.nw_used = 0;
+    L.ks = KS; L.stride = 1; L.variant = variant;
+    L.lds_bytes = (size_t)p.in_buf * 16;
+    (void)T;
+    return L.lds_bytes <= (size_t)150 * 1024;
+}
+
+int f16_wreg_launch(const ConvF16Launch& L, hipStream_t s) {
+    if (L.ks == 3) return launch_wreg_ks<3>(L.p, L.variant, L.lds_bytes, s);
+    if (L.ks == 1) return launch_wreg_ks<1>(L.p, L.variant, L.lds_bytes, s);
+    return MP_ERR_UNSUPPORTED;
+}
+
+}  // namespace mp

@@ -14,6 +14,7 @@ import torch.nn as nn
 from .. import _lib
 
 BN_EPS = 1e-5  # mindspore.nn.BatchNorm2d default eps
+F16_VARIANTS = 31  # csrc/conv_f16.h F_COUNT: tile shapes the fp16 autotuner times per launch shape
 
 
 class Conv2d(nn.Module):
@@ -175,7 +176,7 @@ def tune_conv_variant(lib, d, x, packed, scale, shift, res1, res2, out, half: bo
         return fn(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(res1),
                   _lib.ptr(res2), _lib.ptr(trial_out), stream)
 
-    return _autotune(key, macs, 25 if half else 8, launch)
+    return _autotune(key, macs, F16_VARIANTS if half else 8, launch)
 
 
 class Plan:

@@ -131,6 +131,81 @@ def test_conv_f16_multi_tile_vs_oracle(case, variant, groups, monkeypatch):
     test_conv_f16_vs_oracle(case, variant)
 
 
+WREG_CASES = [
+    # n, cin, cout, k, s, h, w, relu, n_res  - stride-1 "same" convs with >= 64 input channels (conv_f16_wreg.hip)
+    (3, 64, 64, 3, 1, 32, 24, True, 1),     # branch 1: row bands of 4, 8 bands per image
+    (3, 128, 128, 3, 1, 16, 12, True, 1),   # branch 2: half-image bands (P6) / quarter bands (P3)
+    (5, 256, 256, 3, 1, 8, 6, True, 1),     # branch 3: two images per tile, odd batch -> a half-empty last tile
+    (2, 192, 192, 3, 1, 16, 12, True, 0),   # W48 branch 2: three cout tiles per wave
+    (3, 96, 192, 3, 1, 12, 9, False, 1),    # ragged: 10-row bands of a 12-row map, 6 padding lanes per tile
+    (2, 72, 64, 3, 1, 10, 7, True, 0),      # input channels padded 72 -> 96: three zero planes from the range check
+    (2, 256, 64, 1, 1, 16, 12, True, 0),    # 1x1 (no halo column), 8 k-steps
+    (2, 64, 256, 1, 1, 16, 12, True, 1),    # 1x1, four cout tiles per wave
+    (130, 128, 128, 3, 1, 16, 12, True, 1), # more workgroups than CUs
+]
+
+
+@pytest.mark.parametrize("case", WREG_CASES)
+@pytest.mark.parametrize("variant", list(range(25, 31)))
+def test_conv_f16_wreg_vs_oracle_and_bit_identical_to_tile_kernel(case, variant):
+    """The weights-in-registers kernel (LDS-DMA input tile, weight fragments streamed from global memory) against the oracle,
+    and bit for bit against the one-tile kernel: same k order, same epilogue arithmetic."""
+    n, cin, cout, k, s, h, w, relu, n_res = case
+    g = torch.Generator().manual_seed(sum(case[:7]))
+    pad = k // 2
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    res = [torch.randn(n, cout, h, w, generator=g) for _ in range(n_res)]
+    xa = _to_c8(x)
+    ra = [_to_c8(r) for r in res] + [None]
+    nb = LIB.mp_f16_packed_weight_bytes(cout, cin, k, k)
+    packed = torch.empty(nb // 2, device=DEV, dtype=torch.float16)
+    _lib.check(LIB.mp_f16_pack_weight(_lib.ptr(wt.to(DEV)), _lib.ptr(packed), cout, cin, k, k, 0, 0, 0, _lib.stream()), "pack")
+    sc, sh = scale.to(DEV), shift.to(DEV)
+    d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=k, kw=k, stride=s, pad_top=pad, pad_left=pad, conv_h=h, conv_w=w,
+                      out_h=h, out_w=w, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=int(relu), tap_dilation_unused=0)
+
+    def run(v):
+        out = ActC8(n, cout, h, w, DEV)
+        out.c8_tensor.fill_(float("nan"))  # every element of the output must be written
+        rc = LIB.mp_f16_conv2d_fwd(ctypes.byref(d), v, _lib.ptr(xa), _lib.ptr(packed), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(ra[0]), None,
+                                   _lib.ptr(out), _lib.stream())
+        return rc, out
+
+    rc, out = run(variant)
+    if rc != 0:
+        pytest.skip("tile variant not available for this shape")
+    rc0, base = run(-1)
+    _lib.check(rc0, "mp_f16_conv2d_fwd")
+    assert torch.equal(out.c8_tensor, base.c8_tensor), "weights-in-registers kernel differs from the tile kernel"
+    if n <= 8:
+        ref = F.conv2d(_h(x), _h(wt), None, stride=s, padding=pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        for r in res:
+            ref = ref + _h(r)
+        ref = _h(F.relu(ref) if relu else ref)
+        got = _from_c8(out)
+        tol = ref.abs() * 2.0 ** -9 + 1e-4 * ref.abs().max()
+        assert not ((got - ref).abs() > tol).any(), float((got - ref).abs().max())
+
+
+def test_conv_f16_wreg_rejects_what_it_does_not_cover():
+    t = torch.zeros(1 << 16, device=DEV)
+
+    def rc(**kw):
+        base = dict(n=2, cin=128, h=16, w=12, cout=128, kh=3, kw=3, stride=1, pad_top=1, pad_left=1, conv_h=16, conv_w=12, out_h=16,
+                    out_w=12, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=0, tap_dilation_unused=0)
+        base.update(kw)
+        d = _lib.ConvDesc(**base)
+        return LIB.mp_f16_conv2d_fwd(ctypes.byref(d), 25, _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), None, None, _lib.ptr(t), _lib.stream())
+
+    assert rc(stride=2, conv_h=8, conv_w=6, out_h=8, out_w=6) != 0   # stride 2
+    assert rc(cin=32) != 0                                            # small K: the tile kernels' territory
+    assert rc(cout=64) != 0                                           # fewer cout tiles than 4 waves x 2
+    assert rc(pad_top=0, pad_left=0, conv_h=14, conv_w=10, out_h=14, out_w=10) != 0  # not a "same" convolution
+
+
 @pytest.mark.parametrize("variant", [-1, 1, 3, 11, 16])
 def test_deconv_phases_f16_vs_oracle(variant, monkeypatch):
     # Conv2dTranspose(k=4, s=2, p=1) + BN + ReLU as four 2x2 sub-pixel phase convs with the strided-scatter output mapping
