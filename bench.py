@@ -72,8 +72,9 @@ def kernel_name(info):
     if info["kind_id"] == 3:
         v = info["variant"]
         if v >= 25:  # weights-in-registers kernel <KS, pixel tiles, cout tiles per wave, waves/SIMD bound>
-            ps, csw, occ = {25: (6, 2, 1), 26: (3, 2, 2), 27: (6, 1, 2), 28: (6, 3, 1), 29: (3, 3, 1), 30: (3, 4, 1)}[v]
-            return f"conv_f16_wreg_kernel<{info['ks']},{ps},{csw},{occ}>"
+            ps, csw, wp, occ = {25: (6, 2, 1, 1), 26: (3, 2, 1, 2), 27: (6, 1, 1, 2), 28: (6, 3, 1, 1), 29: (3, 3, 1, 1), 30: (3, 4, 1, 1),
+                                31: (6, 2, 2, 2), 32: (6, 3, 2, 1), 33: (3, 2, 2, 2), 34: (6, 2, 4, 2), 35: (6, 3, 4, 1), 36: (3, 2, 4, 2)}[v]
+            return f"conv_f16_wreg_kernel<{info['ks']},{ps},{csw},{wp},{occ}>"
         if v == 24:  # 32 couts x 384 pixels, single-chunk build
             return f"conv_f16_kernel<{info['ks']},{info['stride']},6,2,4,1>"
         if v >= 20:  # 16-cout tiles: regular, light, multi-tile (2 / 1 workgroups per CU)
@@ -390,6 +391,15 @@ def train_roofline(eager_step, half):
         eager_step()
         fam = ct.summary()
     total = sum(f["time"] for f in fam.values())
+    dump = os.environ.get("MINDPOSE_BENCH_TRAIN_SHAPES")
+    if dump:  # per (entry, shape) table of the instrumented step, for kernel work: entry,shape,variant,launches,total_us,avg_us
+        with open(dump, "w") as fh:
+            fh.write("entry,shape,variant,launches,total_us,avg_us,tflops\n")
+            for name, f in sorted(fam.items(), key=lambda kv: -kv[1]["time"]):
+                for (shape, variant, _, _), sh in sorted(f["shapes"].items(), key=lambda kv: -kv[1]["time"]):
+                    tf = sh["flops"] / sh["time"] / 1e12 if sh["time"] > 0 else 0.0
+                    fh.write(f"{name},\"{shape}\",{variant},{sh['launches']},{sh['time'] * 1e6:.1f},"
+                             f"{sh['time'] / sh['launches'] * 1e6:.2f},{tf:.1f}\n")
     mfma_peak = PEAK_FP16_MFMA_TFLOPS if half else PEAK_FP32_MFMA_TFLOPS
     dom = max(fam, key=lambda k: fam[k]["time"])
     d = fam[dom]

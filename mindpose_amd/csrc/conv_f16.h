@@ -57,9 +57,11 @@ enum ConvF16Variant { F_CT32_PT192 = 0, F_CT64_PT192 = 1, F_CT48_PT192 = 2, F_CT
                       // and its weight loads are spread over twice the MFMA work
                       F_CT32_PT384 = 24,
                       // "weights in registers" kernel (conv_f16_wreg.hip): P<pixel tiles of 16>C<cout tiles of 16 per wave, x 4 waves>
+                      // _W<n>: n waves split the pixel tiles (4 / n split the couts); no suffix = 1
                       F_WREG_P6C2 = 25, F_WREG_P3C2 = 26, F_WREG_P6C1 = 27, F_WREG_P6C3 = 28, F_WREG_P3C3 = 29, F_WREG_P3C4 = 30,
-                      F_COUNT = 31 };
-inline bool f16_variant_wreg(int v) { return v >= F_WREG_P6C2 && v <= F_WREG_P3C4; }
+                      F_WREG_P6C2_W2 = 31, F_WREG_P6C3_W2 = 32, F_WREG_P3C2_W2 = 33, F_WREG_P6C2_W4 = 34, F_WREG_P6C3_W4 = 35,
+                      F_WREG_P3C2_W4 = 36, F_COUNT = 37 };
+inline bool f16_variant_wreg(int v) { return v >= F_WREG_P6C2 && v <= F_WREG_P3C2_W4; }
 inline bool f16_variant_mt(int v) { return (v >= F_MT2_BASE && v < F_CT16_PT192) || v == F_CT16_PT192_MT2 || v == F_CT16_PT192_MT1; }
 inline int f16_variant_mt_occ(int v) { return (v >= F_MT1_BASE && v < F_CT16_PT192) || v == F_CT16_PT192_MT1 ? 1 : 2; }
 bool f16_variant_light(int v);
@@ -98,7 +100,7 @@ void f16_variant_dims(int v, int& ct, int& pt);
 int f16_mt_launch(const ConvF16Launch& L, hipStream_t s);
 bool f16_configure_wreg(const mp_conv_desc& d, int variant, ConvF16Launch& L);
 int f16_wreg_launch(const ConvF16Launch& L, hipStream_t s);
-void f16_wreg_dims(int v, int& ps, int& csw);
+void f16_wreg_dims(int v, int& ps, int& csw, int& waves_p);
 int f16_mt_ni(int occ);
 
 }  // namespace mp

@@ -697,10 +697,10 @@ void f16_variant_dims(int v, int& ct, int& pt) {
     static const int cts[5] = {32, 64, 48, 64, 32};
     static const int pts[5] = {192, 192, 192, 96, 96};
     if (f16_variant_wreg(v)) {
-        int ps, csw;
-        f16_wreg_dims(v, ps, csw);
-        ct = 64 * csw;
-        pt = 16 * ps;
+        int ps, csw, wp;
+        f16_wreg_dims(v, ps, csw, wp);
+        ct = 16 * csw * (4 / wp);
+        pt = 16 * ps * wp;
         return;
     }
     if (v == F_CT32_PT384) { ct = 32; pt = 384; return; }

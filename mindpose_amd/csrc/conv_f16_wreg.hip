@@ -15,6 +15,8 @@
 // as the right halo of row r and the left halo of row r + 1 (pixel (r, x) at r * (W + h) + x + h).
 // Per-CU budget at (6 pixel tiles x 2 cout tiles per wave): LDS reads 128 B/clk of 256, weight stream 43 B/clk of the 64 B/clk
 // vector-memory path, 12 MFMAs per tap per wave.
+#include <type_traits>
+
 #include "conv_f16.h"
 #include "conv_f16_dev.h"
 
@@ -22,16 +24,22 @@ namespace mp {
 
 namespace {
 
-template <int KS, int PS, int CSW, int OCC>
+// Wave roles: WAVES_P waves split the workgroup's pixel tiles, 4 / WAVES_P split its couts.  WAVES_P = 1 (every wave all pixels,
+// a quarter of the couts) streams each weight byte once per workgroup - the shape for the 128 - 384-channel layers whose weight
+// stream is what the vector-memory path carries; with fewer couts (64 / 32-channel layers) the pixel split keeps two cout tiles
+// per wave, i.e. half the LDS reads per MFMA, at the price of WAVES_P waves fetching the same (small) weight fragments.
+template <int KS, int PS, int CSW, int WAVES_P, int OCC>
 __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Params p) {
     constexpr int T = KS * KS;
     constexpr int HALO = KS / 2;
-    constexpr int CT = 64 * CSW;  // couts per workgroup: 4 waves x CSW tiles of 16
+    constexpr int WAVES_C = 4 / WAVES_P;
+    constexpr int CT = 16 * CSW * WAVES_C;  // couts per workgroup
     extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
     u32x4* __restrict__ lds_in = smem16;  // [PK][plane]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp_i = wave % WAVES_P, wc_i = wave / WAVES_P;
     const int lq = lane >> 4, lr = lane & 15;
 
     int b = blockIdx.x;
@@ -51,7 +59,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
     unsigned a_goff[CSW];
 #pragma unroll
     for (int cs = 0; cs < CSW; ++cs) {
-        const int co = ct * CT + wave * CSW * 16 + f16_a_row<CSW>(cs, lr);
+        const int co = ct * CT + wc_i * CSW * 16 + f16_a_row<CSW>(cs, lr);
         a_goff[cs] = co < p.Cout_pad16 ? (unsigned)(lq * p.Cout_pad16 + co) * 16u : kOob;
     }
     const unsigned tap_bytes = 4u * p.Cout_pad16 * 16u;  // one (k-step, tap): 4 planes x Cout_pad16 x 16 B
@@ -88,7 +96,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
     const int plane_o = p.out_h * p.out_w;
 #pragma unroll
     for (int ps = 0; ps < PS; ++ps) {
-        const unsigned pl0 = (unsigned)(ps * 16 + lr);
+        const unsigned pl0 = (unsigned)((wp_i * PS + ps) * 16 + lr);
         const bool in_tile = pl0 < (unsigned)(p.G * p.RWo);
         const unsigned pl = in_tile ? pl0 : 0u;
         const unsigned g = fastdiv(pl, p.RWo, p.magic_rwo);
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
     unsigned co_off[CSW];
 #pragma unroll
     for (int cs = 0; cs < CSW; ++cs) {
-        const int co = ct * CT + wave * CSW * 16 + f16_d_cout<CSW>(cs, lq);
+        const int co = ct * CT + wc_i * CSW * 16 + f16_d_cout<CSW>(cs, lq);
         const bool ok = co < p.C8out * 8;
         const int cc = co < p.Cout_pad16 ? co : 0;
         sc[cs] = *reinterpret_cast<const f32x4*>(p.scale + cc);
@@ -131,24 +139,14 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
     u32x4 bv[PS];
 #pragma unroll
     for (int ps = 0; ps < PS; ++ps) bv[ps] = lds_in[b_off[ps]];
-    for (int q = 0; q < nq; ++q) {
-        const bool more = q + 1 < nq;
-        if (!more) {
-            // residual tensors: fetched ahead of the last k-step, so their latency hides under its MFMAs
-            if (p.res1) {
-                const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.res1, o_bytes);
-#pragma unroll
-                for (int j = 0; j < NP; ++j)
-#pragma unroll
-                    for (int ps = 0; ps < PS; ++ps) r1p[j][ps] = __builtin_amdgcn_raw_buffer_load_b128(rs, co_off[2 * j] + pix_off[ps], 0, 0);
-                if (NS) {
-#pragma unroll
-                    for (int ps = 0; ps < PS; ++ps) r1s[ps] = __builtin_amdgcn_raw_buffer_load_b64(rs, co_off[CSW - 1] + pix_off[ps], 0, 0);
-                }
-            }
-        }
+    // One k-step = T taps.  The body is STRAIGHT-LINE code (no branch around a load): hipcc's s_waitcnt insertion counts loads
+    // exactly only then - with the refill under `if (more)` it fell back to vmcnt(0) at the top of every k-step, i.e. it waited
+    // for the whole ring it had just refilled and the prefetch distance collapsed.  REFILL is a compile-time switch: the last
+    // k-step is peeled (no refill; the residual tensor is fetched ahead of it instead).
+    auto kstep = [&](int q, auto refill_tag) {
+        constexpr bool REFILL = decltype(refill_tag)::value;
         const int in_q = q * 4 * p.plane;
-        const int qn = more ? q + 1 : q;  // the final prefetch re-reads a valid position (discarded)
+        const int qn = REFILL ? q + 1 : q;  // the final prefetch re-reads a valid position (discarded)
         const unsigned wq_next = (unsigned)(q + 1) * T * tap_bytes;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -173,15 +171,33 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
                 if (NM > NPAIR) __builtin_amdgcn_sched_group_barrier(0x008, NM - NPAIR, 0);
             }
             // this tap's weight registers are free: refill them for the next k-step (one k-step = T taps of prefetch distance)
-            if (more) {
+            if constexpr (REFILL) {
 #pragma unroll
                 for (int cs = 0; cs < CSW; ++cs)
                     A[t][cs] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, a_goff[cs] == kOob ? kOob : a_goff[cs] + wq_next + t * tap_bytes, 0, 0);
             }
 #pragma unroll
             for (int ps = 0; ps < PS; ++ps) bv[ps] = bn[ps];
+            // nothing crosses a tap boundary: left alone, the scheduler sinks all T x CSW refill loads to the end of the k-step
+            // (shorter live ranges), where they are needed again at once - no prefetch distance left
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    for (int q = 0; q + 1 < nq; ++q) kstep(q, std::true_type{});
+    {
+        // residual tensor: fetched ahead of the last k-step, so its latency hides under that step's MFMAs.  Unconditional loads
+        // (an absent tensor is a zero-length descriptor: the range check answers, nothing is fetched) keep the code branch-free
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.res1 ? p.res1 : p.out, p.res1 ? o_bytes : 0);
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps) r1p[j][ps] = __builtin_amdgcn_raw_buffer_load_b128(rs, co_off[2 * j] + pix_off[ps], 0, 0);
+        if (NS) {
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps) r1s[ps] = __builtin_amdgcn_raw_buffer_load_b64(rs, co_off[CSW - 1] + pix_off[ps], 0, 0);
         }
     }
+    kstep(nq - 1, std::false_type{});
 
     // ---- epilogue: scale/shift, residuals, ReLU, one rounding, 16-byte stores per cout-tile pair
     const bool has1 = p.res1 != nullptr;
@@ -204,9 +220,9 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
     }
 }
 
-template <int KS, int PS, int CSW, int OCC>
+template <int KS, int PS, int CSW, int WAVES_P, int OCC>
 int launch_wreg(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
-    auto kern = conv_f16_wreg_kernel<KS, PS, CSW, OCC>;
+    auto kern = conv_f16_wreg_kernel<KS, PS, CSW, WAVES_P, OCC>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -220,34 +236,43 @@ int launch_wreg(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
 template <int KS>
 int launch_wreg_ks(const ConvF16Params& p, int variant, size_t lds_bytes, hipStream_t s) {
     switch (variant) {
-        case F_WREG_P6C2: return launch_wreg<KS, 6, 2, 1>(p, lds_bytes, s);
-        case F_WREG_P3C2: return launch_wreg<KS, 3, 2, 2>(p, lds_bytes, s);
-        case F_WREG_P6C1: return launch_wreg<KS, 6, 1, 2>(p, lds_bytes, s);
-        case F_WREG_P6C3: return launch_wreg<KS, 6, 3, 1>(p, lds_bytes, s);
-        case F_WREG_P3C3: return launch_wreg<KS, 3, 3, 1>(p, lds_bytes, s);
-        case F_WREG_P3C4: return launch_wreg<KS, 3, 4, 1>(p, lds_bytes, s);
+        case F_WREG_P6C2: return launch_wreg<KS, 6, 2, 1, 1>(p, lds_bytes, s);
+        case F_WREG_P3C2: return launch_wreg<KS, 3, 2, 1, 2>(p, lds_bytes, s);
+        case F_WREG_P6C1: return launch_wreg<KS, 6, 1, 1, 2>(p, lds_bytes, s);
+        case F_WREG_P6C3: return launch_wreg<KS, 6, 3, 1, 1>(p, lds_bytes, s);
+        case F_WREG_P3C3: return launch_wreg<KS, 3, 3, 1, 1>(p, lds_bytes, s);
+        case F_WREG_P3C4: return launch_wreg<KS, 3, 4, 1, 1>(p, lds_bytes, s);
+        case F_WREG_P6C2_W2: return launch_wreg<KS, 6, 2, 2, 2>(p, lds_bytes, s);
+        case F_WREG_P6C3_W2: return launch_wreg<KS, 6, 3, 2, 1>(p, lds_bytes, s);
+        case F_WREG_P3C2_W2: return launch_wreg<KS, 3, 2, 2, 2>(p, lds_bytes, s);
+        case F_WREG_P6C2_W4: return launch_wreg<KS, 6, 2, 4, 2>(p, lds_bytes, s);
+        case F_WREG_P6C3_W4: return launch_wreg<KS, 6, 3, 4, 1>(p, lds_bytes, s);
+        case F_WREG_P3C2_W4: return launch_wreg<KS, 3, 2, 4, 2>(p, lds_bytes, s);
         default: return MP_ERR_UNSUPPORTED;
     }
 }
 
 }  // namespace
 
-void f16_wreg_dims(int v, int& ps, int& csw) {
-    static const int pss[6] = {6, 3, 6, 6, 3, 3};
-    static const int css[6] = {2, 2, 1, 3, 3, 4};
+void f16_wreg_dims(int v, int& ps, int& csw, int& waves_p) {
+    static const int pss[12] = {6, 3, 6, 6, 3, 3, 6, 6, 3, 6, 6, 3};
+    static const int css[12] = {2, 2, 1, 3, 3, 4, 2, 3, 2, 2, 3, 2};
+    static const int wps[12] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 4, 4, 4};
     ps = pss[v - F_WREG_P6C2];
     csw = css[v - F_WREG_P6C2];
+    waves_p = wps[v - F_WREG_P6C2];
 }
 
 // geometry: stride-1 "same" convolutions (3x3 pad 1, 1x1 pad 0) whose output rows tile the pixel tile
 bool f16_configure_wreg(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
-    int PS, CSW;
-    f16_wreg_dims(variant, PS, CSW);
+    int PS, CSW, WP;
+    f16_wreg_dims(variant, PS, CSW, WP);
     const int KS = d.kh, halo = KS / 2, T = KS * KS;
     if (d.stride != 1 || !(KS == 3 || KS == 1)) return false;
     if (d.pad_top != halo || d.pad_left != halo || d.conv_h != d.h || d.conv_w != d.w) return false;
     ConvF16Params& p = L.p;
-    const int PT = 16 * PS, CT = 64 * CSW;
+    const int WC = 4 / WP;
+    const int PT = 16 * PS * WP, CT = 16 * CSW * WC;
     p.N = d.n; p.H = d.h; p.W = d.w; p.Cout = d.cout;
     p.C8in = (d.cin + 7) / 8;
     p.Cout_pad16 = round_up(d.cout, 16);
@@ -258,9 +283,10 @@ bool f16_configure_wreg(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
     p.PKs = p.C8in < p.PK ? p.C8in : p.PK;
     p.n_chunks = 1;
     if (p.Wo > PT) return false;
-    // the structure pays when the weight stream per pixel tile is substantial: large K (the small-K layers are HBM-bound and served
-    // by the tile kernels), and when a wave's cout tiles are all real
-    if (d.cin < 64 || (p.Cout_pad16 / 16) % (4 * CSW) != 0) return false;  // every wave of every workgroup owns CSW real cout tiles
+    // every wave of every workgroup owns CSW real cout tiles; all-pixels-per-wave shapes are for the layers with a substantial
+    // weight stream (the small-K layers are HBM-bound: pixel-split shapes or the tile kernels)
+    if ((p.Cout_pad16 / 16) % (WC * CSW) != 0) return false;
+    if (WP == 1 && d.cin < 64) return false;
     int R = PT / p.Wo;
     if (R > p.Ho) R = p.Ho;
     p.R = R;

@@ -14,7 +14,7 @@ import torch.nn as nn
 from .. import _lib
 
 BN_EPS = 1e-5  # mindspore.nn.BatchNorm2d default eps
-F16_VARIANTS = 31  # csrc/conv_f16.h F_COUNT: tile shapes the fp16 autotuner times per launch shape
+F16_VARIANTS = 37  # csrc/conv_f16.h F_COUNT: tile shapes the fp16 autotuner times per launch shape
 
 
 class Conv2d(nn.Module):

@@ -142,11 +142,14 @@ WREG_CASES = [
     (2, 256, 64, 1, 1, 16, 12, True, 0),    # 1x1 (no halo column), 8 k-steps
     (2, 64, 256, 1, 1, 16, 12, True, 1),    # 1x1, four cout tiles per wave
     (130, 128, 128, 3, 1, 16, 12, True, 1), # more workgroups than CUs
+    (3, 32, 32, 3, 1, 64, 48, True, 1),     # branch 0: pixel-split waves (W4), one k-step (no refill), 8-row bands
+    (2, 48, 48, 3, 1, 24, 16, True, 1),     # W48 widths: three cout tiles, cin padded 48 -> 64
+    (2, 96, 96, 3, 1, 24, 18, True, 0),     # W48 branch 1: W2 with three cout tiles per wave
 ]
 
 
 @pytest.mark.parametrize("case", WREG_CASES)
-@pytest.mark.parametrize("variant", list(range(25, 31)))
+@pytest.mark.parametrize("variant", list(range(25, 37)))
 def test_conv_f16_wreg_vs_oracle_and_bit_identical_to_tile_kernel(case, variant):
     """The weights-in-registers kernel (LDS-DMA input tile, weight fragments streamed from global memory) against the oracle,
     and bit for bit against the one-tile kernel: same k order, same epilogue arithmetic."""
@@ -201,7 +204,7 @@ def test_conv_f16_wreg_rejects_what_it_does_not_cover():
         return LIB.mp_f16_conv2d_fwd(ctypes.byref(d), 25, _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), None, None, _lib.ptr(t), _lib.stream())
 
     assert rc(stride=2, conv_h=8, conv_w=6, out_h=8, out_w=6) != 0   # stride 2
-    assert rc(cin=32) != 0                                            # small K: the tile kernels' territory
+    assert rc(cin=32) != 0                                            # small K with all-pixels-per-wave: not offered
     assert rc(cout=64) != 0                                           # fewer cout tiles than 4 waves x 2
     assert rc(pad_top=0, pad_left=0, conv_h=14, conv_w=10, out_h=14, out_w=10) != 0  # not a "same" convolution
 

@@ -23,21 +23,30 @@ for cin, cout, h, w, k in SHAPES:
                       out_w=w, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=1, tap_dilation_unused=0)
     def args(v):
         return (ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(res), None, _lib.ptr(out), _lib.stream())
-    ok = [v for v in range(31) if lib.mp_f16_conv2d_fwd(*args(v)) == 0]
+    ok = [v for v in range(37) if lib.mp_f16_conv2d_fwd(*args(v)) == 0]
     torch.cuda.synchronize()
+    # one native launch plan per variant (40 back-to-back launches enqueued by ONE C call: no Python / ctypes cost per launch)
+    plans = {}
+    for v in ok:
+        h_ = ctypes.c_void_p(lib.mp_plan_create())
+        for _ in range(40):
+            _lib.check(lib.mp_plan_add_conv_f16(h_, ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(res), None,
+                                                _lib.ptr(out)), "plan add")
+        plans[v] = h_
     times = {v: [] for v in ok}
     for rnd in range(5):
         for v in ok:
-            a = args(v)
-            for _ in range(3): lib.mp_f16_conv2d_fwd(*a)
+            lib.mp_plan_run_range(plans[v], 0, 5, _lib.stream())
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(20): lib.mp_f16_conv2d_fwd(*a)
+            lib.mp_plan_run_range(plans[v], 0, 40, _lib.stream())
             e1.record(); e1.synchronize()
-            times[v].append(e0.elapsed_time(e1) / 20 * 1e3)
+            times[v].append(e0.elapsed_time(e1) / 40 * 1e3)
+    for h_ in plans.values():
+        lib.mp_plan_destroy(h_)
     med = {v: statistics.median(t) for v, t in times.items()}
     gf = 2 * nn * h * w * cout * cin * k * k / 1e9
     old = min((t, v) for v, t in med.items() if v < 25)
     new = min(((t, v) for v, t in med.items() if v >= 25), default=(float("nan"), -1))
-    print(f"{cin:3d}->{cout:3d} k{k} {h}x{w} N={nn}: best tile kernel v{old[1]} {old[0]:6.1f} us ({gf / old[0] / 1e3:6.1f} TF) | best wreg v{new[1]} {new[0]:6.1f} us "
-          f"({gf / new[0] / 1e3:6.1f} TF) | all: " + " ".join(f"v{v}:{t:.1f}" for v, t in sorted(med.items())), flush=True)
+    print(f"{cin:3d}->{cout:3d} k{k} {h}x{w} N={nn}: best tile kernel v{old[1]} {old[0]:6.1f} us ({gf / old[0] * 1e-3:6.1f} TF) | best wreg v{new[1]} {new[0]:6.1f} us "
+          f"({gf / new[0] * 1e-3:6.1f} TF) | all: " + " ".join(f"v{v}:{t:.1f}" for v, t in sorted(med.items())), flush=True)
