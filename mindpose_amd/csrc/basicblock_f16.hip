@@ -295,6 +295,8 @@ int blockf16_build(const void* x, const void* w1, const float* scale1, const flo
     if (c <= 24 || c > 32) return MP_ERR_UNSUPPORTED;  // exactly four 8-channel blocks (channels beyond c are zero padding)
     if (rows < 0) return MP_ERR_SHAPE;
     if (x == out) return MP_ERR_UNSUPPORTED;  // neighbouring tiles read the halo rows this tile would overwrite
+    if (blockf16_v2_build(x, w1, scale1, shift1, w2, scale2, shift2, out, n, c, h, w, rows, L)) return MP_OK;
+    if (rows > 6) return MP_ERR_UNSUPPORTED;
     BlockF16Params p{};
     p.x = x; p.w1 = w1; p.w2 = w2; p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2; p.out = out;
     p.N = n; p.H = h; p.W = w;
@@ -339,6 +341,7 @@ int blockf16_build(const void* x, const void* w1, const float* scale1, const flo
 }
 
 int blockf16_launch(const BlockF16Launch& L, hipStream_t s) {
+    if (L.small == 2) return blockf16_v2_launch(L, s);
     return L.small ? launch_block<5, 3>(L.p, L.lds_bytes, s) : launch_block<6, 5>(L.p, L.lds_bytes, s);
 }
 

@@ -81,7 +81,8 @@ struct BlockF16Params {
     int M1, M2;                      // intermediate / output pixels of a tile
     int in_units;                    // staged 16-byte units of the input tile (4 planes x (R+4) rows x W)
     int tiles_y, tiles_total, tiles_per_wg, total_blocks, ni_used;
-    unsigned magic_w, magic_rw;      // / W, / ((R+4) * W)
+    unsigned magic_w, magic_rw;      // / W, / ((R+4) * W)   (second structure: / (W + 1), / plane_in)
+    unsigned magic_wo;               // second structure: / W
 };
 
 struct BlockF16Launch {
@@ -92,6 +93,10 @@ struct BlockF16Launch {
 int blockf16_build(const void* x, const void* w1, const float* scale1, const float* shift1, const void* w2, const float* scale2,
                    const float* shift2, void* out, int n, int c, int h, int w, int rows, BlockF16Launch& L);
 int blockf16_launch(const BlockF16Launch& L, hipStream_t s);
+// second structure (basicblock_f16_v2.hip): weights in registers, LDS-DMA bands, 512-thread workgroups; L.small == 2 marks it
+bool blockf16_v2_build(const void* x, const void* w1, const float* scale1, const float* shift1, const void* w2, const float* scale2,
+                       const float* shift2, void* out, int n, int c, int h, int w, int rows, BlockF16Launch& L);
+int blockf16_v2_launch(const BlockF16Launch& L, hipStream_t s);
 
 int f16_build_launch(const mp_conv_desc* desc, int variant, const void* x, const void* w, const float* scale,
                      const float* shift, const void* res1, const void* res2, void* out, ConvF16Launch& L);

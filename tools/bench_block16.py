@@ -43,6 +43,10 @@ for n in [int(a) for a in sys.argv[1:]] or [8, 32, 128, 256]:
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3 / 50
 
-    res = {f"two v{v}": timeit(two, v) for v in (0, 5, 10)}
-    res.update({f"fused R{r}": timeit(fused, r) for r in (6, 5, 4, 3)})
+    import os
+    res = {f"two v{v}": timeit(two, v) for v in (10,)}
+    os.environ["MP_F16_BLOCK_V2"] = "0"
+    res.update({f"v1 R{r}": timeit(fused, r) for r in (6, 5)})
+    os.environ["MP_F16_BLOCK_V2"] = "1"
+    res.update({f"v2 R{r}": timeit(fused, r) for r in (8, 6, 4)})
     print(f"N={n:4d} us: " + "  ".join(f"{k} {v:6.1f}" for k, v in res.items()), flush=True)
