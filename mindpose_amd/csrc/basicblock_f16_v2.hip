@@ -194,7 +194,12 @@ __global__ __launch_bounds__(512, 2) void basicblock_f16_v2_kernel(const BlockF1
                 lds_mid[slot] = (u32x4){lo.x, lo.y, hi.x, hi.y};
             }
         }
-        __syncthreads();  // the intermediate tile is complete (and, through the fence, the next band's DMA has landed)
+        // the intermediate tile is complete.  A raw barrier behind an LDS-only wait: __syncthreads() would drain vmcnt and with it
+        // the next band's DMA, which then has only conv1 to hide under - all CUs burst their bands at once, a band takes longer
+        // to arrive than conv1 runs (the first version of this kernel waited here: 23 us per block)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
 
         // ---- conv2 + bn2 + identity + relu over the R output rows -> HBM
         if (wave_has2) {
@@ -222,7 +227,17 @@ __global__ __launch_bounds__(512, 2) void basicblock_f16_v2_kernel(const BlockF1
                 __builtin_amdgcn_raw_buffer_store_b128((u32x4){lo.x, lo.y, hi.x, hi.y}, rs_o, off, 0, 0);
             }
         }
-        __syncthreads();  // both tiles are free: the next band may overwrite the intermediate, the band after it this input buffer
+        // both tiles are free (the next band may overwrite the intermediate, the band after it this input buffer) and the next
+        // band's rows have landed: the DMA pieces are OLDER than this band's PS2 stores, so all but the PS2 youngest operations
+        // are waited for - the stores themselves drain under the next band
+        if (wave_has2) {
+            __builtin_amdgcn_s_waitcnt(0x0F70 | PS2);  // vmcnt(PS2), expcnt / lgkmcnt not waited
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     }
 }
 

@@ -720,7 +720,7 @@ int f16_build_launch(const mp_conv_desc* desc, int variant, const void* x, const
     if ((size_t)desc->n * ((desc->cout + 7) / 8) * desc->out_h * desc->out_w * 16 >= 0x60000000u) return MP_ERR_UNSUPPORTED;
     bool ok = false;
     if (variant >= 0) {
-        if (f16_variant_wreg(variant) && res2) return MP_ERR_UNSUPPORTED;  // one residual tensor in that kernel
+        if (f16_variant_wreg(variant) && res2 && desc->stride != 2) return MP_ERR_UNSUPPORTED;  // second residual: stride-2 builds only
         ok = f16_configure(*desc, variant, L);
     } else {
         // heuristic: widest cout tile that divides the padded couts, 192-pixel tiles unless the grid would not fill the chip

@@ -28,10 +28,11 @@ namespace {
 // a quarter of the couts) streams each weight byte once per workgroup - the shape for the 128 - 384-channel layers whose weight
 // stream is what the vector-memory path carries; with fewer couts (64 / 32-channel layers) the pixel split keeps two cout tiles
 // per wave, i.e. half the LDS reads per MFMA, at the price of WAVES_P waves fetching the same (small) weight fragments.
-template <int KS, int PS, int CSW, int WAVES_P, int OCC>
+template <int KS, int S, int PS, int CSW, int WAVES_P, int OCC>
 __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Params p) {
     constexpr int T = KS * KS;
     constexpr int HALO = KS / 2;
+    constexpr bool RES2 = S == 2;  // the stride-2 layers are the exchange unit's down-sampling convs: running sum + identity
     constexpr int WAVES_C = 4 / WAVES_P;
     constexpr int CT = 16 * CSW * WAVES_C;  // couts per workgroup
     extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
@@ -53,6 +54,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
     const int n0 = tn * p.G, y0 = ty * p.R;
     const int HW = p.H * p.W;
     const int P = p.Wp;  // row pitch W + HALO
+    const int y_in0 = y0 * S - HALO;  // image row of the tile's first staged row
 
     // ---- weight operand: this wave's couts, straight from the packed weights [kq][T][4][Cout_pad16] x 16 B
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.wp, (size_t)(p.PK >> 2) * T * 4 * p.Cout_pad16 * 16);
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
     // ---- input tile: every 16-byte slot of the LDS image is written by LDS-DMA, data or (out of range) zero
     {
         const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x, (size_t)p.N * p.C8in * HW * 16);
-        const int total = p.PK * p.plane;  // multiple of 64
+        const int total = p.PK * p.plane;  // a last partial piece spills (zeros) into the 64-element slack behind the image
         const int img_slots = p.G * p.img_plane;
         for (int s0 = wave * 64; s0 < total; s0 += 256) {
             const unsigned s = (unsigned)(s0 + lane);
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
             const unsigned rr = rem - g * p.img_plane;
             const unsigned r = fastdiv(rr, P, p.magic_ncols);
             const int c = (int)(rr - r * P) - HALO;
-            const int yin = y0 - HALO + (int)r;
+            const int yin = y_in0 + (int)r;
             const bool ok = rem < (unsigned)img_slots && c >= 0 && yin >= 0 && yin < p.H && n0 + (int)g < p.N && pl < (unsigned)p.C8in;
             const unsigned off = ok ? ((((unsigned)(n0 + g) * p.C8in + pl) * HW + yin * p.W + c) * 16u) : kOob;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(lds_in + s0), 16, off, 0, 0, 0);
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
         const unsigned rem = pl - g * p.RWo;
         const unsigned y = fastdiv(rem, p.Wo, p.magic_wo);
         const unsigned xx = rem - y * p.Wo;
-        b_off[ps] = lq * p.plane + g * p.img_plane + y * P + xx;
+        b_off[ps] = lq * p.plane + g * p.img_plane + (y * S) * P + xx * S;
         const int yy = y0 + (int)y;
         const bool ok = in_tile && n0 + (int)g < p.N && yy < p.Ho;
         pix_off[ps] = ok ? (((unsigned)(n0 + g) * p.C8out * plane_o + (yy * p.out_mul + p.off_y) * p.out_w + xx * p.out_mul + p.off_x) * 16u) : kInv;
@@ -132,8 +134,8 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
     constexpr int NP = CSW / 2, NS = CSW - 2 * NP;
     const size_t o_bytes = (size_t)p.N * p.C8out * plane_o * 16;
     const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(p.out, o_bytes);
-    u32x4 r1p[NP ? NP : 1][PS];  // one residual tensor (the BasicBlock identity); launches with two go to the tile kernels
-    u32x2 r1s[PS];
+    u32x4 r1p[NP ? NP : 1][PS], r2p[(RES2 && NP) ? NP : 1][PS];  // second residual tensor: stride-2 builds only
+    u32x2 r1s[PS], r2s[PS];
 
     const int nq = p.PK >> 2;
     u32x4 bv[PS];
@@ -196,33 +198,45 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
 #pragma unroll
             for (int ps = 0; ps < PS; ++ps) r1s[ps] = __builtin_amdgcn_raw_buffer_load_b64(rs, co_off[CSW - 1] + pix_off[ps], 0, 0);
         }
+        if constexpr (RES2) {
+            const __amdgpu_buffer_rsrc_t rs2 = make_rsrc(p.res2 ? p.res2 : p.out, p.res2 ? o_bytes : 0);
+#pragma unroll
+            for (int j = 0; j < NP; ++j)
+#pragma unroll
+                for (int ps = 0; ps < PS; ++ps) r2p[j][ps] = __builtin_amdgcn_raw_buffer_load_b128(rs2, co_off[2 * j] + pix_off[ps], 0, 0);
+            if (NS) {
+#pragma unroll
+                for (int ps = 0; ps < PS; ++ps) r2s[ps] = __builtin_amdgcn_raw_buffer_load_b64(rs2, co_off[CSW - 1] + pix_off[ps], 0, 0);
+            }
+        }
     }
     kstep(nq - 1, std::false_type{});
 
     // ---- epilogue: scale/shift, residuals, ReLU, one rounding, 16-byte stores per cout-tile pair
-    const bool has1 = p.res1 != nullptr;
+    const bool has1 = p.res1 != nullptr, has2 = RES2 && p.res2 != nullptr;
     const u32x2 none = (u32x2){0u, 0u};
 #pragma unroll
     for (int j = 0; j < NP; ++j)
 #pragma unroll
         for (int ps = 0; ps < PS; ++ps) {
             const u32x4 a1 = has1 ? r1p[j][ps] : (u32x4){0u, 0u, 0u, 0u};
-            const u32x2 lo = f16_pack4(f16_epi4(acc[ps][2 * j], sc[2 * j], sh[2 * j], has1, (u32x2){a1.x, a1.y}, false, none, p.relu));
-            const u32x2 hi = f16_pack4(f16_epi4(acc[ps][2 * j + 1], sc[2 * j + 1], sh[2 * j + 1], has1, (u32x2){a1.z, a1.w}, false, none, p.relu));
+            const u32x4 a2 = has2 ? r2p[j][ps] : (u32x4){0u, 0u, 0u, 0u};
+            const u32x2 lo = f16_pack4(f16_epi4(acc[ps][2 * j], sc[2 * j], sh[2 * j], has1, (u32x2){a1.x, a1.y}, has2, (u32x2){a2.x, a2.y}, p.relu));
+            const u32x2 hi = f16_pack4(f16_epi4(acc[ps][2 * j + 1], sc[2 * j + 1], sh[2 * j + 1], has1, (u32x2){a1.z, a1.w}, has2, (u32x2){a2.z, a2.w}, p.relu));
             __builtin_amdgcn_raw_buffer_store_b128((u32x4){lo.x, lo.y, hi.x, hi.y}, rs_o, co_off[2 * j] + pix_off[ps], 0, 0);
         }
     if (NS) {
 #pragma unroll
         for (int ps = 0; ps < PS; ++ps) {
-            const u32x2 o = f16_pack4(f16_epi4(acc[ps][CSW - 1], sc[CSW - 1], sh[CSW - 1], has1, has1 ? r1s[ps] : none, false, none, p.relu));
+            const u32x2 o = f16_pack4(f16_epi4(acc[ps][CSW - 1], sc[CSW - 1], sh[CSW - 1], has1, has1 ? r1s[ps] : none, has2, has2 ? r2s[ps] : none, p.relu));
             __builtin_amdgcn_raw_buffer_store_b64(o, rs_o, co_off[CSW - 1] + pix_off[ps], 0, 0);
         }
     }
 }
 
-template <int KS, int PS, int CSW, int WAVES_P, int OCC>
+template <int KS, int S, int PS, int CSW, int WAVES_P, int OCC>
 int launch_wreg(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
-    auto kern = conv_f16_wreg_kernel<KS, PS, CSW, WAVES_P, OCC>;
+    auto kern = conv_f16_wreg_kernel<KS, S, PS, CSW, WAVES_P, OCC>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -233,21 +247,21 @@ int launch_wreg(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
     return check_launch();
 }
 
-template <int KS>
+template <int KS, int S>
 int launch_wreg_ks(const ConvF16Params& p, int variant, size_t lds_bytes, hipStream_t s) {
     switch (variant) {
-        case F_WREG_P6C2: return launch_wreg<KS, 6, 2, 1, 1>(p, lds_bytes, s);
-        case F_WREG_P3C2: return launch_wreg<KS, 3, 2, 1, 2>(p, lds_bytes, s);
-        case F_WREG_P6C1: return launch_wreg<KS, 6, 1, 1, 2>(p, lds_bytes, s);
-        case F_WREG_P6C3: return launch_wreg<KS, 6, 3, 1, 1>(p, lds_bytes, s);
-        case F_WREG_P3C3: return launch_wreg<KS, 3, 3, 1, 1>(p, lds_bytes, s);
-        case F_WREG_P3C4: return launch_wreg<KS, 3, 4, 1, 1>(p, lds_bytes, s);
-        case F_WREG_P6C2_W2: return launch_wreg<KS, 6, 2, 2, 2>(p, lds_bytes, s);
-        case F_WREG_P6C3_W2: return launch_wreg<KS, 6, 3, 2, 1>(p, lds_bytes, s);
-        case F_WREG_P3C2_W2: return launch_wreg<KS, 3, 2, 2, 2>(p, lds_bytes, s);
-        case F_WREG_P6C2_W4: return launch_wreg<KS, 6, 2, 4, 2>(p, lds_bytes, s);
-        case F_WREG_P6C3_W4: return launch_wreg<KS, 6, 3, 4, 1>(p, lds_bytes, s);
-        case F_WREG_P3C2_W4: return launch_wreg<KS, 3, 2, 4, 2>(p, lds_bytes, s);
+        case F_WREG_P6C2: return launch_wreg<KS, S, 6, 2, 1, 1>(p, lds_bytes, s);
+        case F_WREG_P3C2: return launch_wreg<KS, S, 3, 2, 1, 2>(p, lds_bytes, s);
+        case F_WREG_P6C1: return launch_wreg<KS, S, 6, 1, 1, 2>(p, lds_bytes, s);
+        case F_WREG_P6C3: return launch_wreg<KS, S, 6, 3, 1, 1>(p, lds_bytes, s);
+        case F_WREG_P3C3: return launch_wreg<KS, S, 3, 3, 1, 1>(p, lds_bytes, s);
+        case F_WREG_P3C4: return launch_wreg<KS, S, 3, 4, 1, 1>(p, lds_bytes, s);
+        case F_WREG_P6C2_W2: return launch_wreg<KS, S, 6, 2, 2, 2>(p, lds_bytes, s);
+        case F_WREG_P6C3_W2: return launch_wreg<KS, S, 6, 3, 2, 1>(p, lds_bytes, s);
+        case F_WREG_P3C2_W2: return launch_wreg<KS, S, 3, 2, 2, 2>(p, lds_bytes, s);
+        case F_WREG_P6C2_W4: return launch_wreg<KS, S, 6, 2, 4, 2>(p, lds_bytes, s);
+        case F_WREG_P6C3_W4: return launch_wreg<KS, S, 6, 3, 4, 1>(p, lds_bytes, s);
+        case F_WREG_P3C2_W4: return launch_wreg<KS, S, 3, 2, 4, 2>(p, lds_bytes, s);
         default: return MP_ERR_UNSUPPORTED;
     }
 }
@@ -263,13 +277,14 @@ void f16_wreg_dims(int v, int& ps, int& csw, int& waves_p) {
     waves_p = wps[v - F_WREG_P6C2];
 }
 
-// geometry: stride-1 "same" convolutions (3x3 pad 1, 1x1 pad 0) whose output rows tile the pixel tile
+// geometry: 3x3 pad 1 (stride 1 or 2) and 1x1 pad 0 convolutions whose output rows tile the pixel tile
 bool f16_configure_wreg(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
     int PS, CSW, WP;
     f16_wreg_dims(variant, PS, CSW, WP);
-    const int KS = d.kh, halo = KS / 2, T = KS * KS;
-    if (d.stride != 1 || !(KS == 3 || KS == 1)) return false;
-    if (d.pad_top != halo || d.pad_left != halo || d.conv_h != d.h || d.conv_w != d.w) return false;
+    const int KS = d.kh, S = d.stride, halo = KS / 2, T = KS * KS;
+    if (!((KS == 3 && (S == 1 || S == 2)) || (KS == 1 && S == 1))) return false;
+    if (d.pad_top != halo || d.pad_left != halo) return false;
+    if (d.conv_h != (d.h + 2 * halo - KS) / S + 1 || d.conv_w != (d.w + 2 * halo - KS) / S + 1) return false;
     ConvF16Params& p = L.p;
     const int WC = 4 / WP;
     const int PT = 16 * PS * WP, CT = 16 * CSW * WC;
@@ -298,10 +313,11 @@ bool f16_configure_wreg(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
     }
     p.RWo = p.R * p.Wo;
     if (p.G * p.RWo * 10 < PT * 7) return false;  // more than 30 % padding lanes: another tile shape fits better
-    p.Rin = p.R + 2 * halo;
+    p.Rin = (p.R - 1) * S + KS;
     p.Wp = p.W + halo;  // row pitch: one shared zero column
     p.img_plane = p.Rin * p.Wp;
-    p.plane = round_up(p.G * p.img_plane + halo, 16);
+    // plane stride: == 0 (mod 16) for stride 1, odd for stride 2 (lanes then read every other element): conflict-free ds_read_b128
+    p.plane = S == 1 ? round_up(p.G * p.img_plane + halo, 16) : ((p.G * p.img_plane + halo) | 1);
     p.ncols = p.W;
     p.upc = 0;
     p.in_buf = p.PK * p.plane;
@@ -320,15 +336,15 @@ bool f16_configure_wreg(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
     p.magic_wo = magic_of(p.Wo);
     p.total_blocks = p.n_ct * p.tiles_y * p.tiles_n;
     p.ni_used = p.nw_used = 0;
-    L.ks = KS; L.stride = 1; L.variant = variant;
-    L.lds_bytes = (size_t)p.in_buf * 16;
+    L.ks = KS; L.stride = S; L.variant = variant;
+    L.lds_bytes = ((size_t)p.in_buf + 64) * 16;  // + one DMA piece of slack: the last piece may run past an odd-sized image
     (void)T;
     return L.lds_bytes <= (size_t)150 * 1024;
 }
 
 int f16_wreg_launch(const ConvF16Launch& L, hipStream_t s) {
-    if (L.ks == 3) return launch_wreg_ks<3>(L.p, L.variant, L.lds_bytes, s);
-    if (L.ks == 1) return launch_wreg_ks<1>(L.p, L.variant, L.lds_bytes, s);
+    if (L.ks == 3) return L.stride == 1 ? launch_wreg_ks<3, 1>(L.p, L.variant, L.lds_bytes, s) : launch_wreg_ks<3, 2>(L.p, L.variant, L.lds_bytes, s);
+    if (L.ks == 1 && L.stride == 1) return launch_wreg_ks<1, 1>(L.p, L.variant, L.lds_bytes, s);
     return MP_ERR_UNSUPPORTED;
 }
 

@@ -395,3 +395,56 @@ def test_fused_basicblock_rejects_other_widths():
     assert LIB.mp_f16_basicblock_fwd(_lib.ptr(xa), *args, _lib.ptr(two), 1, 64, 8, 8, 0, _lib.stream()) == -3  # MP_ERR_UNSUPPORTED
     assert LIB.mp_f16_basicblock_fwd(_lib.ptr(xa), *args, _lib.ptr(xa), 1, 32, 8, 8, 0, _lib.stream()) == -3  # MP_ERR_UNSUPPORTED
     assert LIB.mp_f16_basicblock_fwd(None, *args, _lib.ptr(two), 1, 32, 8, 8, 0, _lib.stream()) == -1  # MP_ERR_NULL
+
+
+WREG_S2_CASES = [
+    # n, cin, cout, h, w, n_res - 3x3 stride-2 pad-1 convs of the transition / exchange-unit layers (conv_f16_wreg.hip, S = 2)
+    (3, 32, 64, 64, 48, 2),     # fuse down-sampling conv with running sum + identity
+    (3, 64, 128, 32, 24, 1),
+    (5, 128, 256, 16, 12, 0),   # two images per tile, odd batch
+    (2, 32, 32, 64, 48, 0),
+    (2, 64, 64, 30, 22, 2),     # ragged: odd output extents after the stride
+    (2, 96, 192, 24, 18, 1),    # W48 widths
+    (2, 256, 64, 17, 13, 0),    # odd input extents: the last tap column reads the shared zero slot
+]
+
+
+@pytest.mark.parametrize("case", WREG_S2_CASES)
+@pytest.mark.parametrize("variant", list(range(25, 37)))
+def test_conv_f16_wreg_stride2_bit_identical_to_tile_kernel(case, variant):
+    n, cin, cout, h, w, n_res = case
+    g = torch.Generator().manual_seed(sum(case))
+    ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    res = [_to_c8(torch.randn(n, cout, ho, wo, generator=g)) for _ in range(n_res)] + [None, None]
+    xa = _to_c8(x)
+    nb = LIB.mp_f16_packed_weight_bytes(cout, cin, 3, 3)
+    packed = torch.empty(nb // 2, device=DEV, dtype=torch.float16)
+    _lib.check(LIB.mp_f16_pack_weight(_lib.ptr(wt.to(DEV)), _lib.ptr(packed), cout, cin, 3, 3, 0, 0, 0, _lib.stream()), "pack")
+    padc = (-cout) % 16
+    sc, sh = torch.cat([scale, torch.zeros(padc)]).to(DEV), torch.cat([shift, torch.zeros(padc)]).to(DEV)
+    d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=3, kw=3, stride=2, pad_top=1, pad_left=1, conv_h=ho, conv_w=wo, out_h=ho,
+                      out_w=wo, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=1, tap_dilation_unused=0)
+
+    def run(v):
+        out = ActC8(n, cout, ho, wo, DEV)
+        out.c8_tensor.fill_(float("nan"))
+        rc = LIB.mp_f16_conv2d_fwd(ctypes.byref(d), v, _lib.ptr(xa), _lib.ptr(packed), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(res[0]),
+                                   _lib.ptr(res[1]), _lib.ptr(out), _lib.stream())
+        return rc, out
+
+    rc, out = run(variant)
+    if rc != 0:
+        pytest.skip("tile variant not available for this shape")
+    rc0, base = run(-1)
+    _lib.check(rc0, "mp_f16_conv2d_fwd")
+    assert torch.equal(out.c8_tensor, base.c8_tensor)
+    ref = F.conv2d(_h(x), _h(wt), None, stride=2, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    for r in res[:n_res]:
+        ref = ref + _from_c8(r)
+    ref = _h(F.relu(ref))
+    got = _from_c8(out)
+    tol = ref.abs() * 2.0 ** -9 + 1e-4 * ref.abs().max()
+    assert not ((got - ref).abs() > tol).any(), float((got - ref).abs().max())
