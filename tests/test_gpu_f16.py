@@ -203,7 +203,7 @@ def test_conv_f16_wreg_rejects_what_it_does_not_cover():
         d = _lib.ConvDesc(**base)
         return LIB.mp_f16_conv2d_fwd(ctypes.byref(d), 25, _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), None, None, _lib.ptr(t), _lib.stream())
 
-    assert rc(stride=2, conv_h=8, conv_w=6, out_h=8, out_w=6) != 0   # stride 2
+    assert rc(kh=1, kw=1, pad_top=0, pad_left=0, stride=2, conv_h=8, conv_w=6, out_h=8, out_w=6) != 0   # 1x1 stride 2
     assert rc(cin=32) != 0                                            # small K with all-pixels-per-wave: not offered
     assert rc(cout=64) != 0                                           # fewer cout tiles than 4 waves x 2
     assert rc(pad_top=0, pad_left=0, conv_h=14, conv_w=10, out_h=14, out_w=10) != 0  # not a "same" convolution
