@@ -99,9 +99,10 @@ def test_o2_training_step_vs_oracle_amp_emulation():
     outputs, fp32 accumulation / statistics) - and, as the yardstick for how far two fp16 roundings of the same graph may sit
     apart, against the oracle's fp32 gradients: the HIP path must be at least as close to fp32 as the emulation is (x1.5)."""
     net = mp.init_synthetic(mp.create_network("hrnet_w32", "hrnet_head"), seed=0)
+    cpu_state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}  # before the network moves to the GPU
 
     def leaf_params():
-        d = {k: v.clone() for k, v in net.state_dict().items()}
+        d = {k: v.clone() for k, v in cpu_state.items()}
         for k, v in d.items():
             if v.dtype.is_floating_point and not k.endswith(("moving_mean", "moving_variance")):
                 v.requires_grad_()

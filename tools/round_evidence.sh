@@ -1,14 +1,17 @@
 #!/bin/bash
-# all round-end evidence in one GPU call
+# all round-2 evidence in one GPU call (gpurun_out/r02_*; copy what should be judged into profiles/)
+#   bash tools/round_evidence.sh
 set -e
-bash tools/profile_round.sh r01_e 2>&1 | tail -12
-bash tools/profile_round.sh r01_f_o2 --amp O2 2>&1 | tail -12
-export MINDPOSE_TUNE_CACHE=gpurun_out/r01_g_tune.json
-python3 bench.py --workload hrnet_w48_384_udp_flip --batch 64 --amp O2 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r01_g_config5_o2_bench.json 2> gpurun_out/r01_g.err
-python3 bench.py --workload hrnet_w32_train --batch 128 --steps 3 --warmup 2 > gpurun_out/r01_h_train_bench.json 2> gpurun_out/r01_h.err
-python3 bench.py --workload hrnet_w32_train --batch 128 --amp O2 --steps 10 --warmup 3 > gpurun_out/r01_i_train_o2_bench.json 2> gpurun_out/r01_i.err
-python3 bench.py --workload simplebaseline_r50_train --batch 128 --steps 3 --warmup 2 > gpurun_out/r01_j_sb_train_bench.json 2> gpurun_out/r01_j0.err
-python3 bench.py --workload simplebaseline_r50_train --batch 128 --amp O2 --steps 10 --warmup 3 > gpurun_out/r01_j_sb_train_o2_bench.json 2> gpurun_out/r01_j.err
-python3 bench.py --workload simplebaseline_r50 --batch 64 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r01_k_simplebaseline_bench.json 2> gpurun_out/r01_k.err
-python3 bench.py --workload simplebaseline_r50 --batch 64 --amp O2 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r01_k_simplebaseline_o2_bench.json 2> gpurun_out/r01_k2.err
-tail -c 400 gpurun_out/r01_g_config5_o2_bench.json; echo; tail -c 300 gpurun_out/r01_h_train_bench.json
+out=gpurun_out
+mkdir -p $out
+# the bench line as the driver runs it (headline + cpu_baseline + extra_workloads)
+python3 bench.py > $out/r02_a_bench_full.json 2> $out/r02_a_bench_full.err
+tail -c 300 $out/r02_a_bench_full.json; echo
+# rocprofv3 / PMC evidence; --no-extra: a profiled process must not start child processes (the profiler's preload has already
+# initialised the GPU when the program starts)
+bash tools/profile_round.sh r02_a --no-extra 2>&1 | tail -12
+bash tools/profile_round.sh r02_b_o2 --amp O2 --no-extra 2>&1 | tail -12
+bash tools/profile_train.sh r02_c_train_o2 --amp O2 --batch 128 --steps 5 --warmup 2 --leg 2>&1 | tail -14
+export MINDPOSE_TUNE_CACHE=$out/r02_c_train_o2_tune.json
+python3 bench.py --workload hrnet_w32_train --amp O2 --batch 128 --steps 10 --warmup 3 --leg > $out/r02_c_train_o2_bench.json 2> $out/r02_c.err
+tail -c 300 $out/r02_c_train_o2_bench.json; echo
