@@ -74,7 +74,7 @@ def kernel_name(info):
         if v >= 25:  # weights-in-registers kernel <KS, pixel tiles, cout tiles per wave, waves/SIMD bound>
             ps, csw, wp, occ = {25: (6, 2, 1, 1), 26: (3, 2, 1, 2), 27: (6, 1, 1, 2), 28: (6, 3, 1, 1), 29: (3, 3, 1, 1), 30: (3, 4, 1, 1),
                                 31: (6, 2, 2, 2), 32: (6, 3, 2, 1), 33: (3, 2, 2, 2), 34: (6, 2, 4, 2), 35: (6, 3, 4, 1), 36: (3, 2, 4, 2)}[v]
-            return f"conv_f16_wreg_kernel<{info['ks']},{ps},{csw},{wp},{occ}>"
+            return f"conv_f16_wreg_kernel<{info['ks']},{info['stride']},{ps},{csw},{wp},{occ}>"  # = the rocprof template list
         if v == 24:  # 32 couts x 384 pixels, single-chunk build
             return f"conv_f16_kernel<{info['ks']},{info['stride']},6,2,4,1>"
         if v >= 20:  # 16-cout tiles: regular, light, multi-tile (2 / 1 workgroups per CU)

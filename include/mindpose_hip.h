@@ -369,6 +369,10 @@ int mp_warp_affine(const uint8_t* src_dev, const long long* src_offsets_dev, con
                    const double* trans_dev, void* out_dev, int n, int out_h, int out_w, int normalize, const float mean[3], const float stddev[3],
                    mp_stream_t stream);
 
+/* Horizontal flip of an NCHW fp32 batch, out[n,c,y,x] = in[n,c,y,W-1-x]: the input of the flip test's second run
+ * (mindpose/engine/inferencer/topdown_inferencer.py:168-170), one pass; in and out must not overlap. */
+int mp_flip_width(const float* in_dev, float* out_dev, int n, int c, int h, int w, mp_stream_t stream);
+
 /* fp16 (amp O2) training passes over channel-blocked fp16 activations; same contracts as mp_bn_train_fwd / _bwd and
  * mp_fuse_upsample_sum_bwd (statistics, gamma / beta gradients and the workspace stay fp32 / fp64; mp_bn_workspace_bytes) */
 int mp_f16_bn_train_fwd(const void* z_dev, const float* gamma_dev, const float* beta_dev, const void* res_dev, void* y_dev,

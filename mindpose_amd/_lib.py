@@ -88,6 +88,7 @@ _PROTOTYPES = {
     "mp_f16_gather_phase": (c_int, [c_f32p] * 2 + [c_int] * 6 + [ctypes.c_void_p]),
     "mp_plan_set_lane": (c_int, [ctypes.c_void_p, c_int]),
     "mp_plan_add_barrier": (c_int, [ctypes.c_void_p]),
+    "mp_flip_width": (c_int, [c_f32p, c_f32p] + [c_int] * 4 + [ctypes.c_void_p]),
     "mp_warp_affine": (c_int, [c_f32p] * 6 + [c_int] * 4 + [ctypes.POINTER(ctypes.c_float)] * 2 + [ctypes.c_void_p]),
     # fp16 matrix-core inference path (channel-blocked activations)
     "mp_f16_packed_weight_bytes": (c_size_t, [c_int] * 4),

@@ -103,3 +103,43 @@ extern "C" int mp_warp_affine(const uint8_t* src, const long long* src_offsets, 
                            out_h, out_w, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f);
     return check_launch();
 }
+
+// ---- horizontal flip of an NCHW fp32 batch: the second run of the flip test (topdown_inferencer.py:168-170, ops.ReverseV2 on
+// the width axis).  out[n, c, y, x] = in[n, c, y, W - 1 - x]; one pass, written straight into the network's input buffer (the
+// host mirror used torch.flip + a copy: two passes through PyTorch kernels).  in and out must not overlap.
+namespace mp {
+namespace {
+__global__ __launch_bounds__(256) void flip_width_kernel(const float* __restrict__ in, float* __restrict__ out, size_t rows, int w) {
+    // one thread per output element quad where W % 4 == 0 (16-byte stores, reversed 16-byte loads), else per element
+    const size_t total = rows * (size_t)w;
+    if ((w & 3) == 0) {
+        const size_t quads = total >> 2;
+        const int wq = w >> 2;
+        for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (size_t)gridDim.x * blockDim.x) {
+            const size_t row = q / wq;
+            const int xq = (int)(q - row * wq);
+            const float4 v = *reinterpret_cast<const float4*>(in + row * w + (size_t)(wq - 1 - xq) * 4);
+            *reinterpret_cast<float4*>(out + q * 4) = make_float4(v.w, v.z, v.y, v.x);
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+            const size_t row = i / w;
+            const int x = (int)(i - row * w);
+            out[i] = in[row * w + (w - 1 - x)];
+        }
+    }
+}
+}  // namespace
+}  // namespace mp
+
+extern "C" int mp_flip_width(const float* in, float* out, int n, int c, int h, int w, mp_stream_t stream) {
+    if (!in || !out) return MP_ERR_NULL;
+    if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return MP_ERR_SHAPE;
+    if (in == out) return MP_ERR_UNSUPPORTED;
+    const size_t rows = (size_t)n * c * h;
+    const size_t work = (w & 3) == 0 ? rows * (size_t)w / 4 : rows * (size_t)w;
+    size_t blocks = (work + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(mp::flip_width_kernel, dim3((unsigned)blocks), dim3(256), 0, mp::as_stream(stream), in, out, rows, w);
+    return mp::check_launch();
+}

@@ -295,41 +295,47 @@ __global__ __launch_bounds__(256) void bn16_reduce_kernel(const u32x4_t* __restr
         mu[j] = (BWD && ch < c) ? mean[ch] : 0.f;
         is[j] = (BWD && ch < c) ? invstd[ch] : 0.f;
     }
+    // The block's elements are {images ig, ig + gi, ...} x {pixels p0 .. p1}: walked as ONE flat index space (the small maps give a
+    // block only 1-2 elements per thread and image; an image loop around a pixel loop kept a single load in flight per thread and
+    // made these passes latency-bound), 32-bit index arithmetic with a multiply-high division by the chunk length.
     double acc[16];
+    float f[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.0;
-    for (int img = ig; img < n; img += gi) {
-        const size_t base = ((size_t)img * c8 + blk) * hw;
-        float f[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) f[j] = 0.f;
+    for (int j = 0; j < 16; ++j) f[j] = 0.f;
+    const unsigned len = (unsigned)(p1 > p0 ? p1 - p0 : 0);
+    const unsigned nimg = ig < n ? (unsigned)((n - ig + gi - 1) / gi) : 0u;
+    const unsigned cnt = len * nimg;
+    const unsigned magic = len > 1 ? (unsigned)(0x100000000ULL / len) + 1u : 0u;
+    const bool exact = (unsigned long long)cnt * len < 0x100000000ULL;  // multiply-high division exact on [0, cnt)
+    const size_t img_stride = (size_t)c8 * hw;
 #pragma unroll 4
-        for (int i = p0 + threadIdx.x; i < p1; i += 256) {
-            const h16x8 zv = __builtin_bit_cast(h16x8, z[base + i]);
-            if (BWD) {
-                const h16x8 gv = __builtin_bit_cast(h16x8, a_in[base + i]);
-                h16x8 yv = zv;
-                if (relu) yv = __builtin_bit_cast(h16x8, y[base + i]);
+    for (unsigned e = threadIdx.x; e < cnt; e += 256) {
+        const unsigned a = len <= 1 ? e : (exact ? __umulhi(e, magic) : e / len);
+        const size_t i = ((size_t)(ig + a * gi)) * img_stride + (size_t)blk * hw + p0 + (e - a * len);
+        const h16x8 zv = __builtin_bit_cast(h16x8, z[i]);
+        if (BWD) {
+            const h16x8 gv = __builtin_bit_cast(h16x8, a_in[i]);
+            h16x8 yv = zv;
+            if (relu) yv = __builtin_bit_cast(h16x8, y[i]);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float g = (float)gv[j];
-                    if (relu && !((float)yv[j] > 0.f)) g = 0.f;
-                    const float xh = ((float)zv[j] - mu[j]) * is[j];
-                    f[2 * j] += g;
-                    f[2 * j + 1] += g * xh;
-                }
-            } else {
+            for (int j = 0; j < 8; ++j) {
+                float g = (float)gv[j];
+                if (relu && !((float)yv[j] > 0.f)) g = 0.f;
+                const float xh = ((float)zv[j] - mu[j]) * is[j];
+                f[2 * j] += g;
+                f[2 * j + 1] += g * xh;
+            }
+        } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float v = (float)zv[j];
-                    f[2 * j] += v;
-                    f[2 * j + 1] += v * v;
-                }
+            for (int j = 0; j < 8; ++j) {
+                const float v = (float)zv[j];
+                f[2 * j] += v;
+                f[2 * j + 1] += v * v;
             }
         }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] += (double)f[j];
     }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = (double)f[j];
     __shared__ double sm[4][16];
     block_sum16_256(acc, sm);
     if (threadIdx.x < 16) {
@@ -347,9 +353,23 @@ __device__ __forceinline__ void bn16_channel_sums(const double* __restrict__ par
     s0 = 0.0;
     s1 = 0.0;
     if (ch < c) {
-        for (int sp = threadIdx.x & 31; sp < nsplit; sp += 32) {
-            s0 += part[((size_t)ch * nsplit + sp) * 2 + 0];
-            s1 += part[((size_t)ch * nsplit + sp) * 2 + 1];
+        // fixed trip count (kBn16MaxSplit / 32): all loads issue before the first add - the same sums in the same order as a
+        // `sp < nsplit` loop, without its chain of dependent L2 round trips at the head of every consumer block
+        double v0[kBn16MaxSplit / 32], v1[kBn16MaxSplit / 32];
+#pragma unroll
+        for (int k = 0; k < kBn16MaxSplit / 32; ++k) {
+            const int sp = (threadIdx.x & 31) + 32 * k;
+            const bool ok = sp < nsplit;
+            const double2 v = ok ? *reinterpret_cast<const double2*>(part + ((size_t)ch * nsplit + sp) * 2) : make_double2(0.0, 0.0);
+            v0[k] = v.x;
+            v1[k] = v.y;
+        }
+#pragma unroll
+        for (int k = 0; k < kBn16MaxSplit / 32; ++k) {
+            if ((threadIdx.x & 31) + 32 * k < nsplit) {
+                s0 += v0[k];
+                s1 += v1[k];
+            }
         }
     }
     for (int off = 16; off >= 1; off >>= 1) {  // xor tree inside each 32-lane half: every lane ends with the total
@@ -399,13 +419,18 @@ __global__ __launch_bounds__(256) void bn16_apply_kernel(const u32x4_t* __restri
     float sc[8], sh[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sc[j] = s_scale[j]; sh[j] = s_shift[j]; }
-    const size_t per_blk = (size_t)n * hw;
-    const size_t len = (per_blk + gridDim.y - 1) / gridDim.y;
-    const size_t e0 = (size_t)blockIdx.y * len, e1 = e0 + len < per_blk ? e0 + len : per_blk;
+    // elements of this channel block: (image, pixel) flat, 32-bit, image = multiply-high division by hw (64-bit divisions per
+    // element cost more than the element's memory traffic)
+    const unsigned per_blk = (unsigned)n * (unsigned)hw;
+    const unsigned len = (per_blk + gridDim.y - 1) / gridDim.y;
+    const unsigned e0 = blockIdx.y * len, e1 = e0 + len < per_blk ? e0 + len : per_blk;
+    const unsigned magic_hw = hw > 1 ? (unsigned)(0x100000000ULL / (unsigned)hw) + 1u : 0u;
+    const bool exact = (unsigned long long)per_blk * (unsigned)hw < 0x100000000ULL;
+    const size_t blk_off = (size_t)blk * hw, img_extra = (size_t)(c8 - 1) * hw;
 #pragma unroll 4
-    for (size_t e = e0 + threadIdx.x; e < e1; e += 256) {
-        const size_t img = e / hw;
-        const size_t i = (img * c8 + blk) * hw + (e - img * hw);
+    for (unsigned e = e0 + threadIdx.x; e < e1; e += 256) {
+        const unsigned img = hw <= 1 ? e : (exact ? __umulhi(e, magic_hw) : e / (unsigned)hw);
+        const size_t i = (size_t)e + (size_t)img * img_extra + blk_off;
         const h16x8 zv = __builtin_bit_cast(h16x8, z[i]);
         h16x8 rv = zv;
         if (res) rv = __builtin_bit_cast(h16x8, res[i]);
@@ -463,13 +488,16 @@ __global__ __launch_bounds__(256) void bn16_bwd_apply_kernel(const u32x4_t* __re
     float k[8], mu[8], is[8], mb[8], mg[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { k[j] = s_k[j]; mu[j] = s_mu[j]; is[j] = s_is[j]; mb[j] = s_mb[j]; mg[j] = s_mg[j]; }
-    const size_t per_blk = (size_t)n * hw;
-    const size_t len = (per_blk + gridDim.y - 1) / gridDim.y;
-    const size_t e0 = (size_t)blockIdx.y * len, e1 = e0 + len < per_blk ? e0 + len : per_blk;
+    const unsigned per_blk = (unsigned)n * (unsigned)hw;
+    const unsigned len = (per_blk + gridDim.y - 1) / gridDim.y;
+    const unsigned e0 = blockIdx.y * len, e1 = e0 + len < per_blk ? e0 + len : per_blk;
+    const unsigned magic_hw = hw > 1 ? (unsigned)(0x100000000ULL / (unsigned)hw) + 1u : 0u;
+    const bool exact = (unsigned long long)per_blk * (unsigned)hw < 0x100000000ULL;
+    const size_t blk_off = (size_t)blk * hw, img_extra = (size_t)(c8 - 1) * hw;
 #pragma unroll 4
-    for (size_t e = e0 + threadIdx.x; e < e1; e += 256) {
-        const size_t img = e / hw;
-        const size_t i = (img * c8 + blk) * hw + (e - img * hw);
+    for (unsigned e = e0 + threadIdx.x; e < e1; e += 256) {
+        const unsigned img = hw <= 1 ? e : (exact ? __umulhi(e, magic_hw) : e / (unsigned)hw);
+        const size_t i = (size_t)e + (size_t)img * img_extra + blk_off;
         const h16x8 gv = __builtin_bit_cast(h16x8, dy[i]);
         const h16x8 zv = __builtin_bit_cast(h16x8, z[i]);
         h16x8 yv = zv;

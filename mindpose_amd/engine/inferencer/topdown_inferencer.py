@@ -39,7 +39,10 @@ class _MultiRunNet(nn.Module):
                 score: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         raw_net = self.net.net  # EvalNet.net: backbone + head
         heatmap = raw_net(image).clone()  # the plan's output buffer is reused by the second run
-        flipped = raw_net(torch.flip(image, dims=[3]))
+        if hasattr(raw_net, "get_plan"):  # planned network: the mirror goes straight into its input buffer (mp_flip_width)
+            flipped = raw_net(image, flip_width=True)
+        else:
+            flipped = raw_net(torch.flip(image, dims=[3]))
         return self.decoder.decode_flip_aggregated(heatmap, flipped, self.flip_index, self.shift_heatmap,
                                                    center, scale, score)
 

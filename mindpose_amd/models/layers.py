@@ -515,13 +515,22 @@ class PlannedModule(nn.Module):
         device = device or next(self.parameters()).device
         return self.get_plan(shape, torch.device(device)).input
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, flip_width: bool = False) -> torch.Tensor:
+        """``flip_width``: run the network on the horizontally mirrored batch (the flip test's second run,
+        topdown_inferencer.py:168-170): the mirror is written straight into the plan's input buffer by ``mp_flip_width``."""
         x = _lib.require_cuda_f32(x, "input")
         if self.training:
+            if flip_width:
+                raise ValueError("flip_width is an inference-time option")
             self._plans.clear()  # parameters are about to change: packed weights of recorded plans go stale
             return self.train_forward(x)
         plan = self.get_plan(x.shape, x.device)
-        if x.data_ptr() != plan.input.data_ptr():
+        if flip_width:
+            if x.data_ptr() == plan.input.data_ptr():
+                x = x.clone()  # the caller wrote the batch into the plan's own input buffer: mirror from a copy
+            n, c, h, w = x.shape
+            _lib.check(plan.lib.mp_flip_width(_lib.ptr(x), _lib.ptr(plan.input), n, c, h, w, _lib.stream()), "mp_flip_width")
+        elif x.data_ptr() != plan.input.data_ptr():
             plan.input.copy_(x)
         plan.run()
         return plan.output

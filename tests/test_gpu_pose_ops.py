@@ -261,3 +261,15 @@ def test_dark_refine_intermediates_vs_oracle(case):
                                         boxes.data_ptr(), idx.data_ptr(), n, k, h, w, mp._lib.MP_REFINE_DARK, int(dec.use_udp), 0,
                                         float(dec.pixel_std), blur.data_ptr(), int(dec.kernel_size), mp._lib.stream()), "decode")
     assert torch.equal(preds2.nan_to_num(123.0), preds.nan_to_num(123.0))
+
+
+@pytest.mark.parametrize("shape", [(3, 3, 256, 192), (2, 3, 17, 13), (1, 5, 8, 4)])
+def test_flip_width_bit_exact(shape):
+    """mp_flip_width == ops.ReverseV2 on the width axis (topdown_inferencer.py:168-170), 16-byte and scalar paths."""
+    lib = mp._lib.load()
+    x = torch.randn(*shape, device=DEV)
+    out = torch.full_like(x, float("nan"))
+    n, c, h, w = shape
+    mp._lib.check(lib.mp_flip_width(x.data_ptr(), out.data_ptr(), n, c, h, w, mp._lib.stream()), "mp_flip_width")
+    assert torch.equal(out, torch.flip(x, dims=[3]))
+    assert lib.mp_flip_width(x.data_ptr(), x.data_ptr(), n, c, h, w, mp._lib.stream()) == -3  # in place: unsupported
