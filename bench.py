@@ -68,7 +68,7 @@ def kernel_name(info):
     """Template head <KS,S,PS,CS,WAVES_P,WAVES_C> of the instantiation; '/occ3' marks the light build (rocprof shows it as
     the trailing template argument OCC = 3)."""
     if info["kind_id"] == 8:  # fused fp16 BasicBlock: the <5,3> or <6,5> pixel-tile build ("variant" = 1 for the small one)
-        return {0: "basicblock_f16_kernel<6,5>", 1: "basicblock_f16_kernel<5,3>", 2: "basicblock_f16_v2_kernel<4,3>"}[info["variant"]]
+        return {0: "basicblock_f16_kernel<6,5>", 1: "basicblock_f16_kernel<5,3>", 2: "basicblock_f16_v2_kernel<8,4,3>", 3: "basicblock_f16_v2_kernel<4,5,3>"}[info["variant"]]
     if info["kind_id"] == 3:
         v = info["variant"]
         if v >= 25:  # weights-in-registers kernel <KS, pixel tiles, cout tiles per wave, waves/SIMD bound>

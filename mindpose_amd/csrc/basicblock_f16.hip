@@ -341,7 +341,7 @@ int blockf16_build(const void* x, const void* w1, const float* scale1, const flo
 }
 
 int blockf16_launch(const BlockF16Launch& L, hipStream_t s) {
-    if (L.small == 2) return blockf16_v2_launch(L, s);
+    if (L.small >= 2) return blockf16_v2_launch(L, s);
     return L.small ? launch_block<5, 3>(L.p, L.lds_bytes, s) : launch_block<6, 5>(L.p, L.lds_bytes, s);
 }
 

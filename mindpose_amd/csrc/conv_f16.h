@@ -83,6 +83,7 @@ struct BlockF16Params {
     int tiles_y, tiles_total, tiles_per_wg, total_blocks, ni_used;
     unsigned magic_w, magic_rw;      // / W, / ((R+4) * W)   (second structure: / (W + 1), / plane_in)
     unsigned magic_wo;               // second structure: / W
+    unsigned long long* dbg;         // diagnostic builds (-DMP_BLOCK_STAMPS=1) only: 16 x u64 per (workgroup, wave half)
 };
 
 struct BlockF16Launch {
