@@ -38,6 +38,10 @@ struct Wgrad16Params {
     int tiles_y, tiles, splits, tiles_per_split, ci_tiles;
     int nbuf;  // 2 = double-buffered tiles; 1 = one LDS buffer (wide stride-2 layers whose tiles do not fit twice)
     unsigned magic_wo, magic_w;
+    // LDS-DMA form (conv_wgrad_f16_dma_kernel): channel-block-major LDS images, element counts per 8-channel block
+    int xslots, zslots, pieces;  // == 4 (mod 16) each: the two blocks a 16-lane group reads land on disjoint banks
+    int x_pieces, z_base;        // DMA pieces of the input image; first element of the gradient image (a multiple of 64)
+    unsigned magic_xs, magic_zs, magic_p;
 };
 
 __device__ __forceinline__ s16x4 tr_read(const _Float16* p) {
@@ -188,6 +192,138 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16_kernel(const Wgrad16Par
     }
 }
 
+// ---- LDS-DMA form -----------------------------------------------------------------------------------------------------------
+// The kernel above stages both tiles global -> VGPR -> ds_write into a PIXEL-major LDS image (row = one position x 32 channels),
+// zero-fills its LDS first and pays a load / wait / write / barrier chain per tile; the layers of the deep branches give a
+// workgroup 1 - 4 tiles, so nothing hides that chain (28 - 40 us per layer for 7.25 GFLOP: the matrix pipe ~10 % busy).
+// Here the LDS images keep the HBM layout - [8-channel block][position] x 16 B - so a tile is a plain copy: LDS-DMA
+// (buffer_load ... lds), no staging registers, no ds_write, no zero fill (padding columns, rows outside the image and the K tail
+// arrive as zeros through the buffer range check).  ds_read_b64_tr_b16 takes PER-LANE addresses, so the transposing read works on
+// this image too: lane 4q+p of a 16-lane group points at position q, channels 4p .. 4p+3 = block (p >> 1), byte (p & 1) * 8.
+// Same position trick, same MFMA loop order, same slab layout as above: results are bit-identical.
+template <int KS, int S, int NP>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dma_kernel(const Wgrad16Params p) {
+    constexpr int T = KS * KS;
+    extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
+    // per buffer: [4][xslots] input image, padding up to a whole DMA piece, [4][zslots] gradient image, padding likewise
+    const int buf_units = p.pieces * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co_sub = wave & 1, ci_sub = wave >> 1;
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int co_tile = blockIdx.x / p.ci_tiles, ci_tile = blockIdx.x % p.ci_tiles;
+    const int t_begin = blockIdx.y * p.tiles_per_split;
+    const int t_end = min(t_begin + p.tiles_per_split, p.tiles);
+
+    const __amdgpu_buffer_rsrc_t rs_z = make_rsrc(p.dz, (size_t)p.N * p.C8out * p.Ho * p.Wo * 16);
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x, (size_t)p.N * p.C8in * p.H * p.W * 16);
+
+    // DMA piece descriptors, decoded once: piece = 64 consecutive slots of the buffer; slot -> (image kind, block, row, column)
+    unsigned piece_rel[NP];  // byte offset relative to the tile origin of its tensor; kOob = padding slot
+    int piece_row[NP];       // row within the tile, bit 30 set = gradient image
+    const int x_units = 4 * p.xslots, z_units = 4 * p.zslots;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int piece = wave + 4 * i;
+        piece_rel[i] = kOob;
+        piece_row[i] = 0;
+        if (piece >= p.pieces) continue;  // wave-uniform
+        if (piece < p.x_pieces) {
+            const int s = piece * 64 + lane;
+            const unsigned blk = fastdiv((unsigned)s, p.xslots, p.magic_xs);
+            const unsigned rem = s - blk * p.xslots;
+            const unsigned r = fastdiv(rem, p.Px, p.magic_p);
+            const int c = (int)(rem - r * p.Px) - p.pad;
+            const int cb = ci_tile * 4 + (int)blk;
+            if (s < x_units && r < (unsigned)p.Rin && c >= 0 && c < p.W && cb < p.C8in)
+                piece_rel[i] = ((unsigned)cb * p.H * p.W + r * p.W + c) * 16u;
+            piece_row[i] = (int)r;
+        } else {
+            const int sz = (piece - p.x_pieces) * 64 + lane;
+            const unsigned blk = fastdiv((unsigned)sz, p.zslots, p.magic_zs);
+            const unsigned rem = sz - blk * p.zslots;
+            const unsigned r = fastdiv(rem, p.P, p.magic_p);
+            const unsigned c = rem - r * p.P;
+            const int cb = co_tile * 4 + (int)blk;
+            if (sz < z_units && r < (unsigned)p.R && c < (unsigned)p.Wo && cb < p.C8out)
+                piece_rel[i] = ((unsigned)cb * p.Ho * p.Wo + r * p.Wo + c) * 16u;
+            piece_row[i] = (int)r;
+        }
+    }
+    auto dma_tile = [&](int t, int buf) {
+        const int n = t / p.tiles_y, ty = t - n * p.tiles_y;
+        const int y0 = ty * p.R, yin0 = y0 * S - p.pad;
+        const unsigned zb = (unsigned)((n * p.C8out * p.Ho * p.Wo + y0 * p.Wo) * 16);
+        const unsigned xb = (unsigned)((n * p.C8in * p.H * p.W + yin0 * p.W) * 16);
+        u32x4* dst = smem16 + buf * buf_units;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int piece = wave + 4 * i;
+            if (piece >= p.pieces) break;  // wave-uniform
+            const int r = piece_row[i];
+            if (piece < p.x_pieces) {
+                const bool ok = piece_rel[i] != kOob && yin0 + r >= 0 && yin0 + r < p.H;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(dst + piece * 64), 16,
+                                                         ok ? xb + piece_rel[i] : kOob, 0, 0, 0);
+            } else {
+                const bool ok = piece_rel[i] != kOob && y0 + r < p.Ho;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_z, (__attribute__((address_space(3))) void*)(dst + piece * 64), 16,
+                                                         ok ? zb + piece_rel[i] : kOob, 0, 0, 0);
+            }
+        }
+    };
+
+    f32x4 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // lane-constant operand byte offsets: position (8g + q) of a k-step, channels 4pp .. 4pp+3 of this wave's 16
+    const int a_base = ((co_sub * 2 + (pp >> 1)) * p.zslots + (8 * g + q)) * 16 + (pp & 1) * 8 + p.z_base * 16;
+    const int b_base = ((ci_sub * 2 + (pp >> 1)) * p.xslots + S * (8 * g + q)) * 16 + (pp & 1) * 8;
+    const char* lds_bytes = reinterpret_cast<const char*>(smem16);
+
+    if (t_begin < t_end) dma_tile(t_begin, 0);
+    const int ksteps = p.K >> 5;
+    for (int t = t_begin; t < t_end; ++t) {
+        const int buf = (t - t_begin) & 1;
+        // this tile has landed (every wave waits for its own pieces, the barrier publishes them); the other buffer is free
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < t_end) dma_tile(t + 1, buf ^ 1);  // flies under this tile's MFMA loop
+        const char* zt = lds_bytes + (size_t)buf * buf_units * 16 + a_base;
+        const char* xt = lds_bytes + (size_t)buf * buf_units * 16 + b_base;
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const char* za = zt + ks * 32 * 16;
+            const char* xb = xt + ks * 32 * S * 16;
+            frag8 a;
+            a.lo = tr_read(reinterpret_cast<const _Float16*>(za));
+            a.hi = tr_read(reinterpret_cast<const _Float16*>(za + 4 * 16));
+            const f16x8 af = __builtin_bit_cast(f16x8, a);
+#pragma unroll
+            for (int tp = 0; tp < T; ++tp) {
+                const int off = ((tp / KS) * p.Px + (tp % KS)) * 16;
+                frag8 b;
+                b.lo = tr_read(reinterpret_cast<const _Float16*>(xb + off));
+                b.hi = tr_read(reinterpret_cast<const _Float16*>(xb + off + 4 * S * 16));
+                acc[tp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, __builtin_bit_cast(f16x8, b), acc[tp], 0, 0, 0);
+            }
+        }
+    }
+
+    // D: lane holds couts 4g .. 4g+3 (rows) of cin (lane & 15) (column) -> slab [Cout][Cin][T]
+    float* slab = p.slabs + (size_t)blockIdx.y * p.Cout * p.Cin * T;
+    const int ci = ci_tile * 32 + ci_sub * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = co_tile * 32 + co_sub * 16 + 4 * g + r;
+        if (co < p.Cout && ci < p.Cin) {
+#pragma unroll
+            for (int tp = 0; tp < T; ++tp) slab[((size_t)co * p.Cin + ci) * T + tp] = acc[tp][r];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void wgrad16_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, size_t count,
                                                              int splits, float scale, int accumulate) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
@@ -234,6 +370,36 @@ __global__ __launch_bounds__(256) void wgrad16_reduce_grouped_kernel(const float
     }
 }
 
+constexpr int kDmaPieces = 28;  // DMA pieces per wave and tile the LDS-DMA kernel is built for
+
+// LDS-DMA form of the same decomposition: two buffers of [4][xslots] + [4][zslots] elements; false = does not fit (the
+// register-staged kernel serves the shape).  MP_WGRAD16_DMA=0 switches it off (A/B).
+bool geometry_dma(Wgrad16Params& p, int KS, int S, size_t& lds_bytes) {
+    if (const char* e = getenv("MP_WGRAD16_DMA"))
+        if (atoi(e) == 0) return false;
+    for (int pass = 0; pass < 2; ++pass) {
+        const size_t budget = pass == 0 ? 78 * 1024 : 150 * 1024;
+        for (int R = p.Ho < 16 ? p.Ho : 16; R >= 1; --R) {
+            const int Rin = (R - 1) * S + KS;
+            const int K = (R * p.P + 31) / 32 * 32;
+            int xneed = S * (K - 1) + (KS - 1) * p.Px + (KS - 1) + 1;
+            if (xneed < Rin * p.Px) xneed = Rin * p.Px;
+            // == 4 (mod 16): the two channel blocks a 16-lane group reads are 64 B apart modulo the 256-byte bank row
+            const int xslots = (xneed + 11) / 16 * 16 + 4, zslots = K + 4 + ((K % 16) ? 16 - K % 16 : 0);
+            const int x_pieces = (4 * xslots + 63) / 64, z_pieces = (4 * zslots + 63) / 64;
+            const int pieces = x_pieces + z_pieces;
+            const size_t bytes = (size_t)2 * pieces * 64 * 16;
+            if (pieces > 4 * kDmaPieces || bytes > budget) continue;
+            p.R = R; p.Rin = Rin; p.K = K; p.xrows = xneed; p.nbuf = 2;
+            p.xslots = xslots; p.zslots = zslots; p.pieces = pieces; p.x_pieces = x_pieces; p.z_base = x_pieces * 64;
+            p.magic_xs = magic_of(xslots); p.magic_zs = magic_of(zslots); p.magic_p = magic_of(p.P);
+            lds_bytes = bytes;
+            return true;
+        }
+    }
+    return false;
+}
+
 constexpr int kNZ = 4, kNX = 10;
 
 int geometry(const mp_conv_desc* d, Wgrad16Params& p, size_t& lds_bytes) {
@@ -253,7 +419,8 @@ int geometry(const mp_conv_desc* d, Wgrad16Params& p, size_t& lds_bytes) {
     p.P = p.W + 2 * p.pad > p.Wo ? p.W + 2 * p.pad : p.Wo;
     p.Px = p.P;
     // pass 0: double-buffered, two workgroups per CU; pass 1: double-buffered, whatever fits; pass 2: single buffer
-    bool found = false;
+    p.pieces = 0;
+    bool found = geometry_dma(p, KS, S, lds_bytes);  // the LDS-DMA form where its tiles fit (p.pieces > 0 marks it)
     for (int pass = 0; pass < 3 && !found; ++pass) {
         p.nbuf = pass < 2 ? 2 : 1;
         const size_t budget = pass == 0 ? 78 * 1024 : 150 * 1024;
@@ -288,7 +455,21 @@ int geometry(const mp_conv_desc* d, Wgrad16Params& p, size_t& lds_bytes) {
 }
 
 template <int KS, int S>
+int launch_wgrad16_dma(const Wgrad16Params& p, size_t lds, hipStream_t s) {
+    auto kern = conv_wgrad_f16_dma_kernel<KS, S, kDmaPieces>;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(((p.Cout + 31) / 32) * p.ci_tiles, p.splits), dim3(256), lds, s, p);
+    return check_launch();
+}
+
+template <int KS, int S>
 int launch_wgrad16(const Wgrad16Params& p, size_t lds, hipStream_t s) {
+    if (p.pieces > 0) return launch_wgrad16_dma<KS, S>(p, lds, s);
     auto kern = conv_wgrad_f16_kernel<KS, S, kNZ, kNX>;
     static bool attr = false;
     if (!attr) {
