@@ -192,6 +192,33 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16_kernel(const Wgrad16Par
     }
 }
 
+// one tile's LDS-DMA: the wave's pieces (64 consecutive elements each) of the input image, then of the gradient image.  A macro,
+// expanded at its two call sites: as a lambda (or a function taking the descriptors) it made the HOST compilation pass drop the
+// kernel's stub without a diagnostic - __amdgpu_buffer_rsrc_t cannot be captured / passed there.
+#define WGRAD_DMA_TILE(DST, TILE)                                                                                               \
+    do {                                                                                                                         \
+        const int t_ = (TILE);                                                                                                   \
+        u32x4* dst_ = (DST);                                                                                                     \
+        const int n_ = t_ / p.tiles_y, ty_ = t_ - n_ * p.tiles_y;                                                                \
+        const int y0_ = ty_ * p.R, yin0_ = y0_ * S - p.pad;                                                                      \
+        const unsigned zb_ = (unsigned)((n_ * p.C8out * p.Ho * p.Wo + y0_ * p.Wo) * 16);                                         \
+        const unsigned xb_ = (unsigned)((n_ * p.C8in * p.H * p.W + yin0_ * p.W) * 16);                                           \
+        _Pragma("unroll") for (int i_ = 0; i_ < NP; ++i_) {                                                                      \
+            const int piece_ = wave + 4 * i_;                                                                                    \
+            if (piece_ >= p.pieces) break; /* wave-uniform */                                                                    \
+            const int r_ = piece_row[i_];                                                                                        \
+            if (piece_ < p.x_pieces) {                                                                                           \
+                const bool ok_ = piece_rel[i_] != kOob && yin0_ + r_ >= 0 && yin0_ + r_ < p.H;                                   \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(dst_ + piece_ * 64),   \
+                                                         16, ok_ ? xb_ + piece_rel[i_] : kOob, 0, 0, 0);                         \
+            } else {                                                                                                             \
+                const bool ok_ = piece_rel[i_] != kOob && y0_ + r_ < p.Ho;                                                       \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_z, (__attribute__((address_space(3))) void*)(dst_ + piece_ * 64),   \
+                                                         16, ok_ ? zb_ + piece_rel[i_] : kOob, 0, 0, 0);                         \
+            }                                                                                                                    \
+        }                                                                                                                        \
+    } while (0)
+
 // ---- LDS-DMA form -----------------------------------------------------------------------------------------------------------
 // The kernel above stages both tiles global -> VGPR -> ds_write into a PIXEL-major LDS image (row = one position x 32 channels),
 // zero-fills its LDS first and pays a load / wait / write / barrier chain per tile; the layers of the deep branches give a
@@ -201,8 +228,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16_kernel(const Wgrad16Par
 // arrive as zeros through the buffer range check).  ds_read_b64_tr_b16 takes PER-LANE addresses, so the transposing read works on
 // this image too: lane 4q+p of a 16-lane group points at position q, channels 4p .. 4p+3 = block (p >> 1), byte (p & 1) * 8.
 // Same position trick, same MFMA loop order, same slab layout as above: results are bit-identical.
+// (A __device__ body behind concrete __global__ wrappers: as a __global__ TEMPLATE containing the LDS-DMA builtin the host
+// compilation pass of this file emitted no stub for it - undefined symbol at load time, no diagnostic.)
 template <int KS, int S, int NP>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dma_kernel(const Wgrad16Params p) {
+__device__ __forceinline__ void wgrad_dma_body(const Wgrad16Params& p) {
     constexpr int T = KS * KS;
     extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
     // per buffer: [4][xslots] input image, padding up to a whole DMA piece, [4][zslots] gradient image, padding likewise
@@ -251,29 +280,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dma_kernel(const Wgrad1
             piece_row[i] = (int)r;
         }
     }
-    auto dma_tile = [&](int t, int buf) {
-        const int n = t / p.tiles_y, ty = t - n * p.tiles_y;
-        const int y0 = ty * p.R, yin0 = y0 * S - p.pad;
-        const unsigned zb = (unsigned)((n * p.C8out * p.Ho * p.Wo + y0 * p.Wo) * 16);
-        const unsigned xb = (unsigned)((n * p.C8in * p.H * p.W + yin0 * p.W) * 16);
-        u32x4* dst = smem16 + buf * buf_units;
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int piece = wave + 4 * i;
-            if (piece >= p.pieces) break;  // wave-uniform
-            const int r = piece_row[i];
-            if (piece < p.x_pieces) {
-                const bool ok = piece_rel[i] != kOob && yin0 + r >= 0 && yin0 + r < p.H;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(dst + piece * 64), 16,
-                                                         ok ? xb + piece_rel[i] : kOob, 0, 0, 0);
-            } else {
-                const bool ok = piece_rel[i] != kOob && y0 + r < p.Ho;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_z, (__attribute__((address_space(3))) void*)(dst + piece * 64), 16,
-                                                         ok ? zb + piece_rel[i] : kOob, 0, 0, 0);
-            }
-        }
-    };
-
     f32x4 acc[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -283,14 +289,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dma_kernel(const Wgrad1
     const int b_base = ((ci_sub * 2 + (pp >> 1)) * p.xslots + S * (8 * g + q)) * 16 + (pp & 1) * 8;
     const char* lds_bytes = reinterpret_cast<const char*>(smem16);
 
-    if (t_begin < t_end) dma_tile(t_begin, 0);
+    if (t_begin < t_end) WGRAD_DMA_TILE(smem16, t_begin);
     const int ksteps = p.K >> 5;
     for (int t = t_begin; t < t_end; ++t) {
         const int buf = (t - t_begin) & 1;
         // this tile has landed (every wave waits for its own pieces, the barrier publishes them); the other buffer is free
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (t + 1 < t_end) dma_tile(t + 1, buf ^ 1);  // flies under this tile's MFMA loop
+        if (t + 1 < t_end)  // flies under this tile's MFMA loop
+            WGRAD_DMA_TILE(smem16 + (buf ^ 1) * buf_units, t + 1);
         const char* zt = lds_bytes + (size_t)buf * buf_units * 16 + a_base;
         const char* xt = lds_bytes + (size_t)buf * buf_units * 16 + b_base;
         for (int ks = 0; ks < ksteps; ++ks) {
@@ -371,6 +378,11 @@ __global__ __launch_bounds__(256) void wgrad16_reduce_grouped_kernel(const float
 }
 
 constexpr int kDmaPieces = 28;  // DMA pieces per wave and tile the LDS-DMA kernel is built for
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dma_k1s1(const Wgrad16Params p) { wgrad_dma_body<1, 1, kDmaPieces>(p); }
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dma_k1s2(const Wgrad16Params p) { wgrad_dma_body<1, 2, kDmaPieces>(p); }
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dma_k3s1(const Wgrad16Params p) { wgrad_dma_body<3, 1, kDmaPieces>(p); }
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dma_k3s2(const Wgrad16Params p) { wgrad_dma_body<3, 2, kDmaPieces>(p); }
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dma_k4s2(const Wgrad16Params p) { wgrad_dma_body<4, 2, kDmaPieces>(p); }
 
 // LDS-DMA form of the same decomposition: two buffers of [4][xslots] + [4][zslots] elements; false = does not fit (the
 // register-staged kernel serves the shape).  MP_WGRAD16_DMA=0 switches it off (A/B).
@@ -456,7 +468,9 @@ int geometry(const mp_conv_desc* d, Wgrad16Params& p, size_t& lds_bytes) {
 
 template <int KS, int S>
 int launch_wgrad16_dma(const Wgrad16Params& p, size_t lds, hipStream_t s) {
-    auto kern = conv_wgrad_f16_dma_kernel<KS, S, kDmaPieces>;
+    auto kern = KS == 4 ? conv_wgrad_f16_dma_k4s2
+                        : KS == 3 ? (S == 1 ? conv_wgrad_f16_dma_k3s1 : conv_wgrad_f16_dma_k3s2)
+                                  : (S == 1 ? conv_wgrad_f16_dma_k1s1 : conv_wgrad_f16_dma_k1s2);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
