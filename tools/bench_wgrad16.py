@@ -36,5 +36,5 @@ for cin, cout, h, w, k, st in SHAPES:
         res[mode] = statistics.median(ts); outs[mode] = dw.clone()
     gf = 2 * n * ho * wo * cout * cin * k * k / 1e9
     err = float((outs["1"] - outs["0"]).abs().max() / outs["0"].abs().max())
-    print(f"{cin:3d}->{cout:3d} k{k} s{st} {h}x{w} N={n}: staged {res['0']:6.1f} us ({gf / res["0"] * 1e3:5.0f} TF)  LDS-DMA {res['1']:6.1f} us "
-          f"({gf / res["1"] * 1e3:5.0f} TF)  rel diff {err:.1e}", flush=True)
+    print(f"{cin:3d}->{cout:3d} k{k} s{st} {h}x{w} N={n}: staged {res['0']:6.1f} us ({gf / res['0'] * 1e3:5.0f} TF)  LDS-DMA {res['1']:6.1f} us "
+          f"({gf / res['1'] * 1e3:5.0f} TF)  rel diff {err:.1e}", flush=True)
