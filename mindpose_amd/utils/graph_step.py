@@ -30,6 +30,9 @@ class GraphedTrainStep:
         # inside the graph the branches of an HRModule run on side streams (fork / join = graph dependencies): +5 % on the step
         from ..models.backbones.hrnet import set_branch_streams
         prev_branch_streams = set_branch_streams(True)
+        # ... and the weight gradients (leaves of the backward pass) on a side stream per branch stream, joined after backward
+        from ..models.train_ops import join_wgrad_lanes, set_wgrad_lanes
+        prev_wgrad_lanes = set_wgrad_lanes(True)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -37,6 +40,7 @@ class GraphedTrainStep:
                 optimizer.grads.begin_step()
                 loss = net_with_loss(*self.static_in)
                 (loss * self.scale_t).backward()
+                join_wgrad_lanes(dev)
                 del loss  # drop the autograd graph before the next pass / the capture
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
@@ -45,7 +49,9 @@ class GraphedTrainStep:
             optimizer.grads.arena.zero_()
             self.static_loss = net_with_loss(*self.static_in)
             (self.static_loss * self.scale_t).backward()
+            join_wgrad_lanes(dev)
         set_branch_streams(prev_branch_streams)
+        set_wgrad_lanes(prev_wgrad_lanes)
 
     def __call__(self, *inputs: torch.Tensor) -> torch.Tensor:
         """Copy the batch into the static buffers, replay the graph, run the optimizer; returns the (static) loss tensor."""
