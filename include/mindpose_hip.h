@@ -161,6 +161,19 @@ int mp_conv2d_fwd_variant(const mp_conv_desc* desc, int variant, const float* x_
                           const float* scale_dev, const float* shift_dev, const float* res1_dev, const float* res2_dev,
                           float* out_dev, mp_stream_t stream);
 
+/* The 3x3 stride-1 padding-1 convolutions of the branches (hrnet.py:51-64 BasicBlock, 202-241 _make_one_branch) in Winograd
+ * F(2x2,3x3) form, all fp32: 16 instead of 36 multiplications per 2x2 output tile and (cin, cout) pair; same operands, epilogue
+ * (folded BatchNorm scale/shift, res1, res2, ReLU) and result as mp_conv2d_fwd up to fp32 rounding (the sums are associated
+ * differently).  Needs W % 4 == 0, H % 2 == 0, W <= 96, Cin % 8 == 0 and the plain output mapping; mp_conv_winograd_supported
+ * returns MP_OK or MP_ERR_UNSUPPORTED for a descriptor.  The weights are transformed once: U = G w G^T,
+ * [Cin/4][16][4][Cout_pad16] floats (mp_conv_winograd_packed_weight_bytes). */
+size_t mp_conv_winograd_packed_weight_bytes(int cout, int cin);
+int mp_conv_winograd_pack_weight(const float* w_dev, float* packed_dev, int cout, int cin, mp_stream_t stream);
+int mp_conv_winograd_supported(const mp_conv_desc* desc);
+int mp_conv2d_winograd_fwd(const mp_conv_desc* desc, const float* x_dev, const float* packed_u_dev, const float* scale_dev,
+                           const float* shift_dev, const float* res1_dev, const float* res2_dev, float* out_dev,
+                           mp_stream_t stream);
+
 /* nn.MaxPool2d(kernel_size=3, stride=2, pad_mode="same"), resnet.py:190: pads bottom/right only. */
 int mp_maxpool3x3s2_same(const float* x_dev, float* out_dev, int n, int c, int h, int w, mp_stream_t stream);
 

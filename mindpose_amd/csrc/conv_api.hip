@@ -7,6 +7,7 @@
 
 #include "conv_f16.h"
 #include "conv_mfma.h"
+#include "conv_wino.h"
 
 namespace mp {
 
@@ -98,6 +99,8 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const mp_f16_pac
 
 static unsigned long long* g_stamp_buf = nullptr;
 static size_t g_stamp_bytes = 0;
+
+unsigned long long* conv_stamp_buffer(size_t need_bytes) { return (g_stamp_buf && need_bytes <= g_stamp_bytes) ? g_stamp_buf : nullptr; }
 
 struct ConvLaunch {
     ConvKParams p;

@@ -1,0 +1,455 @@
+// Winograd F(2x2, 3x3) convolution on the fp32 matrix cores of gfx950: the 3x3 stride-1 padding-1 convolutions of the HRNet
+// branches (hrnet.py:51-64, 202-241 - 85 % of the network's FLOP) with 16 multiplications per 2x2 output tile and (cin, cout)
+// pair instead of 36.  Everything is fp32: input transform  V = B^T d B  (adds only), 16 independent GEMMs
+// M_xi[tile][cout] = sum_cin V_xi[tile][cin] * U_xi[cin][cout]  on v_mfma_f32_16x16x4_f32, output transform  Y = A^T M A
+// (adds only), then the same folded-BatchNorm / residual / ReLU epilogue as the direct kernel (conv_mfma.h).
+//
+//   workgroup   256 threads, one image band of TR x TW <= 48 output tiles (2x2 pixels each) x 32 output channels, all of Cin
+//               in chunks of 8 channels
+//   per chunk   (1) raw input rows  global -> registers -> LDS  [8][R+2][W+4] (zero halo, double-buffered; the loads of chunk
+//                   c+1 fly under the arithmetic of chunk c)
+//               (2) input transform: a thread takes two horizontally adjacent tiles of one channel (4 x 6 patch: b128 + b64
+//                   LDS reads per row), writes V[xi][cin][tile] (tile pitch 48 == 16 mod 32: the four cin rows of an MFMA
+//                   operand fetch sit on disjoint banks)
+//               (3) MFMA: wave w owns xi = 4w .. 4w+3 for all 3 x 2 (tile block, cout block) pairs = 24 accumulators;
+//                   U comes straight from global memory / L2 into registers one chunk ahead (no LDS copy of the weights)
+//   epilogue    the accumulators of the four waves meet in LDS ([xi][cout][tile]), a thread gathers the 16 xi values of four
+//               tiles of one cout, applies A^T . A, scale/shift (+res1)(+res2)(+ReLU) and stores 2x2 pixels per tile.
+//   LDS         52 KiB -> three workgroups per CU: while one transforms, the others feed the matrix cores.
+#include <stdlib.h>
+
+#include "conv_mfma.h"
+#include "conv_wino.h"
+
+namespace mp {
+
+namespace {
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+constexpr int kCK = 8;    // input channels per chunk
+constexpr int kTP = 48;   // tile pitch of V (floats), tiles per workgroup <= 48
+constexpr int kXP = 52;   // tile pitch of the accumulator exchange
+constexpr int kVFloats = 16 * kCK * kTP;
+constexpr int kXFloats = 16 * 16 * kXP;
+
+__device__ __forceinline__ void wg_barrier() {
+    // LDS traffic of this wave done, then the workgroup barrier; global loads stay in flight (a __syncthreads() would drain them)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int NI, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_wino_f32_kernel(const WinoParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int raw_buf = kCK * p.cin_plane;
+    float* __restrict__ lds_raw = smem;                 // [2][raw_buf]
+    float* __restrict__ lds_v = smem + 2 * raw_buf;     // [16][kCK][kTP]
+    float* __restrict__ lds_x = smem;                   // epilogue: [16][16][kXP] over everything
+
+    MP_STAMP(t_start);
+    [[maybe_unused]] unsigned long long s_xf = 0, s_b1 = 0, s_mm = 0, s_st = 0, s_b2 = 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane >> 4, lr = lane & 15;
+
+    int b = blockIdx.x;
+    {   // XCD-aware tile id (blocks b, b+8, ... share an XCD): the cout tiles of one band share an L2
+        const int nb = p.total_blocks, q8 = nb >> 3, r8 = nb & 7, xcd = b & 7, j = b >> 3;
+        b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
+    }
+    const int ct = b % p.n_ct;
+    b /= p.n_ct;
+    const int band = b % p.bands, n = b / p.bands;
+    const int y0 = band * p.R, y_in0 = y0 - 1;
+    const int HW = p.H * p.W;
+
+    {   // zero both raw buffers once: halo rows / columns are never written by the chunk copies
+        const int n4 = (2 * raw_buf) >> 2;
+        float4* z = reinterpret_cast<float4*>(lds_raw);
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < n4; i += 256) z[i] = zero;
+    }
+
+    // staging tables: float4 units of the chunk's rows
+    unsigned isrc[NI];
+    int idst[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const unsigned u = tid + 256 * i;
+        isrc[i] = kOob;
+        idst[i] = 0;
+        if (u < (unsigned)(kCK * p.upc)) {
+            const unsigned c = fastdiv(u, p.upc, p.magic_upc);
+            const unsigned rem = u - c * p.upc;
+            const unsigned r = fastdiv(rem, p.upr, p.magic_upr);
+            const unsigned xu = rem - r * p.upr;
+            const int yin = y_in0 + (int)r;
+            if (yin >= 0 && yin < p.H) {
+                isrc[i] = (c * HW + yin * p.W + xu * 4) * 4u;
+                idst[i] = (int)(c * p.cin_plane + r * p.Wp + 1 + xu * 4);
+            }
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x + (size_t)n * p.Cin * HW, (size_t)p.Cin * HW * 4);
+    const __amdgpu_buffer_rsrc_t rs_u = make_rsrc(p.u, (size_t)(p.Cin >> 2) * 16 * 4 * p.Cout_pad16 * 4);
+
+    // transform item of this thread: (cin, pair of adjacent tiles)
+    const int pairs = p.M >> 1;
+    const bool xf_on = tid < kCK * pairs;
+    int xf_raw = 0, xf_v = 0;
+    {
+        const unsigned t = xf_on ? tid : 0;
+        const unsigned c = fastdiv(t, pairs, p.magic_pairs);
+        const unsigned tile0 = (t - c * pairs) * 2;
+        const unsigned ty = fastdiv(tile0, p.TW, p.magic_tw);
+        const unsigned tx = tile0 - ty * p.TW;
+        xf_raw = c * p.cin_plane + (2 * ty) * p.Wp + 2 * tx;
+        xf_v = c * kTP + tile0;
+    }
+
+    // U fragments of this wave: xi = 4 * wave + i, cout block nb, k-step q of the chunk
+    unsigned u_off[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int co = ct * 32 + nb * 16 + lr;
+        u_off[nb] = co < p.Cout_pad16 ? (unsigned)((wave * 4 * 4 + lq) * p.Cout_pad16 + co) * 4u : kOob;
+    }
+    const unsigned u_xi = (unsigned)(4 * p.Cout_pad16) * 4u;        // next xi
+    const unsigned u_q = (unsigned)(16 * 4 * p.Cout_pad16) * 4u;    // next k-step (4 input channels)
+    float ucur[4][2][2];  // loaded at the head of a chunk, first used after its input transform
+    auto load_u = [&](int ch, float (&dst)[4][2][2]) {
+        const unsigned base = (unsigned)(ch * 2) * u_q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    dst[i][nb][q] = buf_load1(rs_u, u_off[nb] == kOob ? kOob : u_off[nb] + base + q * u_q + i * u_xi);
+    };
+
+    f32x4 vin[NI];
+    auto stage_load = [&](int ch) {
+        const unsigned xo = (unsigned)(ch * kCK) * HW * 4u;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) vin[i] = buf_load4(rs_x, isrc[i] == kOob ? kOob : isrc[i] + xo);
+    };
+    auto stage_store = [&](int buf) {
+        float* __restrict__ d0 = lds_raw + buf * raw_buf;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (isrc[i] != kOob) {
+                float* d = d0 + idst[i];
+                d[0] = vin[i].x; d[1] = vin[i].y; d[2] = vin[i].z; d[3] = vin[i].w;
+            }
+        }
+    };
+
+    f32x4 acc[4][3][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[i][mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    stage_load(0);
+    __syncthreads();  // zero fill complete
+    stage_store(0);
+    wg_barrier();
+    MP_STAMP(t_pro);
+
+    const int a_base = wave * 4 * (kCK * kTP) + lq * kTP + lr;
+    for (int ch = 0; ch < p.n_chunks; ++ch) {
+        const bool more = ch + 1 < p.n_chunks;
+        MP_STAMP(t0);
+        if (more) stage_load(ch + 1);
+        load_u(ch, ucur);
+        // ---- input transform of chunk ch: raw[ch & 1] -> V
+        if (xf_on) {
+            const float* __restrict__ src = lds_raw + (ch & 1) * raw_buf + xf_raw;
+            float d[4][6];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(src + r * p.Wp);
+                const float2 c2 = *reinterpret_cast<const float2*>(src + r * p.Wp + 4);
+                d[r][0] = a.x; d[r][1] = a.y; d[r][2] = a.z; d[r][3] = a.w; d[r][4] = c2.x; d[r][5] = c2.y;
+            }
+            float t[4][6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                t[0][c] = d[0][c] - d[2][c];
+                t[1][c] = d[1][c] + d[2][c];
+                t[2][c] = d[2][c] - d[1][c];
+                t[3][c] = d[1][c] - d[3][c];
+            }
+            float* __restrict__ dst = lds_v + xf_v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float va[4], vb[4];
+                va[0] = t[i][0] - t[i][2]; va[1] = t[i][1] + t[i][2]; va[2] = t[i][2] - t[i][1]; va[3] = t[i][1] - t[i][3];
+                vb[0] = t[i][2] - t[i][4]; vb[1] = t[i][3] + t[i][4]; vb[2] = t[i][4] - t[i][3]; vb[3] = t[i][3] - t[i][5];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<float2*>(dst + (i * 4 + j) * (kCK * kTP)) = make_float2(va[j], vb[j]);
+            }
+        }
+        MP_STAMP(t1);
+        wg_barrier();  // V complete
+        MP_STAMP(t2);
+        // ---- 16 GEMMs, this wave's four xi
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* __restrict__ va = lds_v + a_base + i * (kCK * kTP) + q * 4 * kTP;
+                float av[3];
+#pragma unroll
+                for (int mb = 0; mb < 3; ++mb) av[mb] = va[mb * 16];
+#pragma unroll
+                for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+                        acc[i][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], ucur[i][nb][q], acc[i][mb][nb], 0, 0, 0);
+            }
+        MP_STAMP(t3);
+        if (more) stage_store((ch + 1) & 1);
+        MP_STAMP(t4);
+        wg_barrier();  // raw[(ch + 1) & 1] visible, V free
+        MP_STAMP(t5);
+        s_xf += t1 - t0; s_b1 += t2 - t1; s_mm += t3 - t2; s_st += t4 - t3; s_b2 += t5 - t4;
+    }
+    MP_STAMP(t_epi);
+
+    // ---- accumulators -> LDS -> output transform -> epilogue, one 16-channel half at a time
+    const int plane_o = HW;
+    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(p.out + (size_t)n * p.Cout * plane_o, (size_t)p.Cout * plane_o * 4);
+    const unsigned co_l = fastdiv((unsigned)tid, 12, 0x15555556u);  // tid / 12
+    const unsigned quad = tid - co_l * 12;
+    const bool ep_on = tid < 192;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        if (ct * 32 + nb * 16 >= p.Cout_pad16) break;  // workgroup-uniform
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int mb = 0; mb < 3; ++mb)
+                *reinterpret_cast<f32x4*>(lds_x + ((wave * 4 + i) * 16 + lr) * kXP + mb * 16 + lq * 4) = acc[i][mb][nb];
+        wg_barrier();
+        const int co = ct * 32 + nb * 16 + (int)co_l;
+        if (ep_on && co < p.Cout) {
+            f32x4 m[16];
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) m[xi] = *reinterpret_cast<const f32x4*>(lds_x + (xi * 16 + co_l) * kXP + quad * 4);
+            const float sc = p.scale[co], sh = p.shift[co];
+            const unsigned co_off = (unsigned)co * plane_o;
+            unsigned off[4];
+            float y[4][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned tile = quad * 4 + e;
+                const unsigned ty = fastdiv(tile, p.TW, p.magic_tw);
+                const unsigned tx = tile - ty * p.TW;
+                const int oy = y0 + 2 * (int)ty;
+                off[e] = (tile < (unsigned)p.M && oy < p.H) ? (co_off + oy * p.W + 2 * tx) * 4u : kOob;
+                float s[2][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s[0][j] = m[0 * 4 + j][e] + m[1 * 4 + j][e] + m[2 * 4 + j][e];
+                    s[1][j] = m[1 * 4 + j][e] - m[2 * 4 + j][e] - m[3 * 4 + j][e];
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    y[e][a * 2 + 0] = (s[a][0] + s[a][1] + s[a][2]) * sc + sh;
+                    y[e][a * 2 + 1] = (s[a][1] - s[a][2] - s[a][3]) * sc + sh;
+                }
+            }
+            const unsigned row = (unsigned)p.W * 4u;
+            if (p.res1) {
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.res1 + (size_t)n * p.Cout * plane_o, (size_t)p.Cout * plane_o * 4);
+                float2 r[4][2];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+                        r[e][a] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, off[e] == kOob ? kOob : off[e] + a * row, 0, 0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) { y[e][a * 2] += r[e][a].x; y[e][a * 2 + 1] += r[e][a].y; }
+            }
+            if (p.res2) {
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.res2 + (size_t)n * p.Cout * plane_o, (size_t)p.Cout * plane_o * 4);
+                float2 r[4][2];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+                        r[e][a] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, off[e] == kOob ? kOob : off[e] + a * row, 0, 0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) { y[e][a * 2] += r[e][a].x; y[e][a * 2 + 1] += r[e][a].y; }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    float2 v = make_float2(y[e][a * 2], y[e][a * 2 + 1]);
+                    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs_o, off[e] == kOob ? kOob : off[e] + a * row, 0, 0);
+                }
+        }
+        wg_barrier();  // the exchange buffer is free for the second half
+    }
+#if MP_CONV_STAMPS
+    {
+        MP_STAMP(t_end);
+        if (p.dbg && tid == 0) {
+            unsigned long long* d = p.dbg + (size_t)blockIdx.x * 8;
+            d[0] = t_end - t_start; d[1] = t_pro - t_start; d[2] = s_xf; d[3] = s_b1; d[4] = s_mm; d[5] = s_st; d[6] = s_b2;
+            d[7] = t_end - t_epi;
+        }
+    }
+#endif
+}
+
+// U = G g G^T per (cout, cin), laid out [Cin/4][xi][4][Cout_pad16] (the direct kernel's packed layout with 16 "taps")
+__global__ __launch_bounds__(256) void pack_weight_wino_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin,
+                                                               int cin_pad4, int cout_pad16) {
+    const size_t total = (size_t)cin_pad4 * cout_pad16;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % cout_pad16), ci = (int)(i / cout_pad16);
+        float g[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g[a][c] = (co < cout && ci < cin) ? w[(((size_t)co * cin + ci) * 3 + a) * 3 + c] : 0.f;
+        float t[4][3];  // G g
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            t[0][c] = g[0][c];
+            t[1][c] = 0.5f * (g[0][c] + g[1][c] + g[2][c]);
+            t[2][c] = 0.5f * (g[0][c] - g[1][c] + g[2][c]);
+            t[3][c] = g[2][c];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            float u[4];
+            u[0] = t[a][0];
+            u[1] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
+            u[2] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
+            u[3] = t[a][2];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                out[((size_t)((ci >> 2) * 16 + a * 4 + c) * 4 + (ci & 3)) * cout_pad16 + co] = u[c];
+        }
+    }
+}
+
+inline unsigned magic_of(unsigned d) { return d <= 1 ? 0u : (unsigned)(0x100000000ULL / d) + 1u; }
+
+}  // namespace
+
+int wino_configure(const mp_conv_desc* d, WinoLaunch& L) {
+    if (!d) return MP_ERR_NULL;
+    if (d->n <= 0 || d->cin <= 0 || d->cout <= 0 || d->h <= 0 || d->w <= 0) return MP_ERR_SHAPE;
+    if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad_top != 1 || d->pad_left != 1) return MP_ERR_UNSUPPORTED;
+    if (d->conv_h != d->h || d->conv_w != d->w || d->out_h != d->h || d->out_w != d->w) return MP_ERR_UNSUPPORTED;
+    if (d->out_mul != 1 || d->out_rep != 1 || d->out_off_y != 0 || d->out_off_x != 0) return MP_ERR_UNSUPPORTED;
+    if ((d->w & 3) || (d->h & 1) || (d->cin % kCK)) return MP_ERR_UNSUPPORTED;
+    if ((long long)d->cin * d->h * d->w * 4 >= 0x7FFFFFF0LL || (long long)d->cout * d->h * d->w * 4 >= 0x7FFFFFF0LL) return MP_ERR_UNSUPPORTED;
+    WinoParams& p = L.p;
+    p.N = d->n; p.Cin = d->cin; p.Cout = d->cout; p.Cout_pad16 = (d->cout + 15) / 16 * 16; p.H = d->h; p.W = d->w;
+    p.TW = d->w / 2;
+    if (p.TW > kTP) return MP_ERR_UNSUPPORTED;
+    p.TR = kTP / p.TW;
+    if (p.TR > d->h / 2) p.TR = d->h / 2;
+    p.M = p.TR * p.TW;
+    p.R = 2 * p.TR;
+    p.Rin = p.R + 2;
+    p.Wp = d->w + 4;
+    p.cin_plane = p.Rin * p.Wp;
+    p.n_chunks = d->cin / kCK;
+    p.n_ct = (p.Cout_pad16 + 31) / 32;
+    p.bands = (d->h + p.R - 1) / p.R;
+    p.total_blocks = p.n_ct * p.bands * d->n;
+    p.upr = d->w / 4;
+    p.upc = p.Rin * p.upr;
+    if (kCK * p.upc > 3 * 256) return MP_ERR_UNSUPPORTED;
+    p.relu = d->relu;
+    p.magic_upr = magic_of(p.upr); p.magic_upc = magic_of(p.upc); p.magic_tw = magic_of(p.TW); p.magic_pairs = magic_of(p.M >> 1);
+    const size_t main_bytes = ((size_t)2 * kCK * p.cin_plane + kVFloats) * 4, x_bytes = (size_t)kXFloats * 4;
+    L.lds_bytes = main_bytes > x_bytes ? main_bytes : x_bytes;
+    L.ni = (kCK * p.upc + 255) / 256;
+    if (L.lds_bytes > 150 * 1024) return MP_ERR_UNSUPPORTED;
+    return MP_OK;
+}
+
+int wino_launch(const WinoLaunch& L0, hipStream_t s) {
+    WinoLaunch L = L0;
+    L.p.dbg = conv_stamp_buffer((size_t)L.p.total_blocks * 64);
+    auto go = [&](auto kern) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipGetLastError();
+            attr = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(L.p.total_blocks), dim3(256), L.lds_bytes, s, L.p);
+        return check_launch();
+    };
+    static const int occ = [] { const char* e = getenv("MP_WINO_OCC"); return e ? atoi(e) : 2; }();  // experiments: 3 = 168-VGPR build
+    if (occ == 3) {
+        switch (L.ni) {
+            case 1: return go(conv_wino_f32_kernel<1, 3>);
+            case 2: return go(conv_wino_f32_kernel<2, 3>);
+            case 3: return go(conv_wino_f32_kernel<3, 3>);
+            default: return MP_ERR_UNSUPPORTED;
+        }
+    }
+    switch (L.ni) {
+        case 1: return go(conv_wino_f32_kernel<1, 2>);
+        case 2: return go(conv_wino_f32_kernel<2, 2>);
+        case 3: return go(conv_wino_f32_kernel<3, 2>);
+        default: return MP_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace mp
+
+using namespace mp;
+
+extern "C" {
+
+size_t mp_conv_winograd_packed_weight_bytes(int cout, int cin) {
+    if (cout <= 0 || cin <= 0) return 0;
+    return (size_t)((cin + 3) / 4 * 4) * 16 * ((cout + 15) / 16 * 16) * sizeof(float);
+}
+
+int mp_conv_winograd_pack_weight(const float* w, float* packed, int cout, int cin, mp_stream_t stream) {
+    if (!w || !packed) return MP_ERR_NULL;
+    if (cout <= 0 || cin <= 0) return MP_ERR_SHAPE;
+    const int cin_pad4 = (cin + 3) / 4 * 4, cout_pad16 = (cout + 15) / 16 * 16;
+    int blocks = (int)(((size_t)cin_pad4 * cout_pad16 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_weight_wino_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, packed, cout, cin, cin_pad4, cout_pad16);
+    return check_launch();
+}
+
+int mp_conv_winograd_supported(const mp_conv_desc* desc) {
+    WinoLaunch L{};
+    return wino_configure(desc, L);
+}
+
+int mp_conv2d_winograd_fwd(const mp_conv_desc* desc, const float* x, const float* packed_u, const float* scale, const float* shift,
+                           const float* res1, const float* res2, float* out, mp_stream_t stream) {
+    WinoLaunch L{};
+    int rc = wino_configure(desc, L);
+    if (rc != MP_OK) return rc;
+    if (!x || !packed_u || !scale || !shift || !out) return MP_ERR_NULL;
+    L.p.x = x; L.p.u = packed_u; L.p.scale = scale; L.p.shift = shift; L.p.res1 = res1; L.p.res2 = res2; L.p.out = out;
+    return wino_launch(L, as_stream(stream));
+}
+
+}  // extern "C"
