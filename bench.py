@@ -67,6 +67,8 @@ def log(msg):
 def kernel_name(info):
     """Template head <KS,S,PS,CS,WAVES_P,WAVES_C> of the instantiation; '/occ3' marks the light build (rocprof shows it as
     the trailing template argument OCC = 3)."""
+    if info["kind_id"] == 9:  # fp32 Winograd F(2x2,3x3): <NI staging units per thread, OCC workgroups per CU bound>
+        return f"conv_wino_f32_kernel<{info.get('light', 0)},2>"
     if info["kind_id"] == 8:  # fused fp16 BasicBlock: the <5,3> or <6,5> pixel-tile build ("variant" = 1 for the small one)
         return {0: "basicblock_f16_kernel<6,5>", 1: "basicblock_f16_kernel<5,3>", 2: "basicblock_f16_v2_kernel<8,4,3>", 3: "basicblock_f16_v2_kernel<4,5,3>"}[info["variant"]]
     if info["kind_id"] == 3:
@@ -127,7 +129,7 @@ def roofline_report(plan, reps=5, layers_csv=""):
             f.write("index,kind,kernel,us,tflops,n,cin,cout,k,stride,h,w,workgroups,lds_bytes,cin_chunk,images_per_tile,rows_per_tile\n")
             for i, t in enumerate(per_entry):
                 e = plan.entry_info(i)
-                name = kernel_name(e) if e["kind_id"] in (0, 3, 8) else e["kind"]
+                name = kernel_name(e) if e["kind_id"] in (0, 3, 8, 9) else e["kind"]
                 tf = 2.0 * e.get("macs", 0) / t / 1e12 if t > 0 else 0.0
                 f.write(f"{i},{e['kind']},\"{name}\",{t * 1e6:.2f},{tf:.2f},{e.get('n', '')},{e.get('cin', e.get('c', ''))},"
                         f"{e.get('cout', '')},{e.get('k', '')},{e.get('stride', '')},{e.get('h', '')},{e.get('w', '')},"
@@ -135,7 +137,7 @@ def roofline_report(plan, reps=5, layers_csv=""):
     groups = {}
     for i, t in enumerate(per_entry):
         info = plan.entry_info(i)
-        if info["kind_id"] not in (0, 3, 8):
+        if info["kind_id"] not in (0, 3, 8, 9):
             continue
         g = groups.setdefault(kernel_name(info), dict(time=0.0, flops=0.0, launches=0))
         g["time"] += t

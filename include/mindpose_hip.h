@@ -199,6 +199,10 @@ int mp_plan_add_conv(mp_plan* plan, const mp_conv_desc* desc, const float* x_dev
 int mp_plan_add_conv_variant(mp_plan* plan, const mp_conv_desc* desc, int variant, const float* x_dev,
                              const float* packed_w_dev, const float* scale_dev, const float* shift_dev,
                              const float* res1_dev, const float* res2_dev, float* out_dev);
+/* mp_conv2d_winograd_fwd as a plan entry (same operands; MP_ERR_UNSUPPORTED when the descriptor is outside the Winograd form). */
+int mp_plan_add_conv_winograd(mp_plan* plan, const mp_conv_desc* desc, const float* x_dev, const float* packed_u_dev,
+                              const float* scale_dev, const float* shift_dev, const float* res1_dev, const float* res2_dev,
+                              float* out_dev);
 int mp_plan_add_maxpool(mp_plan* plan, const float* x_dev, float* out_dev, int n, int c, int h, int w);
 int mp_plan_add_fuse_sum(mp_plan* plan, const float* base_dev, const float* t1_dev, int s1, const float* t2_dev, int s2,
                          const float* t3_dev, int s3, float* out_dev, int n, int c, int h, int w, int relu);

@@ -51,6 +51,7 @@ _PROTOTYPES = {
     "mp_conv_winograd_pack_weight": (c_int, [c_f32p, c_f32p, c_int, c_int, ctypes.c_void_p]),
     "mp_conv_winograd_supported": (c_int, [ctypes.POINTER(ConvDesc)]),
     "mp_conv2d_winograd_fwd": (c_int, [ctypes.POINTER(ConvDesc)] + [c_f32p] * 7 + [ctypes.c_void_p]),
+    "mp_plan_add_conv_winograd": (c_int, [ctypes.c_void_p, ctypes.POINTER(ConvDesc)] + [c_f32p] * 7),
     "mp_plan_add_conv_variant": (c_int, [ctypes.c_void_p, ctypes.POINTER(ConvDesc), c_int] + [c_f32p] * 7),
     "mp_maxpool3x3s2_same": (c_int, [c_f32p, c_f32p] + [c_int] * 4 + [ctypes.c_void_p]),
     "mp_fuse_upsample_sum": (c_int, [c_f32p, c_f32p, c_int, c_f32p, c_int, c_f32p, c_int, c_f32p] + [c_int] * 5 + [ctypes.c_void_p]),

@@ -289,11 +289,12 @@ using namespace mp;
 struct mp_plan {
     struct Entry {
         int kind;  // 0 conv, 1 maxpool, 2 fuse-sum; fp16 layout: 3 conv, 4 fuse-sum, 5 NCHW fp32 -> c8, 6 c8 -> NCHW fp32;
-                   // 7 = all-lane barrier (no launch), 8 = fused fp16 BasicBlock
+                   // 7 = all-lane barrier (no launch), 8 = fused fp16 BasicBlock, 9 = fp32 Winograd conv
         int lane;  // execution lane: 0 = the caller's stream, 1..3 = the plan's own side streams
         ConvLaunch conv;
         ConvF16Launch conv16;
         BlockF16Launch block16;
+        WinoLaunch wino;
         const void* t16[3];
         const void* x16;
         void* out16;
@@ -335,6 +336,7 @@ static int run_entry(const mp_plan::Entry& e, mp_stream_t stream) {
         case 6: return mp_f16_from_c8(e.x16, e.out, e.n, e.c, e.h, e.w, stream);
         case 7: return MP_OK;
         case 8: return blockf16_launch(e.block16, as_stream(stream));
+        case 9: return wino_launch(e.wino, as_stream(stream));
         default: return MP_ERR_UNSUPPORTED;
     }
 }
@@ -510,6 +512,21 @@ int mp_plan_add_conv_f16(mp_plan* plan, const mp_conv_desc* desc, int variant, c
     return MP_OK;
 }
 
+int mp_plan_add_conv_winograd(mp_plan* plan, const mp_conv_desc* desc, const float* x, const float* packed_u, const float* scale,
+                              const float* shift, const float* res1, const float* res2, float* out) {
+    if (!plan) return MP_ERR_NULL;
+    mp_plan::Entry e{};
+    e.kind = 9;
+    int rc = wino_configure(desc, e.wino);
+    if (rc != MP_OK) return rc;
+    if (!x || !packed_u || !scale || !shift || !out) return MP_ERR_NULL;
+    e.wino.p.x = x; e.wino.p.u = packed_u; e.wino.p.scale = scale; e.wino.p.shift = shift; e.wino.p.res1 = res1; e.wino.p.res2 = res2;
+    e.wino.p.out = out;
+    e.lane = plan->cur_lane;
+    plan->entries.push_back(e);
+    return MP_OK;
+}
+
 int mp_plan_add_basicblock_f16(mp_plan* plan, const void* x, const void* packed_w1, const float* scale1, const float* shift1,
                                const void* packed_w2, const float* scale2, const float* shift2, void* out, int n, int c, int h,
                                int w, int rows) {
@@ -582,6 +599,10 @@ int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]) {
         info[5] = (int64_t)e.conv16.lds_bytes; info[6] = ct; info[7] = pt; info[8] = e.conv16.p.PK * 8; info[9] = e.conv16.p.G;
         info[10] = e.conv16.p.R;
         info[11] = f16_variant_light(e.conv16.variant) ? 1 : 0;
+    } else if (e.kind == 9) {
+        info[1] = 3; info[2] = 1; info[3] = 8 /* the tuner's index of the Winograd form */; info[4] = e.wino.p.total_blocks;
+        info[5] = (int64_t)e.wino.lds_bytes; info[6] = 32; info[7] = e.wino.p.M * 4; info[8] = 8; info[9] = 1; info[10] = e.wino.p.R;
+        info[11] = e.wino.ni;
     } else if (e.kind == 8) {
         info[1] = 3; info[2] = 1; info[3] = e.block16.small; info[4] = e.block16.p.total_blocks;
         info[5] = (int64_t)e.block16.lds_bytes; info[6] = 32; info[7] = e.block16.p.M2; info[8] = 32; info[9] = 1;

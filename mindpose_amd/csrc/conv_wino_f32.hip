@@ -42,9 +42,9 @@ __device__ __forceinline__ void wg_barrier() {
 template <int NI, int OCC>
 __global__ __launch_bounds__(256, OCC) void conv_wino_f32_kernel(const WinoParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int raw_buf = kCK * p.cin_plane;
+    const int raw_buf = kCK * p.cin_plane + 4;  // + one float4 that absorbs the stores of threads without a staging unit
     float* __restrict__ lds_raw = smem;                 // [2][raw_buf]
-    float* __restrict__ lds_v = smem + 2 * raw_buf;     // [16][kCK][kTP]
+    float* __restrict__ lds_v = smem + 2 * raw_buf;     // [2][16][kCK][kTP]
     float* __restrict__ lds_x = smem;                   // epilogue: [16][16][kXP] over everything
 
     MP_STAMP(t_start);
@@ -64,41 +64,42 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_f32_kernel(const WinoParam
     const int HW = p.H * p.W;
 
     {   // zero both raw buffers once: halo rows / columns are never written by the chunk copies
-        const int n4 = (2 * raw_buf) >> 2;
+        const int n4 = (2 * raw_buf) >> 2;  // raw_buf is a multiple of 4
         float4* z = reinterpret_cast<float4*>(lds_raw);
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int i = tid; i < n4; i += 256) z[i] = zero;
     }
 
-    // staging tables: float4 units of the chunk's rows
+    // staging tables: float4 units of the chunk's rows.  Branch-free use: a unit outside the image loads zeros (range-checked
+    // buffer load) and stores them - halo rows are rewritten with zeros, harmless - and a thread without a unit stores its
+    // zeros into the spare float4 behind the buffer.
     unsigned isrc[NI];
     int idst[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const unsigned u = tid + 256 * i;
         isrc[i] = kOob;
-        idst[i] = 0;
+        idst[i] = kCK * p.cin_plane;
         if (u < (unsigned)(kCK * p.upc)) {
             const unsigned c = fastdiv(u, p.upc, p.magic_upc);
             const unsigned rem = u - c * p.upc;
             const unsigned r = fastdiv(rem, p.upr, p.magic_upr);
             const unsigned xu = rem - r * p.upr;
             const int yin = y_in0 + (int)r;
-            if (yin >= 0 && yin < p.H) {
-                isrc[i] = (c * HW + yin * p.W + xu * 4) * 4u;
-                idst[i] = (int)(c * p.cin_plane + r * p.Wp + 1 + xu * 4);
-            }
+            if (yin >= 0 && yin < p.H) isrc[i] = (c * HW + yin * p.W + xu * 4) * 4u;
+            idst[i] = (int)(c * p.cin_plane + r * p.Wp + 1 + xu * 4);
         }
     }
     const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x + (size_t)n * p.Cin * HW, (size_t)p.Cin * HW * 4);
     const __amdgpu_buffer_rsrc_t rs_u = make_rsrc(p.u, (size_t)(p.Cin >> 2) * 16 * 4 * p.Cout_pad16 * 4);
 
-    // transform item of this thread: (cin, pair of adjacent tiles)
+    // transform item of this thread: (cin, pair of adjacent tiles); the threads beyond the item count repeat the first items
+    // (same values to the same addresses) so that the transform needs no branch
     const int pairs = p.M >> 1;
-    const bool xf_on = tid < kCK * pairs;
     int xf_raw = 0, xf_v = 0;
     {
-        const unsigned t = xf_on ? tid : 0;
+        const int items = kCK * pairs;
+        const unsigned t = tid < items ? tid : tid - items;
         const unsigned c = fastdiv(t, pairs, p.magic_pairs);
         const unsigned tile0 = (t - c * pairs) * 2;
         const unsigned ty = fastdiv(tile0, p.TW, p.magic_tw);
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_f32_kernel(const WinoParam
     }
     const unsigned u_xi = (unsigned)(4 * p.Cout_pad16) * 4u;        // next xi
     const unsigned u_q = (unsigned)(16 * 4 * p.Cout_pad16) * 4u;    // next k-step (4 input channels)
-    float ucur[4][2][2];  // loaded at the head of a chunk, first used after its input transform
+    float ucur[4][2][2], unext[4][2][2];
     auto load_u = [&](int ch, float (&dst)[4][2][2]) {
         const unsigned base = (unsigned)(ch * 2) * u_q;
 #pragma unroll
@@ -125,24 +126,50 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_f32_kernel(const WinoParam
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
-                    dst[i][nb][q] = buf_load1(rs_u, u_off[nb] == kOob ? kOob : u_off[nb] + base + q * u_q + i * u_xi);
+                    dst[i][nb][q] = buf_load1(rs_u, u_off[nb] + base + q * u_q + i * u_xi);  // kOob + offset stays out of range
     };
 
     f32x4 vin[NI];
     auto stage_load = [&](int ch) {
         const unsigned xo = (unsigned)(ch * kCK) * HW * 4u;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) vin[i] = buf_load4(rs_x, isrc[i] == kOob ? kOob : isrc[i] + xo);
+        for (int i = 0; i < NI; ++i) vin[i] = buf_load4(rs_x, isrc[i] + xo);  // kOob + offset stays out of range
     };
     auto stage_store = [&](int buf) {
         float* __restrict__ d0 = lds_raw + buf * raw_buf;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            if (isrc[i] != kOob) {
-                float* d = d0 + idst[i];
-                d[0] = vin[i].x; d[1] = vin[i].y; d[2] = vin[i].z; d[3] = vin[i].w;
-            }
+            float* d = d0 + idst[i];
+            d[0] = vin[i].x; d[1] = vin[i].y; d[2] = vin[i].z; d[3] = vin[i].w;
         }
+    };
+    // input transform of one chunk: raw[rb] -> V[vb]; split in three parts so that the MFMA stream can be woven between them
+    float xd[4][6], xt[4][6];
+    auto xf_read = [&](int rb) {
+        const float* __restrict__ src = lds_raw + rb * raw_buf + xf_raw;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(src + r * p.Wp);
+            const float2 c2 = *reinterpret_cast<const float2*>(src + r * p.Wp + 4);
+            xd[r][0] = a.x; xd[r][1] = a.y; xd[r][2] = a.z; xd[r][3] = a.w; xd[r][4] = c2.x; xd[r][5] = c2.y;
+        }
+    };
+    auto xf_cols = [&]() {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            xt[0][c] = xd[0][c] - xd[2][c];
+            xt[1][c] = xd[1][c] + xd[2][c];
+            xt[2][c] = xd[2][c] - xd[1][c];
+            xt[3][c] = xd[1][c] - xd[3][c];
+        }
+    };
+    auto xf_rows_write = [&](int vb, int i) {  // row i of the column-transformed patch -> xi = 4 i .. 4 i + 3 of both tiles
+        float* __restrict__ dst = lds_v + vb * kVFloats + xf_v;
+        float va[4], vbv[4];
+        va[0] = xt[i][0] - xt[i][2]; va[1] = xt[i][1] + xt[i][2]; va[2] = xt[i][2] - xt[i][1]; va[3] = xt[i][1] - xt[i][3];
+        vbv[0] = xt[i][2] - xt[i][4]; vbv[1] = xt[i][3] + xt[i][4]; vbv[2] = xt[i][4] - xt[i][3]; vbv[3] = xt[i][3] - xt[i][5];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float2*>(dst + (i * 4 + j) * (kCK * kTP)) = make_float2(va[j], vbv[j]);
     };
 
     f32x4 acc[4][3][2];
@@ -153,56 +180,37 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_f32_kernel(const WinoParam
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) acc[i][mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // prologue: raw chunk 0 (and 1) staged, chunk 0 transformed
     stage_load(0);
+    load_u(0, ucur);
     __syncthreads();  // zero fill complete
     stage_store(0);
+    stage_load(1);
+    wg_barrier();
+    xf_read(0);
+    xf_cols();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xf_rows_write(0, i);
+    stage_store(1);
     wg_barrier();
     MP_STAMP(t_pro);
 
+    // chunk ch: the 48 MFMAs of this wave over V[ch & 1], with the input transform of chunk ch + 1 (raw[(ch + 1) & 1] ->
+    // V[(ch + 1) & 1]) woven between them; the raw rows of chunk ch + 2 fly in from global memory meanwhile.  The body is
+    // branch-free and the same for every chunk (past the last chunk the buffer loads are out of range and return zeros, the
+    // transform works on stale rows into a V buffer nobody reads): one loop, no peeled copy, the accumulators stay put.
     const int a_base = wave * 4 * (kCK * kTP) + lq * kTP + lr;
     for (int ch = 0; ch < p.n_chunks; ++ch) {
-        const bool more = ch + 1 < p.n_chunks;
         MP_STAMP(t0);
-        if (more) stage_load(ch + 1);
-        load_u(ch, ucur);
-        // ---- input transform of chunk ch: raw[ch & 1] -> V
-        if (xf_on) {
-            const float* __restrict__ src = lds_raw + (ch & 1) * raw_buf + xf_raw;
-            float d[4][6];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(src + r * p.Wp);
-                const float2 c2 = *reinterpret_cast<const float2*>(src + r * p.Wp + 4);
-                d[r][0] = a.x; d[r][1] = a.y; d[r][2] = a.z; d[r][3] = a.w; d[r][4] = c2.x; d[r][5] = c2.y;
-            }
-            float t[4][6];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                t[0][c] = d[0][c] - d[2][c];
-                t[1][c] = d[1][c] + d[2][c];
-                t[2][c] = d[2][c] - d[1][c];
-                t[3][c] = d[1][c] - d[3][c];
-            }
-            float* __restrict__ dst = lds_v + xf_v;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float va[4], vb[4];
-                va[0] = t[i][0] - t[i][2]; va[1] = t[i][1] + t[i][2]; va[2] = t[i][2] - t[i][1]; va[3] = t[i][1] - t[i][3];
-                vb[0] = t[i][2] - t[i][4]; vb[1] = t[i][3] + t[i][4]; vb[2] = t[i][4] - t[i][3]; vb[3] = t[i][3] - t[i][5];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    *reinterpret_cast<float2*>(dst + (i * 4 + j) * (kCK * kTP)) = make_float2(va[j], vb[j]);
-            }
-        }
-        MP_STAMP(t1);
-        wg_barrier();  // V complete
-        MP_STAMP(t2);
-        // ---- 16 GEMMs, this wave's four xi
+        stage_load(ch + 2);
+        load_u(ch + 1, unext);
+        const float* __restrict__ vcur = lds_v + (ch & 1) * kVFloats + a_base;
+        xf_read((ch + 1) & 1);
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float* __restrict__ va = lds_v + a_base + i * (kCK * kTP) + q * 4 * kTP;
+                const float* __restrict__ va = vcur + i * (kCK * kTP) + q * 4 * kTP;
                 float av[3];
 #pragma unroll
                 for (int mb = 0; mb < 3; ++mb) av[mb] = va[mb * 16];
@@ -211,13 +219,22 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_f32_kernel(const WinoParam
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb)
                         acc[i][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], ucur[i][nb][q], acc[i][mb][nb], 0, 0, 0);
+                if (q == 0 && i == 1) xf_cols();
+                if (q == 0 && i >= 2) xf_rows_write((ch + 1) & 1, i - 2);
+                if (q == 1 && i < 2) xf_rows_write((ch + 1) & 1, i + 2);
             }
         MP_STAMP(t3);
-        if (more) stage_store((ch + 1) & 1);
+        stage_store(ch & 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) ucur[i][nb][q] = unext[i][nb][q];
         MP_STAMP(t4);
-        wg_barrier();  // raw[(ch + 1) & 1] visible, V free
+        wg_barrier();
         MP_STAMP(t5);
-        s_xf += t1 - t0; s_b1 += t2 - t1; s_mm += t3 - t2; s_st += t4 - t3; s_b2 += t5 - t4;
+        s_mm += t3 - t0; s_st += t4 - t3; s_b2 += t5 - t4;
     }
     MP_STAMP(t_epi);
 
@@ -379,7 +396,7 @@ int wino_configure(const mp_conv_desc* d, WinoLaunch& L) {
     if (kCK * p.upc > 3 * 256) return MP_ERR_UNSUPPORTED;
     p.relu = d->relu;
     p.magic_upr = magic_of(p.upr); p.magic_upc = magic_of(p.upc); p.magic_tw = magic_of(p.TW); p.magic_pairs = magic_of(p.M >> 1);
-    const size_t main_bytes = ((size_t)2 * kCK * p.cin_plane + kVFloats) * 4, x_bytes = (size_t)kXFloats * 4;
+    const size_t main_bytes = ((size_t)2 * (kCK * p.cin_plane + 4) + 2 * kVFloats) * 4, x_bytes = (size_t)kXFloats * 4;
     L.lds_bytes = main_bytes > x_bytes ? main_bytes : x_bytes;
     L.ni = (kCK * p.upc + 255) / 256;
     if (L.lds_bytes > 150 * 1024) return MP_ERR_UNSUPPORTED;

@@ -159,10 +159,22 @@ def _autotune(key, macs, n_variants, launch) -> int:
     return best
 
 
-def tune_conv_variant(lib, d, x, packed, scale, shift, res1, res2, out, half: bool = False) -> int:
+F32_VARIANTS = 8   # direct MFMA tile variants (csrc/conv_mfma.h ConvVariant)
+F32_WINOGRAD = 8   # the tuner's index of the Winograd F(2x2,3x3) form (csrc/conv_wino_f32.hip)
+
+
+def winograd_enabled() -> bool:
+    """``MINDPOSE_WINOGRAD=0`` keeps every fp32 3x3 convolution on the direct kernel (bit-identical to round 1's results)."""
+    return os.environ.get("MINDPOSE_WINOGRAD", "1") != "0"
+
+
+def tune_conv_variant(lib, d, x, packed, scale, shift, res1, res2, out, half: bool = False, packed_u=None) -> int:
     """Pick the tile variant for one conv launch shape by timing the candidates on the layer's real buffers.  Results
-    are cached per shape, so a network's ~40 distinct shapes are tuned once per process."""
+    are cached per shape, so a network's ~40 distinct shapes are tuned once per process.  ``packed_u`` (fp32 only): the
+    Winograd-transformed weights; the Winograd form then competes as index ``F32_WINOGRAD``."""
     key = tuple(getattr(d, f) for f, _ in d._fields_) + (res1 is not None, res2 is not None, str(out.device), half)
+    if packed_u is not None:
+        key += ("wino",)
     macs = d.n * d.conv_h * d.conv_w * d.cout * d.cin * d.kh * d.kw
     stream = _lib.stream()
     # in-place accumulation (out aliases res1) must not be disturbed by trial launches: tune into a scratch copy
@@ -173,10 +185,13 @@ def tune_conv_variant(lib, d, x, packed, scale, shift, res1, res2, out, half: bo
     fn = lib.mp_f16_conv2d_fwd if half else lib.mp_conv2d_fwd_variant
 
     def launch(v):
+        if not half and v == F32_WINOGRAD:
+            return lib.mp_conv2d_winograd_fwd(ctypes.byref(d), _lib.ptr(x), _lib.ptr(packed_u), _lib.ptr(scale), _lib.ptr(shift),
+                                              _lib.ptr(res1), _lib.ptr(res2), _lib.ptr(trial_out), stream)
         return fn(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(res1),
                   _lib.ptr(res2), _lib.ptr(trial_out), stream)
 
-    return _autotune(key, macs, F16_VARIANTS if half else 8, launch)
+    return _autotune(key, macs, F16_VARIANTS if half else (F32_VARIANTS + (1 if packed_u is not None else 0)), launch)
 
 
 class Plan:
@@ -328,6 +343,19 @@ class Plan:
         self._packed[key] = packed
         return packed
 
+    def _pack_winograd(self, weight: torch.Tensor, cout: int, cin: int) -> torch.Tensor:
+        """U = G w G^T of a 3x3 weight, [Cin/4][16][4][Cout_pad16] fp32 (mp_conv_winograd_pack_weight)."""
+        key = (id(weight), "wino")
+        if key in self._packed:
+            return self._packed[key]
+        w = weight.detach().to(self.device, torch.float32).contiguous()
+        packed = torch.empty(self.lib.mp_conv_winograd_packed_weight_bytes(cout, cin) // 4, device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.mp_conv_winograd_pack_weight(_lib.ptr(w), _lib.ptr(packed), cout, cin, _lib.stream()),
+                   "mp_conv_winograd_pack_weight")
+        self.keep += [w, packed]
+        self._packed[key] = packed
+        return packed
+
     def _affine(self, cout: int, bn: Optional[BatchNorm2d], bias: Optional[torch.Tensor], half: bool = False):
         # keyed on both parameter holders and the width: a conv with neither BatchNorm nor bias must not share the
         # ones / zeros pair of another width (the kernel reads cout entries)
@@ -376,7 +404,18 @@ class Plan:
                           out_off_y=0, out_off_x=0, relu=int(relu), tap_dilation_unused=0)
         if half and upsample != 1:
             raise NotImplementedError("fp16 plans add up-sampled terms with fuse_sum, not through the conv epilogue")
-        variant = tune_conv_variant(self.lib, d, x, packed, scale, shift, res1, res2, out, half=half)
+        packed_u = None
+        if (not half and winograd_enabled() and os.environ.get("MINDPOSE_AUTOTUNE", "1") != "0"
+                and self.lib.mp_conv_winograd_supported(ctypes.byref(d)) == 0):
+            packed_u = self._pack_winograd(conv.weight, conv.out_channels, cin)
+        variant = tune_conv_variant(self.lib, d, x, packed, scale, shift, res1, res2, out, half=half, packed_u=packed_u)
+        if not half and variant == F32_WINOGRAD:
+            _lib.check(self.lib.mp_plan_add_conv_winograd(self.handle, ctypes.byref(d), _lib.ptr(x), _lib.ptr(packed_u), _lib.ptr(scale),
+                                                          _lib.ptr(shift), _lib.ptr(res1), _lib.ptr(res2), _lib.ptr(out)),
+                       "mp_plan_add_conv_winograd")
+            self.layer_info.append(dict(kind="conv_winograd", k=k, stride=s, cin=cin, cout=conv.out_channels, h=h, w=w, n=n,
+                                        macs=n * ho * wo * conv.out_channels * cin * k * k))
+            return out
         add = self.lib.mp_plan_add_conv_f16 if half else self.lib.mp_plan_add_conv_variant
         _lib.check(add(self.handle, ctypes.byref(d), variant, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift),
                        _lib.ptr(res1), _lib.ptr(res2), _lib.ptr(out)), "mp_plan_add_conv")
