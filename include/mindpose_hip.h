@@ -166,7 +166,7 @@ int mp_conv2d_fwd_variant(const mp_conv_desc* desc, int variant, const float* x_
  * (folded BatchNorm scale/shift, res1, res2, ReLU) and result as mp_conv2d_fwd up to fp32 rounding (the sums are associated
  * differently).  Needs W % 4 == 0, H % 2 == 0, W <= 96, Cin % 8 == 0 and the plain output mapping; mp_conv_winograd_supported
  * returns MP_OK or MP_ERR_UNSUPPORTED for a descriptor.  The weights are transformed once: U = G w G^T,
- * [Cin/4][16][4][Cout_pad16] floats (mp_conv_winograd_packed_weight_bytes). */
+ * [Cin_pad4][Cout_pad16][16] floats (mp_conv_winograd_packed_weight_bytes). */
 size_t mp_conv_winograd_packed_weight_bytes(int cout, int cin);
 int mp_conv_winograd_pack_weight(const float* w_dev, float* packed_dev, int cout, int cin, mp_stream_t stream);
 int mp_conv_winograd_supported(const mp_conv_desc* desc);

@@ -6,7 +6,7 @@ namespace mp {
 
 struct WinoParams {
     const float* x;
-    const float* u;  // transformed weights [Cin/4][16][4][Cout_pad16]
+    const float* u;  // transformed weights [Cin_pad4][Cout_pad16][16]
     const float* scale;
     const float* shift;
     const float* res1;

@@ -39,8 +39,8 @@ __device__ __forceinline__ void wg_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int NI, int OCC>
-__global__ __launch_bounds__(256, OCC) void conv_wino_f32_kernel(const WinoParams p) {
+template <int NI, bool QROW>
+__global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int raw_buf = kCK * p.cin_plane + 4;  // + one float4 that absorbs the stores of threads without a staging unit
     float* __restrict__ lds_raw = smem;                 // [2][raw_buf]
@@ -62,13 +62,6 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_f32_kernel(const WinoParam
     const int band = b % p.bands, n = b / p.bands;
     const int y0 = band * p.R, y_in0 = y0 - 1;
     const int HW = p.H * p.W;
-
-    {   // zero both raw buffers once: halo rows / columns are never written by the chunk copies
-        const int n4 = (2 * raw_buf) >> 2;  // raw_buf is a multiple of 4
-        float4* z = reinterpret_cast<float4*>(lds_raw);
-        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = tid; i < n4; i += 256) z[i] = zero;
-    }
 
     // staging tables: float4 units of the chunk's rows.  Branch-free use: a unit outside the image loads zeros (range-checked
     // buffer load) and stores them - halo rows are rewritten with zeros, harmless - and a thread without a unit stores its
@@ -108,25 +101,26 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_f32_kernel(const WinoParam
         xf_v = c * kTP + tile0;
     }
 
-    // U fragments of this wave: xi = 4 * wave + i, cout block nb, k-step q of the chunk
+    // U fragments of this wave: xi = 4 * wave + i, cout block nb, k-step q of the chunk.  U is stored [cin][cout][xi]: the four
+    // xi of a wave are ONE 16-byte load per (nb, q) - 4 loads per chunk instead of 16
     unsigned u_off[2];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
         const int co = ct * 32 + nb * 16 + lr;
-        u_off[nb] = co < p.Cout_pad16 ? (unsigned)((wave * 4 * 4 + lq) * p.Cout_pad16 + co) * 4u : kOob;
+        u_off[nb] = co < p.Cout_pad16 ? (unsigned)((lq * p.Cout_pad16 + co) * 16 + wave * 4) * 4u : kOob;
     }
-    const unsigned u_xi = (unsigned)(4 * p.Cout_pad16) * 4u;        // next xi
-    const unsigned u_q = (unsigned)(16 * 4 * p.Cout_pad16) * 4u;    // next k-step (4 input channels)
+    const unsigned u_q = (unsigned)(4 * p.Cout_pad16 * 16) * 4u;  // next k-step (4 input channels)
     float ucur[4][2][2], unext[4][2][2];
     auto load_u = [&](int ch, float (&dst)[4][2][2]) {
         const unsigned base = (unsigned)(ch * 2) * u_q;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+            for (int q = 0; q < 2; ++q) {
+                const f32x4 v = buf_load4(rs_u, u_off[nb] + base + q * u_q);  // kOob + offset stays out of range
 #pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    dst[i][nb][q] = buf_load1(rs_u, u_off[nb] + base + q * u_q + i * u_xi);  // kOob + offset stays out of range
+                for (int i = 0; i < 4; ++i) dst[i][nb][q] = v[i];
+            }
     };
 
     f32x4 vin[NI];
@@ -180,17 +174,33 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_f32_kernel(const WinoParam
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) acc[i][mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // prologue: raw chunk 0 (and 1) staged, chunk 0 transformed
-    stage_load(0);
+    // prologue: the raw rows of chunks 0 and 1 are requested together, right away (second register set: the accumulators are not
+    // live yet); the zero fill of the halo and the first U fragments run under their latency
+    f32x4 vin1[NI];
+    {
+        const unsigned xo = (unsigned)kCK * HW * 4u;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            vin[i] = buf_load4(rs_x, isrc[i]);
+            vin1[i] = buf_load4(rs_x, isrc[i] + xo);
+        }
+    }
     load_u(0, ucur);
-    __syncthreads();  // zero fill complete
+    {   // zero both raw buffers once: the halo columns are never written by the chunk copies
+        const int n4 = (2 * raw_buf) >> 2;  // raw_buf is a multiple of 4
+        float4* z = reinterpret_cast<float4*>(lds_raw);
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < n4; i += 256) z[i] = zero;
+    }
+    wg_barrier();  // zero fill complete
     stage_store(0);
-    stage_load(1);
     wg_barrier();
     xf_read(0);
     xf_cols();
 #pragma unroll
     for (int i = 0; i < 4; ++i) xf_rows_write(0, i);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) vin[i] = vin1[i];
     stage_store(1);
     wg_barrier();
     MP_STAMP(t_pro);
@@ -238,84 +248,104 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_f32_kernel(const WinoParam
     }
     MP_STAMP(t_epi);
 
-    // ---- accumulators -> LDS -> output transform -> epilogue, one 16-channel half at a time
+    // ---- accumulators -> LDS -> output transform -> epilogue, one 16-channel half at a time.  A thread (0..191) takes cout
+    // co_l of the half and the four tiles 4 quad .. 4 quad + 3; QROW (launch condition: full 48-tile bands, TW % 4 == 0): those
+    // four tiles are eight consecutive pixels of two rows -> 16-byte residual loads and stores.  The residual loads are issued
+    // before the accumulators go to LDS, so their latency runs under the exchange.
     const int plane_o = HW;
-    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(p.out + (size_t)n * p.Cout * plane_o, (size_t)p.Cout * plane_o * 4);
-    const unsigned co_l = fastdiv((unsigned)tid, 12, 0x15555556u);  // tid / 12
-    const unsigned quad = tid - co_l * 12;
+    const size_t img_o = (size_t)p.Cout * plane_o * 4;
+    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(p.out + (size_t)n * p.Cout * plane_o, img_o);
+    const __amdgpu_buffer_rsrc_t rs_r1 = make_rsrc(p.res1 ? p.res1 + (size_t)n * p.Cout * plane_o : p.out, p.res1 ? img_o : 0);
+    const __amdgpu_buffer_rsrc_t rs_r2 = make_rsrc(p.res2 ? p.res2 + (size_t)n * p.Cout * plane_o : p.out, p.res2 ? img_o : 0);
     const bool ep_on = tid < 192;
+    const unsigned co_l = ep_on ? fastdiv((unsigned)tid, 12, 0x15555556u) : 0u;  // tid / 12
+    const unsigned quad = ep_on ? tid - co_l * 12 : 0u;
+    const unsigned row_b = (unsigned)p.W * 4u;
+    unsigned pix[QROW ? 1 : 4];  // byte offset of a tile's first output pixel inside a channel plane; kOob: tile / row not there
+#pragma unroll
+    for (int e = 0; e < (QROW ? 1 : 4); ++e) {
+        const unsigned tile = quad * 4 + e;
+        const unsigned ty = fastdiv(tile, p.TW, p.magic_tw);
+        const unsigned tx = tile - ty * p.TW;
+        const int oy = y0 + 2 * (int)ty;
+        pix[e] = (ep_on && tile < (unsigned)p.M && oy < p.H) ? (unsigned)(oy * p.W + 2 * tx) * 4u : kOob;
+    }
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
         if (ct * 32 + nb * 16 >= p.Cout_pad16) break;  // workgroup-uniform
+        const int co = ct * 32 + nb * 16 + (int)co_l;
+        const unsigned co_off = co < p.Cout ? (unsigned)co * plane_o * 4u : kOob;  // kOob + pixel offset stays out of range
+        f32x4 r1q[2][2], r2q[2][2];
+        float2 r1v[4][2], r2v[4][2];
+        if constexpr (QROW) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const unsigned o = (pix[0] == kOob ? kOob : co_off + pix[0]) + a * row_b + h2 * 16u;
+                    r1q[a][h2] = buf_load4(rs_r1, o);
+                    r2q[a][h2] = buf_load4(rs_r2, o);
+                }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const unsigned o = (pix[e] == kOob ? kOob : co_off + pix[e]) + a * row_b;
+                    r1v[e][a] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_r1, o, 0, 0));
+                    r2v[e][a] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_r2, o, 0, 0));
+                }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int mb = 0; mb < 3; ++mb)
                 *reinterpret_cast<f32x4*>(lds_x + ((wave * 4 + i) * 16 + lr) * kXP + mb * 16 + lq * 4) = acc[i][mb][nb];
         wg_barrier();
-        const int co = ct * 32 + nb * 16 + (int)co_l;
-        if (ep_on && co < p.Cout) {
+        if (ep_on) {
             f32x4 m[16];
 #pragma unroll
             for (int xi = 0; xi < 16; ++xi) m[xi] = *reinterpret_cast<const f32x4*>(lds_x + (xi * 16 + co_l) * kXP + quad * 4);
-            const float sc = p.scale[co], sh = p.shift[co];
-            const unsigned co_off = (unsigned)co * plane_o;
-            unsigned off[4];
-            float y[4][4];
+            const int cc = co < p.Cout ? co : 0;
+            const float sc = p.scale[cc], sh = p.shift[cc];
+            // the four tiles side by side: component e of every vector = tile e
+            f32x4 sv[2][4], y[2][2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const unsigned tile = quad * 4 + e;
-                const unsigned ty = fastdiv(tile, p.TW, p.magic_tw);
-                const unsigned tx = tile - ty * p.TW;
-                const int oy = y0 + 2 * (int)ty;
-                off[e] = (tile < (unsigned)p.M && oy < p.H) ? (co_off + oy * p.W + 2 * tx) * 4u : kOob;
-                float s[2][4];
+            for (int j = 0; j < 4; ++j) {
+                sv[0][j] = m[0 * 4 + j] + m[1 * 4 + j] + m[2 * 4 + j];
+                sv[1][j] = m[1 * 4 + j] - m[2 * 4 + j] - m[3 * 4 + j];
+            }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    s[0][j] = m[0 * 4 + j][e] + m[1 * 4 + j][e] + m[2 * 4 + j][e];
-                    s[1][j] = m[1 * 4 + j][e] - m[2 * 4 + j][e] - m[3 * 4 + j][e];
-                }
+            for (int a = 0; a < 2; ++a) {
+                y[a][0] = (sv[a][0] + sv[a][1] + sv[a][2]) * sc + sh;  // left pixel of each tile, output row a
+                y[a][1] = (sv[a][1] - sv[a][2] - sv[a][3]) * sc + sh;  // right pixel
+            }
+            if constexpr (QROW) {
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
-                    y[e][a * 2 + 0] = (s[a][0] + s[a][1] + s[a][2]) * sc + sh;
-                    y[e][a * 2 + 1] = (s[a][1] - s[a][2] - s[a][3]) * sc + sh;
+                    f32x4 lo = (f32x4){y[a][0][0], y[a][1][0], y[a][0][1], y[a][1][1]};
+                    f32x4 hi = (f32x4){y[a][0][2], y[a][1][2], y[a][0][3], y[a][1][3]};
+                    lo += r1q[a][0] + r2q[a][0];
+                    hi += r1q[a][1] + r2q[a][1];
+                    if (p.relu) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { lo[k] = fmaxf(lo[k], 0.f); hi[k] = fmaxf(hi[k], 0.f); }
+                    }
+                    const unsigned o = (pix[0] == kOob ? kOob : co_off + pix[0]) + a * row_b;
+                    buf_store4(rs_o, o, lo);
+                    buf_store4(rs_o, o + 16u, hi);
                 }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        float2 v = make_float2(y[a][0][e] + r1v[e][a].x + r2v[e][a].x, y[a][1][e] + r1v[e][a].y + r2v[e][a].y);
+                        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs_o,
+                                                              (pix[e] == kOob ? kOob : co_off + pix[e]) + a * row_b, 0, 0);
+                    }
             }
-            const unsigned row = (unsigned)p.W * 4u;
-            if (p.res1) {
-                const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.res1 + (size_t)n * p.Cout * plane_o, (size_t)p.Cout * plane_o * 4);
-                float2 r[4][2];
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int a = 0; a < 2; ++a)
-                        r[e][a] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, off[e] == kOob ? kOob : off[e] + a * row, 0, 0));
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) { y[e][a * 2] += r[e][a].x; y[e][a * 2 + 1] += r[e][a].y; }
-            }
-            if (p.res2) {
-                const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.res2 + (size_t)n * p.Cout * plane_o, (size_t)p.Cout * plane_o * 4);
-                float2 r[4][2];
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int a = 0; a < 2; ++a)
-                        r[e][a] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, off[e] == kOob ? kOob : off[e] + a * row, 0, 0));
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) { y[e][a * 2] += r[e][a].x; y[e][a * 2 + 1] += r[e][a].y; }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    float2 v = make_float2(y[e][a * 2], y[e][a * 2 + 1]);
-                    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs_o, off[e] == kOob ? kOob : off[e] + a * row, 0, 0);
-                }
         }
         wg_barrier();  // the exchange buffer is free for the second half
     }
@@ -331,7 +361,7 @@ __global__ __launch_bounds__(256, OCC) void conv_wino_f32_kernel(const WinoParam
 #endif
 }
 
-// U = G g G^T per (cout, cin), laid out [Cin/4][xi][4][Cout_pad16] (the direct kernel's packed layout with 16 "taps")
+// U = G g G^T per (cout, cin), laid out [Cin_pad4][Cout_pad16][16 xi]
 __global__ __launch_bounds__(256) void pack_weight_wino_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin,
                                                                int cin_pad4, int cout_pad16) {
     const size_t total = (size_t)cin_pad4 * cout_pad16;
@@ -350,17 +380,10 @@ __global__ __launch_bounds__(256) void pack_weight_wino_kernel(const float* __re
             t[2][c] = 0.5f * (g[0][c] - g[1][c] + g[2][c]);
             t[3][c] = g[2][c];
         }
+        float4* o4 = reinterpret_cast<float4*>(out + i * 16);
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            float u[4];
-            u[0] = t[a][0];
-            u[1] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
-            u[2] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
-            u[3] = t[a][2];
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                out[((size_t)((ci >> 2) * 16 + a * 4 + c) * 4 + (ci & 3)) * cout_pad16 + co] = u[c];
-        }
+        for (int a = 0; a < 4; ++a)
+            o4[a] = make_float4(t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]);
     }
 }
 
@@ -416,19 +439,12 @@ int wino_launch(const WinoLaunch& L0, hipStream_t s) {
         hipLaunchKernelGGL(kern, dim3(L.p.total_blocks), dim3(256), L.lds_bytes, s, L.p);
         return check_launch();
     };
-    static const int occ = [] { const char* e = getenv("MP_WINO_OCC"); return e ? atoi(e) : 2; }();  // experiments: 3 = 168-VGPR build
-    if (occ == 3) {
-        switch (L.ni) {
-            case 1: return go(conv_wino_f32_kernel<1, 3>);
-            case 2: return go(conv_wino_f32_kernel<2, 3>);
-            case 3: return go(conv_wino_f32_kernel<3, 3>);
-            default: return MP_ERR_UNSUPPORTED;
-        }
-    }
+    // QROW: the four tiles of an epilogue item are eight consecutive pixels of two rows
+    const bool qrow = L.p.M == kTP && L.p.TW % 4 == 0 && L.p.H % L.p.R == 0;
     switch (L.ni) {
-        case 1: return go(conv_wino_f32_kernel<1, 2>);
-        case 2: return go(conv_wino_f32_kernel<2, 2>);
-        case 3: return go(conv_wino_f32_kernel<3, 2>);
+        case 1: return qrow ? go(conv_wino_f32_kernel<1, true>) : go(conv_wino_f32_kernel<1, false>);
+        case 2: return qrow ? go(conv_wino_f32_kernel<2, true>) : go(conv_wino_f32_kernel<2, false>);
+        case 3: return qrow ? go(conv_wino_f32_kernel<3, true>) : go(conv_wino_f32_kernel<3, false>);
         default: return MP_ERR_UNSUPPORTED;
     }
 }

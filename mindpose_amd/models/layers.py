@@ -344,7 +344,7 @@ class Plan:
         return packed
 
     def _pack_winograd(self, weight: torch.Tensor, cout: int, cin: int) -> torch.Tensor:
-        """U = G w G^T of a 3x3 weight, [Cin/4][16][4][Cout_pad16] fp32 (mp_conv_winograd_pack_weight)."""
+        """U = G w G^T of a 3x3 weight, [Cin_pad4][Cout_pad16][16] fp32 (mp_conv_winograd_pack_weight)."""
         key = (id(weight), "wino")
         if key in self._packed:
             return self._packed[key]
