@@ -91,8 +91,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams 
     const int pairs = p.M >> 1;
     int xf_raw = 0, xf_v = 0;
     {
-        const int items = kCK * pairs;
-        const unsigned t = tid < items ? tid : tid - items;
+        const int items = kCK * pairs;  // <= 192
+        const unsigned t = (unsigned)tid % (unsigned)items;
         const unsigned c = fastdiv(t, pairs, p.magic_pairs);
         const unsigned tile0 = (t - c * pairs) * 2;
         const unsigned ty = fastdiv(tile0, p.TW, p.magic_tw);

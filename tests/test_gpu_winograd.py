@@ -1,0 +1,144 @@
+"""GPU parity of the fp32 Winograd F(2x2,3x3) convolution (csrc/conv_wino_f32.hip) through the C ABI.
+
+The kernel replaces the direct kernel for the 3x3 stride-1 branch convolutions of hrnet.py:51-64 / 202-241 when the per-shape
+tuner finds it faster.  Same operands and epilogue; the sums are associated differently, so the comparison is against an fp64
+torch-CPU formulation at 2e-5 of the output scale (the direct kernel's own single-layer bar, tests/test_gpu_conv.py), and the
+direct kernel must be within the same distance of it.  Edge cases: bands that do not divide the height, fewer than 48 tiles per
+band, cout tiles with a partial second half, cout not a multiple of 16, 8 / 16 input channels (1-2 chunks), two residuals."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from mindpose_amd import _lib  # noqa: E402
+from mindpose_amd.models.layers import BatchNorm2d, Conv2d, Plan, F32_WINOGRAD  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+CASES = [
+    # n, cin, cout, h, w, relu, res1, res2
+    (3, 32, 32, 64, 48, True, True, False),     # W32 branch 0: 48 tiles per band, 16-byte epilogue
+    (2, 64, 64, 32, 24, True, True, False),     # branch 1
+    (2, 128, 128, 16, 12, True, False, False),  # branch 2: whole image per band, tile rows of 6 (8-byte epilogue)
+    (2, 256, 32, 64, 48, True, False, False),   # transition1.0: 32 chunks
+    (1, 64, 64, 64, 48, False, True, True),     # stage-1 bottleneck 3x3, two residuals, no ReLU
+    (2, 8, 16, 8, 8, True, True, False),        # one chunk, one 16-channel half, 16 tiles
+    (2, 16, 48, 20, 16, True, False, False),    # two chunks, second cout tile has one half, 40 tiles per band, H % R != 0
+    (3, 24, 40, 12, 20, False, True, False),    # cout not a multiple of 16 (padding channels masked), 3 chunks
+    (1, 32, 32, 6, 96, True, False, False),     # widest supported row: one tile row per band
+    (2, 48, 96, 10, 28, True, True, False),     # bands of 3 tile rows over 5: last band partly outside the image
+]
+
+
+def _desc(n, cin, cout, h, w, relu):
+    return _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=3, kw=3, stride=1, pad_top=1, pad_left=1, conv_h=h, conv_w=w, out_h=h,
+                         out_w=w, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=int(relu), tap_dilation_unused=0)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"n{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}" for c in CASES])
+def test_winograd_conv_vs_fp64_and_direct(case):
+    n, cin, cout, h, w, relu, has_r1, has_r2 = case
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(cin * 131 + cout * 7 + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    r1 = torch.randn(n, cout, h, w, generator=g) if has_r1 else None
+    r2 = torch.randn(n, cout, h, w, generator=g) if has_r2 else None
+    ref = F.conv2d(x.double(), wt.double(), padding=1) * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]
+    for r in (r1, r2):
+        if r is not None:
+            ref = ref + r.double()
+    if relu:
+        ref = F.relu(ref)
+    d = _desc(n, cin, cout, h, w, relu)
+    assert lib.mp_conv_winograd_supported(ctypes.byref(d)) == 0
+    xd, wd, sc, sh = x.to(DEV), wt.to(DEV), scale.to(DEV), shift.to(DEV)
+    r1d, r2d = (None if r is None else r.to(DEV) for r in (r1, r2))
+    st = _lib.stream()
+    pu = torch.empty(lib.mp_conv_winograd_packed_weight_bytes(cout, cin) // 4, device=DEV)
+    _lib.check(lib.mp_conv_winograd_pack_weight(_lib.ptr(wd), _lib.ptr(pu), cout, cin, st), "pack U")
+    pd = torch.empty(lib.mp_conv_packed_weight_bytes(cout, cin, 3, 3) // 4, device=DEV)
+    _lib.check(lib.mp_conv_pack_weight(_lib.ptr(wd), _lib.ptr(pd), cout, cin, 3, 3, 0, 0, 0, st), "pack W")
+    out_w = torch.full((n, cout, h, w), float("nan"), device=DEV)  # every element must be written
+    out_d = torch.empty(n, cout, h, w, device=DEV)
+    _lib.check(lib.mp_conv2d_winograd_fwd(ctypes.byref(d), _lib.ptr(xd), _lib.ptr(pu), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(r1d),
+                                          _lib.ptr(r2d), _lib.ptr(out_w), st), "winograd")
+    _lib.check(lib.mp_conv2d_fwd(ctypes.byref(d), _lib.ptr(xd), _lib.ptr(pd), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(r1d), _lib.ptr(r2d),
+                                 _lib.ptr(out_d), st), "direct")
+    torch.cuda.synchronize()
+    span = float(ref.abs().max())
+    err_w = float((out_w.double().cpu() - ref).abs().max()) / span
+    err_d = float((out_d.double().cpu() - ref).abs().max()) / span
+    assert torch.isfinite(out_w).all()
+    assert err_w <= 2e-5, (err_w, err_d)
+    assert err_d <= 2e-5, (err_w, err_d)
+
+
+def test_winograd_result_is_deterministic_and_in_place_safe_with_residual_alias():
+    """Two launches give the same bits; res1 may alias out (the exchange-unit accumulation pattern of the plan)."""
+    lib = _lib.load()
+    n, c, h, w = 2, 32, 32, 24
+    g = torch.Generator().manual_seed(3)
+    x, wt = torch.randn(n, c, h, w, generator=g).to(DEV), (torch.randn(c, c, 3, 3, generator=g) * 0.06).to(DEV)
+    ones, zeros = torch.ones(c, device=DEV), torch.zeros(c, device=DEV)
+    base = torch.randn(n, c, h, w, generator=g).to(DEV)
+    d = _desc(n, c, c, h, w, False)
+    st = _lib.stream()
+    pu = torch.empty(lib.mp_conv_winograd_packed_weight_bytes(c, c) // 4, device=DEV)
+    _lib.check(lib.mp_conv_winograd_pack_weight(_lib.ptr(wt), _lib.ptr(pu), c, c, st), "pack U")
+    outs = []
+    for _ in range(2):
+        o = torch.empty_like(base)
+        _lib.check(lib.mp_conv2d_winograd_fwd(ctypes.byref(d), _lib.ptr(x), _lib.ptr(pu), _lib.ptr(ones), _lib.ptr(zeros), _lib.ptr(base),
+                                              None, _lib.ptr(o), st), "winograd")
+        outs.append(o)
+    acc = base.clone()
+    _lib.check(lib.mp_conv2d_winograd_fwd(ctypes.byref(d), _lib.ptr(x), _lib.ptr(pu), _lib.ptr(ones), _lib.ptr(zeros), _lib.ptr(acc), None,
+                                          _lib.ptr(acc), st), "winograd in place")
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(acc, outs[0])
+
+
+@pytest.mark.parametrize("bad", [dict(stride=2), dict(kh=1, kw=1, pad_top=0, pad_left=0), dict(w=6, conv_w=6, out_w=6), dict(h=7, conv_h=7, out_h=7),
+                                 dict(cin=12), dict(out_mul=2, out_rep=2, out_h=16, out_w=16), dict(w=100, conv_w=100, out_w=100)])
+def test_winograd_rejects_what_it_does_not_cover(bad):
+    lib = _lib.load()
+    f = dict(n=1, cin=16, h=8, w=8, cout=16, kh=3, kw=3, stride=1, pad_top=1, pad_left=1, conv_h=8, conv_w=8, out_h=8, out_w=8, out_mul=1,
+             out_rep=1, out_off_y=0, out_off_x=0, relu=0, tap_dilation_unused=0)
+    f.update(bad)
+    d = _lib.ConvDesc(**f)
+    assert lib.mp_conv_winograd_supported(ctypes.byref(d)) == -3  # MP_ERR_UNSUPPORTED
+
+
+def test_plan_takes_the_winograd_form_where_the_tuner_picks_it_and_env_turns_it_off(monkeypatch):
+    """A plan of one branch conv: with the tuner on, whichever form wins is recorded (kind 9 = Winograd) and the result stays
+    within 2e-5 of fp64; MINDPOSE_WINOGRAD=0 records the direct kernel."""
+    g = torch.Generator().manual_seed(11)
+    n, c, h, w = 16, 64, 32, 24
+    conv = Conv2d(c, c, 3, stride=1, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * 0.04)
+    bn = BatchNorm2d(c)
+    x = torch.randn(n, c, h, w, generator=g)
+    scale, shift = bn.folded()
+    ref = F.relu(F.conv2d(x.double(), conv.weight.detach().double(), padding=1) * scale.double()[None, :, None, None] + shift.double()[None, :, None, None])
+    kinds = []
+    for env in ("1", "0"):
+        monkeypatch.setenv("MINDPOSE_WINOGRAD", env)
+        plan = Plan(DEV)
+        xin = x.to(DEV)
+        out = plan.conv(xin, conv, bn, relu=True)
+        plan.run()
+        torch.cuda.synchronize()
+        info = plan.entry_info(0)
+        kinds.append(info["kind_id"])
+        assert float((out.double().cpu() - ref).abs().max() / ref.abs().max()) <= 2e-5
+        if info["kind_id"] == 9:
+            assert info["variant"] == F32_WINOGRAD and info["kind"] == "conv_winograd"
+    assert kinds[1] == 0  # switched off: direct kernel
+    assert kinds[0] in (0, 9)
