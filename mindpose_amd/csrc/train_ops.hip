@@ -4,6 +4,10 @@
 #include "common.h"
 
 #include <math.h>
+#include <stdlib.h>
+
+#include <mutex>
+#include <unordered_map>
 
 namespace mp {
 
@@ -520,6 +524,264 @@ __global__ __launch_bounds__(256) void bn16_bwd_apply_kernel(const u32x4_t* __re
     }
 }
 
+// ---- small maps: both passes of a BatchNorm direction in ONE launch --------------------------------------------------------------
+// On the 32x24 / 16x12 / 8x6 maps (<= 12 MB per tensor at N = 128) the two dependent launches above cost 13 - 20 us whatever they
+// move: the second pass waits for a kernel boundary.  Here a grid of <= 128 workgroups does pass 1 over its slice, publishes its
+// partial sums, meets the other workgroups at a grid barrier (a counter slot owned by the library, one per stream, release /
+// acquire at agent scope) and does pass 2 over the SAME slice, which its XCD's L2 still holds.
+//
+// Forward progress: a grid barrier needs every workgroup resident.  128 workgroups x 256 threads x <= 96 VGPRs x 1.2 KB LDS is a
+// small fraction of the chip (6 such workgroups fit on ONE CU), so even with a cooperative kernel on each of the step's five streams
+// all of them are resident together; other kernels in the way finish on their own.  The wait is bounded anyway (~0.5 s): on expiry
+// the workgroup poisons its outputs with NaN - the step's overflow check then skips the update - instead of hanging the GPU.
+// Same fixed partition and combine order every launch: bit-reproducible.
+constexpr int kCoopMaxGrid = 128;
+
+// slot = {arrival count, generation}, 64 bytes apart; launches on one slot are serialised by their stream.  The last arriver
+// resets the count and bumps the generation: correct for any grid size, no host-side reset between launches.
+__device__ __forceinline__ bool grid_barrier(unsigned long long* slot, unsigned total) {
+    __shared__ int s_ok;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long* count = slot;
+        unsigned long long* generation = slot + 8;
+        const unsigned long long gen = __hip_atomic_load(generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long old = __hip_atomic_fetch_add(count, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 1;
+        if (old == total - 1) {
+            __hip_atomic_store(count, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(generation, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            ok = 0;
+            for (int it = 0; it < (1 << 22); ++it) {
+                if (__hip_atomic_load(generation, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != gen) { ok = 1; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        s_ok = ok;
+    }
+    __syncthreads();
+    return s_ok != 0;
+}
+
+// totals of this block's 8 channels from the per-split partials: thread t = (channel t >> 5, split t & 31); fixed-order xor tree
+__device__ __forceinline__ void coop_channel_sums(const double* part, int ch, int c, int nsplit, double& s0, double& s1) {
+    s0 = 0.0;
+    s1 = 0.0;
+    const int sp = threadIdx.x & 31;
+    if (ch < c && sp < nsplit) {  // written by other workgroups (other XCDs): read at the coherence point
+        s0 = __hip_atomic_load(part + ((size_t)ch * nsplit + sp) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s1 = __hip_atomic_load(part + ((size_t)ch * nsplit + sp) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int off = 16; off >= 1; off >>= 1) {
+        s0 += __shfl_xor(s0, off, 64);
+        s1 += __shfl_xor(s1, off, 64);
+    }
+}
+
+// grid (C8, S): block (blk, sp) owns elements [e0, e1) of the flat (image, pixel) space of channel block blk
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn16_coop_kernel(const u32x4_t* __restrict__ dy, const u32x4_t* __restrict__ z,
+                                                        const u32x4_t* __restrict__ yres, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ mean_io,
+                                                        float* __restrict__ invstd_io, float* __restrict__ moving_mean,
+                                                        float* __restrict__ moving_var, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta, float* __restrict__ dgamma_acc,
+                                                        float* __restrict__ dbeta_acc, u32x4_t* __restrict__ out,
+                                                        u32x4_t* __restrict__ dres, double* __restrict__ part,
+                                                        unsigned long long* __restrict__ counter, int n, int c, int c8, int hw, int relu,
+                                                        float eps, float momentum) {
+    const int blk = blockIdx.x, sp = blockIdx.y, nsplit = gridDim.y;
+    const unsigned per_blk = (unsigned)n * (unsigned)hw;
+    const unsigned len = (per_blk + nsplit - 1) / nsplit;
+    const unsigned e0 = sp * len, e1 = e0 + len < per_blk ? e0 + len : per_blk;
+    const unsigned magic_hw = hw > 1 ? (unsigned)(0x100000000ULL / (unsigned)hw) + 1u : 0u;
+    const bool exact = (unsigned long long)per_blk * (unsigned)hw < 0x100000000ULL;
+    const size_t blk_off = (size_t)blk * hw, img_extra = (size_t)(c8 - 1) * hw;
+    auto index_of = [&](unsigned e) {
+        const unsigned img = hw <= 1 ? e : (exact ? __umulhi(e, magic_hw) : e / (unsigned)hw);
+        return (size_t)e + (size_t)img * img_extra + blk_off;
+    };
+    float mu[8], is[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ch = blk * 8 + j;
+        mu[j] = (BWD && ch < c) ? mean_io[ch] : 0.f;
+        is[j] = (BWD && ch < c) ? invstd_io[ch] : 0.f;
+    }
+    // ---- pass 1: partial sums of this slice
+    float f[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) f[j] = 0.f;
+#pragma unroll 4
+    for (unsigned e = e0 + threadIdx.x; e < e1; e += 256) {
+        const size_t i = index_of(e);
+        const h16x8 zv = __builtin_bit_cast(h16x8, z[i]);
+        if (BWD) {
+            const h16x8 gv = __builtin_bit_cast(h16x8, dy[i]);
+            h16x8 yv = zv;
+            if (relu) yv = __builtin_bit_cast(h16x8, yres[i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float g = (float)gv[j];
+                if (relu && !((float)yv[j] > 0.f)) g = 0.f;
+                f[2 * j] += g;
+                f[2 * j + 1] += g * (((float)zv[j] - mu[j]) * is[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = (float)zv[j];
+                f[2 * j] += v;
+                f[2 * j + 1] += v * v;
+            }
+        }
+    }
+    double acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = (double)f[j];
+    __shared__ double sm[4][16];
+    block_sum16_256(acc, sm);
+    if (threadIdx.x < 16) {
+        const int ch = blk * 8 + (threadIdx.x >> 1);
+        if (ch < c) part[((size_t)ch * nsplit + sp) * 2 + (threadIdx.x & 1)] = acc[0];
+    }
+    const bool ok = grid_barrier(counter, gridDim.x * gridDim.y);
+    // ---- totals of the 8 channels, per-channel constants
+    __shared__ float s_a[8], s_b[8], s_c[8];
+    {
+        const int j = threadIdx.x >> 5, ch = blk * 8 + j;
+        double s0, s1;
+        coop_channel_sums(part, ch, c, nsplit, s0, s1);
+        if ((threadIdx.x & 31) == 0) {
+            float a = 0.f, b = 0.f, cc = 0.f;
+            if (ch < c) {
+                if (BWD) {
+                    const float db = (float)s0, dg = (float)s1, inv_count = (float)(1.0 / ((double)n * hw));
+                    a = gamma[ch] * is[j];   // k
+                    b = db * inv_count;      // mean of g
+                    cc = dg * inv_count;     // mean of g * xhat
+                    if (sp == 0) {
+                        dbeta[ch] = db;
+                        dgamma[ch] = dg;
+                        if (dgamma_acc && dbeta_acc) {
+                            dbeta_acc[ch] += db;
+                            dgamma_acc[ch] += dg;
+                        }
+                    }
+                } else {
+                    const double count = (double)n * hw, mean = s0 / count;
+                    double var = s1 / count - mean * mean;
+                    if (var < 0.0) var = 0.0;
+                    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+                    a = gamma[ch] * invstd;
+                    b = beta[ch] - (float)mean * a;
+                    if (sp == 0) {
+                        mean_io[ch] = (float)mean;
+                        invstd_io[ch] = invstd;
+                        if (moving_mean) {
+                            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                            moving_mean[ch] = momentum * moving_mean[ch] + (1.f - momentum) * (float)mean;
+                            moving_var[ch] = momentum * moving_var[ch] + (1.f - momentum) * (float)unbiased;
+                        }
+                    }
+                }
+                if (!ok) a = b = cc = __builtin_nanf("");  // barrier timed out: poison, never hang
+            }
+            s_a[j] = a; s_b[j] = b; s_c[j] = cc;
+        }
+    }
+    __syncthreads();
+    float ka[8], kb[8], kc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ka[j] = s_a[j]; kb[j] = s_b[j]; kc[j] = s_c[j]; }
+    // ---- pass 2 over the same slice (L2-resident)
+#pragma unroll 4
+    for (unsigned e = e0 + threadIdx.x; e < e1; e += 256) {
+        const size_t i = index_of(e);
+        const h16x8 zv = __builtin_bit_cast(h16x8, z[i]);
+        h16x8 o, og;
+        if (BWD) {
+            const h16x8 gv = __builtin_bit_cast(h16x8, dy[i]);
+            h16x8 yv = zv;
+            if (relu) yv = __builtin_bit_cast(h16x8, yres[i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float g = 0.f, d = 0.f;
+                if (blk * 8 + j < c) {
+                    g = (float)gv[j];
+                    if (relu && !((float)yv[j] > 0.f)) g = 0.f;
+                    const float xh = ((float)zv[j] - mu[j]) * is[j];
+                    d = ka[j] * (g - kb[j] - xh * kc[j]);
+                }
+                o[j] = (_Float16)d;
+                og[j] = (_Float16)g;
+            }
+            out[i] = __builtin_bit_cast(u32x4_t, o);
+            if (dres) dres[i] = __builtin_bit_cast(u32x4_t, og);
+        } else {
+            h16x8 rv = zv;
+            if (yres) rv = __builtin_bit_cast(h16x8, yres[i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = 0.f;
+                if (blk * 8 + j < c) {
+                    v = (float)zv[j] * ka[j] + kb[j];
+                    if (yres) v += (float)rv[j];
+                    if (relu) v = fmaxf(v, 0.f);
+                }
+                o[j] = (_Float16)v;
+            }
+            out[i] = __builtin_bit_cast(u32x4_t, o);
+        }
+    }
+}
+
+// Barrier slots: a zeroed device pool created on the first use outside a stream capture, one 128-byte slot per stream that ever
+// launched a one-launch BatchNorm (the captured graph keeps the slot of its capture stream; kernels of one stream are ordered).
+constexpr int kCoopSlots = 64;
+static unsigned long long* coop_slot_for(hipStream_t s) {
+    static std::mutex mu;
+    static unsigned long long* pool = nullptr;
+    static bool failed = false;
+    static std::unordered_map<hipStream_t, int> slots;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!pool) {
+        if (failed) return nullptr;
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            return nullptr;  // not now: an allocation inside a capture is not allowed; the two-launch form runs instead
+        }
+        void* p = nullptr;
+        if (hipMalloc(&p, (size_t)kCoopSlots * 128) != hipSuccess || hipMemset(p, 0, (size_t)kCoopSlots * 128) != hipSuccess) {
+            (void)hipGetLastError();
+            failed = true;
+            return nullptr;
+        }
+        pool = reinterpret_cast<unsigned long long*>(p);
+    }
+    auto it = slots.find(s);
+    if (it == slots.end()) {
+        if ((int)slots.size() >= kCoopSlots) return nullptr;
+        it = slots.emplace(s, (int)slots.size()).first;
+    }
+    return pool + (size_t)it->second * 16;
+}
+
+// the one-launch form applies to: tensors of <= MP_BN16_COOP_MAX (default 1 M) 16-byte elements with C8 <= 128
+static unsigned long long* bn16_coop_plan(int n, int c8, int hw, hipStream_t s, int& nsplit) {
+    static const long long max_elems = [] {
+        const char* e = getenv("MP_BN16_COOP_MAX");  // 0 switches the one-launch form off
+        return e ? atoll(e) : (1LL << 20);
+    }();
+    if ((long long)n * c8 * hw > max_elems || c8 > kCoopMaxGrid) return nullptr;
+    nsplit = kCoopMaxGrid / c8;
+    if (nsplit > 32) nsplit = 32;
+    while (nsplit > 1 && ((long long)n * hw + nsplit - 1) / nsplit < 256) --nsplit;
+    return coop_slot_for(s);
+}
+
 // backward of the exchange-unit sum in the c8 layout: g = dy * (out > 0); term k gets the s_k x s_k block sums of g
 __global__ __launch_bounds__(256) void fuse_sum16_bwd_kernel(const u32x4_t* __restrict__ dy, const u32x4_t* __restrict__ out,
                                                              u32x4_t* __restrict__ dt, int planes, int h, int w, int sh, int relu) {
@@ -705,11 +967,19 @@ int mp_f16_bn_train_fwd(const void* z, const float* gamma, const float* beta, co
     if (!workspace || workspace_bytes < mp_bn_workspace_bytes(c)) return MP_ERR_WORKSPACE;
     double* part = reinterpret_cast<double*>(workspace);
     const int c8 = (c + 7) / 8;
+    hipStream_t s = as_stream(stream);
+    int coop_split;
+    if (unsigned long long* counter = bn16_coop_plan(n, c8, hw, s, coop_split)) {  // small map: both passes in one launch
+        hipLaunchKernelGGL(bn16_coop_kernel<false>, dim3(c8, coop_split), dim3(256), 0, s, nullptr, reinterpret_cast<const u32x4_t*>(z),
+                           reinterpret_cast<const u32x4_t*>(res), gamma, beta, save_mean, save_invstd, moving_mean, moving_var, nullptr,
+                           nullptr, nullptr, nullptr, reinterpret_cast<u32x4_t*>(y), nullptr, part, counter, n, c, c8, hw, relu ? 1 : 0,
+                           eps, momentum);
+        return check_launch();
+    }
     int gi, gp;
     bn16_split(n, c8, hw, gi, gp);
     float* scale = reinterpret_cast<float*>(part + (size_t)c * kBn16MaxSplit * 2);
     float* shift = scale + c;
-    hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(bn16_reduce_kernel<false>, dim3(c8, gi * gp), dim3(256), 0, s, nullptr, reinterpret_cast<const u32x4_t*>(z),
                        nullptr, nullptr, nullptr, part, n, c, c8, hw, 0, gi, gp);
     int rc = check_launch();
@@ -730,9 +1000,19 @@ int mp_f16_bn_train_bwd(const void* dy, const void* z, const void* y, const floa
     if (!workspace || workspace_bytes < mp_bn_workspace_bytes(c)) return MP_ERR_WORKSPACE;
     double* part = reinterpret_cast<double*>(workspace);
     const int c8 = (c + 7) / 8;
+    hipStream_t s = as_stream(stream);
+    int coop_split;
+    if (unsigned long long* counter = bn16_coop_plan(n, c8, hw, s, coop_split)) {  // small map: both passes in one launch
+        const bool acc2 = dgamma_acc && dbeta_acc;
+        hipLaunchKernelGGL(bn16_coop_kernel<true>, dim3(c8, coop_split), dim3(256), 0, s, reinterpret_cast<const u32x4_t*>(dy),
+                           reinterpret_cast<const u32x4_t*>(z), reinterpret_cast<const u32x4_t*>(y), gamma, nullptr,
+                           const_cast<float*>(save_mean), const_cast<float*>(save_invstd), nullptr, nullptr, dgamma, dbeta,
+                           acc2 ? dgamma_acc : nullptr, acc2 ? dbeta_acc : nullptr, reinterpret_cast<u32x4_t*>(dz),
+                           reinterpret_cast<u32x4_t*>(dres), part, counter, n, c, c8, hw, relu ? 1 : 0, 0.f, 0.f);
+        return check_launch();
+    }
     int gi, gp;
     bn16_split(n, c8, hw, gi, gp);
-    hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(bn16_reduce_kernel<true>, dim3(c8, gi * gp), dim3(256), 0, s, reinterpret_cast<const u32x4_t*>(dy),
                        reinterpret_cast<const u32x4_t*>(z), reinterpret_cast<const u32x4_t*>(y), save_mean, save_invstd, part, n, c,
                        c8, hw, relu ? 1 : 0, gi, gp);
