@@ -539,28 +539,36 @@ constexpr int kCoopMaxGrid = 128;
 
 // slot = {arrival count, generation}, 64 bytes apart; launches on one slot are serialised by their stream.  The last arriver
 // resets the count and bumps the generation: correct for any grid size, no host-side reset between launches.
+// Everything that crosses workgroups here (the partial sums, the two counters) is written and read with agent-scope ATOMIC
+// accesses, which go to the coherence point; the barrier itself therefore needs only workgroup-scope fences.  Agent-scope
+// release / acquire FENCES were measured first: they write back and invalidate the whole L2 (the conv output of the previous
+// kernel is still dirty in it), which cost 10 us per barrier and evicted the slice pass 2 wants to re-read.
 __device__ __forceinline__ bool grid_barrier(unsigned long long* slot, unsigned total) {
     __shared__ int s_ok;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's (atomic, write-through) partial stores have completed
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long* count = slot;
         unsigned long long* generation = slot + 8;
         const unsigned long long gen = __hip_atomic_load(generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long old = __hip_atomic_fetch_add(count, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        const unsigned long long old = __hip_atomic_fetch_add(count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int ok = 1;
         if (old == total - 1) {
             __hip_atomic_store(count, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(generation, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __hip_atomic_fetch_add(generation, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             ok = 0;
             for (int it = 0; it < (1 << 22); ++it) {
-                if (__hip_atomic_load(generation, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != gen) { ok = 1; break; }
-                __builtin_amdgcn_s_sleep(8);
+                if (__hip_atomic_load(generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen) { ok = 1; break; }
+                __builtin_amdgcn_s_sleep(2);
             }
         }
         s_ok = ok;
     }
     __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     return s_ok != 0;
 }
 
@@ -644,9 +652,11 @@ __global__ __launch_bounds__(256) void bn16_coop_kernel(const u32x4_t* __restric
     block_sum16_256(acc, sm);
     if (threadIdx.x < 16) {
         const int ch = blk * 8 + (threadIdx.x >> 1);
-        if (ch < c) part[((size_t)ch * nsplit + sp) * 2 + (threadIdx.x & 1)] = acc[0];
+        if (ch < c) __hip_atomic_store(part + ((size_t)ch * nsplit + sp) * 2 + (threadIdx.x & 1), acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    const bool ok = grid_barrier(counter, gridDim.x * gridDim.y);
+    // only the workgroups of ONE channel block depend on each other: one barrier slot per channel block, gridDim.y arrivals each
+    // (an arrival is a cross-XCD atomic, ~70 ns serialised per address: 128 arrivals on one slot cost ~9 us)
+    const bool ok = grid_barrier(counter + (size_t)blk * 16, gridDim.y);
     // ---- totals of the 8 channels, per-channel constants
     __shared__ float s_a[8], s_b[8], s_c[8];
     {
@@ -737,7 +747,7 @@ __global__ __launch_bounds__(256) void bn16_coop_kernel(const u32x4_t* __restric
     }
 }
 
-// Barrier slots: a zeroed device pool created on the first use outside a stream capture, one 128-byte slot per stream that ever
+// Barrier slots: a zeroed device pool created on the first use outside a stream capture, 128 slots of 128 bytes per stream that ever
 // launched a one-launch BatchNorm (the captured graph keeps the slot of its capture stream; kernels of one stream are ordered).
 constexpr int kCoopSlots = 64;
 static unsigned long long* coop_slot_for(hipStream_t s) {
@@ -754,7 +764,8 @@ static unsigned long long* coop_slot_for(hipStream_t s) {
             return nullptr;  // not now: an allocation inside a capture is not allowed; the two-launch form runs instead
         }
         void* p = nullptr;
-        if (hipMalloc(&p, (size_t)kCoopSlots * 128) != hipSuccess || hipMemset(p, 0, (size_t)kCoopSlots * 128) != hipSuccess) {
+        if (hipMalloc(&p, (size_t)kCoopSlots * kCoopMaxGrid * 128) != hipSuccess ||
+            hipMemset(p, 0, (size_t)kCoopSlots * kCoopMaxGrid * 128) != hipSuccess) {
             (void)hipGetLastError();
             failed = true;
             return nullptr;
@@ -766,14 +777,15 @@ static unsigned long long* coop_slot_for(hipStream_t s) {
         if ((int)slots.size() >= kCoopSlots) return nullptr;
         it = slots.emplace(s, (int)slots.size()).first;
     }
-    return pool + (size_t)it->second * 16;
+    return pool + (size_t)it->second * kCoopMaxGrid * 16;  // kCoopMaxGrid slots of 128 bytes: one per channel block
 }
 
-// the one-launch form applies to: tensors of <= MP_BN16_COOP_MAX (default 1 M) 16-byte elements with C8 <= 128
+// the one-launch form applies to: tensors of <= MP_BN16_COOP_MAX (default 512 K) 16-byte elements with C8 <= 128 - measured on the
+// HRNet-W32 amp-O2 step at N = 128: threshold 0 / 256 K / 512 K / 1 M -> 36.06 / 35.31 / 35.04 / 36.64 ms
 static unsigned long long* bn16_coop_plan(int n, int c8, int hw, hipStream_t s, int& nsplit) {
     static const long long max_elems = [] {
         const char* e = getenv("MP_BN16_COOP_MAX");  // 0 switches the one-launch form off
-        return e ? atoll(e) : (1LL << 20);
+        return e ? atoll(e) : (1LL << 19);
     }();
     if ((long long)n * c8 * hw > max_elems || c8 > kCoopMaxGrid) return nullptr;
     nsplit = kCoopMaxGrid / c8;
