@@ -164,7 +164,8 @@ int mp_conv2d_fwd_variant(const mp_conv_desc* desc, int variant, const float* x_
 /* The 3x3 stride-1 padding-1 convolutions of the branches (hrnet.py:51-64 BasicBlock, 202-241 _make_one_branch) in Winograd
  * F(2x2,3x3) form, all fp32: 16 instead of 36 multiplications per 2x2 output tile and (cin, cout) pair; same operands, epilogue
  * (folded BatchNorm scale/shift, res1, res2, ReLU) and result as mp_conv2d_fwd up to fp32 rounding (the sums are associated
- * differently).  Needs W % 4 == 0, H % 2 == 0, W <= 96, Cin % 8 == 0 and the plain output mapping; mp_conv_winograd_supported
+ * differently).  Needs even H and W <= 96 (W % 4 != 0: whole images of at most 24 tiles with H*W % 4 == 0), Cin % 8 == 0 and the plain
+ * output mapping; mp_conv_winograd_supported
  * returns MP_OK or MP_ERR_UNSUPPORTED for a descriptor.  The weights are transformed once: U = G w G^T,
  * [Cin_pad4][Cout_pad16][16] floats (mp_conv_winograd_packed_weight_bytes). */
 size_t mp_conv_winograd_packed_weight_bytes(int cout, int cin);

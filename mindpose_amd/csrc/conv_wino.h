@@ -14,11 +14,12 @@ struct WinoParams {
     float* out;
     int N, Cin, Cout, Cout_pad16, H, W;
     int TW, TR, M;   // tiles per row, tile rows per workgroup, tiles per workgroup (<= 48, even)
+    int G, tpi, img_plane;  // image-grouped bands (W % 4 != 0 maps): images per workgroup, tiles per image, LDS floats per image
     int R, Rin, Wp, cin_plane;
     int n_chunks, n_ct, bands, total_blocks;
     int upr, upc;    // float4 staging units per input row / per input channel
     int relu;
-    unsigned magic_upr, magic_upc, magic_tw, magic_pairs;
+    unsigned magic_upr, magic_upc, magic_tw, magic_pairs, magic_tpi, magic_w;
     unsigned long long* dbg;  // diagnostic builds (MP_CONV_STAMPS) only: 8 x u64 per workgroup
 };
 
@@ -26,6 +27,7 @@ struct WinoLaunch {
     WinoParams p;
     size_t lds_bytes;
     int ni;
+    bool group;  // image-grouped bands
 };
 
 int wino_configure(const mp_conv_desc* d, WinoLaunch& L);  // MP_OK / MP_ERR_UNSUPPORTED; pointers left null

@@ -39,7 +39,10 @@ __device__ __forceinline__ void wg_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int NI, bool QROW>
+// GROUP: a band = G whole small images (W % 4 != 0 maps, e.g. 8x6: 12 tiles per image, four images per workgroup); the raw
+// planes are staged as contiguous float4 units whose four elements may straddle rows, and the two tiles of a transform item
+// are consecutive tiles, not neighbours in a row.
+template <int NI, bool QROW, bool GROUP>
 __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int raw_buf = kCK * p.cin_plane + 4;  // + one float4 that absorbs the stores of threads without a staging unit
@@ -59,21 +62,38 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams 
     }
     const int ct = b % p.n_ct;
     b /= p.n_ct;
-    const int band = b % p.bands, n = b / p.bands;
+    const int band = GROUP ? 0 : b % p.bands, n = GROUP ? b * p.G : b / p.bands;  // GROUP: b = image group, n = its first image
     const int y0 = band * p.R, y_in0 = y0 - 1;
     const int HW = p.H * p.W;
+    const int n_img = GROUP ? min(p.G, p.N - n) : 1;
 
     // staging tables: float4 units of the chunk's rows.  Branch-free use: a unit outside the image loads zeros (range-checked
     // buffer load) and stores them - halo rows are rewritten with zeros, harmless - and a thread without a unit stores its
     // zeros into the spare float4 behind the buffer.
     unsigned isrc[NI];
     int idst[NI];
+    int idst4[GROUP ? NI : 1][4];  // GROUP: one LDS offset per element of a unit
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const unsigned u = tid + 256 * i;
         isrc[i] = kOob;
         idst[i] = kCK * p.cin_plane;
-        if (u < (unsigned)(kCK * p.upc)) {
+        if constexpr (GROUP) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) idst4[i][j] = kCK * p.cin_plane + j;
+            if (u < (unsigned)(kCK * p.upc)) {  // upc = G * HW / 4 units per channel, upr = HW / 4 per image
+                const unsigned c = fastdiv(u, p.upc, p.magic_upc);
+                const unsigned rem = u - c * p.upc;
+                const unsigned g = fastdiv(rem, p.upr, p.magic_upr);
+                const unsigned k4 = (rem - g * p.upr) * 4;
+                isrc[i] = ((g * p.Cin + c) * HW + k4) * 4u;  // images past the batch: beyond the resource, zeros
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned k = k4 + j, row = fastdiv(k, p.W, p.magic_w), col = k - row * p.W;
+                    idst4[i][j] = (int)(c * p.cin_plane + g * p.img_plane + (row + 1) * p.Wp + 1 + col);
+                }
+            }
+        } else if (u < (unsigned)(kCK * p.upc)) {
             const unsigned c = fastdiv(u, p.upc, p.magic_upc);
             const unsigned rem = u - c * p.upc;
             const unsigned r = fastdiv(rem, p.upr, p.magic_upr);
@@ -83,21 +103,29 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams 
             idst[i] = (int)(c * p.cin_plane + r * p.Wp + 1 + xu * 4);
         }
     }
-    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x + (size_t)n * p.Cin * HW, (size_t)p.Cin * HW * 4);
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x + (size_t)n * p.Cin * HW, (size_t)n_img * p.Cin * HW * 4);
     const __amdgpu_buffer_rsrc_t rs_u = make_rsrc(p.u, (size_t)(p.Cin >> 2) * 16 * 4 * p.Cout_pad16 * 4);
 
     // transform item of this thread: (cin, pair of adjacent tiles); the threads beyond the item count repeat the first items
     // (same values to the same addresses) so that the transform needs no branch
     const int pairs = p.M >> 1;
-    int xf_raw = 0, xf_v = 0;
+    int xf_raw = 0, xf_rawb = 0, xf_v = 0;  // patch of the first tile, of the second tile (GROUP), V offset of the pair
     {
         const int items = kCK * pairs;  // <= 192
         const unsigned t = (unsigned)tid % (unsigned)items;
         const unsigned c = fastdiv(t, pairs, p.magic_pairs);
         const unsigned tile0 = (t - c * pairs) * 2;
-        const unsigned ty = fastdiv(tile0, p.TW, p.magic_tw);
-        const unsigned tx = tile0 - ty * p.TW;
-        xf_raw = c * p.cin_plane + (2 * ty) * p.Wp + 2 * tx;
+        auto patch = [&](unsigned tile) {
+            unsigned g = 0, r = tile;
+            if constexpr (GROUP) {
+                g = fastdiv(tile, p.tpi, p.magic_tpi);
+                r = tile - g * p.tpi;
+            }
+            const unsigned ty = fastdiv(r, p.TW, p.magic_tw), tx = r - ty * p.TW;
+            return (int)(c * p.cin_plane + g * p.img_plane + (2 * ty) * p.Wp + 2 * tx);
+        };
+        xf_raw = patch(tile0);
+        xf_rawb = GROUP ? patch(tile0 + 1) : xf_raw + 2;
         xf_v = c * kTP + tile0;
     }
 
@@ -133,35 +161,51 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams 
         float* __restrict__ d0 = lds_raw + buf * raw_buf;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            float* d = d0 + idst[i];
-            d[0] = vin[i].x; d[1] = vin[i].y; d[2] = vin[i].z; d[3] = vin[i].w;
+            if constexpr (GROUP) {
+                d0[idst4[i][0]] = vin[i].x; d0[idst4[i][1]] = vin[i].y; d0[idst4[i][2]] = vin[i].z; d0[idst4[i][3]] = vin[i].w;
+            } else {
+                float* d = d0 + idst[i];
+                d[0] = vin[i].x; d[1] = vin[i].y; d[2] = vin[i].z; d[3] = vin[i].w;
+            }
         }
     };
     // input transform of one chunk: raw[rb] -> V[vb]; split in three parts so that the MFMA stream can be woven between them
-    float xd[4][6], xt[4][6];
+    // columns 0..3 = patch of the first tile; the second tile's patch is columns 2..5 (its row neighbour) or, GROUP, its own
+    // four columns 4..7 (consecutive tiles need not be neighbours there)
+    constexpr int XC = GROUP ? 8 : 6, XB = GROUP ? 4 : 2;
+    float xd[4][XC], xt[4][XC];
     auto xf_read = [&](int rb) {
         const float* __restrict__ src = lds_raw + rb * raw_buf + xf_raw;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(src + r * p.Wp);
-            const float2 c2 = *reinterpret_cast<const float2*>(src + r * p.Wp + 4);
-            xd[r][0] = a.x; xd[r][1] = a.y; xd[r][2] = a.z; xd[r][3] = a.w; xd[r][4] = c2.x; xd[r][5] = c2.y;
+            if constexpr (GROUP) {
+                const float* __restrict__ srcb = lds_raw + rb * raw_buf + xf_rawb;
+                const float2 a0 = *reinterpret_cast<const float2*>(src + r * p.Wp), a1 = *reinterpret_cast<const float2*>(src + r * p.Wp + 2);
+                const float2 b0 = *reinterpret_cast<const float2*>(srcb + r * p.Wp), b1 = *reinterpret_cast<const float2*>(srcb + r * p.Wp + 2);
+                xd[r][0] = a0.x; xd[r][1] = a0.y; xd[r][2] = a1.x; xd[r][3] = a1.y;
+                xd[r][4] = b0.x; xd[r][5] = b0.y; xd[r][6] = b1.x; xd[r][7] = b1.y;
+            } else {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(src + r * p.Wp);
+                const float2 c2 = *reinterpret_cast<const float2*>(src + r * p.Wp + 4);
+                xd[r][0] = a.x; xd[r][1] = a.y; xd[r][2] = a.z; xd[r][3] = a.w; xd[r][4] = c2.x; xd[r][5] = c2.y;
+            }
         }
     };
     auto xf_cols = [&]() {
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
+        for (int c = 0; c < XC; ++c) {
             xt[0][c] = xd[0][c] - xd[2][c];
             xt[1][c] = xd[1][c] + xd[2][c];
             xt[2][c] = xd[2][c] - xd[1][c];
             xt[3][c] = xd[1][c] - xd[3][c];
         }
     };
-    auto xf_rows_write = [&](int vb, int i) {  // row i of the column-transformed patch -> xi = 4 i .. 4 i + 3 of both tiles
+    auto xf_rows_write = [&](int vb, int i) {  // row i of the column-transformed patches -> xi = 4 i .. 4 i + 3 of both tiles
         float* __restrict__ dst = lds_v + vb * kVFloats + xf_v;
         float va[4], vbv[4];
         va[0] = xt[i][0] - xt[i][2]; va[1] = xt[i][1] + xt[i][2]; va[2] = xt[i][2] - xt[i][1]; va[3] = xt[i][1] - xt[i][3];
-        vbv[0] = xt[i][2] - xt[i][4]; vbv[1] = xt[i][3] + xt[i][4]; vbv[2] = xt[i][4] - xt[i][3]; vbv[3] = xt[i][3] - xt[i][5];
+        vbv[0] = xt[i][XB] - xt[i][XB + 2]; vbv[1] = xt[i][XB + 1] + xt[i][XB + 2]; vbv[2] = xt[i][XB + 2] - xt[i][XB + 1];
+        vbv[3] = xt[i][XB + 1] - xt[i][XB + 3];
 #pragma unroll
         for (int j = 0; j < 4; ++j) *reinterpret_cast<float2*>(dst + (i * 4 + j) * (kCK * kTP)) = make_float2(va[j], vbv[j]);
     };
@@ -253,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams 
     // four tiles are eight consecutive pixels of two rows -> 16-byte residual loads and stores.  The residual loads are issued
     // before the accumulators go to LDS, so their latency runs under the exchange.
     const int plane_o = HW;
-    const size_t img_o = (size_t)p.Cout * plane_o * 4;
+    const size_t img_o = (size_t)n_img * p.Cout * plane_o * 4;
     const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(p.out + (size_t)n * p.Cout * plane_o, img_o);
     const __amdgpu_buffer_rsrc_t rs_r1 = make_rsrc(p.res1 ? p.res1 + (size_t)n * p.Cout * plane_o : p.out, p.res1 ? img_o : 0);
     const __amdgpu_buffer_rsrc_t rs_r2 = make_rsrc(p.res2 ? p.res2 + (size_t)n * p.Cout * plane_o : p.out, p.res2 ? img_o : 0);
@@ -265,10 +309,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams 
 #pragma unroll
     for (int e = 0; e < (QROW ? 1 : 4); ++e) {
         const unsigned tile = quad * 4 + e;
-        const unsigned ty = fastdiv(tile, p.TW, p.magic_tw);
-        const unsigned tx = tile - ty * p.TW;
+        unsigned g = 0, r = tile;
+        if constexpr (GROUP) {
+            g = fastdiv(tile, p.tpi, p.magic_tpi);
+            r = tile - g * p.tpi;
+        }
+        const unsigned ty = fastdiv(r, p.TW, p.magic_tw);
+        const unsigned tx = r - ty * p.TW;
         const int oy = y0 + 2 * (int)ty;
-        pix[e] = (ep_on && tile < (unsigned)p.M && oy < p.H) ? (unsigned)(oy * p.W + 2 * tx) * 4u : kOob;
+        // GROUP: + the image's offset inside the group (an image past the batch is beyond the resources: nothing loaded / stored)
+        pix[e] = (ep_on && tile < (unsigned)p.M && oy < p.H) ? (unsigned)(g * p.Cout * plane_o + oy * p.W + 2 * tx) * 4u : kOob;
     }
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
@@ -397,28 +447,51 @@ int wino_configure(const mp_conv_desc* d, WinoLaunch& L) {
     if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad_top != 1 || d->pad_left != 1) return MP_ERR_UNSUPPORTED;
     if (d->conv_h != d->h || d->conv_w != d->w || d->out_h != d->h || d->out_w != d->w) return MP_ERR_UNSUPPORTED;
     if (d->out_mul != 1 || d->out_rep != 1 || d->out_off_y != 0 || d->out_off_x != 0) return MP_ERR_UNSUPPORTED;
-    if ((d->w & 3) || (d->h & 1) || (d->cin % kCK)) return MP_ERR_UNSUPPORTED;
-    if ((long long)d->cin * d->h * d->w * 4 >= 0x7FFFFFF0LL || (long long)d->cout * d->h * d->w * 4 >= 0x7FFFFFF0LL) return MP_ERR_UNSUPPORTED;
+    if ((d->w & 1) || (d->h & 1) || (d->cin % kCK)) return MP_ERR_UNSUPPORTED;
+    if ((long long)d->cin * d->h * d->w * 4 >= 0x1FFFFFF0LL || (long long)d->cout * d->h * d->w * 4 >= 0x1FFFFFF0LL) return MP_ERR_UNSUPPORTED;
     WinoParams& p = L.p;
     p.N = d->n; p.Cin = d->cin; p.Cout = d->cout; p.Cout_pad16 = (d->cout + 15) / 16 * 16; p.H = d->h; p.W = d->w;
     p.TW = d->w / 2;
     if (p.TW > kTP) return MP_ERR_UNSUPPORTED;
-    p.TR = kTP / p.TW;
-    if (p.TR > d->h / 2) p.TR = d->h / 2;
-    p.M = p.TR * p.TW;
-    p.R = 2 * p.TR;
-    p.Rin = p.R + 2;
-    p.Wp = d->w + 4;
-    p.cin_plane = p.Rin * p.Wp;
     p.n_chunks = d->cin / kCK;
     p.n_ct = (p.Cout_pad16 + 31) / 32;
-    p.bands = (d->h + p.R - 1) / p.R;
-    p.total_blocks = p.n_ct * p.bands * d->n;
-    p.upr = d->w / 4;
-    p.upc = p.Rin * p.upr;
+    p.tpi = (d->h / 2) * p.TW;
+    L.group = (d->w & 3) != 0;
+    if (L.group) {
+        // rows are not 16-byte units: whole small images, staged as contiguous planes (HW % 4 == 0), G of them per workgroup
+        if (((d->h * d->w) & 3) || p.tpi > kTP / 2 || (p.tpi & 1)) return MP_ERR_UNSUPPORTED;
+        p.G = kTP / p.tpi;
+        if (p.G > d->n) p.G = d->n;
+        p.TR = d->h / 2;
+        p.M = p.G * p.tpi;
+        p.R = d->h;
+        p.Rin = p.R + 2;
+        p.Wp = d->w + 4;  // even: 8-byte patch reads
+        p.img_plane = p.Rin * p.Wp;
+        p.cin_plane = (p.G * p.img_plane + 3) / 4 * 4;
+        p.bands = (d->n + p.G - 1) / p.G;  // image groups
+        p.total_blocks = p.n_ct * p.bands;
+        p.upr = d->h * d->w / 4;
+        p.upc = p.G * p.upr;
+    } else {
+        p.G = 1;
+        p.TR = kTP / p.TW;
+        if (p.TR > d->h / 2) p.TR = d->h / 2;
+        p.M = p.TR * p.TW;
+        p.R = 2 * p.TR;
+        p.Rin = p.R + 2;
+        p.Wp = d->w + 4;
+        p.img_plane = p.Rin * p.Wp;
+        p.cin_plane = p.img_plane;
+        p.bands = (d->h + p.R - 1) / p.R;
+        p.total_blocks = p.n_ct * p.bands * d->n;
+        p.upr = d->w / 4;
+        p.upc = p.Rin * p.upr;
+    }
     if (kCK * p.upc > 3 * 256) return MP_ERR_UNSUPPORTED;
     p.relu = d->relu;
     p.magic_upr = magic_of(p.upr); p.magic_upc = magic_of(p.upc); p.magic_tw = magic_of(p.TW); p.magic_pairs = magic_of(p.M >> 1);
+    p.magic_tpi = magic_of(p.tpi); p.magic_w = magic_of(p.W);
     const size_t main_bytes = ((size_t)2 * (kCK * p.cin_plane + 4) + 2 * kVFloats) * 4, x_bytes = (size_t)kXFloats * 4;
     L.lds_bytes = main_bytes > x_bytes ? main_bytes : x_bytes;
     L.ni = (kCK * p.upc + 255) / 256;
@@ -440,11 +513,19 @@ int wino_launch(const WinoLaunch& L0, hipStream_t s) {
         return check_launch();
     };
     // QROW: the four tiles of an epilogue item are eight consecutive pixels of two rows
-    const bool qrow = L.p.M == kTP && L.p.TW % 4 == 0 && L.p.H % L.p.R == 0;
+    const bool qrow = !L.group && L.p.M == kTP && L.p.TW % 4 == 0 && L.p.H % L.p.R == 0;
+    if (L.group) {
+        switch (L.ni) {
+            case 1: return go(conv_wino_f32_kernel<1, false, true>);
+            case 2: return go(conv_wino_f32_kernel<2, false, true>);
+            case 3: return go(conv_wino_f32_kernel<3, false, true>);
+            default: return MP_ERR_UNSUPPORTED;
+        }
+    }
     switch (L.ni) {
-        case 1: return qrow ? go(conv_wino_f32_kernel<1, true>) : go(conv_wino_f32_kernel<1, false>);
-        case 2: return qrow ? go(conv_wino_f32_kernel<2, true>) : go(conv_wino_f32_kernel<2, false>);
-        case 3: return qrow ? go(conv_wino_f32_kernel<3, true>) : go(conv_wino_f32_kernel<3, false>);
+        case 1: return qrow ? go(conv_wino_f32_kernel<1, true, false>) : go(conv_wino_f32_kernel<1, false, false>);
+        case 2: return qrow ? go(conv_wino_f32_kernel<2, true, false>) : go(conv_wino_f32_kernel<2, false, false>);
+        case 3: return qrow ? go(conv_wino_f32_kernel<3, true, false>) : go(conv_wino_f32_kernel<3, false, false>);
         default: return MP_ERR_UNSUPPORTED;
     }
 }

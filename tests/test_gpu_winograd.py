@@ -4,7 +4,8 @@ The kernel replaces the direct kernel for the 3x3 stride-1 branch convolutions o
 tuner finds it faster.  Same operands and epilogue; the sums are associated differently, so the comparison is against an fp64
 torch-CPU formulation at 2e-5 of the output scale (the direct kernel's own single-layer bar, tests/test_gpu_conv.py), and the
 direct kernel must be within the same distance of it.  Edge cases: bands that do not divide the height, fewer than 48 tiles per
-band, cout tiles with a partial second half, cout not a multiple of 16, 8 / 16 input channels (1-2 chunks), two residuals."""
+band, cout tiles with a partial second half, cout not a multiple of 16, 8 / 16 input channels (1-2 chunks), two residuals,
+image-grouped bands (W % 4 != 0: the 8x6 maps) incl. a batch that does not fill the last group."""
 import ctypes
 
 import pytest
@@ -30,6 +31,9 @@ CASES = [
     (3, 24, 40, 12, 20, False, True, False),    # cout not a multiple of 16 (padding channels masked), 3 chunks
     (1, 32, 32, 6, 96, True, False, False),     # widest supported row: one tile row per band
     (2, 48, 96, 10, 28, True, True, False),     # bands of 3 tile rows over 5: last band partly outside the image
+    (5, 256, 256, 8, 6, True, True, False),     # branch 3 (W % 4 != 0): four whole images per band, N not a multiple of 4
+    (2, 16, 32, 4, 6, True, False, True),       # 6 tiles per image, group clipped to the batch
+    (3, 8, 16, 4, 10, False, True, False),      # 10 tiles per image, four images per band, one left over
 ]
 
 
@@ -104,7 +108,7 @@ def test_winograd_result_is_deterministic_and_in_place_safe_with_residual_alias(
     assert torch.equal(acc, outs[0])
 
 
-@pytest.mark.parametrize("bad", [dict(stride=2), dict(kh=1, kw=1, pad_top=0, pad_left=0), dict(w=6, conv_w=6, out_w=6), dict(h=7, conv_h=7, out_h=7),
+@pytest.mark.parametrize("bad", [dict(stride=2), dict(kh=1, kw=1, pad_top=0, pad_left=0), dict(w=6, conv_w=6, out_w=6, h=6, conv_h=6, out_h=6), dict(h=7, conv_h=7, out_h=7), dict(w=18, conv_w=18, out_w=18, h=24, conv_h=24, out_h=24),
                                  dict(cin=12), dict(out_mul=2, out_rep=2, out_h=16, out_w=16), dict(w=100, conv_w=100, out_w=100)])
 def test_winograd_rejects_what_it_does_not_cover(bad):
     lib = _lib.load()

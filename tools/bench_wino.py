@@ -9,7 +9,7 @@ from mindpose_amd import _lib
 lib = _lib.load(); dev = torch.device("cuda:0")
 torch.backends.cudnn.allow_tf32 = False
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-SHAPES = [(32, 32, 64, 48), (64, 64, 32, 24), (128, 128, 16, 12), (64, 64, 64, 48), (256, 32, 64, 48), (32, 48, 20, 16)]
+SHAPES = [(32, 32, 64, 48), (64, 64, 32, 24), (128, 128, 16, 12), (64, 64, 64, 48), (256, 32, 64, 48), (32, 48, 20, 16), (256, 256, 8, 6)]
 st = _lib.stream()
 
 
