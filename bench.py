@@ -301,7 +301,7 @@ class CallTimer:
     per-kernel-family device time of an eager training step.  The entries are wrapped on the loaded library object, which is
     what the host mirror calls through, and restored afterwards."""
 
-    CONV = ("mp_f16_conv2d_fwd", "mp_conv2d_fwd_variant", "mp_conv2d_fwd")
+    CONV = ("mp_f16_conv2d_fwd", "mp_conv2d_fwd_variant", "mp_conv2d_fwd", "mp_conv2d_winograd_fwd")
     WGRAD = ("mp_f16_conv_wgrad", "mp_conv_wgrad")
     BN = ("mp_f16_bn_train_fwd", "mp_f16_bn_train_bwd", "mp_bn_train_fwd", "mp_bn_train_bwd_acc", "mp_bn_train_bwd")
     OTHER = ("mp_f16_fuse_upsample_sum", "mp_f16_fuse_upsample_sum_bwd", "mp_fuse_upsample_sum", "mp_fuse_upsample_sum_bwd",
@@ -338,7 +338,7 @@ class CallTimer:
         if name in CallTimer.CONV + CallTimer.WGRAD:
             d = args[0]._obj  # ctypes.byref(mp_conv_desc)
             flops = 2.0 * d.n * d.conv_h * d.conv_w * d.cout * d.cin * d.kh * d.kw
-            variant = args[1] if name in ("mp_f16_conv2d_fwd", "mp_conv2d_fwd_variant") else None
+            variant = args[1] if name in ("mp_f16_conv2d_fwd", "mp_conv2d_fwd_variant") else (8 if name == "mp_conv2d_winograd_fwd" else None)
             return dict(flops=flops, shape=f"{d.kh}x{d.kw} s{d.stride} {d.cin}->{d.cout} @{d.h}x{d.w} N={d.n}", variant=variant,
                         ks=d.kh, stride=d.stride)
         if name in CallTimer.BN:
@@ -381,6 +381,8 @@ def f16_kernel_for(ks, stride, variant):
 
 
 def f32_kernel_for(ks, stride, variant):
+    if variant == 8:
+        return "conv_wino_f32_kernel"
     light = variant in (0, 5, 7)  # conv_mfma.h variant_light
     return kernel_name(dict(kind_id=0, ks=ks, stride=stride, variant=variant, light=light)) if variant is not None and variant >= 0 else "library heuristic"
 

@@ -147,7 +147,10 @@ size_t mp_conv_packed_weight_bytes(int cout, int cin, int kh, int kw);
  *   2  w_dev = [Cin,Cout,kh,kw]   data gradient of a stride-1 Conv2d whose forward weight is w_dev (roles swapped,
  *                                 taps mirrored): dx = conv(dz, pack2(W)) with the same padding
  *   3  w_dev = [Cin,Cout,3,3]     data gradient of a 3x3 stride-2 pad-1 Conv2d, output parity phase (py,px), kh=kw=2,
- *                                 run with pad 0 and the deconv output mapping (out_mul=2, out_off=(py,px)) */
+ *                                 run with pad 0 and the deconv output mapping (out_mul=2, out_off=(py,px))
+ *   5 / 6  (kh=kw=3)              the Winograd forms U = G w G^T of mode 0 / mode 2, for mp_conv2d_winograd_fwd; packed_dev holds
+ *                                 mp_conv_winograd_packed_weight_bytes (also as jobs of mp_conv_pack_weight_batch: units_j =
+ *                                 Cin_pad4 * Cout_pad16, a thread writes the 16 values of one (cin, cout) pair) */
 int mp_conv_pack_weight(const float* w_dev, float* packed_dev, int cout, int cin, int kh, int kw,
                         int transposed, int phase_y, int phase_x, mp_stream_t stream);
 int mp_conv2d_fwd(const mp_conv_desc* desc, const float* x_dev, const float* packed_w_dev,

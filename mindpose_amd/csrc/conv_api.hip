@@ -78,8 +78,20 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const mp_f16_pac
     }
     const mp_f16_pack_job jb = jobs[lo];
     const int T = jb.kh * jb.kw, cp = (jb.cout + 15) / 16 * 16, cin_pad4 = (jb.cin + 3) / 4 * 4;
-    const unsigned units = (unsigned)cin_pad4 * T * (cp / 4);
     const unsigned u = (blockIdx.x - first_block[lo]) * 256u + threadIdx.x;
+    if (jb.transposed >= 5) {  // Winograd forms (5: forward weight, 6: data gradient): a thread writes the 16 xi of one (cin, cout)
+        if (u >= (unsigned)cin_pad4 * cp) return;
+        const int co = (int)(u % cp), ci = (int)(u / cp);
+        float uu[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) uu[k] = 0.f;
+        if (co < jb.cout && ci < jb.cin) wino_transform_weight(jb.w, jb.cout, jb.cin, jb.transposed == 6, co, ci, uu);
+        float4* o4 = reinterpret_cast<float4*>(jb.packed) + (size_t)u * 4;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) o4[a] = make_float4(uu[a * 4], uu[a * 4 + 1], uu[a * 4 + 2], uu[a * 4 + 3]);
+        return;
+    }
+    const unsigned units = (unsigned)cin_pad4 * T * (cp / 4);
     if (u >= units) return;
     const int c4 = (int)(u % (cp / 4)) * 4;
     unsigned r = u / (cp / 4);
@@ -399,6 +411,8 @@ int mp_conv_pack_weight(const float* w, float* packed, int cout, int cin, int kh
                         int phase_x, mp_stream_t stream) {
     if (!w || !packed) return MP_ERR_NULL;
     if (cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0) return MP_ERR_SHAPE;
+    if (transposed == 5 || transposed == 6)  // Winograd forms of a 3x3 weight (packed size: mp_conv_winograd_packed_weight_bytes)
+        return (kh == 3 && kw == 3) ? wino_pack_launch(w, packed, cout, cin, transposed == 6, as_stream(stream)) : MP_ERR_UNSUPPORTED;
     if (transposed < 0 || transposed > 4) return MP_ERR_UNSUPPORTED;
     if ((transposed == 1 || transposed == 3 || transposed == 4) && (kh != 2 || kw != 2 || phase_y < 0 || phase_y > 1 || phase_x < 0 || phase_x > 1))
         return MP_ERR_UNSUPPORTED;

@@ -413,33 +413,33 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams 
 
 // U = G g G^T per (cout, cin), laid out [Cin_pad4][Cout_pad16][16 xi]
 __global__ __launch_bounds__(256) void pack_weight_wino_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin,
-                                                               int cin_pad4, int cout_pad16) {
+                                                               int cin_pad4, int cout_pad16, int transposed) {
     const size_t total = (size_t)cin_pad4 * cout_pad16;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int co = (int)(i % cout_pad16), ci = (int)(i / cout_pad16);
-        float g[3][3];
+        float u[16];
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) g[a][c] = (co < cout && ci < cin) ? w[(((size_t)co * cin + ci) * 3 + a) * 3 + c] : 0.f;
-        float t[4][3];  // G g
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            t[0][c] = g[0][c];
-            t[1][c] = 0.5f * (g[0][c] + g[1][c] + g[2][c]);
-            t[2][c] = 0.5f * (g[0][c] - g[1][c] + g[2][c]);
-            t[3][c] = g[2][c];
-        }
+        for (int k = 0; k < 16; ++k) u[k] = 0.f;
+        if (co < cout && ci < cin) wino_transform_weight(w, cout, cin, transposed, co, ci, u);
         float4* o4 = reinterpret_cast<float4*>(out + i * 16);
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-            o4[a] = make_float4(t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]);
+        for (int a = 0; a < 4; ++a) o4[a] = make_float4(u[a * 4], u[a * 4 + 1], u[a * 4 + 2], u[a * 4 + 3]);
     }
 }
 
 inline unsigned magic_of(unsigned d) { return d <= 1 ? 0u : (unsigned)(0x100000000ULL / d) + 1u; }
 
 }  // namespace
+
+int wino_pack_launch(const float* w, float* packed, int cout, int cin, int transposed, hipStream_t s) {
+    if (!w || !packed) return MP_ERR_NULL;
+    if (cout <= 0 || cin <= 0) return MP_ERR_SHAPE;
+    const int cin_pad4 = (cin + 3) / 4 * 4, cout_pad16 = (cout + 15) / 16 * 16;
+    int blocks = (int)(((size_t)cin_pad4 * cout_pad16 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_weight_wino_kernel, dim3(blocks), dim3(256), 0, s, w, packed, cout, cin, cin_pad4, cout_pad16, transposed);
+    return check_launch();
+}
 
 int wino_configure(const mp_conv_desc* d, WinoLaunch& L) {
     if (!d) return MP_ERR_NULL;
@@ -542,13 +542,7 @@ size_t mp_conv_winograd_packed_weight_bytes(int cout, int cin) {
 }
 
 int mp_conv_winograd_pack_weight(const float* w, float* packed, int cout, int cin, mp_stream_t stream) {
-    if (!w || !packed) return MP_ERR_NULL;
-    if (cout <= 0 || cin <= 0) return MP_ERR_SHAPE;
-    const int cin_pad4 = (cin + 3) / 4 * 4, cout_pad16 = (cout + 15) / 16 * 16;
-    int blocks = (int)(((size_t)cin_pad4 * cout_pad16 + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(pack_weight_wino_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, packed, cout, cin, cin_pad4, cout_pad16);
-    return check_launch();
+    return wino_pack_launch(w, packed, cout, cin, 0, as_stream(stream));
 }
 
 int mp_conv_winograd_supported(const mp_conv_desc* desc) {

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from .layers import BN_EPS, tune_conv_variant
+from .layers import BN_EPS, F32_WINOGRAD, tune_conv_variant, winograd_enabled
 
 BN_MOMENTUM = 0.9  # mindspore.nn.BatchNorm2d(momentum=0.9): moving = 0.9*moving + 0.1*batch [MS-knowledge]
 
@@ -35,11 +35,23 @@ def _desc(n, cin, h, w, cout, k, stride, pad_t, pad_l, conv_h, conv_w, out_h, ou
                          out_off_y=off_y, out_off_x=off_x, relu=0, tap_dilation_unused=0)
 
 
-def _conv_launch(lib, d, x, packed, scale, shift, out, what):
-    """One forward-kernel launch (forward conv or a data-gradient conv) with the autotuned tile variant."""
-    v = tune_conv_variant(lib, d, x, packed, scale, shift, None, None, out)
+def _conv_launch(lib, d, x, packed, scale, shift, out, what, packed_u=None):
+    """One forward-kernel launch (forward conv or a data-gradient conv) with the autotuned tile variant; ``packed_u``: the
+    Winograd form of the same weights (3x3 stride 1), which then competes in the tuner."""
+    v = tune_conv_variant(lib, d, x, packed, scale, shift, None, None, out, packed_u=packed_u)
+    if v == F32_WINOGRAD and packed_u is not None:
+        _lib.check(lib.mp_conv2d_winograd_fwd(ctypes.byref(d), _lib.ptr(x), _lib.ptr(packed_u), _lib.ptr(scale), _lib.ptr(shift), None, None,
+                                              _lib.ptr(out), _lib.stream()), what)
+        return
     _lib.check(lib.mp_conv2d_fwd_variant(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift),
                                          None, None, _lib.ptr(out), _lib.stream()), what)
+
+
+def _pack_winograd(lib, d, w, cout, cin, mode, owner):
+    """Winograd form of a 3x3 weight (mode 5: forward, 6: data gradient) when the descriptor is inside that form, else None."""
+    if not winograd_enabled() or os.environ.get("MINDPOSE_AUTOTUNE", "1") == "0" or lib.mp_conv_winograd_supported(ctypes.byref(d)) != 0:
+        return None
+    return _cached_pack(lib, w, owner, False, cout, cin, 3, mode, 0, 0)
 
 
 def _pack(lib, w, cout, cin, k, mode, py=0, px=0, owner=None):
@@ -64,7 +76,7 @@ class Conv2dFn(torch.autograd.Function):
         z = torch.empty(n, cout, ho, wo, device=x.device, dtype=torch.float32)
         d = _desc(n, cin, h, wd, cout, k, stride, padding, padding, ho, wo, ho, wo)
         packed = _pack(lib, w, cout, cin, k, 0, owner=weight)
-        _conv_launch(lib, d, x, packed, ones, shift, z, "mp_conv2d_fwd")
+        _conv_launch(lib, d, x, packed, ones, shift, z, "mp_conv2d_fwd", packed_u=_pack_winograd(lib, d, w, cout, cin, 5, weight))
         ctx.save_for_backward(x, w)
         ctx.stride, ctx.padding, ctx.has_bias = stride, padding, bias is not None
         ctx.weight_param = weight
@@ -86,7 +98,8 @@ class Conv2dFn(torch.autograd.Function):
                 dx = torch.empty_like(x)
                 d = _desc(n, cout, ho, wo, cin, k, 1, k - 1 - pad, k - 1 - pad, h, wd, h, wd)
                 packed = _pack(lib, w, cin, cout, k, 2, owner=ctx.weight_param)
-                _conv_launch(lib, d, dz, packed, ones, zeros, dx, "conv dgrad")
+                _conv_launch(lib, d, dz, packed, ones, zeros, dx, "conv dgrad",
+                             packed_u=_pack_winograd(lib, d, w, cin, cout, 6, ctx.weight_param) if k == 3 else None)
             else:
                 if h != 2 * ho or wd != 2 * wo:
                     raise NotImplementedError("stride-2 data gradient needs even input extents")
@@ -318,6 +331,8 @@ def _cached_pack(lib, w, owner, half, cout, cin, k, mode, py, px):
     persistent and a packing refreshed by ``repack_weights`` is handed out without a launch."""
     if half:
         numel, dtype = lib.mp_f16_packed_weight_bytes(cout, cin, k, k) // 2, torch.float16
+    elif mode in (5, 6):  # Winograd forms of a 3x3 weight
+        numel, dtype = lib.mp_conv_winograd_packed_weight_bytes(cout, cin) // 4, torch.float32
     else:
         numel, dtype = lib.mp_conv_packed_weight_bytes(cout, cin, k, k) // 4, torch.float32
     entry = None
@@ -365,6 +380,8 @@ def repack_weights(module):
                 arr[i] = _PackJob(prm.data_ptr(), entry.buf.data_ptr(), cout, cin, k, k, mode, py, px, 0)
                 cp = (cout + 15) // 16 * 16
                 units = (cin + 31) // 32 * k * k * 4 * cp if half else (cin + 3) // 4 * 4 * k * k * (cp // 4)
+                if not half and mode in (5, 6):  # Winograd forms: one thread per (cin, cout) pair
+                    units = (cin + 3) // 4 * 4 * cp
                 first[i + 1] = first[i] + (units + 255) // 256
             dev = group[0][0].device
             jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
