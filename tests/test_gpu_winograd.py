@@ -146,3 +146,53 @@ def test_plan_takes_the_winograd_form_where_the_tuner_picks_it_and_env_turns_it_
             assert info["variant"] == F32_WINOGRAD and info["kind"] == "conv_winograd"
     assert kinds[1] == 0  # switched off: direct kernel
     assert kinds[0] in (0, 9)
+
+
+def test_winograd_data_gradient_form_vs_torch_autograd_and_batched_packing():
+    """Pack mode 6 = the data-gradient form (roles swapped, taps mirrored) of a forward weight: dx = winograd(dz, U6) against
+    torch's autograd; pack mode 5 == mp_conv_winograd_pack_weight; both modes as jobs of mp_conv_pack_weight_batch give the same bits."""
+    import numpy as np
+    from mindpose_amd.models.train_ops import _PackJob
+    lib = _lib.load()
+    n, cin, cout, h, w = 3, 16, 40, 12, 16
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(n, cin, h, w, generator=g, dtype=torch.float64, requires_grad=True)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+    dz = torch.randn(n, cout, h, w, generator=g)
+    F.conv2d(x, wt.double(), padding=1).backward(dz.double())
+    st = _lib.stream()
+    wd, dzd = wt.to(DEV), dz.to(DEV)
+    nb = lib.mp_conv_winograd_packed_weight_bytes(cin, cout)  # the data-gradient conv maps cout -> cin channels
+    u6 = torch.empty(nb // 4, device=DEV)
+    _lib.check(lib.mp_conv_pack_weight(_lib.ptr(wd), _lib.ptr(u6), cin, cout, 3, 3, 6, 0, 0, st), "pack mode 6")
+    d = _desc(n, cout, cin, h, w, False)
+    ones, zeros = torch.ones(cin, device=DEV), torch.zeros(cin, device=DEV)
+    dx = torch.empty(n, cin, h, w, device=DEV)
+    _lib.check(lib.mp_conv2d_winograd_fwd(ctypes.byref(d), _lib.ptr(dzd), _lib.ptr(u6), _lib.ptr(ones), _lib.ptr(zeros), None, None,
+                                          _lib.ptr(dx), st), "winograd dgrad")
+    torch.cuda.synchronize()
+    assert float((dx.double().cpu() - x.grad).abs().max() / x.grad.abs().max()) <= 2e-5
+    # mode 5 == the dedicated entry
+    u5a = torch.empty(lib.mp_conv_winograd_packed_weight_bytes(cout, cin) // 4, device=DEV)
+    u5b = torch.empty_like(u5a)
+    _lib.check(lib.mp_conv_winograd_pack_weight(_lib.ptr(wd), _lib.ptr(u5a), cout, cin, st), "pack U")
+    _lib.check(lib.mp_conv_pack_weight(_lib.ptr(wd), _lib.ptr(u5b), cout, cin, 3, 3, 5, 0, 0, st), "pack mode 5")
+    assert torch.equal(u5a, u5b)
+    # both as batch jobs (next to a direct-form job, to exercise the block table)
+    pd = torch.empty(lib.mp_conv_packed_weight_bytes(cout, cin, 3, 3) // 4, device=DEV)
+    pd_ref = torch.empty_like(pd)
+    _lib.check(lib.mp_conv_pack_weight(_lib.ptr(wd), _lib.ptr(pd_ref), cout, cin, 3, 3, 0, 0, 0, st), "pack direct")
+    b5, b6 = torch.zeros_like(u5a), torch.zeros_like(u6)
+    jobs = [(b5, cout, cin, 5), (pd, cout, cin, 0), (b6, cin, cout, 6)]
+    arr = (_PackJob * len(jobs))()
+    first = np.zeros(len(jobs) + 1, dtype=np.uint32)
+    for i, (buf, co, ci, mode) in enumerate(jobs):
+        arr[i] = _PackJob(wd.data_ptr(), buf.data_ptr(), co, ci, 3, 3, mode, 0, 0, 0)
+        cp = (co + 15) // 16 * 16
+        units = (ci + 3) // 4 * 4 * cp if mode in (5, 6) else (ci + 3) // 4 * 4 * 9 * (cp // 4)
+        first[i + 1] = first[i] + (units + 255) // 256
+    jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+    first_dev = torch.from_numpy(first.view(np.int32)).to(DEV)
+    _lib.check(lib.mp_conv_pack_weight_batch(_lib.ptr(jobs_dev), _lib.ptr(first_dev), len(jobs), int(first[-1]), st), "pack batch")
+    torch.cuda.synchronize()
+    assert torch.equal(b5, u5a) and torch.equal(b6, u6) and torch.equal(pd, pd_ref)
