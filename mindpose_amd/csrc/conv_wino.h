@@ -16,7 +16,8 @@ struct WinoParams {
     int TW, TR, M;   // tiles per row, tile rows per workgroup, tiles per workgroup (<= 48, even)
     int G, tpi, img_plane;  // image-grouped bands (W % 4 != 0 maps): images per workgroup, tiles per image, LDS floats per image
     int R, Rin, Wp, cin_plane;
-    int n_chunks, n_ct, bands, total_blocks;
+    int n_chunks, n_ct, bands, total_blocks;  // total_blocks = tiles; a workgroup takes tiles_per_wg consecutive ones
+    int tiles_per_wg;
     int upr, upc;    // float4 staging units per input row / per input channel
     int relu;
     unsigned magic_upr, magic_upc, magic_tw, magic_pairs, magic_tpi, magic_w;

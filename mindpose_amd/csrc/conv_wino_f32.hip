@@ -48,35 +48,46 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams 
     const int raw_buf = kCK * p.cin_plane + 4;  // + one float4 that absorbs the stores of threads without a staging unit
     float* __restrict__ lds_raw = smem;                 // [2][raw_buf]
     float* __restrict__ lds_v = smem + 2 * raw_buf;     // [2][16][kCK][kTP]
-    float* __restrict__ lds_x = smem;                   // epilogue: [16][16][kXP] over everything
+    float* __restrict__ lds_x = lds_v;                  // epilogue: [16][16][kXP] over the V buffers (never over the raw buffers:
+                                                        // their zero halo columns must survive into the workgroup's next tile)
 
     MP_STAMP(t_start);
-    [[maybe_unused]] unsigned long long s_xf = 0, s_b1 = 0, s_mm = 0, s_st = 0, s_b2 = 0;
+    [[maybe_unused]] unsigned long long s_xf = 0, s_b1 = 0, s_mm = 0, s_st = 0, s_b2 = 0, s_pro = 0, s_ep = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane >> 4, lr = lane & 15;
 
-    int b = blockIdx.x;
-    {   // XCD-aware tile id (blocks b, b+8, ... share an XCD): the cout tiles of one band share an L2
-        const int nb = p.total_blocks, q8 = nb >> 3, r8 = nb & 7, xcd = b & 7, j = b >> 3;
-        b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
+    // A workgroup walks p.tiles_per_wg consecutive tiles (same staging tables, one zero fill; the raw rows of the next tile are
+    // requested before the epilogue of the current one, so only the first tile of a workgroup sees the HBM latency).
+    int wg = blockIdx.x;
+    {   // XCD-aware workgroup id (blocks b, b+8, ... share an XCD): neighbouring tiles (cout tiles of one band) share an L2
+        const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, xcd = wg & 7, j = wg >> 3;
+        wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
     }
-    const int ct = b % p.n_ct;
-    b /= p.n_ct;
-    const int band = GROUP ? 0 : b % p.bands, n = GROUP ? b * p.G : b / p.bands;  // GROUP: b = image group, n = its first image
-    const int y0 = band * p.R, y_in0 = y0 - 1;
     const int HW = p.H * p.W;
-    const int n_img = GROUP ? min(p.G, p.N - n) : 1;
+    int ct, n, y0, n_img;  // coordinates of the tile whose INPUT side is being worked on
+    auto tile_coords = [&](int tile) {
+        int b = tile;
+        ct = b % p.n_ct;
+        b /= p.n_ct;
+        const int band = GROUP ? 0 : b % p.bands;
+        n = GROUP ? b * p.G : b / p.bands;  // GROUP: b = image group, n = its first image
+        y0 = band * p.R;
+        n_img = GROUP ? min(p.G, p.N - n) : 1;
+    };
+    const int tile_first = wg * p.tiles_per_wg;
+    tile_coords(tile_first);
 
     // staging tables: float4 units of the chunk's rows.  Branch-free use: a unit outside the image loads zeros (range-checked
     // buffer load) and stores them - halo rows are rewritten with zeros, harmless - and a thread without a unit stores its
     // zeros into the spare float4 behind the buffer.
-    unsigned isrc[NI];
-    int idst[NI];
+    unsigned isrc[NI], irel[NI];  // irel: tile-independent part (kOob: no unit); isrc: + the tile's row validity
+    int irow[NI], idst[NI];
     int idst4[GROUP ? NI : 1][4];  // GROUP: one LDS offset per element of a unit
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const unsigned u = tid + 256 * i;
-        isrc[i] = kOob;
+        irel[i] = kOob;
+        irow[i] = 0;
         idst[i] = kCK * p.cin_plane;
         if constexpr (GROUP) {
 #pragma unroll
@@ -86,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams 
                 const unsigned rem = u - c * p.upc;
                 const unsigned g = fastdiv(rem, p.upr, p.magic_upr);
                 const unsigned k4 = (rem - g * p.upr) * 4;
-                isrc[i] = ((g * p.Cin + c) * HW + k4) * 4u;  // images past the batch: beyond the resource, zeros
+                irel[i] = ((g * p.Cin + c) * HW + k4) * 4u;  // images past the batch: beyond the resource, zeros
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const unsigned k = k4 + j, row = fastdiv(k, p.W, p.magic_w), col = k - row * p.W;
@@ -98,12 +109,20 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams 
             const unsigned rem = u - c * p.upc;
             const unsigned r = fastdiv(rem, p.upr, p.magic_upr);
             const unsigned xu = rem - r * p.upr;
-            const int yin = y_in0 + (int)r;
-            if (yin >= 0 && yin < p.H) isrc[i] = (c * HW + yin * p.W + xu * 4) * 4u;
+            irel[i] = (c * HW + xu * 4) * 4u;
+            irow[i] = (int)r;
             idst[i] = (int)(c * p.cin_plane + r * p.Wp + 1 + xu * 4);
         }
     }
-    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x + (size_t)n * p.Cin * HW, (size_t)n_img * p.Cin * HW * 4);
+    auto tile_rows = [&]() {  // the rows of the current tile's band that lie inside the image
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int yin = y0 - 1 + irow[i];
+            isrc[i] = (GROUP || (yin >= 0 && yin < p.H)) && irel[i] != kOob ? irel[i] + (GROUP ? 0u : (unsigned)yin * p.W * 4u) : kOob;
+        }
+    };
+    tile_rows();
+    __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x + (size_t)n * p.Cin * HW, (size_t)n_img * p.Cin * HW * 4);
     const __amdgpu_buffer_rsrc_t rs_u = make_rsrc(p.u, (size_t)(p.Cin >> 2) * 16 * 4 * p.Cout_pad16 * 4);
 
     // transform item of this thread: (cin, pair of adjacent tiles); the threads beyond the item count repeat the first items
@@ -132,11 +151,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams 
     // U fragments of this wave: xi = 4 * wave + i, cout block nb, k-step q of the chunk.  U is stored [cin][cout][xi]: the four
     // xi of a wave are ONE 16-byte load per (nb, q) - 4 loads per chunk instead of 16
     unsigned u_off[2];
+    auto tile_u = [&]() {
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        const int co = ct * 32 + nb * 16 + lr;
-        u_off[nb] = co < p.Cout_pad16 ? (unsigned)((lq * p.Cout_pad16 + co) * 16 + wave * 4) * 4u : kOob;
-    }
+        for (int nb = 0; nb < 2; ++nb) {
+            const int co = ct * 32 + nb * 16 + lr;
+            u_off[nb] = co < p.Cout_pad16 ? (unsigned)((lq * p.Cout_pad16 + co) * 16 + wave * 4) * 4u : kOob;
+        }
+    };
+    tile_u();
     const unsigned u_q = (unsigned)(4 * p.Cout_pad16 * 16) * 4u;  // next k-step (4 input channels)
     float ucur[4][2][2], unext[4][2][2];
     auto load_u = [&](int ch, float (&dst)[4][2][2]) {
@@ -210,26 +232,19 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams 
         for (int j = 0; j < 4; ++j) *reinterpret_cast<float2*>(dst + (i * 4 + j) * (kCK * kTP)) = make_float2(va[j], vbv[j]);
     };
 
-    f32x4 acc[4][3][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int mb = 0; mb < 3; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) acc[i][mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // prologue: the raw rows of chunks 0 and 1 are requested together, right away (second register set: the accumulators are not
-    // live yet); the zero fill of the halo and the first U fragments run under their latency
+    // the raw rows of chunks 0 and 1 of a tile are requested together (second register set) - for the first tile right away,
+    // under the zero fill of the halo; for the following tiles before the epilogue of their predecessor
     f32x4 vin1[NI];
-    {
+    auto tile_request = [&]() {
         const unsigned xo = (unsigned)kCK * HW * 4u;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             vin[i] = buf_load4(rs_x, isrc[i]);
             vin1[i] = buf_load4(rs_x, isrc[i] + xo);
         }
-    }
-    load_u(0, ucur);
+        load_u(0, ucur);
+    };
+    tile_request();
     {   // zero both raw buffers once: the halo columns are never written by the chunk copies
         const int n4 = (2 * raw_buf) >> 2;  // raw_buf is a multiple of 4
         float4* z = reinterpret_cast<float4*>(lds_raw);
@@ -237,6 +252,40 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams 
         for (int i = tid; i < n4; i += 256) z[i] = zero;
     }
     wg_barrier();  // zero fill complete
+
+    // epilogue constants of this thread (tile-independent part)
+    const int plane_o = HW;
+    const bool ep_on = tid < 192;
+    const unsigned co_l = ep_on ? fastdiv((unsigned)tid, 12, 0x15555556u) : 0u;  // tid / 12
+    const unsigned quad = ep_on ? tid - co_l * 12 : 0u;
+    const unsigned row_b = (unsigned)p.W * 4u;
+    unsigned pix_rel[QROW ? 1 : 4];  // byte offset of a tile's first output pixel relative to the band start; kOob: no such tile
+    int pix_row[QROW ? 1 : 4];
+#pragma unroll
+    for (int e = 0; e < (QROW ? 1 : 4); ++e) {
+        const unsigned tile = quad * 4 + e;
+        unsigned g = 0, r = tile;
+        if constexpr (GROUP) {
+            g = fastdiv(tile, p.tpi, p.magic_tpi);
+            r = tile - g * p.tpi;
+        }
+        const unsigned ty = fastdiv(r, p.TW, p.magic_tw);
+        const unsigned tx = r - ty * p.TW;
+        pix_row[e] = 2 * (int)ty;
+        // GROUP: + the image's offset inside the group (an image past the batch is beyond the resources: nothing loaded / stored)
+        pix_rel[e] = (ep_on && tile < (unsigned)p.M) ? (unsigned)(g * p.Cout * plane_o + 2 * ty * p.W + 2 * tx) * 4u : kOob;
+    }
+
+    for (int it = 0; it < p.tiles_per_wg; ++it) {
+    if (tile_first + it >= p.total_blocks) break;  // workgroup-uniform
+    MP_STAMP(t_tile);
+    f32x4 acc[4][3][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[i][mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     stage_store(0);
     wg_barrier();
     xf_read(0);
@@ -248,6 +297,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams 
     stage_store(1);
     wg_barrier();
     MP_STAMP(t_pro);
+    s_pro += t_pro - t_tile;
 
     // chunk ch: the 48 MFMAs of this wave over V[ch & 1], with the input transform of chunk ch + 1 (raw[(ch + 1) & 1] ->
     // V[(ch + 1) & 1]) woven between them; the raw rows of chunk ch + 2 fly in from global memory meanwhile.  The body is
@@ -296,34 +346,27 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams 
     // co_l of the half and the four tiles 4 quad .. 4 quad + 3; QROW (launch condition: full 48-tile bands, TW % 4 == 0): those
     // four tiles are eight consecutive pixels of two rows -> 16-byte residual loads and stores.  The residual loads are issued
     // before the accumulators go to LDS, so their latency runs under the exchange.
-    const int plane_o = HW;
+    const int e_ct = ct, e_n = n, e_y0 = y0;
     const size_t img_o = (size_t)n_img * p.Cout * plane_o * 4;
-    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(p.out + (size_t)n * p.Cout * plane_o, img_o);
-    const __amdgpu_buffer_rsrc_t rs_r1 = make_rsrc(p.res1 ? p.res1 + (size_t)n * p.Cout * plane_o : p.out, p.res1 ? img_o : 0);
-    const __amdgpu_buffer_rsrc_t rs_r2 = make_rsrc(p.res2 ? p.res2 + (size_t)n * p.Cout * plane_o : p.out, p.res2 ? img_o : 0);
-    const bool ep_on = tid < 192;
-    const unsigned co_l = ep_on ? fastdiv((unsigned)tid, 12, 0x15555556u) : 0u;  // tid / 12
-    const unsigned quad = ep_on ? tid - co_l * 12 : 0u;
-    const unsigned row_b = (unsigned)p.W * 4u;
+    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(p.out + (size_t)e_n * p.Cout * plane_o, img_o);
+    const __amdgpu_buffer_rsrc_t rs_r1 = make_rsrc(p.res1 ? p.res1 + (size_t)e_n * p.Cout * plane_o : p.out, p.res1 ? img_o : 0);
+    const __amdgpu_buffer_rsrc_t rs_r2 = make_rsrc(p.res2 ? p.res2 + (size_t)e_n * p.Cout * plane_o : p.out, p.res2 ? img_o : 0);
     unsigned pix[QROW ? 1 : 4];  // byte offset of a tile's first output pixel inside a channel plane; kOob: tile / row not there
 #pragma unroll
-    for (int e = 0; e < (QROW ? 1 : 4); ++e) {
-        const unsigned tile = quad * 4 + e;
-        unsigned g = 0, r = tile;
-        if constexpr (GROUP) {
-            g = fastdiv(tile, p.tpi, p.magic_tpi);
-            r = tile - g * p.tpi;
-        }
-        const unsigned ty = fastdiv(r, p.TW, p.magic_tw);
-        const unsigned tx = r - ty * p.TW;
-        const int oy = y0 + 2 * (int)ty;
-        // GROUP: + the image's offset inside the group (an image past the batch is beyond the resources: nothing loaded / stored)
-        pix[e] = (ep_on && tile < (unsigned)p.M && oy < p.H) ? (unsigned)(g * p.Cout * plane_o + oy * p.W + 2 * tx) * 4u : kOob;
+    for (int e = 0; e < (QROW ? 1 : 4); ++e)
+        pix[e] = (pix_rel[e] != kOob && e_y0 + pix_row[e] < p.H) ? pix_rel[e] + (unsigned)(e_y0 * p.W) * 4u : kOob;
+    // the next tile of this workgroup: its first raw rows and U fragments are requested now and land during the epilogue
+    if (it + 1 < p.tiles_per_wg && tile_first + it + 1 < p.total_blocks) {
+        tile_coords(tile_first + it + 1);
+        tile_rows();
+        tile_u();
+        rs_x = make_rsrc(p.x + (size_t)n * p.Cin * HW, (size_t)n_img * p.Cin * HW * 4);
+        tile_request();
     }
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-        if (ct * 32 + nb * 16 >= p.Cout_pad16) break;  // workgroup-uniform
-        const int co = ct * 32 + nb * 16 + (int)co_l;
+        if (e_ct * 32 + nb * 16 >= p.Cout_pad16) break;  // workgroup-uniform
+        const int co = e_ct * 32 + nb * 16 + (int)co_l;
         const unsigned co_off = co < p.Cout ? (unsigned)co * plane_o * 4u : kOob;  // kOob + pixel offset stays out of range
         f32x4 r1q[2][2], r2q[2][2];
         float2 r1v[4][2], r2v[4][2];
@@ -397,15 +440,18 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams 
                     }
             }
         }
-        wg_barrier();  // the exchange buffer is free for the second half
+        wg_barrier();  // the exchange buffer is free for the second half / the next tile's raw rows
     }
+    MP_STAMP(t_tile_end);
+    s_ep += t_tile_end - t_epi;
+    }  // tiles of this workgroup
 #if MP_CONV_STAMPS
     {
         MP_STAMP(t_end);
         if (p.dbg && tid == 0) {
             unsigned long long* d = p.dbg + (size_t)blockIdx.x * 8;
-            d[0] = t_end - t_start; d[1] = t_pro - t_start; d[2] = s_xf; d[3] = s_b1; d[4] = s_mm; d[5] = s_st; d[6] = s_b2;
-            d[7] = t_end - t_epi;
+            d[0] = t_end - t_start; d[1] = s_pro; d[2] = s_xf; d[3] = s_b1; d[4] = s_mm; d[5] = s_st; d[6] = s_b2;
+            d[7] = s_ep;
         }
     }
 #endif
@@ -489,11 +535,19 @@ int wino_configure(const mp_conv_desc* d, WinoLaunch& L) {
         p.upc = p.Rin * p.upr;
     }
     if (kCK * p.upc > 3 * 256) return MP_ERR_UNSUPPORTED;
+    // tiles per workgroup: about two resident workgroups per CU in ONE round (at most 8 tiles each)
+    p.tiles_per_wg = p.total_blocks / 512;
+    if (p.tiles_per_wg < 1) p.tiles_per_wg = 1;
+    if (p.tiles_per_wg > 8) p.tiles_per_wg = 8;
+    if (const char* e = getenv("MP_WINO_TILES")) {  // experiments
+        const int v = atoi(e);
+        if (v >= 1 && v <= 64) p.tiles_per_wg = v;
+    }
     p.relu = d->relu;
     p.magic_upr = magic_of(p.upr); p.magic_upc = magic_of(p.upc); p.magic_tw = magic_of(p.TW); p.magic_pairs = magic_of(p.M >> 1);
     p.magic_tpi = magic_of(p.tpi); p.magic_w = magic_of(p.W);
-    const size_t main_bytes = ((size_t)2 * (kCK * p.cin_plane + 4) + 2 * kVFloats) * 4, x_bytes = (size_t)kXFloats * 4;
-    L.lds_bytes = main_bytes > x_bytes ? main_bytes : x_bytes;
+    const size_t raw_bytes = (size_t)2 * (kCK * p.cin_plane + 4) * 4, v_bytes = (size_t)2 * kVFloats * 4, x_bytes = (size_t)kXFloats * 4;
+    L.lds_bytes = raw_bytes + (v_bytes > x_bytes ? v_bytes : x_bytes);
     L.ni = (kCK * p.upc + 255) / 256;
     if (L.lds_bytes > 150 * 1024) return MP_ERR_UNSUPPORTED;
     return MP_OK;
@@ -509,7 +563,7 @@ int wino_launch(const WinoLaunch& L0, hipStream_t s) {
             (void)hipGetLastError();
             attr = true;
         }
-        hipLaunchKernelGGL(kern, dim3(L.p.total_blocks), dim3(256), L.lds_bytes, s, L.p);
+        hipLaunchKernelGGL(kern, dim3((L.p.total_blocks + L.p.tiles_per_wg - 1) / L.p.tiles_per_wg), dim3(256), L.lds_bytes, s, L.p);
         return check_launch();
     };
     // QROW: the four tiles of an epilogue item are eight consecutive pixels of two rows
