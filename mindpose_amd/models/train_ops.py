@@ -35,16 +35,16 @@ def _desc(n, cin, h, w, cout, k, stride, pad_t, pad_l, conv_h, conv_w, out_h, ou
                          out_off_y=off_y, out_off_x=off_x, relu=0, tap_dilation_unused=0)
 
 
-def _conv_launch(lib, d, x, packed, scale, shift, out, what, packed_u=None):
+def _conv_launch(lib, d, x, packed, scale, shift, out, what, packed_u=None, res1=None):
     """One forward-kernel launch (forward conv or a data-gradient conv) with the autotuned tile variant; ``packed_u``: the
-    Winograd form of the same weights (3x3 stride 1), which then competes in the tuner."""
-    v = tune_conv_variant(lib, d, x, packed, scale, shift, None, None, out, packed_u=packed_u)
+    Winograd form of the same weights (3x3 stride 1), which then competes in the tuner; ``res1``: added in the epilogue."""
+    v = tune_conv_variant(lib, d, x, packed, scale, shift, res1, None, out, packed_u=packed_u)
     if v == F32_WINOGRAD and packed_u is not None:
-        _lib.check(lib.mp_conv2d_winograd_fwd(ctypes.byref(d), _lib.ptr(x), _lib.ptr(packed_u), _lib.ptr(scale), _lib.ptr(shift), None, None,
-                                              _lib.ptr(out), _lib.stream()), what)
+        _lib.check(lib.mp_conv2d_winograd_fwd(ctypes.byref(d), _lib.ptr(x), _lib.ptr(packed_u), _lib.ptr(scale), _lib.ptr(shift),
+                                              _lib.ptr(res1), None, _lib.ptr(out), _lib.stream()), what)
         return
     _lib.check(lib.mp_conv2d_fwd_variant(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift),
-                                         None, None, _lib.ptr(out), _lib.stream()), what)
+                                         _lib.ptr(res1), None, _lib.ptr(out), _lib.stream()), what)
 
 
 def _pack_winograd(lib, d, w, cout, cin, mode, owner):
@@ -98,8 +98,10 @@ class Conv2dFn(torch.autograd.Function):
                 dx = torch.empty_like(x)
                 d = _desc(n, cout, ho, wo, cin, k, 1, k - 1 - pad, k - 1 - pad, h, wd, h, wd)
                 packed = _pack(lib, w, cin, cout, k, 2, owner=ctx.weight_param)
+                # ResidualBlockFn: the gradient that reaches x through the identity is added in this launch's epilogue
                 _conv_launch(lib, d, dz, packed, ones, zeros, dx, "conv dgrad",
-                             packed_u=_pack_winograd(lib, d, w, cin, cout, 6, ctx.weight_param) if k == 3 else None)
+                             packed_u=_pack_winograd(lib, d, w, cin, cout, 6, ctx.weight_param) if k == 3 else None,
+                             res1=getattr(ctx, "dx_residual", None))
             else:
                 if h != 2 * ho or wd != 2 * wo:
                     raise NotImplementedError("stride-2 data gradient needs even input extents")
@@ -830,54 +832,79 @@ class _SubCtx:
         self.saved_tensors = tensors
 
 
-class ResidualBlock16Fn(torch.autograd.Function):
-    """A whole residual block on channel-blocked fp16 - conv+BN+ReLU groups whose last BatchNorm adds the block input and applies
-    the ReLU (BasicBlock: two groups, Bottleneck without down-sample: three) - as ONE autograd node.  Same kernels as the
-    per-cell Functions; what it saves is autograd's separate launch that sums the two gradients reaching the block input:
-    the identity's gradient is added in the epilogue of the first conv's data-gradient launch (160 launches per HRNet-W32
-    step)."""
+class _ResidualBlockFn(torch.autograd.Function):
+    """A whole residual block - conv+BN+ReLU groups whose last BatchNorm adds the block input and applies the ReLU (BasicBlock: two
+    groups, Bottleneck without down-sample: three) - as ONE autograd node.  Same kernels as the per-cell Functions; what it
+    saves is autograd's separate launch that sums the two gradients reaching the block input: the identity's gradient is added
+    in the epilogue of the first conv's data-gradient launch (104 launches per HRNet-W32 step).  ``CONV`` / ``BN``: the per-cell
+    Functions of the activation type (channel-blocked fp16, or fp32 NCHW)."""
+    CONV = BN = None
 
-    @staticmethod
-    def forward(ctx, x, meta, *params):
+    @classmethod
+    def forward(cls, ctx, x, meta, *params):
         groups = []
         y = x
         n_groups = len(meta)
         for gi, (stride, padding, mm, mv) in enumerate(meta):
             w, gamma, beta = params[3 * gi: 3 * gi + 3]
             cc, bc = _SubCtx(5), _SubCtx(7)
-            z = Conv16Fn.forward(cc, y, w, None, stride, padding)
+            z = cls.CONV.forward(cc, y, w, None, stride, padding)
             last = gi == n_groups - 1
-            y = BatchNormAct16Fn.forward(bc, z, gamma, beta, x if last else None, mm, mv, True)
+            y = cls.BN.forward(bc, z, gamma, beta, x if last else None, mm, mv, True)
             groups.append((cc, bc))
         ctx.groups = groups
         return y
 
-    @staticmethod
-    def backward(ctx, dy):
+    @classmethod
+    def backward(cls, ctx, dy):
         grads = []
         g = dy
         dres = None
         for gi in range(len(ctx.groups) - 1, -1, -1):
             cc, bc = ctx.groups[gi]
-            dz, dgamma, dbeta, dr, _, _, _ = BatchNormAct16Fn.backward(bc, g)
+            dz, dgamma, dbeta, dr, _, _, _ = cls.BN.backward(bc, g)
             if dr is not None:
                 dres = dr
             if gi == 0:
                 cc.dx_residual = dres
-            g, dw, _, _, _ = Conv16Fn.backward(cc, dz)
+            g, dw, _, _, _ = cls.CONV.backward(cc, dz)
             grads = [dw, dgamma, dbeta] + grads
         ctx.groups = None
         return (g, None, *grads)
 
 
+class ResidualBlock16Fn(_ResidualBlockFn):
+    CONV, BN = Conv16Fn, BatchNormAct16Fn
+
+    @staticmethod
+    def forward(ctx, x, meta, *params):
+        return _ResidualBlockFn.forward.__func__(ResidualBlock16Fn, ctx, x, meta, *params)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _ResidualBlockFn.backward.__func__(ResidualBlock16Fn, ctx, dy)
+
+
+class ResidualBlock32Fn(_ResidualBlockFn):
+    CONV, BN = Conv2dFn, BatchNormActFn
+
+    @staticmethod
+    def forward(ctx, x, meta, *params):
+        return _ResidualBlockFn.forward.__func__(ResidualBlock32Fn, ctx, x, meta, *params)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _ResidualBlockFn.backward.__func__(ResidualBlock32Fn, ctx, dy)
+
+
 def residual_block(x, groups):
-    """``groups`` = [(conv, bn), ...]; relu(bn_k(conv_k(... relu(bn_1(conv_1 x)) ...)) + x).  Channel-blocked fp16 activations with
-    stride-1 first conv take the one-node form above; anything else composes the per-cell functions."""
+    """``groups`` = [(conv, bn), ...]; relu(bn_k(conv_k(... relu(bn_1(conv_1 x)) ...)) + x).  Blocks with a stride-1 first conv take the
+    one-node form above (both activation types); anything else composes the per-cell functions."""
     first = groups[0][0]
-    if _is_c8(x) and first.stride == 1 and all(cv.bias is None for cv, _ in groups) and os.environ.get("MINDPOSE_FUSE_RESIDUAL", "1") != "0":
+    if first.stride == 1 and all(cv.bias is None for cv, _ in groups) and os.environ.get("MINDPOSE_FUSE_RESIDUAL", "1") != "0":
         meta = tuple((cv.stride, cv.padding, bn.moving_mean, bn.moving_variance) for cv, bn in groups)
         params = [t for cv, bn in groups for t in (cv.weight, bn.gamma, bn.beta)]
-        return ResidualBlock16Fn.apply(x, meta, *params)
+        return (ResidualBlock16Fn if _is_c8(x) else ResidualBlock32Fn).apply(x, meta, *params)
     y = x
     for i, (cv, bn) in enumerate(groups):
         y = conv_bn_act(y, cv, bn, relu=True, res=x if i == len(groups) - 1 else None)
