@@ -41,17 +41,43 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     for (int img = sp; img < n; img += kBnSplit) {
         const size_t base = ((size_t)img * c + ch) * hw;
         float f0 = 0.f, f1 = 0.f;  // fp32 per-thread partial over <= hw/256 elements, then fp64
-        for (int i = threadIdx.x; i < hw; i += 256) {
-            if (BWD) {
-                float g = a_in[base + i];
-                if (relu && !(y[base + i] > 0.f)) g = 0.f;
-                const float xh = (z[base + i] - mu) * is;
-                f0 += g;
-                f1 += g * xh;
-            } else {
-                const float v = z[base + i];
-                f0 += v;
-                f1 += v * v;
+        if ((hw & 3) == 0) {  // planes are 16-byte multiples: float4 loads (same element-to-thread order whatever the width:
+                              // thread t takes elements 4q .. 4q+3 for q = t, t + 256, ...)
+            for (int q = threadIdx.x; q < (hw >> 2); q += 256) {
+                const float4 zv = reinterpret_cast<const float4*>(z + base)[q];
+                if (BWD) {
+                    float4 g = reinterpret_cast<const float4*>(a_in + base)[q];
+                    if (relu) {
+                        const float4 yv = reinterpret_cast<const float4*>(y + base)[q];
+                        if (!(yv.x > 0.f)) g.x = 0.f;
+                        if (!(yv.y > 0.f)) g.y = 0.f;
+                        if (!(yv.z > 0.f)) g.z = 0.f;
+                        if (!(yv.w > 0.f)) g.w = 0.f;
+                    }
+                    f0 += g.x; f1 += g.x * ((zv.x - mu) * is);
+                    f0 += g.y; f1 += g.y * ((zv.y - mu) * is);
+                    f0 += g.z; f1 += g.z * ((zv.z - mu) * is);
+                    f0 += g.w; f1 += g.w * ((zv.w - mu) * is);
+                } else {
+                    f0 += zv.x; f1 += zv.x * zv.x;
+                    f0 += zv.y; f1 += zv.y * zv.y;
+                    f0 += zv.z; f1 += zv.z * zv.z;
+                    f0 += zv.w; f1 += zv.w * zv.w;
+                }
+            }
+        } else {
+            for (int i = threadIdx.x; i < hw; i += 256) {
+                if (BWD) {
+                    float g = a_in[base + i];
+                    if (relu && !(y[base + i] > 0.f)) g = 0.f;
+                    const float xh = (z[base + i] - mu) * is;
+                    f0 += g;
+                    f1 += g * xh;
+                } else {
+                    const float v = z[base + i];
+                    f0 += v;
+                    f1 += v * v;
+                }
             }
         }
         s0 += (double)f0;
@@ -66,51 +92,61 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     }
 }
 
-// stage 2 (forward): per channel mean / biased variance -> scale/shift, saved stats, moving-average update.
-// mindspore.nn.BatchNorm2d(momentum=0.9): moving = 0.9 * moving + 0.1 * batch; the moving variance takes the
-// UNBIASED batch variance (cuDNN / PyTorch convention) [MS-knowledge, unverifiable here - affects only the
-// moving statistics, never the training-mode output or any gradient].
-__global__ void bn_finalize_fwd_kernel(const double* __restrict__ part, const float* __restrict__ gamma,
-                                       const float* __restrict__ beta, float* __restrict__ save_mean,
-                                       float* __restrict__ save_invstd, float* __restrict__ scale,
-                                       float* __restrict__ shift, float* __restrict__ moving_mean,
-                                       float* __restrict__ moving_var, int c, double count, float eps, float momentum,
-                                       int nsplit) {
-    // one wave per channel: lane l sums splits l, l + 64, ... then a fixed-order shuffle tree (deterministic)
-    const int ch = blockIdx.x;
-    double s0 = 0.0, s1 = 0.0;
-    for (int sp = threadIdx.x; sp < nsplit; sp += 64) {
-        s0 += part[((size_t)ch * nsplit + sp) * 2 + 0];
-        s1 += part[((size_t)ch * nsplit + sp) * 2 + 1];
+// stage 2 (folded into the apply kernels below): per channel mean / biased variance -> scale/shift, saved stats, moving-average
+// update.  mindspore.nn.BatchNorm2d(momentum=0.9): moving = 0.9 * moving + 0.1 * batch; the moving variance takes the UNBIASED batch
+// variance (cuDNN / PyTorch convention) [MS-knowledge, unverifiable here - affects only the moving statistics, never the
+// training-mode output or any gradient].
+// totals of one channel from its kBnSplit partials: the first wave of the block, lane l = split l, fixed-order shuffle tree
+__device__ __forceinline__ void bn_channel_sums(const double* __restrict__ part, int ch, double& s0, double& s1) {
+    s0 = 0.0;
+    s1 = 0.0;
+    if (threadIdx.x < kBnSplit) {
+        const double2 v = *reinterpret_cast<const double2*>(part + ((size_t)ch * kBnSplit + threadIdx.x) * 2);
+        s0 = v.x;
+        s1 = v.y;
     }
     for (int off = 32; off >= 1; off >>= 1) {
         s0 += __shfl_down(s0, off, 64);
         s1 += __shfl_down(s1, off, 64);
     }
-    if (threadIdx.x != 0) return;
-    const double mean = s0 / count;
-    double var = s1 / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    save_mean[ch] = (float)mean;
-    save_invstd[ch] = invstd;
-    const float sc = gamma[ch] * invstd;
-    scale[ch] = sc;
-    shift[ch] = beta[ch] - (float)mean * sc;
-    if (moving_mean) {
-        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        moving_mean[ch] = momentum * moving_mean[ch] + (1.f - momentum) * (float)mean;
-        moving_var[ch] = momentum * moving_var[ch] + (1.f - momentum) * (float)unbiased;
-    }
 }
 
-// y = act(z * scale[c] + shift[c] (+ res)) - block per (n, c) plane, 16 B per lane when hw % 4 == 0
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, const float* __restrict__ res,
-                                                       float* __restrict__ y, int c, int hw, int relu) {
+// y = act(z * scale[c] + shift[c] (+ res)) - block per (n, c) plane, 16 B per lane when hw % 4 == 0.  Stage 2 is folded in: every
+// block reduces its channel's 32 partials itself (same values, same order in every block); the block of image 0 also writes the
+// saved statistics and the moving averages - one launch less per BatchNorm and direction.
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, const double* __restrict__ part,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                       float* __restrict__ moving_mean, float* __restrict__ moving_var,
+                                                       const float* __restrict__ res, float* __restrict__ y, int c, int hw, int relu,
+                                                       double count, float eps, float momentum) {
     const size_t plane = blockIdx.x;
     const int ch = (int)(plane % c);
-    const float sc = scale[ch], sh = shift[ch];
+    __shared__ float s_sc, s_sh;
+    if (threadIdx.x < 64) {
+        double s0, s1;
+        bn_channel_sums(part, ch, s0, s1);
+        if (threadIdx.x == 0) {
+            const double mean = s0 / count;
+            double var = s1 / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float a = gamma[ch] * invstd;
+            s_sc = a;
+            s_sh = beta[ch] - (float)mean * a;
+            if (plane < (size_t)c) {  // image 0
+                save_mean[ch] = (float)mean;
+                save_invstd[ch] = invstd;
+                if (moving_mean) {
+                    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                    moving_mean[ch] = momentum * moving_mean[ch] + (1.f - momentum) * (float)mean;
+                    moving_var[ch] = momentum * moving_var[ch] + (1.f - momentum) * (float)unbiased;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const float sc = s_sc, sh = s_sh;
     const size_t base = plane * hw;
     if ((hw & 3) == 0) {
         for (int q = threadIdx.x; q < (hw >> 2); q += 256) {
@@ -130,47 +166,66 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     }
 }
 
-// stage 2 (backward): dgamma = sum g*xhat, dbeta = sum g
-__global__ void bn_finalize_bwd_kernel(const double* __restrict__ part, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, float* __restrict__ dgamma_acc,
-                                       float* __restrict__ dbeta_acc, int c, int nsplit) {
-    const int ch = blockIdx.x;
-    double s0 = 0.0, s1 = 0.0;
-    for (int sp = threadIdx.x; sp < nsplit; sp += 64) {
-        s0 += part[((size_t)ch * nsplit + sp) * 2 + 0];
-        s1 += part[((size_t)ch * nsplit + sp) * 2 + 1];
-    }
-    for (int off = 32; off >= 1; off >>= 1) {
-        s0 += __shfl_down(s0, off, 64);
-        s1 += __shfl_down(s1, off, 64);
-    }
-    if (threadIdx.x != 0) return;
-    dbeta[ch] = (float)s0;
-    dgamma[ch] = (float)s1;
-    if (dgamma_acc && dbeta_acc) {  // + straight into the caller's gradient buffers (no separate add launch)
-        dbeta_acc[ch] += (float)s0;
-        dgamma_acc[ch] += (float)s1;
-    }
-}
-
-// dz = gamma*invstd * (g - dbeta/M - xhat*dgamma/M), dres = g  (g = dy masked by the ReLU of the forward output)
+// dz = gamma*invstd * (g - dbeta/M - xhat*dgamma/M), dres = g  (g = dy masked by the ReLU of the forward output); stage 2 folded
+// in like the forward (the block of image 0 writes dgamma / dbeta and adds them into the caller's gradient buffers)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ z,
-                                                           const float* __restrict__ y, const float* __restrict__ gamma,
-                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                           float* __restrict__ dz, float* __restrict__ dres, int c, int hw,
-                                                           int relu, float inv_count) {
+                                                           const float* __restrict__ y, const double* __restrict__ part,
+                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, float* __restrict__ dgamma_acc,
+                                                           float* __restrict__ dbeta_acc, float* __restrict__ dz,
+                                                           float* __restrict__ dres, int c, int hw, int relu, float inv_count) {
     const size_t plane = blockIdx.x;
     const int ch = (int)(plane % c);
+    __shared__ float s_mb, s_mg;
+    if (threadIdx.x < 64) {
+        double s0, s1;
+        bn_channel_sums(part, ch, s0, s1);
+        if (threadIdx.x == 0) {
+            const float db = (float)s0, dg = (float)s1;
+            s_mb = db * inv_count;
+            s_mg = dg * inv_count;
+            if (plane < (size_t)c) {  // image 0
+                dbeta[ch] = db;
+                dgamma[ch] = dg;
+                if (dgamma_acc && dbeta_acc) {  // + straight into the caller's gradient buffers (no separate add launch)
+                    dbeta_acc[ch] += db;
+                    dgamma_acc[ch] += dg;
+                }
+            }
+        }
+    }
+    __syncthreads();
     const float mu = mean[ch], is = invstd[ch];
-    const float k = gamma[ch] * is, mb = dbeta[ch] * inv_count, mg = dgamma[ch] * inv_count;
+    const float k = gamma[ch] * is, mb = s_mb, mg = s_mg;
     const size_t base = plane * hw;
-    for (int i = threadIdx.x; i < hw; i += 256) {
-        float g = dy[base + i];
-        if (relu && !(y[base + i] > 0.f)) g = 0.f;
-        const float xh = (z[base + i] - mu) * is;
-        dz[base + i] = k * (g - mb - xh * mg);
-        if (dres) dres[base + i] = g;
+    if ((hw & 3) == 0) {
+        for (int q = threadIdx.x; q < (hw >> 2); q += 256) {
+            float4 g = reinterpret_cast<const float4*>(dy + base)[q];
+            const float4 zv = reinterpret_cast<const float4*>(z + base)[q];
+            if (relu) {
+                const float4 yv = reinterpret_cast<const float4*>(y + base)[q];
+                if (!(yv.x > 0.f)) g.x = 0.f;
+                if (!(yv.y > 0.f)) g.y = 0.f;
+                if (!(yv.z > 0.f)) g.z = 0.f;
+                if (!(yv.w > 0.f)) g.w = 0.f;
+            }
+            float4 d;
+            d.x = k * (g.x - mb - ((zv.x - mu) * is) * mg);
+            d.y = k * (g.y - mb - ((zv.y - mu) * is) * mg);
+            d.z = k * (g.z - mb - ((zv.z - mu) * is) * mg);
+            d.w = k * (g.w - mb - ((zv.w - mu) * is) * mg);
+            reinterpret_cast<float4*>(dz + base)[q] = d;
+            if (dres) reinterpret_cast<float4*>(dres + base)[q] = g;
+        }
+    } else {
+        for (int i = threadIdx.x; i < hw; i += 256) {
+            float g = dy[base + i];
+            if (relu && !(y[base + i] > 0.f)) g = 0.f;
+            const float xh = (z[base + i] - mu) * is;
+            dz[base + i] = k * (g - mb - xh * mg);
+            if (dres) dres[base + i] = g;
+        }
     }
 }
 
@@ -870,18 +925,13 @@ int mp_bn_train_fwd(const float* z, const float* gamma, const float* beta, const
     if (n <= 0 || c <= 0 || hw <= 0) return MP_ERR_SHAPE;
     if (!workspace || workspace_bytes < mp_bn_workspace_bytes(c)) return MP_ERR_WORKSPACE;
     double* part = reinterpret_cast<double*>(workspace);
-    float* scale = reinterpret_cast<float*>(part + (size_t)c * kBnSplit * 2);
-    float* shift = scale + c;
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(bn_reduce_kernel<false>, dim3(c, kBnSplit), dim3(256), 0, s, nullptr, z, nullptr, nullptr, nullptr, part,
                        n, c, hw, 0);
     int rc = check_launch();
     if (rc != MP_OK) return rc;
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(c), dim3(64), 0, s, part, gamma, beta, save_mean, save_invstd,
-                       scale, shift, moving_mean, moving_var, c, (double)n * hw, eps, momentum, kBnSplit);
-    rc = check_launch();
-    if (rc != MP_OK) return rc;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(n * c), dim3(256), 0, s, z, scale, shift, res, y, c, hw, relu ? 1 : 0);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(n * c), dim3(256), 0, s, z, part, gamma, beta, save_mean, save_invstd, moving_mean,
+                       moving_var, res, y, c, hw, relu ? 1 : 0, (double)n * hw, eps, momentum);
     return check_launch();
 }
 
@@ -907,12 +957,9 @@ int mp_bn_train_bwd_acc(const float* dy, const float* z, const float* y, const f
     int rc = check_launch();
     if (rc != MP_OK) return rc;
     const bool acc = dgamma_acc && dbeta_acc;
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(c), dim3(64), 0, s, part, dgamma, dbeta, acc ? dgamma_acc : nullptr,
-                       acc ? dbeta_acc : nullptr, c, kBnSplit);
-    rc = check_launch();
-    if (rc != MP_OK) return rc;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(n * c), dim3(256), 0, s, dy, z, y, gamma, save_mean, save_invstd, dgamma, dbeta,
-                       dz, dres, c, hw, relu ? 1 : 0, (float)(1.0 / ((double)n * hw)));
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(n * c), dim3(256), 0, s, dy, z, y, part, gamma, save_mean, save_invstd, dgamma, dbeta,
+                       acc ? dgamma_acc : nullptr, acc ? dbeta_acc : nullptr, dz, dres, c, hw, relu ? 1 : 0,
+                       (float)(1.0 / ((double)n * hw)));
     return check_launch();
 }
 

@@ -372,9 +372,13 @@ def test_simplebaseline_r50_fp32_training_step_vs_oracle():
           f"{e_cpu['head.deconv_layer.6.weight']:.2e}; loss {float(loss.detach())} / {l32} / {l64}")
     top = sorted(e_hip, key=e_hip.get, reverse=True)[:6]
     print({n: (f"{e_hip[n]:.2e}", f"{e_cpu[n]:.2e}") for n in top})
-    # worst tensor: the first transposed conv sits on a 4x3 map behind 50 fp32 layers; where exactly a ReLU mask flips differs
-    # between any two fp32 implementations (its kernels match fp64 to 1e-6 at these very shapes: test_deconv_fp32_autograd)
-    assert med_hip < max(2 * med_cpu, 1e-4) and worst_hip < max(2 * worst_cpu, 0.1)
+    # The bulk of the tensors (median, 90th percentile) must be as close to fp64 as torch-CPU fp32 is.  The WORST tensor is not a
+    # stable quantity: the last stage has 4 x 12 positions per channel behind 50 fp32 layers, and where exactly one ReLU mask flips
+    # differs between any two fp32 implementations - a single flip moves a BatchNorm beta gradient of that stage by ~10 % of its
+    # largest entry (seen: 0.06 - 0.11 across summation orders of the same kernels, all of which match fp64 to 1e-6 layer by layer:
+    # test_bn_train_fwd_bwd_vs_torch, test_deconv_fp32_autograd_vs_torch, test_conv_fwd_dgrad_wgrad_vs_torch) - so it only gets a loose bound.
+    p90_hip, p90_cpu = float(np.percentile(list(e_hip.values()), 90)), float(np.percentile(list(e_cpu.values()), 90))
+    assert med_hip < max(2 * med_cpu, 1e-4) and p90_hip < max(2 * p90_cpu, 2e-2) and worst_hip < max(2 * worst_cpu, 0.3)
     for name in ("head.final_layer.weight", "head.final_layer.bias"):
         assert e_hip[name] < 5e-5, (name, e_hip[name])
 
