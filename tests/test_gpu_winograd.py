@@ -196,3 +196,26 @@ def test_winograd_data_gradient_form_vs_torch_autograd_and_batched_packing():
     _lib.check(lib.mp_conv_pack_weight_batch(_lib.ptr(jobs_dev), _lib.ptr(first_dev), len(jobs), int(first[-1]), st), "pack batch")
     torch.cuda.synchronize()
     assert torch.equal(b5, u5a) and torch.equal(b6, u6) and torch.equal(pd, pd_ref)
+
+
+def test_whole_network_with_and_without_the_winograd_form(monkeypatch):
+    """HRNet-W32 at the recipe's resolution, N large enough for the tuner to time candidates: the plan recorded with the Winograd
+    form available contains Winograd entries, and its heat-maps agree with the all-direct plan to 2e-5 of the output scale (each
+    within 1e-3 of the oracle: tests/test_gpu_conv.py) with the same arg-max wherever the top-1 / top-2 margin exceeds that."""
+    import mindpose_amd as mp
+    x = torch.randn(16, 3, 256, 192, generator=torch.Generator().manual_seed(5)).to(DEV)
+    outs, kinds = [], []
+    for env in ("1", "0"):
+        monkeypatch.setenv("MINDPOSE_WINOGRAD", env)
+        net = mp.init_synthetic(mp.create_network("hrnet_w32", "hrnet_head"), seed=0).to(DEV).eval()
+        outs.append(net(x).clone())
+        plan = next(iter(net._plans.values()))
+        kinds.append([plan.entry_info(i)["kind_id"] for i in range(len(plan))])
+    assert kinds[0].count(9) > 100 and kinds[1].count(9) == 0  # 213 eligible 3x3 launches when every shape picks it
+    a, b = outs
+    span = float(b.abs().max())
+    assert float((a - b).abs().max()) / span <= 2e-5
+    n, k = a.shape[:2]
+    top2 = b.reshape(n, k, -1).topk(2, dim=2).values
+    safe = (top2[..., 0] - top2[..., 1]) > 1e-4 * span
+    assert torch.equal(a.reshape(n, k, -1).argmax(2)[safe], b.reshape(n, k, -1).argmax(2)[safe])
