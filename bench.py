@@ -352,9 +352,10 @@ class CallTimer:
                 n, c, hw = args[9:12]
                 tensors = 2 + (args[3] is not None)            # read z, write y (+ read res)
             else:
-                k = 12 if name in ("mp_f16_bn_train_bwd", "mp_bn_train_bwd_acc") else 10
+                k = 13 if name == "mp_f16_bn_train_bwd" else (12 if name == "mp_bn_train_bwd_acc" else 10)
                 n, c, hw = args[k:k + 3]
-                tensors = 4 + (args[7] is not None)            # read dy, z, y; write dz (+ dres)
+                dres = args[8] if name == "mp_f16_bn_train_bwd" else args[7]
+                tensors = 3 + (args[2] is not None) + (dres is not None)   # read dy, z (, y); write dz (+ dres)
             return dict(bytes=float(tensors) * n * c * hw * (2 if half else 4), shape=f"C={c} HW={hw} N={n}")
         return {}
 

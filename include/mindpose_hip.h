@@ -400,11 +400,14 @@ int mp_f16_bn_train_fwd(const void* z_dev, const float* gamma_dev, const float* 
                         float* save_mean_dev, float* save_invstd_dev, float* moving_mean_dev, float* moving_var_dev, int n, int c,
                         int hw, float eps, float momentum, int relu, void* workspace_dev, size_t workspace_bytes, mp_stream_t stream);
 /* dgamma_acc / dbeta_acc (both or neither, may be NULL): the gamma / beta gradients are ALSO added into these buffers (the
- * caller's gradient arena), which saves the framework's separate accumulate launch */
-int mp_f16_bn_train_bwd(const void* dy_dev, const void* z_dev, const void* y_dev, const float* gamma_dev, const float* save_mean_dev,
-                        const float* save_invstd_dev, void* dz_dev, void* dres_dev, float* dgamma_dev, float* dbeta_dev,
-                        float* dgamma_acc_dev, float* dbeta_acc_dev, int n, int c, int hw, int relu, void* workspace_dev,
-                        size_t workspace_bytes, mp_stream_t stream);
+ * caller's gradient arena), which saves the framework's separate accumulate launch.
+ * ReLU mask (relu != 0): taken from the stored forward output y_dev - or, for a layer WITHOUT residual input (dres_dev NULL),
+ * re-derived from z with the forward arithmetic when y_dev is NULL and beta_dev is given (y is then not read: two tensor
+ * reads less).  beta_dev may be NULL when y_dev is passed. */
+int mp_f16_bn_train_bwd(const void* dy_dev, const void* z_dev, const void* y_dev, const float* gamma_dev, const float* beta_dev,
+                        const float* save_mean_dev, const float* save_invstd_dev, void* dz_dev, void* dres_dev, float* dgamma_dev,
+                        float* dbeta_dev, float* dgamma_acc_dev, float* dbeta_acc_dev, int n, int c, int hw, int relu,
+                        void* workspace_dev, size_t workspace_bytes, mp_stream_t stream);
 int mp_f16_fuse_upsample_sum_bwd(const void* dy_dev, const void* out_dev, void* dbase_dev, void* dt1_dev, int s1, void* dt2_dev,
                                  int s2, void* dt3_dev, int s3, int n, int c, int h, int w, int relu, mp_stream_t stream);
 /* weight gradient of a conv (kernel 1x1 or 3x3, stride 1 or 2, padding k/2) from channel-blocked fp16 x and dz on the fp16

@@ -318,6 +318,13 @@ __global__ __launch_bounds__(256) void optimizer_kernel(float* __restrict__ p, c
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
+// The forward output is y = half(max(fma(z, sc, sh), 0)) with sc = gamma * invstd, sh = fma(-mean, sc, beta): these two helpers are
+// the ONLY place that arithmetic is written, because the backward pass of a ReLU layer WITHOUT a residual input re-derives the
+// ReLU mask (y > 0) from z with them instead of reading y (relu mode 2: two tensor reads less per backward BatchNorm).
+__device__ __forceinline__ float bn16_shift(float beta, float mean, float sc) { return __builtin_fmaf(-mean, sc, beta); }
+__device__ __forceinline__ float bn16_affine(float z, float sc, float sh) { return __builtin_fmaf(z, sc, sh); }
+__device__ __forceinline__ bool bn16_relu_open(float z, float sc, float sh) { return (float)(_Float16)bn16_affine(z, sc, sh) > 0.f; }
+
 // fixed-order block reduction of 16 doubles per thread (wave shuffles, then the four waves through LDS)
 __device__ __forceinline__ void block_sum16_256(double (&v)[16], double (*sm)[16]) {
 #pragma unroll
@@ -341,18 +348,21 @@ __device__ __forceinline__ void block_sum16_256(double (&v)[16], double (*sm)[16
 template <bool BWD>
 __global__ __launch_bounds__(256) void bn16_reduce_kernel(const u32x4_t* __restrict__ a_in, const u32x4_t* __restrict__ z,
                                                           const u32x4_t* __restrict__ y, const float* __restrict__ mean,
-                                                          const float* __restrict__ invstd, double* __restrict__ part, int n,
+                                                          const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, double* __restrict__ part, int n,
                                                           int c, int c8, int hw, int relu, int gi, int gp) {
     // split sp = (image group sp % gi, pixel chunk sp / gi): enough blocks to fill the chip even for 4 channel blocks
     const int blk = blockIdx.x, sp = blockIdx.y, nsplit = gi * gp;
     const int ig = sp % gi, pc = sp / gi;
     const int chunk = (hw + gp - 1) / gp, p0 = pc * chunk, p1 = min(p0 + chunk, hw);
-    float mu[8], is[8];
+    float mu[8], is[8], msc[8], msh[8];  // msc / msh: forward scale / shift, for the recomputed ReLU mask (relu == 2)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int ch = blk * 8 + j;
         mu[j] = (BWD && ch < c) ? mean[ch] : 0.f;
         is[j] = (BWD && ch < c) ? invstd[ch] : 0.f;
+        msc[j] = (BWD && relu == 2 && ch < c) ? gamma[ch] * is[j] : 0.f;
+        msh[j] = (BWD && relu == 2 && ch < c) ? bn16_shift(beta[ch], mu[j], msc[j]) : 0.f;
     }
     // The block's elements are {images ig, ig + gi, ...} x {pixels p0 .. p1}: walked as ONE flat index space (the small maps give a
     // block only 1-2 elements per thread and image; an image loop around a pixel loop kept a single load in flight per thread and
@@ -375,11 +385,12 @@ __global__ __launch_bounds__(256) void bn16_reduce_kernel(const u32x4_t* __restr
         if (BWD) {
             const h16x8 gv = __builtin_bit_cast(h16x8, a_in[i]);
             h16x8 yv = zv;
-            if (relu) yv = __builtin_bit_cast(h16x8, y[i]);
+            if (relu == 1) yv = __builtin_bit_cast(h16x8, y[i]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float g = (float)gv[j];
-                if (relu && !((float)yv[j] > 0.f)) g = 0.f;
+                if (relu == 1 && !((float)yv[j] > 0.f)) g = 0.f;
+                if (relu == 2 && !bn16_relu_open((float)zv[j], msc[j], msh[j])) g = 0.f;
                 const float xh = ((float)zv[j] - mu[j]) * is[j];
                 f[2 * j] += g;
                 f[2 * j + 1] += g * xh;
@@ -459,7 +470,7 @@ __global__ __launch_bounds__(256) void bn16_apply_kernel(const u32x4_t* __restri
                 if (var < 0.0) var = 0.0;
                 const float invstd = (float)(1.0 / sqrt(var + (double)eps));
                 sc = gamma[ch] * invstd;
-                sh = beta[ch] - (float)mean * sc;
+                sh = bn16_shift(beta[ch], (float)mean, sc);
                 if (blockIdx.y == 0) {
                     save_mean[ch] = (float)mean;
                     save_invstd[ch] = invstd;
@@ -498,7 +509,7 @@ __global__ __launch_bounds__(256) void bn16_apply_kernel(const u32x4_t* __restri
         for (int j = 0; j < 8; ++j) {
             float v = 0.f;
             if (blk * 8 + j < c) {
-                v = (float)zv[j] * sc[j] + sh[j];
+                v = bn16_affine((float)zv[j], sc[j], sh[j]);
                 if (res) v += (float)rv[j];
                 if (relu) v = fmaxf(v, 0.f);
             }
@@ -515,9 +526,9 @@ __global__ __launch_bounds__(256) void bn16_bwd_apply_kernel(const u32x4_t* __re
                                                              float* __restrict__ dbeta, float* __restrict__ dgamma_acc,
                                                              float* __restrict__ dbeta_acc, u32x4_t* __restrict__ dz,
                                                              u32x4_t* __restrict__ dres, int n, int c, int c8, int hw, int nsplit,
-                                                             int relu, float inv_count) {
+                                                             int relu, float inv_count, const float* __restrict__ beta) {
     const int blk = blockIdx.x;
-    __shared__ float s_k[8], s_mu[8], s_is[8], s_mb[8], s_mg[8];
+    __shared__ float s_k[8], s_mu[8], s_is[8], s_mb[8], s_mg[8], s_sh[8];
     {
         const int j = threadIdx.x >> 5, ch = blk * 8 + j;
         double s0, s1;
@@ -541,12 +552,13 @@ __global__ __launch_bounds__(256) void bn16_bwd_apply_kernel(const u32x4_t* __re
                 }
             }
             s_k[j] = k; s_mu[j] = mu; s_is[j] = is; s_mb[j] = mb; s_mg[j] = mg;
+            s_sh[j] = (relu == 2 && ch < c) ? bn16_shift(beta[ch], mu, k) : 0.f;  // k = gamma * invstd = the forward scale
         }
     }
     __syncthreads();
-    float k[8], mu[8], is[8], mb[8], mg[8];
+    float k[8], mu[8], is[8], mb[8], mg[8], msh[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { k[j] = s_k[j]; mu[j] = s_mu[j]; is[j] = s_is[j]; mb[j] = s_mb[j]; mg[j] = s_mg[j]; }
+    for (int j = 0; j < 8; ++j) { k[j] = s_k[j]; mu[j] = s_mu[j]; is[j] = s_is[j]; mb[j] = s_mb[j]; mg[j] = s_mg[j]; msh[j] = s_sh[j]; }
     const unsigned per_blk = (unsigned)n * (unsigned)hw;
     const unsigned len = (per_blk + gridDim.y - 1) / gridDim.y;
     const unsigned e0 = blockIdx.y * len, e1 = e0 + len < per_blk ? e0 + len : per_blk;
@@ -560,14 +572,15 @@ __global__ __launch_bounds__(256) void bn16_bwd_apply_kernel(const u32x4_t* __re
         const h16x8 gv = __builtin_bit_cast(h16x8, dy[i]);
         const h16x8 zv = __builtin_bit_cast(h16x8, z[i]);
         h16x8 yv = zv;
-        if (relu) yv = __builtin_bit_cast(h16x8, y[i]);
+        if (relu == 1) yv = __builtin_bit_cast(h16x8, y[i]);
         h16x8 oz, og;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float g = 0.f, d = 0.f;
             if (blk * 8 + j < c) {
                 g = (float)gv[j];
-                if (relu && !((float)yv[j] > 0.f)) g = 0.f;
+                if (relu == 1 && !((float)yv[j] > 0.f)) g = 0.f;
+                if (relu == 2 && !bn16_relu_open((float)zv[j], k[j], msh[j])) g = 0.f;
                 const float xh = ((float)zv[j] - mu[j]) * is[j];
                 d = k[j] * (g - mb[j] - xh * mg[j]);
             }
@@ -665,12 +678,14 @@ __global__ __launch_bounds__(256) void bn16_coop_kernel(const u32x4_t* __restric
         const unsigned img = hw <= 1 ? e : (exact ? __umulhi(e, magic_hw) : e / (unsigned)hw);
         return (size_t)e + (size_t)img * img_extra + blk_off;
     };
-    float mu[8], is[8];
+    float mu[8], is[8], msc[8], msh[8];  // msc / msh: forward scale / shift for the recomputed ReLU mask (relu == 2)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int ch = blk * 8 + j;
         mu[j] = (BWD && ch < c) ? mean_io[ch] : 0.f;
         is[j] = (BWD && ch < c) ? invstd_io[ch] : 0.f;
+        msc[j] = (BWD && relu == 2 && ch < c) ? gamma[ch] * is[j] : 0.f;
+        msh[j] = (BWD && relu == 2 && ch < c) ? bn16_shift(beta[ch], mu[j], msc[j]) : 0.f;
     }
     // ---- pass 1: partial sums of this slice
     float f[16];
@@ -683,11 +698,12 @@ __global__ __launch_bounds__(256) void bn16_coop_kernel(const u32x4_t* __restric
         if (BWD) {
             const h16x8 gv = __builtin_bit_cast(h16x8, dy[i]);
             h16x8 yv = zv;
-            if (relu) yv = __builtin_bit_cast(h16x8, yres[i]);
+            if (relu == 1) yv = __builtin_bit_cast(h16x8, yres[i]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float g = (float)gv[j];
-                if (relu && !((float)yv[j] > 0.f)) g = 0.f;
+                if (relu == 1 && !((float)yv[j] > 0.f)) g = 0.f;
+                if (relu == 2 && !bn16_relu_open((float)zv[j], msc[j], msh[j])) g = 0.f;
                 f[2 * j] += g;
                 f[2 * j + 1] += g * (((float)zv[j] - mu[j]) * is[j]);
             }
@@ -740,7 +756,7 @@ __global__ __launch_bounds__(256) void bn16_coop_kernel(const u32x4_t* __restric
                     if (var < 0.0) var = 0.0;
                     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
                     a = gamma[ch] * invstd;
-                    b = beta[ch] - (float)mean * a;
+                    b = bn16_shift(beta[ch], (float)mean, a);
                     if (sp == 0) {
                         mean_io[ch] = (float)mean;
                         invstd_io[ch] = invstd;
@@ -769,13 +785,14 @@ __global__ __launch_bounds__(256) void bn16_coop_kernel(const u32x4_t* __restric
         if (BWD) {
             const h16x8 gv = __builtin_bit_cast(h16x8, dy[i]);
             h16x8 yv = zv;
-            if (relu) yv = __builtin_bit_cast(h16x8, yres[i]);
+            if (relu == 1) yv = __builtin_bit_cast(h16x8, yres[i]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float g = 0.f, d = 0.f;
                 if (blk * 8 + j < c) {
                     g = (float)gv[j];
-                    if (relu && !((float)yv[j] > 0.f)) g = 0.f;
+                    if (relu == 1 && !((float)yv[j] > 0.f)) g = 0.f;
+                if (relu == 2 && !bn16_relu_open((float)zv[j], msc[j], msh[j])) g = 0.f;
                     const float xh = ((float)zv[j] - mu[j]) * is[j];
                     d = ka[j] * (g - kb[j] - xh * kc[j]);
                 }
@@ -791,7 +808,7 @@ __global__ __launch_bounds__(256) void bn16_coop_kernel(const u32x4_t* __restric
             for (int j = 0; j < 8; ++j) {
                 float v = 0.f;
                 if (blk * 8 + j < c) {
-                    v = (float)zv[j] * ka[j] + kb[j];
+                    v = bn16_affine((float)zv[j], ka[j], kb[j]);
                     if (yres) v += (float)rv[j];
                     if (relu) v = fmaxf(v, 0.f);
                 }
@@ -1040,7 +1057,7 @@ int mp_f16_bn_train_fwd(const void* z, const float* gamma, const float* beta, co
     float* scale = reinterpret_cast<float*>(part + (size_t)c * kBn16MaxSplit * 2);
     float* shift = scale + c;
     hipLaunchKernelGGL(bn16_reduce_kernel<false>, dim3(c8, gi * gp), dim3(256), 0, s, nullptr, reinterpret_cast<const u32x4_t*>(z),
-                       nullptr, nullptr, nullptr, part, n, c, c8, hw, 0, gi, gp);
+                       nullptr, nullptr, nullptr, nullptr, nullptr, part, n, c, c8, hw, 0, gi, gp);
     int rc = check_launch();
     if (rc != MP_OK) return rc;
     (void)scale; (void)shift;
@@ -1050,11 +1067,14 @@ int mp_f16_bn_train_fwd(const void* z, const float* gamma, const float* beta, co
     return check_launch();
 }
 
-int mp_f16_bn_train_bwd(const void* dy, const void* z, const void* y, const float* gamma, const float* save_mean,
+int mp_f16_bn_train_bwd(const void* dy, const void* z, const void* y, const float* gamma, const float* beta, const float* save_mean,
                         const float* save_invstd, void* dz, void* dres, float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc,
                         int n, int c, int hw, int relu, void* workspace, size_t workspace_bytes, mp_stream_t stream) {
     if (!dy || !z || !gamma || !save_mean || !save_invstd || !dz || !dgamma || !dbeta) return MP_ERR_NULL;
-    if (relu && !y) return MP_ERR_NULL;
+    // ReLU mask: from the stored output y - or, for a layer without residual input, re-derived from z with the forward arithmetic
+    // (y == NULL, beta given): y is then not read at all
+    if (relu && !y && (!beta || dres)) return MP_ERR_NULL;
+    relu = relu ? (y ? 1 : 2) : 0;
     if (n <= 0 || c <= 0 || hw <= 0) return MP_ERR_SHAPE;
     if (!workspace || workspace_bytes < mp_bn_workspace_bytes(c)) return MP_ERR_WORKSPACE;
     double* part = reinterpret_cast<double*>(workspace);
@@ -1064,25 +1084,25 @@ int mp_f16_bn_train_bwd(const void* dy, const void* z, const void* y, const floa
     if (unsigned long long* counter = bn16_coop_plan(n, c8, hw, s, coop_split)) {  // small map: both passes in one launch
         const bool acc2 = dgamma_acc && dbeta_acc;
         hipLaunchKernelGGL(bn16_coop_kernel<true>, dim3(c8, coop_split), dim3(256), 0, s, reinterpret_cast<const u32x4_t*>(dy),
-                           reinterpret_cast<const u32x4_t*>(z), reinterpret_cast<const u32x4_t*>(y), gamma, nullptr,
+                           reinterpret_cast<const u32x4_t*>(z), reinterpret_cast<const u32x4_t*>(y), gamma, beta,
                            const_cast<float*>(save_mean), const_cast<float*>(save_invstd), nullptr, nullptr, dgamma, dbeta,
                            acc2 ? dgamma_acc : nullptr, acc2 ? dbeta_acc : nullptr, reinterpret_cast<u32x4_t*>(dz),
-                           reinterpret_cast<u32x4_t*>(dres), part, counter, n, c, c8, hw, relu ? 1 : 0, 0.f, 0.f);
+                           reinterpret_cast<u32x4_t*>(dres), part, counter, n, c, c8, hw, relu, 0.f, 0.f);
         return check_launch();
     }
     int gi, gp;
     bn16_split(n, c8, hw, gi, gp);
     hipLaunchKernelGGL(bn16_reduce_kernel<true>, dim3(c8, gi * gp), dim3(256), 0, s, reinterpret_cast<const u32x4_t*>(dy),
-                       reinterpret_cast<const u32x4_t*>(z), reinterpret_cast<const u32x4_t*>(y), save_mean, save_invstd, part, n, c,
-                       c8, hw, relu ? 1 : 0, gi, gp);
+                       reinterpret_cast<const u32x4_t*>(z), reinterpret_cast<const u32x4_t*>(y), save_mean, save_invstd, gamma, beta,
+                       part, n, c, c8, hw, relu, gi, gp);
     int rc = check_launch();
     if (rc != MP_OK) return rc;
     const bool acc = dgamma_acc && dbeta_acc;
     hipLaunchKernelGGL(bn16_bwd_apply_kernel, dim3(c8, bn16_apply_chunks(n, c8, hw)), dim3(256), 0, s,
                        reinterpret_cast<const u32x4_t*>(dy), reinterpret_cast<const u32x4_t*>(z), reinterpret_cast<const u32x4_t*>(y),
                        part, gamma, save_mean, save_invstd, dgamma, dbeta, acc ? dgamma_acc : nullptr, acc ? dbeta_acc : nullptr,
-                       reinterpret_cast<u32x4_t*>(dz), reinterpret_cast<u32x4_t*>(dres), n, c, c8, hw, gi * gp, relu ? 1 : 0,
-                       (float)(1.0 / ((double)n * hw)));
+                       reinterpret_cast<u32x4_t*>(dz), reinterpret_cast<u32x4_t*>(dres), n, c, c8, hw, gi * gp, relu,
+                       (float)(1.0 / ((double)n * hw)), beta);
     return check_launch();
 }
 

@@ -551,7 +551,7 @@ class BatchNormAct16Fn(torch.autograd.Function):
         _lib.check(lib.mp_f16_bn_train_fwd(_lib.ptr(z), _lib.ptr(g), _lib.ptr(b), _lib.ptr(r), _lib.ptr(y), _lib.ptr(mean),
                                            _lib.ptr(invstd), _lib.ptr(moving_mean), _lib.ptr(moving_var), n, c, h * w, BN_EPS,
                                            BN_MOMENTUM, int(relu), _lib.ptr(ws), ws_bytes, _lib.stream()), "mp_f16_bn_train_fwd")
-        ctx.save_for_backward(z, y, g, mean, invstd)
+        ctx.save_for_backward(z, y, g, b, mean, invstd)
         ctx.relu, ctx.has_res = relu, res is not None
         ctx.gamma_param, ctx.beta_param = gamma, beta
         return y
@@ -559,7 +559,9 @@ class BatchNormAct16Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        z, y, g, mean, invstd = ctx.saved_tensors
+        z, y, g, b, mean, invstd = ctx.saved_tensors
+        if ctx.relu and not ctx.has_res and os.environ.get("MINDPOSE_BN16_MASK_FROM_Z", "1") != "0":
+            y = None  # no residual: the ReLU mask is re-derived from z (forward arithmetic), y is not read
         dy = dy.contiguous()
         n, _, h, w, _ = z.shape
         c = g.numel()
@@ -571,9 +573,10 @@ class BatchNormAct16Fn(torch.autograd.Function):
         ga, ba = _direct_grad(ctx.gamma_param), _direct_grad(ctx.beta_param)
         if ga is None or ba is None:
             ga = ba = None
-        _lib.check(lib.mp_f16_bn_train_bwd(_lib.ptr(dy), _lib.ptr(z), _lib.ptr(y), _lib.ptr(g), _lib.ptr(mean), _lib.ptr(invstd),
-                                           _lib.ptr(dz), _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ga), _lib.ptr(ba),
-                                           n, c, h * w, int(ctx.relu), _lib.ptr(ws), ws_bytes, _lib.stream()), "mp_f16_bn_train_bwd")
+        _lib.check(lib.mp_f16_bn_train_bwd(_lib.ptr(dy), _lib.ptr(z), _lib.ptr(y), _lib.ptr(g), _lib.ptr(b), _lib.ptr(mean),
+                                           _lib.ptr(invstd), _lib.ptr(dz), _lib.ptr(dres), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ga),
+                                           _lib.ptr(ba), n, c, h * w, int(ctx.relu), _lib.ptr(ws), ws_bytes, _lib.stream()),
+                   "mp_f16_bn_train_bwd")
         if ga is not None:
             return dz, None, None, dres, None, None, None
         return dz, dgamma, dbeta, dres, None, None, None

@@ -175,10 +175,21 @@ def test_bn_train_f16_fwd_bwd_vs_torch(c, h, w, relu, with_res):
     dgm, dbt = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
     acc_g, acc_b = torch.full((c,), 1.0, device=DEV), torch.full((c,), 2.0, device=DEV)
     dya = _to_c8(dy)
-    _lib.check(LIB.mp_f16_bn_train_bwd(_lib.ptr(dya), _lib.ptr(za), _lib.ptr(ya), _lib.ptr(dgam), _lib.ptr(mean),
+    _lib.check(LIB.mp_f16_bn_train_bwd(_lib.ptr(dya), _lib.ptr(za), _lib.ptr(ya), _lib.ptr(dgam), _lib.ptr(dbet), _lib.ptr(mean),
                                        _lib.ptr(invstd), _lib.ptr(dza), _lib.ptr(dra), _lib.ptr(dgm), _lib.ptr(dbt), _lib.ptr(acc_g),
                                        _lib.ptr(acc_b), n, c, h * w, int(relu), _lib.ptr(ws), nb, _lib.stream()), "bn bwd")
     assert torch.equal(acc_g, dgm + 1.0) and torch.equal(acc_b, dbt + 2.0)  # also added into the caller's buffers
+    if relu and not with_res:
+        # the same pass with the ReLU mask re-derived from z (y not passed): bit-identical outputs
+        dz2, dg2, db2 = ActC8(n, c, h, w, DEV), torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+        _lib.check(LIB.mp_f16_bn_train_bwd(_lib.ptr(dya), _lib.ptr(za), None, _lib.ptr(dgam), _lib.ptr(dbet), _lib.ptr(mean),
+                                           _lib.ptr(invstd), _lib.ptr(dz2), None, _lib.ptr(dg2), _lib.ptr(db2), None, None, n, c, h * w, 1,
+                                           _lib.ptr(ws), nb, _lib.stream()), "bn bwd, mask from z")
+        assert torch.equal(dz2.c8_tensor, dza.c8_tensor) and torch.equal(dg2, dgm) and torch.equal(db2, dbt)
+    if relu and with_res:  # a residual layer cannot re-derive its mask: rejected, not silently wrong
+        assert LIB.mp_f16_bn_train_bwd(_lib.ptr(dya), _lib.ptr(za), None, _lib.ptr(dgam), _lib.ptr(dbet), _lib.ptr(mean), _lib.ptr(invstd),
+                                       _lib.ptr(dza), _lib.ptr(dra), _lib.ptr(dgm), _lib.ptr(dbt), None, None, n, c, h * w, 1, _lib.ptr(ws),
+                                       nb, _lib.stream()) == -1  # MP_ERR_NULL
     # where the kernel's fp16 y and torch's fp32 y disagree about the ReLU mask (y within an ulp of 0) nothing is compared
     _close16(_from_c8(dza), _h(zt.grad), "dz")
     assert torch.allclose(dgm.cpu(), gt.grad, rtol=2e-3, atol=2e-3 * float(gt.grad.abs().max()))

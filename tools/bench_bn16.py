@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """fp16 training BatchNorm passes (mp_f16_bn_train_fwd / _bwd) on the HRNet-W32 layer shapes: time per call against the
-algorithmic bytes (forward: z twice + y [+ res]; backward: dy, z [, y] twice + dz [+ dres]).
+algorithmic bytes (forward: z twice + y [+ res]; backward: dy, z twice + dz, with a residual also y twice + dres).
    python tools/bench_bn16.py [N]"""
 import os, statistics, sys
 import torch
@@ -38,10 +38,12 @@ for c, h, w in SHAPES:
         r = res if with_res else None
         f = lambda: _lib.check(lib.mp_f16_bn_train_fwd(_lib.ptr(z), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(r), _lib.ptr(y), _lib.ptr(mean),
                                                        _lib.ptr(invstd), _lib.ptr(mm), _lib.ptr(mv), n, c, hw, 1e-5, 0.9, relu, _lib.ptr(ws), nb, st), "fwd")
-        b = lambda: _lib.check(lib.mp_f16_bn_train_bwd(_lib.ptr(dy), _lib.ptr(z), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(mean), _lib.ptr(invstd),
-                                                       _lib.ptr(dz), _lib.ptr(dres if with_res else None), _lib.ptr(dg), _lib.ptr(db), None, None,
+        # a layer without residual input re-derives its ReLU mask from z (y not passed), as the training path does
+        b = lambda: _lib.check(lib.mp_f16_bn_train_bwd(_lib.ptr(dy), _lib.ptr(z), _lib.ptr(y if with_res else None), _lib.ptr(gamma),
+                                                       _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(dz),
+                                                       _lib.ptr(dres if with_res else None), _lib.ptr(dg), _lib.ptr(db), None, None,
                                                        n, c, hw, relu, _lib.ptr(ws), nb, st), "bwd")
         tf, tb = timed(f), timed(b)
-        bf, bb = a * (3 + with_res), a * (7 + with_res)
+        bf, bb = a * (3 + with_res), a * (5 + 3 * with_res)
         print(f"C={c:3d} {h}x{w} N={n} ({a / 1e6:6.1f} MB) relu res={int(with_res)}: fwd {tf:6.1f} us ({bf / tf / 1e6:5.2f} TB/s)   "
               f"bwd {tb:6.1f} us ({bb / tb / 1e6:5.2f} TB/s)", flush=True)
