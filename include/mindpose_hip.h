@@ -410,6 +410,12 @@ int mp_f16_bn_train_bwd(const void* dy_dev, const void* z_dev, const void* y_dev
                         void* workspace_dev, size_t workspace_bytes, mp_stream_t stream);
 int mp_f16_fuse_upsample_sum_bwd(const void* dy_dev, const void* out_dev, void* dbase_dev, void* dt1_dev, int s1, void* dt2_dev,
                                  int s2, void* dt3_dev, int s3, int n, int c, int h, int w, int relu, mp_stream_t stream);
+
+/* out = a + b (+ c) (+ d) over `bytes` bytes (a multiple of 16) of fp32 (half = 0) or fp16 (half = 1, fp32 sums, one rounding):
+ * the fan-in of gradients at a tensor with several consumers - every branch output of an HRModule feeds every exchange-unit row
+ * (hrnet.py:318-344) - in one pass instead of the framework's k - 1 pairwise adds.  out may alias an input. */
+int mp_sum_tensors(const void* a_dev, const void* b_dev, const void* c_dev, const void* d_dev, void* out_dev, size_t bytes, int half,
+                   mp_stream_t stream);
 /* weight gradient of a conv (kernel 1x1 or 3x3, stride 1 or 2, padding k/2) from channel-blocked fp16 x and dz on the fp16
  * matrix cores, fp32 accumulation and fp32 result dw [Cout,Cin,kh,kw] (times `scale`: pass 1 / loss_scale); accumulate != 0
  * adds into dw (the caller's gradient arena) instead of overwriting; workspace from mp_f16_conv_wgrad_workspace_bytes */

@@ -83,6 +83,7 @@ _PROTOTYPES = {
     "mp_allreduce_grads": (c_int, [ctypes.c_void_p, c_f32p, c_size_t, c_int, ctypes.c_void_p]),
     "mp_reduce_scatter_allgather_grads": (c_int, [ctypes.c_void_p, c_f32p, c_size_t, c_int, c_int, c_int, ctypes.c_void_p]),
     "mp_f16_bn_train_fwd": (c_int, [c_f32p] * 9 + [c_int] * 3 + [ctypes.c_float, ctypes.c_float, c_int, c_f32p, c_size_t, ctypes.c_void_p]),
+    "mp_sum_tensors": (c_int, [c_f32p] * 5 + [c_size_t, c_int, ctypes.c_void_p]),
     "mp_f16_bn_train_bwd": (c_int, [c_f32p] * 13 + [c_int] * 4 + [c_f32p, c_size_t, ctypes.c_void_p]),
     "mp_f16_fuse_upsample_sum_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_int, c_f32p, c_int] + [c_int] * 5 + [ctypes.c_void_p]),
     "mp_f16_conv_wgrad_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),

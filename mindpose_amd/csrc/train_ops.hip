@@ -897,6 +897,41 @@ __global__ __launch_bounds__(256) void fuse_sum16_bwd_kernel(const u32x4_t* __re
     }
 }
 
+// out = a + b (+ c) (+ d): the gradients that reach one tensor from its consumers (the exchange unit feeds every branch output to
+// every row) summed in ONE pass with fp32 arithmetic - autograd would add them pairwise, k - 1 launches of 3 tensors each.
+// fp16: 16-byte units of 8 halves, one rounding at the end.
+template <bool HALF>
+__global__ __launch_bounds__(256) void sum_tensors_kernel(const u32x4_t* __restrict__ a, const u32x4_t* __restrict__ b,
+                                                          const u32x4_t* __restrict__ c, const u32x4_t* __restrict__ d,
+                                                          u32x4_t* __restrict__ out, size_t units) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < units; i += (size_t)gridDim.x * 256) {
+        const u32x4_t va = a[i], vb = b[i];
+        u32x4_t vc = va, vd = va;
+        if (c) vc = c[i];
+        if (d) vd = d[i];
+        if (HALF) {
+            const h16x8 ha = __builtin_bit_cast(h16x8, va), hb = __builtin_bit_cast(h16x8, vb), hc = __builtin_bit_cast(h16x8, vc),
+                        hd = __builtin_bit_cast(h16x8, vd);
+            h16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = (float)ha[j] + (float)hb[j];
+                if (c) v += (float)hc[j];
+                if (d) v += (float)hd[j];
+                o[j] = (_Float16)v;
+            }
+            out[i] = __builtin_bit_cast(u32x4_t, o);
+        } else {
+            const float4 fa = __builtin_bit_cast(float4, va), fb = __builtin_bit_cast(float4, vb), fc = __builtin_bit_cast(float4, vc),
+                         fd = __builtin_bit_cast(float4, vd);
+            float4 o = make_float4(fa.x + fb.x, fa.y + fb.y, fa.z + fb.z, fa.w + fb.w);
+            if (c) { o.x += fc.x; o.y += fc.y; o.z += fc.z; o.w += fc.w; }
+            if (d) { o.x += fd.x; o.y += fd.y; o.z += fd.z; o.w += fd.w; }
+            out[i] = __builtin_bit_cast(u32x4_t, o);
+        }
+    }
+}
+
 // image groups x pixel chunks of the fp16 reductions: about 512+ blocks, fixed by the shape (deterministic)
 static void bn16_split(int n, int c8, int hw, int& gi, int& gp) {
     int want = 512 / c8;  // a block should stream >= ~50 KB to amortise its reduction tail
@@ -1127,6 +1162,24 @@ int mp_f16_fuse_upsample_sum_bwd(const void* dy, const void* out, void* dbase, v
         if (rc != MP_OK) return rc;
     }
     return MP_OK;
+}
+
+int mp_sum_tensors(const void* a, const void* b, const void* c, const void* d, void* out, size_t bytes, int half, mp_stream_t stream) {
+    if (!a || !b || !out) return MP_ERR_NULL;
+    if (d && !c) return MP_ERR_NULL;
+    if (bytes == 0 || (bytes & 15)) return MP_ERR_SHAPE;
+    const size_t units = bytes / 16;
+    size_t blocks = (units + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    const u32x4_t *pa = reinterpret_cast<const u32x4_t*>(a), *pb = reinterpret_cast<const u32x4_t*>(b),
+                  *pc = reinterpret_cast<const u32x4_t*>(c), *pd = reinterpret_cast<const u32x4_t*>(d);
+    if (half)
+        hipLaunchKernelGGL(sum_tensors_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), pa, pb, pc, pd,
+                           reinterpret_cast<u32x4_t*>(out), units);
+    else
+        hipLaunchKernelGGL(sum_tensors_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), pa, pb, pc, pd,
+                           reinterpret_cast<u32x4_t*>(out), units);
+    return check_launch();
 }
 
 }  // extern "C"

@@ -265,21 +265,26 @@ class HRModule(nn.Module):
                     xs[i] = blk.train_forward(xs[i])
         if self.num_branches == 1:
             return xs
+        # every branch output feeds every row of the exchange unit: one handle per row, so that the backward pass sums the rows'
+        # gradients in one launch per branch (T.FanOutFn) instead of pairwise
+        rows = len(self.fuse_layers)
+        handles = [T.fan_out(x, rows) for x in xs]
         outs = []
-        for i in range(len(self.fuse_layers)):
+        for i in range(rows):
             terms = []
             for j in range(self.num_branches):
+                xj = handles[j][i]
                 if j == i:
-                    terms.append((xs[j], 1))
+                    terms.append((xj, 1))
                 elif j > i:
                     seq = self.fuse_layers[i][j]
                     up = xs[i].shape[2] // xs[j].shape[2]
                     if xs[j].shape[2] * up != xs[i].shape[2] or xs[j].shape[3] * up != xs[i].shape[3]:
                         raise ValueError("HRNet fuse needs an integer nearest-upsample factor")
-                    terms.append((_train_conv_bn(seq, xs[j], relu=False), up))
+                    terms.append((_train_conv_bn(seq, xj, relu=False), up))
                 else:
                     chain = self.fuse_layers[i][j]
-                    t = xs[j]
+                    t = xj
                     for k in range(len(chain)):
                         t = _train_conv_bn(chain[k], t)
                     terms.append((t, 1))

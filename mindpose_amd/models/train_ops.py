@@ -928,6 +928,42 @@ def conv_bn_act(x, conv, bn, relu: bool, res: Optional[torch.Tensor] = None):
     return BatchNormActFn.apply(z, bn.gamma, bn.beta, res, bn.moving_mean, bn.moving_variance, relu)
 
 
+class FanOutFn(torch.autograd.Function):
+    """``k`` handles on one tensor for ``k`` consumers; the backward pass sums the ``k`` gradients in ONE launch
+    (``mp_sum_tensors``: fp32 arithmetic, one rounding) instead of autograd's ``k - 1`` pairwise add kernels."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(k))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g.contiguous() for g in grads if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        lib = _lib.load()
+        half = gs[0].dtype == torch.float16
+        out = gs[0]
+        for i in range(1, len(gs), 3):  # up to four operands per launch (the running sum + three more)
+            ops = gs[i:i + 3]
+            dst = torch.empty_like(gs[0])
+            _lib.check(lib.mp_sum_tensors(_lib.ptr(out), _lib.ptr(ops[0]), _lib.ptr(ops[1]) if len(ops) > 1 else None,
+                                          _lib.ptr(ops[2]) if len(ops) > 2 else None, _lib.ptr(dst), dst.numel() * dst.element_size(),
+                                          int(half), _lib.stream()), "mp_sum_tensors")
+            out = dst
+        return out, None
+
+
+def fan_out(x, k: int):
+    """``k`` handles on ``x`` whose gradients are summed by one kernel; needs 16-byte multiples (every activation here is)."""
+    if k <= 1 or not x.is_cuda or not x.requires_grad or (x.numel() * x.element_size()) % 16 or os.environ.get("MINDPOSE_FAN_OUT", "1") == "0":
+        return (x,) * k
+    return FanOutFn.apply(x, k)
+
+
 def fuse_sum(base, terms):
     """terms = [(tensor, integer scale), ...] (1-3 entries)."""
     fn = FuseSum16Fn if _is_c8(base) else FuseSumFn

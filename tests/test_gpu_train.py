@@ -410,3 +410,28 @@ def test_batched_fp32_weight_pack_equals_individual_packs():
     torch.cuda.synchronize()
     for a, b, sp in zip(single, batch, specs):
         assert torch.equal(a, b), sp
+
+
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("k", [2, 3, 4, 6])
+def test_fan_out_sums_consumer_gradients_in_one_launch(half, k):
+    """T.fan_out(x, k): k handles on x; the backward pass returns the sum of the k consumers' gradients (mp_sum_tensors: fp32
+    arithmetic, for fp16 one rounding per running sum of up to four operands)."""
+    from mindpose_amd.models import train_ops as T
+    g = torch.Generator().manual_seed(k)
+    shape = (3, 4, 6, 10, 8) if half else (3, 32, 6, 10)
+    x = torch.randn(shape, generator=g).to(DEV)
+    x = (x.half() if half else x).requires_grad_(True)
+    ws = [torch.randn(shape, generator=g).to(DEV).to(x.dtype) for _ in range(k)]
+    hs = T.fan_out(x, k)
+    assert len(hs) == k and all(h.data_ptr() == x.data_ptr() for h in hs)
+    sum((h * w).sum() for h, w in zip(hs, ws)).backward()
+    ref = torch.stack([w.double() for w in ws]).sum(0)
+    tol = 2e-3 if half else 1e-6
+    assert float((x.grad.double() - ref).abs().max()) <= tol * float(ref.abs().max())
+    # a consumer that produces no gradient is skipped
+    x2 = x.detach().clone().requires_grad_(True)
+    a, b, c = T.fan_out(x2, 3)
+    ((a * ws[0]).sum() + (c * ws[1]).sum() + b.detach().sum()).backward()
+    ref2 = ws[0].double() + ws[1].double()
+    assert float((x2.grad.double() - ref2).abs().max()) <= tol * float(ref2.abs().max())
