@@ -219,3 +219,35 @@ def test_whole_network_with_and_without_the_winograd_form(monkeypatch):
     top2 = b.reshape(n, k, -1).topk(2, dim=2).values
     safe = (top2[..., 0] - top2[..., 1]) > 1e-4 * span
     assert torch.equal(a.reshape(n, k, -1).argmax(2)[safe], b.reshape(n, k, -1).argmax(2)[safe])
+
+
+@pytest.mark.parametrize("tiles", [2, 3, 8])
+@pytest.mark.parametrize("case", [(5, 16, 32, 16, 24), (3, 32, 48, 12, 48), (9, 24, 16, 8, 6), (2, 8, 80, 20, 16)],
+                         ids=lambda c: f"n{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}")
+def test_winograd_several_tiles_per_workgroup(case, tiles, monkeypatch):
+    """The production launches give a workgroup up to 8 consecutive tiles (next tile's rows requested before the epilogue, zero
+    halo columns and staging tables reused); small test shapes would never get more than one, so the count is forced here -
+    incl. counts that do not divide the number of tiles, cout tiles changing inside a workgroup's run, image-grouped bands."""
+    monkeypatch.setenv("MP_WINO_TILES", str(tiles))
+    n, cin, cout, h, w = case
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n * 7 + tiles)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    r1 = torch.randn(n, cout, h, w, generator=g)
+    ref = F.relu(F.conv2d(x.double(), wt.double(), padding=1) * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]
+                 + r1.double())
+    d = _desc(n, cin, cout, h, w, True)
+    assert lib.mp_conv_winograd_supported(ctypes.byref(d)) == 0
+    st = _lib.stream()
+    wd = wt.to(DEV)
+    pu = torch.empty(lib.mp_conv_winograd_packed_weight_bytes(cout, cin) // 4, device=DEV)
+    _lib.check(lib.mp_conv_winograd_pack_weight(_lib.ptr(wd), _lib.ptr(pu), cout, cin, st), "pack U")
+    out = torch.full((n, cout, h, w), float("nan"), device=DEV)
+    xd, sc, sh, rd = x.to(DEV), scale.to(DEV), shift.to(DEV), r1.to(DEV)  # (held: the launch is asynchronous)
+    _lib.check(lib.mp_conv2d_winograd_fwd(ctypes.byref(d), _lib.ptr(xd), _lib.ptr(pu), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(rd), None,
+                                          _lib.ptr(out), st), "winograd")
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    assert float((out.double().cpu() - ref).abs().max() / ref.abs().max()) <= 2e-5
