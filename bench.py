@@ -90,6 +90,8 @@ def kernel_name(info):
         if v >= 10:
             return f"conv_f16_mt_kernel<{info['ks']},{info['stride']},{F16_VARIANT_TEMPLATE[v % 5]}>/occ{1 if v >= 15 else 2}"
         return f"conv_f16_kernel<{info['ks']},{info['stride']},{F16_VARIANT_TEMPLATE[v]}>" + ("/occ3" if info.get("light") else "")
+    if info["variant"] == 8:  # streaming 1x1 kernel <Cin / 4, cout blocks per wave> (entry_info: light = Cin / 4, images_per_tile = CBW)
+        return f"conv1x1_f32_stream_kernel<{info.get('light', 0)},{info.get('images_per_tile', 0)}>"
     return f"conv_mfma_kernel<{info['ks']},{info['stride']},{VARIANT_TEMPLATE[info['variant']]}>" + ("/occ3" if info.get("light") else "")
 
 
@@ -340,7 +342,7 @@ class CallTimer:
         if name in CallTimer.CONV + CallTimer.WGRAD:
             d = args[0]._obj  # ctypes.byref(mp_conv_desc)
             flops = 2.0 * d.n * d.conv_h * d.conv_w * d.cout * d.cin * d.kh * d.kw
-            variant = args[1] if name in ("mp_f16_conv2d_fwd", "mp_conv2d_fwd_variant") else (8 if name == "mp_conv2d_winograd_fwd" else None)
+            variant = args[1] if name in ("mp_f16_conv2d_fwd", "mp_conv2d_fwd_variant") else (9 if name == "mp_conv2d_winograd_fwd" else None)
             return dict(flops=flops, shape=f"{d.kh}x{d.kw} s{d.stride} {d.cin}->{d.cout} @{d.h}x{d.w} N={d.n}", variant=variant,
                         ks=d.kh, stride=d.stride)
         if name in CallTimer.BN:
@@ -384,8 +386,10 @@ def f16_kernel_for(ks, stride, variant):
 
 
 def f32_kernel_for(ks, stride, variant):
-    if variant == 8:
+    if variant == 9:
         return "conv_wino_f32_kernel"
+    if variant == 8:
+        return "conv1x1_f32_stream_kernel"
     light = variant in (0, 5, 7)  # conv_mfma.h variant_light
     return kernel_name(dict(kind_id=0, ks=ks, stride=stride, variant=variant, light=light)) if variant is not None and variant >= 0 else "library heuristic"
 

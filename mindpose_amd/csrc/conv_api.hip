@@ -7,6 +7,7 @@
 
 #include "conv_f16.h"
 #include "conv_mfma.h"
+#include "conv_pw.h"
 #include "conv_wino.h"
 
 namespace mp {
@@ -118,7 +119,11 @@ struct ConvLaunch {
     ConvKParams p;
     int ks, stride, variant;
     size_t lds_bytes;
+    bool pointwise;  // variant kPointwise: the streaming 1x1 kernel (conv_pw_f32.hip), launch record in pw
+    PwLaunch pw;
 };
+
+constexpr int kPointwise = V_COUNT;  // forced-variant index of the streaming 1x1 kernel (never chosen by the library heuristic)
 
 static const int kLdsMax = 150 * 1024;
 
@@ -214,6 +219,14 @@ static bool configure(const mp_conv_desc& d, int variant, ConvLaunch& L) {
 }
 
 static int choose_variant(const mp_conv_desc& d, ConvLaunch& best, int forced = -1) {
+    if (forced == kPointwise) {
+        int rc = pw_configure(&d, best.pw);
+        if (rc != MP_OK) return rc;
+        best.pointwise = true;
+        best.ks = 1; best.stride = 1; best.variant = kPointwise;
+        best.lds_bytes = best.pw.lds_bytes;
+        return MP_OK;
+    }
     if (forced >= 0) {
         if (forced >= V_COUNT) return MP_ERR_UNSUPPORTED;
         return configure(d, forced, best) ? MP_OK : MP_ERR_UNSUPPORTED;
@@ -270,6 +283,7 @@ static int validate_desc(const mp_conv_desc* d) {
 }
 
 static int launch(const ConvLaunch& L0, hipStream_t s) {
+    if (L0.pointwise) return pw_launch(L0.pw, s);
     ConvLaunch L = L0;
     L.p.dbg = (g_stamp_buf && (size_t)L.p.total_blocks * 64 <= g_stamp_bytes) ? g_stamp_buf : nullptr;
     switch (L.ks) {
@@ -290,6 +304,11 @@ static int build_launch(const mp_conv_desc* desc, const float* x, const float* w
     if (!x || !w || !scale || !shift || !out) return MP_ERR_NULL;
     rc = choose_variant(*desc, L, forced);
     if (rc != MP_OK) return rc;
+    if (L.pointwise) {
+        if (res2) return MP_ERR_UNSUPPORTED;  // one residual tensor in the streaming kernel
+        L.pw.p.x = x; L.pw.p.wp = w; L.pw.p.scale = scale; L.pw.p.shift = shift; L.pw.p.res1 = res1; L.pw.p.out = out;
+        return MP_OK;
+    }
     L.p.x = x; L.p.wp = w; L.p.scale = scale; L.p.shift = shift; L.p.res1 = res1; L.p.res2 = res2; L.p.out = out;
     return MP_OK;
 }
@@ -599,7 +618,11 @@ int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]) {
     const mp_plan::Entry& e = plan->entries[index];
     for (int i = 0; i < 12; ++i) info[i] = 0;
     info[0] = e.kind;
-    if (e.kind == 0) {
+    if (e.kind == 0 && e.conv.pointwise) {
+        info[1] = 1; info[2] = 1; info[3] = kPointwise; info[4] = e.conv.pw.grid; info[5] = (int64_t)e.conv.pw.lds_bytes;
+        info[6] = e.conv.pw.p.Cout; info[7] = 64; info[8] = 64; info[9] = e.conv.pw.cbw; info[10] = e.conv.pw.p.tiles_per_wg;
+        info[11] = e.conv.pw.kq;
+    } else if (e.kind == 0) {
         int ct, pt;
         variant_dims(e.conv.variant, ct, pt);
         info[1] = e.conv.ks; info[2] = e.conv.stride; info[3] = e.conv.variant; info[4] = e.conv.p.total_blocks;
@@ -614,7 +637,7 @@ int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]) {
         info[10] = e.conv16.p.R;
         info[11] = f16_variant_light(e.conv16.variant) ? 1 : 0;
     } else if (e.kind == 9) {
-        info[1] = 3; info[2] = 1; info[3] = 8 /* the tuner's index of the Winograd form */; info[4] = e.wino.p.total_blocks;
+        info[1] = 3; info[2] = 1; info[3] = 9 /* the tuner's index of the Winograd form */; info[4] = e.wino.p.total_blocks;
         info[5] = (int64_t)e.wino.lds_bytes; info[6] = 32; info[7] = e.wino.p.M * 4; info[8] = 8; info[9] = 1; info[10] = e.wino.p.R;
         info[11] = e.wino.ni;
     } else if (e.kind == 8) {

@@ -159,8 +159,8 @@ def _autotune(key, macs, n_variants, launch) -> int:
     return best
 
 
-F32_VARIANTS = 8   # direct MFMA tile variants (csrc/conv_mfma.h ConvVariant)
-F32_WINOGRAD = 8   # the tuner's index of the Winograd F(2x2,3x3) form (csrc/conv_wino_f32.hip)
+F32_VARIANTS = 9   # direct MFMA tile variants 0..7 (csrc/conv_mfma.h ConvVariant) + 8 = the streaming 1x1 kernel (conv_pw_f32.hip)
+F32_WINOGRAD = 9   # the tuner's index of the Winograd F(2x2,3x3) form (csrc/conv_wino_f32.hip)
 
 
 def winograd_enabled() -> bool:

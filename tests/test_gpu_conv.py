@@ -270,3 +270,55 @@ def test_execution_lanes_are_bit_identical_to_single_stream(amp, monkeypatch):
     for o in outs["1"]:
         assert torch.equal(o, outs["0"][0])
     assert all(torch.equal(o, outs["0"][0]) for o in outs["0"])
+
+
+PW_CASES = [
+    # n, cin, cout, h, w, relu, res
+    (3, 64, 256, 64, 48, False, True),    # stage-1 Bottleneck conv3 + identity (hrnet.py:86-146)
+    (2, 256, 64, 64, 48, True, False),    # Bottleneck conv1: four 64-channel chunks per tile
+    (2, 64, 64, 64, 48, True, False),     # first Bottleneck conv1
+    (5, 128, 128, 16, 12, True, True),    # two chunks, two cout blocks per wave, N x HW / 64 not a multiple of the workgroup run
+    (2, 64, 200, 8, 8, False, True),      # cout not a multiple of 16 / 64: padding channels masked
+]
+
+
+@pytest.mark.parametrize("case", PW_CASES, ids=[f"n{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}" for c in PW_CASES])
+def test_streaming_1x1_kernel_vs_torch_and_direct(case):
+    """Forced variant 8 of mp_conv2d_fwd_variant: the persistent streaming 1x1 kernel (weights in registers, all couts of a
+    64-pixel tile in one workgroup) - same packed weights, same result as the direct kernel to fp32 rounding."""
+    import ctypes
+    from mindpose_amd import _lib
+    n, cin, cout, h, w, relu, res = case
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    r1 = torch.randn(n, cout, h, w, generator=g) if res else None
+    ref = F.conv2d(x.double(), wt.double()) * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]
+    if res:
+        ref = ref + r1.double()
+    if relu:
+        ref = F.relu(ref)
+    d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=1, kw=1, stride=1, pad_top=0, pad_left=0, conv_h=h, conv_w=w, out_h=h, out_w=w,
+                      out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=int(relu), tap_dilation_unused=0)
+    st = _lib.stream()
+    xd, wd, sc, sh = x.to(DEV), wt.to(DEV), scale.to(DEV), shift.to(DEV)
+    rd = r1.to(DEV) if res else None
+    pk = torch.empty(lib.mp_conv_packed_weight_bytes(cout, cin, 1, 1) // 4, device=DEV)
+    _lib.check(lib.mp_conv_pack_weight(_lib.ptr(wd), _lib.ptr(pk), cout, cin, 1, 1, 0, 0, 0, st), "pack")
+    out = torch.full((n, cout, h, w), float("nan"), device=DEV)
+    _lib.check(lib.mp_conv2d_fwd_variant(ctypes.byref(d), 8, _lib.ptr(xd), _lib.ptr(pk), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(rd), None,
+                                         _lib.ptr(out), st), "streaming 1x1")
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    assert _nerr(out.double().cpu(), ref) <= 2e-5
+    # outside its form: refused, the tuner then never sees it
+    d2 = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=1, kw=1, stride=1, pad_top=0, pad_left=0, conv_h=h, conv_w=w, out_h=h, out_w=w,
+                       out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=0, tap_dilation_unused=0)
+    assert lib.mp_conv2d_fwd_variant(ctypes.byref(d2), 8, _lib.ptr(xd), _lib.ptr(pk), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(rd), _lib.ptr(out),
+                                     _lib.ptr(out), st) == -3  # a second residual tensor
+    d3 = _lib.ConvDesc(n=1, cin=48, h=8, w=8, cout=64, kh=1, kw=1, stride=1, pad_top=0, pad_left=0, conv_h=8, conv_w=8, out_h=8, out_w=8,
+                       out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=0, tap_dilation_unused=0)
+    assert lib.mp_conv2d_fwd_variant(ctypes.byref(d3), 8, _lib.ptr(xd), _lib.ptr(pk), _lib.ptr(sc), _lib.ptr(sh), None, None, _lib.ptr(out),
+                                     st) == -3  # Cin = 48 is not a built shape
