@@ -150,18 +150,33 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const WgradPara
         int n, y0, npix, yin0;
         tile_geom(tile, n, y0, npix, yin0);
         const int npix4 = (npix + 3) & ~3;
-        const float* __restrict__ az = lz + buf * zbuf + (co_sub * 16 + lr) * p.zpitch;
-        const float* __restrict__ bx = lx + buf * xbuf + (ci_sub * 16 + lr) * p.xplane;
-        for (int q = 0; q < npix4; q += 4) {
-            const int px = q + lq;  // Wo % 4 == 0: the 4 pixels of a k-step share one output row
-            const int y = q / p.Wo, xo = px - y * p.Wo;
-            const float a = az[px];
-            const int boff = (y * S) * p.Wp + xo * S;
+        const float* __restrict__ az = lz + buf * zbuf + (co_sub * 16 + lr) * p.zpitch + lq;
+        const float* __restrict__ bx = lx + buf * xbuf + (ci_sub * 16 + lr) * p.xplane + lq * S;
+        // Wo % 4 == 0: the 4 pixels of a k-step share one output row, so the k-steps are walked row by row (no division in the
+        // loop) and the T + 1 operand fragments of k-step i + 1 are fetched while the T MFMAs of k-step i run
+        const int ksteps = npix4 >> 2, kpr = p.Wo >> 2;  // k-steps of the tile / per output row
+        float a_cur = az[0], b_cur[T];
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-                const float b = bx[boff + (t / KS) * p.Wp + (t % KS)];
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+        for (int t = 0; t < T; ++t) b_cur[t] = bx[(t / KS) * p.Wp + (t % KS)];
+        int col = 0, zoff = 0, xoff = 0;  // k-step inside its row; offsets of the CURRENT k-step in the dz / x tiles
+        for (int i = 0; i < ksteps; ++i) {
+            // offsets of the next k-step (the last one re-reads the current: discarded)
+            int zn = zoff, xn = xoff, cn = col;
+            if (i + 1 < ksteps) {
+                zn = zoff + 4;
+                if (++cn == kpr) { cn = 0; xn = xoff - (kpr - 1) * 4 * S + S * p.Wp; }
+                else xn = xoff + 4 * S;
             }
+            const float a_nxt = az[zn];
+            float b_nxt[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) b_nxt[t] = bx[xn + (t / KS) * p.Wp + (t % KS)];
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur, b_cur[t], acc[t], 0, 0, 0);
+            a_cur = a_nxt;
+#pragma unroll
+            for (int t = 0; t < T; ++t) b_cur[t] = b_nxt[t];
+            zoff = zn; xoff = xn; col = cn;
         }
         if (next < p.n_tiles) stage_store(buf ^ 1);
         __syncthreads();
@@ -359,7 +374,7 @@ static int wgrad_geometry(const mp_conv_desc* d, WgradParams& p, size_t& lds_byt
     int splits = 1024 / out_tiles;
     if (splits < 1) splits = 1;
     if (splits > p.n_tiles) splits = p.n_tiles;
-    if (splits > 256) splits = 256;
+    if (splits > 256) splits = 256;  // (512 / 1024 measured: no gain, the slab reduction grows)
     p.splits = splits;
     return MP_OK;
 }
