@@ -68,12 +68,13 @@ def kernel_name(info):
     """Template head <KS,S,PS,CS,WAVES_P,WAVES_C> of the instantiation; '/occ3' marks the light build (rocprof shows it as
     the trailing template argument OCC = 3)."""
     if info["kind_id"] == 9:  # fp32 Winograd F(2x2,3x3): <NI staging units per thread, QROW = 16-byte epilogue (full 48-tile bands,
-        # TW % 4 == 0), GROUP = image-grouped bands (W % 4 != 0)> - the rocprofv3 template list
+        # TW % 4 == 0), GROUP = image-grouped bands (W % 4 != 0), TEAMS> - the rocprofv3 template list
         group = info["w"] % 4 != 0
         tw = info["w"] // 2
         tr = min(48 // tw, info["h"] // 2)
         qrow = not group and tr * tw == 48 and tw % 4 == 0 and info["h"] % (2 * tr) == 0
-        return f"conv_wino_f32_kernel<{info.get('light', 0)},{'true' if qrow else 'false'},{'true' if group else 'false'}>"
+        teams = max(1, info.get("cout_tile", 32) // 32)  # two four-wave teams: a 64-channel cout tile per workgroup
+        return f"conv_wino_f32_kernel<{info.get('light', 0)},{'true' if qrow else 'false'},{'true' if group else 'false'},{teams}>"
     if info["kind_id"] == 8:  # fused fp16 BasicBlock: the <5,3> or <6,5> pixel-tile build ("variant" = 1 for the small one)
         return {0: "basicblock_f16_kernel<6,5>", 1: "basicblock_f16_kernel<5,3>", 2: "basicblock_f16_v2_kernel<8,4,3>", 3: "basicblock_f16_v2_kernel<4,5,3>"}[info["variant"]]
     if info["kind_id"] == 3:

@@ -136,8 +136,13 @@ typedef struct mp_conv_desc {
     int32_t out_h, out_w;          /* extent of the out / res tensors */
     int32_t out_mul, out_rep, out_off_y, out_off_x;
     int32_t relu;                  /* apply ReLU last */
-    int32_t tap_dilation_unused;   /* reserved, must be 0 */
+    int32_t flags;                 /* MP_CONV_* bits; an unknown bit is refused (MP_ERR_UNSUPPORTED) */
 } mp_conv_desc;
+
+/* mp_conv_desc.flags: the launch will share the CUs with other kernels of the caller - a training step's BatchNorm and
+ * weight-gradient launches on sibling streams.  Forms that take a CU's whole register file (the two-team Winograd
+ * workgroup) are then not chosen: they are faster alone and slower in that company. */
+#define MP_CONV_SHARES_CUS 1
 
 /* bytes of the packed weight buffer for a (cout, cin, kh, kw) kernel */
 size_t mp_conv_packed_weight_bytes(int cout, int cin, int kh, int kw);

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MINDPOSE_HIP_LIB", os.path.join(_HERE, "csrc", "libmindpose_hip.so"))
 
 MP_REFINE_NONE, MP_REFINE_SHIFT, MP_REFINE_DARK = 0, 1, 2
+MP_CONV_SHARES_CUS = 1  # mp_conv_desc.flags: the launch runs beside other kernels of a training step (include/mindpose_hip.h)
 
 c_f32p = ctypes.c_void_p  # device pointers travel as integers
 c_int = ctypes.c_int
@@ -22,7 +23,7 @@ class ConvDesc(ctypes.Structure):
     """``mp_conv_desc`` of include/mindpose_hip.h."""
     _fields_ = [(name, ctypes.c_int32) for name in (
         "n", "cin", "h", "w", "cout", "kh", "kw", "stride", "pad_top", "pad_left", "conv_h", "conv_w",
-        "out_h", "out_w", "out_mul", "out_rep", "out_off_y", "out_off_x", "relu", "tap_dilation_unused")]
+        "out_h", "out_w", "out_mul", "out_rep", "out_off_y", "out_off_x", "relu", "flags")]
 
 
 class MindposeHipError(RuntimeError):

@@ -274,7 +274,7 @@ static int validate_desc(const mp_conv_desc* d) {
     if (d->pad_top < 0 || d->pad_left < 0 || d->pad_top >= d->kh + 1 || d->pad_left >= d->kw + 1) return MP_ERR_SHAPE;
     if (d->conv_h <= 0 || d->conv_w <= 0 || d->out_h <= 0 || d->out_w <= 0) return MP_ERR_SHAPE;
     if (d->out_mul < 1 || d->out_rep < 1 || d->out_off_y < 0 || d->out_off_x < 0) return MP_ERR_SHAPE;
-    if (d->tap_dilation_unused != 0) return MP_ERR_UNSUPPORTED;
+    if (d->flags & ~MP_CONV_SHARES_CUS) return MP_ERR_UNSUPPORTED;
     // output mapping must stay inside [out_h, out_w]
     if ((d->conv_h - 1) * d->out_mul + d->out_off_y + d->out_rep > d->out_h) return MP_ERR_SHAPE;
     if ((d->conv_w - 1) * d->out_mul + d->out_off_x + d->out_rep > d->out_w) return MP_ERR_SHAPE;
@@ -638,7 +638,7 @@ int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]) {
         info[11] = f16_variant_light(e.conv16.variant) ? 1 : 0;
     } else if (e.kind == 9) {
         info[1] = 3; info[2] = 1; info[3] = 9 /* the tuner's index of the Winograd form */; info[4] = e.wino.p.total_blocks;
-        info[5] = (int64_t)e.wino.lds_bytes; info[6] = 32; info[7] = e.wino.p.M * 4; info[8] = 8; info[9] = 1; info[10] = e.wino.p.R;
+        info[5] = (int64_t)e.wino.lds_bytes; info[6] = 32 * e.wino.teams; info[7] = e.wino.p.M * 4; info[8] = 8; info[9] = 1; info[10] = e.wino.p.R;
         info[11] = e.wino.ni;
     } else if (e.kind == 8) {
         info[1] = 3; info[2] = 1; info[3] = e.block16.small; info[4] = e.block16.p.total_blocks;

@@ -522,7 +522,7 @@ int f16_validate(const mp_conv_desc* d) {
     if (d->conv_h <= 0 || d->conv_w <= 0) return MP_ERR_SHAPE;
     // plain or strided-scatter output mapping (sub-pixel phases of the transposed convolution); replication (nearest
     // up-sampling) is not part of this kernel: the exchange unit has its own streaming kernel in this layout
-    if (d->out_rep != 1 || d->out_mul < 1 || d->out_off_y < 0 || d->out_off_x < 0 || d->tap_dilation_unused != 0) return MP_ERR_UNSUPPORTED;
+    if (d->out_rep != 1 || d->out_mul < 1 || d->out_off_y < 0 || d->out_off_x < 0 || (d->flags & ~MP_CONV_SHARES_CUS)) return MP_ERR_UNSUPPORTED;
     if (d->out_h <= 0 || d->out_w <= 0) return MP_ERR_SHAPE;
     if ((d->conv_h - 1) * d->out_mul + d->out_off_y >= d->out_h || (d->conv_w - 1) * d->out_mul + d->out_off_x >= d->out_w) return MP_ERR_SHAPE;
     // every input row / column a tap reads must exist or be zero padding on the top / left only up to pad; the bottom /

@@ -29,6 +29,7 @@ struct WinoLaunch {
     size_t lds_bytes;
     int ni;
     bool group;  // image-grouped bands
+    int teams;   // 1 or 2 four-wave teams per workgroup (2: a 64-channel cout tile on one shared input transform)
 };
 
 // U = G g G^T of one (cout co, cin ci) pair -> out[16] (xi = 4 row + col).  `transposed` = 0: w is [cout][cin][3][3] (forward);

@@ -42,18 +42,22 @@ __device__ __forceinline__ void wg_barrier() {
 // GROUP: a band = G whole small images (W % 4 != 0 maps, e.g. 8x6: 12 tiles per image, four images per workgroup); the raw
 // planes are staged as contiguous float4 units whose four elements may straddle rows, and the two tiles of a transform item
 // are consecutive tiles, not neighbours in a row.
-template <int NI, bool QROW, bool GROUP>
-__global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams p) {
+// TEAMS = 2: 512 threads = two teams of four waves on ONE band: the teams share the raw rows, the input transform (done by team 0)
+// and V, and each computes its own 32 output channels of a 64-channel cout tile - the transform work per MFMA halves.
+template <int NI, bool QROW, bool GROUP, int TEAMS>
+__global__ __launch_bounds__(256 * TEAMS, TEAMS == 1 ? 2 : 1) void conv_wino_f32_kernel(const WinoParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int raw_buf = kCK * p.cin_plane + 4;  // + one float4 that absorbs the stores of threads without a staging unit
     float* __restrict__ lds_raw = smem;                 // [2][raw_buf]
     float* __restrict__ lds_v = smem + 2 * raw_buf;     // [2][16][kCK][kTP]
-    float* __restrict__ lds_x = lds_v;                  // epilogue: [16][16][kXP] over the V buffers (never over the raw buffers:
-                                                        // their zero halo columns must survive into the workgroup's next tile)
+    const int tid_wg = threadIdx.x;
+    const int team = TEAMS == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid_wg >> 8);
+    float* __restrict__ lds_x = lds_v + team * kXFloats;  // epilogue: [16][16][kXP] per team over the V buffers (never over the raw
+                                                          // buffers: their zero halo columns must survive into the next tile)
 
     MP_STAMP(t_start);
     [[maybe_unused]] unsigned long long s_xf = 0, s_b1 = 0, s_mm = 0, s_st = 0, s_b2 = 0, s_pro = 0, s_ep = 0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = tid_wg & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // thread / wave inside the team
     const int lq = lane >> 4, lr = lane & 15;
 
     // A workgroup walks p.tiles_per_wg consecutive tiles (same staging tables, one zero fill; the raw rows of the next tile are
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams 
     int idst4[GROUP ? NI : 1][4];  // GROUP: one LDS offset per element of a unit
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-        const unsigned u = tid + 256 * i;
+        const unsigned u = tid_wg + 256 * TEAMS * i;  // every thread of the workgroup stages
         irel[i] = kOob;
         irow[i] = 0;
         idst[i] = kCK * p.cin_plane;
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams 
     auto tile_u = [&]() {
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
-            const int co = ct * 32 + nb * 16 + lr;
+            const int co = (ct * TEAMS + team) * 32 + nb * 16 + lr;
             u_off[nb] = co < p.Cout_pad16 ? (unsigned)((lq * p.Cout_pad16 + co) * 16 + wave * 4) * 4u : kOob;
         }
     };
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams 
         const int n4 = (2 * raw_buf) >> 2;  // raw_buf is a multiple of 4
         float4* z = reinterpret_cast<float4*>(lds_raw);
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = tid; i < n4; i += 256) z[i] = zero;
+        for (int i = tid_wg; i < n4; i += 256 * TEAMS) z[i] = zero;
     }
     wg_barrier();  // zero fill complete
 
@@ -288,10 +292,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams 
             for (int nb = 0; nb < 2; ++nb) acc[i][mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     stage_store(0);
     wg_barrier();
-    xf_read(0);
-    xf_cols();
+    if (team == 0) {
+        xf_read(0);
+        xf_cols();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xf_rows_write(0, i);
+        for (int i = 0; i < 4; ++i) xf_rows_write(0, i);
+    }
 #pragma unroll
     for (int i = 0; i < NI; ++i) vin[i] = vin1[i];
     stage_store(1);
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams 
         stage_load(ch + 2);
         load_u(ch + 1, unext);
         const float* __restrict__ vcur = lds_v + (ch & 1) * kVFloats + a_base;
-        xf_read((ch + 1) & 1);
+        if (TEAMS == 1 || team == 0) xf_read((ch + 1) & 1);
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -323,9 +329,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams 
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb)
                         acc[i][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], ucur[i][nb][q], acc[i][mb][nb], 0, 0, 0);
-                if (q == 0 && i == 1) xf_cols();
-                if (q == 0 && i >= 2) xf_rows_write((ch + 1) & 1, i - 2);
-                if (q == 1 && i < 2) xf_rows_write((ch + 1) & 1, i + 2);
+                if (TEAMS == 1 || team == 0) {  // (team: wave-uniform)
+                    if (q == 0 && i == 1) xf_cols();
+                    if (q == 0 && i >= 2) xf_rows_write((ch + 1) & 1, i - 2);
+                    if (q == 1 && i < 2) xf_rows_write((ch + 1) & 1, i + 2);
+                }
             }
         MP_STAMP(t3);
         stage_store(ch & 1);
@@ -365,8 +373,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams 
     }
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-        if (e_ct * 32 + nb * 16 >= p.Cout_pad16) break;  // workgroup-uniform
-        const int co = e_ct * 32 + nb * 16 + (int)co_l;
+        if (TEAMS == 1 && e_ct * 32 + nb * 16 >= p.Cout_pad16) break;  // workgroup-uniform (two teams: both always pass the barriers)
+        const int co = (e_ct * TEAMS + team) * 32 + nb * 16 + (int)co_l;
         const unsigned co_off = co < p.Cout ? (unsigned)co * plane_o * 4u : kOob;  // kOob + pixel offset stays out of range
         f32x4 r1q[2][2], r2q[2][2];
         float2 r1v[4][2], r2v[4][2];
@@ -448,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_f32_kernel(const WinoParams 
 #if MP_CONV_STAMPS
     {
         MP_STAMP(t_end);
-        if (p.dbg && tid == 0) {
+        if (p.dbg && tid_wg == 0) {
             unsigned long long* d = p.dbg + (size_t)blockIdx.x * 8;
             d[0] = t_end - t_start; d[1] = s_pro; d[2] = s_xf; d[3] = s_b1; d[4] = s_mm; d[5] = s_st; d[6] = s_b2;
             d[7] = s_ep;
@@ -493,16 +501,30 @@ int wino_configure(const mp_conv_desc* d, WinoLaunch& L) {
     if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad_top != 1 || d->pad_left != 1) return MP_ERR_UNSUPPORTED;
     if (d->conv_h != d->h || d->conv_w != d->w || d->out_h != d->h || d->out_w != d->w) return MP_ERR_UNSUPPORTED;
     if (d->out_mul != 1 || d->out_rep != 1 || d->out_off_y != 0 || d->out_off_x != 0) return MP_ERR_UNSUPPORTED;
-    if ((d->w & 1) || (d->h & 1) || (d->cin % kCK)) return MP_ERR_UNSUPPORTED;
+    if ((d->w & 1) || (d->h & 1) || (d->cin % kCK) || (d->flags & ~MP_CONV_SHARES_CUS)) return MP_ERR_UNSUPPORTED;
     if ((long long)d->cin * d->h * d->w * 4 >= 0x1FFFFFF0LL || (long long)d->cout * d->h * d->w * 4 >= 0x1FFFFFF0LL) return MP_ERR_UNSUPPORTED;
     WinoParams& p = L.p;
     p.N = d->n; p.Cin = d->cin; p.Cout = d->cout; p.Cout_pad16 = (d->cout + 15) / 16 * 16; p.H = d->h; p.W = d->w;
     p.TW = d->w / 2;
     if (p.TW > kTP) return MP_ERR_UNSUPPORTED;
     p.n_chunks = d->cin / kCK;
-    p.n_ct = (p.Cout_pad16 + 31) / 32;
     p.tpi = (d->h / 2) * p.TW;
     L.group = (d->w & 3) != 0;
+    // two teams (64 output channels per workgroup on one shared input transform) where there are 64 channels to share it, the
+    // launch still has a workgroup for every CU, and the CUs are this launch's own: eight waves of 242-256 registers fill a
+    // CU's register file, so nothing else is resident beside them - inside a training step (MP_CONV_SHARES_CUS), where
+    // BatchNorm launches of sibling streams would otherwise run under the convolution, that costs more than it saves
+    L.teams = 1;
+    if (!L.group && p.Cout_pad16 >= 64 && !(d->flags & MP_CONV_SHARES_CUS)) {
+        const int tr = kTP / p.TW < d->h / 2 ? kTP / p.TW : d->h / 2;
+        const long long wgs2 = (long long)((p.Cout_pad16 + 63) / 64) * ((d->h + 2 * tr - 1) / (2 * tr)) * d->n;
+        if (wgs2 >= 256) L.teams = 2;
+    }
+    if (const char* e = getenv("MP_WINO_TEAMS")) {  // experiments
+        if (atoi(e) == 1) L.teams = 1;
+        if (atoi(e) == 2 && !L.group) L.teams = 2;
+    }
+    p.n_ct = (p.Cout_pad16 + 32 * L.teams - 1) / (32 * L.teams);
     if (L.group) {
         // rows are not 16-byte units: whole small images, staged as contiguous planes (HW % 4 == 0), G of them per workgroup
         if (((d->h * d->w) & 3) || p.tpi > kTP / 2 || (p.tpi & 1)) return MP_ERR_UNSUPPORTED;
@@ -536,7 +558,7 @@ int wino_configure(const mp_conv_desc* d, WinoLaunch& L) {
     }
     if (kCK * p.upc > 3 * 256) return MP_ERR_UNSUPPORTED;
     // tiles per workgroup: about two resident workgroups per CU in ONE round (at most 8 tiles each)
-    p.tiles_per_wg = p.total_blocks / 512;
+    p.tiles_per_wg = p.total_blocks / (512 / L.teams);
     if (p.tiles_per_wg < 1) p.tiles_per_wg = 1;
     if (p.tiles_per_wg > 8) p.tiles_per_wg = 8;
     if (const char* e = getenv("MP_WINO_TILES")) {  // experiments
@@ -546,9 +568,9 @@ int wino_configure(const mp_conv_desc* d, WinoLaunch& L) {
     p.relu = d->relu;
     p.magic_upr = magic_of(p.upr); p.magic_upc = magic_of(p.upc); p.magic_tw = magic_of(p.TW); p.magic_pairs = magic_of(p.M >> 1);
     p.magic_tpi = magic_of(p.tpi); p.magic_w = magic_of(p.W);
-    const size_t raw_bytes = (size_t)2 * (kCK * p.cin_plane + 4) * 4, v_bytes = (size_t)2 * kVFloats * 4, x_bytes = (size_t)kXFloats * 4;
+    const size_t raw_bytes = (size_t)2 * (kCK * p.cin_plane + 4) * 4, v_bytes = (size_t)2 * kVFloats * 4, x_bytes = (size_t)L.teams * kXFloats * 4;
     L.lds_bytes = raw_bytes + (v_bytes > x_bytes ? v_bytes : x_bytes);
-    L.ni = (kCK * p.upc + 255) / 256;
+    L.ni = (kCK * p.upc + 256 * L.teams - 1) / (256 * L.teams);
     if (L.lds_bytes > 150 * 1024) return MP_ERR_UNSUPPORTED;
     return MP_OK;
 }
@@ -563,23 +585,31 @@ int wino_launch(const WinoLaunch& L0, hipStream_t s) {
             (void)hipGetLastError();
             attr = true;
         }
-        hipLaunchKernelGGL(kern, dim3((L.p.total_blocks + L.p.tiles_per_wg - 1) / L.p.tiles_per_wg), dim3(256), L.lds_bytes, s, L.p);
+        hipLaunchKernelGGL(kern, dim3((L.p.total_blocks + L.p.tiles_per_wg - 1) / L.p.tiles_per_wg), dim3(256 * L.teams), L.lds_bytes, s, L.p);
         return check_launch();
     };
     // QROW: the four tiles of an epilogue item are eight consecutive pixels of two rows
     const bool qrow = !L.group && L.p.M == kTP && L.p.TW % 4 == 0 && L.p.H % L.p.R == 0;
     if (L.group) {
         switch (L.ni) {
-            case 1: return go(conv_wino_f32_kernel<1, false, true>);
-            case 2: return go(conv_wino_f32_kernel<2, false, true>);
-            case 3: return go(conv_wino_f32_kernel<3, false, true>);
+            case 1: return go(conv_wino_f32_kernel<1, false, true, 1>);
+            case 2: return go(conv_wino_f32_kernel<2, false, true, 1>);
+            case 3: return go(conv_wino_f32_kernel<3, false, true, 1>);
+            default: return MP_ERR_UNSUPPORTED;
+        }
+    }
+    if (L.teams == 2) {
+        switch (L.ni) {
+            case 1: return qrow ? go(conv_wino_f32_kernel<1, true, false, 2>) : go(conv_wino_f32_kernel<1, false, false, 2>);
+            case 2: return qrow ? go(conv_wino_f32_kernel<2, true, false, 2>) : go(conv_wino_f32_kernel<2, false, false, 2>);
+            case 3: return qrow ? go(conv_wino_f32_kernel<3, true, false, 2>) : go(conv_wino_f32_kernel<3, false, false, 2>);
             default: return MP_ERR_UNSUPPORTED;
         }
     }
     switch (L.ni) {
-        case 1: return qrow ? go(conv_wino_f32_kernel<1, true, false>) : go(conv_wino_f32_kernel<1, false, false>);
-        case 2: return qrow ? go(conv_wino_f32_kernel<2, true, false>) : go(conv_wino_f32_kernel<2, false, false>);
-        case 3: return qrow ? go(conv_wino_f32_kernel<3, true, false>) : go(conv_wino_f32_kernel<3, false, false>);
+        case 1: return qrow ? go(conv_wino_f32_kernel<1, true, false, 1>) : go(conv_wino_f32_kernel<1, false, false, 1>);
+        case 2: return qrow ? go(conv_wino_f32_kernel<2, true, false, 1>) : go(conv_wino_f32_kernel<2, false, false, 1>);
+        case 3: return qrow ? go(conv_wino_f32_kernel<3, true, false, 1>) : go(conv_wino_f32_kernel<3, false, false, 1>);
         default: return MP_ERR_UNSUPPORTED;
     }
 }

@@ -401,7 +401,7 @@ class Plan:
         scale, shift = self._affine(conv.out_channels, bn, conv.bias, half)
         d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=conv.out_channels, kh=k, kw=k, stride=s, pad_top=pad,
                           pad_left=pad, conv_h=ho, conv_w=wo, out_h=oh, out_w=ow, out_mul=upsample, out_rep=upsample,
-                          out_off_y=0, out_off_x=0, relu=int(relu), tap_dilation_unused=0)
+                          out_off_y=0, out_off_x=0, relu=int(relu), flags=0)
         if half and upsample != 1:
             raise NotImplementedError("fp16 plans add up-sampled terms with fuse_sum, not through the conv epilogue")
         packed_u = None
@@ -458,7 +458,7 @@ class Plan:
                 packed = self._pack(deconv.weight, cout, cin, 2, True, py, px, half)
                 d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=2, kw=2, stride=1, pad_top=1 - py,
                                   pad_left=1 - px, conv_h=h, conv_w=w, out_h=2 * h, out_w=2 * w, out_mul=2, out_rep=1,
-                                  out_off_y=py, out_off_x=px, relu=int(relu), tap_dilation_unused=0)
+                                  out_off_y=py, out_off_x=px, relu=int(relu), flags=0)
                 if half:
                     v = tune_conv_variant(self.lib, d, x, packed, scale, shift, None, None, out, half=True)
                     _lib.check(self.lib.mp_plan_add_conv_f16(self.handle, ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed),

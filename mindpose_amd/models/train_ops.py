@@ -32,7 +32,7 @@ def _desc(n, cin, h, w, cout, k, stride, pad_t, pad_l, conv_h, conv_w, out_h, ou
           off_x=0):
     return _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=k, kw=k, stride=stride, pad_top=pad_t, pad_left=pad_l,
                          conv_h=conv_h, conv_w=conv_w, out_h=out_h, out_w=out_w, out_mul=out_mul, out_rep=out_rep,
-                         out_off_y=off_y, out_off_x=off_x, relu=0, tap_dilation_unused=0)
+                         out_off_y=off_y, out_off_x=off_x, relu=0, flags=_lib.MP_CONV_SHARES_CUS)
 
 
 def _conv_launch(lib, d, x, packed, scale, shift, out, what, packed_u=None, res1=None):

@@ -301,7 +301,7 @@ def test_streaming_1x1_kernel_vs_torch_and_direct(case):
     if relu:
         ref = F.relu(ref)
     d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=1, kw=1, stride=1, pad_top=0, pad_left=0, conv_h=h, conv_w=w, out_h=h, out_w=w,
-                      out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=int(relu), tap_dilation_unused=0)
+                      out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=int(relu), flags=0)
     st = _lib.stream()
     xd, wd, sc, sh = x.to(DEV), wt.to(DEV), scale.to(DEV), shift.to(DEV)
     rd = r1.to(DEV) if res else None
@@ -315,10 +315,10 @@ def test_streaming_1x1_kernel_vs_torch_and_direct(case):
     assert _nerr(out.double().cpu(), ref) <= 2e-5
     # outside its form: refused, the tuner then never sees it
     d2 = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=1, kw=1, stride=1, pad_top=0, pad_left=0, conv_h=h, conv_w=w, out_h=h, out_w=w,
-                       out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=0, tap_dilation_unused=0)
+                       out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=0, flags=0)
     assert lib.mp_conv2d_fwd_variant(ctypes.byref(d2), 8, _lib.ptr(xd), _lib.ptr(pk), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(rd), _lib.ptr(out),
                                      _lib.ptr(out), st) == -3  # a second residual tensor
     d3 = _lib.ConvDesc(n=1, cin=48, h=8, w=8, cout=64, kh=1, kw=1, stride=1, pad_top=0, pad_left=0, conv_h=8, conv_w=8, out_h=8, out_w=8,
-                       out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=0, tap_dilation_unused=0)
+                       out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=0, flags=0)
     assert lib.mp_conv2d_fwd_variant(ctypes.byref(d3), 8, _lib.ptr(xd), _lib.ptr(pk), _lib.ptr(sc), _lib.ptr(sh), None, None, _lib.ptr(out),
                                      st) == -3  # Cin = 48 is not a built shape

@@ -105,7 +105,7 @@ def test_conv_f16_vs_oracle(case, variant):
     sh = torch.cat([shift, torch.zeros(padc)]).to(DEV)
     d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=k, kw=k, stride=s, pad_top=pad, pad_left=pad, conv_h=ho,
                       conv_w=wo, out_h=ho, out_w=wo, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=int(relu),
-                      tap_dilation_unused=0)
+                      flags=0)
     rc = LIB.mp_f16_conv2d_fwd(ctypes.byref(d), variant, _lib.ptr(xa), _lib.ptr(packed), _lib.ptr(sc), _lib.ptr(sh),
                                _lib.ptr(ra[0]), _lib.ptr(ra[1]), _lib.ptr(out), _lib.stream())
     if rc != 0 and variant >= 0:
@@ -168,7 +168,7 @@ def test_conv_f16_wreg_vs_oracle_and_bit_identical_to_tile_kernel(case, variant)
     _lib.check(LIB.mp_f16_pack_weight(_lib.ptr(wt.to(DEV)), _lib.ptr(packed), cout, cin, k, k, 0, 0, 0, _lib.stream()), "pack")
     sc, sh = scale.to(DEV), shift.to(DEV)
     d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=k, kw=k, stride=s, pad_top=pad, pad_left=pad, conv_h=h, conv_w=w,
-                      out_h=h, out_w=w, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=int(relu), tap_dilation_unused=0)
+                      out_h=h, out_w=w, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=int(relu), flags=0)
 
     def run(v):
         out = ActC8(n, cout, h, w, DEV)
@@ -198,7 +198,7 @@ def test_conv_f16_wreg_rejects_what_it_does_not_cover():
 
     def rc(**kw):
         base = dict(n=2, cin=128, h=16, w=12, cout=128, kh=3, kw=3, stride=1, pad_top=1, pad_left=1, conv_h=16, conv_w=12, out_h=16,
-                    out_w=12, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=0, tap_dilation_unused=0)
+                    out_w=12, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=0, flags=0)
         base.update(kw)
         d = _lib.ConvDesc(**base)
         return LIB.mp_f16_conv2d_fwd(ctypes.byref(d), 25, _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), None, None, _lib.ptr(t), _lib.stream())
@@ -232,7 +232,7 @@ def test_deconv_phases_f16_vs_oracle(variant, monkeypatch):
             _lib.check(LIB.mp_f16_pack_weight(_lib.ptr(wt.to(DEV)), _lib.ptr(packed), cout, cin, 2, 2, 1, py, px, _lib.stream()), "pack")
             d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=2, kw=2, stride=1, pad_top=1 - py, pad_left=1 - px, conv_h=h,
                               conv_w=w, out_h=2 * h, out_w=2 * w, out_mul=2, out_rep=1, out_off_y=py, out_off_x=px, relu=1,
-                              tap_dilation_unused=0)
+                              flags=0)
             rc = LIB.mp_f16_conv2d_fwd(ctypes.byref(d), variant, _lib.ptr(xa), _lib.ptr(packed), _lib.ptr(sc), _lib.ptr(sh), None,
                                        None, _lib.ptr(out), _lib.stream())
             if rc != 0 and variant >= 0:
@@ -247,7 +247,7 @@ def test_deconv_phases_f16_vs_oracle(variant, monkeypatch):
 
 def test_conv_f16_rejects_unsupported():
     d = _lib.ConvDesc(n=1, cin=8, h=8, w=8, cout=8, kh=7, kw=7, stride=2, pad_top=3, pad_left=3, conv_h=4, conv_w=4,
-                      out_h=4, out_w=4, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=0, tap_dilation_unused=0)
+                      out_h=4, out_w=4, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=0, flags=0)
     t = torch.zeros(4096, device=DEV)
     assert LIB.mp_f16_conv2d_fwd(ctypes.byref(d), -1, _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), None, None,
                                  _lib.ptr(t), _lib.stream()) != 0
@@ -363,7 +363,7 @@ def _block_pair(n, c, h, w, seed):
         scs.append(torch.cat([scale, torch.zeros(padc)]).to(DEV))
         shs.append(torch.cat([shift, torch.zeros(padc)]).to(DEV))
     d = _lib.ConvDesc(n=n, cin=c, h=h, w=w, cout=c, kh=3, kw=3, stride=1, pad_top=1, pad_left=1, conv_h=h, conv_w=w, out_h=h,
-                      out_w=w, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=1, tap_dilation_unused=0)
+                      out_w=w, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=1, flags=0)
     mid, two = ActC8(n, c, h, w, DEV), ActC8(n, c, h, w, DEV)
     _lib.check(LIB.mp_f16_conv2d_fwd(ctypes.byref(d), -1, _lib.ptr(xa), _lib.ptr(packed[0]), _lib.ptr(scs[0]), _lib.ptr(shs[0]),
                                      None, None, _lib.ptr(mid), _lib.stream()), "conv1")
@@ -426,7 +426,7 @@ def test_conv_f16_wreg_stride2_bit_identical_to_tile_kernel(case, variant):
     padc = (-cout) % 16
     sc, sh = torch.cat([scale, torch.zeros(padc)]).to(DEV), torch.cat([shift, torch.zeros(padc)]).to(DEV)
     d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=3, kw=3, stride=2, pad_top=1, pad_left=1, conv_h=ho, conv_w=wo, out_h=ho,
-                      out_w=wo, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=1, tap_dilation_unused=0)
+                      out_w=wo, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=1, flags=0)
 
     def run(v):
         out = ActC8(n, cout, ho, wo, DEV)

@@ -46,7 +46,7 @@ def _close16(got, ref, what=""):
 def _desc(n, cin, h, w, cout, k, s, pad, ho, wo, oh=None, ow=None, mul=1, oy=0, ox=0, pt=None, pl=None):
     return _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=k, kw=k, stride=s, pad_top=pad if pt is None else pt,
                          pad_left=pad if pl is None else pl, conv_h=ho, conv_w=wo, out_h=oh or ho, out_w=ow or wo, out_mul=mul,
-                         out_rep=1, out_off_y=oy, out_off_x=ox, relu=0, tap_dilation_unused=0)
+                         out_rep=1, out_off_y=oy, out_off_x=ox, relu=0, flags=0)
 
 
 WGRAD_CASES = [

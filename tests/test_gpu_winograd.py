@@ -39,12 +39,19 @@ CASES = [
 
 def _desc(n, cin, cout, h, w, relu):
     return _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=3, kw=3, stride=1, pad_top=1, pad_left=1, conv_h=h, conv_w=w, out_h=h,
-                         out_w=w, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=int(relu), tap_dilation_unused=0)
+                         out_w=w, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=int(relu), flags=0)
 
 
+@pytest.mark.parametrize("teams", [0, 2])
 @pytest.mark.parametrize("case", CASES, ids=[f"n{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}" for c in CASES])
-def test_winograd_conv_vs_fp64_and_direct(case):
+def test_winograd_conv_vs_fp64_and_direct(case, teams, monkeypatch):
+    """teams = 2 forces the two-team workgroup (64 output channels on one shared input transform; by itself only taken when the
+    launch still covers every CU) on every shape incl. cout tiles whose second team is partly or wholly past Cout."""
     n, cin, cout, h, w, relu, has_r1, has_r2 = case
+    if teams:
+        if w % 4:
+            pytest.skip("image-grouped bands have one team")
+        monkeypatch.setenv("MP_WINO_TEAMS", str(teams))
     lib = _lib.load()
     g = torch.Generator().manual_seed(cin * 131 + cout * 7 + h)
     x = torch.randn(n, cin, h, w, generator=g)
@@ -109,14 +116,41 @@ def test_winograd_result_is_deterministic_and_in_place_safe_with_residual_alias(
 
 
 @pytest.mark.parametrize("bad", [dict(stride=2), dict(kh=1, kw=1, pad_top=0, pad_left=0), dict(w=6, conv_w=6, out_w=6, h=6, conv_h=6, out_h=6), dict(h=7, conv_h=7, out_h=7), dict(w=18, conv_w=18, out_w=18, h=24, conv_h=24, out_h=24),
-                                 dict(cin=12), dict(out_mul=2, out_rep=2, out_h=16, out_w=16), dict(w=100, conv_w=100, out_w=100)])
+                                 dict(cin=12), dict(out_mul=2, out_rep=2, out_h=16, out_w=16), dict(w=100, conv_w=100, out_w=100), dict(flags=2)])
 def test_winograd_rejects_what_it_does_not_cover(bad):
     lib = _lib.load()
     f = dict(n=1, cin=16, h=8, w=8, cout=16, kh=3, kw=3, stride=1, pad_top=1, pad_left=1, conv_h=8, conv_w=8, out_h=8, out_w=8, out_mul=1,
-             out_rep=1, out_off_y=0, out_off_x=0, relu=0, tap_dilation_unused=0)
+             out_rep=1, out_off_y=0, out_off_x=0, relu=0, flags=0)
     f.update(bad)
     d = _lib.ConvDesc(**f)
     assert lib.mp_conv_winograd_supported(ctypes.byref(d)) == -3  # MP_ERR_UNSUPPORTED
+
+
+def test_shares_cus_flag_picks_the_one_team_workgroup_with_the_same_bits():
+    """A launch large enough for the two-team workgroup (64 -> 64 at 32x24, N = 64: 256 workgroups of 64 channels): with
+    MP_CONV_SHARES_CUS in the descriptor (what the training step passes) the one-team form runs - a 64-channel cout tile
+    becomes two 32-channel tiles, every output is still the same chunk-ordered sum, so the results are bit-identical."""
+    lib = _lib.load()
+    n, c, h, w = 64, 64, 32, 24
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, c, h, w, generator=g).to(DEV)
+    wt = (torch.randn(c, c, 3, 3, generator=g) * 0.05).to(DEV)
+    sc, sh = (torch.rand(c, generator=g) + 0.5).to(DEV), torch.randn(c, generator=g).to(DEV)
+    st = _lib.stream()
+    pu = torch.empty(lib.mp_conv_winograd_packed_weight_bytes(c, c) // 4, device=DEV)
+    _lib.check(lib.mp_conv_winograd_pack_weight(_lib.ptr(wt), _lib.ptr(pu), c, c, st), "pack U")
+    outs = []
+    for flags in (0, _lib.MP_CONV_SHARES_CUS):
+        d = _desc(n, c, c, h, w, True)
+        d.flags = flags
+        out = torch.full((n, c, h, w), float("nan"), device=DEV)
+        _lib.check(lib.mp_conv2d_winograd_fwd(ctypes.byref(d), _lib.ptr(x), _lib.ptr(pu), _lib.ptr(sc), _lib.ptr(sh), None, None,
+                                              _lib.ptr(out), st), "winograd")
+        outs.append(out)
+    torch.cuda.synchronize()
+    ref = F.relu(F.conv2d(x.double(), wt.double(), padding=1) * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
+    assert float((outs[0].double() - ref).abs().max() / ref.abs().max()) <= 2e-5
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_plan_takes_the_winograd_form_where_the_tuner_picks_it_and_env_turns_it_off(monkeypatch):
@@ -222,14 +256,16 @@ def test_whole_network_with_and_without_the_winograd_form(monkeypatch):
 
 
 @pytest.mark.parametrize("tiles", [2, 3, 8])
-@pytest.mark.parametrize("case", [(5, 16, 32, 16, 24), (3, 32, 48, 12, 48), (9, 24, 16, 8, 6), (2, 8, 80, 20, 16)],
+@pytest.mark.parametrize("case", [(5, 16, 32, 16, 24), (3, 32, 48, 12, 48), (9, 24, 16, 8, 6), (2, 8, 80, 20, 16), (7, 16, 96, 12, 16, 2)],
                          ids=lambda c: f"n{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}")
 def test_winograd_several_tiles_per_workgroup(case, tiles, monkeypatch):
     """The production launches give a workgroup up to 8 consecutive tiles (next tile's rows requested before the epilogue, zero
     halo columns and staging tables reused); small test shapes would never get more than one, so the count is forced here -
     incl. counts that do not divide the number of tiles, cout tiles changing inside a workgroup's run, image-grouped bands."""
     monkeypatch.setenv("MP_WINO_TILES", str(tiles))
-    n, cin, cout, h, w = case
+    n, cin, cout, h, w = case[:5]
+    if len(case) > 5:  # two-team workgroups walking several tiles (96 channels: the last cout tile has an empty second team)
+        monkeypatch.setenv("MP_WINO_TEAMS", str(case[5]))
     lib = _lib.load()
     g = torch.Generator().manual_seed(n * 7 + tiles)
     x = torch.randn(n, cin, h, w, generator=g)

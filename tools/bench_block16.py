@@ -22,7 +22,7 @@ for n in [int(a) for a in sys.argv[1:]] or [8, 32, 128, 256]:
         pk.append(p)
     sc, sh = torch.ones(32, device=dev), torch.zeros(32, device=dev)
     d = _lib.ConvDesc(n=n, cin=c, h=h, w=w, cout=c, kh=3, kw=3, stride=1, pad_top=1, pad_left=1, conv_h=h, conv_w=w, out_h=h,
-                      out_w=w, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=1, tap_dilation_unused=0)
+                      out_w=w, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=1, flags=0)
 
     def two(v):
         lib.mp_f16_conv2d_fwd(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(pk[0]), _lib.ptr(sc), _lib.ptr(sh), None, None, _lib.ptr(mid), _lib.stream())

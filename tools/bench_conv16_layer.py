@@ -16,7 +16,7 @@ for n in (8, 32, 128, 256):
     x, out = ActC8(n, c, h, w, dev), ActC8(n, c, h, w, dev)
     x.c8_tensor.normal_()
     d = _lib.ConvDesc(n=n, cin=c, h=h, w=w, cout=c, kh=3, kw=3, stride=1, pad_top=1, pad_left=1, conv_h=h, conv_w=w, out_h=h, out_w=w,
-                      out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=1, tap_dilation_unused=0)
+                      out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=1, flags=0)
     row = []
     for v in variants:
         args = (ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(sc), _lib.ptr(sh), None, None, _lib.ptr(out), _lib.stream())

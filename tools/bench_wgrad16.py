@@ -16,7 +16,7 @@ for cin, cout, h, w, k, st in SHAPES:
     x, dz = ActC8(n, cin, h, w, dev), ActC8(n, cout, ho, wo, dev)
     x.c8_tensor.normal_(); dz.c8_tensor.normal_()
     d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=k, kw=k, stride=st, pad_top=pad, pad_left=pad, conv_h=ho, conv_w=wo, out_h=ho,
-                      out_w=wo, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=0, tap_dilation_unused=0)
+                      out_w=wo, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=0, flags=0)
     res, outs = {}, {}
     for mode in ("1", "0"):
         os.environ["MP_WGRAD16_DMA"] = mode

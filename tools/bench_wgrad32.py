@@ -16,7 +16,7 @@ for cin, cout, h, w, k, st in SHAPES:
     ho, wo = (h + 2 * pad - k) // st + 1, (w + 2 * pad - k) // st + 1
     x, dz = torch.randn(n, cin, h, w, device=dev), torch.randn(n, cout, ho, wo, device=dev)
     d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=k, kw=k, stride=st, pad_top=pad, pad_left=pad, conv_h=ho, conv_w=wo, out_h=ho,
-                      out_w=wo, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=0, tap_dilation_unused=0)
+                      out_w=wo, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=0, flags=0)
     nb = lib.mp_conv_wgrad_workspace_bytes(ctypes.byref(d))
     ws = torch.empty(nb // 4, device=dev); dw = torch.empty(cout, cin, k, k, device=dev)
     args = (ctypes.byref(d), _lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), 0, _lib.ptr(ws), nb, _lib.stream())

@@ -32,7 +32,7 @@ for cin, cout, h, w in SHAPES:
     scale = (torch.rand(cout, generator=g) + 0.5).to(dev); shift = torch.randn(cout, generator=g).to(dev)
     res = torch.randn(n, cout, h, w, generator=g).to(dev)
     d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=3, kw=3, stride=1, pad_top=1, pad_left=1, conv_h=h, conv_w=w, out_h=h,
-                      out_w=w, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=1, tap_dilation_unused=0)
+                      out_w=w, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=1, flags=0)
     rc = lib.mp_conv_winograd_supported(ctypes.byref(d))
     if rc != 0:
         print(f"{cin}->{cout} {h}x{w}: not supported ({rc})"); continue
@@ -61,7 +61,7 @@ if lib.mp_debug_set_stamp_buffer(dbg.data_ptr(), dbg.numel() * 8) == 0:
         x = torch.randn(n, cin, h, w, device=dev); wt = torch.randn(cout, cin, 3, 3, device=dev)
         scale = torch.ones(cout, device=dev); shift = torch.zeros(cout, device=dev); ow = torch.empty(n, cout, h, w, device=dev)
         d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=3, kw=3, stride=1, pad_top=1, pad_left=1, conv_h=h, conv_w=w, out_h=h,
-                          out_w=w, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=1, tap_dilation_unused=0)
+                          out_w=w, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=1, flags=0)
         pu = torch.empty(lib.mp_conv_winograd_packed_weight_bytes(cout, cin) // 4, device=dev)
         lib.mp_conv_winograd_pack_weight(_lib.ptr(wt), _lib.ptr(pu), cout, cin, st)
         call = lambda: lib.mp_conv2d_winograd_fwd(ctypes.byref(d), _lib.ptr(x), _lib.ptr(pu), _lib.ptr(scale), _lib.ptr(shift), None, None, _lib.ptr(ow), st)

@@ -24,7 +24,7 @@ for cin, cout, h, w, k, st in SHAPES:
     x, out, res = ActC8(nn, cin, h, w, dev), ActC8(nn, cout, ho, wo, dev), ActC8(nn, cout, ho, wo, dev)
     x.c8_tensor.normal_(); res.c8_tensor.normal_()
     d = _lib.ConvDesc(n=nn, cin=cin, h=h, w=w, cout=cout, kh=k, kw=k, stride=st, pad_top=k // 2, pad_left=k // 2, conv_h=ho, conv_w=wo, out_h=ho,
-                      out_w=wo, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=1, tap_dilation_unused=0)
+                      out_w=wo, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=1, flags=0)
     def args(v):
         return (ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(res), None, _lib.ptr(out), _lib.stream())
     ok = [v for v in range(37) if lib.mp_f16_conv2d_fwd(*args(v)) == 0]
