@@ -350,8 +350,8 @@ __global__ __launch_bounds__(256 * TEAMS, TEAMS == 1 ? 2 : 1) void conv_wino_f32
     }
     MP_STAMP(t_epi);
 
-    // ---- accumulators -> LDS -> output transform -> epilogue, one 16-channel half at a time.  A thread (0..191) takes cout
-    // co_l of the half and the four tiles 4 quad .. 4 quad + 3; QROW (launch condition: full 48-tile bands, TW % 4 == 0): those
+    // ---- accumulators -> LDS -> output transform -> epilogue.  A thread (0..191) takes cout co_l of each 16-channel half and
+    // the four tiles 4 quad .. 4 quad + 3; QROW (launch condition: full 48-tile bands, TW % 4 == 0): those
     // four tiles are eight consecutive pixels of two rows -> 16-byte residual loads and stores.  The residual loads are issued
     // before the accumulators go to LDS, so their latency runs under the exchange.
     const int e_ct = ct, e_n = n, e_y0 = y0;
@@ -371,68 +371,83 @@ __global__ __launch_bounds__(256 * TEAMS, TEAMS == 1 ? 2 : 1) void conv_wino_f32
         rs_x = make_rsrc(p.x + (size_t)n * p.Cin * HW, (size_t)n_img * p.Cin * HW * 4);
         tile_request();
     }
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        if (TEAMS == 1 && e_ct * 32 + nb * 16 >= p.Cout_pad16) break;  // workgroup-uniform (two teams: both always pass the barriers)
-        const int co = (e_ct * TEAMS + team) * 32 + nb * 16 + (int)co_l;
-        const unsigned co_off = co < p.Cout ? (unsigned)co * plane_o * 4u : kOob;  // kOob + pixel offset stays out of range
-        f32x4 r1q[2][2], r2q[2][2];
-        float2 r1v[4][2], r2v[4][2];
+    // Output transform Y = A^T M A in two steps.  A wave owns row i = wave of the 4x4 M of every (tile, cout): the column step
+    // P[i][b] = sum_j M[i][j] A[j][b] happens on its own accumulators in registers, so only the 2 (not 4) values per row go
+    // through LDS - both 16-channel halves in ONE exchange ([half][row i][b][cout][tile], the size of the old one-half
+    // buffer) and two barriers per tile.  The row step Y[a][b] = sum_i A^T[a][i] P[i][b] is done by the reading thread.
+    const int co_base = (e_ct * TEAMS + team) * 32;
+    f32x4 r1q[2][2][2], r2q[2][2][2];
+    float2 r1v[2][4][2], r2v[2][4][2];
+    unsigned co_off[2];
+    auto res_request = [&](int nb) {
+        const int co = co_base + nb * 16 + (int)co_l;
+        co_off[nb] = co < p.Cout ? (unsigned)co * plane_o * 4u : kOob;  // kOob + pixel offset stays out of range
         if constexpr (QROW) {
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
-                    const unsigned o = (pix[0] == kOob ? kOob : co_off + pix[0]) + a * row_b + h2 * 16u;
-                    r1q[a][h2] = buf_load4(rs_r1, o);
-                    r2q[a][h2] = buf_load4(rs_r2, o);
+                    const unsigned o = (pix[0] == kOob ? kOob : co_off[nb] + pix[0]) + a * row_b + h2 * 16u;
+                    r1q[nb][a][h2] = buf_load4(rs_r1, o);
+                    r2q[nb][a][h2] = buf_load4(rs_r2, o);
                 }
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
-                    const unsigned o = (pix[e] == kOob ? kOob : co_off + pix[e]) + a * row_b;
-                    r1v[e][a] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_r1, o, 0, 0));
-                    r2v[e][a] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_r2, o, 0, 0));
+                    const unsigned o = (pix[e] == kOob ? kOob : co_off[nb] + pix[e]) + a * row_b;
+                    r1v[nb][e][a] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_r1, o, 0, 0));
+                    r2v[nb][e][a] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_r2, o, 0, 0));
                 }
         }
+    };
+    res_request(0);  // the residual rows of the first half fly under the exchange, those of the second under the first half
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+    for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-            for (int mb = 0; mb < 3; ++mb)
-                *reinterpret_cast<f32x4*>(lds_x + ((wave * 4 + i) * 16 + lr) * kXP + mb * 16 + lq * 4) = acc[i][mb][nb];
-        wg_barrier();
+        for (int mb = 0; mb < 3; ++mb) {
+            const f32x4 p0 = acc[0][mb][nb] + acc[1][mb][nb] + acc[2][mb][nb];
+            const f32x4 p1 = acc[1][mb][nb] - acc[2][mb][nb] - acc[3][mb][nb];
+            float* __restrict__ dst = lds_x + (((nb * 4 + wave) * 2) * 16 + lr) * kXP + mb * 16 + lq * 4;
+            *reinterpret_cast<f32x4*>(dst) = p0;
+            *reinterpret_cast<f32x4*>(dst + 16 * kXP) = p1;
+        }
+    res_request(1);
+    wg_barrier();
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        if (co_base + nb * 16 >= p.Cout_pad16) break;  // wave-uniform; no barrier below
         if (ep_on) {
-            f32x4 m[16];
+            const int co = co_base + nb * 16 + (int)co_l;
+            f32x4 pr[4][2];
 #pragma unroll
-            for (int xi = 0; xi < 16; ++xi) m[xi] = *reinterpret_cast<const f32x4*>(lds_x + (xi * 16 + co_l) * kXP + quad * 4);
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    pr[i][b] = *reinterpret_cast<const f32x4*>(lds_x + (((nb * 4 + i) * 2 + b) * 16 + co_l) * kXP + quad * 4);
             const int cc = co < p.Cout ? co : 0;
             const float sc = p.scale[cc], sh = p.shift[cc];
-            // the four tiles side by side: component e of every vector = tile e
-            f32x4 sv[2][4], y[2][2];
+            // the four tiles side by side: component e of every vector = tile e; y[a][0] = left pixel of each tile in output
+            // row a, y[a][1] = right pixel
+            f32x4 y[2][2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                sv[0][j] = m[0 * 4 + j] + m[1 * 4 + j] + m[2 * 4 + j];
-                sv[1][j] = m[1 * 4 + j] - m[2 * 4 + j] - m[3 * 4 + j];
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                y[a][0] = (sv[a][0] + sv[a][1] + sv[a][2]) * sc + sh;  // left pixel of each tile, output row a
-                y[a][1] = (sv[a][1] - sv[a][2] - sv[a][3]) * sc + sh;  // right pixel
+            for (int b = 0; b < 2; ++b) {
+                y[0][b] = (pr[0][b] + pr[1][b] + pr[2][b]) * sc + sh;
+                y[1][b] = (pr[1][b] - pr[2][b] - pr[3][b]) * sc + sh;
             }
             if constexpr (QROW) {
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
                     f32x4 lo = (f32x4){y[a][0][0], y[a][1][0], y[a][0][1], y[a][1][1]};
                     f32x4 hi = (f32x4){y[a][0][2], y[a][1][2], y[a][0][3], y[a][1][3]};
-                    lo += r1q[a][0] + r2q[a][0];
-                    hi += r1q[a][1] + r2q[a][1];
+                    lo += r1q[nb][a][0] + r2q[nb][a][0];
+                    hi += r1q[nb][a][1] + r2q[nb][a][1];
                     if (p.relu) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) { lo[k] = fmaxf(lo[k], 0.f); hi[k] = fmaxf(hi[k], 0.f); }
                     }
-                    const unsigned o = (pix[0] == kOob ? kOob : co_off + pix[0]) + a * row_b;
+                    const unsigned o = (pix[0] == kOob ? kOob : co_off[nb] + pix[0]) + a * row_b;
                     buf_store4(rs_o, o, lo);
                     buf_store4(rs_o, o + 16u, hi);
                 }
@@ -441,15 +456,15 @@ __global__ __launch_bounds__(256 * TEAMS, TEAMS == 1 ? 2 : 1) void conv_wino_f32
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int a = 0; a < 2; ++a) {
-                        float2 v = make_float2(y[a][0][e] + r1v[e][a].x + r2v[e][a].x, y[a][1][e] + r1v[e][a].y + r2v[e][a].y);
+                        float2 v = make_float2(y[a][0][e] + r1v[nb][e][a].x + r2v[nb][e][a].x, y[a][1][e] + r1v[nb][e][a].y + r2v[nb][e][a].y);
                         if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); }
                         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs_o,
-                                                              (pix[e] == kOob ? kOob : co_off + pix[e]) + a * row_b, 0, 0);
+                                                              (pix[e] == kOob ? kOob : co_off[nb] + pix[e]) + a * row_b, 0, 0);
                     }
             }
         }
-        wg_barrier();  // the exchange buffer is free for the second half / the next tile's raw rows
     }
+    wg_barrier();  // the exchange buffer is free for the next tile's V
     MP_STAMP(t_tile_end);
     s_ep += t_tile_end - t_epi;
     }  // tiles of this workgroup
