@@ -9,6 +9,7 @@
 #include "conv_mfma.h"
 #include "conv_pw.h"
 #include "conv_wino.h"
+#include "conv_gemm.h"
 
 namespace mp {
 
@@ -121,8 +122,11 @@ struct ConvLaunch {
     size_t lds_bytes;
     bool pointwise;  // variant kPointwise: the streaming 1x1 kernel (conv_pw_f32.hip), launch record in pw
     PwLaunch pw;
+    bool gemm;       // variant kGemm: the blocked-GEMM 1x1 kernel (conv_gemm_f32.hip), launch record in gm
+    GemmLaunch gm;
 };
 
+constexpr int kGemm = V_COUNT + 2;   // forced-variant index of the blocked-GEMM 1x1 kernel (V_COUNT + 1 is the tuner's index of the Winograd form)
 constexpr int kPointwise = V_COUNT;  // forced-variant index of the streaming 1x1 kernel (never chosen by the library heuristic)
 
 static const int kLdsMax = 150 * 1024;
@@ -227,6 +231,14 @@ static int choose_variant(const mp_conv_desc& d, ConvLaunch& best, int forced = 
         best.lds_bytes = best.pw.lds_bytes;
         return MP_OK;
     }
+    if (forced == kGemm) {
+        int rc = gemm_configure(&d, best.gm);
+        if (rc != MP_OK) return rc;
+        best.gemm = true;
+        best.ks = 1; best.stride = best.gm.stride; best.variant = kGemm;
+        best.lds_bytes = best.gm.lds_bytes;
+        return MP_OK;
+    }
     if (forced >= 0) {
         if (forced >= V_COUNT) return MP_ERR_UNSUPPORTED;
         return configure(d, forced, best) ? MP_OK : MP_ERR_UNSUPPORTED;
@@ -284,6 +296,7 @@ static int validate_desc(const mp_conv_desc* d) {
 
 static int launch(const ConvLaunch& L0, hipStream_t s) {
     if (L0.pointwise) return pw_launch(L0.pw, s);
+    if (L0.gemm) return gemm_launch(L0.gm, s);
     ConvLaunch L = L0;
     L.p.dbg = (g_stamp_buf && (size_t)L.p.total_blocks * 64 <= g_stamp_bytes) ? g_stamp_buf : nullptr;
     switch (L.ks) {
@@ -307,6 +320,11 @@ static int build_launch(const mp_conv_desc* desc, const float* x, const float* w
     if (L.pointwise) {
         if (res2) return MP_ERR_UNSUPPORTED;  // one residual tensor in the streaming kernel
         L.pw.p.x = x; L.pw.p.wp = w; L.pw.p.scale = scale; L.pw.p.shift = shift; L.pw.p.res1 = res1; L.pw.p.out = out;
+        return MP_OK;
+    }
+    if (L.gemm) {
+        if (res2) return MP_ERR_UNSUPPORTED;  // one residual tensor in the GEMM kernel
+        L.gm.p.x = x; L.gm.p.wp = w; L.gm.p.scale = scale; L.gm.p.shift = shift; L.gm.p.res1 = res1; L.gm.p.out = out;
         return MP_OK;
     }
     L.p.x = x; L.p.wp = w; L.p.scale = scale; L.p.shift = shift; L.p.res1 = res1; L.p.res2 = res2; L.p.out = out;
@@ -622,6 +640,9 @@ int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]) {
         info[1] = 1; info[2] = 1; info[3] = kPointwise; info[4] = e.conv.pw.grid; info[5] = (int64_t)e.conv.pw.lds_bytes;
         info[6] = e.conv.pw.p.Cout; info[7] = 64; info[8] = 64; info[9] = e.conv.pw.cbw; info[10] = e.conv.pw.p.tiles_per_wg;
         info[11] = e.conv.pw.kq;
+    } else if (e.kind == 0 && e.conv.gemm) {
+        info[1] = 1; info[2] = e.conv.gm.stride; info[3] = kGemm; info[4] = e.conv.gm.grid; info[5] = (int64_t)e.conv.gm.lds_bytes;
+        info[6] = 128; info[7] = 64 * e.conv.gm.ni; info[8] = 16; info[9] = 1; info[10] = 1;
     } else if (e.kind == 0) {
         int ct, pt;
         variant_dims(e.conv.variant, ct, pt);

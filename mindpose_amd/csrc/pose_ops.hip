@@ -480,7 +480,7 @@ using namespace mp;
 
 extern "C" {
 
-const char* mp_version(void) { return "mindpose_hip 0.3.0 (gfx950)"; }
+const char* mp_version(void) { return "mindpose_hip 0.4.0 (gfx950)"; }
 
 const char* mp_error_string(int code) {
     switch (code) {

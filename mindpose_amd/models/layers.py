@@ -161,6 +161,7 @@ def _autotune(key, macs, n_variants, launch) -> int:
 
 F32_VARIANTS = 9   # direct MFMA tile variants 0..7 (csrc/conv_mfma.h ConvVariant) + 8 = the streaming 1x1 kernel (conv_pw_f32.hip)
 F32_WINOGRAD = 9   # the tuner's index of the Winograd F(2x2,3x3) form (csrc/conv_wino_f32.hip)
+F32_GEMM = 10      # the blocked-GEMM 1x1 kernel (csrc/conv_gemm_f32.hip; conv_api.hip kGemm)
 
 
 def winograd_enabled() -> bool:
@@ -186,12 +187,14 @@ def tune_conv_variant(lib, d, x, packed, scale, shift, res1, res2, out, half: bo
 
     def launch(v):
         if not half and v == F32_WINOGRAD:
+            if packed_u is None:
+                return -3  # MP_ERR_UNSUPPORTED: no Winograd form of this layer
             return lib.mp_conv2d_winograd_fwd(ctypes.byref(d), _lib.ptr(x), _lib.ptr(packed_u), _lib.ptr(scale), _lib.ptr(shift),
                                               _lib.ptr(res1), _lib.ptr(res2), _lib.ptr(trial_out), stream)
         return fn(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(res1),
                   _lib.ptr(res2), _lib.ptr(trial_out), stream)
 
-    return _autotune(key, macs, F16_VARIANTS if half else (F32_VARIANTS + (1 if packed_u is not None else 0)), launch)
+    return _autotune(key, macs, F16_VARIANTS if half else F32_GEMM + 1, launch)
 
 
 class Plan:

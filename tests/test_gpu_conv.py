@@ -322,3 +322,91 @@ def test_streaming_1x1_kernel_vs_torch_and_direct(case):
                        out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=0, flags=0)
     assert lib.mp_conv2d_fwd_variant(ctypes.byref(d3), 8, _lib.ptr(xd), _lib.ptr(pk), _lib.ptr(sc), _lib.ptr(sh), None, None, _lib.ptr(out),
                                      st) == -3  # Cin = 48 is not a built shape
+
+
+GEMM_CASES = [
+    # n, cin, cout, h, w, stride, relu, res
+    (3, 256, 1024, 16, 12, 1, False, True),   # ResNet layer3 conv3 + identity (resnet.py:74-138): 576 columns = 4.5 column tiles
+    (2, 512, 128, 32, 24, 1, True, False),    # layer2 conv1: one cout tile, 32 chunks
+    (5, 512, 2048, 8, 6, 1, False, True),     # layer4 conv3: 48-pixel planes, a column tile spans 2.67 images
+    (2, 64, 256, 64, 48, 1, False, True),     # stage-1 conv3 (the streaming kernel's shape: both must agree)
+    (3, 256, 512, 64, 48, 2, False, False),   # layer2 down_sample: stride-2 column gather, even rows / columns only
+    (3, 1024, 2048, 16, 12, 2, False, False),  # layer4 down_sample: 8x6 output rows of 6 (a staging unit straddles rows)
+    (2, 32, 200, 10, 6, 1, True, True),       # cout not a multiple of 16 / 128, two chunks, 120 columns in one tile
+    (1, 16, 96, 7, 4, 2, False, True),        # odd height under stride 2 (conv_h = 4), one chunk
+]
+
+
+@pytest.mark.parametrize("ni", ["1", "2"])
+@pytest.mark.parametrize("case", GEMM_CASES, ids=[f"n{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}_s{c[5]}" for c in GEMM_CASES])
+def test_gemm_1x1_kernel_vs_torch_and_direct(case, ni, monkeypatch):
+    """Forced variant 10 of mp_conv2d_fwd_variant: the blocked-GEMM 1x1 kernel (128 x 128 / 128 x 64 output tiles over the pixel
+    columns of the whole batch, 32x32x2 MFMA; the tile width is forced both ways here, the library picks it by the workgroup
+    count) on the direct kernel's packed weights - against fp64 torch at the direct kernel's own bar, and against the direct
+    kernel's result."""
+    import ctypes
+    from mindpose_amd import _lib
+    monkeypatch.setenv("MP_GEMM_NI", ni)
+    n, cin, cout, h, w, stride, relu, res = case
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(cin + cout + h + stride)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    r1 = torch.randn(n, cout, ho, wo, generator=g) if res else None
+    ref = F.conv2d(x.double(), wt.double(), stride=stride) * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]
+    if res:
+        ref = ref + r1.double()
+    if relu:
+        ref = F.relu(ref)
+    d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=1, kw=1, stride=stride, pad_top=0, pad_left=0, conv_h=ho, conv_w=wo, out_h=ho,
+                      out_w=wo, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=int(relu), flags=0)
+    st = _lib.stream()
+    xd, wd, sc, sh = x.to(DEV), wt.to(DEV), scale.to(DEV), shift.to(DEV)
+    rd = r1.to(DEV) if res else None
+    pk = torch.empty(lib.mp_conv_packed_weight_bytes(cout, cin, 1, 1) // 4, device=DEV)
+    _lib.check(lib.mp_conv_pack_weight(_lib.ptr(wd), _lib.ptr(pk), cout, cin, 1, 1, 0, 0, 0, st), "pack")
+    out = torch.full((n, cout, ho, wo), float("nan"), device=DEV)
+    out_d = torch.empty(n, cout, ho, wo, device=DEV)
+    _lib.check(lib.mp_conv2d_fwd_variant(ctypes.byref(d), 10, _lib.ptr(xd), _lib.ptr(pk), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(rd), None,
+                                         _lib.ptr(out), st), "gemm 1x1")
+    _lib.check(lib.mp_conv2d_fwd(ctypes.byref(d), _lib.ptr(xd), _lib.ptr(pk), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(rd), None,
+                                 _lib.ptr(out_d), st), "direct 1x1")
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()  # every element written
+    assert _nerr(out.double().cpu(), ref) <= 2e-5
+    assert _nerr(out.double().cpu(), out_d.double().cpu()) <= 2e-5
+    # in-place on the residual (the training path's accumulate-into form) gives the same bits
+    if res:
+        acc = rd.clone()
+        _lib.check(lib.mp_conv2d_fwd_variant(ctypes.byref(d), 10, _lib.ptr(xd), _lib.ptr(pk), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(acc), None,
+                                             _lib.ptr(acc), st), "gemm 1x1 in place")
+        torch.cuda.synchronize()
+        assert torch.equal(acc, out)
+
+
+def test_gemm_1x1_kernel_rejects_what_it_does_not_cover():
+    import ctypes
+    from mindpose_amd import _lib
+    lib = _lib.load()
+    st = _lib.stream()
+    buf = torch.zeros(1 << 20, device=DEV)
+    base = dict(n=2, cin=64, h=8, w=8, cout=128, kh=1, kw=1, stride=1, pad_top=0, pad_left=0, conv_h=8, conv_w=8, out_h=8, out_w=8,
+                out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=0, flags=0)
+
+    def rc(res2=None, **kw):
+        f = dict(base)
+        f.update(kw)
+        d = _lib.ConvDesc(**f)
+        return lib.mp_conv2d_fwd_variant(ctypes.byref(d), 10, _lib.ptr(buf), _lib.ptr(buf), _lib.ptr(buf), _lib.ptr(buf), None, res2,
+                                         _lib.ptr(buf), st)
+
+    assert rc() == 0
+    assert rc(res2=_lib.ptr(buf)) == -3                                  # a second residual tensor
+    assert rc(cin=40) == -3                                              # not whole 16-channel chunks
+    assert rc(cout=64) == -3                                             # less than most of one 128-channel tile
+    assert rc(kh=3, kw=3, pad_top=1, pad_left=1) == -3                   # not pointwise
+    assert rc(h=5, w=5, conv_h=5, conv_w=5, out_h=5, out_w=5) == -3      # 25-pixel planes: columns are staged in fours
+    assert rc(out_mul=2, out_rep=2, out_h=16, out_w=16) == -3            # fused up-sampling stays with the direct kernel
+    torch.cuda.synchronize()

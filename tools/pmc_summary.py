@@ -17,7 +17,7 @@ import sys
 
 
 def key_of(name):
-    m = re.search(r"(conv_f16_wreg_kernel|basicblock_f16_v2_kernel|basicblock_f16_kernel|conv_wino_f32_kernel|conv1x1_f32_stream_kernel)<([^>]*)>", name)
+    m = re.search(r"(conv_f16_wreg_kernel|basicblock_f16_v2_kernel|basicblock_f16_kernel|conv_wino_f32_kernel|conv1x1_f32_stream_kernel|conv1x1_f32_gemm_kernel)<([^>]*)>", name)
     if m:  # these names are used with their full template argument list
         return f"{m.group(1)}<{','.join(a.strip() for a in m.group(2).split(','))}>"
     m = re.search(r"(conv_mfma_kernel|conv_f16_mt_kernel|conv_f16_kernel)<([^>]*)>", name)
