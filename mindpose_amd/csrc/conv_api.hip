@@ -235,7 +235,7 @@ static int choose_variant(const mp_conv_desc& d, ConvLaunch& best, int forced = 
         int rc = gemm_configure(&d, best.gm);
         if (rc != MP_OK) return rc;
         best.gemm = true;
-        best.ks = 1; best.stride = best.gm.stride; best.variant = kGemm;
+        best.ks = d.kh; best.stride = best.gm.stride; best.variant = kGemm;
         best.lds_bytes = best.gm.lds_bytes;
         return MP_OK;
     }
@@ -641,8 +641,8 @@ int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]) {
         info[6] = e.conv.pw.p.Cout; info[7] = 64; info[8] = 64; info[9] = e.conv.pw.cbw; info[10] = e.conv.pw.p.tiles_per_wg;
         info[11] = e.conv.pw.kq;
     } else if (e.kind == 0 && e.conv.gemm) {
-        info[1] = 1; info[2] = e.conv.gm.stride; info[3] = kGemm; info[4] = e.conv.gm.grid; info[5] = (int64_t)e.conv.gm.lds_bytes;
-        info[6] = 128; info[7] = 64 * e.conv.gm.ni; info[8] = 16; info[9] = 1; info[10] = 1;
+        info[1] = e.conv.ks; info[2] = e.conv.gm.stride; info[3] = kGemm; info[11] = e.conv.gm.gather ? 1 : 0; info[4] = e.conv.gm.grid; info[5] = (int64_t)e.conv.gm.lds_bytes;
+        info[6] = 64 * e.conv.gm.mi; info[7] = 64 * e.conv.gm.ni; info[8] = 16; info[9] = 1; info[10] = 1;
     } else if (e.kind == 0) {
         int ct, pt;
         variant_dims(e.conv.variant, ct, pt);

@@ -12,20 +12,23 @@ struct GemmParams {
     const float* res1;
     float* out;
     int N, Cin, Cin_pad4, Cout, Cout_pad16;
-    int HWi;        // pixels of an input plane
-    int Wi;         // input row length (stride 2: the gather walks rows)
-    int HWo, Wo;    // pixels / row length of an output plane
+    int HWi, Hi, Wi;        // input plane
+    int HWo, Wo;            // the convolution's own output grid (columns of the GEMM: N * HWo)
+    int OHW, OW;            // the output tensor's plane (sub-pixel phases write every out_mul-th pixel of it)
+    int out_mul, off_y, off_x;
+    int stride, pad_top, pad_left;
+    int T, t_shift, kw_shift;  // taps (1 or 4 = 2x2), log2(T), log2(kw)
     int cols;       // N * HWo: the GEMM's column count
-    int n_ct;       // 128-channel cout tiles
-    int n_chunks;   // ceil(Cin / 16)
+    int n_ct;       // cout tiles (128 or 64 channels)
+    int n_iters;    // (Cin / 16) * T k-loop steps
     int relu;
-    unsigned magic_hwo, magic_wo;
 };
 
 struct GemmLaunch {
     GemmParams p;
-    int stride;  // 1 or 2 and
-    int ni;      // 32-column blocks per wave (2: 128-column tiles, 1: 64-column tiles): the instantiation
+    int stride, taps;
+    bool gather; // columns fetched one by one (stride 2, 2x2 phases) and
+    int ni, mi;  // 32-column / 32-cout blocks per wave (2: 128-wide tiles, 1: 64-wide): the instantiation
     int grid;
     size_t lds_bytes;
 };

@@ -468,9 +468,10 @@ class Plan:
                                                              _lib.ptr(scale), _lib.ptr(shift), None, None, _lib.ptr(out)),
                                "mp_plan_add_conv_f16(deconv phase)")
                 else:
-                    _lib.check(self.lib.mp_plan_add_conv(self.handle, ctypes.byref(d), _lib.ptr(x), _lib.ptr(packed),
-                                                         _lib.ptr(scale), _lib.ptr(shift), None, None, _lib.ptr(out)),
-                               "mp_plan_add_conv(deconv phase)")
+                    v = tune_conv_variant(self.lib, d, x, packed, scale, shift, None, None, out)
+                    _lib.check(self.lib.mp_plan_add_conv_variant(self.handle, ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed),
+                                                                 _lib.ptr(scale), _lib.ptr(shift), None, None, _lib.ptr(out)),
+                               "mp_plan_add_conv_variant(deconv phase)")
                 self.layer_info.append(dict(kind="deconv_phase_f16" if half else "deconv_phase", k=2, stride=1, cin=cin, cout=cout, h=h, w=w, n=n,
                                             macs=n * h * w * cout * cin * 4))
         return out

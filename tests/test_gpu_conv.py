@@ -337,12 +337,12 @@ GEMM_CASES = [
 ]
 
 
-@pytest.mark.parametrize("ni", ["1", "2"])
+@pytest.mark.parametrize("ni", ["1", "2", "11"])
 @pytest.mark.parametrize("case", GEMM_CASES, ids=[f"n{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}_s{c[5]}" for c in GEMM_CASES])
 def test_gemm_1x1_kernel_vs_torch_and_direct(case, ni, monkeypatch):
     """Forced variant 10 of mp_conv2d_fwd_variant: the blocked-GEMM 1x1 kernel (128 x 128 / 128 x 64 output tiles over the pixel
-    columns of the whole batch, 32x32x2 MFMA; the tile width is forced both ways here, the library picks it by the workgroup
-    count) on the direct kernel's packed weights - against fp64 torch at the direct kernel's own bar, and against the direct
+    columns of the whole batch, 32x32x2 MFMA; the tile shape - 128 x 64, 128 x 128, 64 x 64 - is forced here, the library picks it by the
+    workgroup count) on the direct kernel's packed weights - against fp64 torch at the direct kernel's own bar, and against the direct
     kernel's result."""
     import ctypes
     from mindpose_amd import _lib
@@ -406,7 +406,42 @@ def test_gemm_1x1_kernel_rejects_what_it_does_not_cover():
     assert rc(res2=_lib.ptr(buf)) == -3                                  # a second residual tensor
     assert rc(cin=40) == -3                                              # not whole 16-channel chunks
     assert rc(cout=64) == -3                                             # less than most of one 128-channel tile
-    assert rc(kh=3, kw=3, pad_top=1, pad_left=1) == -3                   # not pointwise
+    assert rc(kh=3, kw=3, pad_top=1, pad_left=1) == -3                   # neither pointwise nor a 2x2 phase
     assert rc(h=5, w=5, conv_h=5, conv_w=5, out_h=5, out_w=5) == -3      # 25-pixel planes: columns are staged in fours
     assert rc(out_mul=2, out_rep=2, out_h=16, out_w=16) == -3            # fused up-sampling stays with the direct kernel
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("ni", ["1", "2", "11"])
+@pytest.mark.parametrize("case", [(3, 64, 256, 8, 6), (2, 32, 128, 16, 12), (5, 16, 100, 4, 4)], ids=lambda c: f"n{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}")
+def test_gemm_kernel_deconv_phases_vs_conv_transpose(case, ni, monkeypatch):
+    """Conv2dTranspose(k=4, s=2, p=1) + scale / shift + ReLU (simple_baseline_head.py:80-90) as four 2x2 sub-pixel phase launches of
+    the blocked-GEMM kernel (forced variant 10: k loop over (cin chunk, tap), zero padding through the buffer range check, output on
+    every second pixel) against torch's conv_transpose2d in fp64; every output pixel is written by exactly one phase."""
+    import ctypes
+    from mindpose_amd import _lib
+    monkeypatch.setenv("MP_GEMM_NI", ni)
+    n, cin, cout, h, w = case
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cin, cout, 4, 4, generator=g) * (2.0 / (cin * 4)) ** 0.5  # (Cin, Cout, 4, 4): the transposed conv's layout
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ref = F.relu(F.conv_transpose2d(x.double(), wt.double(), stride=2, padding=1) * scale.double()[None, :, None, None]
+                 + shift.double()[None, :, None, None])
+    st = _lib.stream()
+    xd, wd, sc, sh = x.to(DEV), wt.to(DEV), scale.to(DEV), shift.to(DEV)
+    out = torch.full((n, cout, 2 * h, 2 * w), float("nan"), device=DEV)
+    keep = []
+    for py in (0, 1):
+        for px in (0, 1):
+            pk = torch.empty(lib.mp_conv_packed_weight_bytes(cout, cin, 2, 2) // 4, device=DEV)
+            keep.append(pk)
+            _lib.check(lib.mp_conv_pack_weight(_lib.ptr(wd), _lib.ptr(pk), cout, cin, 2, 2, 1, py, px, st), "pack phase")
+            d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=2, kw=2, stride=1, pad_top=1 - py, pad_left=1 - px, conv_h=h, conv_w=w,
+                              out_h=2 * h, out_w=2 * w, out_mul=2, out_rep=1, out_off_y=py, out_off_x=px, relu=1, flags=0)
+            _lib.check(lib.mp_conv2d_fwd_variant(ctypes.byref(d), 10, _lib.ptr(xd), _lib.ptr(pk), _lib.ptr(sc), _lib.ptr(sh), None, None,
+                                                 _lib.ptr(out), st), "gemm phase")
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    assert _nerr(out.double().cpu(), ref) <= 2e-5
