@@ -116,11 +116,17 @@ def time_plan_entries(plan, reps):
     return out
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*_pmc_traffic.json;
-    bench.py cannot collect PMC counters itself).  None when no summary names the kernel."""
+def pmc_traffic(kernel, family=""):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary OF THE SAME WORKLOAD FAMILY
+    (profiles/<tag>_pmc_traffic.json with <tag> ending in `_o2` for the fp16 plans, `_sb` for SimpleBaseline, neither for the fp32
+    HRNet headline: the same instantiation runs other shapes in another network; bench.py cannot collect PMC counters itself).
+    None when no such summary names the kernel."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        tag = os.path.basename(path)[:-len("_pmc_traffic.json")]
+        fam = "_o2" if tag.endswith("_o2") else "_sb" if tag.endswith("_sb") else ""
+        if fam != family:
+            continue
         try:
             with open(path) as f:
                 k = json.load(f)["kernels"].get(kernel)
@@ -131,7 +137,7 @@ def pmc_traffic(kernel):
     return None, None
 
 
-def roofline_report(plan, reps=5, layers_csv=""):
+def roofline_report(plan, reps=5, layers_csv="", workload=""):
     peak = PEAK_FP16_MFMA_TFLOPS if plan.half else PEAK_FP32_MFMA_TFLOPS
     per_entry = time_plan_entries(plan, reps)
     if layers_csv:
@@ -158,7 +164,7 @@ def roofline_report(plan, reps=5, layers_csv=""):
     fam_t = sum(v["time"] for v in groups.values())
     fam_f = sum(v["flops"] for v in groups.values())
     achieved = g["flops"] / g["time"] / 1e12
-    traffic, traffic_source = pmc_traffic(dom)
+    traffic, traffic_source = pmc_traffic(dom, "_o2" if plan.half else "_sb" if workload.startswith("simplebaseline") else "" if workload == "hrnet_w32" else "-")
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
         "frac": round(achieved / peak, 4),
@@ -731,7 +737,7 @@ def main():
                        "execution_lanes": 4 if any(e["kind"] == "barrier" for e in plan.layer_info) else 1},
         }
         if not args.no_roofline:
-            result["roofline"] = roofline_report(plan, layers_csv=args.layers)
+            result["roofline"] = roofline_report(plan, layers_csv=args.layers, workload=args.workload)
             log("roofline done")
         headline = world == 1 and args.workload == "hrnet_w32" and args.amp == "O0" and not args.leg
         if headline and not args.no_cpu_baseline:

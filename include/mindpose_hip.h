@@ -164,8 +164,10 @@ int mp_conv2d_fwd(const mp_conv_desc* desc, const float* x_dev, const float* pac
 
 /* Same as mp_conv2d_fwd / mp_plan_add_conv with the tile variant forced (0..7 = cout tile x pixel tile builds of the direct
  * kernel; 8 = the streaming 1x1 kernel for the HBM-bound stage-1 / layer1 layers - Cin 64 / 128 / 256 with Cin * Cout <= 16384,
- * image planes a multiple of 64 pixels, one residual tensor, same packed weights; -1 = library heuristic).  Returns MP_ERR_UNSUPPORTED when that variant cannot
- * run the shape.  Used by the host-side autotuner, which times the candidates once per distinct layer shape. */
+ * image planes a multiple of 64 pixels, one residual tensor, same packed weights; 10 = the blocked-GEMM kernel for 1x1 stride 1 / 2
+ * and the 2x2 stride-1 sub-pixel phases of the transposed convolution - Cin a multiple of 16, Cout >= 96, planes a multiple of 4
+ * pixels, one residual tensor, same packed weights; 9 is the host tuner's index of the Winograd form, which has its own entry
+ * points below; -1 = library heuristic).  Returns MP_ERR_UNSUPPORTED when that variant cannot run the shape.  Used by the host-side autotuner, which times the candidates once per distinct layer shape. */
 int mp_conv2d_fwd_variant(const mp_conv_desc* desc, int variant, const float* x_dev, const float* packed_w_dev,
                           const float* scale_dev, const float* shift_dev, const float* res1_dev, const float* res2_dev,
                           float* out_dev, mp_stream_t stream);
