@@ -445,3 +445,30 @@ def test_gemm_kernel_deconv_phases_vs_conv_transpose(case, ni, monkeypatch):
     torch.cuda.synchronize()
     assert torch.isfinite(out).all()
     assert _nerr(out.double().cpu(), ref) <= 2e-5
+
+
+def test_simplebaseline_whole_network_tuned_forms_vs_library_heuristic(monkeypatch):
+    """SimpleBaseline-R50 at the recipe's resolution, N large enough for the tuner to time candidates: the tuned plan - blocked-GEMM
+    kernel on the pointwise / stride-2 / transposed-conv-phase launches, Winograd on the 3x3 ones - against the plan recorded with
+    MINDPOSE_AUTOTUNE=0 (direct kernel everywhere, the configuration the oracle tests pin): heat-maps within 2e-5 of the output
+    scale, same arg-max wherever the top-1 / top-2 margin exceeds that."""
+    import mindpose_amd as mp
+    x = torch.randn(32, 3, 256, 192, generator=torch.Generator().manual_seed(7)).to(DEV)
+    outs, variants = [], []
+    for env in ("1", "0"):
+        monkeypatch.setenv("MINDPOSE_AUTOTUNE", env)
+        net = mp.init_synthetic(mp.create_network("resnet50", "simple_baseline_head"), seed=0).to(DEV).eval()
+        outs.append(net(x).clone())
+        plan = next(iter(net._plans.values()))
+        infos = [plan.entry_info(i) for i in range(len(plan))]
+        variants.append([(i["kind_id"], i["variant"]) for i in infos])
+    tuned, plain = variants
+    assert sum(1 for k, v in tuned if k == 0 and v == 10) >= 10 and sum(1 for k, v in tuned if k == 9) >= 5
+    assert all(k == 0 and v < 8 for k, v in plain if k in (0, 9))
+    a, b = outs
+    span = float(b.abs().max())
+    assert float((a - b).abs().max()) / span <= 2e-5
+    n, k = a.shape[:2]
+    top2 = b.reshape(n, k, -1).topk(2, dim=2).values
+    safe = (top2[..., 0] - top2[..., 1]) > 1e-4 * span
+    assert torch.equal(a.reshape(n, k, -1).argmax(2)[safe], b.reshape(n, k, -1).argmax(2)[safe])
