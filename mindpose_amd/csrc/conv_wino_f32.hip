@@ -5,17 +5,19 @@
 // (adds only), then the same folded-BatchNorm / residual / ReLU epilogue as the direct kernel (conv_mfma.h).
 //
 //   workgroup   256 threads, one image band of TR x TW <= 48 output tiles (2x2 pixels each) x 32 output channels, all of Cin
-//               in chunks of 8 channels
+//               in chunks of 8 channels; a run of up to 8 consecutive tiles per workgroup.  TEAMS = 2: 512 threads, two
+//               four-wave teams on one band and 64 output channels - shared raw rows / transform / V, see the kernel comment
 //   per chunk   (1) raw input rows  global -> registers -> LDS  [8][R+2][W+4] (zero halo, double-buffered; the loads of chunk
-//                   c+1 fly under the arithmetic of chunk c)
+//                   c+2 fly under the arithmetic of chunk c)
 //               (2) input transform: a thread takes two horizontally adjacent tiles of one channel (4 x 6 patch: b128 + b64
 //                   LDS reads per row), writes V[xi][cin][tile] (tile pitch 48 == 16 mod 32: the four cin rows of an MFMA
-//                   operand fetch sit on disjoint banks)
+//                   operand fetch sit on disjoint banks); woven between the MFMAs of the previous chunk
 //               (3) MFMA: wave w owns xi = 4w .. 4w+3 for all 3 x 2 (tile block, cout block) pairs = 24 accumulators;
 //                   U comes straight from global memory / L2 into registers one chunk ahead (no LDS copy of the weights)
-//   epilogue    the accumulators of the four waves meet in LDS ([xi][cout][tile]), a thread gathers the 16 xi values of four
-//               tiles of one cout, applies A^T . A, scale/shift (+res1)(+res2)(+ReLU) and stores 2x2 pixels per tile.
-//   LDS         52 KiB -> three workgroups per CU: while one transforms, the others feed the matrix cores.
+//   epilogue    the column step of Y = A^T M A on the wave's own accumulators (it owns row w of every 4x4 M), the two values
+//               per row of both 16-channel halves through LDS in one exchange, the row step + scale/shift (+res1)(+res2)(+ReLU)
+//               by the reading thread: four tiles of one cout = 2x2 pixels each, 16-byte stores when they are one pixel row.
+//   LDS         73 KiB -> two workgroups per CU (TEAMS = 2: 126 KiB, one): while one transforms, the other feeds the matrix cores.
 #include <stdlib.h>
 
 #include "conv_mfma.h"

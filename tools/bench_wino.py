@@ -66,7 +66,7 @@ if lib.mp_debug_set_stamp_buffer(dbg.data_ptr(), dbg.numel() * 8) == 0:
         lib.mp_conv_winograd_pack_weight(_lib.ptr(wt), _lib.ptr(pu), cout, cin, st)
         call = lambda: lib.mp_conv2d_winograd_fwd(ctypes.byref(d), _lib.ptr(x), _lib.ptr(pu), _lib.ptr(scale), _lib.ptr(shift), None, None, _lib.ptr(ow), st)
         call(); call(); torch.cuda.synchronize(); dbg.zero_(); call(); torch.cuda.synchronize()
-        wgs = n * ((h + 1) // 2 * (w // 2) + 47) // 48 * ((cout + 31) // 32)
+        wgs = n * ((h + 1) // 2 * (w // 2) + 47) // 48 * ((cout + 31) // 32)  # upper bound (two-team launches have half of it)
         a = dbg[: wgs * 8].reshape(-1, 8).cpu().numpy().astype(np.float64)
         a = a[a[:, 0] > 0]
         names = ["total", "prologue", "transform", "bar(V)", "mfma", "store+wait", "bar(raw)", "epilogue"]
