@@ -566,7 +566,7 @@ EXTRA_LEGS = {
     "hrnet_w32_256x192_infer_ampO2": ["--workload", "hrnet_w32", "--amp", "O2", "--batch", "128", "--steps", "10", "--warmup", "3"],
     "config5_hrnet_w48_384x288_udp_dark_flip_ampO2": ["--workload", "hrnet_w48_384_udp_flip", "--amp", "O2", "--batch", "64",
                                                       "--steps", "5", "--warmup", "2"],
-    "config1_simplebaseline_r50_256x192_infer_f32": ["--workload", "simplebaseline_r50", "--batch", "64", "--steps", "5", "--warmup", "2"],
+    "config1_simplebaseline_r50_256x192_infer_f32": ["--workload", "simplebaseline_r50", "--batch", "128", "--steps", "5", "--warmup", "2"],
     "config3_hrnet_w32_train_f32": ["--workload", "hrnet_w32_train", "--batch", "128", "--steps", "5", "--warmup", "2"],
     "config3_hrnet_w32_train_ampO2": ["--workload", "hrnet_w32_train", "--amp", "O2", "--batch", "128", "--steps", "5", "--warmup", "2"],
 }
