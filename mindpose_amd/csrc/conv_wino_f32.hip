@@ -312,12 +312,14 @@ __global__ __launch_bounds__(256 * TEAMS, TEAMS == 1 ? 2 : 1) void conv_wino_f32
     // branch-free and the same for every chunk (past the last chunk the buffer loads are out of range and return zeros, the
     // transform works on stale rows into a V buffer nobody reads): one loop, no peeled copy, the accumulators stay put.
     const int a_base = wave * 4 * (kCK * kTP) + lq * kTP + lr;
-    for (int ch = 0; ch < p.n_chunks; ++ch) {
+    // Two chunks per trip with the roles of the two U register sets exchanged in between (no copy of the 16 fragments, buffer
+    // parities are constants); an odd chunk count runs one chunk past the end - zeros times zeros, see above.
+    auto chunk = [&](int ch, const int par, float (&ua)[4][2][2], float (&ub)[4][2][2]) {
         MP_STAMP(t0);
         stage_load(ch + 2);
-        load_u(ch + 1, unext);
-        const float* __restrict__ vcur = lds_v + (ch & 1) * kVFloats + a_base;
-        if (TEAMS == 1 || team == 0) xf_read((ch + 1) & 1);
+        load_u(ch + 1, ub);
+        const float* __restrict__ vcur = lds_v + par * kVFloats + a_base;
+        if (TEAMS == 1 || team == 0) xf_read(par ^ 1);
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -330,25 +332,35 @@ __global__ __launch_bounds__(256 * TEAMS, TEAMS == 1 ? 2 : 1) void conv_wino_f32
                 for (int mb = 0; mb < 3; ++mb)
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb)
-                        acc[i][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], ucur[i][nb][q], acc[i][mb][nb], 0, 0, 0);
+                        acc[i][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], ua[i][nb][q], acc[i][mb][nb], 0, 0, 0);
                 if (TEAMS == 1 || team == 0) {  // (team: wave-uniform)
                     if (q == 0 && i == 1) xf_cols();
-                    if (q == 0 && i >= 2) xf_rows_write((ch + 1) & 1, i - 2);
-                    if (q == 1 && i < 2) xf_rows_write((ch + 1) & 1, i + 2);
+                    if (q == 0 && i >= 2) xf_rows_write(par ^ 1, i - 2);
+                    if (q == 1 && i < 2) xf_rows_write(par ^ 1, i + 2);
                 }
             }
         MP_STAMP(t3);
-        stage_store(ch & 1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) ucur[i][nb][q] = unext[i][nb][q];
+        stage_store(par);
         MP_STAMP(t4);
         wg_barrier();
         MP_STAMP(t5);
         s_mm += t3 - t0; s_st += t4 - t3; s_b2 += t5 - t4;
+    };
+    if constexpr (TEAMS == 1) {
+        for (int ch = 0; ch < p.n_chunks; ch += 2) {
+            chunk(ch, 0, ucur, unext);
+            chunk(ch + 1, 1, unext, ucur);
+        }
+    } else {  // two teams: at 256 registers the double-length body spills; one chunk per trip, the fragments copied
+        for (int ch = 0; ch < p.n_chunks; ++ch) {
+            chunk(ch, ch & 1, ucur, unext);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) ucur[i][nb][q] = unext[i][nb][q];
+        }
     }
     MP_STAMP(t_epi);
 
