@@ -166,17 +166,17 @@ __global__ __launch_bounds__(256 * TEAMS, TEAMS == 1 ? 2 : 1) void conv_wino_f32
     };
     tile_u();
     const unsigned u_q = (unsigned)(4 * p.Cout_pad16 * 16) * 4u;  // next k-step (4 input channels)
-    float ucur[4][2][2], unext[4][2][2];
-    auto load_u = [&](int ch, float (&dst)[4][2][2]) {
-        const unsigned base = (unsigned)(ch * 2) * u_q;
+    // ONE register set for the U fragments: the k-step q half of chunk c + 1 is loaded into the registers of the k-step q half of
+    // chunk c right after the MFMAs that consumed it (its latency runs under the other half) - no second set, no copies
+    float ucur[4][2][2];
+    auto load_u_half = [&](int ch, int q) {
+        const unsigned base = (unsigned)(ch * 2 + q) * u_q;
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < 2; ++nb) {
+            const f32x4 v = buf_load4(rs_u, u_off[nb] + base);  // kOob + offset stays out of range
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const f32x4 v = buf_load4(rs_u, u_off[nb] + base + q * u_q);  // kOob + offset stays out of range
-#pragma unroll
-                for (int i = 0; i < 4; ++i) dst[i][nb][q] = v[i];
-            }
+            for (int i = 0; i < 4; ++i) ucur[i][nb][q] = v[i];
+        }
     };
 
     f32x4 vin[NI];
@@ -248,7 +248,8 @@ __global__ __launch_bounds__(256 * TEAMS, TEAMS == 1 ? 2 : 1) void conv_wino_f32
             vin[i] = buf_load4(rs_x, isrc[i]);
             vin1[i] = buf_load4(rs_x, isrc[i] + xo);
         }
-        load_u(0, ucur);
+        load_u_half(0, 0);
+        load_u_half(0, 1);
     };
     tile_request();
     {   // zero both raw buffers once: the halo columns are never written by the chunk copies
@@ -312,16 +313,15 @@ __global__ __launch_bounds__(256 * TEAMS, TEAMS == 1 ? 2 : 1) void conv_wino_f32
     // branch-free and the same for every chunk (past the last chunk the buffer loads are out of range and return zeros, the
     // transform works on stale rows into a V buffer nobody reads): one loop, no peeled copy, the accumulators stay put.
     const int a_base = wave * 4 * (kCK * kTP) + lq * kTP + lr;
-    // Two chunks per trip with the roles of the two U register sets exchanged in between (no copy of the 16 fragments, buffer
-    // parities are constants); an odd chunk count runs one chunk past the end - zeros times zeros, see above.
-    auto chunk = [&](int ch, const int par, float (&ua)[4][2][2], float (&ub)[4][2][2]) {
+    // (one team: two chunks per trip - the buffer parities are constants; an odd chunk count runs one chunk past the end, zeros
+    // times zeros, see above.  Two teams, at the 256-register ceiling, spill with the double-length body: one chunk per trip)
+    auto chunk = [&](int ch, const int par) {
         MP_STAMP(t0);
         stage_load(ch + 2);
-        load_u(ch + 1, ub);
         const float* __restrict__ vcur = lds_v + par * kVFloats + a_base;
         if (TEAMS == 1 || team == 0) xf_read(par ^ 1);
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < 2; ++q) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float* __restrict__ va = vcur + i * (kCK * kTP) + q * 4 * kTP;
@@ -332,13 +332,16 @@ __global__ __launch_bounds__(256 * TEAMS, TEAMS == 1 ? 2 : 1) void conv_wino_f32
                 for (int mb = 0; mb < 3; ++mb)
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb)
-                        acc[i][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], ua[i][nb][q], acc[i][mb][nb], 0, 0, 0);
+                        acc[i][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], ucur[i][nb][q], acc[i][mb][nb], 0, 0, 0);
                 if (TEAMS == 1 || team == 0) {  // (team: wave-uniform)
                     if (q == 0 && i == 1) xf_cols();
                     if (q == 0 && i >= 2) xf_rows_write(par ^ 1, i - 2);
                     if (q == 1 && i < 2) xf_rows_write(par ^ 1, i + 2);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);  // the refill below must not move above the MFMAs that read these registers' old values
+            load_u_half(ch + 1, q);
+        }
         MP_STAMP(t3);
         stage_store(par);
         MP_STAMP(t4);
@@ -348,19 +351,11 @@ __global__ __launch_bounds__(256 * TEAMS, TEAMS == 1 ? 2 : 1) void conv_wino_f32
     };
     if constexpr (TEAMS == 1) {
         for (int ch = 0; ch < p.n_chunks; ch += 2) {
-            chunk(ch, 0, ucur, unext);
-            chunk(ch + 1, 1, unext, ucur);
+            chunk(ch, 0);
+            chunk(ch + 1, 1);
         }
-    } else {  // two teams: at 256 registers the double-length body spills; one chunk per trip, the fragments copied
-        for (int ch = 0; ch < p.n_chunks; ++ch) {
-            chunk(ch, ch & 1, ucur, unext);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) ucur[i][nb][q] = unext[i][nb][q];
-        }
+    } else {
+        for (int ch = 0; ch < p.n_chunks; ++ch) chunk(ch, ch & 1);
     }
     MP_STAMP(t_epi);
 
