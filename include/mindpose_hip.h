@@ -212,6 +212,17 @@ int mp_plan_add_conv_variant(mp_plan* plan, const mp_conv_desc* desc, int varian
                              const float* packed_w_dev, const float* scale_dev, const float* shift_dev,
                              const float* res1_dev, const float* res2_dev, float* out_dev);
 /* mp_conv2d_winograd_fwd as a plan entry (same operands; MP_ERR_UNSUPPORTED when the descriptor is outside the Winograd form). */
+/* Conv2dTranspose(k=4, s=2, pad_mode="pad", padding=1) + scale / shift (+ReLU) - simple_baseline_head.py:80-90 - with ALL FOUR
+ * sub-pixel phases in one launch of the blocked-GEMM kernel (variant 10 above; phase = a grid dimension, so the small-map layers
+ * of the head fill the chip with efficient tiles).  `phase00_desc` is the phase (0, 0) launch of the per-phase form: kh = kw = 2,
+ * stride 1, pad_top = pad_left = 1, conv = input size, out = 2x input size, out_mul 2, offsets 0; `packed4_dev` = the four phase
+ * packings of mp_conv_pack_weight(transposed = 1, phase_y, phase_x) back to back in the order (0,0) (0,1) (1,0) (1,1), each
+ * mp_conv_packed_weight_bytes(cout, cin, 2, 2) long.  Same arithmetic per output as four mp_conv2d_fwd_variant(10) launches. */
+int mp_deconv4x4s2_gemm_supported(const mp_conv_desc* phase00_desc);
+int mp_deconv4x4s2_gemm_fwd(const mp_conv_desc* phase00_desc, const float* x_dev, const float* packed4_dev, const float* scale_dev,
+                            const float* shift_dev, float* out_dev, mp_stream_t stream);
+int mp_plan_add_deconv4x4s2_gemm(mp_plan* plan, const mp_conv_desc* phase00_desc, const float* x_dev, const float* packed4_dev,
+                                 const float* scale_dev, const float* shift_dev, float* out_dev);
 int mp_plan_add_conv_winograd(mp_plan* plan, const mp_conv_desc* desc, const float* x_dev, const float* packed_u_dev,
                               const float* scale_dev, const float* shift_dev, const float* res1_dev, const float* res2_dev,
                               float* out_dev);

@@ -54,6 +54,9 @@ _PROTOTYPES = {
     "mp_conv2d_winograd_fwd": (c_int, [ctypes.POINTER(ConvDesc)] + [c_f32p] * 7 + [ctypes.c_void_p]),
     "mp_plan_add_conv_winograd": (c_int, [ctypes.c_void_p, ctypes.POINTER(ConvDesc)] + [c_f32p] * 7),
     "mp_plan_add_conv_variant": (c_int, [ctypes.c_void_p, ctypes.POINTER(ConvDesc), c_int] + [c_f32p] * 7),
+    "mp_deconv4x4s2_gemm_supported": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "mp_deconv4x4s2_gemm_fwd": (c_int, [ctypes.POINTER(ConvDesc)] + [c_f32p] * 5 + [ctypes.c_void_p]),
+    "mp_plan_add_deconv4x4s2_gemm": (c_int, [ctypes.c_void_p, ctypes.POINTER(ConvDesc)] + [c_f32p] * 5),
     "mp_maxpool3x3s2_same": (c_int, [c_f32p, c_f32p] + [c_int] * 4 + [ctypes.c_void_p]),
     "mp_fuse_upsample_sum": (c_int, [c_f32p, c_f32p, c_int, c_f32p, c_int, c_f32p, c_int, c_f32p] + [c_int] * 5 + [ctypes.c_void_p]),
     "mp_plan_add_fuse_sum": (c_int, [ctypes.c_void_p, c_f32p, c_f32p, c_int, c_f32p, c_int, c_f32p, c_int, c_f32p] + [c_int] * 5),

@@ -511,6 +511,45 @@ int mp_plan_add_conv_variant(mp_plan* plan, const mp_conv_desc* desc, int varian
     return MP_OK;
 }
 
+static int build_deconv_gemm(const mp_conv_desc* desc, const float* x, const float* packed4, const float* scale, const float* shift,
+                             float* out, ConvLaunch& L) {
+    int rc = validate_desc(desc);
+    if (rc != MP_OK) return rc;
+    if (!x || !packed4 || !scale || !shift || !out) return MP_ERR_NULL;
+    rc = gemm_configure_deconv(desc, L.gm);
+    if (rc != MP_OK) return rc;
+    L.gemm = true;
+    L.ks = 2; L.stride = 1; L.variant = kGemm; L.lds_bytes = L.gm.lds_bytes;
+    L.gm.p.x = x; L.gm.p.wp = packed4; L.gm.p.scale = scale; L.gm.p.shift = shift; L.gm.p.res1 = nullptr; L.gm.p.out = out;
+    return MP_OK;
+}
+
+int mp_deconv4x4s2_gemm_supported(const mp_conv_desc* phase00_desc) {
+    GemmLaunch L{};
+    int rc = validate_desc(phase00_desc);
+    return rc != MP_OK ? rc : gemm_configure_deconv(phase00_desc, L);
+}
+
+int mp_deconv4x4s2_gemm_fwd(const mp_conv_desc* phase00_desc, const float* x, const float* packed4, const float* scale,
+                            const float* shift, float* out, mp_stream_t stream) {
+    ConvLaunch L{};
+    int rc = build_deconv_gemm(phase00_desc, x, packed4, scale, shift, out, L);
+    if (rc != MP_OK) return rc;
+    return launch(L, as_stream(stream));
+}
+
+int mp_plan_add_deconv4x4s2_gemm(mp_plan* plan, const mp_conv_desc* phase00_desc, const float* x, const float* packed4,
+                                 const float* scale, const float* shift, float* out) {
+    if (!plan) return MP_ERR_NULL;
+    mp_plan::Entry e{};
+    e.kind = 0;
+    int rc = build_deconv_gemm(phase00_desc, x, packed4, scale, shift, out, e.conv);
+    if (rc != MP_OK) return rc;
+    e.lane = plan->cur_lane;
+    plan->entries.push_back(e);
+    return MP_OK;
+}
+
 mp_plan* mp_plan_create(void) { return new (std::nothrow) mp_plan(); }
 
 void mp_plan_destroy(mp_plan* plan) { delete plan; }
@@ -641,8 +680,8 @@ int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]) {
         info[6] = e.conv.pw.p.Cout; info[7] = 64; info[8] = 64; info[9] = e.conv.pw.cbw; info[10] = e.conv.pw.p.tiles_per_wg;
         info[11] = e.conv.pw.kq;
     } else if (e.kind == 0 && e.conv.gemm) {
-        info[1] = e.conv.ks; info[2] = e.conv.gm.stride; info[3] = kGemm; info[11] = e.conv.gm.gather ? 1 : 0; info[4] = e.conv.gm.grid; info[5] = (int64_t)e.conv.gm.lds_bytes;
-        info[6] = 64 * e.conv.gm.mi; info[7] = 64 * e.conv.gm.ni; info[8] = 16; info[9] = 1; info[10] = 1;
+        info[1] = e.conv.ks; info[2] = e.conv.gm.stride; info[3] = kGemm; info[11] = e.conv.gm.gather ? 1 : 0; info[4] = (int64_t)e.conv.gm.grid * e.conv.gm.phases; info[5] = (int64_t)e.conv.gm.lds_bytes;
+        info[6] = 64 * e.conv.gm.mi; info[7] = 64 * e.conv.gm.ni; info[8] = 16; info[9] = e.conv.gm.phases; info[10] = 1;
     } else if (e.kind == 0) {
         int ct, pt;
         variant_dims(e.conv.variant, ct, pt);

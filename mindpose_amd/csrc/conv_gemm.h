@@ -22,11 +22,13 @@ struct GemmParams {
     int n_ct;       // cout tiles (128 or 64 channels)
     int n_iters;    // (Cin / 16) * T k-loop steps
     int relu;
+    int phases;                 // 1, or 4 = all sub-pixel phases of a transposed convolution in one launch (grid.y)
+    unsigned wp_phase_floats;   // floats per phase slice of the packed weights
 };
 
 struct GemmLaunch {
     GemmParams p;
-    int stride, taps;
+    int stride, taps, phases;
     bool gather; // columns fetched one by one (stride 2, 2x2 phases) and
     int ni, mi;  // 32-column / 32-cout blocks per wave (2: 128-wide tiles, 1: 64-wide): the instantiation
     int grid;
@@ -34,6 +36,7 @@ struct GemmLaunch {
 };
 
 int gemm_configure(const mp_conv_desc* d, GemmLaunch& L);  // MP_OK / MP_ERR_UNSUPPORTED; pointers left null
+int gemm_configure_deconv(const mp_conv_desc* phase00, GemmLaunch& L);  // all four phases of Conv2dTranspose(k=4, s=2, p=1)
 int gemm_launch(const GemmLaunch& L, hipStream_t s);
 
 }  // namespace mp

@@ -63,6 +63,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f32_gemm_kernel(const GemmPara
         wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
     }
     const int ct = wg % p.n_ct, co0 = ct * TM, col0 = (wg / p.n_ct) * TN;
+    // p.phases == 4: the four sub-pixel phases of a transposed convolution in ONE launch, phase (py, px) = blockIdx.y - its own
+    // packed weights (four equal slices of one buffer), padding 1 - p on the top / left, output pixels (2 y + py, 2 x + px)
+    const int phase = GATHER && p.phases > 1 ? (int)blockIdx.y : 0;
+    const int pad_top = GATHER && p.phases > 1 ? 1 - (phase >> 1) : p.pad_top, pad_left = GATHER && p.phases > 1 ? 1 - (phase & 1) : p.pad_left;
+    const int off_y = GATHER && p.phases > 1 ? phase >> 1 : p.off_y, off_x = GATHER && p.phases > 1 ? phase & 1 : p.off_x;
+    const float* __restrict__ wp = p.wp + (size_t)phase * p.wp_phase_floats;
 
     if (tid < TM) {
         const int co = co0 + tid;
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f32_gemm_kernel(const GemmPara
     const int srow = MI == 2 ? tid >> 5 : tid >> 4, c4 = MI == 2 ? (tid & 31) * 4 : (tid & 15) * 4;
     const int srow_b = NI == 2 ? tid >> 5 : tid >> 4, c4_b = NI == 2 ? (tid & 31) * 4 : (tid & 15) * 4;
     const int T = GATHER ? p.T : 1;
-    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.wp, (size_t)p.Cin_pad4 * T * p.Cout_pad16 * 4);
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(wp, (size_t)p.Cin_pad4 * T * p.Cout_pad16 * 4);
     const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x, (size_t)p.N * p.Cin * p.HWi * 4);
     const unsigned a_src = co0 + c4 < p.Cout_pad16 ? (unsigned)((((srow >> 2) * T) * 4 + (srow & 3)) * p.Cout_pad16 + co0 + c4) * 4u : kOob;
     const unsigned a_row8 = (unsigned)(8 * T * p.Cout_pad16) * 4u, a_chunk = (unsigned)(kKC * T * p.Cout_pad16) * 4u;
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f32_gemm_kernel(const GemmPara
         const int n = j / p.HWo, pp = j - n * p.HWo;
         if constexpr (GATHER) {
             const int oy = pp / p.Wo, ox = pp - oy * p.Wo;
-            const int y0 = oy * p.stride - p.pad_top, x0 = ox * p.stride - p.pad_left;
+            const int y0 = oy * p.stride - pad_top, x0 = ox * p.stride - pad_left;
             b_src[e] = (unsigned)((n * p.Cin + srow_b) * p.HWi + y0 * p.Wi + x0) * 4u;  // may wrap below zero: masked then
             for (int t = 0; t < T; ++t) {
                 const int yy = y0 + (t >> p.kw_shift), xx = x0 + (t & ((1 << p.kw_shift) - 1));
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f32_gemm_kernel(const GemmPara
         const int j = col0 + wn * 32 * NI + ni * 32 + l31;
         const int n = j / p.HWo, pp = j - n * p.HWo;
         const int oy = pp / p.Wo, ox = pp - oy * p.Wo;
-        o_col[ni] = j < p.cols ? (unsigned)(n * p.Cout * p.OHW + (oy * p.out_mul + p.off_y) * p.OW + ox * p.out_mul + p.off_x) * 4u : kOob;
+        o_col[ni] = j < p.cols ? (unsigned)(n * p.Cout * p.OHW + (oy * p.out_mul + off_y) * p.OW + ox * p.out_mul + off_x) * 4u : kOob;
     }
     const unsigned plane = (unsigned)p.OHW * 4u;
     f32x16 r1[MI][NI];
@@ -241,6 +247,8 @@ int gemm_configure(const mp_conv_desc* d, GemmLaunch& L) {
     p.OHW = ohw; p.OW = d->out_w; p.out_mul = d->out_mul; p.off_y = d->out_off_y; p.off_x = d->out_off_x;
     p.stride = d->stride; p.pad_top = d->pad_top; p.pad_left = d->pad_left;
     p.T = d->kh * d->kw; p.t_shift = phase ? 2 : 0; p.kw_shift = phase ? 1 : 0;
+    p.phases = 1; p.wp_phase_floats = 0;
+    L.phases = 1;
     p.cols = d->n * hwo;
     p.n_iters = d->cin / kKC * p.T;
     p.relu = d->relu;
@@ -260,14 +268,40 @@ int gemm_configure(const mp_conv_desc* d, GemmLaunch& L) {
     return MP_OK;
 }
 
+int gemm_configure_deconv(const mp_conv_desc* d, GemmLaunch& L) {
+    // `d` = the phase (0, 0) launch of Conv2dTranspose(k=4, s=2, p=1): 2x2, stride 1, padding 1 / 1, output offset 0 / 0, every second
+    // pixel of a 2h x 2w plane (layers.py Plan.deconv4x4s2); the other three phases differ in padding and offset only
+    if (!d) return MP_ERR_NULL;
+    if (d->kh != 2 || d->kw != 2 || d->stride != 1 || d->pad_top != 1 || d->pad_left != 1 || d->out_mul != 2 || d->out_rep != 1 ||
+        d->out_off_y != 0 || d->out_off_x != 0 || d->out_h != 2 * d->h || d->out_w != 2 * d->w || d->conv_h != d->h || d->conv_w != d->w)
+        return MP_ERR_UNSUPPORTED;
+    int rc = gemm_configure(d, L);
+    if (rc != MP_OK) return rc;
+    GemmParams& p = L.p;
+    p.phases = 4;
+    p.wp_phase_floats = (unsigned)((size_t)p.Cin_pad4 * 4 * p.Cout_pad16);
+    L.phases = 4;
+    // tile shape by the workgroup count of all four phases together
+    const long long t128 = 4LL * ((p.Cout_pad16 + kTM - 1) / kTM) * ((p.cols + kTN - 1) / kTN);
+    L.ni = t128 >= 512 ? 2 : 1;
+    L.mi = t128 >= 192 ? 2 : 1;
+    if (const char* e = getenv("MP_GEMM_NI")) {
+        if (atoi(e) == 1 || atoi(e) == 2) { L.ni = atoi(e); L.mi = 2; }
+        if (atoi(e) == 11) { L.ni = 1; L.mi = 1; }
+    }
+    p.n_ct = (p.Cout_pad16 + 64 * L.mi - 1) / (64 * L.mi);
+    L.grid = p.n_ct * ((p.cols + 64 * L.ni - 1) / (64 * L.ni));
+    return MP_OK;
+}
+
 int gemm_launch(const GemmLaunch& L, hipStream_t s) {
     if (L.mi == 1) {
-        if (L.gather) hipLaunchKernelGGL((conv1x1_f32_gemm_kernel<true, 1, 1>), dim3(L.grid), dim3(256), L.lds_bytes, s, L.p);
-        else hipLaunchKernelGGL((conv1x1_f32_gemm_kernel<false, 1, 1>), dim3(L.grid), dim3(256), L.lds_bytes, s, L.p);
-    } else if (L.gather && L.ni == 2) hipLaunchKernelGGL((conv1x1_f32_gemm_kernel<true, 2, 2>), dim3(L.grid), dim3(256), L.lds_bytes, s, L.p);
-    else if (L.gather) hipLaunchKernelGGL((conv1x1_f32_gemm_kernel<true, 1, 2>), dim3(L.grid), dim3(256), L.lds_bytes, s, L.p);
-    else if (L.ni == 2) hipLaunchKernelGGL((conv1x1_f32_gemm_kernel<false, 2, 2>), dim3(L.grid), dim3(256), L.lds_bytes, s, L.p);
-    else hipLaunchKernelGGL((conv1x1_f32_gemm_kernel<false, 1, 2>), dim3(L.grid), dim3(256), L.lds_bytes, s, L.p);
+        if (L.gather) hipLaunchKernelGGL((conv1x1_f32_gemm_kernel<true, 1, 1>), dim3(L.grid, L.phases), dim3(256), L.lds_bytes, s, L.p);
+        else hipLaunchKernelGGL((conv1x1_f32_gemm_kernel<false, 1, 1>), dim3(L.grid, L.phases), dim3(256), L.lds_bytes, s, L.p);
+    } else if (L.gather && L.ni == 2) hipLaunchKernelGGL((conv1x1_f32_gemm_kernel<true, 2, 2>), dim3(L.grid, L.phases), dim3(256), L.lds_bytes, s, L.p);
+    else if (L.gather) hipLaunchKernelGGL((conv1x1_f32_gemm_kernel<true, 1, 2>), dim3(L.grid, L.phases), dim3(256), L.lds_bytes, s, L.p);
+    else if (L.ni == 2) hipLaunchKernelGGL((conv1x1_f32_gemm_kernel<false, 2, 2>), dim3(L.grid, L.phases), dim3(256), L.lds_bytes, s, L.p);
+    else hipLaunchKernelGGL((conv1x1_f32_gemm_kernel<false, 1, 2>), dim3(L.grid, L.phases), dim3(256), L.lds_bytes, s, L.p);
     return check_launch();
 }
 

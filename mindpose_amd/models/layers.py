@@ -450,30 +450,75 @@ class Plan:
         return out
 
     def deconv4x4s2(self, x: torch.Tensor, deconv: Conv2dTranspose, bn: BatchNorm2d, relu: bool = True) -> torch.Tensor:
-        """Conv2dTranspose(k=4, s=2, p=1) + BN + ReLU as four 2x2 sub-pixel phase convolutions."""
+        """Conv2dTranspose(k=4, s=2, p=1) + BN + ReLU as four 2x2 sub-pixel phase convolutions - four launches with a tuned form each,
+        or (fp32, where the tuner finds it faster: the small maps of the head) all four phases in ONE launch of the blocked-GEMM
+        kernel (mp_plan_add_deconv4x4s2_gemm)."""
         half = isinstance(x, ActC8)
         n, cin, h, w = x.shape
         cout = deconv.out_channels
         out = self.alloc(n, cout, 2 * h, 2 * w) if half else self.alloc_f32(n, cout, 2 * h, 2 * w)
         scale, shift = self._affine(cout, bn, None, half)
-        for py in (0, 1):
-            for px in (0, 1):
-                packed = self._pack(deconv.weight, cout, cin, 2, True, py, px, half)
-                d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=2, kw=2, stride=1, pad_top=1 - py,
-                                  pad_left=1 - px, conv_h=h, conv_w=w, out_h=2 * h, out_w=2 * w, out_mul=2, out_rep=1,
-                                  out_off_y=py, out_off_x=px, relu=int(relu), flags=0)
-                if half:
-                    v = tune_conv_variant(self.lib, d, x, packed, scale, shift, None, None, out, half=True)
-                    _lib.check(self.lib.mp_plan_add_conv_f16(self.handle, ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed),
-                                                             _lib.ptr(scale), _lib.ptr(shift), None, None, _lib.ptr(out)),
-                               "mp_plan_add_conv_f16(deconv phase)")
-                else:
-                    v = tune_conv_variant(self.lib, d, x, packed, scale, shift, None, None, out)
-                    _lib.check(self.lib.mp_plan_add_conv_variant(self.handle, ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed),
-                                                                 _lib.ptr(scale), _lib.ptr(shift), None, None, _lib.ptr(out)),
-                               "mp_plan_add_conv_variant(deconv phase)")
-                self.layer_info.append(dict(kind="deconv_phase_f16" if half else "deconv_phase", k=2, stride=1, cin=cin, cout=cout, h=h, w=w, n=n,
-                                            macs=n * h * w * cout * cin * 4))
+
+        def desc(py, px):
+            return _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=2, kw=2, stride=1, pad_top=1 - py, pad_left=1 - px, conv_h=h,
+                                 conv_w=w, out_h=2 * h, out_w=2 * w, out_mul=2, out_rep=1, out_off_y=py, out_off_x=px, relu=int(relu),
+                                 flags=0)
+
+        phases = [(py, px) for py in (0, 1) for px in (0, 1)]
+        macs = n * h * w * cout * cin * 4
+        if half:
+            for py, px in phases:
+                packed = self._pack(deconv.weight, cout, cin, 2, True, py, px, True)
+                d = desc(py, px)
+                v = tune_conv_variant(self.lib, d, x, packed, scale, shift, None, None, out, half=True)
+                _lib.check(self.lib.mp_plan_add_conv_f16(self.handle, ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed),
+                                                         _lib.ptr(scale), _lib.ptr(shift), None, None, _lib.ptr(out)),
+                           "mp_plan_add_conv_f16(deconv phase)")
+                self.layer_info.append(dict(kind="deconv_phase_f16", k=2, stride=1, cin=cin, cout=cout, h=h, w=w, n=n, macs=macs))
+            return out
+        # fp32: the four phase packings back to back in one buffer (the one-launch form reads them as slices)
+        key = (id(deconv.weight), "deconv4")
+        if key not in self._packed:
+            wsrc = deconv.weight.detach().to(self.device, torch.float32).contiguous()
+            per = self.lib.mp_conv_packed_weight_bytes(cout, cin, 2, 2) // 4
+            buf = torch.empty(4 * per, device=self.device, dtype=torch.float32)
+            for i, (py, px) in enumerate(phases):
+                _lib.check(self.lib.mp_conv_pack_weight(_lib.ptr(wsrc), _lib.ptr(buf[i * per:(i + 1) * per]), cout, cin, 2, 2, 1, py, px,
+                                                        _lib.stream()), "mp_conv_pack_weight(deconv phase)")
+            self.keep += [wsrc, buf]
+            self._packed[key] = buf
+        buf = self._packed[key]
+        per = buf.numel() // 4
+        slices = [buf[i * per:(i + 1) * per] for i in range(4)]
+        descs = [desc(py, px) for py, px in phases]
+        variants = [tune_conv_variant(self.lib, d, x, pk, scale, shift, None, None, out) for d, pk in zip(descs, slices)]
+        fused = False
+        if os.environ.get("MINDPOSE_AUTOTUNE", "1") != "0" and self.lib.mp_deconv4x4s2_gemm_supported(ctypes.byref(descs[0])) == 0:
+            stream = _lib.stream()
+
+            def launch(form):
+                if form == 1:
+                    return self.lib.mp_deconv4x4s2_gemm_fwd(ctypes.byref(descs[0]), _lib.ptr(x), _lib.ptr(buf), _lib.ptr(scale),
+                                                            _lib.ptr(shift), _lib.ptr(out), stream)
+                rc = 0
+                for d, pk, v in zip(descs, slices, variants):
+                    rc = rc or self.lib.mp_conv2d_fwd_variant(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(pk), _lib.ptr(scale),
+                                                              _lib.ptr(shift), None, None, _lib.ptr(out), stream)
+                return rc
+
+            tkey = ("deconv4x4s2",) + tuple(getattr(descs[0], f) for f, _ in descs[0]._fields_) + (str(out.device),)
+            fused = _autotune(tkey, 4 * macs, 2, launch) == 1
+        if fused:
+            _lib.check(self.lib.mp_plan_add_deconv4x4s2_gemm(self.handle, ctypes.byref(descs[0]), _lib.ptr(x), _lib.ptr(buf),
+                                                             _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(out)),
+                       "mp_plan_add_deconv4x4s2_gemm")
+            self.layer_info.append(dict(kind="deconv_gemm", k=2, stride=1, cin=cin, cout=cout, h=h, w=w, n=n, macs=4 * macs))
+            return out
+        for d, pk, v in zip(descs, slices, variants):
+            _lib.check(self.lib.mp_plan_add_conv_variant(self.handle, ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(pk),
+                                                         _lib.ptr(scale), _lib.ptr(shift), None, None, _lib.ptr(out)),
+                       "mp_plan_add_conv_variant(deconv phase)")
+            self.layer_info.append(dict(kind="deconv_phase", k=2, stride=1, cin=cin, cout=cout, h=h, w=w, n=n, macs=macs))
         return out
 
     def fuse_sum(self, base: torch.Tensor, terms, out: torch.Tensor, relu: bool = True) -> torch.Tensor:

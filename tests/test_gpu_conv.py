@@ -472,3 +472,45 @@ def test_simplebaseline_whole_network_tuned_forms_vs_library_heuristic(monkeypat
     top2 = b.reshape(n, k, -1).topk(2, dim=2).values
     safe = (top2[..., 0] - top2[..., 1]) > 1e-4 * span
     assert torch.equal(a.reshape(n, k, -1).argmax(2)[safe], b.reshape(n, k, -1).argmax(2)[safe])
+
+
+@pytest.mark.parametrize("ni", ["1", "2", "11"])
+@pytest.mark.parametrize("case", [(3, 64, 256, 8, 6), (2, 32, 128, 16, 12), (5, 16, 100, 4, 4)], ids=lambda c: f"n{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}")
+def test_deconv_all_phases_in_one_gemm_launch(case, ni, monkeypatch):
+    """mp_deconv4x4s2_gemm_fwd: the four sub-pixel phases of Conv2dTranspose(k=4, s=2, p=1) + scale / shift + ReLU as ONE launch (phase =
+    grid dimension, the four phase packings back to back) - against conv_transpose2d in fp64, and bit-identical to the four
+    per-phase launches of the same kernel."""
+    import ctypes
+    from mindpose_amd import _lib
+    monkeypatch.setenv("MP_GEMM_NI", ni)
+    n, cin, cout, h, w = case
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(cin + cout + h + 1)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cin, cout, 4, 4, generator=g) * (2.0 / (cin * 4)) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ref = F.relu(F.conv_transpose2d(x.double(), wt.double(), stride=2, padding=1) * scale.double()[None, :, None, None]
+                 + shift.double()[None, :, None, None])
+    st = _lib.stream()
+    xd, wd, sc, sh = x.to(DEV), wt.to(DEV), scale.to(DEV), shift.to(DEV)
+    per = lib.mp_conv_packed_weight_bytes(cout, cin, 2, 2) // 4
+    buf = torch.empty(4 * per, device=DEV)
+    out1 = torch.full((n, cout, 2 * h, 2 * w), float("nan"), device=DEV)
+    out4 = torch.full((n, cout, 2 * h, 2 * w), float("nan"), device=DEV)
+    descs = []
+    for i, (py, px) in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
+        _lib.check(lib.mp_conv_pack_weight(_lib.ptr(wd), _lib.ptr(buf[i * per:(i + 1) * per]), cout, cin, 2, 2, 1, py, px, st), "pack phase")
+        descs.append(_lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=2, kw=2, stride=1, pad_top=1 - py, pad_left=1 - px, conv_h=h, conv_w=w,
+                                   out_h=2 * h, out_w=2 * w, out_mul=2, out_rep=1, out_off_y=py, out_off_x=px, relu=1, flags=0))
+    assert lib.mp_deconv4x4s2_gemm_supported(ctypes.byref(descs[0])) == 0
+    _lib.check(lib.mp_deconv4x4s2_gemm_fwd(ctypes.byref(descs[0]), _lib.ptr(xd), _lib.ptr(buf), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(out1), st),
+               "one launch")
+    for i, d in enumerate(descs):
+        _lib.check(lib.mp_conv2d_fwd_variant(ctypes.byref(d), 10, _lib.ptr(xd), _lib.ptr(buf[i * per:(i + 1) * per]), _lib.ptr(sc), _lib.ptr(sh),
+                                             None, None, _lib.ptr(out4), st), "phase launch")
+    torch.cuda.synchronize()
+    assert torch.isfinite(out1).all()
+    assert _nerr(out1.double().cpu(), ref) <= 2e-5
+    assert torch.equal(out1, out4)
+    # only the phase (0, 0) descriptor of the k=4 / s=2 / p=1 recipe is taken
+    assert lib.mp_deconv4x4s2_gemm_supported(ctypes.byref(descs[1])) == -3
