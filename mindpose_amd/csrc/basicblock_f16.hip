@@ -276,11 +276,10 @@ __global__ __launch_bounds__(256, 2) void basicblock_f16_kernel(const BlockF16Pa
 template <int PS1, int PS2>
 int launch_block(const BlockF16Params& p, size_t lds_bytes, hipStream_t s) {
     auto kern = basicblock_f16_kernel<PS1, PS2>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static AttrOnce attr_set_once;
+    if (attr_set_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(256), lds_bytes, s, p);
     return check_launch();
@@ -324,7 +323,7 @@ int blockf16_build(const void* x, const void* w1, const float* scale1, const flo
     p.tiles_total = p.tiles_y * n;
     // persistent workgroups: two per CU walk runs of tiles, the next tile's rows in flight under the current MFMA loops
     int groups = 512;
-    if (const char* e = getenv("MP_F16_BLOCK_GROUPS")) {  // tests: force long tile runs on small problems
+    if (const char* e = knob("MP_F16_BLOCK_GROUPS")) {  // tests: force long tile runs on small problems
         const int v = atoi(e);
         if (v >= 1) groups = v;
     }

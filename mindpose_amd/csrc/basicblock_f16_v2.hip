@@ -311,11 +311,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void basicblock_f16_v2_kernel(const 
 template <int WAVES, int PS1, int PS2>
 int launch_block_v2(const BlockF16Params& p, size_t lds_bytes, hipStream_t s) {
     auto kern = basicblock_f16_v2_kernel<WAVES, PS1, PS2>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static AttrOnce attr_set_once;
+    if (attr_set_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(WAVES * 64), lds_bytes, s, p);
     return check_launch();
@@ -326,7 +325,7 @@ int launch_block_v2(const BlockF16Params& p, size_t lds_bytes, hipStream_t s) {
 // geometry of the second structure; false = shape not covered (the first kernel serves it)
 bool blockf16_v2_build(const void* x, const void* w1, const float* scale1, const float* shift1, const void* w2, const float* scale2,
                        const float* shift2, void* out, int n, int c, int h, int w, int rows, BlockF16Launch& L) {
-    if (const char* e = getenv("MP_F16_BLOCK_V2"))
+    if (const char* e = knob("MP_F16_BLOCK_V2"))
         if (atoi(e) == 0) return false;
     if (c <= 24 || c > 32 || x == out) return false;
     if ((size_t)n * 4 * h * w * 16 > 0x7FFFFFF0u) return false;
@@ -338,7 +337,7 @@ bool blockf16_v2_build(const void* x, const void* w1, const float* scale1, const
     // (PS1 = 5, PS2 = 3: up to 4 rows of 48) - two independent workgroups drift out of phase, so one's epilogues / DMA issue run
     // beside the other's MFMA loops instead of in lockstep with its SIMD partner (MP_F16_BLOCK_SHAPE selects; measured 26.6 us against 23.3 us for shape 0 at N = 128: default 0)
     int shape = 0;
-    if (const char* e = getenv("MP_F16_BLOCK_SHAPE")) shape = atoi(e) ? 1 : 0;
+    if (const char* e = knob("MP_F16_BLOCK_SHAPE")) shape = atoi(e) ? 1 : 0;
     const int waves = shape ? 4 : 8, PS1 = shape ? 5 : 4, PS2 = 3;
     int best = 0;
     for (int R = (rows > 0 ? rows : (shape ? 4 : 8)); R >= 1; --R) {
@@ -360,7 +359,7 @@ bool blockf16_v2_build(const void* x, const void* w1, const float* scale1, const
     p.tiles_y = (h + best - 1) / best;
     p.tiles_total = p.tiles_y * n;
     int groups = shape ? 512 : 256;  // workgroups resident at once
-    if (const char* e = getenv("MP_F16_BLOCK_GROUPS")) {  // tests: force long tile runs on small problems
+    if (const char* e = knob("MP_F16_BLOCK_GROUPS")) {  // tests: force long tile runs on small problems
         const int v = atoi(e);
         if (v >= 1) groups = v;
     }

@@ -136,7 +136,7 @@ static const int kLdsMax = 150 * 1024;
 static int lds_budget() {
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("MP_CONV_LDS_KB");
+        const char* e = knob("MP_CONV_LDS_KB");
         int kb = e ? atoi(e) : 0;
         v = (kb >= 16 && kb <= 150) ? kb * 1024 : 78 * 1024;
     }
@@ -189,7 +189,7 @@ static bool configure(const mp_conv_desc& d, int variant, ConvLaunch& L) {
     const bool light = variant_light(variant) && KS <= 3;
     const int nw = stage_nw(KS, light), ni = stage_ni(KS, light, p.vec != 0);
     // three workgroups per CU for the light variants (160 KiB / 3), two otherwise
-    const int budget = (light && !getenv("MP_CONV_LDS_KB")) ? 52 * 1024 : lds_budget();
+    const int budget = (light && !knob("MP_CONV_LDS_KB")) ? 52 * 1024 : lds_budget();
     int best_ck = 0;
     for (int ck = 4; ck <= p.Cin_pad4 && ck <= 128; ck += 4) {
         if (p.Cin_pad4 % ck) continue;

@@ -309,11 +309,10 @@ constexpr int f16_occ(bool light) { return light ? 3 : 2; }
 template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, bool LIGHT>
 int launch_f16_variant(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
     auto kern = conv_f16_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, f16_ni(KS, LIGHT), f16_nw(KS, LIGHT), f16_occ(LIGHT)>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static AttrOnce attr_set_once;
+    if (attr_set_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(256), lds_bytes, s, p);
     return check_launch();
@@ -337,11 +336,10 @@ int launch_f16_ks(const ConvF16Params& p, int variant, size_t lds_bytes, hipStre
         case F_CT32_PT384: {
             if (p.n_chunks != 1) return MP_ERR_UNSUPPORTED;
             auto kern = conv_f16_kernel<KS, S, 6, 2, 4, 1, f16_ni(KS, false), f16_nw(KS, false), 2, true>;
-            static bool attr_set = false;
-            if (!attr_set) {
+            static AttrOnce attr_set_once;
+            if (attr_set_once.need()) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 (void)hipGetLastError();
-                attr_set = true;
             }
             hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(256), lds_bytes, s, p);
             return check_launch();
@@ -411,7 +409,7 @@ bool f16_configure_mt(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
     p.tiles_n = (p.N + p.G - 1) / p.G;
     p.tiles_total = p.tiles_y * p.tiles_n;
     int max_groups = occ * 256 / p.n_ct;
-    if (const char* e = getenv("MP_F16_MT_GROUPS")) {  // tests: force long tile runs on small problems
+    if (const char* e = knob("MP_F16_MT_GROUPS")) {  // tests: force long tile runs on small problems
         const int v = atoi(e);
         if (v >= 1) max_groups = v;
     }

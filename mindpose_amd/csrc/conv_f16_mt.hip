@@ -271,11 +271,10 @@ constexpr int mt_ni(int occ) { return occ == 1 ? 12 : 8; }
 template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, int OCC>
 int launch_mt_variant(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
     auto kern = conv_f16_mt_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, mt_ni(OCC), OCC>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static AttrOnce attr_set_once;
+    if (attr_set_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(256), lds_bytes, s, p);
     return check_launch();

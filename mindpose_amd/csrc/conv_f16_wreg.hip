@@ -237,11 +237,10 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
 template <int KS, int S, int PS, int CSW, int WAVES_P, int OCC>
 int launch_wreg(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
     auto kern = conv_f16_wreg_kernel<KS, S, PS, CSW, WAVES_P, OCC>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static AttrOnce attr_set_once;
+    if (attr_set_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(256), lds_bytes, s, p);
     return check_launch();

@@ -258,7 +258,7 @@ int gemm_configure(const mp_conv_desc* d, GemmLaunch& L) {
     const long long t128 = (long long)((p.Cout_pad16 + kTM - 1) / kTM) * ((p.cols + kTN - 1) / kTN);
     L.ni = t128 >= 512 ? 2 : 1;
     L.mi = t128 >= 192 ? 2 : 1;
-    if (const char* e = getenv("MP_GEMM_NI")) {  // experiments / tests: 1, 2 = column blocks per wave; 11 = 64 x 64 tiles
+    if (const char* e = knob("MP_GEMM_NI")) {  // experiments / tests: 1, 2 = column blocks per wave; 11 = 64 x 64 tiles
         if (atoi(e) == 1 || atoi(e) == 2) { L.ni = atoi(e); L.mi = 2; }
         if (atoi(e) == 11) { L.ni = 1; L.mi = 1; }
     }
@@ -285,7 +285,7 @@ int gemm_configure_deconv(const mp_conv_desc* d, GemmLaunch& L) {
     const long long t128 = 4LL * ((p.Cout_pad16 + kTM - 1) / kTM) * ((p.cols + kTN - 1) / kTN);
     L.ni = t128 >= 512 ? 2 : 1;
     L.mi = t128 >= 192 ? 2 : 1;
-    if (const char* e = getenv("MP_GEMM_NI")) {
+    if (const char* e = knob("MP_GEMM_NI")) {
         if (atoi(e) == 1 || atoi(e) == 2) { L.ni = atoi(e); L.mi = 2; }
         if (atoi(e) == 11) { L.ni = 1; L.mi = 1; }
     }

@@ -555,11 +555,10 @@ constexpr int stage_occ(bool light) { return light ? 3 : 2; }
 template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, bool VEC, bool LIGHT>
 int launch_variant(const ConvKParams& p, size_t lds_bytes, hipStream_t s) {
     auto kern = conv_mfma_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, stage_ni(KS, LIGHT, VEC), stage_nw(KS, LIGHT), VEC, stage_occ(LIGHT)>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static AttrOnce attr_set_once;
+    if (attr_set_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(256), lds_bytes, s, p);
     return check_launch();

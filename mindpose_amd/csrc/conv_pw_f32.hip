@@ -179,7 +179,7 @@ int pw_configure(const mp_conv_desc* d, PwLaunch& L) {
     p.N = d->n; p.Cin = d->cin; p.Cout = d->cout; p.Cout_pad16 = (d->cout + 15) / 16 * 16; p.HW = hw;
     p.tiles = d->n * (hw / kPT);
     int wgs = 512;  // two persistent workgroups per CU
-    if (const char* e = getenv("MP_PW_WGS")) {
+    if (const char* e = knob("MP_PW_WGS")) {
         const int v = atoi(e);
         if (v >= 1) wgs = v;
     }

@@ -324,7 +324,7 @@ static int wgrad_geometry(const mp_conv_desc* d, WgradParams& p, size_t& lds_byt
     int R = 192 / p.Wo;
     if (R < 1) R = 1;
     if (R > p.Ho) R = p.Ho;
-    p.vec = ((p.W & 3) == 0 && (p.Wo & 3) == 0 && d->kh != 4 && !getenv("MP_WGRAD_SIMPLE")) ? 1 : 0;
+    p.vec = ((p.W & 3) == 0 && (p.Wo & 3) == 0 && d->kh != 4 && !knob("MP_WGRAD_SIMPLE")) ? 1 : 0;
     if (p.vec) {
         // pipelined kernel: double-buffered tiles; R limited by the per-thread staging registers (NZ = 6, NX = 9
         // 16-B units) and by 2 workgroups per CU (<= 78 KiB LDS)
@@ -407,22 +407,20 @@ int mp_conv_wgrad(const mp_conv_desc* desc, const float* x, const float* dz, flo
 #define MP_WGRAD_LAUNCH(KS_, S_)                                                                                        \
     do {                                                                                                                \
         auto kern = conv_wgrad_kernel<KS_, S_>;                                                                         \
-        static bool attr = false;                                                                                       \
-        if (!attr) {                                                                                                    \
+        static AttrOnce attr_once;                                                                                       \
+        if (attr_once.need()) {                                                                                                    \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             (void)hipGetLastError();                                                                                    \
-            attr = true;                                                                                                \
         }                                                                                                               \
         hipLaunchKernelGGL(kern, grid, block, lds, s, p);                                                               \
     } while (0)
 #define MP_WGRAD_LAUNCH_PIPE(KS_, S_)                                                                                   \
     do {                                                                                                                \
         auto kern = conv_wgrad_pipe_kernel<KS_, S_, 6, 9>;                                                              \
-        static bool attr = false;                                                                                       \
-        if (!attr) {                                                                                                    \
+        static AttrOnce attr_once;                                                                                       \
+        if (attr_once.need()) {                                                                                                    \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             (void)hipGetLastError();                                                                                    \
-            attr = true;                                                                                                \
         }                                                                                                               \
         hipLaunchKernelGGL(kern, grid, block, lds, s, p);                                                               \
     } while (0)

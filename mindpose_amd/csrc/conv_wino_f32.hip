@@ -544,7 +544,7 @@ int wino_configure(const mp_conv_desc* d, WinoLaunch& L) {
         const long long wgs2 = (long long)((p.Cout_pad16 + 63) / 64) * ((d->h + 2 * tr - 1) / (2 * tr)) * d->n;
         if (wgs2 >= 256) L.teams = 2;
     }
-    if (const char* e = getenv("MP_WINO_TEAMS")) {  // experiments
+    if (const char* e = knob("MP_WINO_TEAMS")) {  // experiments
         if (atoi(e) == 1) L.teams = 1;
         if (atoi(e) == 2 && !L.group) L.teams = 2;
     }
@@ -585,7 +585,7 @@ int wino_configure(const mp_conv_desc* d, WinoLaunch& L) {
     p.tiles_per_wg = p.total_blocks / (512 / L.teams);
     if (p.tiles_per_wg < 1) p.tiles_per_wg = 1;
     if (p.tiles_per_wg > 8) p.tiles_per_wg = 8;
-    if (const char* e = getenv("MP_WINO_TILES")) {  // experiments
+    if (const char* e = knob("MP_WINO_TILES")) {  // experiments
         const int v = atoi(e);
         if (v >= 1 && v <= 64) p.tiles_per_wg = v;
     }
@@ -603,11 +603,10 @@ int wino_launch(const WinoLaunch& L0, hipStream_t s) {
     WinoLaunch L = L0;
     L.p.dbg = conv_stamp_buffer((size_t)L.p.total_blocks * 64);
     auto go = [&](auto kern) {
-        static bool attr = false;
-        if (!attr) {
+        static AttrOnce attr_once;
+        if (attr_once.need()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipGetLastError();
-            attr = true;
         }
         hipLaunchKernelGGL(kern, dim3((L.p.total_blocks + L.p.tiles_per_wg - 1) / L.p.tiles_per_wg), dim3(256 * L.teams), L.lds_bytes, s, L.p);
         return check_launch();

@@ -4,8 +4,8 @@
 // Reference: tools/train.py:43-49 (data_parallel, gradients_mean=True: MindSpore all-reduces every gradient each step),
 // tools/train.py:170-181 (DynamicLossScaleManager: overflow check, skip + halve), optim/optim_factory.py:69-72 (AdamWeightDecay).
 //
-// RCCL is bound at run time (dlsym on the copy the process already holds - PyTorch ships its own librccl - else
-// dlopen("librccl.so.1")): the library has no link-time dependency on it and single-GPU users never load it.
+// RCCL is bound at run time (the copy the process already holds - PyTorch ships its own librccl - found with RTLD_NOLOAD; the
+// system library only when none is loaded): the library has no link-time dependency on it and single-GPU users never load it.
 #include <dlfcn.h>
 
 #include "common.h"
@@ -67,8 +67,14 @@ Rccl& rccl() {
         Rccl t;
         void* h = nullptr;
         if (dlsym(RTLD_DEFAULT, "ncclAllReduce") == nullptr) {
-            h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-            if (h == nullptr) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            // PyTorch links its own librccl.so (SONAME librccl.so.1) and Python loads it RTLD_LOCAL, so the symbols are not in the
+            // global scope: RTLD_NOLOAD hands out THAT copy by soname.  A second RCCL in the process (two sets of IPC state, two
+            // proxy threads per communicator) is never created: only when no copy is loaded at all - a C caller without PyTorch -
+            // the system library is loaded.
+            h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+            if (h == nullptr) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+            if (h == nullptr) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+            if (h == nullptr) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
         }
         void* scope = h ? h : RTLD_DEFAULT;
         t.GetUniqueId = reinterpret_cast<decltype(t.GetUniqueId)>(dlsym(scope, "ncclGetUniqueId"));

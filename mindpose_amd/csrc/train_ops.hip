@@ -856,7 +856,7 @@ static unsigned long long* coop_slot_for(hipStream_t s) {
 // HRNet-W32 amp-O2 step at N = 128: threshold 0 / 256 K / 512 K / 1 M -> 36.06 / 35.31 / 35.04 / 36.64 ms
 static unsigned long long* bn16_coop_plan(int n, int c8, int hw, hipStream_t s, int& nsplit) {
     static const long long max_elems = [] {
-        const char* e = getenv("MP_BN16_COOP_MAX");  // 0 switches the one-launch form off
+        const char* e = knob("MP_BN16_COOP_MAX");  // 0 switches the one-launch form off
         return e ? atoll(e) : (1LL << 19);
     }();
     if ((long long)n * c8 * hw > max_elems || c8 > kCoopMaxGrid) return nullptr;

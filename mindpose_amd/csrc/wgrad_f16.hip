@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dma_k4s2(const Wgrad16P
 // LDS-DMA form of the same decomposition: two buffers of [4][xslots] + [4][zslots] elements; false = does not fit (the
 // register-staged kernel serves the shape).  MP_WGRAD16_DMA=0 switches it off (A/B).
 bool geometry_dma(Wgrad16Params& p, int KS, int S, size_t& lds_bytes) {
-    if (const char* e = getenv("MP_WGRAD16_DMA"))
+    if (const char* e = knob("MP_WGRAD16_DMA"))
         if (atoi(e) == 0) return false;
     for (int pass = 0; pass < 2; ++pass) {
         const size_t budget = pass == 0 ? 78 * 1024 : 150 * 1024;
@@ -452,7 +452,7 @@ int geometry(const mp_conv_desc* d, Wgrad16Params& p, size_t& lds_bytes) {
     p.ci_tiles = (p.Cin + 31) / 32;
     const int ct = ((p.Cout + 31) / 32) * p.ci_tiles;
     int target = 512;  // two workgroups per CU; the slab reduce reads splits x |dW| floats, so no finer than that
-    if (const char* e = getenv("MP_WGRAD16_WGS")) {  // experiments: total workgroups per launch
+    if (const char* e = knob("MP_WGRAD16_WGS")) {  // experiments: total workgroups per launch
         const int v = atoi(e);
         if (v >= 1) target = v;
     }
@@ -471,11 +471,10 @@ int launch_wgrad16_dma(const Wgrad16Params& p, size_t lds, hipStream_t s) {
     auto kern = KS == 4 ? conv_wgrad_f16_dma_k4s2
                         : KS == 3 ? (S == 1 ? conv_wgrad_f16_dma_k3s1 : conv_wgrad_f16_dma_k3s2)
                                   : (S == 1 ? conv_wgrad_f16_dma_k1s1 : conv_wgrad_f16_dma_k1s2);
-    static bool attr = false;
-    if (!attr) {
+    static AttrOnce attr_once;
+    if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
-        attr = true;
     }
     hipLaunchKernelGGL(kern, dim3(((p.Cout + 31) / 32) * p.ci_tiles, p.splits), dim3(256), lds, s, p);
     return check_launch();
@@ -485,11 +484,10 @@ template <int KS, int S>
 int launch_wgrad16(const Wgrad16Params& p, size_t lds, hipStream_t s) {
     if (p.pieces > 0) return launch_wgrad16_dma<KS, S>(p, lds, s);
     auto kern = conv_wgrad_f16_kernel<KS, S, kNZ, kNX>;
-    static bool attr = false;
-    if (!attr) {
+    static AttrOnce attr_once;
+    if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
-        attr = true;
     }
     hipLaunchKernelGGL(kern, dim3(((p.Cout + 31) / 32) * p.ci_tiles, p.splits), dim3(256), lds, s, p);
     return check_launch();

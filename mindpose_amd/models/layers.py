@@ -69,9 +69,24 @@ def _tune_file() -> Optional[str]:
     return os.environ.get("MINDPOSE_TUNE_CACHE") or None
 
 
+_BUILD_ID = None
+
+
 def _tune_stamp() -> str:
-    """Variant indices only mean something for one build of the kernels on one architecture."""
-    return f"{_lib.load().mp_version().decode()}|gfx950"
+    """Variant indices only mean something for one BUILD of the kernels: the stamp carries the library's version string and a
+    digest of the shared object itself (a rebuilt kernel invalidates the persisted choices without a hand-bumped version)."""
+    global _BUILD_ID
+    if _BUILD_ID is None:
+        import hashlib
+        h = hashlib.sha1()
+        try:
+            with open(_lib.LIB_PATH, "rb") as f:
+                for block in iter(lambda: f.read(1 << 20), b""):
+                    h.update(block)
+            _BUILD_ID = h.hexdigest()[:16]
+        except OSError:
+            _BUILD_ID = "unknown"
+    return f"{_lib.load().mp_version().decode()}|{_BUILD_ID}"
 
 
 def _tune_load() -> None:
@@ -92,10 +107,35 @@ def _tune_load() -> None:
         pass
 
 
+def _dist_rank_world():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except Exception:
+        pass
+    return 0, 1
+
+
+def _sync_choice(choice: int) -> int:
+    """Ranks of one job must run the SAME form of every layer (the candidates differ numerically: Winograd vs direct, one GEMM
+    launch vs four phase convs) - rank 0's choice, tuned or read from its cache, is broadcast and every rank adopts it.  All ranks
+    build the same network, so they reach this point for the same keys in the same order.  ``MINDPOSE_TUNE_SYNC=0`` turns the
+    broadcast off (ranks that build different plans)."""
+    rank, world = _dist_rank_world()
+    if world == 1 or os.environ.get("MINDPOSE_TUNE_SYNC", "1") == "0":
+        return choice
+    import torch.distributed as dist
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([int(choice)], dtype=torch.int64, device=dev)
+    dist.broadcast(t, src=0)
+    return int(t.item())
+
+
 def _tune_save() -> None:
-    """Whole-file replace through a temporary (ranks of one job share the path; a torn file would silently drop the cache)."""
+    """Whole-file replace through a temporary (a torn file would silently drop the cache); rank 0 is the only writer of a job."""
     path = _tune_file()
-    if not path:
+    if not path or _dist_rank_world()[0] != 0:
         return
     try:
         import json
@@ -135,9 +175,12 @@ def _autotune(key, macs, n_variants, launch) -> int:
     key = repr(key)
     hit = _TUNE_CACHE.get(key)
     if hit is not None:
+        if macs >= (1 << 26) and ("synced", key) not in _TUNE_CACHE:  # first use in this process: agree with rank 0 (no-op on one rank)
+            hit = _TUNE_CACHE[key] = _sync_choice(hit)
+            _TUNE_CACHE[("synced", key)] = 1
         return hit
     best, best_t = -1, None
-    if macs >= (1 << 26):
+    if macs >= (1 << 26) and _dist_rank_world()[0] == 0:
         for v in range(n_variants):
             if launch(v) != 0:
                 continue
@@ -153,6 +196,9 @@ def _autotune(key, macs, n_variants, launch) -> int:
                 t = dt if t is None or dt < t else t
             if best_t is None or t < best_t:
                 best, best_t = v, t
+    if macs >= (1 << 26):
+        best = _sync_choice(best)
+        _TUNE_CACHE[("synced", key)] = 1
     _TUNE_CACHE[key] = best
     if macs >= (1 << 26):
         _tune_save()

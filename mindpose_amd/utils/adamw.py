@@ -66,6 +66,10 @@ class _ArenaOptimizer:
     def zero_grad(self) -> None:
         self.grads.begin_step()
 
+    def close(self) -> None:
+        """Release the gradient averager's hooks and communicator (call before ``destroy_process_group``)."""
+        self.grads.close()
+
     def step(self, loss_scale_manager=None) -> bool:
         """All-reduce (mean) the gradients, then one streaming update per decay group.
 

@@ -26,7 +26,13 @@ import torch.distributed as dist
 
 
 class NativeComm:
-    """``mp_comm_*``: an RCCL communicator owned by libmindpose_hip.so, one per process group."""
+    """``mp_comm_*``: an RCCL communicator owned by libmindpose_hip.so, one per process group.
+
+    Ordering against ``torch.distributed``'s own communicator (EvalCallback's loss all-reduce, ``broadcast_object_list``): a native
+    collective is enqueued on this object's stream AFTER everything on the caller's current stream (``wait_stream``), and its
+    consumer waits for the returned event on the current stream; torch's collectives order themselves against the current stream the
+    same way.  Two collectives of the two communicators are therefore never in flight together as long as each is waited for
+    (synchronous torch calls, ``GradientAverager.finish()``) before the next is issued - what every caller in this package does."""
 
     def __init__(self, device: torch.device, process_group=None) -> None:
         from .. import _lib
@@ -64,9 +70,20 @@ class NativeComm:
         return ev
 
     def close(self) -> None:
+        """ncclCommDestroy (after the communicator's stream has drained); idempotent."""
         if self.handle:
+            try:
+                self.stream.synchronize()
+            except Exception:
+                pass
             self.lib.mp_comm_destroy(self.handle)
             self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class _EventHandle:
@@ -195,3 +212,22 @@ class GradientAverager:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+
+    def close(self) -> None:
+        """Tear-down: pending collectives are waited for, hooks removed, the library's own communicator destroyed
+        (``ncclCommDestroy``) - the owner (the arena optimizers' ``close()``) calls this before the process group goes away."""
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        self.remove_hooks()
+        if self.native is not None:
+            self.native.close()
+            self.native = None
+            self.active = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "native", None) is not None:
+                self.native.close()
+        except Exception:
+            pass

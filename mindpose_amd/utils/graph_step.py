@@ -52,6 +52,7 @@ class GraphedTrainStep:
             join_wgrad_lanes(dev)
         set_branch_streams(prev_branch_streams)
         set_wgrad_lanes(prev_wgrad_lanes)
+        self._planned = [m for m in net_with_loss.modules() if hasattr(m, "_plans")]  # walked once, not per step
 
     def __call__(self, *inputs: torch.Tensor) -> torch.Tensor:
         """Copy the batch into the static buffers, replay the graph, run the optimizer; returns the (static) loss tensor."""
@@ -67,7 +68,6 @@ class GraphedTrainStep:
             # a replay never passes through PlannedModule.forward, which is what drops recorded inference plans in training
             # mode: without this an evaluation between graphed steps would replay packed weights / folded BatchNorm of an
             # earlier parameter state
-            for m in self.nwl.modules():
-                if hasattr(m, "_plans"):
-                    m._plans.clear()
+            for m in self._planned:
+                m._plans.clear()
         return self.static_loss

@@ -25,8 +25,9 @@ class Allreduce:
 
 class AverageMeter:
     """val / sum / count / avg of a stream of values (misc.py:19-36).  Values may be scalars or small tensors (a loss with
-    several items); they are accumulated in fp64 on the host, so `update` of a CUDA scalar costs one synchronising read - call it
-    with a detached loss once per step, as the reference's callback does."""
+    several items).  Like the reference's meter, the running sum lives where the values live: a CUDA loss is accumulated ON THE
+    DEVICE in fp64 (two tiny asynchronous kernels per update, no read-back), so a per-step `update` never stalls the host behind
+    the graphed / overlapped training step; the one synchronising read happens when somebody looks at `avg` (once per epoch)."""
 
     def __init__(self) -> None:
         self.reset()
@@ -38,8 +39,8 @@ class AverageMeter:
         self.count = 0.0
 
     def update(self, val: Union[float, torch.Tensor], n: int = 1) -> None:
-        v = torch.as_tensor(val).detach().to("cpu", torch.float64)
+        v = torch.as_tensor(val).detach().to(torch.float64)  # stays on the value's device
         self.val = v
-        self.sum = self.sum + v * n
+        self.sum = (self.sum.to(v.device) if self.sum.device != v.device else self.sum) + v * n
         self.count += n
         self.avg = self.sum / self.count

@@ -4,6 +4,8 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the library honours its MP_* experiment knobs (forced tile runs / forms) only in processes that ask for them (csrc/common.h)
+os.environ.setdefault("MINDPOSE_EXPERIMENT_KNOBS", "1")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

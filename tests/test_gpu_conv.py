@@ -153,6 +153,8 @@ def test_reference_shape_tests():
     ("hrnet_w48", "hrnet_head", (1, 3, 128, 96)),
     ("resnet50", "simple_baseline_head", (2, 3, 256, 192)),
     ("resnet50", "simple_baseline_head", (1, 3, 64, 64)),
+    ("resnet101", "simple_baseline_head", (2, 3, 64, 64)),   # resnet.py:298-340: layers [3, 4, 23, 3] / [3, 8, 36, 3]
+    ("resnet152", "simple_baseline_head", (2, 3, 64, 64)),
 ])
 def test_network_heatmaps_vs_oracle(backbone, head, shape):
     net = _net(backbone, head)

@@ -1,0 +1,127 @@
+"""The plan the benchmark times, held to the oracle (VERDICT r2 "what's weak" 2 / 3).
+
+`bench.py` runs N = 128 with the per-shape tuner on and four execution lanes; the oracle comparisons of test_gpu_conv.py run at
+N <= 3, where the tuner picks other forms (one-team Winograd, other GEMM tiles).  Outputs are per-image independent, so the
+N = 128 plan is built exactly as bench.py builds it and images [0:4] + [124:128] are compared with `oracle/nets.py`
+(1e-3 of the heat-map scale + arg-max equality wherever the oracle's top-1 / top-2 margin exceeds that tolerance).
+
+Reproducibility: the tuner chooses between numerically different algorithms (Winograd vs direct, one GEMM launch vs four phase
+convs) from timings, so heat-map BITS depend on its choices.  `MINDPOSE_TUNE_CACHE=<file>` pins them: a second, fresh process
+replaying the same file must produce bit-identical heat maps.
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import mindpose_amd as mp  # noqa: E402
+from oracle import nets as onets  # noqa: E402
+
+DEV = torch.device("cuda:0")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N = 128
+SLICE = list(range(0, 4)) + list(range(N - 4, N))
+
+
+def _bench_like_batch(n, h, w, seed=1000):
+    """bench.py's synthetic crops: randn from a CPU generator seeded 1000 + rank."""
+    return torch.randn(n, 3, h, w, generator=torch.Generator(device="cpu").manual_seed(seed))
+
+
+def _check_slice(got, ref, tol):
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err < tol, f"normalised max error {err}"
+    n, k = got.shape[:2]
+    rf = ref.reshape(n, k, -1)
+    top2 = rf.topk(2, dim=2).values
+    safe = (top2[..., 0] - top2[..., 1]) > 2.0 * tol * ref.abs().max()
+    assert safe.float().mean() > 0.5
+    assert torch.equal(got.reshape(n, k, -1).argmax(2)[safe], rf.argmax(2)[safe])
+    return err
+
+
+@pytest.mark.parametrize("backbone,head", [("hrnet_w32", "hrnet_head"), ("resnet50", "simple_baseline_head")])
+def test_headline_plan_n128_fp32_vs_oracle(backbone, head):
+    net = mp.init_synthetic(mp.create_network(backbone, head), seed=0).to(DEV).eval()
+    x = _bench_like_batch(N, 256, 192)
+    image = net.input_buffer((N, 3, 256, 192), DEV)  # as bench.py: crops written straight into the plan's input buffer
+    image.copy_(x)
+    got = net(image)[SLICE].cpu()
+    plan = net.get_plan((N, 3, 256, 192), DEV)
+    kinds = {e["kind"] for e in plan.layer_info}
+    assert "conv_winograd" in kinds  # the tuned plan of the benchmark, not the small-batch forms
+    if backbone == "hrnet_w32":
+        assert "barrier" in kinds  # four execution lanes
+    params = {k: v.cpu() for k, v in net.state_dict().items()}
+    ref = onets.net_forward(params, x[SLICE], backbone, head)
+    _check_slice(got, ref, 1e-3)
+
+
+def test_headline_plan_n128_amp_o2_vs_amp_oracle():
+    net = mp.init_synthetic(mp.create_network("hrnet_w32", "hrnet_head"), seed=0).to(DEV).eval()
+    mp.models.auto_mixed_precision(net, "O2")
+    x = _bench_like_batch(N, 256, 192)
+    image = net.input_buffer((N, 3, 256, 192), DEV)
+    image.copy_(x)
+    got = net(image)[SLICE].cpu()
+    params = {k: v.cpu() for k, v in net.state_dict().items()}
+    ref32 = onets.net_forward(params, x[SLICE], "hrnet_w32", "hrnet_head")
+    ref16 = onets.net_forward(params, x[SLICE], "hrnet_w32", "hrnet_head", amp=True)
+    e_hip = float((got - ref32).abs().max() / ref32.abs().max())
+    e_emul = float((ref16 - ref32).abs().max() / ref32.abs().max())
+    # one rounding per stored tensor here, one per cell in the reference's amp O2: not further from fp32 than the emulation (x1.5)
+    assert e_hip <= 1.5 * e_emul + 1e-3, f"HIP fp16 {e_hip} vs op-by-op amp-O2 emulation {e_emul}"
+    assert e_hip < 2e-2
+    n, k = got.shape[:2]
+    rf = ref32.reshape(n, k, -1)
+    top2 = rf.topk(2, dim=2).values
+    safe = (top2[..., 0] - top2[..., 1]) > 2.5 * e_hip * ref32.abs().max()
+    assert safe.float().mean() > 0.5
+    assert torch.equal(got.reshape(n, k, -1).argmax(2)[safe], rf.argmax(2)[safe])
+
+
+_CHILD = r"""
+import hashlib, json, sys, torch
+sys.path.insert(0, {root!r})
+import mindpose_amd as mp
+from mindpose_amd.models import layers
+dev = torch.device("cuda:0")
+net = mp.init_synthetic(mp.create_network("hrnet_w32", "hrnet_head"), seed=0).to(dev).eval()
+x = torch.randn(16, 3, 256, 192, generator=torch.Generator().manual_seed(7)).to(dev)
+hm = net(x).cpu().contiguous()
+plan = net.get_plan(x.shape, dev)
+print(json.dumps(dict(sha=hashlib.sha256(hm.numpy().tobytes()).hexdigest(),
+                      kinds=[e["kind"] for e in plan.layer_info],
+                      tuned=len([k for k in layers._TUNE_CACHE if isinstance(k, str)]))))
+"""
+
+
+def _run_child(env):
+    proc = subprocess.run([sys.executable, "-c", _CHILD.format(root=ROOT)], env=env, stdout=subprocess.PIPE, text=True, timeout=600)
+    assert proc.returncode == 0
+    return json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_persisted_tune_cache_reproduces_heatmap_bits(tmp_path):
+    """Two fresh processes sharing one MINDPOSE_TUNE_CACHE file: the first tunes and writes it, the second replays it without a
+    trial launch; same plan forms, heat maps equal bit for bit."""
+    cache = tmp_path / "tune.json"
+    env = dict(os.environ, MINDPOSE_TUNE_CACHE=str(cache))
+    first = _run_child(env)
+    assert cache.exists()
+    doc = json.loads(cache.read_text())
+    assert doc["choices"] and "stamp" in doc
+    second = _run_child(env)
+    assert second["kinds"] == first["kinds"]
+    assert second["sha"] == first["sha"], "heat maps differ between two processes replaying one tune cache"
+    # and the switch for bit-reproducible runs WITHOUT a cache: no timing decides anything
+    env0 = dict(os.environ, MINDPOSE_AUTOTUNE="0")
+    env0.pop("MINDPOSE_TUNE_CACHE", None)
+    a, b = _run_child(env0), _run_child(env0)
+    assert a["sha"] == b["sha"] and a["tuned"] == 0

@@ -141,6 +141,13 @@ def test_o2_training_step_vs_oracle_amp_emulation():
           f"{cos(all_hip, all_amp):.5f}, vs fp32 {cos(all_hip, all_f32):.5f} (emulation vs fp32 {cos(all_amp, all_f32):.5f}); "
           f"per-tensor vs emulation median {np.median(list(c_amp.values())):.5f} min {min(c_amp.values()):.4f}")
     assert cos(all_hip, all_amp) > 0.98 and np.median(list(c_amp.values())) > 0.99 and min(c_amp.values()) > 0.9
+    # per-tensor floor 0.97 (measured minimum 0.9736: BatchNorm parameters of the deepest layers, whose gradient is a
+    # small difference of large sums - the emulation itself sits that far from the fp32 gradient on them)
+    low = sorted((k for k in got if c_amp[k] < 0.98), key=lambda k: c_amp[k])
+    for k in low[:8]:
+        print(f"  lowest: {k} numel {got[k].numel()} cos(hip, emu) {c_amp[k]:.4f} cos(hip, f32) {c_hip_f32[k]:.4f} "
+              f"cos(emu, f32) {c_emu_f32[k]:.4f}")
+    assert min(c_amp.values()) > 0.97
     # distance to the fp32 gradients: not worse than the op-by-op emulation of the reference's recipe
     assert 1 - cos(all_hip, all_f32) <= 1.5 * (1 - cos(all_amp, all_f32)) + 1e-4
     assert np.median([1 - c for c in c_hip_f32.values()]) <= 1.5 * np.median([1 - c for c in c_emu_f32.values()]) + 1e-4

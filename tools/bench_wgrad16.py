@@ -2,6 +2,7 @@
 """fp16 weight-gradient kernel: LDS-DMA form vs the register-staged form on the HRNet layer shapes.
    python tools/bench_wgrad16.py [N]"""
 import ctypes, os, statistics, sys
+os.environ.setdefault("MINDPOSE_EXPERIMENT_KNOBS", "1")  # the MP_* knobs below are honoured only then
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mindpose_amd import _lib
