@@ -346,9 +346,10 @@ class CallTimer:
     per-kernel-family device time of an eager training step.  The entries are wrapped on the loaded library object, which is
     what the host mirror calls through, and restored afterwards."""
 
-    CONV = ("mp_f16_conv2d_fwd", "mp_conv2d_fwd_variant", "mp_conv2d_fwd", "mp_conv2d_winograd_fwd")
+    CONV = ("mp_f16_conv2d_fwd", "mp_f16_conv2d_fwd_stats", "mp_conv2d_fwd_variant", "mp_conv2d_fwd", "mp_conv2d_winograd_fwd")
     WGRAD = ("mp_f16_conv_wgrad", "mp_conv_wgrad")
-    BN = ("mp_f16_bn_train_fwd", "mp_f16_bn_train_bwd", "mp_bn_train_fwd", "mp_bn_train_bwd_acc", "mp_bn_train_bwd")
+    BN = ("mp_f16_bn_train_fwd", "mp_f16_bn_train_bwd", "mp_f16_bn_train_fwd_stats", "mp_f16_bn_train_bwd_stats", "mp_bn_train_fwd",
+          "mp_bn_train_bwd_acc", "mp_bn_train_bwd")
     OTHER = ("mp_f16_fuse_upsample_sum", "mp_f16_fuse_upsample_sum_bwd", "mp_fuse_upsample_sum", "mp_fuse_upsample_sum_bwd",
              "mp_f16_to_c8", "mp_f16_from_c8", "mp_f16_pack_weight_batch", "mp_conv_pack_weight_batch", "mp_f16_pack_weight",
              "mp_conv_pack_weight", "mp_joints_mse_fwd", "mp_joints_mse_bwd", "mp_gaussian_target", "mp_adamw_step_scaled",
@@ -383,12 +384,16 @@ class CallTimer:
         if name in CallTimer.CONV + CallTimer.WGRAD:
             d = args[0]._obj  # ctypes.byref(mp_conv_desc)
             flops = 2.0 * d.n * d.conv_h * d.conv_w * d.cout * d.cin * d.kh * d.kw
-            variant = args[1] if name in ("mp_f16_conv2d_fwd", "mp_conv2d_fwd_variant") else (9 if name == "mp_conv2d_winograd_fwd" else None)
+            variant = args[1] if name in ("mp_f16_conv2d_fwd", "mp_f16_conv2d_fwd_stats", "mp_conv2d_fwd_variant") else (
+                9 if name == "mp_conv2d_winograd_fwd" else None)
             return dict(flops=flops, shape=f"{d.kh}x{d.kw} s{d.stride} {d.cin}->{d.cout} @{d.h}x{d.w} N={d.n}", variant=variant,
                         ks=d.kh, stride=d.stride)
         if name in CallTimer.BN:
-            fwd = name.endswith("fwd")
             half = "f16" in name
+            if name == "mp_f16_bn_train_bwd_stats":  # apply pass only: read g, z; write dz (g, z, gamma, mean, invstd, dz, ... n, c, hw at 10..12)
+                n, c, hw = args[10:13]
+                return dict(bytes=3.0 * n * c * hw * 2, shape=f"C={c} HW={hw} N={n}")
+            fwd = name.endswith("fwd") or name.endswith("fwd_stats")
             # positional layout of the BatchNorm entries (include/mindpose_hip.h): fwd (z,g,b,res,y,...,n,c,hw at 9..11);
             # bwd (dy,z,y,g,mean,invstd,dz,dres,...) with n,c,hw after the pointer block
             if fwd:
@@ -477,7 +482,7 @@ def train_roofline(eager_step, half):
     if d["flops"]:
         shapes = d["shapes"]
         top = max(shapes, key=lambda k: shapes[k]["time"])
-        name = (f16_kernel_for if "f16" in dom else f32_kernel_for)(top[2], top[3], top[1]) if dom in CallTimer.CONV else (
+        name = (f16_kernel_for if "f16" in dom else f32_kernel_for)(top[2], top[3], top[1] if top[1] is None or top[1] >= 0 else None) if dom in CallTimer.CONV else (
             f"conv_wgrad_f16_kernel<{top[2]},{top[3]}>" if "f16" in dom else f"conv_wgrad_pipe_kernel<{top[2]},{top[3]}>")
         t = shapes[top]
         ach = t["flops"] / t["time"] / 1e12

@@ -430,6 +430,50 @@ int mp_f16_bn_train_bwd(const void* dy_dev, const void* z_dev, const void* y_dev
 int mp_f16_fuse_upsample_sum_bwd(const void* dy_dev, const void* out_dev, void* dbase_dev, void* dt1_dev, int s1, void* dt2_dev,
                                  int s2, void* dt3_dev, int s3, int n, int c, int h, int w, int relu, mp_stream_t stream);
 
+/* ---- BatchNorm fused out of the amp-O2 training step (round 3) ------------------------------------------------------------------
+ * Reference: every conv of mindpose/models/backbones/hrnet.py:51-64 is followed by nn.BatchNorm2d, trained under amp O2
+ * (tools/train.py:170-181).  MindSpore runs conv, the batch-statistics reduction and the normalisation as separate cells; here the
+ * conv launch that PRODUCES a tensor also produces the per-channel partial sums its BatchNorm needs, so the reduction passes
+ * over the tensor disappear in both directions:
+ *   mode 1 (forward):  the launch computes z = conv(x); partials of  sum z, sum z*z  over the fp16-rounded output.
+ *   mode 2 (backward): the launch computes the gradient dy reaching a BatchNorm's OUTPUT (a stride-1 data-gradient conv; res1 = the
+ *                      residual gradient, as in mp_f16_conv2d_fwd).  z_dev = that BatchNorm's input, y_dev its output (relu != 0:
+ *                      mask = y > 0), both in the output geometry.  The tensor STORED is g = dy * mask, and the partials are
+ *                      sum g, sum g * z (raw z: the consumer forms sum g * xhat = invstd * (sum g z - mean * sum g) in fp64).
+ *                      Kernel 1x1 or 3x3, plain output mapping.  mean / invstd / gamma / beta of the struct are unused by the conv.
+ * partials: fp32 [ceil(cout/8)][n_parts][8][2], n_parts = mp_f16_conv_stats_parts(desc, variant) (one slot per pixel-tile workgroup;
+ * variant -1 = the library's deterministic choice, the same in both calls; 0 = this variant / shape has no statistics build: use
+ * the plain entry + the reduction passes).  Fixed summation order, no
+ * atomics: bit-reproducible.  The conv output is bit-identical to mp_f16_conv2d_fwd's (mode 2: times the mask). */
+typedef struct mp_f16_conv_stats {
+    int mode, relu;
+    float* partials_dev;
+    size_t partials_bytes;
+    const void* z_dev;
+    const void* y_dev;
+    const float* mean_dev;
+    const float* invstd_dev;
+    const float* gamma_dev;
+    const float* beta_dev;
+} mp_f16_conv_stats;
+int mp_f16_conv_stats_parts(const mp_conv_desc* desc, int variant);
+int mp_f16_conv2d_fwd_stats(const mp_conv_desc* desc, int variant, const void* x_c8_dev, const void* packed_w_dev,
+                            const float* scale_dev, const float* shift_dev, const void* res1_c8_dev, void* out_c8_dev,
+                            const mp_f16_conv_stats* stats, mp_stream_t stream);
+/* The consumers.  mp_f16_bn_train_fwd_stats: mp_f16_bn_train_fwd without its reduction pass (statistics from the mode-1 partials;
+ * one launch: every workgroup folds the partials of its 8 channels itself, in a fixed order; above 512 slots a small fold
+ * launch runs first).  mp_f16_bn_train_bwd_stats: dy_dev is the PRE-MASKED gradient g a mode-2 launch stored;
+ *   dz = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat));  the residual branch's gradient is g itself (no dres tensor).
+ * workspace: mp_bn_workspace_bytes(c). */
+int mp_f16_bn_train_fwd_stats(const void* z_dev, const float* gamma_dev, const float* beta_dev, const void* res_dev, void* y_dev,
+                              float* save_mean_dev, float* save_invstd_dev, float* moving_mean_dev, float* moving_var_dev, int n,
+                              int c, int hw, float eps, float momentum, int relu, const float* partials_dev, int n_parts,
+                              void* workspace_dev, size_t workspace_bytes, mp_stream_t stream);
+int mp_f16_bn_train_bwd_stats(const void* g_dev, const void* z_dev, const float* gamma_dev, const float* save_mean_dev,
+                              const float* save_invstd_dev, void* dz_dev, float* dgamma_dev, float* dbeta_dev, float* dgamma_acc_dev,
+                              float* dbeta_acc_dev, int n, int c, int hw, const float* partials_dev, int n_parts,
+                              void* workspace_dev, size_t workspace_bytes, mp_stream_t stream);
+
 /* out = a + b (+ c) (+ d) over `bytes` bytes (a multiple of 16) of fp32 (half = 0) or fp16 (half = 1, fp32 sums, one rounding):
  * the fan-in of gradients at a tensor with several consumers - every branch output of an HRModule feeds every exchange-unit row
  * (hrnet.py:318-344) - in one pass instead of the framework's k - 1 pairwise adds.  out may alias an input. */

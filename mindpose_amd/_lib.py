@@ -26,6 +26,13 @@ class ConvDesc(ctypes.Structure):
         "out_h", "out_w", "out_mul", "out_rep", "out_off_y", "out_off_x", "relu", "flags")]
 
 
+class ConvStats(ctypes.Structure):
+    """``mp_f16_conv_stats`` of include/mindpose_hip.h (BatchNorm partial sums from a conv launch's epilogue)."""
+    _fields_ = [("mode", ctypes.c_int), ("relu", ctypes.c_int), ("partials", ctypes.c_void_p), ("partials_bytes", ctypes.c_size_t),
+                ("z", ctypes.c_void_p), ("y", ctypes.c_void_p), ("mean", ctypes.c_void_p), ("invstd", ctypes.c_void_p),
+                ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p)]
+
+
 class MindposeHipError(RuntimeError):
     pass
 
@@ -109,6 +116,11 @@ _PROTOTYPES = {
     "mp_f16_to_c8": (c_int, [c_f32p, c_f32p] + [c_int] * 4 + [ctypes.c_void_p]),
     "mp_f16_from_c8": (c_int, [c_f32p, c_f32p] + [c_int] * 4 + [ctypes.c_void_p]),
     "mp_f16_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_int] + [c_f32p] * 7 + [ctypes.c_void_p]),
+    "mp_f16_conv_stats_parts": (c_int, [ctypes.POINTER(ConvDesc), c_int]),
+    "mp_f16_conv2d_fwd_stats": (c_int, [ctypes.POINTER(ConvDesc), c_int] + [c_f32p] * 6 + [ctypes.POINTER(ConvStats), ctypes.c_void_p]),
+    "mp_f16_bn_train_fwd_stats": (c_int, [c_f32p] * 9 + [c_int] * 3 + [ctypes.c_float, ctypes.c_float, c_int, c_f32p, c_int, c_f32p,
+                                          c_size_t, ctypes.c_void_p]),
+    "mp_f16_bn_train_bwd_stats": (c_int, [c_f32p] * 10 + [c_int] * 3 + [c_f32p, c_int, c_f32p, c_size_t, ctypes.c_void_p]),
     "mp_optimizer_step": (c_int, [c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_size_t, ctypes.c_float,
                                   ctypes.c_float, ctypes.c_float, ctypes.POINTER(ctypes.c_float * 5), ctypes.c_void_p]),
     "mp_f16_basicblock_fwd": (c_int, [c_f32p] * 8 + [c_int] * 5 + [ctypes.c_void_p]),

@@ -38,6 +38,12 @@ struct ConvF16Params {
     int ni_used, nw_used;  // staging slots (of the kernel's NI / NW) that carry data for this shape: the rest are skipped
     unsigned magic_rows;       // / (G * Rin)
     int step_rows, step_cols;  // 256 staging units = step_rows whole rows + step_cols columns (slot-to-slot stepping)
+    // BatchNorm statistics from the epilogue (training; conv_f16_dev.h): 0 = off, 1 = forward sums of the output, 2 = backward sums
+    // of the masked gradient (the stored tensor is then the masked gradient)
+    int st_mode, st_nparts, st_relu;
+    float* st_part;        // [C8out][st_nparts][8][2] fp32
+    const void* st_z;      // mode 2: the BatchNorm's input (output geometry, c8 halfs)
+    const void* st_y;      // mode 2, st_relu == 1: the BatchNorm's output (mask = y > 0)
 };
 
 struct ConvF16Launch {
@@ -102,6 +108,8 @@ int blockf16_v2_launch(const BlockF16Launch& L, hipStream_t s);
 int f16_build_launch(const mp_conv_desc* desc, int variant, const void* x, const void* w, const float* scale,
                      const float* shift, const void* res1, const void* res2, void* out, ConvF16Launch& L);
 int f16_launch(const ConvF16Launch& L, hipStream_t s);
+// partial-sum slots (per channel) a launch with epilogue statistics writes: one per pixel-tile workgroup / persistent workgroup
+int f16_stats_parts(const ConvF16Launch& L);
 void f16_variant_dims(int v, int& ct, int& pt);
 int f16_mt_launch(const ConvF16Launch& L, hipStream_t s);
 bool f16_configure_wreg(const mp_conv_desc& d, int variant, ConvF16Launch& L);

@@ -22,7 +22,8 @@ namespace {
 
 // ONE_CHUNK: the build for layers whose whole K fits one chunk (the 32-channel layers): no chunk loop, so the staging
 // registers are dead before the MFMA loop and a wave can own six pixel tiles instead of three
-template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, int NI, int NW, int OCC, bool ONE_CHUNK = false>
+// STATS: the training build whose epilogue also produces the partial BatchNorm sums of conv_f16_dev.h (p.st_mode 1 / 2)
+template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, int NI, int NW, int OCC, bool ONE_CHUNK = false, int STATS = 0>
 __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params p) {
     static_assert(WAVES_P * WAVES_C == 4, "4 waves per workgroup");
     constexpr int T = KS * KS;
@@ -43,6 +44,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
     }
     const int ct = b % p.n_ct;
     b /= p.n_ct;
+    const int part_idx = b;  // pixel tile = partial-sum slot of the epilogue statistics
     const int ty = b % p.tiles_y, tn = b / p.tiles_y;
     const int n0 = tn * p.G, y0 = ty * p.R;
     const int y_in0 = y0 * S - p.pad_t;
@@ -278,6 +280,34 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
             for (int ps = 0; ps < PS; ++ps) r2s[ps] = __builtin_amdgcn_raw_buffer_load_b64(rs, co_off[CS - 1] + pix_off[ps], 0, 0);
         }
     }
+    // epilogue statistics, backward mode: the BatchNorm's z (and y) at the output positions, fetched like the residuals
+    f32x4 st_a[STATS ? CS : 1], st_b[STATS ? CS : 1];
+    u32x4 zp[(STATS && NP) ? NP : 1][PS], yp[(STATS && NP) ? NP : 1][PS];
+    u32x2 zs[PS], ys[PS];
+    if constexpr (STATS) {
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs) {
+            st_a[cs] = st_b[cs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if constexpr (STATS == 2) {
+            const __amdgpu_buffer_rsrc_t rz = make_rsrc(reinterpret_cast<const char*>(p.st_z) + grp, grp_bytes);
+            const __amdgpu_buffer_rsrc_t ry = make_rsrc(reinterpret_cast<const char*>(p.st_y ? p.st_y : p.st_z) + grp, p.st_y ? grp_bytes : 0);
+#pragma unroll
+            for (int j = 0; j < NP; ++j)
+#pragma unroll
+                for (int ps = 0; ps < PS; ++ps) {
+                    zp[j][ps] = __builtin_amdgcn_raw_buffer_load_b128(rz, co_off[2 * j] + pix_off[ps], 0, 0);
+                    yp[j][ps] = __builtin_amdgcn_raw_buffer_load_b128(ry, co_off[2 * j] + pix_off[ps], 0, 0);
+                }
+            if (NS) {
+#pragma unroll
+                for (int ps = 0; ps < PS; ++ps) {
+                    zs[ps] = __builtin_amdgcn_raw_buffer_load_b64(rz, co_off[CS - 1] + pix_off[ps], 0, 0);
+                    ys[ps] = __builtin_amdgcn_raw_buffer_load_b64(ry, co_off[CS - 1] + pix_off[ps], 0, 0);
+                }
+            }
+        }
+    }
     compute(p.nbuf == 2 ? ((p.n_chunks - 1) & 1) : 0);
 
     // ---- epilogue: scale/shift, residuals (fetched before the MFMA loop), ReLU, one rounding, 16-byte stores per tile pair
@@ -287,18 +317,37 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
 #pragma unroll
         for (int ps = 0; ps < PS; ++ps) {
             const u32x4 a1 = has1 ? r1p[j][ps] : (u32x4){0u, 0u, 0u, 0u}, a2 = has2 ? r2p[j][ps] : (u32x4){0u, 0u, 0u, 0u};
-            const u32x2 lo = f16_pack4(f16_epi4(acc[ps][2 * j], sc[2 * j], sh[2 * j], has1, (u32x2){a1.x, a1.y}, has2, (u32x2){a2.x, a2.y}, p.relu));
-            const u32x2 hi = f16_pack4(f16_epi4(acc[ps][2 * j + 1], sc[2 * j + 1], sh[2 * j + 1], has1, (u32x2){a1.z, a1.w}, has2, (u32x2){a2.z, a2.w}, p.relu));
+            u32x2 lo = f16_pack4(f16_epi4(acc[ps][2 * j], sc[2 * j], sh[2 * j], has1, (u32x2){a1.x, a1.y}, has2, (u32x2){a2.x, a2.y}, p.relu));
+            u32x2 hi = f16_pack4(f16_epi4(acc[ps][2 * j + 1], sc[2 * j + 1], sh[2 * j + 1], has1, (u32x2){a1.z, a1.w}, has2, (u32x2){a2.z, a2.w}, p.relu));
+            if constexpr (STATS) {
+                const bool valid = pix_off[ps] != kInv;
+                if constexpr (STATS == 2) {
+                    const u32x4 zq = zp[j][ps], yq = yp[j][ps];
+                    f16_stats_acc<2>(lo, valid, st_a[2 * j], st_b[2 * j], (u32x2){zq.x, zq.y}, (u32x2){yq.x, yq.y}, p.st_relu);
+                    f16_stats_acc<2>(hi, valid, st_a[2 * j + 1], st_b[2 * j + 1], (u32x2){zq.z, zq.w}, (u32x2){yq.z, yq.w}, p.st_relu);
+                } else {
+                    f16_stats_acc<1>(lo, valid, st_a[2 * j], st_b[2 * j], lo, lo, 0);
+                    f16_stats_acc<1>(hi, valid, st_a[2 * j + 1], st_b[2 * j + 1], hi, hi, 0);
+                }
+            }
             __builtin_amdgcn_raw_buffer_store_b128((u32x4){lo.x, lo.y, hi.x, hi.y}, rs_o, co_off[2 * j] + pix_off[ps], 0, 0);
         }
     if (NS) {
 #pragma unroll
         for (int ps = 0; ps < PS; ++ps) {
-            const u32x2 o = f16_pack4(f16_epi4(acc[ps][CS - 1], sc[CS - 1], sh[CS - 1], has1, has1 ? r1s[ps] : (u32x2){0u, 0u}, has2,
-                                               has2 ? r2s[ps] : (u32x2){0u, 0u}, p.relu));
+            u32x2 o = f16_pack4(f16_epi4(acc[ps][CS - 1], sc[CS - 1], sh[CS - 1], has1, has1 ? r1s[ps] : (u32x2){0u, 0u}, has2,
+                                         has2 ? r2s[ps] : (u32x2){0u, 0u}, p.relu));
+            if constexpr (STATS) {
+                const bool valid = pix_off[ps] != kInv;
+                if constexpr (STATS == 2) f16_stats_acc<2>(o, valid, st_a[CS - 1], st_b[CS - 1], zs[ps], ys[ps], p.st_relu);
+                else f16_stats_acc<1>(o, valid, st_a[CS - 1], st_b[CS - 1], o, o, 0);
+            }
             __builtin_amdgcn_raw_buffer_store_b64(o, rs_o, co_off[CS - 1] + pix_off[ps], 0, 0);
         }
     }
+    if constexpr (STATS)
+        f16_stats_flush<CS, WAVES_P, WAVES_C>(st_a, st_b, reinterpret_cast<float*>(smem16), p.st_part, p.st_nparts, part_idx, ct * CT,
+                                              p.C8out, wp_i, wc_i, lq, lr);
 }
 
 // regular: big chunks, two workgroups per CU; light: small chunks / few staging registers, three per CU (<= 52 KiB LDS)
@@ -306,9 +355,13 @@ constexpr int f16_ni(int ks, bool light) { return light ? 5 : 10; }
 constexpr int f16_nw(int ks, bool light) { return light ? 5 : (ks == 3 ? 9 : 8); }  // ks 2 (deconv phases): 8
 constexpr int f16_occ(bool light) { return light ? 3 : 2; }
 
-template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, bool LIGHT>
-int launch_f16_variant(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
-    auto kern = conv_f16_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, f16_ni(KS, LIGHT), f16_nw(KS, LIGHT), f16_occ(LIGHT)>;
+// the training builds (epilogue statistics) exist for the kernel sizes a BatchNorm follows / a data gradient runs through: 1x1, 3x3
+constexpr bool f16_has_stats(int ks) { return ks == 1 || ks == 3; }
+
+template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, bool LIGHT, bool ONE_CHUNK, int STATS>
+int launch_f16_kernel(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
+    auto kern = conv_f16_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, f16_ni(KS, LIGHT), f16_nw(KS, LIGHT), ONE_CHUNK ? 2 : f16_occ(LIGHT),
+                                ONE_CHUNK, STATS>;
     static AttrOnce attr_set_once;
     if (attr_set_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -316,6 +369,18 @@ int launch_f16_variant(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) 
     }
     hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(256), lds_bytes, s, p);
     return check_launch();
+}
+
+template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, bool LIGHT, bool ONE_CHUNK = false>
+int launch_f16_variant(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
+    if (p.st_mode != 0) {
+        if constexpr (f16_has_stats(KS)) {
+            if (p.st_mode == 1) return launch_f16_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, LIGHT, ONE_CHUNK, 1>(p, lds_bytes, s);
+            if constexpr (S == 1) return launch_f16_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, LIGHT, ONE_CHUNK, 2>(p, lds_bytes, s);  // data gradients are stride-1 launches
+        }
+        return MP_ERR_UNSUPPORTED;
+    }
+    return launch_f16_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, LIGHT, ONE_CHUNK, 0>(p, lds_bytes, s);
 }
 
 template <int KS, int S>
@@ -333,17 +398,9 @@ int launch_f16_ks(const ConvF16Params& p, int variant, size_t lds_bytes, hipStre
         case F_CT32_PT96_L: return launch_f16_variant<KS, S, 3, 1, 2, 2, true>(p, lds_bytes, s);
         case F_CT16_PT192: return launch_f16_variant<KS, S, 3, 1, 4, 1, false>(p, lds_bytes, s);
         case F_CT16_PT192_L: return launch_f16_variant<KS, S, 3, 1, 4, 1, true>(p, lds_bytes, s);
-        case F_CT32_PT384: {
+        case F_CT32_PT384:
             if (p.n_chunks != 1) return MP_ERR_UNSUPPORTED;
-            auto kern = conv_f16_kernel<KS, S, 6, 2, 4, 1, f16_ni(KS, false), f16_nw(KS, false), 2, true>;
-            static AttrOnce attr_set_once;
-            if (attr_set_once.need()) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipGetLastError();
-            }
-            hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(256), lds_bytes, s, p);
-            return check_launch();
-        }
+            return launch_f16_variant<KS, S, 6, 2, 4, 1, false, true>(p, lds_bytes, s);
         default: return MP_ERR_UNSUPPORTED;
     }
 }
@@ -746,6 +803,11 @@ int f16_build_launch(const mp_conv_desc* desc, int variant, const void* x, const
     return MP_OK;
 }
 
+int f16_stats_parts(const ConvF16Launch& L) {
+    // tile / weights-in-registers kernels: one slot per pixel tile; persistent multi-tile kernel: one per workgroup run
+    return f16_variant_mt(L.variant) ? L.p.n_groups : L.p.tiles_y * L.p.tiles_n;
+}
+
 int f16_launch(const ConvF16Launch& L, hipStream_t s) {
     if (f16_variant_wreg(L.variant)) return f16_wreg_launch(L, s);
     if (f16_variant_mt(L.variant)) return f16_mt_launch(L, s);
@@ -816,6 +878,46 @@ int mp_f16_conv2d_fwd(const mp_conv_desc* desc, int variant, const void* x, cons
     ConvF16Launch L{};
     int rc = f16_build_launch(desc, variant, x, packed_w, scale, shift, res1, res2, out, L);
     if (rc != MP_OK) return rc;
+    return f16_launch(L, as_stream(stream));
+}
+
+static bool f16_stats_shape_ok(const mp_conv_desc* d) {
+    return (d->kh == 1 || d->kh == 3) && d->out_rep == 1;
+}
+
+int mp_f16_conv_stats_parts(const mp_conv_desc* desc, int variant) {
+    if (!desc || f16_validate(desc) != MP_OK || variant >= F_COUNT || !f16_stats_shape_ok(desc)) return 0;
+    ConvF16Launch L{};
+    // the launch geometry exactly as mp_f16_conv2d_fwd_stats builds it (variant < 0: the library's deterministic heuristic);
+    // the pointers only travel into the parameter block
+    const void* dummy = reinterpret_cast<const void*>(static_cast<uintptr_t>(16));
+    if (f16_build_launch(desc, variant, dummy, dummy, reinterpret_cast<const float*>(dummy), reinterpret_cast<const float*>(dummy), nullptr,
+                         nullptr, const_cast<void*>(dummy), L) != MP_OK)
+        return 0;
+    if (desc->kh == 2) return 0;
+    return f16_stats_parts(L);
+}
+
+int mp_f16_conv2d_fwd_stats(const mp_conv_desc* desc, int variant, const void* x, const void* packed_w, const float* scale,
+                            const float* shift, const void* res1, void* out, const mp_f16_conv_stats* st, mp_stream_t stream) {
+    if (!st || !st->partials_dev) return MP_ERR_NULL;
+    ConvF16Launch L{};
+    int rc = f16_build_launch(desc, variant, x, packed_w, scale, shift, res1, nullptr, out, L);
+    if (rc != MP_OK) return rc;
+    if (!f16_stats_shape_ok(desc)) return MP_ERR_UNSUPPORTED;
+    if (st->mode != 1 && st->mode != 2) return MP_ERR_UNSUPPORTED;
+    const int parts = f16_stats_parts(L);
+    if (st->partials_bytes < (size_t)L.p.C8out * parts * 16 * sizeof(float)) return MP_ERR_WORKSPACE;
+    L.p.st_mode = st->mode;
+    L.p.st_nparts = parts;
+    L.p.st_part = st->partials_dev;
+    if (st->mode == 2) {
+        if (!st->z_dev || (st->relu != 0 && !st->y_dev)) return MP_ERR_NULL;
+        if (desc->stride != 1 || desc->out_mul != 1 || desc->out_off_y != 0 || desc->out_off_x != 0) return MP_ERR_UNSUPPORTED;
+        L.p.st_relu = st->relu != 0 ? 1 : 0;
+        L.p.st_z = st->z_dev;
+        L.p.st_y = st->relu != 0 ? st->y_dev : nullptr;
+    }
     return f16_launch(L, as_stream(stream));
 }
 

@@ -11,7 +11,7 @@ namespace mp {
 
 namespace {
 
-template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, int NI, int OCC>
+template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, int NI, int OCC, int STATS = 0>
 __global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Params p) {
     static_assert(WAVES_P * WAVES_C == 4, "4 waves per workgroup");
     constexpr int T = KS * KS;
@@ -147,6 +147,18 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Para
     stage_store(0);
     __syncthreads();
 
+    // epilogue statistics (conv_f16_dev.h): the per-lane sums run over ALL tiles of the workgroup - one partial per workgroup
+    constexpr int NPz = CS / 2;
+    f32x4 st_a[STATS ? CS : 1], st_b[STATS ? CS : 1];
+    if constexpr (STATS) {
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs) {
+            st_a[cs] = st_b[cs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rs_z = make_rsrc((STATS && p.st_z) ? p.st_z : p.out, (STATS && p.st_z) ? o_bytes : 0);
+    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc((STATS && p.st_y) ? p.st_y : p.out, (STATS && p.st_y) ? o_bytes : 0);
+
     const int nq = p.PK >> 2;
     for (int t = t_begin; t < t_end; ++t) {
         const int buf = p.nbuf == 2 ? ((t - t_begin) & 1) : 0;
@@ -185,6 +197,27 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Para
             if (NS) {
 #pragma unroll
                 for (int ps = 0; ps < PS; ++ps) r2s[ps] = __builtin_amdgcn_raw_buffer_load_b64(rs_r2, co_off[CS - 1] + pix_off[ps], 0, 0);
+            }
+        }
+
+        u32x4 zp[(STATS && NPz) ? NPz : 1][PS], yp[(STATS && NPz) ? NPz : 1][PS];
+        u32x2 zs[PS], ys[PS];
+        if constexpr (STATS) {
+            if constexpr (STATS == 2) {  // the BatchNorm's z (and y) at this tile's output positions, fetched like the residuals
+#pragma unroll
+                for (int j = 0; j < NPz; ++j)
+#pragma unroll
+                    for (int ps = 0; ps < PS; ++ps) {
+                        zp[j][ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_z, co_off[2 * j] + pix_off[ps], 0, 0);
+                        yp[j][ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, co_off[2 * j] + pix_off[ps], 0, 0);
+                    }
+                if (CS & 1) {
+#pragma unroll
+                    for (int ps = 0; ps < PS; ++ps) {
+                        zs[ps] = __builtin_amdgcn_raw_buffer_load_b64(rs_z, co_off[CS - 1] + pix_off[ps], 0, 0);
+                        ys[ps] = __builtin_amdgcn_raw_buffer_load_b64(rs_y, co_off[CS - 1] + pix_off[ps], 0, 0);
+                    }
+                }
             }
         }
 
@@ -245,15 +278,31 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Para
 #pragma unroll
             for (int ps = 0; ps < PS; ++ps) {
                 const u32x4 a1 = has1 ? r1p[j][ps] : (u32x4){0u, 0u, 0u, 0u}, a2 = has2 ? r2p[j][ps] : (u32x4){0u, 0u, 0u, 0u};
-                const u32x2 lo = f16_pack4(f16_epi4(acc[ps][2 * j], sc[2 * j], sh[2 * j], has1, (u32x2){a1.x, a1.y}, has2, (u32x2){a2.x, a2.y}, p.relu));
-                const u32x2 hi = f16_pack4(f16_epi4(acc[ps][2 * j + 1], sc[2 * j + 1], sh[2 * j + 1], has1, (u32x2){a1.z, a1.w}, has2, (u32x2){a2.z, a2.w}, p.relu));
+                u32x2 lo = f16_pack4(f16_epi4(acc[ps][2 * j], sc[2 * j], sh[2 * j], has1, (u32x2){a1.x, a1.y}, has2, (u32x2){a2.x, a2.y}, p.relu));
+                u32x2 hi = f16_pack4(f16_epi4(acc[ps][2 * j + 1], sc[2 * j + 1], sh[2 * j + 1], has1, (u32x2){a1.z, a1.w}, has2, (u32x2){a2.z, a2.w}, p.relu));
+                if constexpr (STATS) {
+                    const bool valid = pix_off[ps] != kInv;
+                    if constexpr (STATS == 2) {
+                        const u32x4 zq = zp[j][ps], yq = yp[j][ps];
+                        f16_stats_acc<2>(lo, valid, st_a[2 * j], st_b[2 * j], (u32x2){zq.x, zq.y}, (u32x2){yq.x, yq.y}, p.st_relu);
+                        f16_stats_acc<2>(hi, valid, st_a[2 * j + 1], st_b[2 * j + 1], (u32x2){zq.z, zq.w}, (u32x2){yq.z, yq.w}, p.st_relu);
+                    } else {
+                        f16_stats_acc<1>(lo, valid, st_a[2 * j], st_b[2 * j], lo, lo, 0);
+                        f16_stats_acc<1>(hi, valid, st_a[2 * j + 1], st_b[2 * j + 1], hi, hi, 0);
+                    }
+                }
                 __builtin_amdgcn_raw_buffer_store_b128((u32x4){lo.x, lo.y, hi.x, hi.y}, rs_o, co_off[2 * j] + pix_off[ps], 0, 0);
             }
         if (NS) {
 #pragma unroll
             for (int ps = 0; ps < PS; ++ps) {
-                const u32x2 o = f16_pack4(f16_epi4(acc[ps][CS - 1], sc[CS - 1], sh[CS - 1], has1, has1 ? r1s[ps] : (u32x2){0u, 0u}, has2,
-                                                   has2 ? r2s[ps] : (u32x2){0u, 0u}, p.relu));
+                u32x2 o = f16_pack4(f16_epi4(acc[ps][CS - 1], sc[CS - 1], sh[CS - 1], has1, has1 ? r1s[ps] : (u32x2){0u, 0u}, has2,
+                                             has2 ? r2s[ps] : (u32x2){0u, 0u}, p.relu));
+                if constexpr (STATS) {
+                    const bool valid = pix_off[ps] != kInv;
+                    if constexpr (STATS == 2) f16_stats_acc<2>(o, valid, st_a[CS - 1], st_b[CS - 1], zs[ps], ys[ps], p.st_relu);
+                    else f16_stats_acc<1>(o, valid, st_a[CS - 1], st_b[CS - 1], o, o, 0);
+                }
                 __builtin_amdgcn_raw_buffer_store_b64(o, rs_o, co_off[CS - 1] + pix_off[ps], 0, 0);
             }
         }
@@ -264,13 +313,16 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Para
             __syncthreads();
         }
     }
+    if constexpr (STATS)  // the scratch lies over the weight slice (the flush's first barrier: every wave is past its last MFMA loop)
+        f16_stats_flush<CS, WAVES_P, WAVES_C>(st_a, st_b, reinterpret_cast<float*>(smem16), p.st_part, p.st_nparts, grp, ct * CT, p.C8out,
+                                              wp_i, wc_i, lq, lr);
 }
 
 constexpr int mt_ni(int occ) { return occ == 1 ? 12 : 8; }
 
-template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, int OCC>
-int launch_mt_variant(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
-    auto kern = conv_f16_mt_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, mt_ni(OCC), OCC>;
+template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, int OCC, int STATS>
+int launch_mt_kernel(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
+    auto kern = conv_f16_mt_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, mt_ni(OCC), OCC, STATS>;
     static AttrOnce attr_set_once;
     if (attr_set_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -278,6 +330,18 @@ int launch_mt_variant(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
     }
     hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(256), lds_bytes, s, p);
     return check_launch();
+}
+
+template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, int OCC>
+int launch_mt_variant(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
+    if (p.st_mode != 0) {  // training builds with epilogue statistics: the kernel sizes a BatchNorm follows
+        if constexpr (KS == 1 || KS == 3) {
+            if (p.st_mode == 1) return launch_mt_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, OCC, 1>(p, lds_bytes, s);
+            if constexpr (S == 1) return launch_mt_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, OCC, 2>(p, lds_bytes, s);
+        }
+        return MP_ERR_UNSUPPORTED;
+    }
+    return launch_mt_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, OCC, 0>(p, lds_bytes, s);
 }
 
 template <int KS, int S, int OCC>

@@ -28,7 +28,7 @@ namespace {
 // a quarter of the couts) streams each weight byte once per workgroup - the shape for the 128 - 384-channel layers whose weight
 // stream is what the vector-memory path carries; with fewer couts (64 / 32-channel layers) the pixel split keeps two cout tiles
 // per wave, i.e. half the LDS reads per MFMA, at the price of WAVES_P waves fetching the same (small) weight fragments.
-template <int KS, int S, int PS, int CSW, int WAVES_P, int OCC>
+template <int KS, int S, int PS, int CSW, int WAVES_P, int OCC, int STATS = 0>
 __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Params p) {
     constexpr int T = KS * KS;
     constexpr int HALO = KS / 2;
@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
     }
     const int ct = b % p.n_ct;
     b /= p.n_ct;
+    const int part_idx = b;  // pixel tile = partial-sum slot of the epilogue statistics
     const int ty = b % p.tiles_y, tn = b / p.tiles_y;
     const int n0 = tn * p.G, y0 = ty * p.R;
     const int HW = p.H * p.W;
@@ -210,6 +211,34 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
             }
         }
     }
+    // epilogue statistics (conv_f16_dev.h), backward mode: the BatchNorm's z (and y), fetched with the residual
+    f32x4 st_a[STATS ? CSW : 1], st_b[STATS ? CSW : 1];
+    u32x4 zp[(STATS && NP) ? NP : 1][PS], yp[(STATS && NP) ? NP : 1][PS];
+    u32x2 zs[PS], ys[PS];
+    if constexpr (STATS) {
+#pragma unroll
+        for (int cs = 0; cs < CSW; ++cs) {
+            st_a[cs] = st_b[cs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if constexpr (STATS == 2) {
+            const __amdgpu_buffer_rsrc_t rz = make_rsrc(p.st_z, o_bytes);
+            const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.st_y ? p.st_y : p.st_z, p.st_y ? o_bytes : 0);
+#pragma unroll
+            for (int j = 0; j < NP; ++j)
+#pragma unroll
+                for (int ps = 0; ps < PS; ++ps) {
+                    zp[j][ps] = __builtin_amdgcn_raw_buffer_load_b128(rz, co_off[2 * j] + pix_off[ps], 0, 0);
+                    yp[j][ps] = __builtin_amdgcn_raw_buffer_load_b128(ry, co_off[2 * j] + pix_off[ps], 0, 0);
+                }
+            if (NS) {
+#pragma unroll
+                for (int ps = 0; ps < PS; ++ps) {
+                    zs[ps] = __builtin_amdgcn_raw_buffer_load_b64(rz, co_off[CSW - 1] + pix_off[ps], 0, 0);
+                    ys[ps] = __builtin_amdgcn_raw_buffer_load_b64(ry, co_off[CSW - 1] + pix_off[ps], 0, 0);
+                }
+            }
+        }
+    }
     kstep(nq - 1, std::false_type{});
 
     // ---- epilogue: scale/shift, residuals, ReLU, one rounding, 16-byte stores per cout-tile pair
@@ -221,22 +250,41 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
         for (int ps = 0; ps < PS; ++ps) {
             const u32x4 a1 = has1 ? r1p[j][ps] : (u32x4){0u, 0u, 0u, 0u};
             const u32x4 a2 = has2 ? r2p[j][ps] : (u32x4){0u, 0u, 0u, 0u};
-            const u32x2 lo = f16_pack4(f16_epi4(acc[ps][2 * j], sc[2 * j], sh[2 * j], has1, (u32x2){a1.x, a1.y}, has2, (u32x2){a2.x, a2.y}, p.relu));
-            const u32x2 hi = f16_pack4(f16_epi4(acc[ps][2 * j + 1], sc[2 * j + 1], sh[2 * j + 1], has1, (u32x2){a1.z, a1.w}, has2, (u32x2){a2.z, a2.w}, p.relu));
+            u32x2 lo = f16_pack4(f16_epi4(acc[ps][2 * j], sc[2 * j], sh[2 * j], has1, (u32x2){a1.x, a1.y}, has2, (u32x2){a2.x, a2.y}, p.relu));
+            u32x2 hi = f16_pack4(f16_epi4(acc[ps][2 * j + 1], sc[2 * j + 1], sh[2 * j + 1], has1, (u32x2){a1.z, a1.w}, has2, (u32x2){a2.z, a2.w}, p.relu));
+            if constexpr (STATS) {
+                const bool valid = pix_off[ps] != kInv;
+                if constexpr (STATS == 2) {
+                    const u32x4 zq = zp[j][ps], yq = yp[j][ps];
+                    f16_stats_acc<2>(lo, valid, st_a[2 * j], st_b[2 * j], (u32x2){zq.x, zq.y}, (u32x2){yq.x, yq.y}, p.st_relu);
+                    f16_stats_acc<2>(hi, valid, st_a[2 * j + 1], st_b[2 * j + 1], (u32x2){zq.z, zq.w}, (u32x2){yq.z, yq.w}, p.st_relu);
+                } else {
+                    f16_stats_acc<1>(lo, valid, st_a[2 * j], st_b[2 * j], lo, lo, 0);
+                    f16_stats_acc<1>(hi, valid, st_a[2 * j + 1], st_b[2 * j + 1], hi, hi, 0);
+                }
+            }
             __builtin_amdgcn_raw_buffer_store_b128((u32x4){lo.x, lo.y, hi.x, hi.y}, rs_o, co_off[2 * j] + pix_off[ps], 0, 0);
         }
     if (NS) {
 #pragma unroll
         for (int ps = 0; ps < PS; ++ps) {
-            const u32x2 o = f16_pack4(f16_epi4(acc[ps][CSW - 1], sc[CSW - 1], sh[CSW - 1], has1, has1 ? r1s[ps] : none, has2, has2 ? r2s[ps] : none, p.relu));
+            u32x2 o = f16_pack4(f16_epi4(acc[ps][CSW - 1], sc[CSW - 1], sh[CSW - 1], has1, has1 ? r1s[ps] : none, has2, has2 ? r2s[ps] : none, p.relu));
+            if constexpr (STATS) {
+                const bool valid = pix_off[ps] != kInv;
+                if constexpr (STATS == 2) f16_stats_acc<2>(o, valid, st_a[CSW - 1], st_b[CSW - 1], zs[ps], ys[ps], p.st_relu);
+                else f16_stats_acc<1>(o, valid, st_a[CSW - 1], st_b[CSW - 1], o, o, 0);
+            }
             __builtin_amdgcn_raw_buffer_store_b64(o, rs_o, co_off[CSW - 1] + pix_off[ps], 0, 0);
         }
     }
+    if constexpr (STATS)
+        f16_stats_flush<CSW, WAVES_P, WAVES_C>(st_a, st_b, reinterpret_cast<float*>(smem16), p.st_part, p.st_nparts, part_idx, ct * CT,
+                                               p.C8out, wp_i, wc_i, lq, lr);
 }
 
-template <int KS, int S, int PS, int CSW, int WAVES_P, int OCC>
-int launch_wreg(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
-    auto kern = conv_f16_wreg_kernel<KS, S, PS, CSW, WAVES_P, OCC>;
+template <int KS, int S, int PS, int CSW, int WAVES_P, int OCC, int STATS>
+int launch_wreg_kernel(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
+    auto kern = conv_f16_wreg_kernel<KS, S, PS, CSW, WAVES_P, OCC, STATS>;
     static AttrOnce attr_set_once;
     if (attr_set_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -244,6 +292,16 @@ int launch_wreg(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
     }
     hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(256), lds_bytes, s, p);
     return check_launch();
+}
+
+template <int KS, int S, int PS, int CSW, int WAVES_P, int OCC>
+int launch_wreg(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
+    if (p.st_mode == 1) return launch_wreg_kernel<KS, S, PS, CSW, WAVES_P, OCC, 1>(p, lds_bytes, s);  // training builds: epilogue statistics
+    if (p.st_mode == 2) {
+        if constexpr (S == 1) return launch_wreg_kernel<KS, S, PS, CSW, WAVES_P, OCC, 2>(p, lds_bytes, s);
+        return MP_ERR_UNSUPPORTED;
+    }
+    return launch_wreg_kernel<KS, S, PS, CSW, WAVES_P, OCC, 0>(p, lds_bytes, s);
 }
 
 template <int KS, int S>

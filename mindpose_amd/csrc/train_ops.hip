@@ -592,6 +592,200 @@ __global__ __launch_bounds__(256) void bn16_bwd_apply_kernel(const u32x4_t* __re
     }
 }
 
+// ---- statistics from the conv epilogue (round 3): the apply passes alone -----------------------------------------------------------
+// The conv launch that produced z (forward) or the pre-masked gradient g (backward) left per-workgroup fp32 partial sums
+// pre[blk][n_parts][8 channels][2] (conv_f16_dev.h); the reduction launches above do not run at all.  A block of the apply
+// kernels folds the n_parts x 64 bytes of ITS channel block itself (contiguous: coalesced 16-byte loads, fp64 sums in a fixed
+// order, every block the same values), kMaxFoldParts slots at most - above that bn16_fold_kernel reduces them to one slot first.
+constexpr int kMaxFoldParts = 512;
+
+// totals of the 8 channels of block blk -> tot[16] = {sum0, sumsq0, sum1, ...} (fp64, LDS); ends with a barrier
+__device__ __forceinline__ void bn16_fold_parts(const float* __restrict__ pre, int blk, int n_parts, double* tot, double (*sm)[16]) {
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(pre + (size_t)blk * n_parts * 16);
+    const int q = threadIdx.x & 3, r = threadIdx.x >> 2;  // float4 q of slot r, r + 64, ...
+    float4 v[kMaxFoldParts / 64];
+#pragma unroll
+    for (int k = 0; k < kMaxFoldParts / 64; ++k) {
+        const int slot = r + 64 * k;
+        v[k] = slot < n_parts ? src[(size_t)slot * 4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < kMaxFoldParts / 64; ++k) {
+        a[0] += (double)v[k].x; a[1] += (double)v[k].y; a[2] += (double)v[k].z; a[3] += (double)v[k].w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        for (int off = 4; off <= 32; off <<= 1) a[i] += __shfl_xor(a[i], off, 64);  // over the 16 slot rows of the wave, q fixed
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sm[wave][lane * 4 + i] = a[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) tot[threadIdx.x] = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+    __syncthreads();
+}
+
+// n_parts > kMaxFoldParts: grid (C8), one block folds ALL slots of its channel block (fixed order) into slot 0 of `out`
+__global__ __launch_bounds__(256) void bn16_fold_kernel(const float* __restrict__ pre, float* __restrict__ out, int n_parts) {
+    const int blk = blockIdx.x;
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(pre + (size_t)blk * n_parts * 16);
+    const int q = threadIdx.x & 3, r = threadIdx.x >> 2;
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int slot = r; slot < n_parts; slot += 64) {
+        const float4 v = src[(size_t)slot * 4 + q];
+        a[0] += (double)v.x; a[1] += (double)v.y; a[2] += (double)v.z; a[3] += (double)v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        for (int off = 4; off <= 32; off <<= 1) a[i] += __shfl_xor(a[i], off, 64);
+    __shared__ double sm[4][16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sm[wave][lane * 4 + i] = a[i];
+    }
+    __syncthreads();
+    // one fp32 slot per channel block: the totals of a layer (|sum| < 2^24 * mean) keep 24 bits - the consumers' fp64 mean / variance
+    // arithmetic starts from the same precision the slots themselves have
+    if (threadIdx.x < 16)
+        out[(size_t)blk * 16 + threadIdx.x] = (float)(((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x]);
+}
+
+// forward apply with the statistics folded from the conv's partials: y = act(z * scale + shift (+ res))
+__global__ __launch_bounds__(256) void bn16_apply_pre_kernel(const u32x4_t* __restrict__ z, const float* __restrict__ pre, int n_parts,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                             float* __restrict__ moving_mean, float* __restrict__ moving_var,
+                                                             const u32x4_t* __restrict__ res, u32x4_t* __restrict__ y, int n, int c,
+                                                             int c8, int hw, double count, float eps, float momentum, int relu) {
+    const int blk = blockIdx.x;
+    __shared__ double s_tot[16];
+    __shared__ double s_sm[4][16];
+    __shared__ float s_scale[8], s_shift[8];
+    bn16_fold_parts(pre, blk, n_parts, s_tot, s_sm);
+    if (threadIdx.x < 8) {
+        const int j = threadIdx.x, ch = blk * 8 + j;
+        float sc = 0.f, sh = 0.f;
+        if (ch < c) {
+            const double mean = s_tot[2 * j] / count;
+            double var = s_tot[2 * j + 1] / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            sc = gamma[ch] * invstd;
+            sh = bn16_shift(beta[ch], (float)mean, sc);
+            if (blockIdx.y == 0) {
+                save_mean[ch] = (float)mean;
+                save_invstd[ch] = invstd;
+                if (moving_mean) {
+                    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                    moving_mean[ch] = momentum * moving_mean[ch] + (1.f - momentum) * (float)mean;
+                    moving_var[ch] = momentum * moving_var[ch] + (1.f - momentum) * (float)unbiased;
+                }
+            }
+        }
+        s_scale[j] = sc;
+        s_shift[j] = sh;
+    }
+    __syncthreads();
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = s_scale[j]; sh[j] = s_shift[j]; }
+    const unsigned per_blk = (unsigned)n * (unsigned)hw;
+    const unsigned len = (per_blk + gridDim.y - 1) / gridDim.y;
+    const unsigned e0 = blockIdx.y * len, e1 = e0 + len < per_blk ? e0 + len : per_blk;
+    const unsigned magic_hw = hw > 1 ? (unsigned)(0x100000000ULL / (unsigned)hw) + 1u : 0u;
+    const bool exact = (unsigned long long)per_blk * (unsigned)hw < 0x100000000ULL;
+    const size_t blk_off = (size_t)blk * hw, img_extra = (size_t)(c8 - 1) * hw;
+#pragma unroll 4
+    for (unsigned e = e0 + threadIdx.x; e < e1; e += 256) {
+        const unsigned img = hw <= 1 ? e : (exact ? __umulhi(e, magic_hw) : e / (unsigned)hw);
+        const size_t i = (size_t)e + (size_t)img * img_extra + blk_off;
+        const h16x8 zv = __builtin_bit_cast(h16x8, z[i]);
+        h16x8 rv = zv;
+        if (res) rv = __builtin_bit_cast(h16x8, res[i]);
+        h16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = 0.f;
+            if (blk * 8 + j < c) {
+                v = bn16_affine((float)zv[j], sc[j], sh[j]);
+                if (res) v += (float)rv[j];
+                if (relu) v = fmaxf(v, 0.f);
+            }
+            o[j] = (_Float16)v;
+        }
+        y[i] = __builtin_bit_cast(u32x4_t, o);
+    }
+}
+
+// backward apply on a PRE-MASKED gradient g with sum g, sum g * z folded from the data-gradient conv's partials:
+// dz = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)); the residual branch's gradient is g itself (nothing to write)
+__global__ __launch_bounds__(256) void bn16_bwd_apply_pre_kernel(const u32x4_t* __restrict__ g_in, const u32x4_t* __restrict__ z,
+                                                                 const float* __restrict__ pre, int n_parts,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta, float* __restrict__ dgamma_acc,
+                                                                 float* __restrict__ dbeta_acc, u32x4_t* __restrict__ dz, int n, int c,
+                                                                 int c8, int hw, float inv_count) {
+    const int blk = blockIdx.x;
+    __shared__ double s_tot[16];
+    __shared__ double s_sm[4][16];
+    __shared__ float s_k[8], s_mu[8], s_is[8], s_mb[8], s_mg[8];
+    bn16_fold_parts(pre, blk, n_parts, s_tot, s_sm);
+    if (threadIdx.x < 8) {
+        const int j = threadIdx.x, ch = blk * 8 + j;
+        float k = 0.f, mu = 0.f, is = 0.f, mb = 0.f, mg = 0.f;
+        if (ch < c) {
+            mu = mean[ch];
+            is = invstd[ch];
+            // the conv epilogue summed g and g * z (raw z): sum g * xhat = invstd * (sum g z - mean * sum g), in fp64
+            const float db = (float)s_tot[2 * j], dg = (float)((s_tot[2 * j + 1] - (double)mu * s_tot[2 * j]) * (double)is);
+            k = gamma[ch] * is;
+            mb = db * inv_count;
+            mg = dg * inv_count;
+            if (blockIdx.y == 0) {
+                dbeta[ch] = db;
+                dgamma[ch] = dg;
+                if (dgamma_acc && dbeta_acc) {
+                    dbeta_acc[ch] += db;
+                    dgamma_acc[ch] += dg;
+                }
+            }
+        }
+        s_k[j] = k; s_mu[j] = mu; s_is[j] = is; s_mb[j] = mb; s_mg[j] = mg;
+    }
+    __syncthreads();
+    float k[8], mu[8], is[8], mb[8], mg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { k[j] = s_k[j]; mu[j] = s_mu[j]; is[j] = s_is[j]; mb[j] = s_mb[j]; mg[j] = s_mg[j]; }
+    const unsigned per_blk = (unsigned)n * (unsigned)hw;
+    const unsigned len = (per_blk + gridDim.y - 1) / gridDim.y;
+    const unsigned e0 = blockIdx.y * len, e1 = e0 + len < per_blk ? e0 + len : per_blk;
+    const unsigned magic_hw = hw > 1 ? (unsigned)(0x100000000ULL / (unsigned)hw) + 1u : 0u;
+    const bool exact = (unsigned long long)per_blk * (unsigned)hw < 0x100000000ULL;
+    const size_t blk_off = (size_t)blk * hw, img_extra = (size_t)(c8 - 1) * hw;
+#pragma unroll 4
+    for (unsigned e = e0 + threadIdx.x; e < e1; e += 256) {
+        const unsigned img = hw <= 1 ? e : (exact ? __umulhi(e, magic_hw) : e / (unsigned)hw);
+        const size_t i = (size_t)e + (size_t)img * img_extra + blk_off;
+        const h16x8 gv = __builtin_bit_cast(h16x8, g_in[i]);
+        const h16x8 zv = __builtin_bit_cast(h16x8, z[i]);
+        h16x8 oz;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float d = 0.f;
+            if (blk * 8 + j < c) {
+                const float xh = ((float)zv[j] - mu[j]) * is[j];
+                d = k[j] * ((float)gv[j] - mb[j] - xh * mg[j]);
+            }
+            oz[j] = (_Float16)d;
+        }
+        dz[i] = __builtin_bit_cast(u32x4_t, oz);
+    }
+}
+
 // ---- small maps: both passes of a BatchNorm direction in ONE launch --------------------------------------------------------------
 // On the 32x24 / 16x12 / 8x6 maps (<= 12 MB per tensor at N = 128) the two dependent launches above cost 13 - 20 us whatever they
 // move: the second pass waits for a kernel boundary.  Here a grid of <= 128 workgroups does pass 1 over its slice, publishes its
@@ -1138,6 +1332,62 @@ int mp_f16_bn_train_bwd(const void* dy, const void* z, const void* y, const floa
                        part, gamma, save_mean, save_invstd, dgamma, dbeta, acc ? dgamma_acc : nullptr, acc ? dbeta_acc : nullptr,
                        reinterpret_cast<u32x4_t*>(dz), reinterpret_cast<u32x4_t*>(dres), n, c, c8, hw, gi * gp, relu,
                        (float)(1.0 / ((double)n * hw)), beta);
+    return check_launch();
+}
+
+// pixel-range chunks per channel block of the statistics-free apply kernels: every block folds n_parts x 64 bytes of partials first,
+// so blocks are fatter than bn16_apply_chunks' (>= 2048 elements each): ~512 blocks on the large maps, a few dozen on the small ones
+static unsigned bn16_pre_chunks(int n, int c8, int hw) {
+    size_t chunks = (512 + c8 - 1) / c8;
+    const size_t per_blk = (size_t)n * hw;
+    while (chunks > 1 && per_blk / chunks < 2048) --chunks;
+    return (unsigned)chunks;
+}
+
+// more slots than a consumer block folds: reduce them to one per channel block (into the workspace)
+static int bn16_prefold(const float*& pre, int& n_parts, int c8, void* workspace, hipStream_t s) {
+    if (n_parts <= kMaxFoldParts) return MP_OK;
+    float* folded = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(bn16_fold_kernel, dim3(c8), dim3(256), 0, s, pre, folded, n_parts);
+    pre = folded;
+    n_parts = 1;
+    return check_launch();
+}
+
+int mp_f16_bn_train_fwd_stats(const void* z, const float* gamma, const float* beta, const void* res, void* y, float* save_mean,
+                              float* save_invstd, float* moving_mean, float* moving_var, int n, int c, int hw, float eps,
+                              float momentum, int relu, const float* partials, int n_parts, void* workspace, size_t workspace_bytes,
+                              mp_stream_t stream) {
+    if (!z || !gamma || !beta || !y || !save_mean || !save_invstd || !partials) return MP_ERR_NULL;
+    if ((moving_mean == nullptr) != (moving_var == nullptr)) return MP_ERR_NULL;
+    if (n <= 0 || c <= 0 || hw <= 0 || n_parts <= 0) return MP_ERR_SHAPE;
+    if (!workspace || workspace_bytes < mp_bn_workspace_bytes(c)) return MP_ERR_WORKSPACE;
+    const int c8 = (c + 7) / 8;
+    hipStream_t s = as_stream(stream);
+    int rc = bn16_prefold(partials, n_parts, c8, workspace, s);
+    if (rc != MP_OK) return rc;
+    hipLaunchKernelGGL(bn16_apply_pre_kernel, dim3(c8, bn16_pre_chunks(n, c8, hw)), dim3(256), 0, s, reinterpret_cast<const u32x4_t*>(z),
+                       partials, n_parts, gamma, beta, save_mean, save_invstd, moving_mean, moving_var,
+                       reinterpret_cast<const u32x4_t*>(res), reinterpret_cast<u32x4_t*>(y), n, c, c8, hw, (double)n * hw, eps, momentum,
+                       relu ? 1 : 0);
+    return check_launch();
+}
+
+int mp_f16_bn_train_bwd_stats(const void* g, const void* z, const float* gamma, const float* save_mean, const float* save_invstd,
+                              void* dz, float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc, int n, int c, int hw,
+                              const float* partials, int n_parts, void* workspace, size_t workspace_bytes, mp_stream_t stream) {
+    if (!g || !z || !gamma || !save_mean || !save_invstd || !dz || !dgamma || !dbeta || !partials) return MP_ERR_NULL;
+    if (n <= 0 || c <= 0 || hw <= 0 || n_parts <= 0) return MP_ERR_SHAPE;
+    if (!workspace || workspace_bytes < mp_bn_workspace_bytes(c)) return MP_ERR_WORKSPACE;
+    const int c8 = (c + 7) / 8;
+    hipStream_t s = as_stream(stream);
+    int rc = bn16_prefold(partials, n_parts, c8, workspace, s);
+    if (rc != MP_OK) return rc;
+    const bool acc = dgamma_acc && dbeta_acc;
+    hipLaunchKernelGGL(bn16_bwd_apply_pre_kernel, dim3(c8, bn16_pre_chunks(n, c8, hw)), dim3(256), 0, s,
+                       reinterpret_cast<const u32x4_t*>(g), reinterpret_cast<const u32x4_t*>(z), partials, n_parts, gamma, save_mean,
+                       save_invstd, dgamma, dbeta, acc ? dgamma_acc : nullptr, acc ? dbeta_acc : nullptr, reinterpret_cast<u32x4_t*>(dz),
+                       n, c, c8, hw, (float)(1.0 / ((double)n * hw)));
     return check_launch();
 }
 

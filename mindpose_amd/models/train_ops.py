@@ -804,6 +804,7 @@ class DeconvFn(torch.autograd.Function):
 
 def deconv_bn_relu(x, deconv, bn):
     """Conv2dTranspose(4, 2, 1) + BatchNorm(train) + ReLU of the SimpleBaseline head."""
+    _claim(x)
     if _is_c8(x):
         y = Deconv16Fn.apply(x, deconv.weight)
         return BatchNormAct16Fn.apply(y, bn.gamma, bn.beta, None, bn.moving_mean, bn.moving_variance, True)
@@ -816,6 +817,7 @@ def to_c8(x: torch.Tensor) -> torch.Tensor:
 
 
 def from_c8(x: torch.Tensor, channels: int) -> torch.Tensor:
+    _claim(x)
     return FromC8Fn.apply(x, channels)
 
 
@@ -900,10 +902,246 @@ class ResidualBlock32Fn(_ResidualBlockFn):
         return _ResidualBlockFn.backward.__func__(ResidualBlock32Fn, ctx, dy)
 
 
+# ---- amp O2: BatchNorm fused into the neighbouring convs (round 3) ----------------------------------------------------------------
+# A chain  conv -> BN (-> ReLU) [-> conv -> BN ...] (+ chain input on the last BN)  is ONE autograd node whose conv launches also do
+# the BatchNorm REDUCTIONS (csrc/conv_f16_dev.h):
+#   forward   conv_i's epilogue leaves the partial sums of z_i, z_i^2        -> BN_i runs its apply pass only
+#   backward  the data-gradient launch that produces the gradient reaching BN_i's OUTPUT (conv_{i+1}'s, or - across nodes - the
+#             first conv of the NEXT chain, residual gradient included) masks it with y_i > 0 and leaves the partial sums of g, g z_i
+#             -> BN_i's backward runs its apply pass only, on the pre-masked gradient (which is also the residual branch's gradient)
+# The cross-node hand-over goes through a `_BnLink` the producing chain hangs on its output tensor.  It is used only when the
+# consuming chain is the tensor's ONLY consumer: every function of this module that takes a channel-blocked activation counts
+# itself on the link (`_claim`), so a second consumer - autograd then SUMS gradients, and the sum is not what the conv's epilogue
+# saw - switches the hand-over off for that tensor and the BatchNorm falls back to its own reduction launch.
+# MINDPOSE_BN_FUSE=0 keeps the per-cell functions everywhere (A/B, parity tests of the two paths against each other).
+
+
+def bn_fuse_enabled() -> bool:
+    return os.environ.get("MINDPOSE_BN_FUSE", "1") != "0"
+
+
+def _bn_fuse_parts() -> int:
+    """Bit mask of the fused pieces (debugging / A-B): 1 forward statistics, 2 backward statistics inside a chain, 4 across chains."""
+    return int(os.environ.get("MINDPOSE_BN_FUSE_PARTS", "7"))
+
+
+class _BnLink:
+    """The last BatchNorm of a chain, as seen by whoever consumes the chain's output: its input z, its output y (mask), whether it
+    has a ReLU.  ``claimed`` counts the consumers of y; ``partials`` is filled by the consumer's data-gradient launch."""
+    __slots__ = ("z", "y", "relu", "claimed", "partials", "n_parts")
+
+    def __init__(self, z, y, relu):
+        self.z, self.y, self.relu, self.claimed, self.partials, self.n_parts = z, y, relu, 0, None, 0
+
+
+def _claim(t):
+    """A consumer of the activation ``t`` announces itself (see above); returns the link or None."""
+    link = getattr(t, "_mp_bn_link", None)
+    if link is not None:
+        link.claimed += 1
+    return link
+
+
+def _stats_alloc(lib, d, v, c8out, device):
+    """Partial-sum buffer of a conv launch with epilogue statistics: (tensor, n_parts) or (None, 0) when variant ``v`` has no
+    statistics build for this shape."""
+    n_parts = lib.mp_f16_conv_stats_parts(ctypes.byref(d), v)  # v = -1 (tiny layers, tuner off): the library's own choice
+    if n_parts <= 0:
+        return None, 0
+    return torch.empty(c8out * n_parts * 16, device=device, dtype=torch.float32), n_parts
+
+
+def _conv16_stats_launch(lib, d, x, packed, scale, shift, out, res1, mode, z=None, y=None, relu=0):
+    """The tuned conv launch with epilogue statistics (mode 1 forward / 2 backward); returns (partials, n_parts) or (None, 0) after
+    a PLAIN launch when the tuned variant has no statistics build."""
+    v = tune_conv_variant(lib, d, x, packed, scale, shift, res1, None, out, half=True)
+    part, n_parts = _stats_alloc(lib, d, v, (d.cout + 7) // 8, out.device)
+    if part is None:
+        _lib.check(lib.mp_f16_conv2d_fwd(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift),
+                                         _lib.ptr(res1), None, _lib.ptr(out), _lib.stream()), "mp_f16_conv2d_fwd")
+        return None, 0
+    st = _lib.ConvStats(mode=mode, relu=int(relu), partials=part.data_ptr(), partials_bytes=part.numel() * 4,
+                        z=_lib.ptr(z), y=_lib.ptr(y) if relu else None)
+    _lib.check(lib.mp_f16_conv2d_fwd_stats(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift),
+                                           _lib.ptr(res1), _lib.ptr(out), ctypes.byref(st), _lib.stream()), "mp_f16_conv2d_fwd_stats")
+    return part, n_parts
+
+
+class Chain16Fn(torch.autograd.Function):
+    """``meta`` = per group (stride, padding, moving_mean, moving_var, relu); ``residual``: the chain input is added before the last
+    group's activation (BasicBlock / Bottleneck without down-sample, hrnet.py:66-83, 126-146); ``params`` = (weight, gamma, beta)
+    per group.  k in {1, 3}, stride in {1, 2}, padding = k // 2, no conv bias."""
+
+    @staticmethod
+    def forward(ctx, x, meta, residual, in_link, *params):
+        lib = _lib.load()
+        groups = []
+        a = x
+        n_groups = len(meta)
+        for gi, (stride, padding, mm, mv, relu) in enumerate(meta):
+            weight, gamma, beta = params[3 * gi: 3 * gi + 3]
+            w = weight.detach().contiguous()
+            n, _, h, wd, _ = a.shape
+            cout, cin, k, _ = w.shape
+            if padding != k // 2 or k not in (1, 3) or stride not in (1, 2):
+                raise NotImplementedError("training path covers k in {1,3}, stride in {1,2}, padding = k//2")
+            ho, wo = (h + 2 * padding - k) // stride + 1, (wd + 2 * padding - k) // stride + 1
+            ones, zeros = _ones_zeros16(cout, a.device)
+            z = _c8_alloc(n, cout, ho, wo, a.device)
+            d = _desc(n, cin, h, wd, cout, k, stride, padding, padding, ho, wo, ho, wo)
+            packed = _pack16(lib, w, cout, cin, k, 0, owner=weight)
+            if _bn_fuse_parts() & 1:
+                part, n_parts = _conv16_stats_launch(lib, d, a, packed, ones, zeros, z, None, 1)
+            else:
+                part, n_parts = None, 0
+                _conv16_launch(lib, d, a, packed, ones, zeros, z, "mp_f16_conv2d_fwd")
+            last = gi == n_groups - 1
+            res = x if (last and residual) else None
+            y = torch.empty_like(z)
+            mean = torch.empty(cout, device=z.device)
+            invstd = torch.empty(cout, device=z.device)
+            ws, ws_bytes = _bn16_workspace(lib, cout, z.device)
+            g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+            if part is not None:
+                _lib.check(lib.mp_f16_bn_train_fwd_stats(_lib.ptr(z), _lib.ptr(g), _lib.ptr(b), _lib.ptr(res), _lib.ptr(y), _lib.ptr(mean),
+                                                         _lib.ptr(invstd), _lib.ptr(mm), _lib.ptr(mv), n, cout, ho * wo, BN_EPS, BN_MOMENTUM,
+                                                         int(relu), _lib.ptr(part), n_parts, _lib.ptr(ws), ws_bytes, _lib.stream()),
+                           "mp_f16_bn_train_fwd_stats")
+            else:
+                _lib.check(lib.mp_f16_bn_train_fwd(_lib.ptr(z), _lib.ptr(g), _lib.ptr(b), _lib.ptr(res), _lib.ptr(y), _lib.ptr(mean),
+                                                   _lib.ptr(invstd), _lib.ptr(mm), _lib.ptr(mv), n, cout, ho * wo, BN_EPS, BN_MOMENTUM,
+                                                   int(relu), _lib.ptr(ws), ws_bytes, _lib.stream()), "mp_f16_bn_train_fwd")
+            groups.append(dict(a=a, w=w, weight=weight, gamma=gamma, beta=beta, g=g, b=b, z=z, y=y, mean=mean, invstd=invstd,
+                               stride=stride, padding=padding, relu=bool(relu), res=res is not None))
+            a = y
+        ctx.groups = groups
+        ctx.in_link = in_link
+        ctx.out_link = _BnLink(groups[-1]["z"], a, groups[-1]["relu"])
+        ctx.needs_dx = x.requires_grad
+        return a
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        groups, ctx.groups = ctx.groups, None
+        dy = dy.contiguous()
+        grads = []
+        # the gradient reaching the LAST BatchNorm: pre-masked with partial sums when the (only) consumer's data gradient made them
+        link = ctx.out_link
+        pre = (link.partials, link.n_parts) if (link.partials is not None and link.claimed == 1) else None
+        dres = None
+        for gi in range(len(groups) - 1, -1, -1):
+            G = groups[gi]
+            z, y, a, w = G["z"], G["y"], G["a"], G["w"]
+            n, _, ho, wo, _ = z.shape
+            cout, cin, k, _ = w.shape
+            h, wd = a.shape[2], a.shape[3]
+            dz = torch.empty_like(z)
+            dgamma = torch.empty(cout, device=z.device)
+            dbeta = torch.empty(cout, device=z.device)
+            ws, ws_bytes = _bn16_workspace(lib, cout, z.device)
+            ga, ba = _direct_grad(G["gamma"]), _direct_grad(G["beta"])
+            if ga is None or ba is None:
+                ga = ba = None
+            if pre is not None:  # apply pass only: dy is g = dy * mask, its sums came with it
+                _lib.check(lib.mp_f16_bn_train_bwd_stats(_lib.ptr(dy), _lib.ptr(z), _lib.ptr(G["g"]), _lib.ptr(G["mean"]), _lib.ptr(G["invstd"]),
+                                                         _lib.ptr(dz), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ga), _lib.ptr(ba), n, cout,
+                                                         ho * wo, _lib.ptr(pre[0]), pre[1], _lib.ptr(ws), ws_bytes, _lib.stream()),
+                           "mp_f16_bn_train_bwd_stats")
+                if G["res"]:
+                    dres = dy
+            else:
+                yy = y if (G["relu"] and G["res"]) else None  # no residual: the mask is re-derived from z, y is not read
+                if G["relu"] and not G["res"] and os.environ.get("MINDPOSE_BN16_MASK_FROM_Z", "1") == "0":
+                    yy = y
+                dr = torch.empty_like(z) if G["res"] else None
+                _lib.check(lib.mp_f16_bn_train_bwd(_lib.ptr(dy), _lib.ptr(z), _lib.ptr(yy), _lib.ptr(G["g"]), _lib.ptr(G["b"]),
+                                                   _lib.ptr(G["mean"]), _lib.ptr(G["invstd"]), _lib.ptr(dz), _lib.ptr(dr), _lib.ptr(dgamma),
+                                                   _lib.ptr(dbeta), _lib.ptr(ga), _lib.ptr(ba), n, cout, ho * wo, int(G["relu"]), _lib.ptr(ws),
+                                                   ws_bytes, _lib.stream()), "mp_f16_bn_train_bwd")
+                if G["res"]:
+                    dres = dr
+            if ga is not None:
+                dgamma = dbeta = None
+            # ---- conv: weight gradient (a leaf), then the data gradient that feeds the BatchNorm below
+            s, pad = G["stride"], G["padding"]
+            direct = _direct_grad(G["weight"])
+            dw = direct if direct is not None else torch.empty_like(w)
+            d = _desc(n, cin, h, wd, cout, k, s, pad, pad, ho, wo, ho, wo)
+            wsb = lib.mp_f16_conv_wgrad_workspace_bytes(ctypes.byref(d))
+            wws = torch.empty(max(wsb // 4, 1), device=z.device, dtype=torch.float32)
+            _lib.check(lib.mp_f16_conv_wgrad(ctypes.byref(d), _lib.ptr(a), _lib.ptr(dz), _lib.ptr(dw), 1.0, int(direct is not None),
+                                             _lib.ptr(wws), wsb, _lib.stream()), "mp_f16_conv_wgrad")
+            if direct is not None:
+                dw = None
+            pre = None
+            dx = None
+            if gi > 0 or ctx.needs_dx:
+                ones, zeros = _ones_zeros16(cin, z.device)
+                dx = _c8_alloc(n, cin, h, wd, z.device)
+                res1 = dres if gi == 0 else None  # the chain input's second path: added in this launch's epilogue
+                # which BatchNorm does this gradient reach?  the previous group's - or, across nodes, the producer of the chain input
+                below = None
+                if gi > 0:
+                    if _bn_fuse_parts() & 2:
+                        P = groups[gi - 1]
+                        below = (P["z"], P["y"], P["relu"], None)
+                elif ctx.in_link is not None and ctx.in_link.claimed == 1 and (_bn_fuse_parts() & 4):
+                    below = (ctx.in_link.z, ctx.in_link.y, ctx.in_link.relu, ctx.in_link)
+                if s == 1:
+                    dd = _desc(n, cout, ho, wo, cin, k, 1, k - 1 - pad, k - 1 - pad, h, wd, h, wd)
+                    packed = _pack16(lib, w, cin, cout, k, 2, owner=G["weight"])
+                    if below is not None and tuple(below[0].shape) == tuple(dx.shape):
+                        part, n_parts = _conv16_stats_launch(lib, dd, dz, packed, ones, zeros, dx, res1, 2, z=below[0], y=below[1],
+                                                             relu=below[2])
+                        if part is not None:
+                            if below[3] is not None:
+                                below[3].partials, below[3].n_parts = part, n_parts
+                            else:
+                                pre = (part, n_parts)
+                    else:
+                        _conv16_launch(lib, dd, dz, packed, ones, zeros, dx, "conv dgrad", res1=res1)
+                else:
+                    if h != 2 * ho or wd != 2 * wo:
+                        raise NotImplementedError("stride-2 data gradient needs even input extents")
+                    if res1 is not None:
+                        raise NotImplementedError("a residual chain starts with a stride-1 conv")
+                    if k == 3:
+                        for py in (0, 1):
+                            for px in (0, 1):
+                                dd = _desc(n, cout, ho, wo, cin, 2, 1, 0, 0, ho, wo, h, wd, out_mul=2, off_y=py, off_x=px)
+                                _conv16_launch(lib, dd, dz, _pack16(lib, w, cin, cout, 2, 3, py, px, owner=G["weight"]), ones, zeros, dx,
+                                               "conv dgrad phase")
+                    else:
+                        dx.zero_()
+                        dd = _desc(n, cout, ho, wo, cin, 1, 1, 0, 0, ho, wo, h, wd, out_mul=2)
+                        _conv16_launch(lib, dd, dz, _pack16(lib, w, cin, cout, 1, 2, owner=G["weight"]), ones, zeros, dx, "conv dgrad 1x1s2")
+            elif gi == 0 and dres is not None:
+                dx = dres
+            grads = [dw, dgamma, dbeta] + grads
+            dy = dx
+        return (dy, None, None, None, *grads)
+
+
+def _chain16(x, groups, relus, residual):
+    """groups = [(conv, bn), ...] on a channel-blocked activation, as ONE fused node."""
+    link = _claim(x)  # a residual chain's second use of x (the identity) is inside the node: still ONE consumer
+    meta = tuple((cv.stride, cv.padding, bn.moving_mean, bn.moving_variance, bool(r)) for (cv, bn), r in zip(groups, relus))
+    params = [t for cv, bn in groups for t in (cv.weight, bn.gamma, bn.beta)]
+    y = Chain16Fn.apply(x, meta, bool(residual), link, *params)
+    out_link = getattr(y.grad_fn, "out_link", None)  # the node object IS the ctx of forward / backward
+    if out_link is not None:
+        y._mp_bn_link = out_link
+    return y
+
+
 def residual_block(x, groups):
     """``groups`` = [(conv, bn), ...]; relu(bn_k(conv_k(... relu(bn_1(conv_1 x)) ...)) + x).  Blocks with a stride-1 first conv take the
     one-node form above (both activation types); anything else composes the per-cell functions."""
     first = groups[0][0]
+    if _is_c8(x) and bn_fuse_enabled() and first.stride == 1 and all(cv.bias is None for cv, _ in groups):
+        return _chain16(x, groups, [True] * len(groups), residual=True)
+    _claim(x)
     if first.stride == 1 and all(cv.bias is None for cv, _ in groups) and os.environ.get("MINDPOSE_FUSE_RESIDUAL", "1") != "0":
         meta = tuple((cv.stride, cv.padding, bn.moving_mean, bn.moving_variance) for cv, bn in groups)
         params = [t for cv, bn in groups for t in (cv.weight, bn.gamma, bn.beta)]
@@ -918,6 +1156,11 @@ def conv_bn_act(x, conv, bn, relu: bool, res: Optional[torch.Tensor] = None):
     """One conv + BatchNorm(train) (+ residual) (+ ReLU) group of the reference's cells; the kernel family follows the
     activation type (fp32 NCHW, or channel-blocked fp16 under amp O2)."""
     if _is_c8(x):
+        if bn is not None and res is None and conv.bias is None and bn_fuse_enabled():
+            return _chain16(x, [(conv, bn)], [relu], residual=False)
+        _claim(x)
+        if res is not None:
+            _claim(res)
         z = Conv16Fn.apply(x, conv.weight, conv.bias, conv.stride, conv.padding)
         if bn is None:
             return z
@@ -960,11 +1203,15 @@ class FanOutFn(torch.autograd.Function):
 def fan_out(x, k: int):
     """``k`` handles on ``x`` whose gradients are summed by one kernel; needs 16-byte multiples (every activation here is)."""
     if k <= 1 or not x.is_cuda or not x.requires_grad or (x.numel() * x.element_size()) % 16 or os.environ.get("MINDPOSE_FAN_OUT", "1") == "0":
-        return (x,) * k
+        return (x,) * k  # the consumers of the k handles count themselves on x's BatchNorm link (the same tensor object)
+    _claim(x)
     return FanOutFn.apply(x, k)
 
 
 def fuse_sum(base, terms):
     """terms = [(tensor, integer scale), ...] (1-3 entries)."""
     fn = FuseSum16Fn if _is_c8(base) else FuseSumFn
+    _claim(base)
+    for t, _ in terms:
+        _claim(t)
     return fn.apply(base, [s for _, s in terms], *[t for t, _ in terms])

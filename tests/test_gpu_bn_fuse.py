@@ -1,0 +1,352 @@
+"""BatchNorm fused out of the amp-O2 training step (round 3): the conv launches produce the BatchNorm partial sums in their
+epilogues (csrc/conv_f16_dev.h), the BatchNorm passes run as apply-only kernels, the autograd node `Chain16Fn` wires it up.
+
+Bars: the conv OUTPUT of a statistics build is bit-identical to the plain launch (mode 2: times the ReLU mask); the partial
+sums equal fp64 sums of that output to 1e-5 relative (fp32 partials over <= a few thousand values, fp64 combination); the
+apply-only BatchNorm passes agree with the reduction-pass kernels to one fp16 ulp / 1e-4 on the parameter gradients; a whole
+HRNet-W32 step through the fused chains agrees with the per-cell step (loss 1e-4 relative, gradient cosine > 0.9995) and is
+bit-reproducible run to run.  Reference semantics: hrnet.py:51-64 (conv -> BatchNorm -> ReLU), tools/train.py:170-181 (amp O2).
+"""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs an MI355X", allow_module_level=True)
+
+from mindpose_amd import _lib  # noqa: E402
+from mindpose_amd.models.layers import ActC8, F16_VARIANTS  # noqa: E402
+
+DEV = torch.device("cuda:0")
+LIB = _lib.load()
+
+
+def _to_c8(x):
+    n, c, h, w = x.shape
+    a = ActC8(n, c, h, w, DEV)
+    _lib.check(LIB.mp_f16_to_c8(_lib.ptr(x.to(DEV).contiguous()), _lib.ptr(a), n, c, h, w, _lib.stream()), "to_c8")
+    return a
+
+
+def _from_c8(a):
+    n, c, h, w = a.shape
+    out = torch.empty(n, c, h, w, device=DEV)
+    _lib.check(LIB.mp_f16_from_c8(_lib.ptr(a), _lib.ptr(out), n, c, h, w, _lib.stream()), "from_c8")
+    return out
+
+
+def _desc(n, cin, h, w, cout, k, s):
+    pad = k // 2
+    ho, wo = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+    return _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=k, kw=k, stride=s, pad_top=pad, pad_left=pad, conv_h=ho, conv_w=wo,
+                         out_h=ho, out_w=wo, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=0, flags=0), ho, wo
+
+
+def _pack(w):
+    cout, cin, k, _ = w.shape
+    packed = torch.empty(LIB.mp_f16_packed_weight_bytes(cout, cin, k, k) // 2, device=DEV, dtype=torch.float16)
+    _lib.check(LIB.mp_f16_pack_weight(_lib.ptr(w.to(DEV).contiguous()), _lib.ptr(packed), cout, cin, k, k, 0, 0, 0, _lib.stream()), "pack")
+    return packed
+
+
+def _sums_from_partials(part, c, n_parts):
+    """[C8][n_parts][8][2] fp32 -> per-channel (sum a, sum b) in fp64."""
+    c8 = (c + 7) // 8
+    p = part.double().reshape(c8, n_parts, 8, 2).sum(dim=1).reshape(c8 * 8, 2)[:c]
+    return p[:, 0].cpu(), p[:, 1].cpu()
+
+
+CASES = [
+    # n, cin, cout, k, s, h, w
+    (5, 32, 32, 3, 1, 64, 48),     # W32 branch 0 (multi-tile runs when N is large enough)
+    (6, 64, 64, 3, 1, 32, 24),
+    (6, 128, 128, 3, 1, 16, 12),
+    (9, 256, 256, 3, 1, 8, 6),     # image-grouped tiles, ragged last group
+    (3, 64, 256, 1, 1, 64, 48),    # stage-1 1x1
+    (3, 256, 64, 1, 1, 32, 24),
+    (3, 32, 64, 3, 2, 64, 48),     # fuse down-sampling conv
+    (2, 3, 64, 3, 2, 64, 48),      # stem
+    (3, 48, 48, 3, 1, 24, 18),     # W48 widths (48 couts: odd cout-tile counts)
+    (2, 40, 24, 3, 1, 9, 7),       # ragged everything, cout % 16 != 0
+    (40, 32, 32, 3, 1, 64, 48),    # > 512 partial slots on the one-tile kernels: the fold launch
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"n{c[0]}_{c[1]}to{c[2]}_k{c[3]}s{c[4]}_{c[5]}x{c[6]}" for c in CASES])
+def test_conv_epilogue_statistics_forward(case, monkeypatch):
+    n, cin, cout, k, s, h, w = case
+    monkeypatch.setenv("MP_F16_MT_GROUPS", "7")  # persistent kernels: several tiles per workgroup even at this size
+    g = torch.Generator().manual_seed(sum(case))
+    x = _to_c8(torch.randn(n, cin, h, w, generator=g))
+    wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    packed = _pack(wt)
+    d, ho, wo = _desc(n, cin, h, w, cout, k, s)
+    c16 = (cout + 15) // 16 * 16
+    ones, zeros = torch.ones(c16, device=DEV), torch.zeros(c16, device=DEV)
+    tested = 0
+    for v in range(F16_VARIANTS):
+        z0 = ActC8(n, cout, ho, wo, DEV)
+        if LIB.mp_f16_conv2d_fwd(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(ones), _lib.ptr(zeros), None, None,
+                                 _lib.ptr(z0), _lib.stream()) != 0:
+            continue
+        n_parts = LIB.mp_f16_conv_stats_parts(ctypes.byref(d), v)
+        assert n_parts > 0, f"variant {v} runs this shape but has no statistics build"
+        c8 = (cout + 7) // 8
+        part = torch.full((c8 * n_parts * 16,), float("nan"), device=DEV)
+        st = _lib.ConvStats(mode=1, relu=0, partials=part.data_ptr(), partials_bytes=part.numel() * 4)
+        z1 = ActC8(n, cout, ho, wo, DEV)
+        _lib.check(LIB.mp_f16_conv2d_fwd_stats(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(ones), _lib.ptr(zeros), None,
+                                               _lib.ptr(z1), ctypes.byref(st), _lib.stream()), f"stats launch, variant {v}")
+        assert torch.equal(z1.c8_tensor, z0.c8_tensor), f"variant {v}: output of the statistics build differs"
+        zf = _from_c8(z0).double()
+        ref_a, ref_b = zf.sum(dim=(0, 2, 3)).cpu(), (zf * zf).sum(dim=(0, 2, 3)).cpu()
+        got_a, got_b = _sums_from_partials(part, cout, n_parts)
+        assert torch.isfinite(part).all(), f"variant {v}: a partial slot was never written"
+        scale_a = zf.abs().sum(dim=(0, 2, 3)).cpu().clamp_min(1e-30)
+        assert ((got_a - ref_a).abs() / scale_a).max() < 1e-5, f"variant {v}: sum"
+        assert ((got_b - ref_b).abs() / ref_b.clamp_min(1e-30)).max() < 1e-5, f"variant {v}: sum of squares"
+        # too small a buffer is refused, not overrun
+        st_small = _lib.ConvStats(mode=1, relu=0, partials=part.data_ptr(), partials_bytes=part.numel() * 4 - 4)
+        assert LIB.mp_f16_conv2d_fwd_stats(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(ones), _lib.ptr(zeros), None,
+                                           _lib.ptr(z1), ctypes.byref(st_small), _lib.stream()) != 0
+        tested += 1
+    assert tested >= 3
+
+
+@pytest.mark.parametrize("relu", [0, 1])
+@pytest.mark.parametrize("case", [c for c in CASES if c[4] == 1 and c[1] == c[2]][:5] + [(3, 64, 256, 1, 1, 64, 48)],
+                         ids=lambda c: f"n{c[0]}_{c[1]}to{c[2]}_k{c[3]}_{c[5]}x{c[6]}")
+def test_conv_epilogue_statistics_backward(case, relu, monkeypatch):
+    """Mode 2: a data-gradient-shaped launch (residual gradient in res1) masks its output with y > 0 and sums g, g * z."""
+    n, cin, cout, k, s, h, w = case
+    monkeypatch.setenv("MP_F16_MT_GROUPS", "5")
+    g = torch.Generator().manual_seed(sum(case) + relu)
+    x = _to_c8(torch.randn(n, cin, h, w, generator=g))
+    packed = _pack(torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5)
+    d, ho, wo = _desc(n, cin, h, w, cout, k, s)
+    res = _to_c8(torch.randn(n, cout, ho, wo, generator=g))
+    zt = torch.randn(n, cout, ho, wo, generator=g) * 1.5 + 0.2
+    yt = torch.relu(torch.randn(n, cout, ho, wo, generator=g))  # about half the positions closed
+    z, y = _to_c8(zt), _to_c8(yt)
+    c16 = (cout + 15) // 16 * 16
+    ones, zeros = torch.ones(c16, device=DEV), torch.zeros(c16, device=DEV)
+    tested = 0
+    for v in range(F16_VARIANTS):
+        o0 = ActC8(n, cout, ho, wo, DEV)
+        if LIB.mp_f16_conv2d_fwd(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(ones), _lib.ptr(zeros), _lib.ptr(res), None,
+                                 _lib.ptr(o0), _lib.stream()) != 0:
+            continue
+        n_parts = LIB.mp_f16_conv_stats_parts(ctypes.byref(d), v)
+        assert n_parts > 0
+        c8 = (cout + 7) // 8
+        part = torch.full((c8 * n_parts * 16,), float("nan"), device=DEV)
+        st = _lib.ConvStats(mode=2, relu=relu, partials=part.data_ptr(), partials_bytes=part.numel() * 4, z=_lib.ptr(z),
+                            y=_lib.ptr(y) if relu else None)
+        o1 = ActC8(n, cout, ho, wo, DEV)
+        _lib.check(LIB.mp_f16_conv2d_fwd_stats(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(ones), _lib.ptr(zeros),
+                                               _lib.ptr(res), _lib.ptr(o1), ctypes.byref(st), _lib.stream()), f"mode 2, variant {v}")
+        mask = (y.c8_tensor > 0) if relu else torch.ones_like(y.c8_tensor, dtype=torch.bool)
+        want = torch.where(mask, o0.c8_tensor, torch.zeros_like(o0.c8_tensor))
+        assert torch.equal(o1.c8_tensor, want), f"variant {v}: stored tensor is not the masked gradient"
+        gf, zf = _from_c8(o1).double(), _from_c8(z).double()
+        ref_a, ref_b = gf.sum(dim=(0, 2, 3)).cpu(), (gf * zf).sum(dim=(0, 2, 3)).cpu()
+        got_a, got_b = _sums_from_partials(part, cout, n_parts)
+        sa, sb = gf.abs().sum(dim=(0, 2, 3)).cpu().clamp_min(1e-30), (gf * zf).abs().sum(dim=(0, 2, 3)).cpu().clamp_min(1e-30)
+        assert ((got_a - ref_a).abs() / sa).max() < 1e-5 and ((got_b - ref_b).abs() / sb).max() < 1e-5, f"variant {v}"
+        tested += 1
+    assert tested >= 3
+
+
+@pytest.mark.parametrize("c,h,w,relu,with_res,n_parts", [(32, 64, 48, True, True, 37), (64, 16, 12, True, False, 5),
+                                                         (256, 8, 6, True, False, 1), (48, 24, 18, False, False, 700),
+                                                         (17, 8, 6, False, False, 3)])
+def test_bn_apply_only_passes_vs_reduction_passes(c, h, w, relu, with_res, n_parts):
+    """mp_f16_bn_train_fwd_stats / _bwd_stats fed with EXACT partial sums (made here in fp64, split over n_parts slots) against the
+    two-pass kernels on the same tensors."""
+    g = torch.Generator().manual_seed(c + h)
+    n = 6
+    zt = torch.randn(n, c, h, w, generator=g) * 1.5 + 0.3
+    z = _to_c8(zt)
+    res = _to_c8(torch.randn(n, c, h, w, generator=g)) if with_res else None
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).to(DEV), (torch.randn(c, generator=g) * 0.1).to(DEV)
+    nb = LIB.mp_bn_workspace_bytes(c)
+    ws = torch.empty(nb // 4 + 1, device=DEV)
+    c8 = (c + 7) // 8
+
+    def partials(a, b):
+        """per-channel sums a, b ([c] fp64) spread over n_parts slots with uneven weights (the fold must add them all)."""
+        wts = torch.rand(n_parts, generator=g).double() + 0.1
+        wts = (wts / wts.sum()).to(DEV)
+        full = torch.zeros(c8 * 8, 2, dtype=torch.float64, device=DEV)
+        full[:c, 0], full[:c, 1] = a, b
+        p = (full.reshape(c8, 1, 8, 2) * wts.reshape(1, n_parts, 1, 1)).float().contiguous()
+        return p.reshape(-1)
+
+    # ---- forward
+    zf = _from_c8(z).double()
+    pf = partials(zf.sum(dim=(0, 2, 3)), (zf * zf).sum(dim=(0, 2, 3)))
+    outs = []
+    for fused in (False, True):
+        y = ActC8(n, c, h, w, DEV)
+        mean, invstd = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+        mm, mv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+        if fused:
+            _lib.check(LIB.mp_f16_bn_train_fwd_stats(_lib.ptr(z), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(res), _lib.ptr(y), _lib.ptr(mean),
+                                                     _lib.ptr(invstd), _lib.ptr(mm), _lib.ptr(mv), n, c, h * w, 1e-5, 0.9, int(relu),
+                                                     _lib.ptr(pf), n_parts, _lib.ptr(ws), nb, _lib.stream()), "fwd_stats")
+        else:
+            _lib.check(LIB.mp_f16_bn_train_fwd(_lib.ptr(z), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(res), _lib.ptr(y), _lib.ptr(mean),
+                                               _lib.ptr(invstd), _lib.ptr(mm), _lib.ptr(mv), n, c, h * w, 1e-5, 0.9, int(relu), _lib.ptr(ws),
+                                               nb, _lib.stream()), "fwd")
+        outs.append((y, mean, invstd, mm, mv))
+    (y0, m0, i0, mm0, mv0), (y1, m1, i1, mm1, mv1) = outs
+    assert torch.allclose(m1, m0, rtol=1e-5, atol=1e-6) and torch.allclose(i1, i0, rtol=1e-5)
+    assert torch.allclose(mm1, mm0, rtol=1e-5, atol=1e-6) and torch.allclose(mv1, mv0, rtol=1e-5)
+    a, b = _from_c8(y0), _from_c8(y1)
+    tol = a.abs() * 2.0 ** -9 + 2e-4 * a.abs().max()
+    assert ((a - b).abs() <= tol).all()
+    assert (y0.c8_tensor != y1.c8_tensor).float().mean() < 1e-3  # statistics differ in the last bits: a rare one-ulp flip at most
+
+    # ---- backward: the pre-masked gradient g and its sums against the two-pass kernel given dy, y
+    dyt = torch.randn(n, c, h, w, generator=g)
+    dy = _to_c8(dyt)
+    dz0, dr0 = ActC8(n, c, h, w, DEV), (ActC8(n, c, h, w, DEV) if with_res else None)
+    dg0, db0 = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    _lib.check(LIB.mp_f16_bn_train_bwd(_lib.ptr(dy), _lib.ptr(z), _lib.ptr(y0), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(m0), _lib.ptr(i0),
+                                       _lib.ptr(dz0), _lib.ptr(dr0), _lib.ptr(dg0), _lib.ptr(db0), None, None, n, c, h * w, int(relu),
+                                       _lib.ptr(ws), nb, _lib.stream()), "bwd")
+    gm = ActC8(n, c, h, w, DEV)
+    gm.c8_tensor.copy_(torch.where(y0.c8_tensor > 0, dy.c8_tensor, torch.zeros_like(dy.c8_tensor)) if relu else dy.c8_tensor)
+    gf = _from_c8(gm).double()
+    pb = partials(gf.sum(dim=(0, 2, 3)), (gf * zf).sum(dim=(0, 2, 3)))
+    dz1 = ActC8(n, c, h, w, DEV)
+    dg1, db1 = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    acc_g, acc_b = torch.full((c,), 1.0, device=DEV), torch.full((c,), 2.0, device=DEV)
+    _lib.check(LIB.mp_f16_bn_train_bwd_stats(_lib.ptr(gm), _lib.ptr(z), _lib.ptr(gamma), _lib.ptr(m0), _lib.ptr(i0), _lib.ptr(dz1), _lib.ptr(dg1),
+                                             _lib.ptr(db1), _lib.ptr(acc_g), _lib.ptr(acc_b), n, c, h * w, _lib.ptr(pb), n_parts, _lib.ptr(ws),
+                                             nb, _lib.stream()), "bwd_stats")
+    assert torch.equal(acc_g, dg1 + 1.0) and torch.equal(acc_b, db1 + 2.0)
+    assert torch.allclose(db1, db0, rtol=1e-4, atol=1e-4 * float(db0.abs().max()))
+    assert torch.allclose(dg1, dg0, rtol=1e-4, atol=1e-4 * float(dg0.abs().max()))
+    a, b = _from_c8(dz0), _from_c8(dz1)
+    tol = a.abs() * 2.0 ** -9 + 2e-4 * a.abs().max()
+    assert ((a - b).abs() <= tol).all()
+    if with_res:  # the residual branch's gradient IS the pre-masked gradient
+        assert torch.equal(dr0.c8_tensor, gm.c8_tensor)
+
+
+def _step(fused, monkeypatch, backbone="hrnet_w32", head="hrnet_head", size=(2, 64, 64)):
+    import mindpose_amd as mp
+    from mindpose_amd.utils import AdamWeightDecay
+    monkeypatch.setenv("MINDPOSE_BN_FUSE", "1" if fused else "0")
+    torch.manual_seed(0)
+    net = mp.init_synthetic(mp.create_network(backbone, head), seed=0).to(DEV).train()
+    mp.models.auto_mixed_precision(net, "O2")
+    nwl = mp.create_network_with_loss(net, mp.create_loss("joint_mse", use_target_weight=True), has_extra_inputs=True)
+    opt = AdamWeightDecay(net, lr=1e-3, weight_decay=0.05, filter_bias_and_bn=True, overlap=False)
+    g = torch.Generator().manual_seed(3)
+    n, h, w = size
+    x = torch.randn(n, 3, h, w, generator=g).to(DEV)
+    kp = (torch.rand(n, 17, 3, generator=g) * torch.tensor([float(w), float(h), 2.0])).to(DEV)
+    target, weight = mp.TopDownGenerateTarget(config=dict(image_size=[w, h], heatmap_size=[w // 4, h // 4]), sigma=2.0)(kp)
+    opt.zero_grad()
+    loss = nwl(x, target, weight)
+    (loss * 1024.0).backward()
+    stats = {k: v.clone() for k, v in net.state_dict().items() if k.endswith(("moving_mean", "moving_variance"))}
+    return float(loss.detach()), opt.grads.arena.clone(), stats
+
+
+def test_single_chain_statistics_match_reduction_path(monkeypatch):
+    """One conv -> BatchNorm -> ReLU group, fused against per-cell, on the SAME input: the statistics (seen through the moving
+    averages) agree to fp32 summation order, the outputs except for rare one-ulp flips, the gradients to 1e-3."""
+    from mindpose_amd.models import train_ops as T
+    from mindpose_amd.models.layers import BatchNorm2d, Conv2d
+    torch.manual_seed(2)
+    cv, bn = Conv2d(32, 64, 3, padding=1).to(DEV), BatchNorm2d(64).to(DEV)
+    torch.nn.init.normal_(cv.weight, std=(2.0 / (9 * 32)) ** 0.5)
+    x = torch.randn(16, 32, 32, 24, device=DEV)
+    out = {}
+    for fused in (True, False):
+        monkeypatch.setenv("MINDPOSE_BN_FUSE", "1" if fused else "0")
+        bn.moving_mean.zero_()
+        bn.moving_variance.fill_(1.0)
+        for p in list(cv.parameters()) + list(bn.parameters()):
+            p.grad = None
+        xi = T.to_c8(x.clone().requires_grad_(True))
+        y = T.conv_bn_act(xi, cv, bn, relu=True)
+        T.from_c8(y, 64).square().mean().backward()
+        out[fused] = (y.detach().clone(), bn.moving_mean.clone(), bn.moving_variance.clone(), cv.weight.grad.clone(), bn.gamma.grad.clone(),
+                      bn.beta.grad.clone())
+    (y1, mm1, mv1, dw1, dg1, db1), (y0, mm0, mv0, dw0, dg0, db0) = out[True], out[False]
+    assert torch.allclose(mm1, mm0, rtol=2e-6, atol=1e-7) and torch.allclose(mv1, mv0, rtol=2e-6)
+    assert (y1 != y0).float().mean() < 1e-3
+    assert float((y1.float() - y0.float()).abs().max()) <= 2.0 ** -9 * float(y0.float().abs().max())
+    for a, b in ((dw1, dw0), (dg1, dg0), (db1, db0)):
+        assert float((a - b).norm() / b.norm()) < 1e-3
+
+
+@pytest.mark.parametrize("backbone,head,size", [("hrnet_w32", "hrnet_head", (3, 128, 96)), ("resnet50", "simple_baseline_head", (2, 64, 64))])
+def test_fused_chain_step_vs_per_cell_step(backbone, head, size, monkeypatch):
+    """Whole step.  The BACKWARD pieces alone (MINDPOSE_BN_FUSE_PARTS=6: gradients pre-masked and reduced by the data-gradient
+    launches) reproduce the per-cell gradients to summation order; the forward statistics come out in another summation order,
+    which flips rare fp16 roundings of the BatchNorm outputs - through ~100 layers the two steps are then two fp16 evaluations of
+    one graph, as far apart as the HIP step and the oracle's emulation are (tests/test_gpu_train_full.py: 0.99)."""
+    l0, g0, s0 = _step(False, monkeypatch, backbone, head, size)
+    monkeypatch.setenv("MINDPOSE_BN_FUSE_PARTS", "6")
+    lb, gb, _ = _step(True, monkeypatch, backbone, head, size)
+    assert lb == l0
+    assert float(torch.nn.functional.cosine_similarity(gb.double(), g0.double(), dim=0)) > 0.99995
+    assert float((gb - g0).norm() / g0.norm()) < 1e-2
+    monkeypatch.setenv("MINDPOSE_BN_FUSE_PARTS", "7")
+    l1, g1, s1 = _step(True, monkeypatch, backbone, head, size)
+    assert abs(l1 - l0) <= 1e-3 * abs(l0), (l1, l0)
+    cos = float(torch.nn.functional.cosine_similarity(g1.double(), g0.double(), dim=0))
+    assert cos > 0.985, cos
+    for k in s0:
+        assert torch.allclose(s1[k], s0[k], rtol=5e-3, atol=5e-4), k
+    # fixed partitions, fixed orders, no atomics: the fused step is bit-reproducible
+    l2, g2, _ = _step(True, monkeypatch, backbone, head, size)
+    assert l2 == l1 and torch.equal(g2, g1)
+
+
+def test_link_is_dropped_when_a_tensor_has_two_consumers(monkeypatch):
+    """The cross-node hand-over (the next chain's data gradient reduces for the previous chain's last BatchNorm) is only valid for a
+    single consumer: with two, autograd sums two gradients and the BatchNorm must do its own reduction."""
+    import mindpose_amd as mp
+    from mindpose_amd.models import train_ops as T
+    from mindpose_amd.models.layers import BatchNorm2d, Conv2d
+    torch.manual_seed(1)
+
+    def mk(cin, cout):
+        cv, bn = Conv2d(cin, cout, 3, padding=1), BatchNorm2d(cout)
+        torch.nn.init.normal_(cv.weight, std=(2.0 / (9 * cin)) ** 0.5)
+        return cv.to(DEV), bn.to(DEV)
+
+    (c0, b0), (c1, b1), (c2, b2) = mk(16, 32), mk(32, 32), mk(32, 32)
+    x = torch.randn(2, 16, 16, 12, device=DEV)
+
+    def run(two_consumers, fused):
+        monkeypatch.setenv("MINDPOSE_BN_FUSE", "1" if fused else "0")
+        for m in (c0, b0, c1, b1, c2, b2):
+            for p in m.parameters():
+                p.grad = None
+        a = T.conv_bn_act(T.to_c8(x), c0, b0, relu=True)
+        link = getattr(a, "_mp_bn_link", None)
+        assert (link is not None) == fused
+        u = T.conv_bn_act(a, c1, b1, relu=True)
+        out = T.from_c8(u, 32)
+        if two_consumers:
+            out = out + T.from_c8(T.conv_bn_act(a, c2, b2, relu=True), 32)
+        out.square().mean().backward()
+        if fused:
+            assert link.claimed == (2 if two_consumers else 1)
+            assert (link.partials is not None) == (not two_consumers)
+        return torch.cat([p.grad.flatten() for m in (c0, b0, c1, b1) for p in m.parameters()])
+
+    for two in (False, True):
+        gf, gr = run(two, True), run(two, False)
+        cos = float(torch.nn.functional.cosine_similarity(gf.double(), gr.double(), dim=0))
+        assert cos > 0.9999, (two, cos)

@@ -408,6 +408,8 @@ def test_residual_block_as_one_autograd_node_matches_per_cell_functions(monkeypa
     import mindpose_amd as mp
     from mindpose_amd.utils import AdamWeightDecay
 
+    monkeypatch.setenv("MINDPOSE_BN_FUSE", "0")  # the round-3 fused chains replace both forms (tests/test_gpu_bn_fuse.py)
+
     def run(fused):
         monkeypatch.setenv("MINDPOSE_FUSE_RESIDUAL", "1" if fused else "0")
         torch.manual_seed(0)
