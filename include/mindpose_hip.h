@@ -469,6 +469,19 @@ int mp_f16_bn_train_fwd_stats(const void* z_dev, const float* gamma_dev, const f
                               float* save_mean_dev, float* save_invstd_dev, float* moving_mean_dev, float* moving_var_dev, int n,
                               int c, int hw, float eps, float momentum, int relu, const float* partials_dev, int n_parts,
                               void* workspace_dev, size_t workspace_bytes, mp_stream_t stream);
+/* The two element-wise producers of a BatchNorm's output gradient with the same statistics (partials [ceil(c/8)][n_parts][8][2],
+ * n_parts = mp_f16_ew_stats_parts(n, c, hw of the OUTPUT tensor)):
+ *   mp_f16_sum_tensors_stats: out = fp16(((a + b) + c) + d) * [y > 0] - mp_sum_tensors (the gradients of the consumers of a branch
+ *     output, hrnet.py:327-339) followed by the mask; sums of g, g * z.
+ *   mp_f16_fuse_sum_bwd_term_stats: ONE term of mp_f16_fuse_upsample_sum_bwd (scale s; s = 1: the base term), masked with y_t > 0 when
+ *     relu_t; z_t / y_t: input / output of the BatchNorm that produced the term. */
+int mp_f16_ew_stats_parts(int n, int c, int hw);
+int mp_f16_sum_tensors_stats(const void* a_dev, const void* b_dev, const void* c_dev, const void* d_dev, void* out_dev, const void* z_dev,
+                             const void* y_dev, int relu, int n, int c, int hw, float* partials_dev, size_t partials_bytes,
+                             mp_stream_t stream);
+int mp_f16_fuse_sum_bwd_term_stats(const void* dy_dev, const void* out_dev, void* dt_dev, int s, int n, int c, int h, int w, int relu,
+                                   const void* z_t_dev, const void* y_t_dev, int relu_t, float* partials_dev, size_t partials_bytes,
+                                   mp_stream_t stream);
 int mp_f16_bn_train_bwd_stats(const void* g_dev, const void* z_dev, const float* gamma_dev, const float* save_mean_dev,
                               const float* save_invstd_dev, void* dz_dev, float* dgamma_dev, float* dbeta_dev, float* dgamma_acc_dev,
                               float* dbeta_acc_dev, int n, int c, int hw, const float* partials_dev, int n_parts,

@@ -1126,6 +1126,114 @@ __global__ __launch_bounds__(256) void sum_tensors_kernel(const u32x4_t* __restr
     }
 }
 
+// ---- the element-wise producers of a BatchNorm's output gradient, with that BatchNorm's backward sums (round 3) --------------------
+// Where the gradient that reaches a BatchNorm does not come out of a data-gradient conv - the sum over the consumers of a branch
+// output (FanOutFn), a term of the exchange unit's backward (FuseSum16Fn) - the kernel that writes it takes the conv epilogue's
+// role: grid (C8, chunks) like the BatchNorm passes (a block stays inside ONE channel block, so per-channel sums live in registers),
+// g = value * [y > 0] stored, partial sums of g and g * z per (channel block, chunk) in the conv epilogue's layout
+// [C8][chunks][8][2] fp32.  Fixed partition, fixed order: bit-reproducible.
+__device__ __forceinline__ void ew_stats_tail(float (&f)[16], float* __restrict__ part, int blk, int chunk, int n_parts) {
+    double acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = (double)f[j];
+    __shared__ double sm[4][16];
+    block_sum16_256(acc, sm);
+    if (threadIdx.x < 16) part[((size_t)blk * n_parts + chunk) * 16 + threadIdx.x] = (float)acc[0];
+}
+
+// out = fp16(((a + b) + c) + d) * [y > 0]  (mp_sum_tensors' arithmetic, then the mask)
+__global__ __launch_bounds__(256) void sum_tensors16_stats_kernel(const u32x4_t* __restrict__ a, const u32x4_t* __restrict__ b,
+                                                                  const u32x4_t* __restrict__ c, const u32x4_t* __restrict__ d,
+                                                                  const u32x4_t* __restrict__ z, const u32x4_t* __restrict__ y,
+                                                                  u32x4_t* __restrict__ out, float* __restrict__ part, int n, int c8,
+                                                                  int hw, int relu) {
+    const int blk = blockIdx.x;
+    const unsigned per_blk = (unsigned)n * (unsigned)hw;
+    const unsigned len = (per_blk + gridDim.y - 1) / gridDim.y;
+    const unsigned e0 = blockIdx.y * len, e1 = e0 + len < per_blk ? e0 + len : per_blk;
+    const unsigned magic_hw = hw > 1 ? (unsigned)(0x100000000ULL / (unsigned)hw) + 1u : 0u;
+    const bool exact = (unsigned long long)per_blk * (unsigned)hw < 0x100000000ULL;
+    const size_t blk_off = (size_t)blk * hw, img_extra = (size_t)(c8 - 1) * hw;
+    float f[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) f[j] = 0.f;
+#pragma unroll 2
+    for (unsigned e = e0 + threadIdx.x; e < e1; e += 256) {
+        const unsigned img = hw <= 1 ? e : (exact ? __umulhi(e, magic_hw) : e / (unsigned)hw);
+        const size_t i = (size_t)e + (size_t)img * img_extra + blk_off;
+        const h16x8 ha = __builtin_bit_cast(h16x8, a[i]), hb = __builtin_bit_cast(h16x8, b[i]);
+        h16x8 hc = ha, hd = ha;
+        if (c) hc = __builtin_bit_cast(h16x8, c[i]);
+        if (d) hd = __builtin_bit_cast(h16x8, d[i]);
+        const h16x8 zv = __builtin_bit_cast(h16x8, z[i]);
+        h16x8 yv = zv;
+        if (relu) yv = __builtin_bit_cast(h16x8, y[i]);
+        h16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = (float)ha[j] + (float)hb[j];
+            if (c) v += (float)hc[j];
+            if (d) v += (float)hd[j];
+            _Float16 h = (_Float16)v;
+            if (relu && !((float)yv[j] > 0.f)) h = (_Float16)0.f;
+            o[j] = h;
+            f[2 * j] += (float)h;
+            f[2 * j + 1] = __builtin_fmaf((float)h, (float)zv[j], f[2 * j + 1]);
+        }
+        out[i] = __builtin_bit_cast(u32x4_t, o);
+    }
+    ew_stats_tail(f, part, blk, blockIdx.y, gridDim.y);
+}
+
+// one term of the exchange unit's backward: dt = fp16(sum over the s x s block of dy * [out > 0]) * [y_t > 0]
+__global__ __launch_bounds__(256) void fuse_sum16_bwd_stats_kernel(const u32x4_t* __restrict__ dy, const u32x4_t* __restrict__ outp,
+                                                                   const u32x4_t* __restrict__ z, const u32x4_t* __restrict__ y,
+                                                                   u32x4_t* __restrict__ dt, float* __restrict__ part, int n, int c8, int h,
+                                                                   int w, int sh, int relu, int relu_t) {
+    const int blk = blockIdx.x;
+    const int lh = h >> sh, lw = w >> sh, s = 1 << sh, lhw = lh * lw;
+    const unsigned per_blk = (unsigned)n * (unsigned)lhw;
+    const unsigned len = (per_blk + gridDim.y - 1) / gridDim.y;
+    const unsigned e0 = blockIdx.y * len, e1 = e0 + len < per_blk ? e0 + len : per_blk;
+    float f[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) f[j] = 0.f;
+    for (unsigned e = e0 + threadIdx.x; e < e1; e += 256) {
+        const unsigned img = e / (unsigned)lhw, pix = e - img * (unsigned)lhw;
+        const unsigned ly = pix / (unsigned)lw, lx = pix - ly * (unsigned)lw;
+        const size_t plane = (size_t)img * c8 + blk;
+        const size_t i = plane * lhw + pix;
+        const size_t o = (plane * h + (size_t)ly * s) * w + (size_t)lx * s;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < s; ++a)
+            for (int b = 0; b < s; ++b) {
+                const h16x8 gv = __builtin_bit_cast(h16x8, dy[o + (size_t)a * w + b]);
+                h16x8 ov = gv;
+                if (relu) ov = __builtin_bit_cast(h16x8, outp[o + (size_t)a * w + b]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float g = (float)gv[j];
+                    if (relu && !((float)ov[j] > 0.f)) g = 0.f;
+                    acc[j] += g;
+                }
+            }
+        const h16x8 zv = __builtin_bit_cast(h16x8, z[i]);
+        h16x8 yv = zv;
+        if (relu_t) yv = __builtin_bit_cast(h16x8, y[i]);
+        h16x8 res;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            _Float16 hv = (_Float16)acc[j];
+            if (relu_t && !((float)yv[j] > 0.f)) hv = (_Float16)0.f;
+            res[j] = hv;
+            f[2 * j] += (float)hv;
+            f[2 * j + 1] = __builtin_fmaf((float)hv, (float)zv[j], f[2 * j + 1]);
+        }
+        dt[i] = __builtin_bit_cast(u32x4_t, res);
+    }
+    ew_stats_tail(f, part, blk, blockIdx.y, gridDim.y);
+}
+
 // image groups x pixel chunks of the fp16 reductions: about 512+ blocks, fixed by the shape (deterministic)
 static void bn16_split(int n, int c8, int hw, int& gi, int& gp) {
     int want = 512 / c8;  // a block should stream >= ~50 KB to amortise its reduction tail
@@ -1412,6 +1520,39 @@ int mp_f16_fuse_upsample_sum_bwd(const void* dy, const void* out, void* dbase, v
         if (rc != MP_OK) return rc;
     }
     return MP_OK;
+}
+
+int mp_f16_ew_stats_parts(int n, int c, int hw) {
+    if (n <= 0 || c <= 0 || hw <= 0) return 0;
+    return (int)bn16_apply_chunks(n, (c + 7) / 8, hw);
+}
+
+int mp_f16_sum_tensors_stats(const void* a, const void* b, const void* c, const void* d, void* out, const void* z, const void* y,
+                             int relu, int n, int ch, int hw, float* partials, size_t partials_bytes, mp_stream_t stream) {
+    if (!a || !b || !out || !z || !partials || (relu && !y)) return MP_ERR_NULL;
+    if (d && !c) return MP_ERR_NULL;
+    if (n <= 0 || ch <= 0 || hw <= 0) return MP_ERR_SHAPE;
+    const int c8 = (ch + 7) / 8, parts = mp_f16_ew_stats_parts(n, ch, hw);
+    if (partials_bytes < (size_t)c8 * parts * 16 * sizeof(float)) return MP_ERR_WORKSPACE;
+    hipLaunchKernelGGL(sum_tensors16_stats_kernel, dim3(c8, parts), dim3(256), 0, as_stream(stream), reinterpret_cast<const u32x4_t*>(a),
+                       reinterpret_cast<const u32x4_t*>(b), reinterpret_cast<const u32x4_t*>(c), reinterpret_cast<const u32x4_t*>(d),
+                       reinterpret_cast<const u32x4_t*>(z), reinterpret_cast<const u32x4_t*>(y), reinterpret_cast<u32x4_t*>(out), partials, n,
+                       c8, hw, relu ? 1 : 0);
+    return check_launch();
+}
+
+int mp_f16_fuse_sum_bwd_term_stats(const void* dy, const void* out, void* dt, int s, int n, int c, int h, int w, int relu, const void* z_t,
+                                   const void* y_t, int relu_t, float* partials, size_t partials_bytes, mp_stream_t stream) {
+    if (!dy || !dt || !z_t || !partials || (relu && !out) || (relu_t && !y_t)) return MP_ERR_NULL;
+    if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return MP_ERR_SHAPE;
+    const int sh = log2_exact_t(s);
+    if (sh < 0 || (h % s) || (w % s)) return MP_ERR_UNSUPPORTED;
+    const int c8 = (c + 7) / 8, lhw = (h >> sh) * (w >> sh), parts = mp_f16_ew_stats_parts(n, c, lhw);
+    if (partials_bytes < (size_t)c8 * parts * 16 * sizeof(float)) return MP_ERR_WORKSPACE;
+    hipLaunchKernelGGL(fuse_sum16_bwd_stats_kernel, dim3(c8, parts), dim3(256), 0, as_stream(stream), reinterpret_cast<const u32x4_t*>(dy),
+                       reinterpret_cast<const u32x4_t*>(out), reinterpret_cast<const u32x4_t*>(z_t), reinterpret_cast<const u32x4_t*>(y_t),
+                       reinterpret_cast<u32x4_t*>(dt), partials, n, c8, h, w, sh, relu ? 1 : 0, relu_t ? 1 : 0);
+    return check_launch();
 }
 
 int mp_sum_tensors(const void* a, const void* b, const void* c, const void* d, void* out, size_t bytes, int half, mp_stream_t stream) {

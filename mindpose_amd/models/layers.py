@@ -215,13 +215,17 @@ def winograd_enabled() -> bool:
     return os.environ.get("MINDPOSE_WINOGRAD", "1") != "0"
 
 
-def tune_conv_variant(lib, d, x, packed, scale, shift, res1, res2, out, half: bool = False, packed_u=None) -> int:
+def tune_conv_variant(lib, d, x, packed, scale, shift, res1, res2, out, half: bool = False, packed_u=None, stats=None) -> int:
     """Pick the tile variant for one conv launch shape by timing the candidates on the layer's real buffers.  Results
     are cached per shape, so a network's ~40 distinct shapes are tuned once per process.  ``packed_u`` (fp32 only): the
-    Winograd-transformed weights; the Winograd form then competes as index ``F32_WINOGRAD``."""
+    Winograd-transformed weights; the Winograd form then competes as index ``F32_WINOGRAD``.  ``stats`` (fp16 training):
+    ``dict(mode, z, y, relu)`` - the launch is the one with BatchNorm statistics in its epilogue (mp_f16_conv2d_fwd_stats: other
+    register budgets, two more tensor reads in mode 2), timed as such and cached under its own key."""
     key = tuple(getattr(d, f) for f, _ in d._fields_) + (res1 is not None, res2 is not None, str(out.device), half)
     if packed_u is not None:
         key += ("wino",)
+    if stats is not None:
+        key += ("stats", int(stats["mode"]), int(bool(stats.get("relu"))))
     macs = d.n * d.conv_h * d.conv_w * d.cout * d.cin * d.kh * d.kw
     stream = _lib.stream()
     # in-place accumulation (out aliases res1) must not be disturbed by trial launches: tune into a scratch copy
@@ -231,7 +235,20 @@ def tune_conv_variant(lib, d, x, packed, scale, shift, res1, res2, out, half: bo
         trial_out = torch.empty_like(out) if torch.is_tensor(out) else ActC8(*out.shape, out.device)
     fn = lib.mp_f16_conv2d_fwd if half else lib.mp_conv2d_fwd_variant
 
+    stats_buf = {}
+
     def launch(v):
+        if stats is not None:
+            n_parts = lib.mp_f16_conv_stats_parts(ctypes.byref(d), v)
+            if n_parts <= 0:
+                return -3
+            need = (d.cout + 7) // 8 * n_parts * 16
+            if stats_buf.get("n", 0) < need:
+                stats_buf["t"], stats_buf["n"] = torch.empty(need, device=out.device, dtype=torch.float32), need
+            st = _lib.ConvStats(mode=int(stats["mode"]), relu=int(bool(stats.get("relu"))), partials=stats_buf["t"].data_ptr(),
+                                partials_bytes=need * 4, z=_lib.ptr(stats.get("z")), y=_lib.ptr(stats.get("y")) if stats.get("relu") else None)
+            return lib.mp_f16_conv2d_fwd_stats(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift),
+                                               _lib.ptr(res1), _lib.ptr(trial_out), ctypes.byref(st), stream)
         if not half and v == F32_WINOGRAD:
             if packed_u is None:
                 return -3  # MP_ERR_UNSUPPORTED: no Winograd form of this layer

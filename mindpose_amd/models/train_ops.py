@@ -583,8 +583,11 @@ class BatchNormAct16Fn(torch.autograd.Function):
 
 
 class FuseSum16Fn(torch.autograd.Function):
+    """``links``: per operand (base, terms...) the BatchNorm link of the chain that produced it, or None - an operand whose only
+    consumer is this sum gets its gradient masked and reduced by the backward kernel itself (``mp_f16_fuse_sum_bwd_term_stats``)."""
+
     @staticmethod
-    def forward(ctx, base, scales, *terms):
+    def forward(ctx, base, scales, links, *terms):
         lib = _lib.load()
         n, c8, h, w, _ = base.shape
         base = base.contiguous()
@@ -597,6 +600,7 @@ class FuseSum16Fn(torch.autograd.Function):
                    "mp_f16_fuse_upsample_sum")
         ctx.save_for_backward(out)
         ctx.scales = [int(s) for s in scales[:len(ts)]]
+        ctx.links = list(links) if links is not None else [None] * (1 + len(ts))
         return out
 
     @staticmethod
@@ -607,12 +611,26 @@ class FuseSum16Fn(torch.autograd.Function):
         n, c8, h, w, _ = out.shape
         dbase = torch.empty_like(out)
         dts = [torch.empty(n, c8, h // s, w // s, 8, device=out.device, dtype=torch.float16) for s in ctx.scales]
-        args = []
-        for i in range(3):
-            args += [_lib.ptr(dts[i]), ctx.scales[i]] if i < len(dts) else [None, 1]
-        _lib.check(lib.mp_f16_fuse_upsample_sum_bwd(_lib.ptr(dy), _lib.ptr(out), _lib.ptr(dbase), *args, n, c8 * 8, h, w, 1,
-                                                    _lib.stream()), "mp_f16_fuse_upsample_sum_bwd")
-        return (dbase, None, *dts)
+        outs, scs = [dbase] + dts, [1] + ctx.scales
+        plain = [None, None, None, None]
+        for k, (dst, sc, link) in enumerate(zip(outs, scs, ctx.links)):
+            if (link is not None and link.claimed == 1 and (_bn_fuse_parts() & 8) and tuple(link.z.shape) == tuple(dst.shape)):
+                n_parts = lib.mp_f16_ew_stats_parts(n, c8 * 8, (h // sc) * (w // sc))
+                part = torch.empty(c8 * n_parts * 16, device=out.device, dtype=torch.float32)
+                _lib.check(lib.mp_f16_fuse_sum_bwd_term_stats(_lib.ptr(dy), _lib.ptr(out), _lib.ptr(dst), sc, n, c8 * 8, h, w, 1,
+                                                              _lib.ptr(link.z), _lib.ptr(link.y) if link.relu else None, int(link.relu),
+                                                              _lib.ptr(part), part.numel() * 4, _lib.stream()),
+                           "mp_f16_fuse_sum_bwd_term_stats")
+                link.partials, link.n_parts = part, n_parts
+            else:
+                plain[k] = dst
+        if any(p is not None for p in plain):
+            args = []
+            for i in range(3):
+                args += [_lib.ptr(plain[i + 1]), ctx.scales[i]] if i < len(dts) else [None, 1]
+            _lib.check(lib.mp_f16_fuse_upsample_sum_bwd(_lib.ptr(dy), _lib.ptr(out), _lib.ptr(plain[0]), *args, n, c8 * 8, h, w, 1,
+                                                        _lib.stream()), "mp_f16_fuse_upsample_sum_bwd")
+        return (dbase, None, None, *dts)
 
 
 class StemConvFn(torch.autograd.Function):
@@ -921,8 +939,9 @@ def bn_fuse_enabled() -> bool:
 
 
 def _bn_fuse_parts() -> int:
-    """Bit mask of the fused pieces (debugging / A-B): 1 forward statistics, 2 backward statistics inside a chain, 4 across chains."""
-    return int(os.environ.get("MINDPOSE_BN_FUSE_PARTS", "7"))
+    """Bit mask of the fused pieces (debugging / A-B): 1 forward statistics, 2 backward statistics inside a chain, 4 across chains,
+    8 from the element-wise gradient producers (fan-out sum, exchange-unit backward)."""
+    return int(os.environ.get("MINDPOSE_BN_FUSE_PARTS", "15"))
 
 
 class _BnLink:
@@ -954,7 +973,7 @@ def _stats_alloc(lib, d, v, c8out, device):
 def _conv16_stats_launch(lib, d, x, packed, scale, shift, out, res1, mode, z=None, y=None, relu=0):
     """The tuned conv launch with epilogue statistics (mode 1 forward / 2 backward); returns (partials, n_parts) or (None, 0) after
     a PLAIN launch when the tuned variant has no statistics build."""
-    v = tune_conv_variant(lib, d, x, packed, scale, shift, res1, None, out, half=True)
+    v = tune_conv_variant(lib, d, x, packed, scale, shift, res1, None, out, half=True, stats=dict(mode=mode, z=z, y=y, relu=relu))
     part, n_parts = _stats_alloc(lib, d, v, (d.cout + 7) // 8, out.device)
     if part is None:
         _lib.check(lib.mp_f16_conv2d_fwd(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift),
@@ -1173,22 +1192,38 @@ def conv_bn_act(x, conv, bn, relu: bool, res: Optional[torch.Tensor] = None):
 
 class FanOutFn(torch.autograd.Function):
     """``k`` handles on one tensor for ``k`` consumers; the backward pass sums the ``k`` gradients in ONE launch
-    (``mp_sum_tensors``: fp32 arithmetic, one rounding) instead of autograd's ``k - 1`` pairwise add kernels."""
+    (``mp_sum_tensors``: fp32 arithmetic, one rounding) instead of autograd's ``k - 1`` pairwise add kernels.  ``link``: the tensor
+    is the output of a fused chain whose only consumer is this fan-out - the sum kernel then also masks the gradient and leaves the
+    last BatchNorm's backward sums (``mp_f16_sum_tensors_stats``)."""
 
     @staticmethod
-    def forward(ctx, x, k):
+    def forward(ctx, x, k, link):
         ctx.set_materialize_grads(False)
+        ctx.link = link
         return tuple(x.view_as(x) for _ in range(k))
 
     @staticmethod
     def backward(ctx, *grads):
         gs = [g.contiguous() for g in grads if g is not None]
         if not gs:
-            return None, None
+            return None, None, None
         if len(gs) == 1:
-            return gs[0], None
+            return gs[0], None, None
         lib = _lib.load()
         half = gs[0].dtype == torch.float16
+        link = ctx.link
+        if (half and link is not None and link.claimed == 1 and len(gs) <= 4 and (_bn_fuse_parts() & 8)
+                and tuple(link.z.shape) == tuple(gs[0].shape)):
+            n, c8, h, w, _ = gs[0].shape
+            n_parts = lib.mp_f16_ew_stats_parts(n, c8 * 8, h * w)
+            part = torch.empty(c8 * n_parts * 16, device=gs[0].device, dtype=torch.float32)
+            dst = torch.empty_like(gs[0])
+            ops = gs + [None] * (4 - len(gs))
+            _lib.check(lib.mp_f16_sum_tensors_stats(_lib.ptr(ops[0]), _lib.ptr(ops[1]), _lib.ptr(ops[2]), _lib.ptr(ops[3]), _lib.ptr(dst),
+                                                    _lib.ptr(link.z), _lib.ptr(link.y) if link.relu else None, int(link.relu), n, c8 * 8,
+                                                    h * w, _lib.ptr(part), part.numel() * 4, _lib.stream()), "mp_f16_sum_tensors_stats")
+            link.partials, link.n_parts = part, n_parts
+            return dst, None, None
         out = gs[0]
         for i in range(1, len(gs), 3):  # up to four operands per launch (the running sum + three more)
             ops = gs[i:i + 3]
@@ -1197,21 +1232,19 @@ class FanOutFn(torch.autograd.Function):
                                           _lib.ptr(ops[2]) if len(ops) > 2 else None, _lib.ptr(dst), dst.numel() * dst.element_size(),
                                           int(half), _lib.stream()), "mp_sum_tensors")
             out = dst
-        return out, None
+        return out, None, None
 
 
 def fan_out(x, k: int):
     """``k`` handles on ``x`` whose gradients are summed by one kernel; needs 16-byte multiples (every activation here is)."""
     if k <= 1 or not x.is_cuda or not x.requires_grad or (x.numel() * x.element_size()) % 16 or os.environ.get("MINDPOSE_FAN_OUT", "1") == "0":
         return (x,) * k  # the consumers of the k handles count themselves on x's BatchNorm link (the same tensor object)
-    _claim(x)
-    return FanOutFn.apply(x, k)
+    return FanOutFn.apply(x, k, _claim(x))
 
 
 def fuse_sum(base, terms):
     """terms = [(tensor, integer scale), ...] (1-3 entries)."""
-    fn = FuseSum16Fn if _is_c8(base) else FuseSumFn
-    _claim(base)
-    for t, _ in terms:
-        _claim(t)
-    return fn.apply(base, [s for _, s in terms], *[t for t, _ in terms])
+    links = [_claim(base)] + [_claim(t) for t, _ in terms]
+    if _is_c8(base):
+        return FuseSum16Fn.apply(base, [s for _, s in terms], links, *[t for t, _ in terms])
+    return FuseSumFn.apply(base, [s for _, s in terms], *[t for t, _ in terms])

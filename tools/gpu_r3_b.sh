@@ -8,8 +8,8 @@ tail -15 gpurun_out/r3b_tests.log
 grep -q "tests rc=0" gpurun_out/r3b_tests.log || exit 1
 MINDPOSE_BENCH_TRAIN_SHAPES=gpurun_out/r3b_train_shapes.csv timeout -k 10 300 python bench.py --workload hrnet_w32_train --amp O2 --batch 128 --steps 20 --warmup 5 --leg > gpurun_out/r3b_train_o2.json 2> gpurun_out/r3b_train_o2.err
 echo "bench rc=$?"
-MINDPOSE_BN_FUSE=0 timeout -k 10 300 python bench.py --workload hrnet_w32_train --amp O2 --batch 128 --steps 20 --warmup 5 --leg --no-roofline > gpurun_out/r3b_train_o2_nofuse.json 2> gpurun_out/r3b_train_o2_nofuse.err
-echo "bench2 rc=$?"
+
+
 python - <<'PY'
 import json
 for f in ("gpurun_out/r3b_train_o2.json", "gpurun_out/r3b_train_o2_nofuse.json"):
