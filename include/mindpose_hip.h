@@ -476,6 +476,7 @@ int mp_f16_bn_train_fwd_stats(const void* z_dev, const float* gamma_dev, const f
  *   mp_f16_fuse_sum_bwd_term_stats: ONE term of mp_f16_fuse_upsample_sum_bwd (scale s; s = 1: the base term), masked with y_t > 0 when
  *     relu_t; z_t / y_t: input / output of the BatchNorm that produced the term. */
 int mp_f16_ew_stats_parts(int n, int c, int hw);
+int mp_f16_fuse_term_stats_parts(int n, int c, int h, int w, int s); /* n_parts of mp_f16_fuse_sum_bwd_term_stats (h, w: full resolution) */
 int mp_f16_sum_tensors_stats(const void* a_dev, const void* b_dev, const void* c_dev, const void* d_dev, void* out_dev, const void* z_dev,
                              const void* y_dev, int relu, int n, int c, int hw, float* partials_dev, size_t partials_bytes,
                              mp_stream_t stream);

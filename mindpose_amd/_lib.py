@@ -122,6 +122,7 @@ _PROTOTYPES = {
                                           c_size_t, ctypes.c_void_p]),
     "mp_f16_bn_train_bwd_stats": (c_int, [c_f32p] * 10 + [c_int] * 3 + [c_f32p, c_int, c_f32p, c_size_t, ctypes.c_void_p]),
     "mp_f16_ew_stats_parts": (c_int, [c_int] * 3),
+    "mp_f16_fuse_term_stats_parts": (c_int, [c_int] * 5),
     "mp_f16_sum_tensors_stats": (c_int, [c_f32p] * 7 + [c_int] * 4 + [c_f32p, c_size_t, ctypes.c_void_p]),
     "mp_f16_fuse_sum_bwd_term_stats": (c_int, [c_f32p] * 3 + [c_int] * 6 + [c_f32p, c_f32p, c_int, c_f32p, c_size_t, ctypes.c_void_p]),
     "mp_optimizer_step": (c_int, [c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_size_t, ctypes.c_float,

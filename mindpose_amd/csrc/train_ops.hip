@@ -598,6 +598,7 @@ __global__ __launch_bounds__(256) void bn16_bwd_apply_kernel(const u32x4_t* __re
 // kernels folds the n_parts x 64 bytes of ITS channel block itself (contiguous: coalesced 16-byte loads, fp64 sums in a fixed
 // order, every block the same values), kMaxFoldParts slots at most - above that bn16_fold_kernel reduces them to one slot first.
 constexpr int kMaxFoldParts = 512;
+constexpr int kFoldSplit = 8;  // slot ranges of the fold launch (more than kMaxFoldParts slots)
 
 // totals of the 8 channels of block blk -> tot[16] = {sum0, sumsq0, sum1, ...} (fp64, LDS); ends with a barrier
 __device__ __forceinline__ void bn16_fold_parts(const float* __restrict__ pre, int blk, int n_parts, double* tot, double (*sm)[16]) {
@@ -627,13 +628,15 @@ __device__ __forceinline__ void bn16_fold_parts(const float* __restrict__ pre, i
     __syncthreads();
 }
 
-// n_parts > kMaxFoldParts: grid (C8), one block folds ALL slots of its channel block (fixed order) into slot 0 of `out`
+// n_parts > kMaxFoldParts: grid (C8, kFoldSplit), block (blk, f) folds slot range f of its channel block (fixed order) into slot f of
+// `out` ([C8][kFoldSplit][16]); the consumers then fold kFoldSplit slots
 __global__ __launch_bounds__(256) void bn16_fold_kernel(const float* __restrict__ pre, float* __restrict__ out, int n_parts) {
-    const int blk = blockIdx.x;
+    const int blk = blockIdx.x, f = blockIdx.y;
+    const int per = (n_parts + kFoldSplit - 1) / kFoldSplit, s0 = f * per, s1 = min(s0 + per, n_parts);
     const float4* __restrict__ src = reinterpret_cast<const float4*>(pre + (size_t)blk * n_parts * 16);
     const int q = threadIdx.x & 3, r = threadIdx.x >> 2;
     double a[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int slot = r; slot < n_parts; slot += 64) {
+    for (int slot = s0 + r; slot < s1; slot += 64) {
         const float4 v = src[(size_t)slot * 4 + q];
         a[0] += (double)v.x; a[1] += (double)v.y; a[2] += (double)v.z; a[3] += (double)v.w;
     }
@@ -647,10 +650,10 @@ __global__ __launch_bounds__(256) void bn16_fold_kernel(const float* __restrict_
         for (int i = 0; i < 4; ++i) sm[wave][lane * 4 + i] = a[i];
     }
     __syncthreads();
-    // one fp32 slot per channel block: the totals of a layer (|sum| < 2^24 * mean) keep 24 bits - the consumers' fp64 mean / variance
-    // arithmetic starts from the same precision the slots themselves have
+    // fp32 slots: a range total (|sum| < 2^24 x its mean term) keeps 24 bits - the precision the conv's slots themselves have
     if (threadIdx.x < 16)
-        out[(size_t)blk * 16 + threadIdx.x] = (float)(((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x]);
+        out[((size_t)blk * kFoldSplit + f) * 16 + threadIdx.x] =
+            (float)(((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x]);
 }
 
 // forward apply with the statistics folded from the conv's partials: y = act(z * scale + shift (+ res))
@@ -659,29 +662,58 @@ __global__ __launch_bounds__(256) void bn16_apply_pre_kernel(const u32x4_t* __re
                                                              float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                                              float* __restrict__ moving_mean, float* __restrict__ moving_var,
                                                              const u32x4_t* __restrict__ res, u32x4_t* __restrict__ y, int n, int c,
-                                                             int c8, int hw, double count, float eps, float momentum, int relu) {
+                                                             int c8, int hw, double inv_count, double unbias, float eps, float momentum,
+                                                             int relu) {
     const int blk = blockIdx.x;
     __shared__ double s_tot[16];
     __shared__ double s_sm[4][16];
     __shared__ float s_scale[8], s_shift[8];
+    const unsigned per_blk = (unsigned)n * (unsigned)hw;
+    const unsigned len = (per_blk + gridDim.y - 1) / gridDim.y;
+    const unsigned e0 = blockIdx.y * len, e1 = e0 + len < per_blk ? e0 + len : per_blk;
+    const unsigned magic_hw = hw > 1 ? (unsigned)(0x100000000ULL / (unsigned)hw) + 1u : 0u;
+    const bool exact = (unsigned long long)per_blk * (unsigned)hw < 0x100000000ULL;
+    const size_t blk_off = (size_t)blk * hw, img_extra = (size_t)(c8 - 1) * hw;
+    auto index_of = [&](unsigned e) {
+        const unsigned img = hw <= 1 ? e : (exact ? __umulhi(e, magic_hw) : e / (unsigned)hw);
+        return (size_t)e + (size_t)img * img_extra + blk_off;
+    };
+    // the thread's first four elements are requested BEFORE the fold: the statistics prologue (partial slots -> totals -> scale /
+    // shift: three dependent round trips) then runs under their latency - on the small maps these four are all a thread has
+    constexpr int kHead = 4;
+    u32x4_t hz[kHead], hr[kHead];
+    size_t hi[kHead];
+#pragma unroll
+    for (int k = 0; k < kHead; ++k) {
+        const unsigned e = e0 + threadIdx.x + 256u * k;
+        hi[k] = e < e1 ? index_of(e) : (size_t)0;
+        hz[k] = hr[k] = (u32x4_t){0u, 0u, 0u, 0u};
+        if (e < e1) {
+            hz[k] = z[hi[k]];
+            if (res) hr[k] = res[hi[k]];
+        }
+    }
     bn16_fold_parts(pre, blk, n_parts, s_tot, s_sm);
     if (threadIdx.x < 8) {
         const int j = threadIdx.x, ch = blk * 8 + j;
         float sc = 0.f, sh = 0.f;
         if (ch < c) {
-            const double mean = s_tot[2 * j] / count;
-            double var = s_tot[2 * j + 1] / count - mean * mean;
+            const double mean = s_tot[2 * j] * inv_count;
+            double var = s_tot[2 * j + 1] * inv_count - mean * mean;
             if (var < 0.0) var = 0.0;
-            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            // 1 / sqrt(var + eps): fp32 estimate + one Newton step in fp64 (relative error ~1e-14, no fp64 divide / sqrt sequence)
+            const double x = var + (double)eps;
+            double r = (double)rsqrtf((float)x);
+            r = r * (1.5 - 0.5 * x * r * r);
+            const float invstd = (float)r;
             sc = gamma[ch] * invstd;
             sh = bn16_shift(beta[ch], (float)mean, sc);
             if (blockIdx.y == 0) {
                 save_mean[ch] = (float)mean;
                 save_invstd[ch] = invstd;
                 if (moving_mean) {
-                    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
                     moving_mean[ch] = momentum * moving_mean[ch] + (1.f - momentum) * (float)mean;
-                    moving_var[ch] = momentum * moving_var[ch] + (1.f - momentum) * (float)unbiased;
+                    moving_var[ch] = momentum * moving_var[ch] + (1.f - momentum) * (float)(var * unbias);
                 }
             }
         }
@@ -692,19 +724,8 @@ __global__ __launch_bounds__(256) void bn16_apply_pre_kernel(const u32x4_t* __re
     float sc[8], sh[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sc[j] = s_scale[j]; sh[j] = s_shift[j]; }
-    const unsigned per_blk = (unsigned)n * (unsigned)hw;
-    const unsigned len = (per_blk + gridDim.y - 1) / gridDim.y;
-    const unsigned e0 = blockIdx.y * len, e1 = e0 + len < per_blk ? e0 + len : per_blk;
-    const unsigned magic_hw = hw > 1 ? (unsigned)(0x100000000ULL / (unsigned)hw) + 1u : 0u;
-    const bool exact = (unsigned long long)per_blk * (unsigned)hw < 0x100000000ULL;
-    const size_t blk_off = (size_t)blk * hw, img_extra = (size_t)(c8 - 1) * hw;
-#pragma unroll 4
-    for (unsigned e = e0 + threadIdx.x; e < e1; e += 256) {
-        const unsigned img = hw <= 1 ? e : (exact ? __umulhi(e, magic_hw) : e / (unsigned)hw);
-        const size_t i = (size_t)e + (size_t)img * img_extra + blk_off;
-        const h16x8 zv = __builtin_bit_cast(h16x8, z[i]);
-        h16x8 rv = zv;
-        if (res) rv = __builtin_bit_cast(h16x8, res[i]);
+    auto apply = [&](const u32x4_t zq, const u32x4_t rq, size_t i) {
+        const h16x8 zv = __builtin_bit_cast(h16x8, zq), rv = __builtin_bit_cast(h16x8, rq);
         h16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -717,6 +738,17 @@ __global__ __launch_bounds__(256) void bn16_apply_pre_kernel(const u32x4_t* __re
             o[j] = (_Float16)v;
         }
         y[i] = __builtin_bit_cast(u32x4_t, o);
+    };
+#pragma unroll
+    for (int k = 0; k < kHead; ++k)
+        if (e0 + threadIdx.x + 256u * k < e1) apply(hz[k], hr[k], hi[k]);
+#pragma unroll 4
+    for (unsigned e = e0 + threadIdx.x + 256u * kHead; e < e1; e += 256) {
+        const size_t i = index_of(e);
+        const u32x4_t zq = z[i];
+        u32x4_t rq = zq;
+        if (res) rq = res[i];
+        apply(zq, rq, i);
     }
 }
 
@@ -733,6 +765,29 @@ __global__ __launch_bounds__(256) void bn16_bwd_apply_pre_kernel(const u32x4_t* 
     __shared__ double s_tot[16];
     __shared__ double s_sm[4][16];
     __shared__ float s_k[8], s_mu[8], s_is[8], s_mb[8], s_mg[8];
+    const unsigned per_blk = (unsigned)n * (unsigned)hw;
+    const unsigned len = (per_blk + gridDim.y - 1) / gridDim.y;
+    const unsigned e0 = blockIdx.y * len, e1 = e0 + len < per_blk ? e0 + len : per_blk;
+    const unsigned magic_hw = hw > 1 ? (unsigned)(0x100000000ULL / (unsigned)hw) + 1u : 0u;
+    const bool exact = (unsigned long long)per_blk * (unsigned)hw < 0x100000000ULL;
+    const size_t blk_off = (size_t)blk * hw, img_extra = (size_t)(c8 - 1) * hw;
+    auto index_of = [&](unsigned e) {
+        const unsigned img = hw <= 1 ? e : (exact ? __umulhi(e, magic_hw) : e / (unsigned)hw);
+        return (size_t)e + (size_t)img * img_extra + blk_off;
+    };
+    constexpr int kHead = 4;  // first elements requested before the fold (see bn16_apply_pre_kernel)
+    u32x4_t hg[kHead], hz[kHead];
+    size_t hi[kHead];
+#pragma unroll
+    for (int q = 0; q < kHead; ++q) {
+        const unsigned e = e0 + threadIdx.x + 256u * q;
+        hi[q] = e < e1 ? index_of(e) : (size_t)0;
+        hg[q] = hz[q] = (u32x4_t){0u, 0u, 0u, 0u};
+        if (e < e1) {
+            hg[q] = g_in[hi[q]];
+            hz[q] = z[hi[q]];
+        }
+    }
     bn16_fold_parts(pre, blk, n_parts, s_tot, s_sm);
     if (threadIdx.x < 8) {
         const int j = threadIdx.x, ch = blk * 8 + j;
@@ -760,18 +815,8 @@ __global__ __launch_bounds__(256) void bn16_bwd_apply_pre_kernel(const u32x4_t* 
     float k[8], mu[8], is[8], mb[8], mg[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { k[j] = s_k[j]; mu[j] = s_mu[j]; is[j] = s_is[j]; mb[j] = s_mb[j]; mg[j] = s_mg[j]; }
-    const unsigned per_blk = (unsigned)n * (unsigned)hw;
-    const unsigned len = (per_blk + gridDim.y - 1) / gridDim.y;
-    const unsigned e0 = blockIdx.y * len, e1 = e0 + len < per_blk ? e0 + len : per_blk;
-    const unsigned magic_hw = hw > 1 ? (unsigned)(0x100000000ULL / (unsigned)hw) + 1u : 0u;
-    const bool exact = (unsigned long long)per_blk * (unsigned)hw < 0x100000000ULL;
-    const size_t blk_off = (size_t)blk * hw, img_extra = (size_t)(c8 - 1) * hw;
-#pragma unroll 4
-    for (unsigned e = e0 + threadIdx.x; e < e1; e += 256) {
-        const unsigned img = hw <= 1 ? e : (exact ? __umulhi(e, magic_hw) : e / (unsigned)hw);
-        const size_t i = (size_t)e + (size_t)img * img_extra + blk_off;
-        const h16x8 gv = __builtin_bit_cast(h16x8, g_in[i]);
-        const h16x8 zv = __builtin_bit_cast(h16x8, z[i]);
+    auto apply = [&](const u32x4_t gq, const u32x4_t zq, size_t i) {
+        const h16x8 gv = __builtin_bit_cast(h16x8, gq), zv = __builtin_bit_cast(h16x8, zq);
         h16x8 oz;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -783,6 +828,14 @@ __global__ __launch_bounds__(256) void bn16_bwd_apply_pre_kernel(const u32x4_t* 
             oz[j] = (_Float16)d;
         }
         dz[i] = __builtin_bit_cast(u32x4_t, oz);
+    };
+#pragma unroll
+    for (int q = 0; q < kHead; ++q)
+        if (e0 + threadIdx.x + 256u * q < e1) apply(hg[q], hz[q], hi[q]);
+#pragma unroll 4
+    for (unsigned e = e0 + threadIdx.x + 256u * kHead; e < e1; e += 256) {
+        const size_t i = index_of(e);
+        apply(g_in[i], z[i], i);
     }
 }
 
@@ -1445,8 +1498,10 @@ int mp_f16_bn_train_bwd(const void* dy, const void* z, const void* y, const floa
 
 // pixel-range chunks per channel block of the statistics-free apply kernels: every block folds n_parts x 64 bytes of partials first,
 // so blocks are fatter than bn16_apply_chunks' (>= 2048 elements each): ~512 blocks on the large maps, a few dozen on the small ones
-static unsigned bn16_pre_chunks(int n, int c8, int hw) {
-    size_t chunks = (512 + c8 - 1) / c8;
+static unsigned bn16_pre_chunks(int n, int c8, int hw, int n_parts) {
+    // a block folds n_parts x 64 bytes before it streams: with many slots, fewer and fatter blocks (the redundant fold traffic stays
+    // well below the tensor traffic)
+    size_t chunks = ((n_parts > 256 ? 256 : 512) + c8 - 1) / c8;
     const size_t per_blk = (size_t)n * hw;
     while (chunks > 1 && per_blk / chunks < 2048) --chunks;
     return (unsigned)chunks;
@@ -1456,9 +1511,9 @@ static unsigned bn16_pre_chunks(int n, int c8, int hw) {
 static int bn16_prefold(const float*& pre, int& n_parts, int c8, void* workspace, hipStream_t s) {
     if (n_parts <= kMaxFoldParts) return MP_OK;
     float* folded = reinterpret_cast<float*>(workspace);
-    hipLaunchKernelGGL(bn16_fold_kernel, dim3(c8), dim3(256), 0, s, pre, folded, n_parts);
+    hipLaunchKernelGGL(bn16_fold_kernel, dim3(c8, kFoldSplit), dim3(256), 0, s, pre, folded, n_parts);
     pre = folded;
-    n_parts = 1;
+    n_parts = kFoldSplit;
     return check_launch();
 }
 
@@ -1474,10 +1529,10 @@ int mp_f16_bn_train_fwd_stats(const void* z, const float* gamma, const float* be
     hipStream_t s = as_stream(stream);
     int rc = bn16_prefold(partials, n_parts, c8, workspace, s);
     if (rc != MP_OK) return rc;
-    hipLaunchKernelGGL(bn16_apply_pre_kernel, dim3(c8, bn16_pre_chunks(n, c8, hw)), dim3(256), 0, s, reinterpret_cast<const u32x4_t*>(z),
+    hipLaunchKernelGGL(bn16_apply_pre_kernel, dim3(c8, bn16_pre_chunks(n, c8, hw, n_parts)), dim3(256), 0, s, reinterpret_cast<const u32x4_t*>(z),
                        partials, n_parts, gamma, beta, save_mean, save_invstd, moving_mean, moving_var,
-                       reinterpret_cast<const u32x4_t*>(res), reinterpret_cast<u32x4_t*>(y), n, c, c8, hw, (double)n * hw, eps, momentum,
-                       relu ? 1 : 0);
+                       reinterpret_cast<const u32x4_t*>(res), reinterpret_cast<u32x4_t*>(y), n, c, c8, hw, 1.0 / ((double)n * hw),
+                       (double)n * hw > 1.0 ? ((double)n * hw) / ((double)n * hw - 1.0) : 1.0, eps, momentum, relu ? 1 : 0);
     return check_launch();
 }
 
@@ -1492,7 +1547,7 @@ int mp_f16_bn_train_bwd_stats(const void* g, const void* z, const float* gamma, 
     int rc = bn16_prefold(partials, n_parts, c8, workspace, s);
     if (rc != MP_OK) return rc;
     const bool acc = dgamma_acc && dbeta_acc;
-    hipLaunchKernelGGL(bn16_bwd_apply_pre_kernel, dim3(c8, bn16_pre_chunks(n, c8, hw)), dim3(256), 0, s,
+    hipLaunchKernelGGL(bn16_bwd_apply_pre_kernel, dim3(c8, bn16_pre_chunks(n, c8, hw, n_parts)), dim3(256), 0, s,
                        reinterpret_cast<const u32x4_t*>(g), reinterpret_cast<const u32x4_t*>(z), partials, n_parts, gamma, save_mean,
                        save_invstd, dgamma, dbeta, acc ? dgamma_acc : nullptr, acc ? dbeta_acc : nullptr, reinterpret_cast<u32x4_t*>(dz),
                        n, c, c8, hw, (float)(1.0 / ((double)n * hw)));
@@ -1527,6 +1582,19 @@ int mp_f16_ew_stats_parts(int n, int c, int hw) {
     return (int)bn16_apply_chunks(n, (c + 7) / 8, hw);
 }
 
+// a term at scale s sums s x s gradient elements per output element: blocks of >= 1024 / s^2 outputs (>= 64) keep the chip busy on
+// the low-resolution terms
+int mp_f16_fuse_term_stats_parts(int n, int c, int h, int w, int s) {
+    if (n <= 0 || c <= 0 || h <= 0 || w <= 0 || s <= 0 || (h % s) || (w % s)) return 0;
+    const int c8 = (c + 7) / 8;
+    const size_t per_blk = (size_t)n * (h / s) * (w / s);
+    size_t min_elems = 1024 / ((size_t)s * s);
+    if (min_elems < 64) min_elems = 64;
+    size_t chunks = (768 + c8 - 1) / c8;
+    while (chunks > 1 && per_blk / chunks < min_elems) --chunks;
+    return (int)chunks;
+}
+
 int mp_f16_sum_tensors_stats(const void* a, const void* b, const void* c, const void* d, void* out, const void* z, const void* y,
                              int relu, int n, int ch, int hw, float* partials, size_t partials_bytes, mp_stream_t stream) {
     if (!a || !b || !out || !z || !partials || (relu && !y)) return MP_ERR_NULL;
@@ -1547,7 +1615,7 @@ int mp_f16_fuse_sum_bwd_term_stats(const void* dy, const void* out, void* dt, in
     if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return MP_ERR_SHAPE;
     const int sh = log2_exact_t(s);
     if (sh < 0 || (h % s) || (w % s)) return MP_ERR_UNSUPPORTED;
-    const int c8 = (c + 7) / 8, lhw = (h >> sh) * (w >> sh), parts = mp_f16_ew_stats_parts(n, c, lhw);
+    const int c8 = (c + 7) / 8, parts = mp_f16_fuse_term_stats_parts(n, c, h, w, s);
     if (partials_bytes < (size_t)c8 * parts * 16 * sizeof(float)) return MP_ERR_WORKSPACE;
     hipLaunchKernelGGL(fuse_sum16_bwd_stats_kernel, dim3(c8, parts), dim3(256), 0, as_stream(stream), reinterpret_cast<const u32x4_t*>(dy),
                        reinterpret_cast<const u32x4_t*>(out), reinterpret_cast<const u32x4_t*>(z_t), reinterpret_cast<const u32x4_t*>(y_t),

@@ -615,7 +615,7 @@ class FuseSum16Fn(torch.autograd.Function):
         plain = [None, None, None, None]
         for k, (dst, sc, link) in enumerate(zip(outs, scs, ctx.links)):
             if (link is not None and link.claimed == 1 and (_bn_fuse_parts() & 8) and tuple(link.z.shape) == tuple(dst.shape)):
-                n_parts = lib.mp_f16_ew_stats_parts(n, c8 * 8, (h // sc) * (w // sc))
+                n_parts = lib.mp_f16_fuse_term_stats_parts(n, c8 * 8, h, w, sc)
                 part = torch.empty(c8 * n_parts * 16, device=out.device, dtype=torch.float32)
                 _lib.check(lib.mp_f16_fuse_sum_bwd_term_stats(_lib.ptr(dy), _lib.ptr(out), _lib.ptr(dst), sc, n, c8 * 8, h, w, 1,
                                                               _lib.ptr(link.z), _lib.ptr(link.y) if link.relu else None, int(link.relu),

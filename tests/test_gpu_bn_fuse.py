@@ -161,7 +161,7 @@ def test_conv_epilogue_statistics_backward(case, relu, monkeypatch):
 
 
 @pytest.mark.parametrize("c,h,w,relu,with_res,n_parts", [(32, 64, 48, True, True, 37), (64, 16, 12, True, False, 5),
-                                                         (256, 8, 6, True, False, 1), (48, 24, 18, False, False, 700),
+                                                         (256, 8, 6, True, False, 1), (48, 24, 18, False, False, 700), (64, 16, 12, True, False, 1500),
                                                          (17, 8, 6, False, False, 3)])
 def test_bn_apply_only_passes_vs_reduction_passes(c, h, w, relu, with_res, n_parts):
     """mp_f16_bn_train_fwd_stats / _bwd_stats fed with EXACT partial sums (made here in fp64, split over n_parts slots) against the
@@ -282,7 +282,7 @@ def test_exchange_unit_backward_term_with_statistics(s, relu_t):
         args[0], args[1] = _lib.ptr(ref), s
         _lib.check(LIB.mp_f16_fuse_upsample_sum_bwd(_lib.ptr(dy), _lib.ptr(outp), None, *args, n, c, h, w, 1, _lib.stream()), "bwd")
     want = torch.where(y.c8_tensor > 0, ref.c8_tensor, torch.zeros_like(ref.c8_tensor)) if relu_t else ref.c8_tensor
-    n_parts = LIB.mp_f16_ew_stats_parts(n, c, lh * lw)
+    n_parts = LIB.mp_f16_fuse_term_stats_parts(n, c, h, w, s)
     part = torch.full((c // 8 * n_parts * 16,), float("nan"), device=DEV)
     got = ActC8(n, c, lh, lw, DEV)
     _lib.check(LIB.mp_f16_fuse_sum_bwd_term_stats(_lib.ptr(dy), _lib.ptr(outp), _lib.ptr(got), s, n, c, h, w, 1, _lib.ptr(z),
