@@ -299,15 +299,18 @@ class TopDownAffine:
         out = dict()
         out["image"] = self._launch([image], [0], trans[None], False, None, self.NORMALIZE_MEAN, self.NORMALIZE_STD)[0]
         if "keypoints" in state:
-            kp = state["keypoints"]
-            if self.use_udp:
-                kp[:, 0:2] = np.dot(np.concatenate((kp[:, 0:2], np.ones((kp.shape[0], 1), dtype=np.float32)), axis=-1), trans.T)
-            else:
-                for i in range(kp.shape[0]):
-                    if kp[i, 2] > 0.0:
-                        kp[i, 0:2] = np.array(trans) @ np.array([kp[i, 0], kp[i, 1], 1.0])
-            out["keypoints"] = kp
+            out["keypoints"] = self.transform_keypoints(state["keypoints"], trans)
         return out
+
+    def transform_keypoints(self, kp: np.ndarray, trans: np.ndarray) -> np.ndarray:
+        """Key points through the crop matrix, in place (:204-207 visible joints only; UDP :242-245 all joints)."""
+        if self.use_udp:
+            kp[:, 0:2] = np.dot(np.concatenate((kp[:, 0:2], np.ones((kp.shape[0], 1), dtype=np.float32)), axis=-1), trans.T)
+        else:
+            for i in range(kp.shape[0]):
+                if kp[i, 2] > 0.0:
+                    kp[i, 0:2] = np.array(trans) @ np.array([kp[i, 0], kp[i, 1], 1.0])
+        return kp
 
 
 def fliplr_joints(keypoints: np.ndarray, img_width: int, flip_pairs=None, flip_index: Optional[np.ndarray] = None) -> np.ndarray:

@@ -275,6 +275,42 @@ def gen_nms():
     print("nms.npz", len(out), "arrays")
 
 
+def gen_dataset():
+    """``TopDownDataset._sanitize_bbox`` (mindpose/data/dataset/topdown.py:123-137) from the reference itself: the module imports
+    only numpy / logging / copy, so it loads by file path.  Inputs: boxes around and across the image border, zero / negative
+    extents, annotations without ``bbox`` or with ``area`` <= 0; outputs: which annotations survive and their clipped boxes."""
+    spec = importlib.util.spec_from_file_location("ref_topdown_dataset", REF + "/data/dataset/topdown.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.RandomState(7)
+    out = {}
+    for case, (w, h) in enumerate([(640, 480), (333, 500), (64, 64)]):
+        n = 40
+        boxes = np.stack([rng.uniform(-0.3 * w, 1.1 * w, n), rng.uniform(-0.3 * h, 1.1 * h, n), rng.uniform(-5, 0.8 * w, n),
+                          rng.uniform(-5, 0.8 * h, n)], axis=1)
+        boxes[::7] = np.round(boxes[::7])          # integer boxes (COCO has both)
+        boxes[3] = [10.0, 10.0, 1.0, 50.0]         # one pixel wide: x2 == x1 -> dropped
+        boxes[4] = [w - 1.0, 5.0, 30.0, 30.0]      # starts on the last column
+        area = rng.uniform(-1.0, 50.0, n)          # some <= 0
+        has_area = rng.rand(n) < 0.8
+        has_bbox = rng.rand(n) < 0.9
+        annos = []
+        for i in range(n):
+            a = dict(id=i)
+            if has_bbox[i]:
+                a["bbox"] = [float(v) for v in boxes[i]]
+            if has_area[i]:
+                a["area"] = float(area[i])
+            annos.append(a)
+        kept = mod.TopDownDataset._sanitize_bbox(annos, w, h)
+        out[f"c{case}_size"] = np.array([w, h])
+        out[f"c{case}_boxes"], out[f"c{case}_area"] = boxes, area
+        out[f"c{case}_has_area"], out[f"c{case}_has_bbox"] = has_area, has_bbox
+        out[f"c{case}_kept_ids"] = np.array([a["id"] for a in kept], dtype=np.int64)
+        out[f"c{case}_kept_boxes"] = np.array([a["bbox"] for a in kept], dtype=np.float64).reshape(-1, 4)
+    np.savez_compressed(os.path.join(HERE, "dataset.npz"), source="reference mindpose/data/dataset/topdown.py::_sanitize_bbox", **out)
+
+
 def gen_helpers():
     """Point helpers of the REFERENCE's mindpose/data/transform/utils.py (numpy only): affine_transform, rotate_point,
     warp_affine_joints, pad_to_same, transform_keypoints on seeded inputs."""
@@ -307,7 +343,9 @@ def gen_helpers():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["targets", "decoder", "flip", "loss", "geometry", "nms", "helpers"]
+    which = sys.argv[1:] or ["targets", "decoder", "flip", "loss", "geometry", "nms", "helpers", "dataset"]
+    if "dataset" in which:
+        gen_dataset()
     if "helpers" in which:
         gen_helpers()
     if "nms" in which:

@@ -160,16 +160,46 @@ def test_ap_chain_real_network_through_ckpt_vs_oracle_chain(tmp_path):
     for k, v in src.state_dict().items():
         assert torch.equal(net.state_dict()[k].cpu(), v), k
 
+    # tools/eval.py:30-52: the records come from the detection file through create_dataset, the crops from create_pipeline
+    # (Decode -> topdown_box_to_center_scale -> topdown_affine -> Normalize -> HWC2CHW, the pixel steps as one HIP launch per batch)
+    scores = np.linspace(0.5, 1.0, n).astype(np.float32)
+    img_dir = os.path.join(tmp_path, "val2017")
+    os.makedirs(img_dir)
+    for i, im in enumerate(images):
+        with open(os.path.join(img_dir, f"{i:012d}.jpg"), "wb") as f:  # a .npy payload under the annotation's file name (no JPEG
+            np.save(f, im)                                               # encoder offline; the pipeline's decoder sniffs the magic)
+    ann0 = os.path.join(tmp_path, "person_keypoints_images_only.json")
+    _write_annotations(ann0, boxes, image_index, np.zeros((n, 17, 2), np.float32))
+    det_file = os.path.join(tmp_path, "detections.json")
+    dets = [dict(image_id=100 + int(im), category_id=1, bbox=[float(v) for v in box], score=float(sc))
+            for box, im, sc in zip(boxes, image_index, scores)]
+    dets.insert(3, dict(image_id=100, category_id=1, bbox=[1.0, 1.0, 50.0, 50.0], score=0.01))   # below det_bbox_thr
+    dets.insert(5, dict(image_id=101, category_id=3, bbox=[1.0, 1.0, 50.0, 50.0], score=0.99))   # not a person
+    with open(det_file, "w") as f:
+        json.dump(dets, f)
+    dataset = mp.create_dataset(img_dir, ann0, dataset_format="coco_topdown", is_train=False, use_gt_bbox_for_val=False,
+                                detection_file=det_file, num_workers=2, config=dict(det_bbox_thr=0.3))
+    assert len(dataset) == n
+    pipeline = mp.create_pipeline(dataset, ["topdown_box_to_center_scale", "topdown_affine"], method="topdown", batch_size=8,
+                                  is_train=False, num_workers=2, config=DATA_CFG)
+    batches = list(pipeline)
+    assert len(batches) == len(pipeline) == 2 and list(batches[0]) == ["image", "image_file", "boxes", "bbox_ids", "center", "scale", "bbox_scores"]
+    # the same crops / geometry as the transforms called directly
     b2cs = mp.TopDownBoxToCenterScale(is_train=False, config=DATA_CFG)
     centers, scales = b2cs.transform_batch(boxes)
     aff = mp.TopDownAffine(is_train=False, config=DATA_CFG)
     crops, _ = aff.crop_batch([torch.from_numpy(im).to(DEV) for im in images], centers, scales, image_index=image_index)
+    assert torch.equal(torch.cat([b["image"] for b in batches]), crops)
+    assert np.array_equal(torch.cat([b["center"] for b in batches]).cpu().numpy(), centers)
+    assert np.array_equal(torch.cat([b["scale"] for b in batches]).cpu().numpy(), scales)
+    assert np.array_equal(np.concatenate([b["bbox_ids"] for b in batches]), np.arange(n))
+    assert np.array_equal(np.concatenate([b["boxes"] for b in batches]), boxes)
+    assert batches[1]["image_file"][-1] == os.path.join(img_dir, f"{N_IMAGES - 1:012d}.jpg")
     decoder = mp.create_decoder("topdown_heatmap", shift_coordinate=True).to(DEV)
     eval_net = mp.create_eval_network(net, decoder, output_raw=True)
     inf_cfg = dict(has_heatmap_output=True, hflip_tta=True, shift_heatmap=True, flip_pairs=COCO_FLIP_PAIRS)
     inferencer = mp.TopDownHeatMapInferencer(eval_net, config=inf_cfg, decoder=decoder)
-    scores = np.linspace(0.5, 1.0, n).astype(np.float32)
-    records = inferencer(_batches(crops, centers, scales, scores, image_index))
+    records = inferencer(pipeline)
 
     # the oracle chain on the same files: crop (cv2.warpAffine restatement + Normalize + HWC2CHW), network twice, flip-back with
     # the one-pixel shift, average, arg-max + shift decode

@@ -120,3 +120,62 @@ def test_training_augmentation_chain_flip_in_kernel():
         src = np.ascontiguousarray(img[:, ::-1]) if flips[i] else img
         ref, _ = ol.crop(src, centers[i], scales[i], rots[i], [192, 256])
         assert np.array_equal(got[i], ref), i
+
+
+def test_training_pipeline_batches_match_per_sample_transforms(tmp_path):
+    """create_dataset / create_pipeline in training mode (data_factory.py:116-151 with the recipe's transform list): the batched
+    GPU pipeline (one crop launch + one target launch per batch) against the SAME transforms applied sample by sample with the
+    same random draws - crops and targets bit-exact - plus shuffling, drop_remainder and the final columns."""
+    import json
+    import os
+    from oracle import loader as ol
+    from oracle import target as otarget
+    rng = np.random.RandomState(5)
+    n_img = 7
+    cfg = dict(image_size=[192, 256], heatmap_size=[48, 64], pixel_std=200.0, scale_padding=1.25, upper_body_ids=list(range(11)),
+               flip_pairs=[[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]], det_bbox_thr=0.0)
+    images, anns = [], []
+    for i in range(n_img):
+        im = rng.randint(0, 256, (120 + 8 * i, 160, 3)).astype(np.uint8)
+        with open(os.path.join(tmp_path, f"{i}.jpg"), "wb") as f:
+            np.save(f, im)
+        images.append(dict(id=i + 1, file_name=f"{i}.jpg", width=160, height=120 + 8 * i))
+        kp = np.concatenate([rng.uniform(20, 100, (17, 2)), rng.randint(0, 3, (17, 1))], axis=1)
+        kp[kp[:, 2] == 0, :2] = 0
+        anns.append(dict(id=i + 1, image_id=i + 1, category_id=1, iscrowd=0, bbox=[15.0, 12.0, 100.0, 90.0], area=9000.0,
+                         num_keypoints=int((kp[:, 2] > 0).sum()), keypoints=kp.reshape(-1).tolist()))
+    ann = os.path.join(tmp_path, "train.json")
+    with open(ann, "w") as f:
+        json.dump(dict(images=images, annotations=anns, categories=[dict(id=1, name="person")]), f)
+    names = ["topdown_box_to_center_scale", {"topdown_horizontal_random_flip": {"flip_prob": 0.5}}, "topdown_halfbody_transform",
+             "topdown_randomscale_rotation", "topdown_affine", {"topdown_generate_target": {"sigma": 2.0}}]
+    ds = mp.create_dataset(str(tmp_path), ann, is_train=True, config=cfg)
+    pipe = mp.create_pipeline(ds, names, batch_size=3, is_train=True, config=cfg)
+    assert len(pipe) == 2  # 7 samples, batch 3, drop_remainder
+    order = ds.indices().tolist()
+    assert sorted(order) == list(range(n_img)) and order != list(range(n_img))
+    np.random.seed(11)
+    batches = list(pipe)
+    assert len(batches) == 2 and list(batches[0]) == ["image", "target", "target_weight"]
+    assert batches[0]["image"].shape == (3, 3, 256, 192) and batches[0]["target"].shape == (3, 17, 64, 48)
+    # the same samples, one by one, with the same draws: host transforms of the package + the oracle's crop / target
+    from mindpose_amd.data.data_factory import _convert_names_to_transform
+    ts = _convert_names_to_transform(names, is_train=True, config=cfg)
+    np.random.seed(11)
+    k = 0
+    for b in batches:
+        for j in range(3):
+            rec = ds.source.record(order[k])
+            k += 1
+            img = np.load(rec["image_file"])
+            st = dict(image=img, boxes=np.asarray(rec["boxes"], np.float32), keypoints=np.asarray(rec["keypoints"], np.float32),
+                      rotation=np.float32(rec["rotation"]))
+            for t in ts[:4]:
+                st.update(t.transform(st))
+            flipped = st["image"].strides[1] < 0
+            src = np.ascontiguousarray(st["image"])
+            crop, trans = ol.crop(src, st["center"], st["scale"], float(st["rotation"]), [192, 256])
+            assert np.array_equal(b["image"][j].cpu().numpy(), crop), (k, flipped)
+            kp = ts[4].transform_keypoints(st["keypoints"].copy(), ts[4].get_matrix(st["center"], st["scale"], st["rotation"]))
+            tgt, wgt = otarget.generate_target(kp[None], (192, 256), (48, 64), sigma=2.0)
+            assert np.array_equal(b["target"][j].cpu().numpy(), tgt[0]) and np.array_equal(b["target_weight"][j].cpu().numpy(), wgt[0])
