@@ -310,6 +310,8 @@ int mp_comm_last_error(void);
 int mp_comm_get_unique_id(void* id128_host);
 int mp_comm_init_rank(void** comm_out, int nranks, const void* id128_host, int rank);
 int mp_comm_destroy(void* comm);
+/* ncclCommCount: the number of ranks the communicator itself reports (-1 on error) */
+int mp_comm_count(void* comm);
 int mp_allreduce_grads(void* comm, float* arena_dev, size_t count, int average, mp_stream_t stream);
 int mp_reduce_scatter_allgather_grads(void* comm, float* arena_dev, size_t count, int nranks, int rank, int average,
                                       mp_stream_t stream);

@@ -91,6 +91,7 @@ _PROTOTYPES = {
     "mp_comm_get_unique_id": (c_int, [ctypes.c_void_p]),
     "mp_comm_init_rank": (c_int, [ctypes.POINTER(ctypes.c_void_p), c_int, ctypes.c_void_p, c_int]),
     "mp_comm_destroy": (c_int, [ctypes.c_void_p]),
+    "mp_comm_count": (c_int, [ctypes.c_void_p]),
     "mp_allreduce_grads": (c_int, [ctypes.c_void_p, c_f32p, c_size_t, c_int, ctypes.c_void_p]),
     "mp_reduce_scatter_allgather_grads": (c_int, [ctypes.c_void_p, c_f32p, c_size_t, c_int, c_int, c_int, ctypes.c_void_p]),
     "mp_f16_bn_train_fwd": (c_int, [c_f32p] * 9 + [c_int] * 3 + [ctypes.c_float, ctypes.c_float, c_int, c_f32p, c_size_t, ctypes.c_void_p]),

@@ -55,6 +55,7 @@ struct Rccl {
     int (*GetUniqueId)(void*) = nullptr;
     int (*CommInitRank)(void**, int, Id128, int) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*ReduceScatter)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
@@ -80,6 +81,7 @@ Rccl& rccl() {
         t.GetUniqueId = reinterpret_cast<decltype(t.GetUniqueId)>(dlsym(scope, "ncclGetUniqueId"));
         t.CommInitRank = reinterpret_cast<decltype(t.CommInitRank)>(dlsym(scope, "ncclCommInitRank"));
         t.CommDestroy = reinterpret_cast<decltype(t.CommDestroy)>(dlsym(scope, "ncclCommDestroy"));
+        t.CommCount = reinterpret_cast<decltype(t.CommCount)>(dlsym(scope, "ncclCommCount"));
         t.AllReduce = reinterpret_cast<decltype(t.AllReduce)>(dlsym(scope, "ncclAllReduce"));
         t.ReduceScatter = reinterpret_cast<decltype(t.ReduceScatter)>(dlsym(scope, "ncclReduceScatter"));
         t.AllGather = reinterpret_cast<decltype(t.AllGather)>(dlsym(scope, "ncclAllGather"));
@@ -164,6 +166,17 @@ int mp_comm_destroy(void* comm) {
         return MP_ERR_HIP;
     }
     return MP_OK;
+}
+
+int mp_comm_count(void* comm) {
+    if (!comm || !rccl().ok || !rccl().CommCount) return -1;
+    int n = -1;
+    const int rc = rccl().CommCount(comm, &n);
+    if (rc != 0) {
+        g_last_rccl_error = rc;
+        return -1;
+    }
+    return n;
 }
 
 int mp_allreduce_grads(void* comm, float* arena, size_t count, int average, mp_stream_t stream) {

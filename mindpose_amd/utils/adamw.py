@@ -62,6 +62,7 @@ class _ArenaOptimizer:
         self._grad_flat = self.grads.arena
         self._overflow = torch.zeros(1, device=dev, dtype=torch.int32)  # device flag of the loss-scale overflow check
         self.global_step = 0
+        self.time_comm, self.comm_events = False, []
 
     def zero_grad(self) -> None:
         self.grads.begin_step()
@@ -77,7 +78,16 @@ class _ArenaOptimizer:
         scale and checked: on overflow (inf / nan anywhere) the update is skipped and the scale halves, exactly one
         host read-back per step; returns whether the parameters were updated."""
         lib = _lib.load()
-        self.grads.finish()
+        if getattr(self, "time_comm", False) and self.grads.active and self._grad_flat.is_cuda:
+            # bench.py's DP leg: device time from "all gradients are in the arena" to "the bucket all-reduces have landed" as the
+            # compute stream sees it (the native transport runs them on its own stream; finish() makes this stream wait for them)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.grads.finish()
+            e1.record()
+            self.comm_events.append((e0, e1))
+        else:
+            self.grads.finish()
         # gradient scale the update kernels apply while reading the arena: 1 / loss_scale (amp O2) x 1 / world (gradient mean)
         self.grad_scale = self.grads.mean_scale
         if loss_scale_manager is not None:

@@ -69,6 +69,10 @@ class NativeComm:
         ev.record(self.stream)
         return ev
 
+    def count(self) -> int:
+        """ncclCommCount of the library's communicator."""
+        return int(self.lib.mp_comm_count(self.handle))
+
     def close(self) -> None:
         """ncclCommDestroy (after the communicator's stream has drained); idempotent."""
         if self.handle:
@@ -156,6 +160,13 @@ class GradientAverager:
             # themselves (train_ops._direct_grad) instead of returning a tensor for autograd's AccumulateGrad to add
             p._mp_grad_direct = not self.overlap
         self.begin_step()
+
+    def comm_ranks(self) -> int:
+        """Ranks of the communicator the collectives run on - asked of the communicator (ncclCommCount for the native transport,
+        the process group's size for torch.distributed), not of the launcher's arguments."""
+        if self.native is not None:
+            return self.native.count()
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
     @property
     def mean_scale(self) -> float:

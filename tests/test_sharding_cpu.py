@@ -127,3 +127,53 @@ def test_bench_spawns_its_own_ranks_without_a_launcher(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def _dp_leg_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import importlib
+    import json
+    from mindpose_amd.utils.grad_allreduce import GradientAverager
+    bench = importlib.import_module("bench")
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+
+    class Opt:  # the slice of the arena optimizers dp_leg_report reads
+        def __init__(self):
+            self.grads = GradientAverager(model.parameters(), bucket_mb=1e-4, overlap=False, mean="pass")
+            self.time_comm, self.comm_events = False, []
+
+    opt = Opt()
+    x = torch.randn(5, 8, generator=torch.Generator().manual_seed(rank))
+
+    def step():
+        opt.grads.begin_step()
+        model(x).square().mean().backward()
+        opt.grads.finish()
+
+    rep = bench.dp_leg_report(step, opt, dist, world, rank, torch.device("cpu"), per_gpu_batch=5, steps=3, warmup=1)
+    # after the leg every rank holds the MEAN gradient
+    g = opt.grads.arena.clone()
+    ref = [torch.zeros_like(g) for _ in range(world)]
+    dist.all_gather(ref, g)
+    assert all(torch.equal(r, g) for r in ref)
+    if rank == 0:
+        with open(os.path.join(out_dir, "dp_leg.json"), "w") as f:
+            json.dump(rep, f)
+    dist.destroy_process_group()
+
+
+def test_dp_training_leg_report_keys_world_size_2_gloo(tmp_path):
+    """bench.py attaches `extra_workloads.config3_train_ampO2_dp` on multi-rank runs: the reporting code on two
+    gloo ranks with a stand-in model - keys, the communicator's own rank count, aggregate throughput."""
+    import json
+    port = _free_port()
+    mp_.spawn(_dp_leg_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    rep = json.load(open(tmp_path / "dp_leg.json"))
+    for key in ("value", "unit", "ms_per_step", "steps", "warmup", "per_gpu_batch", "global_batch", "allreduce_ms_per_step", "rccl_nranks",
+                "transport", "gradient_bytes", "buckets", "mean", "n_gpus_seen"):
+        assert key in rep, key
+    assert rep["rccl_nranks"] == 2 and rep["global_batch"] == 10 and rep["steps"] == 3 and "gloo" in rep["transport"]
+    assert rep["value"] > 0 and rep["buckets"] >= 2 and rep["gradient_bytes"] == 4 * (8 * 16 + 16 + 16 * 4 + 4)
+    assert rep["allreduce_ms_per_step"] is None  # no device events on CPU tensors
