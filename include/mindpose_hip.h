@@ -501,6 +501,14 @@ int mp_sum_tensors(const void* a_dev, const void* b_dev, const void* c_dev, cons
 size_t mp_f16_conv_wgrad_workspace_bytes(const mp_conv_desc* desc);
 int mp_f16_conv_wgrad(const mp_conv_desc* desc, const void* x_c8_dev, const void* dz_c8_dev, float* dw_dev, float scale,
                       int accumulate, void* workspace_dev, size_t workspace_bytes, mp_stream_t stream);
+/* The same for 1 .. 8 layers of ONE shape in a single launch pair (weight gradients are leaves of the backward pass, tools/train.py:233:
+ * nothing waits for them before the update, so the layers of an HRNet branch - hrnet.py:202-241, eight 3x3 convs of one shape - are
+ * collected and run together): per layer fewer, longer pixel slabs, 1/n of the launches.  x / dz / dw: HOST arrays of n_jobs device
+ * pointers (they travel in the kernel arguments: no upload, hipGraph-capturable).  Same fixed-order reduction per layer as the
+ * single-layer entry; a layer's result does not depend on its group (slab partition aside: fp32 summation order). */
+size_t mp_f16_conv_wgrad_grouped_workspace_bytes(const mp_conv_desc* desc, int n_jobs);
+int mp_f16_conv_wgrad_grouped(const mp_conv_desc* desc, const void* const* x_dev, const void* const* dz_dev, float* const* dw_dev,
+                              int n_jobs, float scale, int accumulate, void* workspace_dev, size_t workspace_bytes, mp_stream_t stream);
 
 /* ---- training kernels of the SimpleBaseline-ResNet family ---------------------------------------------------------------
  * mp_maxpool3x3s2_same_bwd: backward of nn.MaxPool2d(3, 2, pad_mode="same") (resnet.py:190), gradient to the first maximum of

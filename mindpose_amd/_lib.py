@@ -100,6 +100,9 @@ _PROTOTYPES = {
     "mp_f16_fuse_upsample_sum_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_int, c_f32p, c_int] + [c_int] * 5 + [ctypes.c_void_p]),
     "mp_f16_conv_wgrad_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "mp_f16_conv_wgrad": (c_int, [ctypes.POINTER(ConvDesc), c_f32p, c_f32p, c_f32p, ctypes.c_float, c_int, c_f32p, c_size_t, ctypes.c_void_p]),
+    "mp_f16_conv_wgrad_grouped_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc), c_int]),
+    "mp_f16_conv_wgrad_grouped": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                                          ctypes.POINTER(ctypes.c_void_p), c_int, ctypes.c_float, c_int, c_f32p, c_size_t, ctypes.c_void_p]),
     "mp_maxpool3x3s2_same_bwd": (c_int, [c_f32p] * 3 + [c_int] * 4 + [ctypes.c_void_p]),
     "mp_stem_conv_wgrad": (c_int, [c_f32p] * 3 + [c_int] * 6 + [ctypes.c_void_p]),
     "mp_gather_phase": (c_int, [c_f32p] * 2 + [c_int] * 6 + [ctypes.c_void_p]),

@@ -42,7 +42,14 @@ struct Wgrad16Params {
     int xslots, zslots, pieces;  // == 4 (mod 16) each: the two blocks a 16-lane group reads land on disjoint banks
     int x_pieces, z_base;        // DMA pieces of the input image; first element of the gradient image (a multiple of 64)
     unsigned magic_xs, magic_zs, magic_p;
+    // grouped launch (mp_f16_conv_wgrad_grouped): blockIdx.z = job, up to kWgradJobs layers of ONE shape; the operand pointers
+    // travel by value in the kernel arguments (nothing to upload, hipGraph-capturable); n_jobs == 0: the single-layer launch
+    int n_jobs;
+    const void* jx[8];
+    const void* jdz[8];
+    float* jdw[8];
 };
+constexpr int kWgradJobs = 8;
 
 __device__ __forceinline__ s16x4 tr_read(const _Float16* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
@@ -104,8 +111,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16_kernel(const Wgrad16Par
         }
     }
 
-    const __amdgpu_buffer_rsrc_t rs_z = make_rsrc(p.dz, (size_t)p.N * p.C8out * p.Ho * p.Wo * 16);
-    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x, (size_t)p.N * p.C8in * p.H * p.W * 16);
+    const void* const x_ptr = p.n_jobs ? p.jx[blockIdx.z] : p.x;
+    const void* const dz_ptr = p.n_jobs ? p.jdz[blockIdx.z] : p.dz;
+    const __amdgpu_buffer_rsrc_t rs_z = make_rsrc(dz_ptr, (size_t)p.N * p.C8out * p.Ho * p.Wo * 16);
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x_ptr, (size_t)p.N * p.C8in * p.H * p.W * 16);
     u32x4 vz[NZ], vx[NX];
     auto stage_load = [&](int t) {
         const int n = t / p.tiles_y, ty = t - n * p.tiles_y;
@@ -180,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16_kernel(const Wgrad16Par
     }
 
     // D: lane holds couts 4g .. 4g+3 (rows) of cin (lane & 15) (column) -> slab [Cout][Cin][T]
-    float* slab = p.slabs + (size_t)blockIdx.y * p.Cout * p.Cin * T;
+    float* slab = p.slabs + ((size_t)blockIdx.z * p.splits + blockIdx.y) * p.Cout * p.Cin * T;
     const int ci = ci_tile * 32 + ci_sub * 16 + (lane & 15);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -245,8 +254,10 @@ __device__ __forceinline__ void wgrad_dma_body(const Wgrad16Params& p) {
     const int t_begin = blockIdx.y * p.tiles_per_split;
     const int t_end = min(t_begin + p.tiles_per_split, p.tiles);
 
-    const __amdgpu_buffer_rsrc_t rs_z = make_rsrc(p.dz, (size_t)p.N * p.C8out * p.Ho * p.Wo * 16);
-    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x, (size_t)p.N * p.C8in * p.H * p.W * 16);
+    const void* const x_ptr = p.n_jobs ? p.jx[blockIdx.z] : p.x;
+    const void* const dz_ptr = p.n_jobs ? p.jdz[blockIdx.z] : p.dz;
+    const __amdgpu_buffer_rsrc_t rs_z = make_rsrc(dz_ptr, (size_t)p.N * p.C8out * p.Ho * p.Wo * 16);
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x_ptr, (size_t)p.N * p.C8in * p.H * p.W * 16);
 
     // DMA piece descriptors, decoded once: piece = 64 consecutive slots of the buffer; slot -> (image kind, block, row, column)
     unsigned piece_rel[NP];  // byte offset relative to the tile origin of its tensor; kOob = padding slot
@@ -319,7 +330,7 @@ __device__ __forceinline__ void wgrad_dma_body(const Wgrad16Params& p) {
     }
 
     // D: lane holds couts 4g .. 4g+3 (rows) of cin (lane & 15) (column) -> slab [Cout][Cin][T]
-    float* slab = p.slabs + (size_t)blockIdx.y * p.Cout * p.Cin * T;
+    float* slab = p.slabs + ((size_t)blockIdx.z * p.splits + blockIdx.y) * p.Cout * p.Cin * T;
     const int ci = ci_tile * 32 + ci_sub * 16 + (lane & 15);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -331,8 +342,14 @@ __device__ __forceinline__ void wgrad_dma_body(const Wgrad16Params& p) {
     }
 }
 
-__global__ __launch_bounds__(256) void wgrad16_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, size_t count,
+struct WgradDst {  // destinations of a grouped reduce: blockIdx.y = job
+    float* dw[8];
+};
+
+__global__ __launch_bounds__(256) void wgrad16_reduce_kernel(const float* __restrict__ slabs, WgradDst dst, size_t count,
                                                              int splits, float scale, int accumulate) {
+    float* __restrict__ dw = dst.dw[blockIdx.y];
+    slabs += (size_t)blockIdx.y * splits * count;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
         float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         int k = 0;
@@ -351,8 +368,10 @@ __global__ __launch_bounds__(256) void wgrad16_reduce_kernel(const float* __rest
 // per element, thread g summing slabs g, g + G, ... (four interleaved partial sums), then a fixed-order combine through LDS
 // (deterministic): G times the blocks, 1 / G of the serial depth.
 template <int G>
-__global__ __launch_bounds__(256) void wgrad16_reduce_grouped_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
+__global__ __launch_bounds__(256) void wgrad16_reduce_grouped_kernel(const float* __restrict__ slabs, WgradDst dst,
                                                                      size_t count, int splits, float scale, int accumulate) {
+    float* __restrict__ dw = dst.dw[blockIdx.y];
+    slabs += (size_t)blockIdx.y * splits * count;
     constexpr int E = 256 / G;
     __shared__ float sm[G][E];
     const int e = threadIdx.x % E, g = threadIdx.x / E;
@@ -414,7 +433,7 @@ bool geometry_dma(Wgrad16Params& p, int KS, int S, size_t& lds_bytes) {
 
 constexpr int kNZ = 4, kNX = 10;
 
-int geometry(const mp_conv_desc* d, Wgrad16Params& p, size_t& lds_bytes) {
+int geometry(const mp_conv_desc* d, Wgrad16Params& p, size_t& lds_bytes, int n_jobs = 1) {
     if (!d) return MP_ERR_NULL;
     if (d->n <= 0 || d->cin <= 0 || d->cout <= 0 || d->h <= 0 || d->w <= 0 || d->conv_h <= 0 || d->conv_w <= 0) return MP_ERR_SHAPE;
     // 1x1 / 3x3 with padding k/2, or the 4x4 stride-2 padding-1 form (the transposed convolution's weight gradient)
@@ -456,7 +475,9 @@ int geometry(const mp_conv_desc* d, Wgrad16Params& p, size_t& lds_bytes) {
         const int v = atoi(e);
         if (v >= 1) target = v;
     }
-    int splits = target / ct;
+    // a grouped launch spreads ~768 workgroups over its layers: per layer fewer, longer pixel slabs - the slab traffic (written here,
+    // re-read by the reduce) and the per-workgroup prologue / epilogue shrink by the group size
+    int splits = n_jobs > 1 ? (target + target / 2) / (ct * n_jobs) : target / ct;
     if (splits < 1) splits = 1;
     if (splits > p.tiles) splits = p.tiles;
     p.tiles_per_split = (p.tiles + splits - 1) / splits;
@@ -476,7 +497,7 @@ int launch_wgrad16_dma(const Wgrad16Params& p, size_t lds, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
     }
-    hipLaunchKernelGGL(kern, dim3(((p.Cout + 31) / 32) * p.ci_tiles, p.splits), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3(((p.Cout + 31) / 32) * p.ci_tiles, p.splits, p.n_jobs ? p.n_jobs : 1), dim3(256), lds, s, p);
     return check_launch();
 }
 
@@ -489,7 +510,31 @@ int launch_wgrad16(const Wgrad16Params& p, size_t lds, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
     }
-    hipLaunchKernelGGL(kern, dim3(((p.Cout + 31) / 32) * p.ci_tiles, p.splits), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3(((p.Cout + 31) / 32) * p.ci_tiles, p.splits, p.n_jobs ? p.n_jobs : 1), dim3(256), lds, s, p);
+    return check_launch();
+}
+
+// launches + fixed-order slab reduction of 1 .. kWgradJobs layers of one shape
+int wgrad16_run(const mp_conv_desc* desc, Wgrad16Params& p, size_t lds, const WgradDst& dst, int jobs, float scale, int accumulate,
+                hipStream_t s) {
+    int rc;
+    if (desc->kh == 4) rc = launch_wgrad16<4, 2>(p, lds, s);
+    else if (desc->kh == 3) rc = desc->stride == 1 ? launch_wgrad16<3, 1>(p, lds, s) : launch_wgrad16<3, 2>(p, lds, s);
+    else rc = desc->stride == 1 ? launch_wgrad16<1, 1>(p, lds, s) : launch_wgrad16<1, 2>(p, lds, s);
+    if (rc != MP_OK) return rc;
+    const size_t count = (size_t)p.Cout * p.Cin * desc->kh * desc->kw;
+    if (count * 16 <= 147456 * 2 && p.splits >= 64) {  // <= 18 K weights (32-channel 3x3): 16 threads per element
+        hipLaunchKernelGGL(wgrad16_reduce_grouped_kernel<16>, dim3((unsigned)((count + 15) / 16), jobs), dim3(256), 0, s, p.slabs, dst, count,
+                           p.splits, scale, accumulate ? 1 : 0);
+    } else if (count * 4 <= 147456 * 2 && p.splits >= 16) {  // <= 74 K weights (64-channel 3x3, the 1x1 convs): 4 per element
+        hipLaunchKernelGGL(wgrad16_reduce_grouped_kernel<4>, dim3((unsigned)((count + 63) / 64), jobs), dim3(256), 0, s, p.slabs, dst, count,
+                           p.splits, scale, accumulate ? 1 : 0);
+    } else {
+        size_t blocks = (count + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(wgrad16_reduce_kernel, dim3((unsigned)blocks, jobs), dim3(256), 0, s, p.slabs, dst, count, p.splits, scale,
+                           accumulate ? 1 : 0);
+    }
     return check_launch();
 }
 
@@ -517,24 +562,38 @@ int mp_f16_conv_wgrad(const mp_conv_desc* desc, const void* x, const void* dz, f
     const size_t count = (size_t)p.Cout * p.Cin * desc->kh * desc->kw;
     if (!workspace || workspace_bytes < (size_t)p.splits * count * sizeof(float)) return MP_ERR_WORKSPACE;
     p.x = x; p.dz = dz; p.slabs = reinterpret_cast<float*>(workspace);
-    hipStream_t s = as_stream(stream);
-    if (desc->kh == 4) rc = launch_wgrad16<4, 2>(p, lds, s);
-    else if (desc->kh == 3) rc = desc->stride == 1 ? launch_wgrad16<3, 1>(p, lds, s) : launch_wgrad16<3, 2>(p, lds, s);
-    else rc = desc->stride == 1 ? launch_wgrad16<1, 1>(p, lds, s) : launch_wgrad16<1, 2>(p, lds, s);
+    WgradDst dst{};
+    dst.dw[0] = dw;
+    return wgrad16_run(desc, p, lds, dst, 1, scale, accumulate, as_stream(stream));
+}
+
+size_t mp_f16_conv_wgrad_grouped_workspace_bytes(const mp_conv_desc* desc, int n_jobs) {
+    if (n_jobs < 1 || n_jobs > kWgradJobs) return 0;
+    Wgrad16Params p{};
+    size_t lds = 0;
+    if (geometry(desc, p, lds, n_jobs) != MP_OK) return 0;
+    return (size_t)n_jobs * p.splits * p.Cout * p.Cin * desc->kh * desc->kw * sizeof(float);
+}
+
+int mp_f16_conv_wgrad_grouped(const mp_conv_desc* desc, const void* const* x, const void* const* dz, float* const* dw, int n_jobs,
+                              float scale, int accumulate, void* workspace, size_t workspace_bytes, mp_stream_t stream) {
+    if (!x || !dz || !dw) return MP_ERR_NULL;
+    if (n_jobs < 1 || n_jobs > kWgradJobs) return MP_ERR_SHAPE;
+    Wgrad16Params p{};
+    size_t lds = 0;
+    int rc = geometry(desc, p, lds, n_jobs);
     if (rc != MP_OK) return rc;
-    if (count * 16 <= 147456 * 2 && p.splits >= 64) {  // <= 18 K weights (32-channel 3x3): 16 threads per element
-        hipLaunchKernelGGL(wgrad16_reduce_grouped_kernel<16>, dim3((unsigned)((count + 15) / 16)), dim3(256), 0, s, p.slabs, dw, count,
-                           p.splits, scale, accumulate ? 1 : 0);
-    } else if (count * 4 <= 147456 * 2 && p.splits >= 16) {  // <= 74 K weights (64-channel 3x3, the 1x1 convs): 4 per element
-        hipLaunchKernelGGL(wgrad16_reduce_grouped_kernel<4>, dim3((unsigned)((count + 63) / 64)), dim3(256), 0, s, p.slabs, dw, count,
-                           p.splits, scale, accumulate ? 1 : 0);
-    } else {
-        size_t blocks = (count + 255) / 256;
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(wgrad16_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p.slabs, dw, count, p.splits, scale,
-                           accumulate ? 1 : 0);
+    const size_t count = (size_t)p.Cout * p.Cin * desc->kh * desc->kw;
+    if (!workspace || workspace_bytes < (size_t)n_jobs * p.splits * count * sizeof(float)) return MP_ERR_WORKSPACE;
+    WgradDst dst{};
+    for (int j = 0; j < n_jobs; ++j) {
+        if (!x[j] || !dz[j] || !dw[j]) return MP_ERR_NULL;
+        p.jx[j] = x[j]; p.jdz[j] = dz[j]; p.jdw[j] = dw[j];
+        dst.dw[j] = dw[j];
     }
-    return check_launch();
+    p.n_jobs = n_jobs;
+    p.slabs = reinterpret_cast<float*>(workspace);
+    return wgrad16_run(desc, p, lds, dst, n_jobs, scale, accumulate, as_stream(stream));
 }
 
 }  // extern "C"

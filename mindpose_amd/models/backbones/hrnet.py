@@ -45,8 +45,9 @@ class BasicBlock(nn.Module):
     def train_forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.down_sample is None:
             return T.residual_block(x, [(self.conv1, self.bn1), (self.conv2, self.bn2)])
-        identity = T.conv_bn_act(x, self.down_sample[0], self.down_sample[1], relu=False)
-        out = T.conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        xd, xc = T.fan_out(x, 2)  # two consumers: their gradients are summed (and reduced for the producer's BatchNorm) in one launch
+        identity = T.conv_bn_act(xd, self.down_sample[0], self.down_sample[1], relu=False)
+        out = T.conv_bn_act(xc, self.conv1, self.bn1, relu=True)
         return T.conv_bn_act(out, self.conv2, self.bn2, relu=True, res=identity)
 
 
@@ -75,12 +76,11 @@ class Bottleneck(nn.Module):
         return plan.conv(out, self.conv3, self.bn3, relu=True, res1=identity)
 
     def train_forward(self, x: torch.Tensor) -> torch.Tensor:
-        identity = x
-        if self.down_sample is not None:
-            identity = T.conv_bn_act(x, self.down_sample[0], self.down_sample[1], relu=False)
         if self.down_sample is None:
             return T.residual_block(x, [(self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)])
-        out = T.conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        xd, xc = T.fan_out(x, 2)  # two consumers: their gradients are summed (and reduced for the producer's BatchNorm) in one launch
+        identity = T.conv_bn_act(xd, self.down_sample[0], self.down_sample[1], relu=False)
+        out = T.conv_bn_act(xc, self.conv1, self.bn1, relu=True)
         out = T.conv_bn_act(out, self.conv2, self.bn2, relu=True)
         return T.conv_bn_act(out, self.conv3, self.bn3, relu=True, res=identity)
 
@@ -405,14 +405,19 @@ class HRNet(Backbone):
             trans = getattr(self, f"transition{idx - 1}")
             flags = getattr(self, f"transition{idx - 1}_flags")
             cfg = getattr(self, f"stage{idx}_cfg")
+            # the last previous output feeds its own branch AND every new branch (hrnet.py:591, :600): one handle per consumer, so
+            # that the gradients meet in one fan-in launch instead of autograd's adds
+            uses = [1 if i < len(ys) else 0 for i in range(len(ys))]
+            uses[-1] += sum(1 for i in range(cfg["num_branches"]) if i >= len(ys))
+            handles = [list(T.fan_out(y, u)) for y, u in zip(ys, uses)]
             xs = []
             for i in range(cfg["num_branches"]):
                 if not flags[i]:
-                    xs.append(ys[i])
+                    xs.append(handles[i].pop())
                 elif i < len(ys):
-                    xs.append(_train_conv_bn(trans[i], ys[i]))
+                    xs.append(_train_conv_bn(trans[i], handles[i].pop()))
                 else:
-                    t = ys[-1]
+                    t = handles[-1].pop()
                     for seq in trans[i]:
                         t = _train_conv_bn(seq, t)
                     xs.append(t)

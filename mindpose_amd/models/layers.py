@@ -236,11 +236,16 @@ def tune_conv_variant(lib, d, x, packed, scale, shift, res1, res2, out, half: bo
     fn = lib.mp_f16_conv2d_fwd if half else lib.mp_conv2d_fwd_variant
 
     stats_buf = {}
+    # a statistics build that leaves more than 512 partial slots per channel costs its consumer an extra fold launch (~5 us): such
+    # variants compete only when no variant of the shape stays within 512
+    slot_cap = [512]
+    if stats is not None and not any(0 < lib.mp_f16_conv_stats_parts(ctypes.byref(d), v) <= 512 for v in range(F16_VARIANTS)):
+        slot_cap[0] = 1 << 30
 
     def launch(v):
         if stats is not None:
             n_parts = lib.mp_f16_conv_stats_parts(ctypes.byref(d), v)
-            if n_parts <= 0:
+            if n_parts <= 0 or n_parts > slot_cap[0]:
                 return -3
             need = (d.cout + 7) // 8 * n_parts * 16
             if stats_buf.get("n", 0) < need:

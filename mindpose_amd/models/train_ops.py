@@ -986,13 +986,94 @@ def _conv16_stats_launch(lib, d, x, packed, scale, shift, out, res1, mode, z=Non
     return part, n_parts
 
 
+# ---- deferred, grouped weight gradients ------------------------------------------------------------------------------------------------
+# A weight gradient is a leaf of the backward pass: nothing reads it before the optimizer.  The fused chains therefore do not launch
+# it per layer: the (input, output-gradient, arena slot) triple is queued under its launch shape and stream, and every
+# ``WGRAD_GROUP`` layers of one shape - the eight 3x3 convs of an HRNet branch (hrnet.py:202-241) - run as ONE
+# ``mp_f16_conv_wgrad_grouped`` launch pair: per layer fewer and longer pixel slabs (an eighth of the split-K traffic), an eighth of
+# the launches.  ``flush_wgrad_jobs()`` runs the remainders; whoever reads the gradient arena calls it first (the arena optimizers'
+# ``step``, ``GraphedTrainStep`` before its capture ends).  MINDPOSE_WGRAD_GROUP=1 launches every layer on its own as before.
+WGRAD_GROUP = 8
+_WGRAD_PENDING = {}
+
+
+def _wgrad_group_size() -> int:
+    return max(1, min(WGRAD_GROUP, int(os.environ.get("MINDPOSE_WGRAD_GROUP", str(WGRAD_GROUP)))))
+
+
+def _wgrad_enqueue(lib, d, x, dz, dw):
+    """Queue dW += x (*) dz (accumulating into the arena slot ``dw``); launches the group when it is full."""
+    dev = x.device
+    key = (tuple(getattr(d, f) for f, _ in d._fields_), dev, torch.cuda.current_stream(dev).cuda_stream)
+    jobs = _WGRAD_PENDING.setdefault(key, [])
+    jobs.append((d, x, dz, dw))
+    if len(jobs) >= _wgrad_group_size():
+        _wgrad_flush_key(lib, key)
+    elif not _WGRAD_CALLBACK[0]:
+        # the remainders are launched when THIS backward pass ends (autograd's final callbacks run after the engine has joined the
+        # streams of the pass with the caller's stream): whoever looks at the gradient arena after backward() sees them
+        _WGRAD_CALLBACK[0] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_wgrad_backward_done)
+
+
+def _wgrad_flush_key(lib, key):
+    jobs = _WGRAD_PENDING.pop(key, [])
+    if not jobs:
+        return
+    d, dev = jobs[0][0], key[1]
+    n = len(jobs)
+    with torch.cuda.device(dev):
+        if n == 1:
+            _, x, dz, dw = jobs[0]
+            wsb = lib.mp_f16_conv_wgrad_workspace_bytes(ctypes.byref(d))
+            ws = torch.empty(max(wsb // 4, 1), device=dev, dtype=torch.float32)
+            _lib.check(lib.mp_f16_conv_wgrad(ctypes.byref(d), _lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), 1.0, 1, _lib.ptr(ws), wsb,
+                                             _lib.stream()), "mp_f16_conv_wgrad")
+            return
+        wsb = lib.mp_f16_conv_wgrad_grouped_workspace_bytes(ctypes.byref(d), n)
+        ws = torch.empty(max(wsb // 4, 1), device=dev, dtype=torch.float32)
+        arr = ctypes.c_void_p * n
+        _lib.check(lib.mp_f16_conv_wgrad_grouped(ctypes.byref(d), arr(*[_lib.ptr(j[1]) for j in jobs]), arr(*[_lib.ptr(j[2]) for j in jobs]),
+                                                 arr(*[_lib.ptr(j[3]) for j in jobs]), n, 1.0, 1, _lib.ptr(ws), wsb, _lib.stream()),
+                   "mp_f16_conv_wgrad_grouped")
+
+
+_WGRAD_CALLBACK = [False]
+
+
+def _wgrad_backward_done() -> None:
+    _WGRAD_CALLBACK[0] = False
+    flush_wgrad_jobs()
+
+
+def flush_wgrad_jobs() -> None:
+    """Launch every queued weight gradient.  A group runs on the stream its layers ran on (ordered behind their producers there);
+    the current stream then waits for that stream, so the arena is complete for whatever the caller enqueues next."""
+    _WGRAD_CALLBACK[0] = False
+    if not _WGRAD_PENDING:
+        return
+    lib = _lib.load()
+    for key in list(_WGRAD_PENDING):
+        dev, stream_id = key[1], key[2]
+        cur = torch.cuda.current_stream(dev)
+        if stream_id == cur.cuda_stream:
+            _wgrad_flush_key(lib, key)
+            continue
+        side = torch.cuda.ExternalStream(stream_id, device=dev)
+        with torch.cuda.stream(side):
+            _wgrad_flush_key(lib, key)
+        cur.wait_stream(side)
+
+
 class Chain16Fn(torch.autograd.Function):
     """``meta`` = per group (stride, padding, moving_mean, moving_var, relu); ``residual``: the chain input is added before the last
     group's activation (BasicBlock / Bottleneck without down-sample, hrnet.py:66-83, 126-146); ``params`` = (weight, gamma, beta)
     per group.  k in {1, 3}, stride in {1, 2}, padding = k // 2, no conv bias."""
 
     @staticmethod
-    def forward(ctx, x, meta, residual, in_link, *params):
+    def forward(ctx, x, meta, residual, in_link, res_ext, *params):
+        """``res_ext``: a second tensor added before the last group's activation instead of the chain input (the block with a
+        down-sample path, hrnet.py:74-81: identity = bn(conv1x1(x)))."""
         lib = _lib.load()
         groups = []
         a = x
@@ -1015,7 +1096,7 @@ class Chain16Fn(torch.autograd.Function):
                 part, n_parts = None, 0
                 _conv16_launch(lib, d, a, packed, ones, zeros, z, "mp_f16_conv2d_fwd")
             last = gi == n_groups - 1
-            res = x if (last and residual) else None
+            res = (x if residual else res_ext) if last else None
             y = torch.empty_like(z)
             mean = torch.empty(cout, device=z.device)
             invstd = torch.empty(cout, device=z.device)
@@ -1037,6 +1118,7 @@ class Chain16Fn(torch.autograd.Function):
         ctx.in_link = in_link
         ctx.out_link = _BnLink(groups[-1]["z"], a, groups[-1]["relu"])
         ctx.needs_dx = x.requires_grad
+        ctx.res_is_input = bool(residual)
         return a
 
     @staticmethod
@@ -1085,20 +1167,22 @@ class Chain16Fn(torch.autograd.Function):
             # ---- conv: weight gradient (a leaf), then the data gradient that feeds the BatchNorm below
             s, pad = G["stride"], G["padding"]
             direct = _direct_grad(G["weight"])
-            dw = direct if direct is not None else torch.empty_like(w)
             d = _desc(n, cin, h, wd, cout, k, s, pad, pad, ho, wo, ho, wo)
-            wsb = lib.mp_f16_conv_wgrad_workspace_bytes(ctypes.byref(d))
-            wws = torch.empty(max(wsb // 4, 1), device=z.device, dtype=torch.float32)
-            _lib.check(lib.mp_f16_conv_wgrad(ctypes.byref(d), _lib.ptr(a), _lib.ptr(dz), _lib.ptr(dw), 1.0, int(direct is not None),
-                                             _lib.ptr(wws), wsb, _lib.stream()), "mp_f16_conv_wgrad")
-            if direct is not None:
+            if direct is not None:  # into the gradient arena: queued, launched with the other layers of this shape
+                _wgrad_enqueue(lib, d, a, dz, direct)
                 dw = None
+            else:
+                dw = torch.empty_like(w)
+                wsb = lib.mp_f16_conv_wgrad_workspace_bytes(ctypes.byref(d))
+                wws = torch.empty(max(wsb // 4, 1), device=z.device, dtype=torch.float32)
+                _lib.check(lib.mp_f16_conv_wgrad(ctypes.byref(d), _lib.ptr(a), _lib.ptr(dz), _lib.ptr(dw), 1.0, 0, _lib.ptr(wws), wsb,
+                                                 _lib.stream()), "mp_f16_conv_wgrad")
             pre = None
             dx = None
             if gi > 0 or ctx.needs_dx:
                 ones, zeros = _ones_zeros16(cin, z.device)
                 dx = _c8_alloc(n, cin, h, wd, z.device)
-                res1 = dres if gi == 0 else None  # the chain input's second path: added in this launch's epilogue
+                res1 = dres if (gi == 0 and ctx.res_is_input) else None  # the chain input's second path: added in this launch's epilogue
                 # which BatchNorm does this gradient reach?  the previous group's - or, across nodes, the producer of the chain input
                 below = None
                 if gi > 0:
@@ -1135,19 +1219,21 @@ class Chain16Fn(torch.autograd.Function):
                         dx.zero_()
                         dd = _desc(n, cout, ho, wo, cin, 1, 1, 0, 0, ho, wo, h, wd, out_mul=2)
                         _conv16_launch(lib, dd, dz, _pack16(lib, w, cin, cout, 1, 2, owner=G["weight"]), ones, zeros, dx, "conv dgrad 1x1s2")
-            elif gi == 0 and dres is not None:
+            elif gi == 0 and dres is not None and ctx.res_is_input:
                 dx = dres
             grads = [dw, dgamma, dbeta] + grads
             dy = dx
-        return (dy, None, None, None, *grads)
+        return (dy, None, None, None, None if ctx.res_is_input else dres, *grads)
 
 
-def _chain16(x, groups, relus, residual):
+def _chain16(x, groups, relus, residual, res_ext=None):
     """groups = [(conv, bn), ...] on a channel-blocked activation, as ONE fused node."""
     link = _claim(x)  # a residual chain's second use of x (the identity) is inside the node: still ONE consumer
+    if res_ext is not None:
+        _claim(res_ext)
     meta = tuple((cv.stride, cv.padding, bn.moving_mean, bn.moving_variance, bool(r)) for (cv, bn), r in zip(groups, relus))
     params = [t for cv, bn in groups for t in (cv.weight, bn.gamma, bn.beta)]
-    y = Chain16Fn.apply(x, meta, bool(residual), link, *params)
+    y = Chain16Fn.apply(x, meta, bool(residual), link, res_ext, *params)
     out_link = getattr(y.grad_fn, "out_link", None)  # the node object IS the ctx of forward / backward
     if out_link is not None:
         y._mp_bn_link = out_link
@@ -1175,8 +1261,8 @@ def conv_bn_act(x, conv, bn, relu: bool, res: Optional[torch.Tensor] = None):
     """One conv + BatchNorm(train) (+ residual) (+ ReLU) group of the reference's cells; the kernel family follows the
     activation type (fp32 NCHW, or channel-blocked fp16 under amp O2)."""
     if _is_c8(x):
-        if bn is not None and res is None and conv.bias is None and bn_fuse_enabled():
-            return _chain16(x, [(conv, bn)], [relu], residual=False)
+        if bn is not None and conv.bias is None and bn_fuse_enabled():
+            return _chain16(x, [(conv, bn)], [relu], residual=False, res_ext=res)
         _claim(x)
         if res is not None:
             _claim(res)

@@ -78,6 +78,8 @@ class _ArenaOptimizer:
         scale and checked: on overflow (inf / nan anywhere) the update is skipped and the scale halves, exactly one
         host read-back per step; returns whether the parameters were updated."""
         lib = _lib.load()
+        from ..models.train_ops import flush_wgrad_jobs
+        flush_wgrad_jobs()  # queued (grouped) weight gradients land in the arena before anything reads it
         if getattr(self, "time_comm", False) and self.grads.active and self._grad_flat.is_cuda:
             # bench.py's DP leg: device time from "all gradients are in the arena" to "the bucket all-reduces have landed" as the
             # compute stream sees it (the native transport runs them on its own stream; finish() makes this stream wait for them)

@@ -31,7 +31,7 @@ class GraphedTrainStep:
         from ..models.backbones.hrnet import set_branch_streams
         prev_branch_streams = set_branch_streams(True)
         # ... and the weight gradients (leaves of the backward pass) on a side stream per branch stream, joined after backward
-        from ..models.train_ops import join_wgrad_lanes, set_wgrad_lanes
+        from ..models.train_ops import flush_wgrad_jobs, join_wgrad_lanes, set_wgrad_lanes
         prev_wgrad_lanes = set_wgrad_lanes(True)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -40,6 +40,7 @@ class GraphedTrainStep:
                 optimizer.grads.begin_step()
                 loss = net_with_loss(*self.static_in)
                 (loss * self.scale_t).backward()
+                flush_wgrad_jobs()
                 join_wgrad_lanes(dev)
                 del loss  # drop the autograd graph before the next pass / the capture
         torch.cuda.current_stream(dev).wait_stream(side)
@@ -49,6 +50,7 @@ class GraphedTrainStep:
             optimizer.grads.arena.zero_()
             self.static_loss = net_with_loss(*self.static_in)
             (self.static_loss * self.scale_t).backward()
+            flush_wgrad_jobs()  # the remainders of the grouped weight gradients belong to the captured step
             join_wgrad_lanes(dev)
         set_branch_streams(prev_branch_streams)
         set_wgrad_lanes(prev_wgrad_lanes)

@@ -296,6 +296,53 @@ def test_exchange_unit_backward_term_with_statistics(s, relu_t):
     assert ((got_a - ref_a).abs() / sa).max() < 1e-5 and ((got_b - ref_b).abs() / sb).max() < 1e-5
 
 
+@pytest.mark.parametrize("case", [(6, 32, 32, 3, 1, 64, 48, 8), (5, 64, 64, 3, 1, 32, 24, 5), (7, 128, 128, 3, 1, 16, 12, 8),
+                                  (9, 256, 256, 3, 1, 8, 6, 3), (4, 64, 256, 1, 1, 32, 24, 2), (3, 32, 64, 3, 2, 64, 48, 4),
+                                  (2, 40, 24, 3, 1, 9, 7, 1)], ids=lambda c: f"n{c[0]}_{c[1]}to{c[2]}_k{c[3]}s{c[4]}_{c[5]}x{c[6]}_jobs{c[7]}")
+def test_grouped_weight_gradient_equals_per_layer_launches(case):
+    """mp_f16_conv_wgrad_grouped (1 .. 8 layers of one shape, blockIdx.z = layer) against mp_f16_conv_wgrad per layer: the same
+    products, another split-K partition (fp32 summation order: 2e-5 of the gradient's scale), accumulation into the destination,
+    bit-reproducible; and against torch autograd for the first layer."""
+    import torch.nn.functional as F
+    n, cin, cout, k, s, h, w, jobs = case
+    g = torch.Generator().manual_seed(sum(case))
+    d, ho, wo = _desc(n, cin, h, w, cout, k, s)
+    xs = [torch.randn(n, cin, h, w, generator=g) for _ in range(jobs)]
+    dzs = [torch.randn(n, cout, ho, wo, generator=g) for _ in range(jobs)]
+    xa, dza = [_to_c8(t) for t in xs], [_to_c8(t) for t in dzs]
+    ref = []
+    for j in range(jobs):
+        dw = torch.full((cout, cin, k, k), 0.5, device=DEV)
+        wsb = LIB.mp_f16_conv_wgrad_workspace_bytes(ctypes.byref(d))
+        ws = torch.empty(wsb // 4, device=DEV)
+        _lib.check(LIB.mp_f16_conv_wgrad(ctypes.byref(d), _lib.ptr(xa[j]), _lib.ptr(dza[j]), _lib.ptr(dw), 1.0, 1, _lib.ptr(ws), wsb,
+                                         _lib.stream()), "wgrad")
+        ref.append(dw)
+    wsb = LIB.mp_f16_conv_wgrad_grouped_workspace_bytes(ctypes.byref(d), jobs)
+    assert wsb > 0
+
+    def grouped():
+        outs = [torch.full((cout, cin, k, k), 0.5, device=DEV) for _ in range(jobs)]
+        ws = torch.empty(wsb // 4, device=DEV)
+        arr = ctypes.c_void_p * jobs
+        _lib.check(LIB.mp_f16_conv_wgrad_grouped(ctypes.byref(d), arr(*[_lib.ptr(t) for t in xa]), arr(*[_lib.ptr(t) for t in dza]),
+                                                 arr(*[_lib.ptr(t) for t in outs]), jobs, 1.0, 1, _lib.ptr(ws), wsb, _lib.stream()), "grouped")
+        return outs
+
+    got, again = grouped(), grouped()
+    for j in range(jobs):
+        scale = float(ref[j].abs().max())
+        assert float((got[j] - ref[j]).abs().max()) <= 2e-5 * scale, j
+        assert torch.equal(got[j], again[j])
+    # torch autograd on the fp16-rounded operands (layer 0); the 0.5 the destination held is still there
+    xt = xs[0].half().float()
+    wt = torch.zeros(cout, cin, k, k, requires_grad=True)
+    F.conv2d(xt, wt, stride=s, padding=k // 2).backward(dzs[0].half().float())
+    assert torch.allclose(got[0].cpu() - 0.5, wt.grad, rtol=1e-3, atol=1e-4 * float(wt.grad.abs().max()))
+    arr1 = ctypes.c_void_p * 9
+    assert LIB.mp_f16_conv_wgrad_grouped(ctypes.byref(d), arr1(), arr1(), arr1(), 9, 1.0, 1, None, 0, _lib.stream()) != 0  # > 8 layers
+
+
 def _step(fused, monkeypatch, backbone="hrnet_w32", head="hrnet_head", size=(2, 64, 64)):
     import mindpose_amd as mp
     from mindpose_amd.utils import AdamWeightDecay
