@@ -347,7 +347,7 @@ class CallTimer:
     what the host mirror calls through, and restored afterwards."""
 
     CONV = ("mp_f16_conv2d_fwd", "mp_f16_conv2d_fwd_stats", "mp_conv2d_fwd_variant", "mp_conv2d_fwd", "mp_conv2d_winograd_fwd")
-    WGRAD = ("mp_f16_conv_wgrad", "mp_conv_wgrad")
+    WGRAD = ("mp_f16_conv_wgrad", "mp_f16_conv_wgrad_grouped", "mp_conv_wgrad")
     BN = ("mp_f16_bn_train_fwd", "mp_f16_bn_train_bwd", "mp_f16_bn_train_fwd_stats", "mp_f16_bn_train_bwd_stats", "mp_bn_train_fwd",
           "mp_bn_train_bwd_acc", "mp_bn_train_bwd")
     OTHER = ("mp_f16_fuse_upsample_sum", "mp_f16_fuse_upsample_sum_bwd", "mp_fuse_upsample_sum", "mp_fuse_upsample_sum_bwd",
@@ -384,6 +384,8 @@ class CallTimer:
         if name in CallTimer.CONV + CallTimer.WGRAD:
             d = args[0]._obj  # ctypes.byref(mp_conv_desc)
             flops = 2.0 * d.n * d.conv_h * d.conv_w * d.cout * d.cin * d.kh * d.kw
+            if name == "mp_f16_conv_wgrad_grouped":
+                flops *= args[4]  # n_jobs layers of this shape in one launch pair
             variant = args[1] if name in ("mp_f16_conv2d_fwd", "mp_f16_conv2d_fwd_stats", "mp_conv2d_fwd_variant") else (
                 9 if name == "mp_conv2d_winograd_fwd" else None)
             return dict(flops=flops, shape=f"{d.kh}x{d.kw} s{d.stride} {d.cin}->{d.cout} @{d.h}x{d.w} N={d.n}", variant=variant,
@@ -483,7 +485,7 @@ def train_roofline(eager_step, half):
         shapes = d["shapes"]
         top = max(shapes, key=lambda k: shapes[k]["time"])
         name = (f16_kernel_for if "f16" in dom else f32_kernel_for)(top[2], top[3], top[1] if top[1] is None or top[1] >= 0 else None) if dom in CallTimer.CONV else (
-            f"conv_wgrad_f16_kernel<{top[2]},{top[3]}>" if "f16" in dom else f"conv_wgrad_pipe_kernel<{top[2]},{top[3]}>")
+            f"conv_wgrad_f16_dma_k{top[2]}s{top[3]}" if "f16" in dom else f"conv_wgrad_pipe_kernel<{top[2]},{top[3]}>")
         t = shapes[top]
         ach = t["flops"] / t["time"] / 1e12
         out.update({"bound": "mfma", "achieved": round(ach, 2), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(ach / mfma_peak, 4),
