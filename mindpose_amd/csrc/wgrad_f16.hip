@@ -51,6 +51,18 @@ struct Wgrad16Params {
 };
 constexpr int kWgradJobs = 8;
 
+// The operand pointers of this workgroup's job (blockIdx.z).  Written as selects over CONSTANT indices: a dynamic index into the
+// by-value argument struct made the compiler copy the whole struct to scratch memory, and every later read of a launch parameter
+// became a scratch load - a vector-memory operation, whose s_waitcnt vmcnt(0) inside the tile loop also waited for the NEXT tile's
+// LDS-DMA, i.e. serialised the copy the loop exists to overlap.
+__device__ __forceinline__ void job_tensors(const Wgrad16Params& p, const void*& x, const void*& dz) {
+    if (p.n_jobs == 0) return;
+    const int job = blockIdx.z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (job == j) { x = p.jx[j]; dz = p.jdz[j]; }
+}
+
 __device__ __forceinline__ s16x4 tr_read(const _Float16* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 }
@@ -111,8 +123,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16_kernel(const Wgrad16Par
         }
     }
 
-    const void* const x_ptr = p.n_jobs ? p.jx[blockIdx.z] : p.x;
-    const void* const dz_ptr = p.n_jobs ? p.jdz[blockIdx.z] : p.dz;
+    const void* x_ptr = p.x;
+    const void* dz_ptr = p.dz;
+    job_tensors(p, x_ptr, dz_ptr);
     const __amdgpu_buffer_rsrc_t rs_z = make_rsrc(dz_ptr, (size_t)p.N * p.C8out * p.Ho * p.Wo * 16);
     const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x_ptr, (size_t)p.N * p.C8in * p.H * p.W * 16);
     u32x4 vz[NZ], vx[NX];
@@ -239,6 +252,57 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16_kernel(const Wgrad16Par
 // Same position trick, same MFMA loop order, same slab layout as above: results are bit-identical.
 // (A __device__ body behind concrete __global__ wrappers: as a __global__ TEMPLATE containing the LDS-DMA builtin the host
 // compilation pass of this file emitted no stub for it - undefined symbol at load time, no diagnostic.)
+// LDS operand reads of the LDS-DMA kernel, as inline assembly.  Written with the builtin, every ds_read of the tile loop got a
+// compiler-inserted s_waitcnt vmcnt(0) in front of it: the waitcnt pass cannot tell the stage being read from the stage the
+// in-flight DMA (buffer_load ... lds) writes, so it waited for the NEXT tile's copy before the first MFMA of THIS tile - the two
+// stages ran strictly one after the other (round-3 counters: waves 53 % waiting, matrix pipe 20 % busy).  An asm read is invisible
+// to that pass; the hazards are handled by hand instead: vmcnt(0) + barrier at the top of a tile (the stage has landed, the other
+// one is no longer read), and counted lgkmcnt waits - tied to the registers they guard - before each MFMA.
+template <int OFF>
+__device__ __forceinline__ s16x4 lds_tr(unsigned addr) {
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_landed(frag8& f) {  // at most N LDS reads issued after f's may still be in flight
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.lo), "+v"(f.hi) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void lds_landed(frag8& f, frag8& g) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f.lo), "+v"(f.hi), "+v"(g.lo), "+v"(g.hi) : "n"(N));
+}
+
+// one k-step's taps, unrolled by template recursion (the read offsets and wait counts must be immediates): the operand of tap
+// TP + D is requested before tap TP's MFMA, so D fragments (2 D reads) are in flight behind the one being consumed
+template <int KS, int S, int T, int D, int TP>
+struct WgradTaps {
+    template <int I>
+    static __device__ __forceinline__ void request(frag8 (&b)[T], const unsigned (&xr)[KS]) {
+        b[I].lo = lds_tr<(I % KS) * 16>(xr[I / KS]);
+        b[I].hi = lds_tr<(I % KS) * 16 + 4 * S * 16>(xr[I / KS]);
+    }
+    static __device__ __forceinline__ void run(frag8& a, frag8 (&b)[T], f32x4 (&acc)[T], const unsigned (&xr)[KS]) {
+        if constexpr (TP == 0) {
+            constexpr int first = D < T ? D : T;
+            prologue<0, first>(b, xr);
+        }
+        if constexpr (TP + D < T) request<TP + D>(b, xr);
+        constexpr int behind = (T - 1 - TP) < D ? (T - 1 - TP) : D;
+        if constexpr (TP == 0) lds_landed<2 * behind>(a, b[0]);
+        else lds_landed<2 * behind>(b[TP]);
+        acc[TP] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b[TP]), acc[TP], 0, 0, 0);
+        if constexpr (TP + 1 < T) WgradTaps<KS, S, T, D, TP + 1>::run(a, b, acc, xr);
+    }
+    template <int I, int N>
+    static __device__ __forceinline__ void prologue(frag8 (&b)[T], const unsigned (&xr)[KS]) {
+        if constexpr (I < N) {
+            request<I>(b, xr);
+            prologue<I + 1, N>(b, xr);
+        }
+    }
+};
+
 template <int KS, int S, int NP>
 __device__ __forceinline__ void wgrad_dma_body(const Wgrad16Params& p) {
     constexpr int T = KS * KS;
@@ -254,8 +318,9 @@ __device__ __forceinline__ void wgrad_dma_body(const Wgrad16Params& p) {
     const int t_begin = blockIdx.y * p.tiles_per_split;
     const int t_end = min(t_begin + p.tiles_per_split, p.tiles);
 
-    const void* const x_ptr = p.n_jobs ? p.jx[blockIdx.z] : p.x;
-    const void* const dz_ptr = p.n_jobs ? p.jdz[blockIdx.z] : p.dz;
+    const void* x_ptr = p.x;
+    const void* dz_ptr = p.dz;
+    job_tensors(p, x_ptr, dz_ptr);
     const __amdgpu_buffer_rsrc_t rs_z = make_rsrc(dz_ptr, (size_t)p.N * p.C8out * p.Ho * p.Wo * 16);
     const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(x_ptr, (size_t)p.N * p.C8in * p.H * p.W * 16);
 
@@ -298,7 +363,7 @@ __device__ __forceinline__ void wgrad_dma_body(const Wgrad16Params& p) {
     // lane-constant operand byte offsets: position (8g + q) of a k-step, channels 4pp .. 4pp+3 of this wave's 16
     const int a_base = ((co_sub * 2 + (pp >> 1)) * p.zslots + (8 * g + q)) * 16 + (pp & 1) * 8 + p.z_base * 16;
     const int b_base = ((ci_sub * 2 + (pp >> 1)) * p.xslots + S * (8 * g + q)) * 16 + (pp & 1) * 8;
-    const char* lds_bytes = reinterpret_cast<const char*>(smem16);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem16;  // LDS byte address of the stages
 
     if (t_begin < t_end) WGRAD_DMA_TILE(smem16, t_begin);
     const int ksteps = p.K >> 5;
@@ -309,23 +374,16 @@ __device__ __forceinline__ void wgrad_dma_body(const Wgrad16Params& p) {
         __syncthreads();
         if (t + 1 < t_end)  // flies under this tile's MFMA loop
             WGRAD_DMA_TILE(smem16 + (buf ^ 1) * buf_units, t + 1);
-        const char* zt = lds_bytes + (size_t)buf * buf_units * 16 + a_base;
-        const char* xt = lds_bytes + (size_t)buf * buf_units * 16 + b_base;
-        for (int ks = 0; ks < ksteps; ++ks) {
-            const char* za = zt + ks * 32 * 16;
-            const char* xb = xt + ks * 32 * S * 16;
-            frag8 a;
-            a.lo = tr_read(reinterpret_cast<const _Float16*>(za));
-            a.hi = tr_read(reinterpret_cast<const _Float16*>(za + 4 * 16));
-            const f16x8 af = __builtin_bit_cast(f16x8, a);
+        unsigned za = lds0 + (unsigned)(buf * buf_units * 16 + a_base);
+        unsigned xb = lds0 + (unsigned)(buf * buf_units * 16 + b_base);
+        for (int ks = 0; ks < ksteps; ++ks, za += 32 * 16, xb += 32 * S * 16) {
+            frag8 a, b[T];
+            a.lo = lds_tr<0>(za);
+            a.hi = lds_tr<4 * 16>(za);
+            unsigned xr[KS];
 #pragma unroll
-            for (int tp = 0; tp < T; ++tp) {
-                const int off = ((tp / KS) * p.Px + (tp % KS)) * 16;
-                frag8 b;
-                b.lo = tr_read(reinterpret_cast<const _Float16*>(xb + off));
-                b.hi = tr_read(reinterpret_cast<const _Float16*>(xb + off + 4 * S * 16));
-                acc[tp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, __builtin_bit_cast(f16x8, b), acc[tp], 0, 0, 0);
-            }
+            for (int r = 0; r < KS; ++r) xr[r] = xb + (unsigned)(r * p.Px * 16);
+            WgradTaps<KS, S, T, (T < 3 ? T : 3), 0>::run(a, b, acc, xr);
         }
     }
 
