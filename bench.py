@@ -422,10 +422,11 @@ class CallTimer:
             f["bytes"] += info.get("bytes", 0.0)
             if "shape" in info:
                 sh = f["shapes"].setdefault((info["shape"], info.get("variant"), info.get("ks"), info.get("stride")),
-                                            dict(time=0.0, launches=0, flops=0.0))
+                                            dict(time=0.0, launches=0, flops=0.0, bytes=0.0))
                 sh["time"] += t
                 sh["launches"] += 1
                 sh["flops"] += info.get("flops", 0.0)
+                sh["bytes"] += info.get("bytes", 0.0)
         return fam
 
 
@@ -458,12 +459,12 @@ def train_roofline(eager_step, half):
     dump = os.environ.get("MINDPOSE_BENCH_TRAIN_SHAPES")
     if dump:  # per (entry, shape) table of the instrumented step, for kernel work: entry,shape,variant,launches,total_us,avg_us
         with open(dump, "w") as fh:
-            fh.write("entry,shape,variant,launches,total_us,avg_us,tflops\n")
+            fh.write("entry,shape,variant,launches,total_us,avg_us,tflops,GBps\n")
             for name, f in sorted(fam.items(), key=lambda kv: -kv[1]["time"]):
                 for (shape, variant, _, _), sh in sorted(f["shapes"].items(), key=lambda kv: -kv[1]["time"]):
                     tf = sh["flops"] / sh["time"] / 1e12 if sh["time"] > 0 else 0.0
                     fh.write(f"{name},\"{shape}\",{variant},{sh['launches']},{sh['time'] * 1e6:.1f},"
-                             f"{sh['time'] / sh['launches'] * 1e6:.2f},{tf:.1f}\n")
+                             f"{sh['time'] / sh['launches'] * 1e6:.2f},{tf:.1f},{sh['bytes'] / sh['time'] / 1e9 if sh['time'] > 0 else 0.0:.0f}\n")
     mfma_peak = PEAK_FP16_MFMA_TFLOPS if half else PEAK_FP32_MFMA_TFLOPS
     dom = max(fam, key=lambda k: fam[k]["time"])
     d = fam[dom]

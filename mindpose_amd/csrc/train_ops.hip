@@ -1501,15 +1501,20 @@ int mp_f16_bn_train_bwd(const void* dy, const void* z, const void* y, const floa
 static unsigned bn16_pre_chunks(int n, int c8, int hw, int n_parts) {
     // a block folds n_parts x 64 bytes before it streams: with many slots, fewer and fatter blocks (the redundant fold traffic stays
     // well below the tensor traffic)
-    size_t chunks = ((n_parts > 256 ? 256 : 512) + c8 - 1) / c8;
+    size_t total = n_parts > 256 ? 256 : 512, floor_elems = 2048;
+    if (const char* e = knob("MP_BN_PRE_BLOCKS")) total = (size_t)atoi(e);
+    if (const char* e = knob("MP_BN_PRE_MIN")) floor_elems = (size_t)atoi(e);
+    size_t chunks = (total + c8 - 1) / c8;
     const size_t per_blk = (size_t)n * hw;
-    while (chunks > 1 && per_blk / chunks < 2048) --chunks;
+    while (chunks > 1 && per_blk / chunks < floor_elems) --chunks;
     return (unsigned)chunks;
 }
 
 // more slots than a consumer block folds: reduce them to one per channel block (into the workspace)
 static int bn16_prefold(const float*& pre, int& n_parts, int c8, void* workspace, hipStream_t s) {
-    if (n_parts <= kMaxFoldParts) return MP_OK;
+    int above = kMaxFoldParts;
+    if (const char* e = knob("MP_BN_PREFOLD_ABOVE")) above = atoi(e);
+    if (n_parts <= above) return MP_OK;
     float* folded = reinterpret_cast<float*>(workspace);
     hipLaunchKernelGGL(bn16_fold_kernel, dim3(c8, kFoldSplit), dim3(256), 0, s, pre, folded, n_parts);
     pre = folded;

@@ -41,6 +41,8 @@ struct Wgrad16Params {
     // LDS-DMA form (conv_wgrad_f16_dma_kernel): channel-block-major LDS images, element counts per 8-channel block
     int xslots, zslots, pieces;  // == 4 (mod 16) each: the two blocks a 16-lane group reads land on disjoint banks
     int x_pieces, z_base;        // DMA pieces of the input image; first element of the gradient image (a multiple of 64)
+    int wide;                    // LDS-DMA form: 1 = 64 x 64 tile per workgroup (wave = one 32 x 32 quarter), co_tiles / ci_tiles count 64s
+    int co_tiles;
     unsigned magic_xs, magic_zs, magic_p;
     // grouped launch (mp_f16_conv_wgrad_grouped): blockIdx.z = job, up to kWgradJobs layers of ONE shape; the operand pointers
     // travel by value in the kernel arguments (nothing to upload, hipGraph-capturable); n_jobs == 0: the single-layer launch
@@ -303,7 +305,71 @@ struct WgradTaps {
     }
 };
 
-template <int KS, int S, int NP>
+// ---- wide form ----------------------------------------------------------------------------------------------------------------
+// Above, a workgroup owns a 32 x 32 (cout x cin) tile and wave (co_sub, ci_sub) a 16 x 16 quarter of it: per 32 positions the
+// workgroup copies 64 channels x 32 positions into LDS for 4 T MFMAs.  Whatever the layer, that is ~130 B of LDS-DMA per MFMA, and
+// the copies - not the matrix pipe, not the LDS reads - set the pace: LDS holds two stages per workgroup, so half of it at most
+// is in flight, and a stage is consumed in a fraction of the time its copy takes to arrive (every grouped launch of 58 GFLOP took
+// 120 - 135 us, 32- to 256-channel layers alike).  Layers with more than 32 channels on both sides get a 64 x 64 tile here:
+// wave (co_half, ci_half) computes a 32 x 32 quarter as 2 x 2 MFMA tiles per tap (4 T accumulators), 128 channels x 32 positions
+// are copied for 16 T MFMAs - half the bytes per MFMA - and a 64-channel layer reads each tensor once instead of twice.
+// NK k-steps are unrolled into one straight-line block (requests of the next k-step fly under the last taps of this one; nothing
+// in flight is carried around a loop edge, where a compiler-inserted register copy would read it early).
+template <int KS, int S, int T, int NK>
+struct WgradTaps2 {
+    static constexpr int NV = NK * T;        // virtual taps of the block: V = (k-step j of the block) * T + tap
+    static constexpr int D = T >= 2 ? 2 : 1;  // request distance in virtual taps
+    static constexpr int reads(int v) { return 4 + ((v % T) == 0 ? 4 : 0); }  // LDS reads request<v> issues
+    static constexpr int behind(int v) {  // reads requested after tap v's, i.e. allowed in flight when v is consumed
+        int n = 0;
+        for (int j = 1; j < D; ++j)
+            if (v + j < NV) n += reads(v + j);
+        return n;
+    }
+    template <int V>
+    static __device__ __forceinline__ void request(frag8 (&a)[NK][2], frag8 (&b)[NV][2], unsigned za0, unsigned za1,
+                                                   const unsigned (&xr0)[KS], const unsigned (&xr1)[KS]) {
+        constexpr int J = V / T, I = V % T;
+        if constexpr (I == 0) {
+            a[J][0].lo = lds_tr<J * 512>(za0);
+            a[J][0].hi = lds_tr<J * 512 + 64>(za0);
+            a[J][1].lo = lds_tr<J * 512>(za1);
+            a[J][1].hi = lds_tr<J * 512 + 64>(za1);
+        }
+        constexpr int OFF = J * 512 * S + (I % KS) * 16;
+        b[V][0].lo = lds_tr<OFF>(xr0[I / KS]);
+        b[V][0].hi = lds_tr<OFF + 4 * S * 16>(xr0[I / KS]);
+        b[V][1].lo = lds_tr<OFF>(xr1[I / KS]);
+        b[V][1].hi = lds_tr<OFF + 4 * S * 16>(xr1[I / KS]);
+    }
+    template <int V>
+    static __device__ __forceinline__ void run(frag8 (&a)[NK][2], frag8 (&b)[NV][2], f32x4 (&acc)[T][2][2], unsigned za0, unsigned za1,
+                                               const unsigned (&xr0)[KS], const unsigned (&xr1)[KS]) {
+        constexpr int J = V / T, I = V % T;
+        if constexpr (V == 0) {
+            request<0>(a, b, za0, za1, xr0, xr1);
+            if constexpr (D == 2 && NV > 1) request<1>(a, b, za0, za1, xr0, xr1);
+        }
+        constexpr int N = behind(V);
+        if constexpr (I == 0)
+            asm volatile("s_waitcnt lgkmcnt(%8)"
+                         : "+v"(a[J][0].lo), "+v"(a[J][0].hi), "+v"(a[J][1].lo), "+v"(a[J][1].hi), "+v"(b[V][0].lo), "+v"(b[V][0].hi),
+                           "+v"(b[V][1].lo), "+v"(b[V][1].hi)
+                         : "n"(N));
+        else
+            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(b[V][0].lo), "+v"(b[V][0].hi), "+v"(b[V][1].lo), "+v"(b[V][1].hi) : "n"(N));
+        if constexpr (V + D < NV) request<V + D>(a, b, za0, za1, xr0, xr1);
+#pragma unroll
+        for (int is = 0; is < 2; ++is)
+#pragma unroll
+            for (int cs = 0; cs < 2; ++cs)
+                acc[I][cs][is] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[J][cs]),
+                                                                        __builtin_bit_cast(f16x8, b[V][is]), acc[I][cs][is], 0, 0, 0);
+        if constexpr (V + 1 < NV) run<V + 1>(a, b, acc, za0, za1, xr0, xr1);
+    }
+};
+
+template <int KS, int S, int NP, bool WIDE = false>
 __device__ __forceinline__ void wgrad_dma_body(const Wgrad16Params& p) {
     constexpr int T = KS * KS;
     extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
@@ -327,7 +393,8 @@ __device__ __forceinline__ void wgrad_dma_body(const Wgrad16Params& p) {
     // DMA piece descriptors, decoded once: piece = 64 consecutive slots of the buffer; slot -> (image kind, block, row, column)
     unsigned piece_rel[NP];  // byte offset relative to the tile origin of its tensor; kOob = padding slot
     int piece_row[NP];       // row within the tile, bit 30 set = gradient image
-    const int x_units = 4 * p.xslots, z_units = 4 * p.zslots;
+    constexpr int TB = WIDE ? 8 : 4;  // 8-channel blocks per tile side
+    const int x_units = TB * p.xslots, z_units = TB * p.zslots;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int piece = wave + 4 * i;
@@ -340,7 +407,7 @@ __device__ __forceinline__ void wgrad_dma_body(const Wgrad16Params& p) {
             const unsigned rem = s - blk * p.xslots;
             const unsigned r = fastdiv(rem, p.Px, p.magic_p);
             const int c = (int)(rem - r * p.Px) - p.pad;
-            const int cb = ci_tile * 4 + (int)blk;
+            const int cb = ci_tile * TB + (int)blk;
             if (s < x_units && r < (unsigned)p.Rin && c >= 0 && c < p.W && cb < p.C8in)
                 piece_rel[i] = ((unsigned)cb * p.H * p.W + r * p.W + c) * 16u;
             piece_row[i] = (int)r;
@@ -350,11 +417,66 @@ __device__ __forceinline__ void wgrad_dma_body(const Wgrad16Params& p) {
             const unsigned rem = sz - blk * p.zslots;
             const unsigned r = fastdiv(rem, p.P, p.magic_p);
             const unsigned c = rem - r * p.P;
-            const int cb = co_tile * 4 + (int)blk;
+            const int cb = co_tile * TB + (int)blk;
             if (sz < z_units && r < (unsigned)p.R && c < (unsigned)p.Wo && cb < p.C8out)
                 piece_rel[i] = ((unsigned)cb * p.Ho * p.Wo + r * p.Wo + c) * 16u;
             piece_row[i] = (int)r;
         }
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem16;  // LDS byte address of the stages
+    if constexpr (WIDE) {
+        f32x4 acc[T][2][2];  // [tap][16-cout half][16-cin half] of this wave's 32 x 32 quarter
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[t][i >> 1][i & 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // lane-constant operand byte offsets: position (8g + q) of a k-step, channels 4pp .. 4pp+3 of the FIRST 16 of this wave's 32
+        // (blocks 4 co_sub .. of the tile); the second 16 channels are two 8-channel blocks further
+        const int a_base = ((co_sub * 4 + (pp >> 1)) * p.zslots + (8 * g + q)) * 16 + (pp & 1) * 8 + p.z_base * 16;
+        const int b_base = ((ci_sub * 4 + (pp >> 1)) * p.xslots + S * (8 * g + q)) * 16 + (pp & 1) * 8;
+        const unsigned a_half = (unsigned)(2 * p.zslots * 16), b_half = (unsigned)(2 * p.xslots * 16);
+        if (t_begin < t_end) WGRAD_DMA_TILE(smem16, t_begin);
+        const int ksteps = p.K >> 5;
+        for (int t = t_begin; t < t_end; ++t) {
+            const int buf = (t - t_begin) & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile has landed; the other stage is no longer read
+            __syncthreads();
+            if (t + 1 < t_end) WGRAD_DMA_TILE(smem16 + (buf ^ 1) * buf_units, t + 1);
+            const unsigned stage = lds0 + (unsigned)(buf * buf_units * 16);
+            int ks = 0;
+            for (; ks + 1 < ksteps; ks += 2) {  // two k-steps per straight-line block
+                const unsigned za0 = stage + (unsigned)(a_base + ks * 512), xb = stage + (unsigned)(b_base + ks * 512 * S);
+                unsigned xr0[KS], xr1[KS];
+#pragma unroll
+                for (int r = 0; r < KS; ++r) { xr0[r] = xb + (unsigned)(r * p.Px * 16); xr1[r] = xr0[r] + b_half; }
+                frag8 a[2][2], b[2 * T][2];
+                WgradTaps2<KS, S, T, 2>::template run<0>(a, b, acc, za0, za0 + a_half, xr0, xr1);
+            }
+            if (ks < ksteps) {
+                const unsigned za0 = stage + (unsigned)(a_base + ks * 512), xb = stage + (unsigned)(b_base + ks * 512 * S);
+                unsigned xr0[KS], xr1[KS];
+#pragma unroll
+                for (int r = 0; r < KS; ++r) { xr0[r] = xb + (unsigned)(r * p.Px * 16); xr1[r] = xr0[r] + b_half; }
+                frag8 a[1][2], b[T][2];
+                WgradTaps2<KS, S, T, 1>::template run<0>(a, b, acc, za0, za0 + a_half, xr0, xr1);
+            }
+        }
+        // D: lane holds couts 4g .. 4g+3 (rows) of cin (lane & 15) (column) -> slab [Cout][Cin][T]
+        float* slab = p.slabs + ((size_t)blockIdx.z * p.splits + blockIdx.y) * p.Cout * p.Cin * T;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cs = i >> 1, is = i & 1;
+            const int ci = ci_tile * 64 + ci_sub * 32 + is * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co_tile * 64 + co_sub * 32 + cs * 16 + 4 * g + r;
+                if (co < p.Cout && ci < p.Cin) {
+#pragma unroll
+                    for (int tp = 0; tp < T; ++tp) slab[((size_t)co * p.Cin + ci) * T + tp] = acc[tp][cs][is][r];
+                }
+            }
+        }
+        return;
     }
     f32x4 acc[T];
 #pragma unroll
@@ -363,7 +485,6 @@ __device__ __forceinline__ void wgrad_dma_body(const Wgrad16Params& p) {
     // lane-constant operand byte offsets: position (8g + q) of a k-step, channels 4pp .. 4pp+3 of this wave's 16
     const int a_base = ((co_sub * 2 + (pp >> 1)) * p.zslots + (8 * g + q)) * 16 + (pp & 1) * 8 + p.z_base * 16;
     const int b_base = ((ci_sub * 2 + (pp >> 1)) * p.xslots + S * (8 * g + q)) * 16 + (pp & 1) * 8;
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem16;  // LDS byte address of the stages
 
     if (t_begin < t_end) WGRAD_DMA_TILE(smem16, t_begin);
     const int ksteps = p.K >> 5;
@@ -455,35 +576,48 @@ __global__ __launch_bounds__(256) void wgrad16_reduce_grouped_kernel(const float
 }
 
 constexpr int kDmaPieces = 28;  // DMA pieces per wave and tile the LDS-DMA kernel is built for
+constexpr int kDmaPiecesK = 12;  // ... and its wide form (4 T accumulators per lane: the piece descriptors must stay small)
 __global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dma_k1s1(const Wgrad16Params p) { wgrad_dma_body<1, 1, kDmaPieces>(p); }
 __global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dma_k1s2(const Wgrad16Params p) { wgrad_dma_body<1, 2, kDmaPieces>(p); }
 __global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dma_k3s1(const Wgrad16Params p) { wgrad_dma_body<3, 1, kDmaPieces>(p); }
 __global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dma_k3s2(const Wgrad16Params p) { wgrad_dma_body<3, 2, kDmaPieces>(p); }
 __global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dma_k4s2(const Wgrad16Params p) { wgrad_dma_body<4, 2, kDmaPieces>(p); }
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dmak_k1s1(const Wgrad16Params p) { wgrad_dma_body<1, 1, kDmaPiecesK, true>(p); }
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dmak_k1s2(const Wgrad16Params p) { wgrad_dma_body<1, 2, kDmaPiecesK, true>(p); }
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dmak_k3s1(const Wgrad16Params p) { wgrad_dma_body<3, 1, kDmaPiecesK, true>(p); }
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dmak_k3s2(const Wgrad16Params p) { wgrad_dma_body<3, 2, kDmaPiecesK, true>(p); }
 
 // LDS-DMA form of the same decomposition: two buffers of [4][xslots] + [4][zslots] elements; false = does not fit (the
 // register-staged kernel serves the shape).  MP_WGRAD16_DMA=0 switches it off (A/B).
 bool geometry_dma(Wgrad16Params& p, int KS, int S, size_t& lds_bytes) {
     if (const char* e = knob("MP_WGRAD16_DMA"))
         if (atoi(e) == 0) return false;
-    for (int pass = 0; pass < 2; ++pass) {
-        const size_t budget = pass == 0 ? 78 * 1024 : 150 * 1024;
-        for (int R = p.Ho < 16 ? p.Ho : 16; R >= 1; --R) {
-            const int Rin = (R - 1) * S + KS;
-            const int K = (R * p.P + 31) / 32 * 32;
-            int xneed = S * (K - 1) + (KS - 1) * p.Px + (KS - 1) + 1;
-            if (xneed < Rin * p.Px) xneed = Rin * p.Px;
-            // == 4 (mod 16): the two channel blocks a 16-lane group reads are 64 B apart modulo the 256-byte bank row
-            const int xslots = (xneed + 11) / 16 * 16 + 4, zslots = K + 4 + ((K % 16) ? 16 - K % 16 : 0);
-            const int x_pieces = (4 * xslots + 63) / 64, z_pieces = (4 * zslots + 63) / 64;
-            const int pieces = x_pieces + z_pieces;
-            const size_t bytes = (size_t)2 * pieces * 64 * 16;
-            if (pieces > 4 * kDmaPieces || bytes > budget) continue;
-            p.R = R; p.Rin = Rin; p.K = K; p.xrows = xneed; p.nbuf = 2;
-            p.xslots = xslots; p.zslots = zslots; p.pieces = pieces; p.x_pieces = x_pieces; p.z_base = x_pieces * 64;
-            p.magic_xs = magic_of(xslots); p.magic_zs = magic_of(zslots); p.magic_p = magic_of(p.P);
-            lds_bytes = bytes;
-            return true;
+    // wide form (64 x 64 tile per workgroup): 1x1 / 3x3 layers with more than 32 channels on both sides
+    bool wide = KS <= 3 && p.Cin > 32 && p.Cout > 32;
+    if (const char* e = knob("MP_WGRAD16_WIDE")) wide = wide && atoi(e) != 0;
+    for (int w = wide ? 1 : 0; w >= 0; --w) {
+        const int tb = w ? 8 : 4;  // 8-channel blocks per tile side
+        const int np = w ? kDmaPiecesK : kDmaPieces;
+        for (int pass = 0; pass < 2; ++pass) {
+            const size_t budget = pass == 0 ? 78 * 1024 : 150 * 1024;
+            for (int R = p.Ho < 16 ? p.Ho : 16; R >= 1; --R) {
+                const int Rin = (R - 1) * S + KS;
+                const int K = (R * p.P + 31) / 32 * 32;
+                int xneed = S * (K - 1) + (KS - 1) * p.Px + (KS - 1) + 1;
+                if (xneed < Rin * p.Px) xneed = Rin * p.Px;
+                // == 4 (mod 16): the two channel blocks a 16-lane group reads are 64 B apart modulo the 256-byte bank row
+                const int xslots = (xneed + 11) / 16 * 16 + 4, zslots = K + 4 + ((K % 16) ? 16 - K % 16 : 0);
+                const int x_pieces = (tb * xslots + 63) / 64, z_pieces = (tb * zslots + 63) / 64;
+                const int pieces = x_pieces + z_pieces;
+                const size_t bytes = (size_t)2 * pieces * 64 * 16;
+                if (pieces > 4 * np || bytes > budget) continue;
+                p.R = R; p.Rin = Rin; p.K = K; p.xrows = xneed; p.nbuf = 2;
+                p.xslots = xslots; p.zslots = zslots; p.pieces = pieces; p.x_pieces = x_pieces; p.z_base = x_pieces * 64;
+                p.magic_xs = magic_of(xslots); p.magic_zs = magic_of(zslots); p.magic_p = magic_of(p.P);
+                p.wide = w;
+                lds_bytes = bytes;
+                return true;
+            }
         }
     }
     return false;
@@ -509,6 +643,7 @@ int geometry(const mp_conv_desc* d, Wgrad16Params& p, size_t& lds_bytes, int n_j
     p.Px = p.P;
     // pass 0: double-buffered, two workgroups per CU; pass 1: double-buffered, whatever fits; pass 2: single buffer
     p.pieces = 0;
+    p.wide = 0;
     bool found = geometry_dma(p, KS, S, lds_bytes);  // the LDS-DMA form where its tiles fit (p.pieces > 0 marks it)
     for (int pass = 0; pass < 3 && !found; ++pass) {
         p.nbuf = pass < 2 ? 2 : 1;
@@ -526,8 +661,10 @@ int geometry(const mp_conv_desc* d, Wgrad16Params& p, size_t& lds_bytes, int n_j
     if (!found) return MP_ERR_UNSUPPORTED;
     p.tiles_y = (p.Ho + p.R - 1) / p.R;
     p.tiles = p.N * p.tiles_y;
-    p.ci_tiles = (p.Cin + 31) / 32;
-    const int ct = ((p.Cout + 31) / 32) * p.ci_tiles;
+    const int tw = p.wide ? 64 : 32;  // channels per tile side
+    p.ci_tiles = (p.Cin + tw - 1) / tw;
+    p.co_tiles = (p.Cout + tw - 1) / tw;
+    const int ct = p.co_tiles * p.ci_tiles;
     int target = 512;  // two workgroups per CU; the slab reduce reads splits x |dW| floats, so no finer than that
     if (const char* e = knob("MP_WGRAD16_WGS")) {  // experiments: total workgroups per launch
         const int v = atoi(e);
@@ -535,7 +672,8 @@ int geometry(const mp_conv_desc* d, Wgrad16Params& p, size_t& lds_bytes, int n_j
     }
     // a grouped launch spreads ~768 workgroups over its layers: per layer fewer, longer pixel slabs - the slab traffic (written here,
     // re-read by the reduce) and the per-workgroup prologue / epilogue shrink by the group size
-    int splits = n_jobs > 1 ? (target + target / 2) / (ct * n_jobs) : target / ct;
+    // (a 64 x 64 tile's slab is four times the bytes: the wide form stays at ~512 workgroups)
+    int splits = n_jobs > 1 ? (p.wide ? target : target + target / 2) / (ct * n_jobs) : target / ct;
     if (splits < 1) splits = 1;
     if (splits > p.tiles) splits = p.tiles;
     p.tiles_per_split = (p.tiles + splits - 1) / splits;
@@ -550,12 +688,16 @@ int launch_wgrad16_dma(const Wgrad16Params& p, size_t lds, hipStream_t s) {
     auto kern = KS == 4 ? conv_wgrad_f16_dma_k4s2
                         : KS == 3 ? (S == 1 ? conv_wgrad_f16_dma_k3s1 : conv_wgrad_f16_dma_k3s2)
                                   : (S == 1 ? conv_wgrad_f16_dma_k1s1 : conv_wgrad_f16_dma_k1s2);
+    auto kern_k = KS == 3 ? (S == 1 ? conv_wgrad_f16_dmak_k3s1 : conv_wgrad_f16_dmak_k3s2)
+                          : (S == 1 ? conv_wgrad_f16_dmak_k1s1 : conv_wgrad_f16_dmak_k1s2);
     static AttrOnce attr_once;
     if (attr_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
     }
-    hipLaunchKernelGGL(kern, dim3(((p.Cout + 31) / 32) * p.ci_tiles, p.splits, p.n_jobs ? p.n_jobs : 1), dim3(256), lds, s, p);
+    if (p.wide && KS <= 3) kern = kern_k;
+    hipLaunchKernelGGL(kern, dim3(p.co_tiles * p.ci_tiles, p.splits, p.n_jobs ? p.n_jobs : 1), dim3(256), lds, s, p);
     return check_launch();
 }
 
@@ -568,7 +710,7 @@ int launch_wgrad16(const Wgrad16Params& p, size_t lds, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
     }
-    hipLaunchKernelGGL(kern, dim3(((p.Cout + 31) / 32) * p.ci_tiles, p.splits, p.n_jobs ? p.n_jobs : 1), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3(p.co_tiles * p.ci_tiles, p.splits, p.n_jobs ? p.n_jobs : 1), dim3(256), lds, s, p);
     return check_launch();
 }
 
