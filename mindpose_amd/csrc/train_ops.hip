@@ -1496,12 +1496,13 @@ int mp_f16_bn_train_bwd(const void* dy, const void* z, const void* y, const floa
     return check_launch();
 }
 
-// pixel-range chunks per channel block of the statistics-free apply kernels: every block folds n_parts x 64 bytes of partials first,
-// so blocks are fatter than bn16_apply_chunks' (>= 2048 elements each): ~512 blocks on the large maps, a few dozen on the small ones
+// pixel-range chunks per channel block of the statistics-free apply kernels.  These passes are bound by the bytes they keep in
+// flight (a thread has 4 x 16 B per operand tensor outstanding), not by the n_parts x 64 bytes of partials every block folds first:
+// ~1024 blocks (four per CU) of >= 1024 elements measured best on every map size of the HRNet step - 512 fatter blocks ran the
+// 64x48 maps at 2.2 TB/s, 1024 at 3.3 TB/s; 2048 and more lose again to the redundant folds (round 3, tools/gpu_r3_m.sh).
 static unsigned bn16_pre_chunks(int n, int c8, int hw, int n_parts) {
-    // a block folds n_parts x 64 bytes before it streams: with many slots, fewer and fatter blocks (the redundant fold traffic stays
-    // well below the tensor traffic)
-    size_t total = n_parts > 256 ? 256 : 512, floor_elems = 2048;
+    (void)n_parts;
+    size_t total = 1024, floor_elems = 1024;
     if (const char* e = knob("MP_BN_PRE_BLOCKS")) total = (size_t)atoi(e);
     if (const char* e = knob("MP_BN_PRE_MIN")) floor_elems = (size_t)atoi(e);
     size_t chunks = (total + c8 - 1) / c8;
