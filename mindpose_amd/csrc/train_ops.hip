@@ -321,6 +321,14 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 // The forward output is y = half(max(fma(z, sc, sh), 0)) with sc = gamma * invstd, sh = fma(-mean, sc, beta): these two helpers are
 // the ONLY place that arithmetic is written, because the backward pass of a ReLU layer WITHOUT a residual input re-derives the
 // ReLU mask (y > 0) from z with them instead of reading y (relu mode 2: two tensor reads less per backward BatchNorm).
+// 16-bit lanes of channel block blk that hold real channels (c8 layout: channel 8 blk + j in half j)
+__device__ __forceinline__ u32x4_t bn16_channel_mask(int blk, int c) {
+    u32x4_t m;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        m[w] = (blk * 8 + 2 * w < c ? 0x0000FFFFu : 0u) | (blk * 8 + 2 * w + 1 < c ? 0xFFFF0000u : 0u);
+    return m;
+}
 __device__ __forceinline__ float bn16_shift(float beta, float mean, float sc) { return __builtin_fmaf(-mean, sc, beta); }
 __device__ __forceinline__ float bn16_affine(float z, float sc, float sh) { return __builtin_fmaf(z, sc, sh); }
 __device__ __forceinline__ bool bn16_relu_open(float z, float sc, float sh) { return (float)(_Float16)bn16_affine(z, sc, sh) > 0.f; }
@@ -678,21 +686,26 @@ __global__ __launch_bounds__(256) void bn16_apply_pre_kernel(const u32x4_t* __re
         const unsigned img = hw <= 1 ? e : (exact ? __umulhi(e, magic_hw) : e / (unsigned)hw);
         return (size_t)e + (size_t)img * img_extra + blk_off;
     };
-    // the thread's first four elements are requested BEFORE the fold: the statistics prologue (partial slots -> totals -> scale /
-    // shift: three dependent round trips) then runs under their latency - on the small maps these four are all a thread has
-    constexpr int kHead = 4;
-    u32x4_t hz[kHead], hr[kHead];
-    size_t hi[kHead];
+    // Batches of kBatch elements per thread: all loads of a batch are issued back to back, and the NEXT batch is requested before
+    // this one is transformed (a loop of load / wait / transform / store per element keeps one load per tensor in flight and ran
+    // the large maps at ~2 TB/s).  The first batch goes out BEFORE the fold: the statistics prologue (partial slots -> totals ->
+    // scale / shift: three dependent round trips) then runs under its latency - on the small maps that batch is all a thread has.
+    constexpr int kBatch = 4;
+    const bool has_res = res != nullptr;
+    const u32x4_t zero4 = (u32x4_t){0u, 0u, 0u, 0u};
+    u32x4_t cz[kBatch], cr[kBatch];
+    size_t ci[kBatch];
+    auto request = [&](unsigned base, u32x4_t (&qz)[kBatch], u32x4_t (&qr)[kBatch], size_t (&qi)[kBatch]) {
 #pragma unroll
-    for (int k = 0; k < kHead; ++k) {
-        const unsigned e = e0 + threadIdx.x + 256u * k;
-        hi[k] = e < e1 ? index_of(e) : (size_t)0;
-        hz[k] = hr[k] = (u32x4_t){0u, 0u, 0u, 0u};
-        if (e < e1) {
-            hz[k] = z[hi[k]];
-            if (res) hr[k] = res[hi[k]];
+        for (int k = 0; k < kBatch; ++k) {
+            const unsigned e = base + threadIdx.x + 256u * k;
+            const bool ok = e < e1;
+            qi[k] = index_of(ok ? e : e0);
+            qz[k] = ok ? z[qi[k]] : zero4;
+            qr[k] = (ok && has_res) ? res[qi[k]] : zero4;
         }
-    }
+    };
+    request(e0, cz, cr, ci);
     bn16_fold_parts(pre, blk, n_parts, s_tot, s_sm);
     if (threadIdx.x < 8) {
         const int j = threadIdx.x, ch = blk * 8 + j;
@@ -723,32 +736,32 @@ __global__ __launch_bounds__(256) void bn16_apply_pre_kernel(const u32x4_t* __re
     __syncthreads();
     float sc[8], sh[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { sc[j] = s_scale[j]; sh[j] = s_shift[j]; }
+    for (int j = 0; j < 8; ++j) { sc[j] = s_scale[j]; sh[j] = s_shift[j]; }  // 0 / 0 on the padding channels: they stay zero
+    const float floor_v = relu ? 0.f : -__builtin_inff();
+    const u32x4_t keep = bn16_channel_mask(blk, c);  // padding channels leave as zeros whatever the operands hold there
     auto apply = [&](const u32x4_t zq, const u32x4_t rq, size_t i) {
         const h16x8 zv = __builtin_bit_cast(h16x8, zq), rv = __builtin_bit_cast(h16x8, rq);
         h16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float v = 0.f;
-            if (blk * 8 + j < c) {
-                v = bn16_affine((float)zv[j], sc[j], sh[j]);
-                if (res) v += (float)rv[j];
-                if (relu) v = fmaxf(v, 0.f);
-            }
-            o[j] = (_Float16)v;
+            float v = bn16_affine((float)zv[j], sc[j], sh[j]);
+            v += (float)rv[j];  // zeros without a residual: exact
+            o[j] = (_Float16)fmaxf(v, floor_v);
         }
-        y[i] = __builtin_bit_cast(u32x4_t, o);
+        y[i] = __builtin_bit_cast(u32x4_t, o) & keep;
     };
+    for (unsigned base = e0; base < e1; base += 256u * kBatch) {
+        u32x4_t nz[kBatch], nr[kBatch];
+        size_t ni[kBatch];
+        const bool more = base + 256u * kBatch < e1;  // uniform
+        if (more) request(base + 256u * kBatch, nz, nr, ni);
 #pragma unroll
-    for (int k = 0; k < kHead; ++k)
-        if (e0 + threadIdx.x + 256u * k < e1) apply(hz[k], hr[k], hi[k]);
-#pragma unroll 4
-    for (unsigned e = e0 + threadIdx.x + 256u * kHead; e < e1; e += 256) {
-        const size_t i = index_of(e);
-        const u32x4_t zq = z[i];
-        u32x4_t rq = zq;
-        if (res) rq = res[i];
-        apply(zq, rq, i);
+        for (int k = 0; k < kBatch; ++k)
+            if (base + threadIdx.x + 256u * k < e1) apply(cz[k], cr[k], ci[k]);
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) { cz[k] = nz[k]; cr[k] = nr[k]; ci[k] = ni[k]; }
+        }
     }
 }
 
@@ -775,19 +788,21 @@ __global__ __launch_bounds__(256) void bn16_bwd_apply_pre_kernel(const u32x4_t* 
         const unsigned img = hw <= 1 ? e : (exact ? __umulhi(e, magic_hw) : e / (unsigned)hw);
         return (size_t)e + (size_t)img * img_extra + blk_off;
     };
-    constexpr int kHead = 4;  // first elements requested before the fold (see bn16_apply_pre_kernel)
-    u32x4_t hg[kHead], hz[kHead];
-    size_t hi[kHead];
+    constexpr int kBatch = 4;  // batched requests, the first batch before the fold (see bn16_apply_pre_kernel)
+    const u32x4_t zero4 = (u32x4_t){0u, 0u, 0u, 0u};
+    u32x4_t cg[kBatch], cz[kBatch];
+    size_t ci[kBatch];
+    auto request = [&](unsigned base, u32x4_t (&qg)[kBatch], u32x4_t (&qz)[kBatch], size_t (&qi)[kBatch]) {
 #pragma unroll
-    for (int q = 0; q < kHead; ++q) {
-        const unsigned e = e0 + threadIdx.x + 256u * q;
-        hi[q] = e < e1 ? index_of(e) : (size_t)0;
-        hg[q] = hz[q] = (u32x4_t){0u, 0u, 0u, 0u};
-        if (e < e1) {
-            hg[q] = g_in[hi[q]];
-            hz[q] = z[hi[q]];
+        for (int k = 0; k < kBatch; ++k) {
+            const unsigned e = base + threadIdx.x + 256u * k;
+            const bool ok = e < e1;
+            qi[k] = index_of(ok ? e : e0);
+            qg[k] = ok ? g_in[qi[k]] : zero4;
+            qz[k] = ok ? z[qi[k]] : zero4;
         }
-    }
+    };
+    request(e0, cg, cz, ci);
     bn16_fold_parts(pre, blk, n_parts, s_tot, s_sm);
     if (threadIdx.x < 8) {
         const int j = threadIdx.x, ch = blk * 8 + j;
@@ -814,28 +829,30 @@ __global__ __launch_bounds__(256) void bn16_bwd_apply_pre_kernel(const u32x4_t* 
     __syncthreads();
     float k[8], mu[8], is[8], mb[8], mg[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { k[j] = s_k[j]; mu[j] = s_mu[j]; is[j] = s_is[j]; mb[j] = s_mb[j]; mg[j] = s_mg[j]; }
+    for (int j = 0; j < 8; ++j) { k[j] = s_k[j]; mu[j] = s_mu[j]; is[j] = s_is[j]; mb[j] = s_mb[j]; mg[j] = s_mg[j]; }  // zeros on padding channels
+    const u32x4_t keep = bn16_channel_mask(blk, c);  // padding channels leave as zeros whatever the operands hold there
     auto apply = [&](const u32x4_t gq, const u32x4_t zq, size_t i) {
         const h16x8 gv = __builtin_bit_cast(h16x8, gq), zv = __builtin_bit_cast(h16x8, zq);
         h16x8 oz;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float d = 0.f;
-            if (blk * 8 + j < c) {
-                const float xh = ((float)zv[j] - mu[j]) * is[j];
-                d = k[j] * ((float)gv[j] - mb[j] - xh * mg[j]);
-            }
-            oz[j] = (_Float16)d;
+            const float xh = ((float)zv[j] - mu[j]) * is[j];
+            oz[j] = (_Float16)(k[j] * ((float)gv[j] - mb[j] - xh * mg[j]));
         }
-        dz[i] = __builtin_bit_cast(u32x4_t, oz);
+        dz[i] = __builtin_bit_cast(u32x4_t, oz) & keep;
     };
+    for (unsigned base = e0; base < e1; base += 256u * kBatch) {
+        u32x4_t ng[kBatch], nz[kBatch];
+        size_t ni[kBatch];
+        const bool more = base + 256u * kBatch < e1;  // uniform
+        if (more) request(base + 256u * kBatch, ng, nz, ni);
 #pragma unroll
-    for (int q = 0; q < kHead; ++q)
-        if (e0 + threadIdx.x + 256u * q < e1) apply(hg[q], hz[q], hi[q]);
-#pragma unroll 4
-    for (unsigned e = e0 + threadIdx.x + 256u * kHead; e < e1; e += 256) {
-        const size_t i = index_of(e);
-        apply(g_in[i], z[i], i);
+        for (int q = 0; q < kBatch; ++q)
+            if (base + threadIdx.x + 256u * q < e1) apply(cg[q], cz[q], ci[q]);
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < kBatch; ++q) { cg[q] = ng[q]; cz[q] = nz[q]; ci[q] = ni[q]; }
+        }
     }
 }
 
