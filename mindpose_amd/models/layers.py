@@ -196,6 +196,10 @@ def _autotune(key, macs, n_variants, launch) -> int:
                 t = dt if t is None or dt < t else t
             if best_t is None or t < best_t:
                 best, best_t = v, t
+            log = os.environ.get("MINDPOSE_TUNE_LOG")  # per-candidate timings (ms per 5 launches), for kernel work
+            if log:
+                with open(log, "a") as fh:
+                    fh.write(f"{key}\t{v}\t{t:.4f}\n")
     if macs >= (1 << 26):
         best = _sync_choice(best)
         _TUNE_CACHE[("synced", key)] = 1
