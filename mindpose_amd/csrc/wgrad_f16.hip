@@ -43,6 +43,8 @@ struct Wgrad16Params {
     int x_pieces, z_base;        // DMA pieces of the input image; first element of the gradient image (a multiple of 64)
     int wide;                    // LDS-DMA form: 1 = 64 x 64 tile per workgroup (wave = one 32 x 32 quarter), co_tiles / ci_tiles count 64s
     int co_tiles;
+    int plane_slots;             // LDS-DMA form, stride 2: > 0 = the input rows of a tile lie in two row-parity planes of this many slots
+    unsigned magic_px;
     unsigned magic_xs, magic_zs, magic_p;
     // grouped launch (mp_f16_conv_wgrad_grouped): blockIdx.z = job, up to kWgradJobs layers of ONE shape; the operand pointers
     // travel by value in the kernel arguments (nothing to upload, hipGraph-capturable); n_jobs == 0: the single-layer launch
@@ -404,9 +406,13 @@ __device__ __forceinline__ void wgrad_dma_body(const Wgrad16Params& p) {
         if (piece < p.x_pieces) {
             const int s = piece * 64 + lane;
             const unsigned blk = fastdiv((unsigned)s, p.xslots, p.magic_xs);
-            const unsigned rem = s - blk * p.xslots;
-            const unsigned r = fastdiv(rem, p.Px, p.magic_p);
-            const int c = (int)(rem - r * p.Px) - p.pad;
+            unsigned rem = s - blk * p.xslots;
+            // stride 2: slots [0, plane_slots) hold the even tile rows, [plane_slots, 2 plane_slots) the odd ones (see geometry_dma)
+            const unsigned plane = (S == 2 && p.plane_slots > 0 && rem >= (unsigned)p.plane_slots) ? 1u : 0u;
+            rem -= plane * p.plane_slots;
+            const unsigned rp = fastdiv(rem, p.Px, p.magic_px);
+            const int c = (int)(rem - rp * p.Px) - p.pad;
+            const unsigned r = (S == 2 && p.plane_slots > 0) ? 2 * rp + plane : rp;
             const int cb = ci_tile * TB + (int)blk;
             if (s < x_units && r < (unsigned)p.Rin && c >= 0 && c < p.W && cb < p.C8in)
                 piece_rel[i] = ((unsigned)cb * p.H * p.W + r * p.W + c) * 16u;
@@ -424,6 +430,10 @@ __device__ __forceinline__ void wgrad_dma_body(const Wgrad16Params& p) {
         }
     }
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem16;  // LDS byte address of the stages
+    unsigned row_off[KS];  // byte offset of tap row ky inside a channel block's input image
+#pragma unroll
+    for (int r = 0; r < KS; ++r)
+        row_off[r] = (S == 2 && p.plane_slots > 0) ? (unsigned)(((r & 1) * p.plane_slots + (r >> 1) * p.Px) * 16) : (unsigned)(r * p.Px * 16);
     if constexpr (WIDE) {
         f32x4 acc[T][2][2];  // [tap][16-cout half][16-cin half] of this wave's 32 x 32 quarter
 #pragma unroll
@@ -448,7 +458,7 @@ __device__ __forceinline__ void wgrad_dma_body(const Wgrad16Params& p) {
                 const unsigned za0 = stage + (unsigned)(a_base + ks * 512), xb = stage + (unsigned)(b_base + ks * 512 * S);
                 unsigned xr0[KS], xr1[KS];
 #pragma unroll
-                for (int r = 0; r < KS; ++r) { xr0[r] = xb + (unsigned)(r * p.Px * 16); xr1[r] = xr0[r] + b_half; }
+                for (int r = 0; r < KS; ++r) { xr0[r] = xb + row_off[r]; xr1[r] = xr0[r] + b_half; }
                 frag8 a[2][2], b[2 * T][2];
                 WgradTaps2<KS, S, T, 2>::template run<0>(a, b, acc, za0, za0 + a_half, xr0, xr1);
             }
@@ -456,7 +466,7 @@ __device__ __forceinline__ void wgrad_dma_body(const Wgrad16Params& p) {
                 const unsigned za0 = stage + (unsigned)(a_base + ks * 512), xb = stage + (unsigned)(b_base + ks * 512 * S);
                 unsigned xr0[KS], xr1[KS];
 #pragma unroll
-                for (int r = 0; r < KS; ++r) { xr0[r] = xb + (unsigned)(r * p.Px * 16); xr1[r] = xr0[r] + b_half; }
+                for (int r = 0; r < KS; ++r) { xr0[r] = xb + row_off[r]; xr1[r] = xr0[r] + b_half; }
                 frag8 a[1][2], b[T][2];
                 WgradTaps2<KS, S, T, 1>::template run<0>(a, b, acc, za0, za0 + a_half, xr0, xr1);
             }
@@ -503,7 +513,7 @@ __device__ __forceinline__ void wgrad_dma_body(const Wgrad16Params& p) {
             a.hi = lds_tr<4 * 16>(za);
             unsigned xr[KS];
 #pragma unroll
-            for (int r = 0; r < KS; ++r) xr[r] = xb + (unsigned)(r * p.Px * 16);
+            for (int r = 0; r < KS; ++r) xr[r] = xb + row_off[r];
             WgradTaps<KS, S, T, (T < 3 ? T : 3), 0>::run(a, b, acc, xr);
         }
     }
@@ -595,6 +605,17 @@ bool geometry_dma(Wgrad16Params& p, int KS, int S, size_t& lds_bytes) {
     // wide form (64 x 64 tile per workgroup): 1x1 / 3x3 layers with more than 32 channels on both sides
     bool wide = KS <= 3 && p.Cin > 32 && p.Cout > 32;
     if (const char* e = knob("MP_WGRAD16_WIDE")) wide = wide && atoi(e) != 0;
+    // Stride 2: the position trick needs (input position) = 2 x (gradient position) + (tap offset), i.e. the gradient rows on the
+    // pitch of the INPUT rows - with one linear input image that is 2 Wo + 2 positions per gradient row of Wo, half of every
+    // k-step multiplying zeros.  With the tile's input rows split by parity into two planes (tile row i -> plane i & 1, row i >> 1;
+    // tap row ky reads plane ky & 1 from row ky >> 1 on) the input pitch Px belongs to ONE plane and the gradient pitch is Px / 2.
+    bool planes = S == 2;
+    if (const char* e = knob("MP_WGRAD16_PLANES")) planes = planes && atoi(e) != 0;
+    const int P0 = p.P, Px0 = p.Px;
+    if (planes) {
+        p.P = (p.W + 2 * p.pad + 1) / 2 > p.Wo ? (p.W + 2 * p.pad + 1) / 2 : p.Wo;
+        p.Px = 2 * p.P;
+    }
     for (int w = wide ? 1 : 0; w >= 0; --w) {
         const int tb = w ? 8 : 4;  // 8-channel blocks per tile side
         const int np = w ? kDmaPiecesK : kDmaPieces;
@@ -605,6 +626,12 @@ bool geometry_dma(Wgrad16Params& p, int KS, int S, size_t& lds_bytes) {
                 const int K = (R * p.P + 31) / 32 * 32;
                 int xneed = S * (K - 1) + (KS - 1) * p.Px + (KS - 1) + 1;
                 if (xneed < Rin * p.Px) xneed = Rin * p.Px;
+                int plane_slots = 0;
+                if (planes) {  // per plane: the furthest position a k-step reads, and every row the plane holds
+                    plane_slots = S * (K - 1) + ((KS - 1) >> 1) * p.Px + (KS - 1) + 1;
+                    if (plane_slots < ((Rin + 1) >> 1) * p.Px) plane_slots = ((Rin + 1) >> 1) * p.Px;
+                    xneed = 2 * plane_slots;
+                }
                 // == 4 (mod 16): the two channel blocks a 16-lane group reads are 64 B apart modulo the 256-byte bank row
                 const int xslots = (xneed + 11) / 16 * 16 + 4, zslots = K + 4 + ((K % 16) ? 16 - K % 16 : 0);
                 const int x_pieces = (tb * xslots + 63) / 64, z_pieces = (tb * zslots + 63) / 64;
@@ -613,13 +640,15 @@ bool geometry_dma(Wgrad16Params& p, int KS, int S, size_t& lds_bytes) {
                 if (pieces > 4 * np || bytes > budget) continue;
                 p.R = R; p.Rin = Rin; p.K = K; p.xrows = xneed; p.nbuf = 2;
                 p.xslots = xslots; p.zslots = zslots; p.pieces = pieces; p.x_pieces = x_pieces; p.z_base = x_pieces * 64;
-                p.magic_xs = magic_of(xslots); p.magic_zs = magic_of(zslots); p.magic_p = magic_of(p.P);
+                p.magic_xs = magic_of(xslots); p.magic_zs = magic_of(zslots); p.magic_p = magic_of(p.P); p.magic_px = magic_of(p.Px);
+                p.plane_slots = plane_slots;
                 p.wide = w;
                 lds_bytes = bytes;
                 return true;
             }
         }
     }
+    p.P = P0; p.Px = Px0;  // the register-staged kernel keeps the single linear image
     return false;
 }
 
@@ -644,6 +673,7 @@ int geometry(const mp_conv_desc* d, Wgrad16Params& p, size_t& lds_bytes, int n_j
     // pass 0: double-buffered, two workgroups per CU; pass 1: double-buffered, whatever fits; pass 2: single buffer
     p.pieces = 0;
     p.wide = 0;
+    p.plane_slots = 0;
     bool found = geometry_dma(p, KS, S, lds_bytes);  // the LDS-DMA form where its tiles fit (p.pieces > 0 marks it)
     for (int pass = 0; pass < 3 && !found; ++pass) {
         p.nbuf = pass < 2 ? 2 : 1;
