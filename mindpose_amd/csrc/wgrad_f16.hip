@@ -41,7 +41,7 @@ struct Wgrad16Params {
     // LDS-DMA form (conv_wgrad_f16_dma_kernel): channel-block-major LDS images, element counts per 8-channel block
     int xslots, zslots, pieces;  // == 4 (mod 16) each: the two blocks a 16-lane group reads land on disjoint banks
     int x_pieces, z_base;        // DMA pieces of the input image; first element of the gradient image (a multiple of 64)
-    int wide;                    // LDS-DMA form: 1 = 64 x 64 tile per workgroup (wave = one 32 x 32 quarter), co_tiles / ci_tiles count 64s
+    int wide;                    // LDS-DMA form, tile shape: 0 = 32 x 32 (cout x cin), 1 = 64 x 64 (wave = one 32 x 32 quarter), 2 = 64 x 16 (narrow)
     int co_tiles;
     int plane_slots;             // LDS-DMA form, stride 2: > 0 = the input rows of a tile lie in two row-parity planes of this many slots
     unsigned magic_px;
@@ -371,7 +371,10 @@ struct WgradTaps2 {
     }
 };
 
-template <int KS, int S, int NP, bool WIDE = false>
+// MODE 0: 32 x 32 tile, wave = (16 couts, 16 cins) quarter.  1 (wide): 64 x 64 tile, wave = 32 x 32 quarter (see above).
+// 2 (narrow, layers with <= 16 input channels - the 3-channel stem): 64 couts x 16 cins, wave w = couts 16 w .. 16 w + 15: no wave
+//   multiplies all-zero channels, the input rows are copied once for all 64 couts and only two channel blocks of them.
+template <int KS, int S, int NP, int MODE = 0>
 __device__ __forceinline__ void wgrad_dma_body(const Wgrad16Params& p) {
     constexpr int T = KS * KS;
     extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
@@ -380,7 +383,8 @@ __device__ __forceinline__ void wgrad_dma_body(const Wgrad16Params& p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int co_sub = wave & 1, ci_sub = wave >> 1;
+    constexpr bool WIDE = MODE == 1;
+    const int co_sub = MODE == 2 ? wave : (wave & 1), ci_sub = MODE == 2 ? 0 : (wave >> 1);
     const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
     const int co_tile = blockIdx.x / p.ci_tiles, ci_tile = blockIdx.x % p.ci_tiles;
     const int t_begin = blockIdx.y * p.tiles_per_split;
@@ -395,8 +399,8 @@ __device__ __forceinline__ void wgrad_dma_body(const Wgrad16Params& p) {
     // DMA piece descriptors, decoded once: piece = 64 consecutive slots of the buffer; slot -> (image kind, block, row, column)
     unsigned piece_rel[NP];  // byte offset relative to the tile origin of its tensor; kOob = padding slot
     int piece_row[NP];       // row within the tile, bit 30 set = gradient image
-    constexpr int TB = WIDE ? 8 : 4;  // 8-channel blocks per tile side
-    const int x_units = TB * p.xslots, z_units = TB * p.zslots;
+    constexpr int TBX = MODE == 1 ? 8 : MODE == 2 ? 2 : 4, TBZ = MODE == 0 ? 4 : 8;  // 8-channel blocks per tile side (input, gradient)
+    const int x_units = TBX * p.xslots, z_units = TBZ * p.zslots;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int piece = wave + 4 * i;
@@ -413,7 +417,7 @@ __device__ __forceinline__ void wgrad_dma_body(const Wgrad16Params& p) {
             const unsigned rp = fastdiv(rem, p.Px, p.magic_px);
             const int c = (int)(rem - rp * p.Px) - p.pad;
             const unsigned r = (S == 2 && p.plane_slots > 0) ? 2 * rp + plane : rp;
-            const int cb = ci_tile * TB + (int)blk;
+            const int cb = ci_tile * TBX + (int)blk;
             if (s < x_units && r < (unsigned)p.Rin && c >= 0 && c < p.W && cb < p.C8in)
                 piece_rel[i] = ((unsigned)cb * p.H * p.W + r * p.W + c) * 16u;
             piece_row[i] = (int)r;
@@ -423,7 +427,7 @@ __device__ __forceinline__ void wgrad_dma_body(const Wgrad16Params& p) {
             const unsigned rem = sz - blk * p.zslots;
             const unsigned r = fastdiv(rem, p.P, p.magic_p);
             const unsigned c = rem - r * p.P;
-            const int cb = co_tile * TB + (int)blk;
+            const int cb = co_tile * TBZ + (int)blk;
             if (sz < z_units && r < (unsigned)p.R && c < (unsigned)p.Wo && cb < p.C8out)
                 piece_rel[i] = ((unsigned)cb * p.Ho * p.Wo + r * p.Wo + c) * 16u;
             piece_row[i] = (int)r;
@@ -520,10 +524,10 @@ __device__ __forceinline__ void wgrad_dma_body(const Wgrad16Params& p) {
 
     // D: lane holds couts 4g .. 4g+3 (rows) of cin (lane & 15) (column) -> slab [Cout][Cin][T]
     float* slab = p.slabs + ((size_t)blockIdx.z * p.splits + blockIdx.y) * p.Cout * p.Cin * T;
-    const int ci = ci_tile * 32 + ci_sub * 16 + (lane & 15);
+    const int ci = ci_tile * (MODE == 2 ? 16 : 32) + ci_sub * 16 + (lane & 15);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int co = co_tile * 32 + co_sub * 16 + 4 * g + r;
+        const int co = co_tile * (MODE == 2 ? 64 : 32) + co_sub * 16 + 4 * g + r;
         if (co < p.Cout && ci < p.Cin) {
 #pragma unroll
             for (int tp = 0; tp < T; ++tp) slab[((size_t)co * p.Cin + ci) * T + tp] = acc[tp][r];
@@ -592,10 +596,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dma_k1s2(const Wgrad16P
 __global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dma_k3s1(const Wgrad16Params p) { wgrad_dma_body<3, 1, kDmaPieces>(p); }
 __global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dma_k3s2(const Wgrad16Params p) { wgrad_dma_body<3, 2, kDmaPieces>(p); }
 __global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dma_k4s2(const Wgrad16Params p) { wgrad_dma_body<4, 2, kDmaPieces>(p); }
-__global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dmak_k1s1(const Wgrad16Params p) { wgrad_dma_body<1, 1, kDmaPiecesK, true>(p); }
-__global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dmak_k1s2(const Wgrad16Params p) { wgrad_dma_body<1, 2, kDmaPiecesK, true>(p); }
-__global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dmak_k3s1(const Wgrad16Params p) { wgrad_dma_body<3, 1, kDmaPiecesK, true>(p); }
-__global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dmak_k3s2(const Wgrad16Params p) { wgrad_dma_body<3, 2, kDmaPiecesK, true>(p); }
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dmak_k1s1(const Wgrad16Params p) { wgrad_dma_body<1, 1, kDmaPiecesK, 1>(p); }
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dmak_k1s2(const Wgrad16Params p) { wgrad_dma_body<1, 2, kDmaPiecesK, 1>(p); }
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dmak_k3s1(const Wgrad16Params p) { wgrad_dma_body<3, 1, kDmaPiecesK, 1>(p); }
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dmak_k3s2(const Wgrad16Params p) { wgrad_dma_body<3, 2, kDmaPiecesK, 1>(p); }
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dman_k3s1(const Wgrad16Params p) { wgrad_dma_body<3, 1, kDmaPieces, 2>(p); }
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16_dman_k3s2(const Wgrad16Params p) { wgrad_dma_body<3, 2, kDmaPieces, 2>(p); }
 
 // LDS-DMA form of the same decomposition: two buffers of [4][xslots] + [4][zslots] elements; false = does not fit (the
 // register-staged kernel serves the shape).  MP_WGRAD16_DMA=0 switches it off (A/B).
@@ -616,9 +622,12 @@ bool geometry_dma(Wgrad16Params& p, int KS, int S, size_t& lds_bytes) {
         p.P = (p.W + 2 * p.pad + 1) / 2 > p.Wo ? (p.W + 2 * p.pad + 1) / 2 : p.Wo;
         p.Px = 2 * p.P;
     }
-    for (int w = wide ? 1 : 0; w >= 0; --w) {
-        const int tb = w ? 8 : 4;  // 8-channel blocks per tile side
-        const int np = w ? kDmaPiecesK : kDmaPieces;
+    // narrow form (64 couts x 16 cins): 3x3 layers with at most 16 input channels
+    bool narrow = KS == 3 && p.Cin <= 16 && p.Cout > 16;
+    if (const char* e = knob("MP_WGRAD16_NARROW")) narrow = narrow && atoi(e) != 0;
+    for (int w = wide ? 1 : narrow ? 2 : 0; w >= 0; w = w == 2 ? 0 : w - 1) {
+        const int tbx = w == 1 ? 8 : w == 2 ? 2 : 4, tbz = w ? 8 : 4;  // 8-channel blocks per tile side (input, gradient)
+        const int np = w == 1 ? kDmaPiecesK : kDmaPieces;
         for (int pass = 0; pass < 2; ++pass) {
             const size_t budget = pass == 0 ? 78 * 1024 : 150 * 1024;
             for (int R = p.Ho < 16 ? p.Ho : 16; R >= 1; --R) {
@@ -634,7 +643,7 @@ bool geometry_dma(Wgrad16Params& p, int KS, int S, size_t& lds_bytes) {
                 }
                 // == 4 (mod 16): the two channel blocks a 16-lane group reads are 64 B apart modulo the 256-byte bank row
                 const int xslots = (xneed + 11) / 16 * 16 + 4, zslots = K + 4 + ((K % 16) ? 16 - K % 16 : 0);
-                const int x_pieces = (tb * xslots + 63) / 64, z_pieces = (tb * zslots + 63) / 64;
+                const int x_pieces = (tbx * xslots + 63) / 64, z_pieces = (tbz * zslots + 63) / 64;
                 const int pieces = x_pieces + z_pieces;
                 const size_t bytes = (size_t)2 * pieces * 64 * 16;
                 if (pieces > 4 * np || bytes > budget) continue;
@@ -691,9 +700,9 @@ int geometry(const mp_conv_desc* d, Wgrad16Params& p, size_t& lds_bytes, int n_j
     if (!found) return MP_ERR_UNSUPPORTED;
     p.tiles_y = (p.Ho + p.R - 1) / p.R;
     p.tiles = p.N * p.tiles_y;
-    const int tw = p.wide ? 64 : 32;  // channels per tile side
-    p.ci_tiles = (p.Cin + tw - 1) / tw;
-    p.co_tiles = (p.Cout + tw - 1) / tw;
+    const int tw_o = p.wide ? 64 : 32, tw_i = p.wide == 1 ? 64 : p.wide == 2 ? 16 : 32;  // channels per tile side
+    p.ci_tiles = (p.Cin + tw_i - 1) / tw_i;
+    p.co_tiles = (p.Cout + tw_o - 1) / tw_o;
     const int ct = p.co_tiles * p.ci_tiles;
     int target = 512;  // two workgroups per CU; the slab reduce reads splits x |dW| floats, so no finer than that
     if (const char* e = knob("MP_WGRAD16_WGS")) {  // experiments: total workgroups per launch
@@ -703,7 +712,7 @@ int geometry(const mp_conv_desc* d, Wgrad16Params& p, size_t& lds_bytes, int n_j
     // a grouped launch spreads ~768 workgroups over its layers: per layer fewer, longer pixel slabs - the slab traffic (written here,
     // re-read by the reduce) and the per-workgroup prologue / epilogue shrink by the group size
     // (a 64 x 64 tile's slab is four times the bytes: the wide form stays at ~512 workgroups)
-    int splits = n_jobs > 1 ? (p.wide ? target : target + target / 2) / (ct * n_jobs) : target / ct;
+    int splits = n_jobs > 1 ? (p.wide == 1 ? target : target + target / 2) / (ct * n_jobs) : target / ct;
     if (splits < 1) splits = 1;
     if (splits > p.tiles) splits = p.tiles;
     p.tiles_per_split = (p.tiles + splits - 1) / splits;
@@ -726,7 +735,15 @@ int launch_wgrad16_dma(const Wgrad16Params& p, size_t lds, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
     }
-    if (p.wide && KS <= 3) kern = kern_k;
+    if (p.wide == 1 && KS <= 3) kern = kern_k;
+    if (p.wide == 2 && KS == 3) {
+        kern = S == 1 ? conv_wgrad_f16_dman_k3s1 : conv_wgrad_f16_dman_k3s2;
+        static AttrOnce attr_n;
+        if (attr_n.need()) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL(kern, dim3(p.co_tiles * p.ci_tiles, p.splits, p.n_jobs ? p.n_jobs : 1), dim3(256), lds, s, p);
     return check_launch();
 }
