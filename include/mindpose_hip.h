@@ -143,6 +143,12 @@ typedef struct mp_conv_desc {
  * weight-gradient launches on sibling streams.  Forms that take a CU's whole register file (the two-team Winograd
  * workgroup) are then not chosen: they are faster alone and slower in that company. */
 #define MP_CONV_SHARES_CUS 1
+/* fp16 family only (mp_f16_conv2d_fwd): the FOUR 2x2 sub-pixel phase convs of a stride-2 3x3 data gradient as ONE launch.  The
+ * descriptor is one phase's (kh = kw = 2, stride 1, out_mul 2, out_off_* = 0; all four phases share its padding - the tap
+ * alignment is in the packing, mp_f16_pack_weight mode 3); phase (py, px) writes output pixels (2 y + py, 2 x + px) and reads its
+ * weights from slice 2 py + px of the packed buffer (four slices of mp_f16_packed_weight_bytes(cout, cin, 2, 2) bytes each).
+ * One-tile and persistent multi-tile variants only; no residual, no statistics. */
+#define MP_CONV_PHASES4 2
 
 /* bytes of the packed weight buffer for a (cout, cin, kh, kw) kernel */
 size_t mp_conv_packed_weight_bytes(int cout, int cin, int kh, int kw);

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("MINDPOSE_HIP_LIB", os.path.join(_HERE, "csrc", "libmi
 
 MP_REFINE_NONE, MP_REFINE_SHIFT, MP_REFINE_DARK = 0, 1, 2
 MP_CONV_SHARES_CUS = 1  # mp_conv_desc.flags: the launch runs beside other kernels of a training step (include/mindpose_hip.h)
+MP_CONV_PHASES4 = 2     # mp_conv_desc.flags (fp16 family): the four 2x2 phase convs of a stride-2 3x3 data gradient as one launch
 
 c_f32p = ctypes.c_void_p  # device pointers travel as integers
 c_int = ctypes.c_int

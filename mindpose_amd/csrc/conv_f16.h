@@ -33,6 +33,8 @@ struct ConvF16Params {
     int out_h, out_w, out_mul, off_y, off_x;  // output mapping: conv pixel (y, x) -> (y*out_mul + off_y, x*out_mul + off_x)
     unsigned magic_upc, magic_ncols, magic_rin, magic_rwo, magic_wo;
     int RWo, total_blocks;
+    int phases;              // 4: MP_CONV_PHASES4 - blockIdx.y = phase 2 py + px (its output offset, its weight slice); else 1
+    unsigned w_phase_bytes;  // bytes per weight slice
     // persistent multi-tile kernel only: a workgroup keeps its weight slice in LDS and walks tiles_per_wg pixel tiles
     int tiles_total, tiles_per_wg, n_groups;
     int ni_used, nw_used;  // staging slots (of the kernel's NI / NW) that carry data for this shape: the rest are skipped

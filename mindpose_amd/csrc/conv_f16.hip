@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
     const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(xg, (size_t)n_img * p.C8in * HW * 16);
     const int w_units = p.PK * T * CT;  // 16-B elements of one weight chunk of this cout tile
     const __amdgpu_buffer_rsrc_t rs_w =
-        make_rsrc(p.wp, (size_t)p.n_chunks * p.PK * T * p.Cout_pad16 * 16);
+        make_rsrc(reinterpret_cast<const char*>(p.wp) + (p.phases > 1 ? (size_t)blockIdx.y * p.w_phase_bytes : (size_t)0),
+                  (size_t)p.n_chunks * p.PK * T * p.Cout_pad16 * 16);
     unsigned wsrc[NW];
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
@@ -235,13 +236,14 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
     const size_t grp = (size_t)n0 * p.C8out * plane_o * 16;
     const size_t grp_bytes = (size_t)n_img * p.C8out * plane_o * 16;
     const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(reinterpret_cast<char*>(p.out) + grp, grp_bytes);
+    const int off_y = p.phases > 1 ? (int)(blockIdx.y >> 1) : p.off_y, off_x = p.phases > 1 ? (int)(blockIdx.y & 1) : p.off_x;
     unsigned pix_off[PS];
 #pragma unroll
     for (int ps = 0; ps < PS; ++ps) {
         const unsigned g = (unsigned)pix_gyx[ps] >> 24, y = ((unsigned)pix_gyx[ps] >> 12) & 0xFFFu, xx = (unsigned)pix_gyx[ps] & 0xFFFu;
         const int yy = y0 + y;
         const bool ok = pix_gyx[ps] >= 0 && n0 + (int)g < p.N && yy < p.Ho;
-        pix_off[ps] = ok ? (g * p.C8out * plane_o + (yy * p.out_mul + p.off_y) * p.out_w + xx * p.out_mul + p.off_x) * 16u : kInv;
+        pix_off[ps] = ok ? (g * p.C8out * plane_o + (yy * p.out_mul + off_y) * p.out_w + xx * p.out_mul + off_x) * 16u : kInv;
     }
     f32x4 sc[CS], sh[CS];
     unsigned co_off[CS];
@@ -367,7 +369,7 @@ int launch_f16_kernel(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
     }
-    hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(256), lds_bytes, s, p);
+    hipLaunchKernelGGL(kern, dim3(p.total_blocks, p.phases > 1 ? p.phases : 1), dim3(256), lds_bytes, s, p);
     return check_launch();
 }
 
@@ -577,9 +579,13 @@ int f16_validate(const mp_conv_desc* d) {
     if (d->conv_h <= 0 || d->conv_w <= 0) return MP_ERR_SHAPE;
     // plain or strided-scatter output mapping (sub-pixel phases of the transposed convolution); replication (nearest
     // up-sampling) is not part of this kernel: the exchange unit has its own streaming kernel in this layout
-    if (d->out_rep != 1 || d->out_mul < 1 || d->out_off_y < 0 || d->out_off_x < 0 || (d->flags & ~MP_CONV_SHARES_CUS)) return MP_ERR_UNSUPPORTED;
+    if (d->out_rep != 1 || d->out_mul < 1 || d->out_off_y < 0 || d->out_off_x < 0 || (d->flags & ~(MP_CONV_SHARES_CUS | MP_CONV_PHASES4)))
+        return MP_ERR_UNSUPPORTED;
+    const int ph = (d->flags & MP_CONV_PHASES4) ? 1 : 0;  // the four phases reach one pixel further than phase (0, 0)
+    if (ph && (d->kh != 2 || d->stride != 1 || d->out_mul != 2 || d->out_off_y != 0 || d->out_off_x != 0)) return MP_ERR_UNSUPPORTED;
     if (d->out_h <= 0 || d->out_w <= 0) return MP_ERR_SHAPE;
-    if ((d->conv_h - 1) * d->out_mul + d->out_off_y >= d->out_h || (d->conv_w - 1) * d->out_mul + d->out_off_x >= d->out_w) return MP_ERR_SHAPE;
+    if ((d->conv_h - 1) * d->out_mul + d->out_off_y + ph >= d->out_h || (d->conv_w - 1) * d->out_mul + d->out_off_x + ph >= d->out_w)
+        return MP_ERR_SHAPE;
     // every input row / column a tap reads must exist or be zero padding on the top / left only up to pad; the bottom /
     // right overhang is covered by the LDS halo, as in the fp32 kernel
     if ((long long)d->n * ((d->cout + 7) / 8) * d->out_h * d->out_w * 16 >= (1LL << 40)) return MP_ERR_UNSUPPORTED;
@@ -774,7 +780,10 @@ int f16_build_launch(const mp_conv_desc* desc, int variant, const void* x, const
     // output offsets are 32-bit sums of masked parts (kInv in conv_f16_dev.h)
     if ((size_t)desc->n * ((desc->cout + 7) / 8) * desc->out_h * desc->out_w * 16 >= 0x60000000u) return MP_ERR_UNSUPPORTED;
     bool ok = false;
+    const bool phases4 = (desc->flags & MP_CONV_PHASES4) != 0;
+    if (phases4 && (res1 || res2)) return MP_ERR_UNSUPPORTED;
     if (variant >= 0) {
+        if (f16_variant_wreg(variant) && phases4) return MP_ERR_UNSUPPORTED;  // one-tile / multi-tile kernels only
         if (f16_variant_wreg(variant) && res2 && desc->stride != 2) return MP_ERR_UNSUPPORTED;  // second residual: stride-2 builds only
         ok = f16_configure(*desc, variant, L);
     } else {
@@ -800,6 +809,8 @@ int f16_build_launch(const mp_conv_desc* desc, int variant, const void* x, const
     }
     if (!ok) return MP_ERR_UNSUPPORTED;
     L.p.x = x; L.p.wp = w; L.p.scale = scale; L.p.shift = shift; L.p.res1 = res1; L.p.res2 = res2; L.p.out = out;
+    L.p.phases = phases4 ? 4 : 1;
+    L.p.w_phase_bytes = phases4 ? (unsigned)((size_t)round_up(desc->cin, 32) * 4 * round_up(desc->cout, 16) * 2) : 0u;
     return MP_OK;
 }
 

@@ -38,7 +38,9 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Para
 
     // ---- weights: the whole K x CT slice, once
     {
-        const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.wp, (size_t)p.PK * T * p.Cout_pad16 * 16);
+        const __amdgpu_buffer_rsrc_t rs_w =
+            make_rsrc(reinterpret_cast<const char*>(p.wp) + (p.phases > 1 ? (size_t)blockIdx.y * p.w_phase_bytes : (size_t)0),
+                      (size_t)p.PK * T * p.Cout_pad16 * 16);
         const int w_units = p.PK * T * CT;
         for (int u0 = 0; u0 < w_units; u0 += 256 * 8) {
             u32x4 v[8];
@@ -84,6 +86,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Para
         }
     }
 
+    const int off_y = p.phases > 1 ? (int)(blockIdx.y >> 1) : p.off_y, off_x = p.phases > 1 ? (int)(blockIdx.y & 1) : p.off_x;
     int b_off[PS];
     int pix_rel[PS], pix_gy[PS];  // output offset of the lane's pixel relative to the tile origin; (image << 16 | row), -1 = padding lane
 #pragma unroll
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Para
         const unsigned y = fastdiv(rem, p.Wo, p.magic_wo);
         const unsigned xx = rem - y * p.Wo;
         b_off[ps] = lq * p.plane + g * p.img_plane + (y * S) * p.Wp + xx * S;
-        pix_rel[ps] = (int)((g * p.C8out * plane_o + (y * p.out_mul + p.off_y) * p.out_w + xx * p.out_mul + p.off_x) * 16u);
+        pix_rel[ps] = (int)((g * p.C8out * plane_o + (y * p.out_mul + off_y) * p.out_w + xx * p.out_mul + off_x) * 16u);
         pix_gy[ps] = pl0 < (unsigned)(p.G * p.RWo) ? (int)((g << 16) | y) : -1;
     }
     int a_off[CS];
@@ -328,7 +331,7 @@ int launch_mt_kernel(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
     }
-    hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(256), lds_bytes, s, p);
+    hipLaunchKernelGGL(kern, dim3(p.total_blocks, p.phases > 1 ? p.phases : 1), dim3(256), lds_bytes, s, p);
     return check_launch();
 }
 

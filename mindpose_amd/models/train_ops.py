@@ -29,10 +29,10 @@ def _ones_zeros(c: int, device):
 
 
 def _desc(n, cin, h, w, cout, k, stride, pad_t, pad_l, conv_h, conv_w, out_h, out_w, out_mul=1, out_rep=1, off_y=0,
-          off_x=0):
+          off_x=0, flags=0):
     return _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=k, kw=k, stride=stride, pad_top=pad_t, pad_left=pad_l,
                          conv_h=conv_h, conv_w=conv_w, out_h=out_h, out_w=out_w, out_mul=out_mul, out_rep=out_rep,
-                         out_off_y=off_y, out_off_x=off_x, relu=0, flags=_lib.MP_CONV_SHARES_CUS)
+                         out_off_y=off_y, out_off_x=off_x, relu=0, flags=_lib.MP_CONV_SHARES_CUS | flags)
 
 
 def _conv_launch(lib, d, x, packed, scale, shift, out, what, packed_u=None, res1=None):
@@ -343,7 +343,16 @@ def _cached_pack(lib, w, owner, half, cout, cin, k, mode, py, px):
         key = (half, cout, cin, k, mode, py, px)
         entry = packs.get(key)
         if entry is None:
-            entry = packs[key] = _PackEntry(torch.empty(numel, device=w.device, dtype=dtype))
+            if half and mode == 3:
+                # the four sub-pixel phase packings of one weight are slices (2 py + px) of ONE buffer: MP_CONV_PHASES4 launches
+                # take the whole of it, per-phase launches their slice
+                parents = owner.__dict__.setdefault("_mp_pack_parents", {})
+                parent = parents.get(key[:5])
+                if parent is None:
+                    parent = parents[key[:5]] = torch.empty(4 * numel, device=w.device, dtype=dtype)
+                entry = packs[key] = _PackEntry(parent[(2 * py + px) * numel:(2 * py + px + 1) * numel])
+            else:
+                entry = packs[key] = _PackEntry(torch.empty(numel, device=w.device, dtype=dtype))
         if (entry.fresh and entry.gen == _PACK_GEN[0] and entry.ptr == w.data_ptr() and entry.version == owner._version):
             entry.fresh = False
             return entry.buf
@@ -356,6 +365,29 @@ def _cached_pack(lib, w, owner, half, cout, cin, k, mode, py, px):
 
 def _pack16(lib, w, cout, cin, k, mode, py=0, px=0, owner=None):
     return _cached_pack(lib, w, owner, True, cout, cin, k, mode, py, px)
+
+
+def phases4_enabled() -> bool:
+    """``MINDPOSE_DGRAD_PHASES4=0``: the stride-2 3x3 data gradient as four phase launches (A/B; the results are bit-identical)."""
+    return os.environ.get("MINDPOSE_DGRAD_PHASES4", "1") != "0"
+
+
+def _dgrad16_stride2(lib, w, owner, dz, dx, n, cin, cout, h, wd, ho, wo, ones, zeros):
+    """Data gradient of a 3x3 stride-2 padding-1 conv: four 2x2 sub-pixel phase convs over dz, each writing every second pixel
+    of dx - as ONE launch (MP_CONV_PHASES4; phase = second grid dimension) when the weight has an owner whose four packings share
+    a buffer, else as four launches."""
+    if owner is not None and phases4_enabled():
+        for py in (0, 1):
+            for px in (0, 1):
+                _pack16(lib, w, cin, cout, 2, 3, py, px, owner=owner)  # fresh slices (no launch after repack_weights)
+        parent = owner.__dict__["_mp_pack_parents"][(True, cin, cout, 2, 3)]
+        d = _desc(n, cout, ho, wo, cin, 2, 1, 0, 0, ho, wo, h, wd, out_mul=2, flags=_lib.MP_CONV_PHASES4)
+        _conv16_launch(lib, d, dz, parent, ones, zeros, dx, "conv dgrad phases")
+        return
+    for py in (0, 1):
+        for px in (0, 1):
+            d = _desc(n, cout, ho, wo, cin, 2, 1, 0, 0, ho, wo, h, wd, out_mul=2, off_y=py, off_x=px)
+            _conv16_launch(lib, d, dz, _pack16(lib, w, cin, cout, 2, 3, py, px, owner=owner), ones, zeros, dx, "conv dgrad phase")
 
 
 def repack_weights(module):
@@ -505,11 +537,7 @@ class Conv16Fn(torch.autograd.Function):
                 if h != 2 * ho or wd != 2 * wo:
                     raise NotImplementedError("stride-2 data gradient needs even input extents")
                 if k == 3:
-                    for py in (0, 1):
-                        for px in (0, 1):
-                            d = _desc(n, cout, ho, wo, cin, 2, 1, 0, 0, ho, wo, h, wd, out_mul=2, off_y=py, off_x=px)
-                            _conv16_launch(lib, d, dz, _pack16(lib, w, cin, cout, 2, 3, py, px, owner=ctx.weight_param), ones, zeros, dx,
-                                           "conv dgrad phase")
+                    _dgrad16_stride2(lib, w, ctx.weight_param, dz, dx, n, cin, cout, h, wd, ho, wo, ones, zeros)
                 else:  # 1x1 stride 2 (ResNet down-sample): only the even positions receive gradient
                     dx.zero_()
                     d = _desc(n, cout, ho, wo, cin, 1, 1, 0, 0, ho, wo, h, wd, out_mul=2)
@@ -1210,11 +1238,7 @@ class Chain16Fn(torch.autograd.Function):
                     if res1 is not None:
                         raise NotImplementedError("a residual chain starts with a stride-1 conv")
                     if k == 3:
-                        for py in (0, 1):
-                            for px in (0, 1):
-                                dd = _desc(n, cout, ho, wo, cin, 2, 1, 0, 0, ho, wo, h, wd, out_mul=2, off_y=py, off_x=px)
-                                _conv16_launch(lib, dd, dz, _pack16(lib, w, cin, cout, 2, 3, py, px, owner=G["weight"]), ones, zeros, dx,
-                                               "conv dgrad phase")
+                        _dgrad16_stride2(lib, w, G["weight"], dz, dx, n, cin, cout, h, wd, ho, wo, ones, zeros)
                     else:
                         dx.zero_()
                         dd = _desc(n, cout, ho, wo, cin, 1, 1, 0, 0, ho, wo, h, wd, out_mul=2)

@@ -136,6 +136,44 @@ def test_dgrad_f16_vs_torch(case):
     _close16(_from_c8(dx), ref, "dx")
 
 
+@pytest.mark.parametrize("case", [(2, 32, 64, 32, 24), (3, 64, 128, 16, 12), (2, 48, 96, 24, 16), (5, 32, 32, 64, 48)])
+@pytest.mark.parametrize("variant", [-1, 0, 4, 10, 13, 17])
+def test_stride2_dgrad_four_phases_in_one_launch_equal_four_launches(case, variant):
+    """MP_CONV_PHASES4: phase = second grid dimension, weight slice and output offset from it - bit-identical to the four launches
+    (one-tile and persistent multi-tile variants; a variant that does not serve the shape is skipped)."""
+    n, cin, cout, h, w = case
+    g = torch.Generator().manual_seed(sum(case) + 7)
+    ho, wo = h // 2, w // 2
+    wdev = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).to(DEV)
+    dza = _to_c8(torch.randn(n, cout, ho, wo, generator=g))
+    ones = torch.ones((cin + 15) // 16 * 16, device=DEV)
+    zeros = torch.zeros_like(ones)
+    nb = LIB.mp_f16_packed_weight_bytes(cin, cout, 2, 2)
+    packed = torch.empty(4 * (nb // 2), device=DEV, dtype=torch.float16)
+    for py in (0, 1):
+        for px in (0, 1):
+            sl = packed[(2 * py + px) * (nb // 2):]
+            _lib.check(LIB.mp_f16_pack_weight(_lib.ptr(wdev), sl.data_ptr(), cin, cout, 2, 2, 3, py, px, _lib.stream()), "pack")
+    one, four = ActC8(n, cin, h, w, DEV), ActC8(n, cin, h, w, DEV)
+    d = _desc(n, cout, ho, wo, cin, 2, 1, 0, ho, wo, oh=h, ow=w, mul=2)
+    d.flags = _lib.MP_CONV_PHASES4
+    rc = LIB.mp_f16_conv2d_fwd(ctypes.byref(d), variant, _lib.ptr(dza), _lib.ptr(packed), _lib.ptr(ones), _lib.ptr(zeros), None, None,
+                               _lib.ptr(one), _lib.stream())
+    if rc != 0 and variant >= 0:
+        pytest.skip(f"variant {variant} does not serve this shape (rc {rc})")
+    _lib.check(rc, "phases4")
+    for py in (0, 1):
+        for px in (0, 1):
+            dd = _desc(n, cout, ho, wo, cin, 2, 1, 0, ho, wo, oh=h, ow=w, mul=2, oy=py, ox=px)
+            sl = packed[(2 * py + px) * (nb // 2):]
+            _lib.check(LIB.mp_f16_conv2d_fwd(ctypes.byref(dd), variant, _lib.ptr(dza), sl.data_ptr(), _lib.ptr(ones), _lib.ptr(zeros), None,
+                                             None, _lib.ptr(four), _lib.stream()), "phase")
+    assert torch.equal(_from_c8(one), _from_c8(four))
+    # weights-in-registers variants do not take the flag
+    assert LIB.mp_f16_conv2d_fwd(ctypes.byref(d), 26, _lib.ptr(dza), _lib.ptr(packed), _lib.ptr(ones), _lib.ptr(zeros), None, None,
+                                 _lib.ptr(one), _lib.stream()) != 0
+
+
 @pytest.mark.parametrize("c,h,w,relu,with_res", [(32, 64, 48, True, True), (64, 16, 12, True, False), (17, 8, 6, False, False),
                                                  (48, 24, 18, True, True)])
 def test_bn_train_f16_fwd_bwd_vs_torch(c, h, w, relu, with_res):
