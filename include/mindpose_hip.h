@@ -147,7 +147,8 @@ typedef struct mp_conv_desc {
  * descriptor is one phase's (kh = kw = 2, stride 1, out_mul 2, out_off_* = 0; all four phases share its padding - the tap
  * alignment is in the packing, mp_f16_pack_weight mode 3); phase (py, px) writes output pixels (2 y + py, 2 x + px) and reads its
  * weights from slice 2 py + px of the packed buffer (four slices of mp_f16_packed_weight_bytes(cout, cin, 2, 2) bytes each).
- * One-tile and persistent multi-tile variants only; no residual, no statistics. */
+ * One-tile and persistent multi-tile variants only; no residual; statistics: the backward sums (mp_f16_conv2d_fwd_stats mode 2,
+ * partial slots = four times a phase's). */
 #define MP_CONV_PHASES4 2
 
 /* bytes of the packed weight buffer for a (cout, cin, kh, kw) kernel */

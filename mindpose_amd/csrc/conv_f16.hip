@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
     }
     const int ct = b % p.n_ct;
     b /= p.n_ct;
-    const int part_idx = b;  // pixel tile = partial-sum slot of the epilogue statistics
+    // pixel tile (of its phase, MP_CONV_PHASES4) = partial-sum slot of the epilogue statistics
+    const int part_idx = (p.phases > 1 ? (int)blockIdx.y * (p.tiles_y * p.tiles_n) : 0) + b;
     const int ty = b % p.tiles_y, tn = b / p.tiles_y;
     const int n0 = tn * p.G, y0 = ty * p.R;
     const int y_in0 = y0 * S - p.pad_t;
@@ -379,6 +380,9 @@ int launch_f16_variant(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) 
         if constexpr (f16_has_stats(KS)) {
             if (p.st_mode == 1) return launch_f16_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, LIGHT, ONE_CHUNK, 1>(p, lds_bytes, s);
             if constexpr (S == 1) return launch_f16_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, LIGHT, ONE_CHUNK, 2>(p, lds_bytes, s);  // data gradients are stride-1 launches
+        }
+        if constexpr (KS == 2 && S == 1) {  // the phase convs of a stride-2 data gradient: backward sums only
+            if (p.st_mode == 2) return launch_f16_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, LIGHT, ONE_CHUNK, 2>(p, lds_bytes, s);
         }
         return MP_ERR_UNSUPPORTED;
     }
@@ -815,8 +819,8 @@ int f16_build_launch(const mp_conv_desc* desc, int variant, const void* x, const
 }
 
 int f16_stats_parts(const ConvF16Launch& L) {
-    // tile / weights-in-registers kernels: one slot per pixel tile; persistent multi-tile kernel: one per workgroup run
-    return f16_variant_mt(L.variant) ? L.p.n_groups : L.p.tiles_y * L.p.tiles_n;
+    // tile / weights-in-registers kernels: one slot per pixel tile; persistent multi-tile kernel: one per workgroup run; per phase
+    return (f16_variant_mt(L.variant) ? L.p.n_groups : L.p.tiles_y * L.p.tiles_n) * (L.p.phases > 1 ? L.p.phases : 1);
 }
 
 int f16_launch(const ConvF16Launch& L, hipStream_t s) {
@@ -893,7 +897,8 @@ int mp_f16_conv2d_fwd(const mp_conv_desc* desc, int variant, const void* x, cons
 }
 
 static bool f16_stats_shape_ok(const mp_conv_desc* d) {
-    return (d->kh == 1 || d->kh == 3) && d->out_rep == 1;
+    // 1x1 / 3x3 convs, and the merged phase launch of a stride-2 data gradient (backward sums)
+    return (d->kh == 1 || d->kh == 3 || (d->kh == 2 && (d->flags & MP_CONV_PHASES4))) && d->out_rep == 1;
 }
 
 int mp_f16_conv_stats_parts(const mp_conv_desc* desc, int variant) {
@@ -905,7 +910,6 @@ int mp_f16_conv_stats_parts(const mp_conv_desc* desc, int variant) {
     if (f16_build_launch(desc, variant, dummy, dummy, reinterpret_cast<const float*>(dummy), reinterpret_cast<const float*>(dummy), nullptr,
                          nullptr, const_cast<void*>(dummy), L) != MP_OK)
         return 0;
-    if (desc->kh == 2) return 0;
     return f16_stats_parts(L);
 }
 
@@ -917,6 +921,8 @@ int mp_f16_conv2d_fwd_stats(const mp_conv_desc* desc, int variant, const void* x
     if (rc != MP_OK) return rc;
     if (!f16_stats_shape_ok(desc)) return MP_ERR_UNSUPPORTED;
     if (st->mode != 1 && st->mode != 2) return MP_ERR_UNSUPPORTED;
+    const bool phases4 = (desc->flags & MP_CONV_PHASES4) != 0;
+    if (phases4 && st->mode != 2) return MP_ERR_UNSUPPORTED;
     const int parts = f16_stats_parts(L);
     if (st->partials_bytes < (size_t)L.p.C8out * parts * 16 * sizeof(float)) return MP_ERR_WORKSPACE;
     L.p.st_mode = st->mode;
@@ -924,7 +930,7 @@ int mp_f16_conv2d_fwd_stats(const mp_conv_desc* desc, int variant, const void* x
     L.p.st_part = st->partials_dev;
     if (st->mode == 2) {
         if (!st->z_dev || (st->relu != 0 && !st->y_dev)) return MP_ERR_NULL;
-        if (desc->stride != 1 || desc->out_mul != 1 || desc->out_off_y != 0 || desc->out_off_x != 0) return MP_ERR_UNSUPPORTED;
+        if (desc->stride != 1 || desc->out_mul != (phases4 ? 2 : 1) || desc->out_off_y != 0 || desc->out_off_x != 0) return MP_ERR_UNSUPPORTED;
         L.p.st_relu = st->relu != 0 ? 1 : 0;
         L.p.st_z = st->z_dev;
         L.p.st_y = st->relu != 0 ? st->y_dev : nullptr;

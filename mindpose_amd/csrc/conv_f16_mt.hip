@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_mt_kernel(const ConvF16Para
         }
     }
     if constexpr (STATS)  // the scratch lies over the weight slice (the flush's first barrier: every wave is past its last MFMA loop)
-        f16_stats_flush<CS, WAVES_P, WAVES_C>(st_a, st_b, reinterpret_cast<float*>(smem16), p.st_part, p.st_nparts, grp, ct * CT, p.C8out,
+        f16_stats_flush<CS, WAVES_P, WAVES_C>(st_a, st_b, reinterpret_cast<float*>(smem16), p.st_part, p.st_nparts, (p.phases > 1 ? (int)blockIdx.y * p.n_groups : 0) + grp, ct * CT, p.C8out,
                                               wp_i, wc_i, lq, lr);
 }
 
@@ -341,6 +341,9 @@ int launch_mt_variant(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
         if constexpr (KS == 1 || KS == 3) {
             if (p.st_mode == 1) return launch_mt_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, OCC, 1>(p, lds_bytes, s);
             if constexpr (S == 1) return launch_mt_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, OCC, 2>(p, lds_bytes, s);
+        }
+        if constexpr (KS == 2 && S == 1) {  // the phase convs of a stride-2 data gradient: backward sums only
+            if (p.st_mode == 2) return launch_mt_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, OCC, 2>(p, lds_bytes, s);
         }
         return MP_ERR_UNSUPPORTED;
     }

@@ -372,22 +372,26 @@ def phases4_enabled() -> bool:
     return os.environ.get("MINDPOSE_DGRAD_PHASES4", "1") != "0"
 
 
-def _dgrad16_stride2(lib, w, owner, dz, dx, n, cin, cout, h, wd, ho, wo, ones, zeros):
+def _dgrad16_stride2(lib, w, owner, dz, dx, n, cin, cout, h, wd, ho, wo, ones, zeros, below=None):
     """Data gradient of a 3x3 stride-2 padding-1 conv: four 2x2 sub-pixel phase convs over dz, each writing every second pixel
     of dx - as ONE launch (MP_CONV_PHASES4; phase = second grid dimension) when the weight has an owner whose four packings share
-    a buffer, else as four launches."""
+    a buffer, else as four launches.  ``below`` = (z, y, relu) of the BatchNorm whose output this conv read: the one launch then
+    also masks the gradient and leaves that BatchNorm's backward sums (returns (partials, n_parts), else (None, 0))."""
     if owner is not None and phases4_enabled():
         for py in (0, 1):
             for px in (0, 1):
                 _pack16(lib, w, cin, cout, 2, 3, py, px, owner=owner)  # fresh slices (no launch after repack_weights)
         parent = owner.__dict__["_mp_pack_parents"][(True, cin, cout, 2, 3)]
         d = _desc(n, cout, ho, wo, cin, 2, 1, 0, 0, ho, wo, h, wd, out_mul=2, flags=_lib.MP_CONV_PHASES4)
+        if below is not None:
+            return _conv16_stats_launch(lib, d, dz, parent, ones, zeros, dx, None, 2, z=below[0], y=below[1], relu=below[2])
         _conv16_launch(lib, d, dz, parent, ones, zeros, dx, "conv dgrad phases")
-        return
+        return None, 0
     for py in (0, 1):
         for px in (0, 1):
             d = _desc(n, cout, ho, wo, cin, 2, 1, 0, 0, ho, wo, h, wd, out_mul=2, off_y=py, off_x=px)
             _conv16_launch(lib, d, dz, _pack16(lib, w, cin, cout, 2, 3, py, px, owner=owner), ones, zeros, dx, "conv dgrad phase")
+    return None, 0
 
 
 def repack_weights(module):
@@ -968,8 +972,9 @@ def bn_fuse_enabled() -> bool:
 
 def _bn_fuse_parts() -> int:
     """Bit mask of the fused pieces (debugging / A-B): 1 forward statistics, 2 backward statistics inside a chain, 4 across chains,
-    8 from the element-wise gradient producers (fan-out sum, exchange-unit backward)."""
-    return int(os.environ.get("MINDPOSE_BN_FUSE_PARTS", "15"))
+    8 from the element-wise gradient producers (fan-out sum, exchange-unit backward), 16 from the merged-phase launch of a
+    stride-2 data gradient."""
+    return int(os.environ.get("MINDPOSE_BN_FUSE_PARTS", "31"))
 
 
 class _BnLink:
@@ -1238,7 +1243,15 @@ class Chain16Fn(torch.autograd.Function):
                     if res1 is not None:
                         raise NotImplementedError("a residual chain starts with a stride-1 conv")
                     if k == 3:
-                        _dgrad16_stride2(lib, w, G["weight"], dz, dx, n, cin, cout, h, wd, ho, wo, ones, zeros)
+                        use = below if (below is not None and tuple(below[0].shape) == tuple(dx.shape) and phases4_enabled()
+                                        and (_bn_fuse_parts() & 16)) else None
+                        part, n_parts = _dgrad16_stride2(lib, w, G["weight"], dz, dx, n, cin, cout, h, wd, ho, wo, ones, zeros,
+                                                         below=use[:3] if use is not None else None)
+                        if part is not None:
+                            if use[3] is not None:
+                                use[3].partials, use[3].n_parts = part, n_parts
+                            else:
+                                pre = (part, n_parts)
                     else:
                         dx.zero_()
                         dd = _desc(n, cout, ho, wo, cin, 1, 1, 0, 0, ho, wo, h, wd, out_mul=2)

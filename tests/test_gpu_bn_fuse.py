@@ -395,17 +395,17 @@ def test_single_chain_statistics_match_reduction_path(monkeypatch):
 
 @pytest.mark.parametrize("backbone,head,size", [("hrnet_w32", "hrnet_head", (3, 128, 96)), ("resnet50", "simple_baseline_head", (2, 64, 64))])
 def test_fused_chain_step_vs_per_cell_step(backbone, head, size, monkeypatch):
-    """Whole step.  The BACKWARD pieces alone (MINDPOSE_BN_FUSE_PARTS=14: gradients pre-masked and reduced by the launches that
+    """Whole step.  The BACKWARD pieces alone (MINDPOSE_BN_FUSE_PARTS=30: gradients pre-masked and reduced by the launches that
     produce them) reproduce the per-cell gradients to summation order; the forward statistics come out in another summation order,
     which flips rare fp16 roundings of the BatchNorm outputs - through ~100 layers the two steps are then two fp16 evaluations of
     one graph, as far apart as the HIP step and the oracle's emulation are (tests/test_gpu_train_full.py: 0.99)."""
     l0, g0, s0 = _step(False, monkeypatch, backbone, head, size)
-    monkeypatch.setenv("MINDPOSE_BN_FUSE_PARTS", "14")
+    monkeypatch.setenv("MINDPOSE_BN_FUSE_PARTS", "30")
     lb, gb, _ = _step(True, monkeypatch, backbone, head, size)
     assert lb == l0
     assert float(torch.nn.functional.cosine_similarity(gb.double(), g0.double(), dim=0)) > 0.99995
     assert float((gb - g0).norm() / g0.norm()) < 1e-2
-    monkeypatch.setenv("MINDPOSE_BN_FUSE_PARTS", "15")
+    monkeypatch.setenv("MINDPOSE_BN_FUSE_PARTS", "31")
     l1, g1, s1 = _step(True, monkeypatch, backbone, head, size)
     assert abs(l1 - l0) <= 1e-3 * abs(l0), (l1, l0)
     cos = float(torch.nn.functional.cosine_similarity(g1.double(), g0.double(), dim=0))

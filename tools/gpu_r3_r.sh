@@ -16,6 +16,6 @@ print("$tag", d.get("value"), d.get("ms_per_step"))
 PY
 }
 run merged A=1
-run four MINDPOSE_DGRAD_PHASES4=0
+run nostats MINDPOSE_BN_FUSE_PARTS=15
 run merged2 A=1
-run four2 MINDPOSE_DGRAD_PHASES4=0
+run nostats2 MINDPOSE_BN_FUSE_PARTS=15
