@@ -497,6 +497,24 @@ int mp_f16_bn_train_bwd_stats(const void* g_dev, const void* z_dev, const float*
                               float* dbeta_acc_dev, int n, int c, int hw, const float* partials_dev, int n_parts,
                               void* workspace_dev, size_t workspace_bytes, mp_stream_t stream);
 
+/* Up to FOUR apply-only BatchNorm passes as ONE launch: the k-th BatchNorm of every branch of an HRModule (hrnet.py:202-241) -
+ * independent tensors of different shapes, each ~10 us of launch, fold and tail around a few us of streaming when launched alone.
+ * A job carries exactly the arguments of mp_f16_bn_train_fwd_stats / mp_f16_bn_train_bwd_stats (same results, bit for bit). */
+typedef struct mp_f16_bn_fwd_job {
+    const void* z_dev; const float* gamma_dev; const float* beta_dev; const void* res_dev; void* y_dev;
+    float* save_mean_dev; float* save_invstd_dev; float* moving_mean_dev; float* moving_var_dev;
+    const float* partials_dev; void* workspace_dev; size_t workspace_bytes;
+    int n, c, hw, relu, n_parts, reserved;
+} mp_f16_bn_fwd_job;
+typedef struct mp_f16_bn_bwd_job {
+    const void* g_dev; const void* z_dev; const float* gamma_dev; const float* save_mean_dev; const float* save_invstd_dev; void* dz_dev;
+    float* dgamma_dev; float* dbeta_dev; float* dgamma_acc_dev; float* dbeta_acc_dev;
+    const float* partials_dev; void* workspace_dev; size_t workspace_bytes;
+    int n, c, hw, n_parts;
+} mp_f16_bn_bwd_job;
+int mp_f16_bn_train_fwd_stats_grouped(const mp_f16_bn_fwd_job* jobs, int n_jobs, float eps, float momentum, mp_stream_t stream);
+int mp_f16_bn_train_bwd_stats_grouped(const mp_f16_bn_bwd_job* jobs, int n_jobs, mp_stream_t stream);
+
 /* out = a + b (+ c) (+ d) over `bytes` bytes (a multiple of 16) of fp32 (half = 0) or fp16 (half = 1, fp32 sums, one rounding):
  * the fan-in of gradients at a tensor with several consumers - every branch output of an HRModule feeds every exchange-unit row
  * (hrnet.py:318-344) - in one pass instead of the framework's k - 1 pairwise adds.  out may alias an input. */

@@ -38,6 +38,18 @@ class MindposeHipError(RuntimeError):
     pass
 
 
+class BnFwdJob(ctypes.Structure):  # mp_f16_bn_fwd_job (include/mindpose_hip.h)
+    _fields_ = [(k, ctypes.c_void_p) for k in ("z", "gamma", "beta", "res", "y", "save_mean", "save_invstd", "moving_mean", "moving_var",
+                                                "partials", "workspace")] + [("workspace_bytes", ctypes.c_size_t)] + \
+               [(k, ctypes.c_int) for k in ("n", "c", "hw", "relu", "n_parts", "reserved")]
+
+
+class BnBwdJob(ctypes.Structure):  # mp_f16_bn_bwd_job
+    _fields_ = [(k, ctypes.c_void_p) for k in ("g", "z", "gamma", "save_mean", "save_invstd", "dz", "dgamma", "dbeta", "dgamma_acc",
+                                                "dbeta_acc", "partials", "workspace")] + [("workspace_bytes", ctypes.c_size_t)] + \
+               [(k, ctypes.c_int) for k in ("n", "c", "hw", "n_parts")]
+
+
 _PROTOTYPES = {
     "mp_version": (ctypes.c_char_p, []),
     "mp_error_string": (ctypes.c_char_p, [c_int]),
@@ -126,6 +138,8 @@ _PROTOTYPES = {
     "mp_f16_bn_train_fwd_stats": (c_int, [c_f32p] * 9 + [c_int] * 3 + [ctypes.c_float, ctypes.c_float, c_int, c_f32p, c_int, c_f32p,
                                           c_size_t, ctypes.c_void_p]),
     "mp_f16_bn_train_bwd_stats": (c_int, [c_f32p] * 10 + [c_int] * 3 + [c_f32p, c_int, c_f32p, c_size_t, ctypes.c_void_p]),
+    "mp_f16_bn_train_fwd_stats_grouped": (c_int, [ctypes.POINTER(BnFwdJob), c_int, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),
+    "mp_f16_bn_train_bwd_stats_grouped": (c_int, [ctypes.POINTER(BnBwdJob), c_int, ctypes.c_void_p]),
     "mp_f16_ew_stats_parts": (c_int, [c_int] * 3),
     "mp_f16_fuse_term_stats_parts": (c_int, [c_int] * 5),
     "mp_f16_sum_tensors_stats": (c_int, [c_f32p] * 7 + [c_int] * 4 + [c_f32p, c_size_t, ctypes.c_void_p]),

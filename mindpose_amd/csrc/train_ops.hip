@@ -665,20 +665,20 @@ __global__ __launch_bounds__(256) void bn16_fold_kernel(const float* __restrict_
 }
 
 // forward apply with the statistics folded from the conv's partials: y = act(z * scale + shift (+ res))
-__global__ __launch_bounds__(256) void bn16_apply_pre_kernel(const u32x4_t* __restrict__ z, const float* __restrict__ pre, int n_parts,
-                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                                             float* __restrict__ moving_mean, float* __restrict__ moving_var,
-                                                             const u32x4_t* __restrict__ res, u32x4_t* __restrict__ y, int n, int c,
-                                                             int c8, int hw, double inv_count, double unbias, float eps, float momentum,
-                                                             int relu) {
-    const int blk = blockIdx.x;
+// (a __device__ body: the one-layer kernel passes blockIdx, the grouped kernel below the block's place inside its job)
+__device__ __forceinline__ void bn16_apply_pre_body(const u32x4_t* __restrict__ z, const float* __restrict__ pre, int n_parts,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                    float* __restrict__ moving_mean, float* __restrict__ moving_var,
+                                                    const u32x4_t* __restrict__ res, u32x4_t* __restrict__ y, int n, int c, int c8, int hw,
+                                                    double inv_count, double unbias, float eps, float momentum, int relu, int blk,
+                                                    unsigned chunk, unsigned chunks) {
     __shared__ double s_tot[16];
     __shared__ double s_sm[4][16];
     __shared__ float s_scale[8], s_shift[8];
     const unsigned per_blk = (unsigned)n * (unsigned)hw;
-    const unsigned len = (per_blk + gridDim.y - 1) / gridDim.y;
-    const unsigned e0 = blockIdx.y * len, e1 = e0 + len < per_blk ? e0 + len : per_blk;
+    const unsigned len = (per_blk + chunks - 1) / chunks;
+    const unsigned e0 = chunk * len, e1 = e0 + len < per_blk ? e0 + len : per_blk;
     const unsigned magic_hw = hw > 1 ? (unsigned)(0x100000000ULL / (unsigned)hw) + 1u : 0u;
     const bool exact = (unsigned long long)per_blk * (unsigned)hw < 0x100000000ULL;
     const size_t blk_off = (size_t)blk * hw, img_extra = (size_t)(c8 - 1) * hw;
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(256) void bn16_apply_pre_kernel(const u32x4_t* __re
             const float invstd = (float)r;
             sc = gamma[ch] * invstd;
             sh = bn16_shift(beta[ch], (float)mean, sc);
-            if (blockIdx.y == 0) {
+            if (chunk == 0) {
                 save_mean[ch] = (float)mean;
                 save_invstd[ch] = invstd;
                 if (moving_mean) {
@@ -765,22 +765,61 @@ __global__ __launch_bounds__(256) void bn16_apply_pre_kernel(const u32x4_t* __re
     }
 }
 
+__global__ __launch_bounds__(256) void bn16_apply_pre_kernel(const u32x4_t* __restrict__ z, const float* __restrict__ pre, int n_parts,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                             float* __restrict__ moving_mean, float* __restrict__ moving_var,
+                                                             const u32x4_t* __restrict__ res, u32x4_t* __restrict__ y, int n, int c,
+                                                             int c8, int hw, double inv_count, double unbias, float eps, float momentum,
+                                                             int relu) {
+    bn16_apply_pre_body(z, pre, n_parts, gamma, beta, save_mean, save_invstd, moving_mean, moving_var, res, y, n, c, c8, hw, inv_count,
+                        unbias, eps, momentum, relu, (int)blockIdx.x, blockIdx.y, gridDim.y);
+}
+
+// ---- grouped apply passes: up to four BatchNorms of ONE step of parallel chains (the k-th BatchNorm of every branch of an HRModule,
+// hrnet.py:202-241) as one launch.  On the 32x24 ... 8x6 maps an apply pass is ~9 - 14 us of launch, fold and tail around 1 - 3 us of
+// streaming; the branches' passes are independent, so a flat grid of [job 0's blocks | job 1's | ...] runs them under the largest
+// one.  The job table travels by value; a block picks its job with compares on constant indices (no dynamic index into the
+// argument struct - that would put it in scratch).
+constexpr int kBnJobs = 4;
+struct Bn16FwdJobs {
+    const u32x4_t* z[kBnJobs]; const float* pre[kBnJobs]; const float* gamma[kBnJobs]; const float* beta[kBnJobs];
+    float* save_mean[kBnJobs]; float* save_invstd[kBnJobs]; float* moving_mean[kBnJobs]; float* moving_var[kBnJobs];
+    const u32x4_t* res[kBnJobs]; u32x4_t* y[kBnJobs];
+    double inv_count[kBnJobs], unbias[kBnJobs];
+    int n_parts[kBnJobs], n[kBnJobs], c[kBnJobs], c8[kBnJobs], hw[kBnJobs], relu[kBnJobs];
+    unsigned chunks[kBnJobs], first[kBnJobs];  // first block of the job in the flat grid (0xFFFFFFFF: no such job)
+    float eps, momentum;
+};
+#define MP_BN_PICK(t, a, j) ((j) == 0 ? (t).a[0] : (j) == 1 ? (t).a[1] : (j) == 2 ? (t).a[2] : (t).a[3])
+
+__global__ __launch_bounds__(256) void bn16_apply_pre_grouped_kernel(const Bn16FwdJobs t) {
+    const unsigned b = blockIdx.x;
+    const int j = (b >= t.first[1] ? 1 : 0) + (b >= t.first[2] ? 1 : 0) + (b >= t.first[3] ? 1 : 0);
+    const unsigned local = b - MP_BN_PICK(t, first, j);
+    const int c8 = MP_BN_PICK(t, c8, j);
+    bn16_apply_pre_body(MP_BN_PICK(t, z, j), MP_BN_PICK(t, pre, j), MP_BN_PICK(t, n_parts, j), MP_BN_PICK(t, gamma, j),
+                        MP_BN_PICK(t, beta, j), MP_BN_PICK(t, save_mean, j), MP_BN_PICK(t, save_invstd, j), MP_BN_PICK(t, moving_mean, j),
+                        MP_BN_PICK(t, moving_var, j), MP_BN_PICK(t, res, j), MP_BN_PICK(t, y, j), MP_BN_PICK(t, n, j), MP_BN_PICK(t, c, j), c8,
+                        MP_BN_PICK(t, hw, j), MP_BN_PICK(t, inv_count, j), MP_BN_PICK(t, unbias, j), t.eps, t.momentum,
+                        MP_BN_PICK(t, relu, j), (int)(local % (unsigned)c8), local / (unsigned)c8, MP_BN_PICK(t, chunks, j));
+}
+
 // backward apply on a PRE-MASKED gradient g with sum g, sum g * z folded from the data-gradient conv's partials:
 // dz = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)); the residual branch's gradient is g itself (nothing to write)
-__global__ __launch_bounds__(256) void bn16_bwd_apply_pre_kernel(const u32x4_t* __restrict__ g_in, const u32x4_t* __restrict__ z,
-                                                                 const float* __restrict__ pre, int n_parts,
-                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                                 const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                                                 float* __restrict__ dbeta, float* __restrict__ dgamma_acc,
-                                                                 float* __restrict__ dbeta_acc, u32x4_t* __restrict__ dz, int n, int c,
-                                                                 int c8, int hw, float inv_count) {
-    const int blk = blockIdx.x;
+__device__ __forceinline__ void bn16_bwd_apply_pre_body(const u32x4_t* __restrict__ g_in, const u32x4_t* __restrict__ z,
+                                                        const float* __restrict__ pre, int n_parts, const float* __restrict__ gamma,
+                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                        float* __restrict__ dgamma_acc, float* __restrict__ dbeta_acc,
+                                                        u32x4_t* __restrict__ dz, int n, int c, int c8, int hw, float inv_count, int blk,
+                                                        unsigned chunk, unsigned chunks) {
     __shared__ double s_tot[16];
     __shared__ double s_sm[4][16];
     __shared__ float s_k[8], s_mu[8], s_is[8], s_mb[8], s_mg[8];
     const unsigned per_blk = (unsigned)n * (unsigned)hw;
-    const unsigned len = (per_blk + gridDim.y - 1) / gridDim.y;
-    const unsigned e0 = blockIdx.y * len, e1 = e0 + len < per_blk ? e0 + len : per_blk;
+    const unsigned len = (per_blk + chunks - 1) / chunks;
+    const unsigned e0 = chunk * len, e1 = e0 + len < per_blk ? e0 + len : per_blk;
     const unsigned magic_hw = hw > 1 ? (unsigned)(0x100000000ULL / (unsigned)hw) + 1u : 0u;
     const bool exact = (unsigned long long)per_blk * (unsigned)hw < 0x100000000ULL;
     const size_t blk_off = (size_t)blk * hw, img_extra = (size_t)(c8 - 1) * hw;
@@ -815,7 +854,7 @@ __global__ __launch_bounds__(256) void bn16_bwd_apply_pre_kernel(const u32x4_t* 
             k = gamma[ch] * is;
             mb = db * inv_count;
             mg = dg * inv_count;
-            if (blockIdx.y == 0) {
+            if (chunk == 0) {
                 dbeta[ch] = db;
                 dgamma[ch] = dg;
                 if (dgamma_acc && dbeta_acc) {
@@ -854,6 +893,38 @@ __global__ __launch_bounds__(256) void bn16_bwd_apply_pre_kernel(const u32x4_t* 
             for (int q = 0; q < kBatch; ++q) { cg[q] = ng[q]; cz[q] = nz[q]; ci[q] = ni[q]; }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void bn16_bwd_apply_pre_kernel(const u32x4_t* __restrict__ g_in, const u32x4_t* __restrict__ z,
+                                                                 const float* __restrict__ pre, int n_parts,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta, float* __restrict__ dgamma_acc,
+                                                                 float* __restrict__ dbeta_acc, u32x4_t* __restrict__ dz, int n, int c,
+                                                                 int c8, int hw, float inv_count) {
+    bn16_bwd_apply_pre_body(g_in, z, pre, n_parts, gamma, mean, invstd, dgamma, dbeta, dgamma_acc, dbeta_acc, dz, n, c, c8, hw, inv_count,
+                            (int)blockIdx.x, blockIdx.y, gridDim.y);
+}
+
+struct Bn16BwdJobs {
+    const u32x4_t* g[kBnJobs]; const u32x4_t* z[kBnJobs]; const float* pre[kBnJobs]; const float* gamma[kBnJobs];
+    const float* mean[kBnJobs]; const float* invstd[kBnJobs]; float* dgamma[kBnJobs]; float* dbeta[kBnJobs];
+    float* dgamma_acc[kBnJobs]; float* dbeta_acc[kBnJobs]; u32x4_t* dz[kBnJobs];
+    float inv_count[kBnJobs];
+    int n_parts[kBnJobs], n[kBnJobs], c[kBnJobs], c8[kBnJobs], hw[kBnJobs];
+    unsigned chunks[kBnJobs], first[kBnJobs];
+};
+
+__global__ __launch_bounds__(256) void bn16_bwd_apply_pre_grouped_kernel(const Bn16BwdJobs t) {
+    const unsigned b = blockIdx.x;
+    const int j = (b >= t.first[1] ? 1 : 0) + (b >= t.first[2] ? 1 : 0) + (b >= t.first[3] ? 1 : 0);
+    const unsigned local = b - MP_BN_PICK(t, first, j);
+    const int c8 = MP_BN_PICK(t, c8, j);
+    bn16_bwd_apply_pre_body(MP_BN_PICK(t, g, j), MP_BN_PICK(t, z, j), MP_BN_PICK(t, pre, j), MP_BN_PICK(t, n_parts, j),
+                            MP_BN_PICK(t, gamma, j), MP_BN_PICK(t, mean, j), MP_BN_PICK(t, invstd, j), MP_BN_PICK(t, dgamma, j),
+                            MP_BN_PICK(t, dbeta, j), MP_BN_PICK(t, dgamma_acc, j), MP_BN_PICK(t, dbeta_acc, j), MP_BN_PICK(t, dz, j),
+                            MP_BN_PICK(t, n, j), MP_BN_PICK(t, c, j), c8, MP_BN_PICK(t, hw, j), MP_BN_PICK(t, inv_count, j),
+                            (int)(local % (unsigned)c8), local / (unsigned)c8, MP_BN_PICK(t, chunks, j));
 }
 
 // ---- small maps: both passes of a BatchNorm direction in ONE launch --------------------------------------------------------------
@@ -1574,6 +1645,84 @@ int mp_f16_bn_train_bwd_stats(const void* g, const void* z, const float* gamma, 
                        reinterpret_cast<const u32x4_t*>(g), reinterpret_cast<const u32x4_t*>(z), partials, n_parts, gamma, save_mean,
                        save_invstd, dgamma, dbeta, acc ? dgamma_acc : nullptr, acc ? dbeta_acc : nullptr, reinterpret_cast<u32x4_t*>(dz),
                        n, c, c8, hw, (float)(1.0 / ((double)n * hw)));
+    return check_launch();
+}
+
+// Grouped apply passes (kernels above): job j must satisfy what the one-layer entries check; a job with more than kMaxFoldParts
+// partial slots is folded by its own bn16_fold_kernel launch first (its workspace).
+int mp_f16_bn_train_fwd_stats_grouped(const mp_f16_bn_fwd_job* jobs, int n_jobs, float eps, float momentum, mp_stream_t stream) {
+    if (!jobs) return MP_ERR_NULL;
+    if (n_jobs < 1 || n_jobs > kBnJobs) return MP_ERR_SHAPE;
+    hipStream_t s = as_stream(stream);
+    Bn16FwdJobs t{};
+    unsigned total = 0;
+    size_t fold_off = 0;
+    for (int j = 0; j < kBnJobs; ++j) t.first[j] = 0xFFFFFFFFu;
+    for (int j = 0; j < n_jobs; ++j) {
+        const mp_f16_bn_fwd_job& q = jobs[j];
+        if (!q.z_dev || !q.gamma_dev || !q.beta_dev || !q.y_dev || !q.save_mean_dev || !q.save_invstd_dev || !q.partials_dev) return MP_ERR_NULL;
+        if ((q.moving_mean_dev == nullptr) != (q.moving_var_dev == nullptr)) return MP_ERR_NULL;
+        if (q.n <= 0 || q.c <= 0 || q.hw <= 0 || q.n_parts <= 0) return MP_ERR_SHAPE;
+        if (!q.workspace_dev || q.workspace_bytes < mp_bn_workspace_bytes(q.c)) return MP_ERR_WORKSPACE;
+        const int c8 = (q.c + 7) / 8;
+        const float* pre = q.partials_dev;
+        int n_parts = q.n_parts;
+        // jobs may share one workspace (chains on one stream): job j folds into its own region behind those of the jobs before it
+        if (q.workspace_bytes < fold_off + (size_t)c8 * kFoldSplit * 16 * sizeof(float)) return MP_ERR_WORKSPACE;
+        const int rc = bn16_prefold(pre, n_parts, c8, reinterpret_cast<char*>(q.workspace_dev) + fold_off, s);
+        if (rc != MP_OK) return rc;
+        fold_off += ((size_t)c8 * kFoldSplit * 16 * sizeof(float) + 255) / 256 * 256;
+        const double cnt = (double)q.n * q.hw;
+        t.z[j] = reinterpret_cast<const u32x4_t*>(q.z_dev); t.pre[j] = pre; t.gamma[j] = q.gamma_dev; t.beta[j] = q.beta_dev;
+        t.save_mean[j] = q.save_mean_dev; t.save_invstd[j] = q.save_invstd_dev; t.moving_mean[j] = q.moving_mean_dev;
+        t.moving_var[j] = q.moving_var_dev; t.res[j] = reinterpret_cast<const u32x4_t*>(q.res_dev); t.y[j] = reinterpret_cast<u32x4_t*>(q.y_dev);
+        t.inv_count[j] = 1.0 / cnt; t.unbias[j] = cnt > 1.0 ? cnt / (cnt - 1.0) : 1.0;
+        t.n_parts[j] = n_parts; t.n[j] = q.n; t.c[j] = q.c; t.c8[j] = c8; t.hw[j] = q.hw; t.relu[j] = q.relu ? 1 : 0;
+        t.chunks[j] = bn16_pre_chunks(q.n, c8, q.hw, n_parts);
+        t.first[j] = total;
+        total += (unsigned)c8 * t.chunks[j];
+    }
+    for (int j = n_jobs; j < kBnJobs; ++j) { t.c8[j] = 1; t.chunks[j] = 1; }
+    t.eps = eps; t.momentum = momentum;
+    hipLaunchKernelGGL(bn16_apply_pre_grouped_kernel, dim3(total), dim3(256), 0, s, t);
+    return check_launch();
+}
+
+int mp_f16_bn_train_bwd_stats_grouped(const mp_f16_bn_bwd_job* jobs, int n_jobs, mp_stream_t stream) {
+    if (!jobs) return MP_ERR_NULL;
+    if (n_jobs < 1 || n_jobs > kBnJobs) return MP_ERR_SHAPE;
+    hipStream_t s = as_stream(stream);
+    Bn16BwdJobs t{};
+    unsigned total = 0;
+    size_t fold_off = 0;
+    for (int j = 0; j < kBnJobs; ++j) t.first[j] = 0xFFFFFFFFu;
+    for (int j = 0; j < n_jobs; ++j) {
+        const mp_f16_bn_bwd_job& q = jobs[j];
+        if (!q.g_dev || !q.z_dev || !q.gamma_dev || !q.save_mean_dev || !q.save_invstd_dev || !q.dz_dev || !q.dgamma_dev || !q.dbeta_dev ||
+            !q.partials_dev)
+            return MP_ERR_NULL;
+        if (q.n <= 0 || q.c <= 0 || q.hw <= 0 || q.n_parts <= 0) return MP_ERR_SHAPE;
+        if (!q.workspace_dev || q.workspace_bytes < mp_bn_workspace_bytes(q.c)) return MP_ERR_WORKSPACE;
+        const int c8 = (q.c + 7) / 8;
+        const float* pre = q.partials_dev;
+        int n_parts = q.n_parts;
+        if (q.workspace_bytes < fold_off + (size_t)c8 * kFoldSplit * 16 * sizeof(float)) return MP_ERR_WORKSPACE;
+        const int rc = bn16_prefold(pre, n_parts, c8, reinterpret_cast<char*>(q.workspace_dev) + fold_off, s);
+        if (rc != MP_OK) return rc;
+        fold_off += ((size_t)c8 * kFoldSplit * 16 * sizeof(float) + 255) / 256 * 256;
+        const bool acc = q.dgamma_acc_dev && q.dbeta_acc_dev;
+        t.g[j] = reinterpret_cast<const u32x4_t*>(q.g_dev); t.z[j] = reinterpret_cast<const u32x4_t*>(q.z_dev); t.pre[j] = pre;
+        t.gamma[j] = q.gamma_dev; t.mean[j] = q.save_mean_dev; t.invstd[j] = q.save_invstd_dev; t.dgamma[j] = q.dgamma_dev;
+        t.dbeta[j] = q.dbeta_dev; t.dgamma_acc[j] = acc ? q.dgamma_acc_dev : nullptr; t.dbeta_acc[j] = acc ? q.dbeta_acc_dev : nullptr;
+        t.dz[j] = reinterpret_cast<u32x4_t*>(q.dz_dev);
+        t.inv_count[j] = (float)(1.0 / ((double)q.n * q.hw));
+        t.n_parts[j] = n_parts; t.n[j] = q.n; t.c[j] = q.c; t.c8[j] = c8; t.hw[j] = q.hw;
+        t.chunks[j] = bn16_pre_chunks(q.n, c8, q.hw, n_parts);
+        t.first[j] = total;
+        total += (unsigned)c8 * t.chunks[j];
+    }
+    for (int j = n_jobs; j < kBnJobs; ++j) { t.c8[j] = 1; t.chunks[j] = 1; }
+    hipLaunchKernelGGL(bn16_bwd_apply_pre_grouped_kernel, dim3(total), dim3(256), 0, s, t);
     return check_launch();
 }
 

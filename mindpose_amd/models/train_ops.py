@@ -1098,6 +1098,245 @@ def flush_wgrad_jobs() -> None:
         cur.wait_stream(side)
 
 
+def bn_group_enabled() -> bool:
+    """``MINDPOSE_BN_GROUP=1`` (opt-in): the residual blocks of an HRModule's branches advance in lockstep (``MultiChain16Fn``) and the
+    BatchNorm apply passes of one position run as one grouped launch.  Same bits; measured slower on HRNet-W32 (see hrnet.py)."""
+    return os.environ.get("MINDPOSE_BN_GROUP", "0") == "1"
+
+
+def _run_bn_fwd_jobs(lib, jobs):
+    """BatchNorm forward apply passes of one lockstep position of 1..4 parallel chains: the ones whose statistics came with the
+    conv as ONE grouped launch, the others (no statistics build for the conv's variant) by themselves."""
+    stat = [j for j in jobs if j["part"] is not None]
+    for j in jobs:
+        if j["part"] is None:
+            _lib.check(lib.mp_f16_bn_train_fwd(_lib.ptr(j["z"]), _lib.ptr(j["g"]), _lib.ptr(j["b"]), _lib.ptr(j["res"]), _lib.ptr(j["y"]),
+                                               _lib.ptr(j["mean"]), _lib.ptr(j["invstd"]), _lib.ptr(j["mm"]), _lib.ptr(j["mv"]), j["n"], j["c"],
+                                               j["hw"], BN_EPS, BN_MOMENTUM, j["relu"], _lib.ptr(j["ws"]), j["ws_bytes"], _lib.stream()),
+                       "mp_f16_bn_train_fwd")
+    if len(stat) == 1 or (stat and not bn_group_enabled()):
+        for j in stat:
+            _lib.check(lib.mp_f16_bn_train_fwd_stats(_lib.ptr(j["z"]), _lib.ptr(j["g"]), _lib.ptr(j["b"]), _lib.ptr(j["res"]), _lib.ptr(j["y"]),
+                                                     _lib.ptr(j["mean"]), _lib.ptr(j["invstd"]), _lib.ptr(j["mm"]), _lib.ptr(j["mv"]), j["n"],
+                                                     j["c"], j["hw"], BN_EPS, BN_MOMENTUM, j["relu"], _lib.ptr(j["part"]), j["n_parts"],
+                                                     _lib.ptr(j["ws"]), j["ws_bytes"], _lib.stream()), "mp_f16_bn_train_fwd_stats")
+    elif stat:
+        for i in range(0, len(stat), 4):
+            grp = stat[i:i + 4]
+            arr = (_lib.BnFwdJob * len(grp))()
+            for k, j in enumerate(grp):
+                arr[k] = _lib.BnFwdJob(z=_lib.ptr(j["z"]), gamma=_lib.ptr(j["g"]), beta=_lib.ptr(j["b"]), res=_lib.ptr(j["res"]),
+                                       y=_lib.ptr(j["y"]), save_mean=_lib.ptr(j["mean"]), save_invstd=_lib.ptr(j["invstd"]),
+                                       moving_mean=_lib.ptr(j["mm"]), moving_var=_lib.ptr(j["mv"]), partials=_lib.ptr(j["part"]),
+                                       workspace=_lib.ptr(j["ws"]), workspace_bytes=j["ws_bytes"], n=j["n"], c=j["c"], hw=j["hw"],
+                                       relu=j["relu"], n_parts=j["n_parts"], reserved=0)
+            _lib.check(lib.mp_f16_bn_train_fwd_stats_grouped(arr, len(grp), BN_EPS, BN_MOMENTUM, _lib.stream()),
+                       "mp_f16_bn_train_fwd_stats_grouped")
+
+
+def _run_bn_bwd_jobs(lib, jobs):
+    """The backward counterpart: apply-only passes (gradient pre-masked, sums delivered by its producer) grouped, the others alone."""
+    stat = [j for j in jobs if j["pre"] is not None]
+    for j in jobs:
+        if j["pre"] is None:
+            _lib.check(lib.mp_f16_bn_train_bwd(_lib.ptr(j["dy"]), _lib.ptr(j["z"]), _lib.ptr(j["yy"]), _lib.ptr(j["g"]), _lib.ptr(j["b"]),
+                                               _lib.ptr(j["mean"]), _lib.ptr(j["invstd"]), _lib.ptr(j["dz"]), _lib.ptr(j["dr"]),
+                                               _lib.ptr(j["dgamma"]), _lib.ptr(j["dbeta"]), _lib.ptr(j["ga"]), _lib.ptr(j["ba"]), j["n"], j["c"],
+                                               j["hw"], j["relu"], _lib.ptr(j["ws"]), j["ws_bytes"], _lib.stream()), "mp_f16_bn_train_bwd")
+    if len(stat) == 1 or (stat and not bn_group_enabled()):
+        for j in stat:
+            _lib.check(lib.mp_f16_bn_train_bwd_stats(_lib.ptr(j["dy"]), _lib.ptr(j["z"]), _lib.ptr(j["g"]), _lib.ptr(j["mean"]),
+                                                     _lib.ptr(j["invstd"]), _lib.ptr(j["dz"]), _lib.ptr(j["dgamma"]), _lib.ptr(j["dbeta"]),
+                                                     _lib.ptr(j["ga"]), _lib.ptr(j["ba"]), j["n"], j["c"], j["hw"], _lib.ptr(j["pre"][0]),
+                                                     j["pre"][1], _lib.ptr(j["ws"]), j["ws_bytes"], _lib.stream()), "mp_f16_bn_train_bwd_stats")
+    elif stat:
+        for i in range(0, len(stat), 4):
+            grp = stat[i:i + 4]
+            arr = (_lib.BnBwdJob * len(grp))()
+            for k, j in enumerate(grp):
+                arr[k] = _lib.BnBwdJob(g=_lib.ptr(j["dy"]), z=_lib.ptr(j["z"]), gamma=_lib.ptr(j["g"]), save_mean=_lib.ptr(j["mean"]),
+                                       save_invstd=_lib.ptr(j["invstd"]), dz=_lib.ptr(j["dz"]), dgamma=_lib.ptr(j["dgamma"]),
+                                       dbeta=_lib.ptr(j["dbeta"]), dgamma_acc=_lib.ptr(j["ga"]), dbeta_acc=_lib.ptr(j["ba"]),
+                                       partials=_lib.ptr(j["pre"][0]), workspace=_lib.ptr(j["ws"]), workspace_bytes=j["ws_bytes"], n=j["n"],
+                                       c=j["c"], hw=j["hw"], n_parts=j["pre"][1])
+            _lib.check(lib.mp_f16_bn_train_bwd_stats_grouped(arr, len(grp), _lib.stream()), "mp_f16_bn_train_bwd_stats_grouped")
+
+
+def _chain16_fwd_steps(lib, x, meta, residual, res_ext, params):
+    """Forward of one conv-BatchNorm chain as a generator: launches a group's conv, YIELDS the BatchNorm apply job (the driver runs
+    it - alone, or grouped with the jobs of the sibling chains at the same position) and goes on; returns (groups, output)."""
+    groups = []
+    a = x
+    n_groups = len(meta)
+    for gi, (stride, padding, mm, mv, relu) in enumerate(meta):
+        weight, gamma, beta = params[3 * gi: 3 * gi + 3]
+        w = weight.detach().contiguous()
+        n, _, h, wd, _ = a.shape
+        cout, cin, k, _ = w.shape
+        if padding != k // 2 or k not in (1, 3) or stride not in (1, 2):
+            raise NotImplementedError("training path covers k in {1,3}, stride in {1,2}, padding = k//2")
+        ho, wo = (h + 2 * padding - k) // stride + 1, (wd + 2 * padding - k) // stride + 1
+        ones, zeros = _ones_zeros16(cout, a.device)
+        z = _c8_alloc(n, cout, ho, wo, a.device)
+        d = _desc(n, cin, h, wd, cout, k, stride, padding, padding, ho, wo, ho, wo)
+        packed = _pack16(lib, w, cout, cin, k, 0, owner=weight)
+        if _bn_fuse_parts() & 1:
+            part, n_parts = _conv16_stats_launch(lib, d, a, packed, ones, zeros, z, None, 1)
+        else:
+            part, n_parts = None, 0
+            _conv16_launch(lib, d, a, packed, ones, zeros, z, "mp_f16_conv2d_fwd")
+        last = gi == n_groups - 1
+        res = (x if residual else res_ext) if last else None
+        y = torch.empty_like(z)
+        mean = torch.empty(cout, device=z.device)
+        invstd = torch.empty(cout, device=z.device)
+        ws, ws_bytes = _bn16_workspace(lib, cout, z.device)
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        yield dict(z=z, g=g, b=b, res=res, y=y, mean=mean, invstd=invstd, mm=mm, mv=mv, n=n, c=cout, hw=ho * wo, relu=int(relu),
+                   part=part, n_parts=n_parts, ws=ws, ws_bytes=ws_bytes)
+        groups.append(dict(a=a, w=w, weight=weight, gamma=gamma, beta=beta, g=g, b=b, z=z, y=y, mean=mean, invstd=invstd,
+                           stride=stride, padding=padding, relu=bool(relu), res=res is not None))
+        a = y
+    return groups, a
+
+
+def _chain16_bwd_steps(lib, groups, dy, out_link, in_link, needs_dx, res_is_input):
+    """Backward of one chain as a generator: YIELDS each group's BatchNorm backward job, then queues the weight gradient and
+    launches the data gradient (which masks / reduces for the BatchNorm below); returns (dx, dres, grads)."""
+    dy = dy.contiguous()
+    grads = []
+    # the gradient reaching the LAST BatchNorm: pre-masked with partial sums when the (only) consumer's data gradient made them
+    link = out_link
+    pre = (link.partials, link.n_parts) if (link.partials is not None and link.claimed == 1) else None
+    dres = None
+    for gi in range(len(groups) - 1, -1, -1):
+        G = groups[gi]
+        z, y, a, w = G["z"], G["y"], G["a"], G["w"]
+        n, _, ho, wo, _ = z.shape
+        cout, cin, k, _ = w.shape
+        h, wd = a.shape[2], a.shape[3]
+        dz = torch.empty_like(z)
+        dgamma = torch.empty(cout, device=z.device)
+        dbeta = torch.empty(cout, device=z.device)
+        ws, ws_bytes = _bn16_workspace(lib, cout, z.device)
+        ga, ba = _direct_grad(G["gamma"]), _direct_grad(G["beta"])
+        if ga is None or ba is None:
+            ga = ba = None
+        job = dict(dy=dy, z=z, g=G["g"], b=G["b"], mean=G["mean"], invstd=G["invstd"], dz=dz, dgamma=dgamma, dbeta=dbeta, ga=ga, ba=ba,
+                   n=n, c=cout, hw=ho * wo, relu=int(G["relu"]), ws=ws, ws_bytes=ws_bytes, pre=pre, yy=None, dr=None)
+        if pre is not None:  # apply pass only: dy is g = dy * mask, its sums came with it
+            if G["res"]:
+                dres = dy
+        else:
+            yy = y if (G["relu"] and G["res"]) else None  # no residual: the mask is re-derived from z, y is not read
+            if G["relu"] and not G["res"] and os.environ.get("MINDPOSE_BN16_MASK_FROM_Z", "1") == "0":
+                yy = y
+            job["yy"] = yy
+            job["dr"] = torch.empty_like(z) if G["res"] else None
+            if G["res"]:
+                dres = job["dr"]
+        yield job
+        if ga is not None:
+            dgamma = dbeta = None
+        # ---- conv: weight gradient (a leaf), then the data gradient that feeds the BatchNorm below
+        s, pad = G["stride"], G["padding"]
+        direct = _direct_grad(G["weight"])
+        d = _desc(n, cin, h, wd, cout, k, s, pad, pad, ho, wo, ho, wo)
+        if direct is not None:  # into the gradient arena: queued, launched with the other layers of this shape
+            _wgrad_enqueue(lib, d, a, dz, direct)
+            dw = None
+        else:
+            dw = torch.empty_like(w)
+            wsb = lib.mp_f16_conv_wgrad_workspace_bytes(ctypes.byref(d))
+            wws = torch.empty(max(wsb // 4, 1), device=z.device, dtype=torch.float32)
+            _lib.check(lib.mp_f16_conv_wgrad(ctypes.byref(d), _lib.ptr(a), _lib.ptr(dz), _lib.ptr(dw), 1.0, 0, _lib.ptr(wws), wsb,
+                                             _lib.stream()), "mp_f16_conv_wgrad")
+        pre = None
+        dx = None
+        if gi > 0 or needs_dx:
+            ones, zeros = _ones_zeros16(cin, z.device)
+            dx = _c8_alloc(n, cin, h, wd, z.device)
+            res1 = dres if (gi == 0 and res_is_input) else None  # the chain input's second path: added in this launch's epilogue
+            # which BatchNorm does this gradient reach?  the previous group's - or, across nodes, the producer of the chain input
+            below = None
+            if gi > 0:
+                if _bn_fuse_parts() & 2:
+                    P = groups[gi - 1]
+                    below = (P["z"], P["y"], P["relu"], None)
+            elif in_link is not None and in_link.claimed == 1 and (_bn_fuse_parts() & 4):
+                below = (in_link.z, in_link.y, in_link.relu, in_link)
+            if s == 1:
+                dd = _desc(n, cout, ho, wo, cin, k, 1, k - 1 - pad, k - 1 - pad, h, wd, h, wd)
+                packed = _pack16(lib, w, cin, cout, k, 2, owner=G["weight"])
+                if below is not None and tuple(below[0].shape) == tuple(dx.shape):
+                    part, n_parts = _conv16_stats_launch(lib, dd, dz, packed, ones, zeros, dx, res1, 2, z=below[0], y=below[1],
+                                                         relu=below[2])
+                    if part is not None:
+                        if below[3] is not None:
+                            below[3].partials, below[3].n_parts = part, n_parts
+                        else:
+                            pre = (part, n_parts)
+                else:
+                    _conv16_launch(lib, dd, dz, packed, ones, zeros, dx, "conv dgrad", res1=res1)
+            else:
+                if h != 2 * ho or wd != 2 * wo:
+                    raise NotImplementedError("stride-2 data gradient needs even input extents")
+                if res1 is not None:
+                    raise NotImplementedError("a residual chain starts with a stride-1 conv")
+                if k == 3:
+                    use = below if (below is not None and tuple(below[0].shape) == tuple(dx.shape) and phases4_enabled()
+                                    and (_bn_fuse_parts() & 16)) else None
+                    part, n_parts = _dgrad16_stride2(lib, w, G["weight"], dz, dx, n, cin, cout, h, wd, ho, wo, ones, zeros,
+                                                     below=use[:3] if use is not None else None)
+                    if part is not None:
+                        if use[3] is not None:
+                            use[3].partials, use[3].n_parts = part, n_parts
+                        else:
+                            pre = (part, n_parts)
+                else:
+                    dx.zero_()
+                    dd = _desc(n, cout, ho, wo, cin, 1, 1, 0, 0, ho, wo, h, wd, out_mul=2)
+                    _conv16_launch(lib, dd, dz, _pack16(lib, w, cin, cout, 1, 2, owner=G["weight"]), ones, zeros, dx, "conv dgrad 1x1s2")
+        elif gi == 0 and dres is not None and res_is_input:
+            dx = dres
+        grads = [dw, dgamma, dbeta] + grads
+        dy = dx
+    return dy, dres, grads
+
+
+def _drive(gens, run_jobs, lib, streams=None):
+    """Advance the generators of 1..4 parallel chains in lockstep: every chain runs to its next BatchNorm job (chain i on
+    ``streams[i]`` when given - None = the current stream - so that the convs of the chains overlap), the jobs of one position run
+    together on the current stream.  Returns the generators' return values."""
+    cur = torch.cuda.current_stream() if streams is not None else None
+    results = [None] * len(gens)
+    alive = list(range(len(gens)))
+    while alive:
+        jobs, nxt = [], []
+        for i in alive:
+            st = streams[i] if streams is not None else None
+            try:
+                if st is not None:
+                    st.wait_stream(cur)  # behind the previous position's grouped launch (and whatever produced the inputs)
+                    with torch.cuda.stream(st):
+                        jobs.append(next(gens[i]))
+                else:
+                    jobs.append(next(gens[i]))
+                nxt.append(i)
+            except StopIteration as stop:
+                results[i] = stop.value
+        if streams is not None:
+            for i in alive:
+                if streams[i] is not None:
+                    cur.wait_stream(streams[i])
+        if jobs:
+            if len(jobs) != len(alive):
+                raise RuntimeError("parallel chains of one MultiChain16Fn node must have the same structure")
+            run_jobs(lib, jobs)
+        alive = nxt
+    return results
+
+
 class Chain16Fn(torch.autograd.Function):
     """``meta`` = per group (stride, padding, moving_mean, moving_var, relu); ``residual``: the chain input is added before the last
     group's activation (BasicBlock / Bottleneck without down-sample, hrnet.py:66-83, 126-146); ``params`` = (weight, gamma, beta)
@@ -1108,45 +1347,7 @@ class Chain16Fn(torch.autograd.Function):
         """``res_ext``: a second tensor added before the last group's activation instead of the chain input (the block with a
         down-sample path, hrnet.py:74-81: identity = bn(conv1x1(x)))."""
         lib = _lib.load()
-        groups = []
-        a = x
-        n_groups = len(meta)
-        for gi, (stride, padding, mm, mv, relu) in enumerate(meta):
-            weight, gamma, beta = params[3 * gi: 3 * gi + 3]
-            w = weight.detach().contiguous()
-            n, _, h, wd, _ = a.shape
-            cout, cin, k, _ = w.shape
-            if padding != k // 2 or k not in (1, 3) or stride not in (1, 2):
-                raise NotImplementedError("training path covers k in {1,3}, stride in {1,2}, padding = k//2")
-            ho, wo = (h + 2 * padding - k) // stride + 1, (wd + 2 * padding - k) // stride + 1
-            ones, zeros = _ones_zeros16(cout, a.device)
-            z = _c8_alloc(n, cout, ho, wo, a.device)
-            d = _desc(n, cin, h, wd, cout, k, stride, padding, padding, ho, wo, ho, wo)
-            packed = _pack16(lib, w, cout, cin, k, 0, owner=weight)
-            if _bn_fuse_parts() & 1:
-                part, n_parts = _conv16_stats_launch(lib, d, a, packed, ones, zeros, z, None, 1)
-            else:
-                part, n_parts = None, 0
-                _conv16_launch(lib, d, a, packed, ones, zeros, z, "mp_f16_conv2d_fwd")
-            last = gi == n_groups - 1
-            res = (x if residual else res_ext) if last else None
-            y = torch.empty_like(z)
-            mean = torch.empty(cout, device=z.device)
-            invstd = torch.empty(cout, device=z.device)
-            ws, ws_bytes = _bn16_workspace(lib, cout, z.device)
-            g, b = gamma.detach().contiguous(), beta.detach().contiguous()
-            if part is not None:
-                _lib.check(lib.mp_f16_bn_train_fwd_stats(_lib.ptr(z), _lib.ptr(g), _lib.ptr(b), _lib.ptr(res), _lib.ptr(y), _lib.ptr(mean),
-                                                         _lib.ptr(invstd), _lib.ptr(mm), _lib.ptr(mv), n, cout, ho * wo, BN_EPS, BN_MOMENTUM,
-                                                         int(relu), _lib.ptr(part), n_parts, _lib.ptr(ws), ws_bytes, _lib.stream()),
-                           "mp_f16_bn_train_fwd_stats")
-            else:
-                _lib.check(lib.mp_f16_bn_train_fwd(_lib.ptr(z), _lib.ptr(g), _lib.ptr(b), _lib.ptr(res), _lib.ptr(y), _lib.ptr(mean),
-                                                   _lib.ptr(invstd), _lib.ptr(mm), _lib.ptr(mv), n, cout, ho * wo, BN_EPS, BN_MOMENTUM,
-                                                   int(relu), _lib.ptr(ws), ws_bytes, _lib.stream()), "mp_f16_bn_train_fwd")
-            groups.append(dict(a=a, w=w, weight=weight, gamma=gamma, beta=beta, g=g, b=b, z=z, y=y, mean=mean, invstd=invstd,
-                               stride=stride, padding=padding, relu=bool(relu), res=res is not None))
-            a = y
+        (groups, a), = _drive([_chain16_fwd_steps(lib, x, meta, residual, res_ext, params)], _run_bn_fwd_jobs, lib)
         ctx.groups = groups
         ctx.in_link = in_link
         ctx.out_link = _BnLink(groups[-1]["z"], a, groups[-1]["relu"])
@@ -1158,109 +1359,74 @@ class Chain16Fn(torch.autograd.Function):
     def backward(ctx, dy):
         lib = _lib.load()
         groups, ctx.groups = ctx.groups, None
-        dy = dy.contiguous()
-        grads = []
-        # the gradient reaching the LAST BatchNorm: pre-masked with partial sums when the (only) consumer's data gradient made them
-        link = ctx.out_link
-        pre = (link.partials, link.n_parts) if (link.partials is not None and link.claimed == 1) else None
-        dres = None
-        for gi in range(len(groups) - 1, -1, -1):
-            G = groups[gi]
-            z, y, a, w = G["z"], G["y"], G["a"], G["w"]
-            n, _, ho, wo, _ = z.shape
-            cout, cin, k, _ = w.shape
-            h, wd = a.shape[2], a.shape[3]
-            dz = torch.empty_like(z)
-            dgamma = torch.empty(cout, device=z.device)
-            dbeta = torch.empty(cout, device=z.device)
-            ws, ws_bytes = _bn16_workspace(lib, cout, z.device)
-            ga, ba = _direct_grad(G["gamma"]), _direct_grad(G["beta"])
-            if ga is None or ba is None:
-                ga = ba = None
-            if pre is not None:  # apply pass only: dy is g = dy * mask, its sums came with it
-                _lib.check(lib.mp_f16_bn_train_bwd_stats(_lib.ptr(dy), _lib.ptr(z), _lib.ptr(G["g"]), _lib.ptr(G["mean"]), _lib.ptr(G["invstd"]),
-                                                         _lib.ptr(dz), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ga), _lib.ptr(ba), n, cout,
-                                                         ho * wo, _lib.ptr(pre[0]), pre[1], _lib.ptr(ws), ws_bytes, _lib.stream()),
-                           "mp_f16_bn_train_bwd_stats")
-                if G["res"]:
-                    dres = dy
-            else:
-                yy = y if (G["relu"] and G["res"]) else None  # no residual: the mask is re-derived from z, y is not read
-                if G["relu"] and not G["res"] and os.environ.get("MINDPOSE_BN16_MASK_FROM_Z", "1") == "0":
-                    yy = y
-                dr = torch.empty_like(z) if G["res"] else None
-                _lib.check(lib.mp_f16_bn_train_bwd(_lib.ptr(dy), _lib.ptr(z), _lib.ptr(yy), _lib.ptr(G["g"]), _lib.ptr(G["b"]),
-                                                   _lib.ptr(G["mean"]), _lib.ptr(G["invstd"]), _lib.ptr(dz), _lib.ptr(dr), _lib.ptr(dgamma),
-                                                   _lib.ptr(dbeta), _lib.ptr(ga), _lib.ptr(ba), n, cout, ho * wo, int(G["relu"]), _lib.ptr(ws),
-                                                   ws_bytes, _lib.stream()), "mp_f16_bn_train_bwd")
-                if G["res"]:
-                    dres = dr
-            if ga is not None:
-                dgamma = dbeta = None
-            # ---- conv: weight gradient (a leaf), then the data gradient that feeds the BatchNorm below
-            s, pad = G["stride"], G["padding"]
-            direct = _direct_grad(G["weight"])
-            d = _desc(n, cin, h, wd, cout, k, s, pad, pad, ho, wo, ho, wo)
-            if direct is not None:  # into the gradient arena: queued, launched with the other layers of this shape
-                _wgrad_enqueue(lib, d, a, dz, direct)
-                dw = None
-            else:
-                dw = torch.empty_like(w)
-                wsb = lib.mp_f16_conv_wgrad_workspace_bytes(ctypes.byref(d))
-                wws = torch.empty(max(wsb // 4, 1), device=z.device, dtype=torch.float32)
-                _lib.check(lib.mp_f16_conv_wgrad(ctypes.byref(d), _lib.ptr(a), _lib.ptr(dz), _lib.ptr(dw), 1.0, 0, _lib.ptr(wws), wsb,
-                                                 _lib.stream()), "mp_f16_conv_wgrad")
-            pre = None
-            dx = None
-            if gi > 0 or ctx.needs_dx:
-                ones, zeros = _ones_zeros16(cin, z.device)
-                dx = _c8_alloc(n, cin, h, wd, z.device)
-                res1 = dres if (gi == 0 and ctx.res_is_input) else None  # the chain input's second path: added in this launch's epilogue
-                # which BatchNorm does this gradient reach?  the previous group's - or, across nodes, the producer of the chain input
-                below = None
-                if gi > 0:
-                    if _bn_fuse_parts() & 2:
-                        P = groups[gi - 1]
-                        below = (P["z"], P["y"], P["relu"], None)
-                elif ctx.in_link is not None and ctx.in_link.claimed == 1 and (_bn_fuse_parts() & 4):
-                    below = (ctx.in_link.z, ctx.in_link.y, ctx.in_link.relu, ctx.in_link)
-                if s == 1:
-                    dd = _desc(n, cout, ho, wo, cin, k, 1, k - 1 - pad, k - 1 - pad, h, wd, h, wd)
-                    packed = _pack16(lib, w, cin, cout, k, 2, owner=G["weight"])
-                    if below is not None and tuple(below[0].shape) == tuple(dx.shape):
-                        part, n_parts = _conv16_stats_launch(lib, dd, dz, packed, ones, zeros, dx, res1, 2, z=below[0], y=below[1],
-                                                             relu=below[2])
-                        if part is not None:
-                            if below[3] is not None:
-                                below[3].partials, below[3].n_parts = part, n_parts
-                            else:
-                                pre = (part, n_parts)
-                    else:
-                        _conv16_launch(lib, dd, dz, packed, ones, zeros, dx, "conv dgrad", res1=res1)
-                else:
-                    if h != 2 * ho or wd != 2 * wo:
-                        raise NotImplementedError("stride-2 data gradient needs even input extents")
-                    if res1 is not None:
-                        raise NotImplementedError("a residual chain starts with a stride-1 conv")
-                    if k == 3:
-                        use = below if (below is not None and tuple(below[0].shape) == tuple(dx.shape) and phases4_enabled()
-                                        and (_bn_fuse_parts() & 16)) else None
-                        part, n_parts = _dgrad16_stride2(lib, w, G["weight"], dz, dx, n, cin, cout, h, wd, ho, wo, ones, zeros,
-                                                         below=use[:3] if use is not None else None)
-                        if part is not None:
-                            if use[3] is not None:
-                                use[3].partials, use[3].n_parts = part, n_parts
-                            else:
-                                pre = (part, n_parts)
-                    else:
-                        dx.zero_()
-                        dd = _desc(n, cout, ho, wo, cin, 1, 1, 0, 0, ho, wo, h, wd, out_mul=2)
-                        _conv16_launch(lib, dd, dz, _pack16(lib, w, cin, cout, 1, 2, owner=G["weight"]), ones, zeros, dx, "conv dgrad 1x1s2")
-            elif gi == 0 and dres is not None and ctx.res_is_input:
-                dx = dres
-            grads = [dw, dgamma, dbeta] + grads
-            dy = dx
-        return (dy, None, None, None, None if ctx.res_is_input else dres, *grads)
+        (dx, dres, grads), = _drive([_chain16_bwd_steps(lib, groups, dy, ctx.out_link, ctx.in_link, ctx.needs_dx, ctx.res_is_input)],
+                                    _run_bn_bwd_jobs, lib)
+        return (dx, None, None, None, None if ctx.res_is_input else dres, *grads)
+
+
+class MultiChain16Fn(torch.autograd.Function):
+    """B (2..4) structurally identical chains on B independent tensors - block k of every branch of an HRModule (hrnet.py:202-241) -
+    as ONE node: the chains advance in lockstep, their convs on the branch streams, and the BatchNorm apply passes of one position
+    run as ONE grouped launch (``mp_f16_bn_train_*_stats_grouped``).  Same kernels on the same operands as B ``Chain16Fn`` nodes:
+    same bits.  ``metas`` / ``links``: per chain; ``tensors`` = the B inputs, then every chain's (weight, gamma, beta) triples."""
+
+    @staticmethod
+    def forward(ctx, metas, residual, links, streams, *tensors):
+        lib = _lib.load()
+        B = len(metas)
+        xs = tensors[:B]
+        per, off = [], B
+        for m in metas:
+            per.append(tensors[off: off + 3 * len(m)])
+            off += 3 * len(m)
+        gens = [_chain16_fwd_steps(lib, xs[i], metas[i], residual, None, per[i]) for i in range(B)]
+        res = _drive(gens, _run_bn_fwd_jobs, lib, streams)
+        ctx.groups = [r[0] for r in res]
+        ctx.in_links = links
+        ctx.out_links = [_BnLink(r[0][-1]["z"], r[1], r[0][-1]["relu"]) for r in res]
+        ctx.needs_dx = [x.requires_grad for x in xs]
+        ctx.res_is_input = bool(residual)
+        ctx.streams = streams
+        ctx.n_params = [3 * len(m) for m in metas]
+        return tuple(r[1] for r in res)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        lib = _lib.load()
+        groups, ctx.groups = ctx.groups, None
+        B = len(groups)
+        gens = [_chain16_bwd_steps(lib, groups[i], dys[i], ctx.out_links[i], ctx.in_links[i], ctx.needs_dx[i], ctx.res_is_input)
+                for i in range(B)]
+        res = _drive(gens, _run_bn_bwd_jobs, lib, ctx.streams)
+        dxs = [r[0] for r in res]
+        grads = [g for r in res for g in r[2]]
+        return (None, None, None, None, *dxs, *grads)
+
+
+def multi_residual_blocks(xs, blocks, streams=None):
+    """``blocks[b]`` = [(conv, bn), ...] of a residual block (every group with ReLU, the input added before the last one) on
+    ``xs[b]``; B = 2..4 structurally identical blocks on independent tensors as ONE lockstep node (``MultiChain16Fn``).
+    ``streams[b]``: side stream for chain b's convs (None = current)."""
+    links = [_claim(x) for x in xs]
+    metas = tuple(tuple((cv.stride, cv.padding, bn.moving_mean, bn.moving_variance, True) for cv, bn in groups) for groups in blocks)
+    params = [t for groups in blocks for cv, bn in groups for t in (cv.weight, bn.gamma, bn.beta)]
+    ys = MultiChain16Fn.apply(metas, True, links, streams, *xs, *params)
+    out_links = getattr(ys[0].grad_fn, "out_links", None)  # the node object IS the ctx of forward / backward
+    if out_links is not None:
+        for y, link in zip(ys, out_links):
+            y._mp_bn_link = link
+    return list(ys)
+
+
+def multi_chain_ok(xs, blocks) -> bool:
+    """Can these parallel residual blocks run as one lockstep node?  (channel-blocked fp16, fused BatchNorm on, same structure,
+    stride 1, no conv bias)"""
+    if not (2 <= len(xs) <= 4) or not bn_fuse_enabled() or not bn_group_enabled():
+        return False
+    if any(not _is_c8(x) or not x.is_cuda for x in xs) or len({len(g) for g in blocks}) != 1:
+        return False
+    return all(cv.bias is None and cv.stride == 1 and cv.padding == cv.kernel_size // 2 and cv.kernel_size in (1, 3)
+               for g in blocks for cv, _ in g)
 
 
 def _chain16(x, groups, relus, residual, res_ext=None):

@@ -417,6 +417,88 @@ def test_fused_chain_step_vs_per_cell_step(backbone, head, size, monkeypatch):
     assert l2 == l1 and torch.equal(g2, g1)
 
 
+@pytest.mark.parametrize("streams", ["1", "0"])
+def test_branch_blocks_in_lockstep_with_grouped_batchnorm_equal_per_branch_nodes(streams, monkeypatch):
+    """MultiChain16Fn (block k of every HRModule branch as one node, BatchNorm apply passes of one position as ONE grouped launch)
+    runs the same kernels on the same operands as the per-branch Chain16Fn nodes: loss, every gradient and the moving statistics
+    are bit-identical - with the branches' convs on side streams and without."""
+    monkeypatch.setenv("MINDPOSE_TRAIN_BRANCH_STREAMS", streams)
+    monkeypatch.setenv("MINDPOSE_BN_GROUP", "0")
+    l0, g0, s0 = _step(True, monkeypatch, size=(3, 128, 96))
+    monkeypatch.setenv("MINDPOSE_BN_GROUP", "1")
+    l1, g1, s1 = _step(True, monkeypatch, size=(3, 128, 96))
+    assert l1 == l0
+    assert torch.equal(g1, g0)
+    for k in s0:
+        assert torch.equal(s1[k], s0[k]), k
+
+
+def test_grouped_batchnorm_apply_entries_equal_the_single_entries():
+    """mp_f16_bn_train_{fwd,bwd}_stats_grouped on four tensors of different shapes == four single calls, bit for bit."""
+    import ctypes
+    from mindpose_amd.models import train_ops as T
+    lib = LIB
+    torch.manual_seed(5)
+    shapes = [(6, 32, 16, 12), (6, 64, 8, 6), (6, 128, 4, 3), (6, 17, 10, 6)]
+    fwd_jobs, bwd_jobs, singles = [], [], []
+    keep = []
+    for (n, c, h, w) in shapes:
+        z = _to_c8(torch.randn(n, c, h, w) * 2 + 0.3)
+        res = _to_c8(torch.randn(n, c, h, w))
+        gy = _to_c8(torch.randn(n, c, h, w))
+        c8 = (c + 7) // 8
+        n_parts = 5
+        # partial sums as a conv epilogue would leave them: random splits of the true sums over 5 slots
+        zf = _from_c8(z)
+        tot = torch.stack([zf.sum((0, 2, 3)), (zf * zf).sum((0, 2, 3))], 1)  # [c, 2]
+        gf = _from_c8(gy)
+        totb = torch.stack([gf.sum((0, 2, 3)), (gf * zf).sum((0, 2, 3))], 1)
+        def slots(t):
+            wgt = torch.rand(n_parts, device=DEV); wgt = wgt / wgt.sum()
+            part = torch.zeros(c8, n_parts, 8, 2, device=DEV)
+            for ch in range(c):
+                part[ch // 8, :, ch % 8, :] = wgt[:, None] * t[ch][None, :]
+            return part.contiguous()
+        pf, pb = slots(tot), slots(totb)
+        gamma, beta = torch.rand(c, device=DEV) + 0.5, torch.randn(c, device=DEV) * 0.1
+        ws, ws_bytes = T._bn16_workspace(lib, c, DEV)
+        ws = ws.clone()  # one workspace per job: the jobs of a grouped launch run concurrently
+        out = {}
+        for tag in ("one", "grp"):
+            out[tag] = dict(y=torch.zeros_like(z.c8_tensor), mean=torch.zeros(c, device=DEV), invstd=torch.zeros(c, device=DEV),
+                            mm=torch.zeros(c, device=DEV), mv=torch.ones(c, device=DEV), dz=torch.zeros_like(z.c8_tensor),
+                            dgamma=torch.zeros(c, device=DEV), dbeta=torch.zeros(c, device=DEV))
+        o = out["one"]
+        _lib.check(lib.mp_f16_bn_train_fwd_stats(_lib.ptr(z), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(res), _lib.ptr(o["y"]), _lib.ptr(o["mean"]),
+                                                 _lib.ptr(o["invstd"]), _lib.ptr(o["mm"]), _lib.ptr(o["mv"]), n, c, h * w, 1e-5, 0.9, 1,
+                                                 _lib.ptr(pf), n_parts, _lib.ptr(ws), ws_bytes, _lib.stream()), "fwd one")
+        _lib.check(lib.mp_f16_bn_train_bwd_stats(_lib.ptr(gy), _lib.ptr(z), _lib.ptr(gamma), _lib.ptr(o["mean"]), _lib.ptr(o["invstd"]),
+                                                 _lib.ptr(o["dz"]), _lib.ptr(o["dgamma"]), _lib.ptr(o["dbeta"]), None, None, n, c, h * w,
+                                                 _lib.ptr(pb), n_parts, _lib.ptr(ws), ws_bytes, _lib.stream()), "bwd one")
+        q = out["grp"]
+        fwd_jobs.append(_lib.BnFwdJob(z=_lib.ptr(z), gamma=_lib.ptr(gamma), beta=_lib.ptr(beta), res=_lib.ptr(res), y=_lib.ptr(q["y"]),
+                                      save_mean=_lib.ptr(q["mean"]), save_invstd=_lib.ptr(q["invstd"]), moving_mean=_lib.ptr(q["mm"]),
+                                      moving_var=_lib.ptr(q["mv"]), partials=_lib.ptr(pf), workspace=_lib.ptr(ws), workspace_bytes=ws_bytes,
+                                      n=n, c=c, hw=h * w, relu=1, n_parts=n_parts, reserved=0))
+        bwd_jobs.append(_lib.BnBwdJob(g=_lib.ptr(gy), z=_lib.ptr(z), gamma=_lib.ptr(gamma), save_mean=_lib.ptr(o["mean"]),
+                                      save_invstd=_lib.ptr(o["invstd"]), dz=_lib.ptr(q["dz"]), dgamma=_lib.ptr(q["dgamma"]),
+                                      dbeta=_lib.ptr(q["dbeta"]), dgamma_acc=None, dbeta_acc=None, partials=_lib.ptr(pb),
+                                      workspace=_lib.ptr(ws), workspace_bytes=ws_bytes, n=n, c=c, hw=h * w, n_parts=n_parts))
+        singles.append(out)
+        keep.append((z, res, gy, pf, pb, gamma, beta, ws))
+    fa = (_lib.BnFwdJob * 4)(*fwd_jobs)
+    ba = (_lib.BnBwdJob * 4)(*bwd_jobs)
+    _lib.check(lib.mp_f16_bn_train_fwd_stats_grouped(fa, 4, 1e-5, 0.9, _lib.stream()), "fwd grouped")
+    _lib.check(lib.mp_f16_bn_train_bwd_stats_grouped(ba, 4, _lib.stream()), "bwd grouped")
+    torch.cuda.synchronize()
+    for out in singles:
+        for k in out["one"]:
+            assert torch.equal(out["one"][k], out["grp"][k]), k
+    # argument checks
+    assert lib.mp_f16_bn_train_fwd_stats_grouped(fa, 5, 1e-5, 0.9, _lib.stream()) != 0
+    assert lib.mp_f16_bn_train_bwd_stats_grouped(ba, 0, _lib.stream()) != 0
+
+
 def test_link_is_dropped_when_a_tensor_has_two_consumers(monkeypatch):
     """The cross-node hand-over (the next chain's data gradient reduces for the previous chain's last BatchNorm) is only valid for a
     single consumer: with two, autograd sums two gradients and the BatchNorm must do its own reduction."""
