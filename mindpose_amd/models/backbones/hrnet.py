@@ -5,6 +5,7 @@ Same graph, constructor arguments, registry names and parameter names as the ref
 direct fp32-MFMA convolution, and the HRModule fuse rows (:318-344) accumulate in place through the
 conv epilogue (nearest up-sampling happens while storing; nothing is materialised).
 """
+import contextlib
 import os
 from typing import Dict, List, Tuple, Type, Union
 
@@ -283,7 +284,28 @@ class HRModule(nn.Module):
         rows = len(self.fuse_layers)
         handles = [T.fan_out(x, rows) for x in xs]
         outs = []
+        # The rows of the exchange unit (hrnet.py:318-344) are independent chains of small launches - 1x1 conv + BatchNorm per
+        # up-sampled term, one to three stride-2 conv + BatchNorm groups per down-sampled one, the sum - ~17 (three branches) to ~36
+        # (four) launches of ~10 us that ran one after the other: row i > 0 goes to side stream i, like the branches above
+        # (MINDPOSE_TRAIN_FUSE_STREAMS=0: all rows on the current stream).
+        row_streams = None
+        if rows > 1 and xs[0].is_cuda and branch_streams_enabled() and os.environ.get("MINDPOSE_TRAIN_FUSE_STREAMS", "1") != "0":
+            cur = torch.cuda.current_stream(xs[0].device)
+            row_streams = _branch_streams(xs[0].device, rows - 1)
+            for st in row_streams:
+                st.wait_stream(cur)
         for i in range(rows):
+            ctxm = torch.cuda.stream(row_streams[i - 1]) if (row_streams is not None and i > 0) else contextlib.nullcontext()
+            with ctxm:
+                outs.append(self._train_row(i, xs, handles))
+        if row_streams is not None:
+            for st in row_streams:
+                cur.wait_stream(st)
+        return outs
+
+    def _train_row(self, i, xs, handles):
+        """Row i of the exchange unit: sum over the branches j of (identity | up-sampled 1x1 conv | stride-2 conv chain)."""
+        if True:
             terms = []
             for j in range(self.num_branches):
                 xj = handles[j][i]
@@ -301,8 +323,7 @@ class HRModule(nn.Module):
                     for k in range(len(chain)):
                         t = _train_conv_bn(chain[k], t)
                     terms.append((t, 1))
-            outs.append(T.fuse_sum(terms[0][0], terms[1:]))
-        return outs
+            return T.fuse_sum(terms[0][0], terms[1:])
 
 
 @register("backbone")

@@ -1037,9 +1037,11 @@ def _wgrad_group_size() -> int:
 def _wgrad_enqueue(lib, d, x, dz, dw):
     """Queue dW += x (*) dz (accumulating into the arena slot ``dw``); launches the group when it is full."""
     dev = x.device
-    key = (tuple(getattr(d, f) for f, _ in d._fields_), dev, torch.cuda.current_stream(dev).cuda_stream)
+    # one queue per launch shape, whatever stream a layer ran on: the groups - and with them the split-K partition, i.e. the bits -
+    # are the same for a single-stream step and for one whose branches / exchange-unit rows run on side streams
+    key = (tuple(getattr(d, f) for f, _ in d._fields_), dev)
     jobs = _WGRAD_PENDING.setdefault(key, [])
-    jobs.append((d, x, dz, dw))
+    jobs.append((d, x, dz, dw, torch.cuda.current_stream(dev).cuda_stream))
     if len(jobs) >= _wgrad_group_size():
         _wgrad_flush_key(lib, key)
     elif not _WGRAD_CALLBACK[0]:
@@ -1055,9 +1057,14 @@ def _wgrad_flush_key(lib, key):
         return
     d, dev = jobs[0][0], key[1]
     n = len(jobs)
+    # the group runs on the current stream, behind the producers of every operand (layers that ran on other streams)
+    cur = torch.cuda.current_stream(dev)
+    for sid in sorted({j[4] for j in jobs}):
+        if sid != cur.cuda_stream:
+            cur.wait_stream(torch.cuda.ExternalStream(sid, device=dev))
     with torch.cuda.device(dev):
         if n == 1:
-            _, x, dz, dw = jobs[0]
+            _, x, dz, dw, _ = jobs[0]
             wsb = lib.mp_f16_conv_wgrad_workspace_bytes(ctypes.byref(d))
             ws = torch.empty(max(wsb // 4, 1), device=dev, dtype=torch.float32)
             _lib.check(lib.mp_f16_conv_wgrad(ctypes.byref(d), _lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), 1.0, 1, _lib.ptr(ws), wsb,
@@ -1080,22 +1087,14 @@ def _wgrad_backward_done() -> None:
 
 
 def flush_wgrad_jobs() -> None:
-    """Launch every queued weight gradient.  A group runs on the stream its layers ran on (ordered behind their producers there);
-    the current stream then waits for that stream, so the arena is complete for whatever the caller enqueues next."""
+    """Launch every queued weight gradient on the current stream (each group behind the producers of its operands): the arena is
+    complete for whatever the caller enqueues next."""
     _WGRAD_CALLBACK[0] = False
     if not _WGRAD_PENDING:
         return
     lib = _lib.load()
     for key in list(_WGRAD_PENDING):
-        dev, stream_id = key[1], key[2]
-        cur = torch.cuda.current_stream(dev)
-        if stream_id == cur.cuda_stream:
-            _wgrad_flush_key(lib, key)
-            continue
-        side = torch.cuda.ExternalStream(stream_id, device=dev)
-        with torch.cuda.stream(side):
-            _wgrad_flush_key(lib, key)
-        cur.wait_stream(side)
+        _wgrad_flush_key(lib, key)
 
 
 def bn_group_enabled() -> bool:
