@@ -245,20 +245,7 @@ class HRModule(nn.Module):
     def train_forward(self, xs: List[torch.Tensor]) -> List[torch.Tensor]:
         """Training form of hrnet.py:318-344: same term order; one exchange-unit sum kernel per row."""
         xs = list(xs)
-        depth = {len(br) for br in self.branches}
-        blocks0 = [[(b.conv1, b.bn1), (b.conv2, b.bn2)] for b in (br[0] for br in self.branches)] if all(
-            isinstance(br[0], BasicBlock) and all(blk.down_sample is None for blk in br) for br in self.branches) else None
-        if self.num_branches > 1 and len(depth) == 1 and blocks0 is not None and T.multi_chain_ok(xs, blocks0):
-            # opt-in (MINDPOSE_BN_GROUP=1): block k of every branch as ONE lockstep node - the branches' convs on side streams, their
-            # BatchNorm apply passes as one grouped launch per position.  Bit-identical to the per-branch nodes, but measured SLOWER on
-            # HRNet-W32 (27.4 vs 25.1 ms per step): the full-resolution branch is the module's critical path, the other branches already
-            # run underneath it, and the lockstep joins put their launches back onto that path (DESIGN 4.9).
-            streams = None
-            if branch_streams_enabled():
-                streams = [None] + list(_branch_streams(xs[0].device, self.num_branches - 1))
-            for k in range(depth.pop()):
-                xs = T.multi_residual_blocks(xs, [[(br[k].conv1, br[k].bn1), (br[k].conv2, br[k].bn2)] for br in self.branches], streams)
-        elif self.num_branches > 1 and xs[0].is_cuda and branch_streams_enabled():
+        if self.num_branches > 1 and xs[0].is_cuda and branch_streams_enabled():
             # the branches are independent until the exchange unit: branch i > 0 on side stream i (forked from / joined to the
             # current stream), so the small launches of the deep branches overlap the large ones; autograd replays each node on
             # its forward stream, which parallelises the backward the same way

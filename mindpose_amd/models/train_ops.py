@@ -1097,73 +1097,37 @@ def flush_wgrad_jobs() -> None:
         _wgrad_flush_key(lib, key)
 
 
-def bn_group_enabled() -> bool:
-    """``MINDPOSE_BN_GROUP=1`` (opt-in): the residual blocks of an HRModule's branches advance in lockstep (``MultiChain16Fn``) and the
-    BatchNorm apply passes of one position run as one grouped launch.  Same bits; measured slower on HRNet-W32 (see hrnet.py)."""
-    return os.environ.get("MINDPOSE_BN_GROUP", "0") == "1"
+def _run_bn_fwd_job(lib, j):
+    """The BatchNorm forward pass a chain yielded: apply-only when the statistics came with the conv, reduce + apply otherwise."""
+    if j["part"] is None:
+        _lib.check(lib.mp_f16_bn_train_fwd(_lib.ptr(j["z"]), _lib.ptr(j["g"]), _lib.ptr(j["b"]), _lib.ptr(j["res"]), _lib.ptr(j["y"]),
+                                           _lib.ptr(j["mean"]), _lib.ptr(j["invstd"]), _lib.ptr(j["mm"]), _lib.ptr(j["mv"]), j["n"], j["c"],
+                                           j["hw"], BN_EPS, BN_MOMENTUM, j["relu"], _lib.ptr(j["ws"]), j["ws_bytes"], _lib.stream()),
+                   "mp_f16_bn_train_fwd")
+    else:
+        _lib.check(lib.mp_f16_bn_train_fwd_stats(_lib.ptr(j["z"]), _lib.ptr(j["g"]), _lib.ptr(j["b"]), _lib.ptr(j["res"]), _lib.ptr(j["y"]),
+                                                 _lib.ptr(j["mean"]), _lib.ptr(j["invstd"]), _lib.ptr(j["mm"]), _lib.ptr(j["mv"]), j["n"],
+                                                 j["c"], j["hw"], BN_EPS, BN_MOMENTUM, j["relu"], _lib.ptr(j["part"]), j["n_parts"],
+                                                 _lib.ptr(j["ws"]), j["ws_bytes"], _lib.stream()), "mp_f16_bn_train_fwd_stats")
 
 
-def _run_bn_fwd_jobs(lib, jobs):
-    """BatchNorm forward apply passes of one lockstep position of 1..4 parallel chains: the ones whose statistics came with the
-    conv as ONE grouped launch, the others (no statistics build for the conv's variant) by themselves."""
-    stat = [j for j in jobs if j["part"] is not None]
-    for j in jobs:
-        if j["part"] is None:
-            _lib.check(lib.mp_f16_bn_train_fwd(_lib.ptr(j["z"]), _lib.ptr(j["g"]), _lib.ptr(j["b"]), _lib.ptr(j["res"]), _lib.ptr(j["y"]),
-                                               _lib.ptr(j["mean"]), _lib.ptr(j["invstd"]), _lib.ptr(j["mm"]), _lib.ptr(j["mv"]), j["n"], j["c"],
-                                               j["hw"], BN_EPS, BN_MOMENTUM, j["relu"], _lib.ptr(j["ws"]), j["ws_bytes"], _lib.stream()),
-                       "mp_f16_bn_train_fwd")
-    if len(stat) == 1 or (stat and not bn_group_enabled()):
-        for j in stat:
-            _lib.check(lib.mp_f16_bn_train_fwd_stats(_lib.ptr(j["z"]), _lib.ptr(j["g"]), _lib.ptr(j["b"]), _lib.ptr(j["res"]), _lib.ptr(j["y"]),
-                                                     _lib.ptr(j["mean"]), _lib.ptr(j["invstd"]), _lib.ptr(j["mm"]), _lib.ptr(j["mv"]), j["n"],
-                                                     j["c"], j["hw"], BN_EPS, BN_MOMENTUM, j["relu"], _lib.ptr(j["part"]), j["n_parts"],
-                                                     _lib.ptr(j["ws"]), j["ws_bytes"], _lib.stream()), "mp_f16_bn_train_fwd_stats")
-    elif stat:
-        for i in range(0, len(stat), 4):
-            grp = stat[i:i + 4]
-            arr = (_lib.BnFwdJob * len(grp))()
-            for k, j in enumerate(grp):
-                arr[k] = _lib.BnFwdJob(z=_lib.ptr(j["z"]), gamma=_lib.ptr(j["g"]), beta=_lib.ptr(j["b"]), res=_lib.ptr(j["res"]),
-                                       y=_lib.ptr(j["y"]), save_mean=_lib.ptr(j["mean"]), save_invstd=_lib.ptr(j["invstd"]),
-                                       moving_mean=_lib.ptr(j["mm"]), moving_var=_lib.ptr(j["mv"]), partials=_lib.ptr(j["part"]),
-                                       workspace=_lib.ptr(j["ws"]), workspace_bytes=j["ws_bytes"], n=j["n"], c=j["c"], hw=j["hw"],
-                                       relu=j["relu"], n_parts=j["n_parts"], reserved=0)
-            _lib.check(lib.mp_f16_bn_train_fwd_stats_grouped(arr, len(grp), BN_EPS, BN_MOMENTUM, _lib.stream()),
-                       "mp_f16_bn_train_fwd_stats_grouped")
-
-
-def _run_bn_bwd_jobs(lib, jobs):
-    """The backward counterpart: apply-only passes (gradient pre-masked, sums delivered by its producer) grouped, the others alone."""
-    stat = [j for j in jobs if j["pre"] is not None]
-    for j in jobs:
-        if j["pre"] is None:
-            _lib.check(lib.mp_f16_bn_train_bwd(_lib.ptr(j["dy"]), _lib.ptr(j["z"]), _lib.ptr(j["yy"]), _lib.ptr(j["g"]), _lib.ptr(j["b"]),
-                                               _lib.ptr(j["mean"]), _lib.ptr(j["invstd"]), _lib.ptr(j["dz"]), _lib.ptr(j["dr"]),
-                                               _lib.ptr(j["dgamma"]), _lib.ptr(j["dbeta"]), _lib.ptr(j["ga"]), _lib.ptr(j["ba"]), j["n"], j["c"],
-                                               j["hw"], j["relu"], _lib.ptr(j["ws"]), j["ws_bytes"], _lib.stream()), "mp_f16_bn_train_bwd")
-    if len(stat) == 1 or (stat and not bn_group_enabled()):
-        for j in stat:
-            _lib.check(lib.mp_f16_bn_train_bwd_stats(_lib.ptr(j["dy"]), _lib.ptr(j["z"]), _lib.ptr(j["g"]), _lib.ptr(j["mean"]),
-                                                     _lib.ptr(j["invstd"]), _lib.ptr(j["dz"]), _lib.ptr(j["dgamma"]), _lib.ptr(j["dbeta"]),
-                                                     _lib.ptr(j["ga"]), _lib.ptr(j["ba"]), j["n"], j["c"], j["hw"], _lib.ptr(j["pre"][0]),
-                                                     j["pre"][1], _lib.ptr(j["ws"]), j["ws_bytes"], _lib.stream()), "mp_f16_bn_train_bwd_stats")
-    elif stat:
-        for i in range(0, len(stat), 4):
-            grp = stat[i:i + 4]
-            arr = (_lib.BnBwdJob * len(grp))()
-            for k, j in enumerate(grp):
-                arr[k] = _lib.BnBwdJob(g=_lib.ptr(j["dy"]), z=_lib.ptr(j["z"]), gamma=_lib.ptr(j["g"]), save_mean=_lib.ptr(j["mean"]),
-                                       save_invstd=_lib.ptr(j["invstd"]), dz=_lib.ptr(j["dz"]), dgamma=_lib.ptr(j["dgamma"]),
-                                       dbeta=_lib.ptr(j["dbeta"]), dgamma_acc=_lib.ptr(j["ga"]), dbeta_acc=_lib.ptr(j["ba"]),
-                                       partials=_lib.ptr(j["pre"][0]), workspace=_lib.ptr(j["ws"]), workspace_bytes=j["ws_bytes"], n=j["n"],
-                                       c=j["c"], hw=j["hw"], n_parts=j["pre"][1])
-            _lib.check(lib.mp_f16_bn_train_bwd_stats_grouped(arr, len(grp), _lib.stream()), "mp_f16_bn_train_bwd_stats_grouped")
+def _run_bn_bwd_job(lib, j):
+    """The backward counterpart: apply-only on a pre-masked gradient whose sums its producer delivered, else reduce + apply."""
+    if j["pre"] is None:
+        _lib.check(lib.mp_f16_bn_train_bwd(_lib.ptr(j["dy"]), _lib.ptr(j["z"]), _lib.ptr(j["yy"]), _lib.ptr(j["g"]), _lib.ptr(j["b"]),
+                                           _lib.ptr(j["mean"]), _lib.ptr(j["invstd"]), _lib.ptr(j["dz"]), _lib.ptr(j["dr"]),
+                                           _lib.ptr(j["dgamma"]), _lib.ptr(j["dbeta"]), _lib.ptr(j["ga"]), _lib.ptr(j["ba"]), j["n"], j["c"],
+                                           j["hw"], j["relu"], _lib.ptr(j["ws"]), j["ws_bytes"], _lib.stream()), "mp_f16_bn_train_bwd")
+    else:
+        _lib.check(lib.mp_f16_bn_train_bwd_stats(_lib.ptr(j["dy"]), _lib.ptr(j["z"]), _lib.ptr(j["g"]), _lib.ptr(j["mean"]),
+                                                 _lib.ptr(j["invstd"]), _lib.ptr(j["dz"]), _lib.ptr(j["dgamma"]), _lib.ptr(j["dbeta"]),
+                                                 _lib.ptr(j["ga"]), _lib.ptr(j["ba"]), j["n"], j["c"], j["hw"], _lib.ptr(j["pre"][0]),
+                                                 j["pre"][1], _lib.ptr(j["ws"]), j["ws_bytes"], _lib.stream()), "mp_f16_bn_train_bwd_stats")
 
 
 def _chain16_fwd_steps(lib, x, meta, residual, res_ext, params):
-    """Forward of one conv-BatchNorm chain as a generator: launches a group's conv, YIELDS the BatchNorm apply job (the driver runs
-    it - alone, or grouped with the jobs of the sibling chains at the same position) and goes on; returns (groups, output)."""
+    """Forward of one conv-BatchNorm chain as a generator: launches a group's conv, YIELDS the BatchNorm job (the driver runs it)
+    and goes on; returns (groups, output)."""
     groups = []
     a = x
     n_groups = len(meta)
@@ -1303,37 +1267,15 @@ def _chain16_bwd_steps(lib, groups, dy, out_link, in_link, needs_dx, res_is_inpu
     return dy, dres, grads
 
 
-def _drive(gens, run_jobs, lib, streams=None):
-    """Advance the generators of 1..4 parallel chains in lockstep: every chain runs to its next BatchNorm job (chain i on
-    ``streams[i]`` when given - None = the current stream - so that the convs of the chains overlap), the jobs of one position run
-    together on the current stream.  Returns the generators' return values."""
-    cur = torch.cuda.current_stream() if streams is not None else None
-    results = [None] * len(gens)
-    alive = list(range(len(gens)))
-    while alive:
-        jobs, nxt = [], []
-        for i in alive:
-            st = streams[i] if streams is not None else None
-            try:
-                if st is not None:
-                    st.wait_stream(cur)  # behind the previous position's grouped launch (and whatever produced the inputs)
-                    with torch.cuda.stream(st):
-                        jobs.append(next(gens[i]))
-                else:
-                    jobs.append(next(gens[i]))
-                nxt.append(i)
-            except StopIteration as stop:
-                results[i] = stop.value
-        if streams is not None:
-            for i in alive:
-                if streams[i] is not None:
-                    cur.wait_stream(streams[i])
-        if jobs:
-            if len(jobs) != len(alive):
-                raise RuntimeError("parallel chains of one MultiChain16Fn node must have the same structure")
-            run_jobs(lib, jobs)
-        alive = nxt
-    return results
+def _drive(gen, run_job, lib):
+    """Run a chain generator to its end, executing the BatchNorm job it yields at every group; returns its return value.
+    (The chains are generators so that a driver CAN interleave several of them - the lockstep experiment of DESIGN 4.9.)"""
+    while True:
+        try:
+            job = next(gen)
+        except StopIteration as stop:
+            return stop.value
+        run_job(lib, job)
 
 
 class Chain16Fn(torch.autograd.Function):
@@ -1346,7 +1288,7 @@ class Chain16Fn(torch.autograd.Function):
         """``res_ext``: a second tensor added before the last group's activation instead of the chain input (the block with a
         down-sample path, hrnet.py:74-81: identity = bn(conv1x1(x)))."""
         lib = _lib.load()
-        (groups, a), = _drive([_chain16_fwd_steps(lib, x, meta, residual, res_ext, params)], _run_bn_fwd_jobs, lib)
+        groups, a = _drive(_chain16_fwd_steps(lib, x, meta, residual, res_ext, params), _run_bn_fwd_job, lib)
         ctx.groups = groups
         ctx.in_link = in_link
         ctx.out_link = _BnLink(groups[-1]["z"], a, groups[-1]["relu"])
@@ -1358,74 +1300,9 @@ class Chain16Fn(torch.autograd.Function):
     def backward(ctx, dy):
         lib = _lib.load()
         groups, ctx.groups = ctx.groups, None
-        (dx, dres, grads), = _drive([_chain16_bwd_steps(lib, groups, dy, ctx.out_link, ctx.in_link, ctx.needs_dx, ctx.res_is_input)],
-                                    _run_bn_bwd_jobs, lib)
+        dx, dres, grads = _drive(_chain16_bwd_steps(lib, groups, dy, ctx.out_link, ctx.in_link, ctx.needs_dx, ctx.res_is_input),
+                                 _run_bn_bwd_job, lib)
         return (dx, None, None, None, None if ctx.res_is_input else dres, *grads)
-
-
-class MultiChain16Fn(torch.autograd.Function):
-    """B (2..4) structurally identical chains on B independent tensors - block k of every branch of an HRModule (hrnet.py:202-241) -
-    as ONE node: the chains advance in lockstep, their convs on the branch streams, and the BatchNorm apply passes of one position
-    run as ONE grouped launch (``mp_f16_bn_train_*_stats_grouped``).  Same kernels on the same operands as B ``Chain16Fn`` nodes:
-    same bits.  ``metas`` / ``links``: per chain; ``tensors`` = the B inputs, then every chain's (weight, gamma, beta) triples."""
-
-    @staticmethod
-    def forward(ctx, metas, residual, links, streams, *tensors):
-        lib = _lib.load()
-        B = len(metas)
-        xs = tensors[:B]
-        per, off = [], B
-        for m in metas:
-            per.append(tensors[off: off + 3 * len(m)])
-            off += 3 * len(m)
-        gens = [_chain16_fwd_steps(lib, xs[i], metas[i], residual, None, per[i]) for i in range(B)]
-        res = _drive(gens, _run_bn_fwd_jobs, lib, streams)
-        ctx.groups = [r[0] for r in res]
-        ctx.in_links = links
-        ctx.out_links = [_BnLink(r[0][-1]["z"], r[1], r[0][-1]["relu"]) for r in res]
-        ctx.needs_dx = [x.requires_grad for x in xs]
-        ctx.res_is_input = bool(residual)
-        ctx.streams = streams
-        ctx.n_params = [3 * len(m) for m in metas]
-        return tuple(r[1] for r in res)
-
-    @staticmethod
-    def backward(ctx, *dys):
-        lib = _lib.load()
-        groups, ctx.groups = ctx.groups, None
-        B = len(groups)
-        gens = [_chain16_bwd_steps(lib, groups[i], dys[i], ctx.out_links[i], ctx.in_links[i], ctx.needs_dx[i], ctx.res_is_input)
-                for i in range(B)]
-        res = _drive(gens, _run_bn_bwd_jobs, lib, ctx.streams)
-        dxs = [r[0] for r in res]
-        grads = [g for r in res for g in r[2]]
-        return (None, None, None, None, *dxs, *grads)
-
-
-def multi_residual_blocks(xs, blocks, streams=None):
-    """``blocks[b]`` = [(conv, bn), ...] of a residual block (every group with ReLU, the input added before the last one) on
-    ``xs[b]``; B = 2..4 structurally identical blocks on independent tensors as ONE lockstep node (``MultiChain16Fn``).
-    ``streams[b]``: side stream for chain b's convs (None = current)."""
-    links = [_claim(x) for x in xs]
-    metas = tuple(tuple((cv.stride, cv.padding, bn.moving_mean, bn.moving_variance, True) for cv, bn in groups) for groups in blocks)
-    params = [t for groups in blocks for cv, bn in groups for t in (cv.weight, bn.gamma, bn.beta)]
-    ys = MultiChain16Fn.apply(metas, True, links, streams, *xs, *params)
-    out_links = getattr(ys[0].grad_fn, "out_links", None)  # the node object IS the ctx of forward / backward
-    if out_links is not None:
-        for y, link in zip(ys, out_links):
-            y._mp_bn_link = link
-    return list(ys)
-
-
-def multi_chain_ok(xs, blocks) -> bool:
-    """Can these parallel residual blocks run as one lockstep node?  (channel-blocked fp16, fused BatchNorm on, same structure,
-    stride 1, no conv bias)"""
-    if not (2 <= len(xs) <= 4) or not bn_fuse_enabled() or not bn_group_enabled():
-        return False
-    if any(not _is_c8(x) or not x.is_cuda for x in xs) or len({len(g) for g in blocks}) != 1:
-        return False
-    return all(cv.bias is None and cv.stride == 1 and cv.padding == cv.kernel_size // 2 and cv.kernel_size in (1, 3)
-               for g in blocks for cv, _ in g)
 
 
 def _chain16(x, groups, relus, residual, res_ext=None):

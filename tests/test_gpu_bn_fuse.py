@@ -417,22 +417,6 @@ def test_fused_chain_step_vs_per_cell_step(backbone, head, size, monkeypatch):
     assert l2 == l1 and torch.equal(g2, g1)
 
 
-@pytest.mark.parametrize("streams", ["1", "0"])
-def test_branch_blocks_in_lockstep_with_grouped_batchnorm_equal_per_branch_nodes(streams, monkeypatch):
-    """MultiChain16Fn (block k of every HRModule branch as one node, BatchNorm apply passes of one position as ONE grouped launch)
-    runs the same kernels on the same operands as the per-branch Chain16Fn nodes: loss, every gradient and the moving statistics
-    are bit-identical - with the branches' convs on side streams and without."""
-    monkeypatch.setenv("MINDPOSE_TRAIN_BRANCH_STREAMS", streams)
-    monkeypatch.setenv("MINDPOSE_BN_GROUP", "0")
-    l0, g0, s0 = _step(True, monkeypatch, size=(3, 128, 96))
-    monkeypatch.setenv("MINDPOSE_BN_GROUP", "1")
-    l1, g1, s1 = _step(True, monkeypatch, size=(3, 128, 96))
-    assert l1 == l0
-    assert torch.equal(g1, g0)
-    for k in s0:
-        assert torch.equal(s1[k], s0[k]), k
-
-
 def test_grouped_batchnorm_apply_entries_equal_the_single_entries():
     """mp_f16_bn_train_{fwd,bwd}_stats_grouped on four tensors of different shapes == four single calls, bit for bit."""
     import ctypes

@@ -69,3 +69,9 @@ for nm, v in excl.most_common(22):
 # hardware queues / streams the step's kernels ran on
 qc = collections.Counter(qs[(s_, e_)] for s_, e_, _ in step)
 print("(queue, stream) -> kernels:", dict(qc))
+
+# compact timeline of the step for offline inspection: start_us,dur_us,queue,kernel
+if len(sys.argv) > 2:
+    with open(sys.argv[2], "w") as fh:
+        for s_, e_, nm in step:
+            fh.write(f"{(s_ - t0) / 1e3:.1f},{(e_ - s_) / 1e3:.1f},{qs[(s_, e_)][0]},{nm[:70]}\n")

@@ -10,6 +10,6 @@ rocprofv3 --kernel-trace --output-format csv -d $out/trace_prof -o trace -- pyth
 f=$(find $out/trace_prof -name "*kernel_trace.csv" | head -1)
 cd $root
 head -2 "$f" > $out/trace_head.txt
-python3 tools/trace_gaps.py "$f" > $out/trace_gaps.txt
+python3 tools/trace_gaps.py "$f" $out/trace_timeline.csv > $out/trace_gaps.txt
 rm -rf $out/trace_prof
 tail -60 $out/trace_gaps.txt
