@@ -1587,7 +1587,7 @@ int mp_f16_bn_train_bwd(const void* dy, const void* z, const void* y, const floa
 // pixel-range chunks per channel block of the statistics-free apply kernels.  These passes are bound by the bytes they keep in
 // flight (a thread has 4 x 16 B per operand tensor outstanding), not by the n_parts x 64 bytes of partials every block folds first:
 // ~1024 blocks (four per CU) of >= 1024 elements measured best on every map size of the HRNet step - 512 fatter blocks ran the
-// 64x48 maps at 2.2 TB/s, 1024 at 3.3 TB/s; 2048 and more lose again to the redundant folds (round 3, tools/gpu_r3_m.sh).
+// 64x48 maps at 2.2 TB/s, 1024 at 3.3 TB/s; 2048 and more lose again to the redundant folds (round 3 sweep with MP_BN_PRE_BLOCKS / MP_BN_PRE_MIN, tools/ab_train.sh).
 static unsigned bn16_pre_chunks(int n, int c8, int hw, int n_parts) {
     (void)n_parts;
     size_t total = 1024, floor_elems = 1024;

@@ -15,7 +15,6 @@ dev = torch.device("cuda:0")
 net = mp.init_synthetic(mp.create_network("hrnet_w32", "hrnet_head"), seed=0).to(dev).train()
 mp.models.auto_mixed_precision(net, "O2")
 bb = net.backbone
-mod = bb.stage3[1]
 N = 128
 xs0 = [T.to_c8(torch.randn(N, c, h, w, device=dev)) for c, h, w in ((32, 64, 48), (64, 32, 24), (128, 16, 12))]
 
@@ -44,10 +43,19 @@ def timed(fn, tag):
 
 
 with torch.no_grad():
-    for streams in (True, False):
-        H.set_branch_streams(streams)
-        timed(lambda: mod.train_forward(list(xs0)), f"module forward, branch streams {streams}")
+    for mi in (0, 1):
+        mod = bb.stage3[mi]
+        for streams in (True, False):
+            H.set_branch_streams(streams)
+            timed(lambda: mod.train_forward(list(xs0)), f"stage3[{mi}] forward, branch streams {streams}")
+    H.set_branch_streams(True)
+
+    def two():
+        ys = bb.stage3[0].train_forward(list(xs0))
+        bb.stage3[1].train_forward(ys)
+    timed(two, "stage3[0] + stage3[1], streams")
     H.set_branch_streams(False)
+    mod = bb.stage3[1]
     for i in range(3):
         def one(i=i):
             x = xs0[i]
