@@ -1,5 +1,5 @@
-"""GPU busy / idle analysis of a rocprofv3 kernel trace (csv): the last complete training step = the kernels between the last two
-launches of the optimizer update kernel.  Prints wall time, the union of kernel intervals (busy), time with >= 2 kernels running,
+"""GPU busy / idle analysis of a rocprofv3 kernel trace (csv): the last complete step = the kernels between the last two
+launches of a delimiting kernel (the optimizer update by default).  Prints wall time, the union of kernel intervals (busy), time with >= 2 kernels running,
 and the largest idle gaps with the kernels around them."""
 import csv
 import sys
@@ -8,11 +8,14 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows]
 qs = {(int(r["Start_Timestamp"]), int(r["End_Timestamp"])): (r.get("Queue_Id"), r.get("Stream_Id")) for r in rows}
 ks.sort()
-upd = [i for i, k in enumerate(ks) if "adamw" in k[2].lower()]
-if len(upd) < 4:
-    sys.exit("not enough optimizer launches in the trace")
-# two update launches per step (decay / no-decay groups): a step = from the end of one pair to the end of the next
-a, b = upd[-3], upd[-1]
+# step delimiter: the optimizer update kernel (two launches per training step: decay / no-decay groups), or - third argument - a
+# kernel that runs once per step (e.g. "decode_kernel" for the inference plan)
+marker = sys.argv[3].lower() if len(sys.argv) > 3 else "adamw"
+per_step = 2 if marker == "adamw" else 1
+upd = [i for i, k in enumerate(ks) if marker in k[2].lower()]
+if len(upd) < 2 * per_step:
+    sys.exit("not enough step-delimiting launches in the trace")
+a, b = upd[-1 - per_step], upd[-1]
 step = ks[a + 1:b + 1]
 t0, t1 = step[0][0], max(k[1] for k in step)
 print(f"kernels in the step: {len(step)}  wall {(t1 - t0) / 1e6:.3f} ms  sum of durations {sum(k[1] - k[0] for k in step) / 1e6:.3f} ms")
