@@ -289,6 +289,9 @@ class Plan:
         self._graph = None
         self._graph_ok = True
         self._runs = 0
+        self._marks: List[Tuple[int, object]] = []  # (entry index, lane | "barrier"): the lane structure, for the captured replay
+        self._multi = False
+        self._lane_streams: List[torch.cuda.Stream] = []
 
     def __del__(self):
         try:
@@ -340,15 +343,23 @@ class Plan:
         the plan): independent sub-graphs overlap on the chip.  No-op when lanes are disabled (MINDPOSE_PLAN_LANES=0)."""
         if self.lanes:
             _lib.check(self.lib.mp_plan_set_lane(self.handle, int(lane) % 4), "mp_plan_set_lane")
+            self._marks.append((int(self.lib.mp_plan_size(self.handle)), int(lane) % 4))
             if lane:
-                # a multi-lane replay is not captured into a hipGraph: ROCm 7.2's capture_end faults on the event fork/join
-                # of the side streams, and capture never bought anything here (the replay is one native call that
-                # enqueues back to back; measured no gain at N = 1 ... 128)
-                self._graph_ok = False
+                # The native multi-lane replay (plain HIP streams and events inside mp_plan_run, all-to-all waits at a barrier)
+                # cannot be captured: ROCm 7.2's capture_end faults on it.  The captured replay is driven from here instead
+                # (_replay_lanes): the lanes as torch streams, every barrier a STAR - side lanes join the origin stream and fork
+                # from it again - which is the only fork / join shape capture survives here (the captured training step has no
+                # other).  Inside a hipGraph a cross-lane dependency costs ~10 us instead of the ~30 us of an event wait between
+                # two queues (tools/trace_infer.sh: 12 barriers per HRNet-W32 forward): O2 inference +10 %, fp32 +2 %.
+                # MINDPOSE_PLAN_GRAPH_LANES=0: keep replaying through the native call.
+                self._multi = True
+                if os.environ.get("MINDPOSE_PLAN_GRAPH_LANES", "1") == "0":
+                    self._graph_ok = False
 
     def barrier(self) -> None:
         """Every lane waits for everything recorded so far on every other lane."""
         if self.lanes:
+            self._marks.append((int(self.lib.mp_plan_size(self.handle)), "barrier"))
             _lib.check(self.lib.mp_plan_add_barrier(self.handle), "mp_plan_add_barrier")
             self.layer_info.append(dict(kind="barrier", macs=0))
 
@@ -368,12 +379,44 @@ class Plan:
         try:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                _lib.check(self.lib.mp_plan_run(self.handle, _lib.stream()), "mp_plan_run (capture)")
+                if self._multi:
+                    self._replay_lanes()
+                else:
+                    _lib.check(self.lib.mp_plan_run(self.handle, _lib.stream()), "mp_plan_run (capture)")
             self._graph = graph
         except Exception as exc:  # capture unsupported in this context: keep direct launches (same kernels)
             self._graph_ok = False
             import warnings
             warnings.warn(f"hipGraph capture of the launch plan failed, using direct launches: {exc}")
+
+    def _replay_lanes(self) -> None:
+        """The recorded forward with lane l on torch stream l (0 = the current stream): what mp_plan_run does natively, in a
+        form stream capture accepts.  Barrier entries become all-to-all wait_stream calls among the lanes in use."""
+        cur = torch.cuda.current_stream(self.device)
+        lanes_used = sorted({m for _, m in self._marks if m != "barrier"} | {0})
+        while len(self._lane_streams) < max(lanes_used):
+            self._lane_streams.append(torch.cuda.Stream(device=self.device))
+        streams = [cur] + self._lane_streams
+        for l in lanes_used[1:]:
+            streams[l].wait_stream(cur)
+        pos, lane = 0, 0
+        for idx, what in self._marks + [(len(self), None)]:
+            if idx > pos:
+                with torch.cuda.stream(streams[lane]):
+                    _lib.check(self.lib.mp_plan_run_range(self.handle, pos, idx - pos, _lib.stream()), "mp_plan_run_range")
+                pos = idx
+            if what == "barrier":
+                pos = idx + 1  # the barrier entry itself launches nothing
+                # star-shaped: every side lane joins the origin stream, then forks from it again.  Side-to-side waits (a stream
+                # joining another FORKED stream) make ROCm 7.2's capture_end fault - the training step's captures never have them
+                for l in lanes_used[1:]:
+                    cur.wait_stream(streams[l])
+                for l in lanes_used[1:]:
+                    streams[l].wait_stream(cur)
+            elif what is not None:
+                lane = what
+        for l in lanes_used[1:]:
+            cur.wait_stream(streams[l])
 
     def run_range(self, first: int, count: int) -> None:
         _lib.check(self.lib.mp_plan_run_range(self.handle, first, count, _lib.stream()), "mp_plan_run_range")
