@@ -1327,12 +1327,17 @@ __global__ __launch_bounds__(256) void sum_tensors16_stats_kernel(const u32x4_t*
 }
 
 // one term of the exchange unit's backward: dt = fp16(sum over the s x s block of dy * [out > 0]) * [y_t > 0]
+// (SH = log2 of the scale as a template parameter: the s x s block is walked by fully unrolled loops whose 2 s loads per row
+// are all issued before the first use - with a run-time s the thread had one load in flight at a time)
+template <int SH>
 __global__ __launch_bounds__(256) void fuse_sum16_bwd_stats_kernel(const u32x4_t* __restrict__ dy, const u32x4_t* __restrict__ outp,
                                                                    const u32x4_t* __restrict__ z, const u32x4_t* __restrict__ y,
                                                                    u32x4_t* __restrict__ dt, float* __restrict__ part, int n, int c8, int h,
-                                                                   int w, int sh, int relu, int relu_t) {
+                                                                   int w, int relu, int relu_t) {
+    constexpr int sh = SH;
     const int blk = blockIdx.x;
-    const int lh = h >> sh, lw = w >> sh, s = 1 << sh, lhw = lh * lw;
+    const int lh = h >> sh, lw = w >> sh, lhw = lh * lw;
+    constexpr int s = 1 << SH;
     const unsigned per_blk = (unsigned)n * (unsigned)lhw;
     const unsigned len = (per_blk + gridDim.y - 1) / gridDim.y;
     const unsigned e0 = blockIdx.y * len, e1 = e0 + len < per_blk ? e0 + len : per_blk;
@@ -1346,11 +1351,18 @@ __global__ __launch_bounds__(256) void fuse_sum16_bwd_stats_kernel(const u32x4_t
         const size_t i = plane * lhw + pix;
         const size_t o = (plane * h + (size_t)ly * s) * w + (size_t)lx * s;
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int a = 0; a < s; ++a)
+        // same summation order as before (row by row, left to right): same bits
+#pragma unroll
+        for (int a = 0; a < s; ++a) {
+            u32x4_t gq[s], oq[s];
+#pragma unroll
             for (int b = 0; b < s; ++b) {
-                const h16x8 gv = __builtin_bit_cast(h16x8, dy[o + (size_t)a * w + b]);
-                h16x8 ov = gv;
-                if (relu) ov = __builtin_bit_cast(h16x8, outp[o + (size_t)a * w + b]);
+                gq[b] = dy[o + (size_t)a * w + b];
+                oq[b] = relu ? outp[o + (size_t)a * w + b] : gq[b];
+            }
+#pragma unroll
+            for (int b = 0; b < s; ++b) {
+                const h16x8 gv = __builtin_bit_cast(h16x8, gq[b]), ov = __builtin_bit_cast(h16x8, oq[b]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float g = (float)gv[j];
@@ -1358,6 +1370,7 @@ __global__ __launch_bounds__(256) void fuse_sum16_bwd_stats_kernel(const u32x4_t
                     acc[j] += g;
                 }
             }
+        }
         const h16x8 zv = __builtin_bit_cast(h16x8, z[i]);
         h16x8 yv = zv;
         if (relu_t) yv = __builtin_bit_cast(h16x8, y[i]);
@@ -1789,9 +1802,12 @@ int mp_f16_fuse_sum_bwd_term_stats(const void* dy, const void* out, void* dt, in
     if (sh < 0 || (h % s) || (w % s)) return MP_ERR_UNSUPPORTED;
     const int c8 = (c + 7) / 8, parts = mp_f16_fuse_term_stats_parts(n, c, h, w, s);
     if (partials_bytes < (size_t)c8 * parts * 16 * sizeof(float)) return MP_ERR_WORKSPACE;
-    hipLaunchKernelGGL(fuse_sum16_bwd_stats_kernel, dim3(c8, parts), dim3(256), 0, as_stream(stream), reinterpret_cast<const u32x4_t*>(dy),
+    if (sh > 3) return MP_ERR_UNSUPPORTED;  // HRNet's exchange units up-sample by 2, 4 and 8 (1: the identity term)
+    auto kern = sh == 0 ? fuse_sum16_bwd_stats_kernel<0> : sh == 1 ? fuse_sum16_bwd_stats_kernel<1>
+              : sh == 2 ? fuse_sum16_bwd_stats_kernel<2> : fuse_sum16_bwd_stats_kernel<3>;
+    hipLaunchKernelGGL(kern, dim3(c8, parts), dim3(256), 0, as_stream(stream), reinterpret_cast<const u32x4_t*>(dy),
                        reinterpret_cast<const u32x4_t*>(out), reinterpret_cast<const u32x4_t*>(z_t), reinterpret_cast<const u32x4_t*>(y_t),
-                       reinterpret_cast<u32x4_t*>(dt), partials, n, c8, h, w, sh, relu ? 1 : 0, relu_t ? 1 : 0);
+                       reinterpret_cast<u32x4_t*>(dt), partials, n, c8, h, w, relu ? 1 : 0, relu_t ? 1 : 0);
     return check_launch();
 }
 
