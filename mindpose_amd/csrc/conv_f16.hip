@@ -751,6 +751,35 @@ __global__ __launch_bounds__(256) void fuse_sum_f16_kernel(const u32x4* __restri
     }
 }
 
+// The same sum with 32-bit index arithmetic: divisions by w and h through reciprocal multiplication, the power-of-two scale
+// factors of HRNet's exchange units (2, 4, 8: hrnet.py:296-312) as shifts.  The generic kernel above spends two 64-bit and eight
+// 32-bit integer divisions per 16-byte element - more instruction time than its memory traffic takes on the large maps.
+__global__ __launch_bounds__(256) void fuse_sum_f16_fast_kernel(const u32x4* __restrict__ base, const u32x4* __restrict__ t1, int sh1,
+                                                                const u32x4* __restrict__ t2, int sh2, const u32x4* __restrict__ t3,
+                                                                int sh3, u32x4* __restrict__ out, unsigned total, unsigned h, unsigned w,
+                                                                unsigned magic_h, unsigned magic_w, int relu) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned r = fastdiv(i, w, magic_w), x = i - r * w;
+        const unsigned pl = fastdiv(r, h, magic_h), y = r - pl * h;
+        const u32x4 bq = base[i];
+        const u32x4 q1 = t1[(pl * (h >> sh1) + (y >> sh1)) * (w >> sh1) + (x >> sh1)];
+        u32x4 q2 = (u32x4){0u, 0u, 0u, 0u}, q3 = q2;
+        if (t2) q2 = t2[(pl * (h >> sh2) + (y >> sh2)) * (w >> sh2) + (x >> sh2)];
+        if (t3) q3 = t3[(pl * (h >> sh3) + (y >> sh3)) * (w >> sh3) + (x >> sh3)];
+        const f16x8 bv = __builtin_bit_cast(f16x8, bq), v1 = __builtin_bit_cast(f16x8, q1), v2 = __builtin_bit_cast(f16x8, q2),
+                    v3 = __builtin_bit_cast(f16x8, q3);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = (float)bv[j] + (float)v1[j];  // the reference's term order; absent terms add +0 (exact)
+            if (t2) v += (float)v2[j];
+            if (t3) v += (float)v3[j];
+            o[j] = (_Float16)(relu ? fmaxf(v, 0.f) : v);
+        }
+        out[i] = __builtin_bit_cast(u32x4, o);
+    }
+}
+
 int grid_for(size_t total) {
     size_t blocks = (total + 255) / 256;
     return (int)(blocks > 8192 ? 8192 : (blocks < 1 ? 1 : blocks));
@@ -948,6 +977,15 @@ int mp_f16_fuse_upsample_sum(const void* base, const void* t1, int s1, const voi
     if (t3 && !t2) return MP_ERR_NULL;
     const int planes = n * ((c + 7) / 8);
     const size_t total = (size_t)planes * h * w;
+    auto log2_of = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+    const int l1 = log2_of(ss[0]), l2 = log2_of(ss[1]), l3 = log2_of(ss[2]);
+    if (l1 >= 0 && l2 >= 0 && l3 >= 0 && (unsigned long long)total * (unsigned)(h > w ? h : w) < 0x100000000ULL) {
+        hipLaunchKernelGGL(fuse_sum_f16_fast_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+                           reinterpret_cast<const u32x4*>(base), reinterpret_cast<const u32x4*>(t1), l1, reinterpret_cast<const u32x4*>(t2), l2,
+                           reinterpret_cast<const u32x4*>(t3), l3, reinterpret_cast<u32x4*>(out), (unsigned)total, (unsigned)h, (unsigned)w,
+                           magic_of((unsigned)h), magic_of((unsigned)w), relu);
+        return check_launch();
+    }
     hipLaunchKernelGGL(fuse_sum_f16_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const u32x4*>(base), reinterpret_cast<const u32x4*>(t1), s1,
                        reinterpret_cast<const u32x4*>(t2), s2, reinterpret_cast<const u32x4*>(t3), s3,
