@@ -261,17 +261,19 @@ def test_fuse_upsample_sum_vs_torch(terms):
 def test_execution_lanes_are_bit_identical_to_single_stream(amp, monkeypatch):
     # the four-lane replay (branches / exchange-unit rows on side streams, event fork / barriers / join) must produce exactly
     # the single-stream result, run after run: a missing ordering edge would show up as a difference at a filling batch size
+    # Runs 1 - 2 of a plan go through the native multi-stream replay, the second one captures, runs 3 - 4 replay the hipGraph driven
+    # over torch streams with star-shaped barriers (Plan._replay_lanes); "native": MINDPOSE_PLAN_GRAPH_LANES=0, never captured.
     x = torch.randn(48, 3, 256, 192, generator=torch.Generator().manual_seed(7)).to(DEV)
     outs = {}
-    for lanes in ("1", "0"):
+    for tag, lanes, graph in (("graph", "1", "1"), ("native", "1", "0"), ("single", "0", "1")):
         monkeypatch.setenv("MINDPOSE_PLAN_LANES", lanes)
+        monkeypatch.setenv("MINDPOSE_PLAN_GRAPH_LANES", graph)
         net = _net("hrnet_w32", "hrnet_head")
         mp.models.auto_mixed_precision(net, amp)
-        outs[lanes] = [net(x).clone() for _ in range(4)]
+        outs[tag] = [net(x).clone() for _ in range(4)]
         torch.cuda.synchronize()
-    for o in outs["1"]:
-        assert torch.equal(o, outs["0"][0])
-    assert all(torch.equal(o, outs["0"][0]) for o in outs["0"])
+    for tag in outs:
+        assert all(torch.equal(o, outs["single"][0]) for o in outs[tag]), tag
 
 
 PW_CASES = [
