@@ -7,12 +7,12 @@ reference's order (bbox_ids count per image for ground truth, globally for detec
 import json
 import os
 from collections import defaultdict
-from typing import Any, Dict, List, Tuple
+from typing import Any, Dict, List
 
 import numpy as np
 
 from ...register import register
-from .topdown import TopDownDataset
+from .topdown import RecordTable, TopDownDataset, clip_boxes_to_image
 
 
 class _CocoIndex:
@@ -46,75 +46,59 @@ class _CocoIndex:
 
 @register("dataset", extra_name="coco_topdown")
 class COCOTopDownDataset(TopDownDataset):
-    """Ground-truth records (training, or ``use_gt_bbox_for_val``) or detector boxes above ``config["det_bbox_thr"]``
-    (evaluation with ``detection_file``): coco_topdown.py:44-163."""
+    """COCO person key points as top-down records.  Two sources, chosen as coco_topdown.py:55-62 does: the annotation file's
+    own boxes (training, or evaluation with ``use_gt_bbox_for_val``) or a detector's boxes (``detection_file``).
+
+    Filtering rules kept from coco_topdown.py:86-160.  Ground truth: non-crowd annotations only; the box must survive
+    `clip_boxes_to_image` with a positive ``area``; at least one labelled key point (some non-zero entry, and ``num_keypoints``
+    not 0 when the field exists); visibility 2 is stored as 1; ``bbox_ids`` restart at 0 for every image.  Detections: category 1
+    with ``score >= config["det_bbox_thr"]``; ``bbox_ids`` number the kept boxes across the whole file.  Every record has rotation
+    0; ground-truth boxes score 1."""
 
     def load_dataset_cfg(self) -> Dict[str, Any]:
-        dataset_cfg = dict()
-        dataset_cfg["det_bbox_thr"] = float(self.config["det_bbox_thr"])
-        return dataset_cfg
+        return {"det_bbox_thr": float(self.config["det_bbox_thr"])}  # KeyError when absent, like the reference
 
-    def load_dataset(self) -> List[Dict[str, Any]]:
+    def load_dataset(self) -> RecordTable:
         self.coco = _CocoIndex(self.annotation_file)
-        self.id2name, self.name2id = self._get_mapping_id_name(self.coco.imgs)
-        if self.is_train or self.use_gt_bbox_for_val:
-            return self._load_coco_keypoint_annotations()
-        return self._load_coco_detection_result()
+        image_ids = self.coco.get_img_ids()  # file order
+        self._image_slot = {image_id: slot for slot, image_id in enumerate(image_ids)}
+        paths = [os.path.join(self.image_root, self.coco.load_img(image_id)["file_name"]) for image_id in image_ids]
+        from_annotations = self.is_train or self.use_gt_bbox_for_val
+        return self._ground_truth_table(image_ids, paths) if from_annotations else self._detection_table(paths)
 
-    def _load_coco_keypoint_annotations(self) -> List[Dict[str, Any]]:
-        self.img_ids = self.coco.get_img_ids()
-        gt_db = []
-        for img_id in self.img_ids:
-            gt_db.extend(self._load_coco_keypoint_annotations_per_img(img_id))
-        return gt_db
-
-    def _load_coco_detection_result(self) -> List[Dict[str, Any]]:
-        """Person detections (``category_id == 1``) with ``score >= det_bbox_thr``; ``bbox_ids`` count the kept boxes (:86-118)."""
-        with open(self.detection_file, "r") as f:
-            all_boxes = json.load(f)
-        bbox_id = 0
-        kpt_db = []
-        for det_res in all_boxes:
-            if det_res["category_id"] != 1:
+    # -- ground truth: one pass over the index, image by image -----------------------------------------------------------------
+    def _ground_truth_table(self, image_ids: List[int], paths: List[str]) -> RecordTable:
+        slots: List[int] = []
+        ranks: List[int] = []
+        boxes: List[np.ndarray] = []
+        joints: List[np.ndarray] = []
+        for slot, image_id in enumerate(image_ids):
+            meta = self.coco.load_img(image_id)
+            people = [a for a in self.coco.anns_of(image_id, iscrowd=False) if "bbox" in a]
+            if not people:
                 continue
-            image_file = os.path.join(self.image_root, self.id2name[det_res["image_id"]])
-            box = det_res["bbox"]
-            score = det_res["score"]
-            if score < self._dataset_cfg["det_bbox_thr"]:
-                continue
-            kpt_db.append({"image_file": image_file, "rotation": 0, "boxes": box, "bbox_ids": bbox_id, "bbox_scores": score})
-            bbox_id += 1
-        return kpt_db
-
-    def _load_coco_keypoint_annotations_per_img(self, img_id: int) -> List[Dict[str, Any]]:
-        """Non-crowd annotations with a sane box and at least one labelled key point; visibility 2 -> 1 (:120-160)."""
-        img_ann = self.coco.load_img(img_id)
-        img_width = img_ann["width"]
-        img_height = img_ann["height"]
-        annos = self.coco.anns_of(img_id, iscrowd=False)  # no need to train crowd instances
-        annos = self._sanitize_bbox(annos, img_width, img_height)
-        bbox_id = 0
-        rec = []
-        for anno in annos:
-            if "keypoints" not in anno:
-                continue
-            if max(anno["keypoints"]) == 0:
-                continue
-            if "num_keypoints" in anno and anno["num_keypoints"] == 0:
-                continue
-            keypoints = np.array(anno["keypoints"]).reshape(-1, 3)
-            keypoints[:, 2] = np.minimum(1, keypoints[:, 2])
-            image_file = os.path.join(self.image_root, self.id2name[img_id])
-            rec.append({"image_file": image_file, "keypoints": keypoints, "rotation": 0, "boxes": anno["bbox"], "bbox_ids": bbox_id,
-                        "bbox_scores": 1.0})
-            bbox_id += 1
-        return rec
+            clipped, positive = clip_boxes_to_image(np.array([a["bbox"] for a in people], dtype=np.float64), meta["width"], meta["height"])
+            rank = 0
+            for anno, box, ok in zip(people, clipped, positive):
+                if not (ok and anno.get("area", 1) > 0 and self._is_labelled(anno)):
+                    continue
+                kp = np.array(anno["keypoints"]).reshape(-1, 3)
+                kp[:, 2] = np.minimum(1, kp[:, 2])
+                slots.append(slot), ranks.append(rank), boxes.append(box), joints.append(kp)
+                rank += 1
+        return RecordTable(paths, slots, boxes, ranks, np.ones(len(slots)), keypoints=joints)
 
     @staticmethod
-    def _get_mapping_id_name(imgs: Dict[int, Dict[str, Any]]) -> Tuple[Dict[int, str], Dict[str, int]]:
-        id2name, name2id = {}, {}
-        for image_id, image in imgs.items():
-            file_name = image["file_name"]
-            id2name[image_id] = file_name
-            name2id[file_name] = image_id
-        return id2name, name2id
+    def _is_labelled(anno: Dict[str, Any]) -> bool:
+        return "keypoints" in anno and max(anno["keypoints"]) != 0 and anno.get("num_keypoints", 1) != 0
+
+    # -- detector boxes: vectorised over the whole result file -----------------------------------------------------------------
+    def _detection_table(self, paths: List[str]) -> RecordTable:
+        with open(self.detection_file, "r") as f:
+            detections = json.load(f)
+        category = np.array([d["category_id"] for d in detections], dtype=np.int64)
+        score = np.array([d["score"] for d in detections], dtype=np.float64)
+        keep = np.flatnonzero((category == 1) & ~(score < self._dataset_cfg["det_bbox_thr"]))
+        slots = [self._image_slot[detections[i]["image_id"]] for i in keep]
+        boxes = [detections[i]["bbox"] for i in keep]
+        return RecordTable(paths, slots, boxes, np.arange(len(keep)), score[keep])
