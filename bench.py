@@ -534,7 +534,7 @@ def train_bench(args, mp, dev, dist, world, rank):
     if graphed:  # forward + loss + backward captured once into a hipGraph, replayed per step (utils/graph_step.py)
         from mindpose_amd.utils import GraphedTrainStep
         t0, w0 = tgt(kp)
-        gstep = GraphedTrainStep(nwl, opt, (image, t0, w0), loss_scale_manager=scaler)
+        gstep = mp.models.tune_on_rank0_first(lambda: GraphedTrainStep(nwl, opt, (image, t0, w0), loss_scale_manager=scaler))
 
     def eager_step(update=True):
         opt.zero_grad()
@@ -642,26 +642,54 @@ def dp_leg_report(step, opt, dist, world, rank, dev, per_gpu_batch, steps, warmu
             "n_gpus_seen": torch.cuda.device_count()}
 
 
+def all_ranks_ok(dist, dev, ok: bool) -> bool:
+    """MIN over ranks of a success flag: a rank that failed on its own (e.g. out of memory while building) must not leave the others
+    blocked inside the leg's collectives - every rank learns of the failure here and all skip the leg together."""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item())
+
+
 def dp_train_leg(args, mp, dev, dist, world, rank):
     """configs[3] under data parallelism on every rank of a multi-rank run: HRNet-W32 amp-O2 training step as
-    one hipGraph replay + bucketed RCCL gradient mean + AdamWeightDecay, so that a scaling run exercises the collective."""
+    one hipGraph replay + bucketed RCCL gradient mean + AdamWeightDecay, so that a scaling run exercises the collective.
+
+    Built in two phases, each followed by `all_ranks_ok`: (A) model, data, optimizer arena - no collective inside; (B) the
+    communicator and the captured step (`tune_on_rank0_first`: one broadcast, reached by every rank whatever its build did).  A rank
+    that fails in either phase makes ALL ranks return an error entry instead of entering the timed collectives alone."""
     from mindpose_amd.utils import AdamWeightDecay, DynamicLossScaleManager, GraphedTrainStep
     n = int(os.environ.get("MINDPOSE_BENCH_DP_BATCH", args.batch))
-    net = mp.init_synthetic(mp.create_network("hrnet_w32", "hrnet_head"), seed=0).to(dev).train()
-    mp.models.auto_mixed_precision(net, "O2")
-    scaler = DynamicLossScaleManager()
-    nwl = mp.create_network_with_loss(net, mp.create_loss("joint_mse", use_target_weight=True), has_extra_inputs=True)
-    opt = AdamWeightDecay(net, lr=1e-3, weight_decay=0.05, filter_bias_and_bn=True, overlap=False)
-    tgt = mp.TopDownGenerateTarget(config=dict(image_size=[192, 256], heatmap_size=[48, 64]), sigma=2.0)
-    gen = torch.Generator(device="cpu").manual_seed(2000 + rank)
-    image = torch.randn(n, 3, 256, 192, generator=gen).to(dev)
-    kp = torch.empty(n, 17, 3)
-    kp[..., 0] = torch.rand(n, 17, generator=gen) * 232 - 20
-    kp[..., 1] = torch.rand(n, 17, generator=gen) * 296 - 20
-    kp[..., 2] = (torch.rand(n, 17, generator=gen) < 0.7).float()
-    kp = kp.to(dev)
-    t0, w0 = tgt(kp)
-    gstep = GraphedTrainStep(nwl, opt, (image, t0, w0), loss_scale_manager=scaler)
+    err = None
+    try:
+        net = mp.init_synthetic(mp.create_network("hrnet_w32", "hrnet_head"), seed=0).to(dev).train()
+        mp.models.auto_mixed_precision(net, "O2")
+        scaler = DynamicLossScaleManager()
+        nwl = mp.create_network_with_loss(net, mp.create_loss("joint_mse", use_target_weight=True), has_extra_inputs=True)
+        tgt = mp.TopDownGenerateTarget(config=dict(image_size=[192, 256], heatmap_size=[48, 64]), sigma=2.0)
+        gen = torch.Generator(device="cpu").manual_seed(2000 + rank)
+        image = torch.randn(n, 3, 256, 192, generator=gen).to(dev)
+        kp = torch.empty(n, 17, 3)
+        kp[..., 0] = torch.rand(n, 17, generator=gen) * 232 - 20
+        kp[..., 1] = torch.rand(n, 17, generator=gen) * 296 - 20
+        kp[..., 2] = (torch.rand(n, 17, generator=gen) < 0.7).float()
+        kp = kp.to(dev)
+        t0, w0 = tgt(kp)
+    except Exception as exc:
+        err = f"build phase A, rank {rank}: {type(exc).__name__}: {exc}"
+    if not all_ranks_ok(dist, dev, err is None):
+        return {"error": err or "another rank failed in build phase A"}
+    opt = gstep = None
+    try:
+        opt = AdamWeightDecay(net, lr=1e-3, weight_decay=0.05, filter_bias_and_bn=True, overlap=False)
+        # the tuner never communicates: rank 0 builds (and tunes) first, its choices reach the other ranks in ONE broadcast, then they
+        # build on cache hits - the warm-up passes and the capture inside GraphedTrainStep contain no collective
+        gstep = mp.models.tune_on_rank0_first(lambda: GraphedTrainStep(nwl, opt, (image, t0, w0), loss_scale_manager=scaler))
+    except Exception as exc:
+        err = f"build phase B, rank {rank}: {type(exc).__name__}: {exc}"
+    if not all_ranks_ok(dist, dev, err is None):
+        if opt is not None:
+            opt.close()
+        return {"error": err or "another rank failed in build phase B"}
 
     def step():
         target, weight = tgt(kp)
@@ -822,7 +850,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    log(f"rank {rank}: plan built ({len(net.get_plan((n, 3, ih, iw), dev))} launches), warming up")
+    plan_len = mp.models.tune_on_rank0_first(lambda: len(net.get_plan((n, 3, ih, iw), dev)))  # rank 0 tunes, one broadcast, the rest replay
+    log(f"rank {rank}: plan built ({plan_len} launches), warming up")
     for _ in range(args.warmup):
         step()
     sync_all()
@@ -868,8 +897,8 @@ def main():
         # region (the inference path itself has no data-path collective)
         try:
             leg = dp_train_leg(args, mp, dev, dist, world, rank)
-        except Exception as exc:  # never take the headline line down (every rank fails or none: the leg's collectives are symmetric)
-            leg = {"error": f"{type(exc).__name__}: {exc}"}
+        except Exception as exc:  # never take the headline line down; build failures of ONE rank are agreed on inside the leg
+            leg = {"error": f"{type(exc).__name__}: {exc}"}  # (all_ranks_ok), so no rank enters the timed collectives alone
         if rank == 0:
             result.setdefault("extra_workloads", {})["config3_train_ampO2_dp"] = leg
     if dist is not None:

@@ -68,8 +68,11 @@ enum ConvF16Variant { F_CT32_PT192 = 0, F_CT64_PT192 = 1, F_CT48_PT192 = 2, F_CT
                       // _W<n>: n waves split the pixel tiles (4 / n split the couts); no suffix = 1
                       F_WREG_P6C2 = 25, F_WREG_P3C2 = 26, F_WREG_P6C1 = 27, F_WREG_P6C3 = 28, F_WREG_P3C3 = 29, F_WREG_P3C4 = 30,
                       F_WREG_P6C2_W2 = 31, F_WREG_P6C3_W2 = 32, F_WREG_P3C2_W2 = 33, F_WREG_P6C2_W4 = 34, F_WREG_P6C3_W4 = 35,
-                      F_WREG_P3C2_W4 = 36, F_COUNT = 37 };
+                      F_WREG_P3C2_W4 = 36,
+                      // weight-stationary persistent kernel (conv_f16_ws.hip): shapes in kWsShapes
+                      F_WS_BASE = 37, F_WS_COUNT = 8, F_COUNT = 45 };
 inline bool f16_variant_wreg(int v) { return v >= F_WREG_P6C2 && v <= F_WREG_P3C2_W4; }
+inline bool f16_variant_ws(int v) { return v >= F_WS_BASE && v < F_WS_BASE + F_WS_COUNT; }
 inline bool f16_variant_mt(int v) { return (v >= F_MT2_BASE && v < F_CT16_PT192) || v == F_CT16_PT192_MT2 || v == F_CT16_PT192_MT1; }
 inline int f16_variant_mt_occ(int v) { return (v >= F_MT1_BASE && v < F_CT16_PT192) || v == F_CT16_PT192_MT1 ? 1 : 2; }
 bool f16_variant_light(int v);
@@ -118,5 +121,8 @@ bool f16_configure_wreg(const mp_conv_desc& d, int variant, ConvF16Launch& L);
 int f16_wreg_launch(const ConvF16Launch& L, hipStream_t s);
 void f16_wreg_dims(int v, int& ps, int& csw, int& waves_p);
 int f16_mt_ni(int occ);
+bool f16_configure_ws(const mp_conv_desc& d, int variant, ConvF16Launch& L);
+int f16_ws_launch(const ConvF16Launch& L, hipStream_t s);
+void f16_ws_dims(int v, int& ps, int& csw, int& waves_p);
 
 }  // namespace mp

@@ -496,6 +496,7 @@ bool f16_configure_mt(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
 }
 
 bool f16_configure(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
+    if (f16_variant_ws(variant)) return f16_configure_ws(d, variant, L);
     if (f16_variant_wreg(variant)) return f16_configure_wreg(d, variant, L);
     if (f16_variant_mt(variant)) return f16_configure_mt(d, variant, L);
     int CT, PT;
@@ -790,9 +791,10 @@ int grid_for(size_t total) {
 void f16_variant_dims(int v, int& ct, int& pt) {
     static const int cts[5] = {32, 64, 48, 64, 32};
     static const int pts[5] = {192, 192, 192, 96, 96};
-    if (f16_variant_wreg(v)) {
+    if (f16_variant_wreg(v) || f16_variant_ws(v)) {
         int ps, csw, wp;
-        f16_wreg_dims(v, ps, csw, wp);
+        if (f16_variant_ws(v)) f16_ws_dims(v, ps, csw, wp);
+        else f16_wreg_dims(v, ps, csw, wp);
         ct = 16 * csw * (4 / wp);
         pt = 16 * ps * wp;
         return;
@@ -816,7 +818,8 @@ int f16_build_launch(const mp_conv_desc* desc, int variant, const void* x, const
     const bool phases4 = (desc->flags & MP_CONV_PHASES4) != 0;
     if (phases4 && (res1 || res2)) return MP_ERR_UNSUPPORTED;
     if (variant >= 0) {
-        if (f16_variant_wreg(variant) && phases4) return MP_ERR_UNSUPPORTED;  // one-tile / multi-tile kernels only
+        if ((f16_variant_wreg(variant) || f16_variant_ws(variant)) && phases4) return MP_ERR_UNSUPPORTED;  // one-tile / multi-tile kernels only
+        if (f16_variant_ws(variant) && res2) return MP_ERR_UNSUPPORTED;
         if (f16_variant_wreg(variant) && res2 && desc->stride != 2) return MP_ERR_UNSUPPORTED;  // second residual: stride-2 builds only
         ok = f16_configure(*desc, variant, L);
     } else {
@@ -849,10 +852,11 @@ int f16_build_launch(const mp_conv_desc* desc, int variant, const void* x, const
 
 int f16_stats_parts(const ConvF16Launch& L) {
     // tile / weights-in-registers kernels: one slot per pixel tile; persistent multi-tile kernel: one per workgroup run; per phase
-    return (f16_variant_mt(L.variant) ? L.p.n_groups : L.p.tiles_y * L.p.tiles_n) * (L.p.phases > 1 ? L.p.phases : 1);
+    return ((f16_variant_mt(L.variant) || f16_variant_ws(L.variant)) ? L.p.n_groups : L.p.tiles_y * L.p.tiles_n) * (L.p.phases > 1 ? L.p.phases : 1);
 }
 
 int f16_launch(const ConvF16Launch& L, hipStream_t s) {
+    if (f16_variant_ws(L.variant)) return f16_ws_launch(L, s);
     if (f16_variant_wreg(L.variant)) return f16_wreg_launch(L, s);
     if (f16_variant_mt(L.variant)) return f16_mt_launch(L, s);
     if (L.ks == 1) return L.stride == 1 ? launch_f16_ks<1, 1>(L.p, L.variant, L.lds_bytes, s) : launch_f16_ks<1, 2>(L.p, L.variant, L.lds_bytes, s);

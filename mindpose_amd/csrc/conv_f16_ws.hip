@@ -1,0 +1,458 @@
+// fp16-MFMA 3x3 stride-1 convolution, WEIGHT-STATIONARY persistent form (round 4) - the HRNet branch convs with 32 - 128 channels
+// (hrnet.py:30-83 BasicBlock, :202-241 branches; W48 cfg :670-718).
+//
+// Why another structure: round-3 counters of the weights-in-registers kernel (conv_f16_wreg.hip) on W48's 96 -> 96 @48x36 layer -
+// a wave lives 18.7 k cycles for 2.6 k cycles of MFMA, issues ~1000 VALU instructions for its 162 MFMAs (slot decoding, offsets,
+// descriptors: all per short-lived workgroup), and every workgroup re-streams its weight slice through the CU's vector-memory path
+// (43 - 85 of 64 B/clk).  Here a workgroup lives for the whole launch:
+//   * ONE workgroup per CU (256 threads, one wave per SIMD, up to 512 registers per lane).  The wave's weight fragments - ALL k of
+//     its CSW cout tiles: NQ k-steps x 9 taps x CSW x 16 B per lane = 72 NQ CSW registers - are loaded ONCE and stay in registers:
+//     in steady state there is no weight traffic at all and no per-tile weight prologue;
+//   * pixel tiles (R full-width rows of one image, all input channels) stream through a TWO-stage LDS ring filled by LDS-DMA
+//     (buffer_load ... lds): tile t + 1 flies while tile t is on the matrix pipe; what a DMA piece maps to (plane, row, column) is
+//     decoded once per kernel, a tile only adds its row origin, and rows outside the image / the halo column arrive as zeros through
+//     the range check of a PER-PLANE buffer descriptor (no compare per piece);
+//   * every B fragment (one ds_read_b128) feeds CSW >= 2 MFMAs, so the LDS read rate stays <= 128 B/clk per CU;
+//   * ONE barrier per tile; the tile's stores drain under the next tile (counted vmcnt: the DMA pieces are older than the stores).
+// Same operand mapping, k order (k-steps ascending, taps ascending) and epilogue arithmetic as conv_f16_kernel / conv_f16_wreg_kernel:
+// outputs are bit-identical to those (tests/test_gpu_f16.py).  Cout slices (n_ct > 1) re-read the input tile from L2.
+// LDS image of a tile: [plane][row][W + 1] 16-byte elements, plane pitch a multiple of 64 elements (a DMA piece never straddles
+// planes): one zero column between rows is the right halo of row r and the left halo of row r + 1.
+#include <type_traits>
+
+#include "conv_f16.h"
+#include "conv_f16_dev.h"
+
+namespace mp {
+
+namespace {
+
+constexpr int kWsMaxPieces = 8;  // DMA pieces (64 x 16 B) per plane: f16_configure_ws admits no more
+constexpr int kWsAgprFrags = 62;  // weight fragments held in the accumulator half of the register file (4 AGPRs each; 256 - slack)
+
+// The MFMA as inline assembly: hipcc keeps MFMA source operands in VGPRs and uses AGPRs only as spill space (a 324-register weight set
+// then costs four v_accvgpr_read per MFMA and the spill traffic wrecks the operand prefetch - the first build of this kernel waited
+// lgkmcnt(0) right behind every ds_read).  The hardware takes the A operand from an AGPR tuple directly; as an asm operand of class
+// "a" the fragment is loaded into AGPRs (buffer_load ... a[..]) and stays there.  Hazards inside these statements: back-to-back MFMAs
+// on independent accumulators need no wait states, the same-accumulator chain (SrcC = vDst of the previous one) needs none either; the
+// epilogue's first VALU read of an accumulator sits behind mfma_results_ready().
+__device__ __forceinline__ void mfma_a(f32x4& acc, const u32x4& a, const u32x4& b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_v(f32x4& acc, const u32x4& a, const u32x4& b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_a0(f32x4& acc, const u32x4& a, const u32x4& b) {  // first MFMA of a chain: C = 0
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_v0(f32x4& acc, const u32x4& a, const u32x4& b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void load_a(u32x4& dst, unsigned voff, const u32x4& rsrc) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=a"(dst) : "v"(voff), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ void load_v(u32x4& dst, unsigned voff, const u32x4& rsrc) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rsrc) : "memory");
+}
+
+template <int NQ, int CSW, int WAVES_P, int PS, int OCC, int STATS>
+__global__ __launch_bounds__(256, OCC) void conv_f16_ws_kernel(const ConvF16Params p) {
+    constexpr int T = 9;
+    constexpr int WAVES_C = 4 / WAVES_P;
+    constexpr int CT = 16 * CSW * WAVES_C;  // couts per workgroup
+    constexpr int NP = CSW / 2, NS = CSW - 2 * NP;
+    constexpr int NST = PS * (NP + NS);  // stores per tile and wave
+    constexpr int NF = NQ * T * CSW;     // weight fragments of a wave
+    constexpr int NFA = NF < kWsAgprFrags ? NF : kWsAgprFrags, NFV = NF - NFA;
+    extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
+    u32x4* __restrict__ lds_in = smem16;  // [2][PK][plane]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp_i = wave % WAVES_P, wc_i = wave / WAVES_P;
+    const int lq = lane >> 4, lr = lane & 15;
+
+    int b = blockIdx.x;
+    {
+        const int nb = p.total_blocks, q8 = nb >> 3, r8 = nb & 7, xcd = b & 7, j = b >> 3;
+        b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
+    }
+    const int ct = b % p.n_ct;  // the cout slices of one tile run sit next to each other: they share the input through one L2
+    const int grp = b / p.n_ct;
+    const int t_begin = grp * p.tiles_per_wg, t_end = min(t_begin + p.tiles_per_wg, p.tiles_total);
+    const int HW = p.H * p.W;
+    const int P = p.Wp;  // row pitch W + 1
+    const int buf_elems = p.in_buf;
+    const unsigned plane_bytes = (unsigned)HW * 16u;
+
+    // ---- LDS-DMA.  Wave w stages planes w, w + 4, ...; piece s of a plane covers its slots 64 s ...: the slot -> (row, column) map
+    //      is the same for every plane and tile, decoded once
+    const int ppp = p.upc;  // pieces per plane
+    unsigned piece_rel[kWsMaxPieces];  // byte offset inside the image plane relative to the tile's first staged row; kOob = zero slot
+#pragma unroll
+    for (int s = 0; s < kWsMaxPieces; ++s) {
+        const unsigned slot = (unsigned)(s * 64 + lane);
+        const unsigned r = __umulhi(slot, p.magic_ncols);  // / (W + 1), W >= 1
+        const int c = (int)(slot - r * P) - 1;
+        piece_rel[s] = (slot < (unsigned)p.img_plane && c >= 0) ? (r * p.W + c) * 16u : kOob;
+    }
+    auto tile_pos = [&](int t, int& n, int& y0) {
+        n = p.tiles_y == 1 ? t : (int)__umulhi((unsigned)t, p.magic_rows);
+        y0 = (t - n * p.tiles_y) * p.R;
+    };
+    auto dma_tile = [&](int t, int buf) {
+        int n, y0;
+        tile_pos(t, n, y0);
+        const unsigned row_off = (unsigned)((y0 - 1) * p.W * 16);  // first staged row = y0 - 1 (-1: wraps out of range)
+        const char* img = reinterpret_cast<const char*>(p.x) + (size_t)n * p.C8in * plane_bytes;
+        u32x4* dst = lds_in + buf * buf_elems;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int pl = wave + 4 * j;
+            if (pl >= p.C8in) break;  // wave-uniform
+            // descriptor of image plane (n, pl) alone: rows above / below the image fall outside it and arrive as zeros
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(img + pl * plane_bytes, plane_bytes);
+#pragma unroll
+            for (int s = 0; s < kWsMaxPieces; ++s) {
+                if (s >= ppp) break;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + pl * p.plane + s * 64), 16,
+                                                         piece_rel[s] + row_off, 0, 0, 0);
+            }
+        }
+    };
+    if (t_begin < t_end) dma_tile(t_begin, 0);  // flies under the weight loads
+
+    // ---- weight operand: ALL k of this wave's couts, from the packed weights [kq][T][4][Cout_pad16] x 16 B, for the kernel's life:
+    //      fragment f = (q * T + t) * CSW + cs; the first NFA in AGPR tuples, the rest in VGPRs
+    u32x4 Aa[NFA], Av[NFV ? NFV : 1];
+    {
+        u32x4 rs_w;
+        const size_t w_bytes = (size_t)NQ * T * 4 * p.Cout_pad16 * 16;
+        rs_w.x = __builtin_amdgcn_readfirstlane((unsigned)(size_t)p.wp);
+        rs_w.y = __builtin_amdgcn_readfirstlane((unsigned)((size_t)p.wp >> 32)) & 0xFFFFu;
+        rs_w.z = __builtin_amdgcn_readfirstlane((unsigned)w_bytes);
+        rs_w.w = 0x00020000u;
+        const unsigned tap_bytes = 4u * p.Cout_pad16 * 16u;
+        unsigned goff[CSW];
+#pragma unroll
+        for (int cs = 0; cs < CSW; ++cs) {
+            const int co = ct * CT + wc_i * CSW * 16 + f16_a_row<CSW>(cs, lr);  // < Cout_pad16: every wave owns real cout tiles
+            goff[cs] = (unsigned)(lq * p.Cout_pad16 + co) * 16u;
+        }
+        asm volatile("s_nop 4" ::: "memory");  // v_readfirstlane -> descriptor read by the first load
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const unsigned off = goff[f % CSW] + (unsigned)(f / CSW) * tap_bytes;
+            if (f < NFA) load_a(Aa[f], off, rs_w);
+            else load_v(Av[f - NFA], off, rs_w);
+        }
+    }
+    // the zero planes behind the last channel block (Cin not a multiple of 32) are never staged: cleared once, in both buffers
+    {
+        const int pad0 = p.C8in * p.plane, padn = (p.PK - p.C8in) * p.plane;
+        const u32x4 zero = (u32x4){0u, 0u, 0u, 0u};
+        for (int i = tid; i < padn; i += 256) {
+            lds_in[pad0 + i] = zero;
+            lds_in[buf_elems + pad0 + i] = zero;
+        }
+    }
+
+    // ---- tile-independent pixel addressing
+    unsigned b_addr[PS];   // byte address (buffer 0) of the pixel's window origin in plane lq
+    unsigned pix_rel[PS];  // output byte offset relative to (image, first row of the tile); kInv = padding lane
+    int y_rel[PS];
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps) {
+        const unsigned pl0 = (unsigned)((wp_i * PS + ps) * 16 + lr);
+        const bool in_tile = pl0 < (unsigned)p.RWo;
+        const unsigned pl = in_tile ? pl0 : 0u;
+        const unsigned y = fastdiv(pl, p.W, p.magic_wo);
+        const unsigned xx = pl - y * p.W;
+        b_addr[ps] = (unsigned)(lq * p.plane + y * P + xx) * 16u;
+        pix_rel[ps] = in_tile ? (y * p.W + xx) * 16u : kInv;
+        y_rel[ps] = (int)y;
+    }
+    f32x4 sc[CSW], sh[CSW];
+    unsigned co_off[CSW];
+#pragma unroll
+    for (int cs = 0; cs < CSW; ++cs) {
+        const int co = ct * CT + wc_i * CSW * 16 + f16_d_cout<CSW>(cs, lq);
+        const bool ok = co < p.C8out * 8;
+        const int cc = co < p.Cout_pad16 ? co : 0;
+        sc[cs] = *reinterpret_cast<const f32x4*>(p.scale + cc);
+        sh[cs] = *reinterpret_cast<const f32x4*>(p.shift + cc);
+        co_off[cs] = ok ? (unsigned)(co >> 3) * plane_bytes + ((co >> 2) & 1) * 8u : kInv;
+    }
+    const size_t o_bytes = (size_t)p.N * p.C8out * plane_bytes;
+    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(p.out, o_bytes);
+    const __amdgpu_buffer_rsrc_t rs_r = make_rsrc(p.res1 ? p.res1 : p.out, p.res1 ? o_bytes : 0);  // absent: zero-length, nothing fetched
+    const bool has1 = p.res1 != nullptr;
+
+    f32x4 st_a[STATS ? CSW : 1], st_b[STATS ? CSW : 1];
+    if constexpr (STATS) {
+#pragma unroll
+        for (int cs = 0; cs < CSW; ++cs) st_a[cs] = st_b[cs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first tile and the weight fragments (asm loads: this wait is theirs) have landed
+    __syncthreads();
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int cur = (t - t_begin) & 1;
+        if (t != t_begin) {
+            // tile t's DMA pieces (issued one tile ago) are OLDER than the previous tile's NST stores: all but those have landed
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (NST & 15) | ((NST >> 4) << 14));  // vmcnt(NST)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // ... in every wave, and nobody reads the other buffer any more
+            asm volatile("" ::: "memory");
+        }
+        if (t + 1 < t_end) dma_tile(t + 1, cur ^ 1);
+
+        int n, y0;
+        tile_pos(t, n, y0);
+        const int rows_valid = min(p.R, p.H - y0);
+        const unsigned tile_o = (unsigned)n * p.C8out * plane_bytes + (unsigned)(y0 * p.W * 16);
+        unsigned pix_off[PS];
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps) pix_off[ps] = y_rel[ps] < rows_valid ? tile_o + pix_rel[ps] : kInv;
+
+        f32x4 acc[PS][CSW];
+        const char* lbase = reinterpret_cast<const char*>(lds_in + cur * buf_elems);
+        u32x4 bv[PS];
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps) bv[ps] = *reinterpret_cast<const u32x4*>(lbase + b_addr[ps]);
+
+        u32x4 r1p[NP ? NP : 1][PS];
+        u32x2 r1s[PS];
+        u32x4 zp[(STATS == 2 && NP) ? NP : 1][PS], yp[(STATS == 2 && NP) ? NP : 1][PS];
+        u32x2 zs[PS], ys[PS];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (q == NQ - 1) {
+                // residual tensor (and, backward statistics, the BatchNorm's z / y): requested ahead of the last k-step
+#pragma unroll
+                for (int j = 0; j < NP; ++j)
+#pragma unroll
+                    for (int ps = 0; ps < PS; ++ps) r1p[j][ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, co_off[2 * j] + pix_off[ps], 0, 0);
+                if (NS) {
+#pragma unroll
+                    for (int ps = 0; ps < PS; ++ps) r1s[ps] = __builtin_amdgcn_raw_buffer_load_b64(rs_r, co_off[CSW - 1] + pix_off[ps], 0, 0);
+                }
+                if constexpr (STATS == 2) {
+                    const __amdgpu_buffer_rsrc_t rz = make_rsrc(p.st_z, o_bytes);
+                    const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.st_y ? p.st_y : p.st_z, p.st_y ? o_bytes : 0);
+#pragma unroll
+                    for (int j = 0; j < NP; ++j)
+#pragma unroll
+                        for (int ps = 0; ps < PS; ++ps) {
+                            zp[j][ps] = __builtin_amdgcn_raw_buffer_load_b128(rz, co_off[2 * j] + pix_off[ps], 0, 0);
+                            yp[j][ps] = __builtin_amdgcn_raw_buffer_load_b128(ry, co_off[2 * j] + pix_off[ps], 0, 0);
+                        }
+                    if (NS) {
+#pragma unroll
+                        for (int ps = 0; ps < PS; ++ps) {
+                            zs[ps] = __builtin_amdgcn_raw_buffer_load_b64(rz, co_off[CSW - 1] + pix_off[ps], 0, 0);
+                            ys[ps] = __builtin_amdgcn_raw_buffer_load_b64(ry, co_off[CSW - 1] + pix_off[ps], 0, 0);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int tp = 0; tp < T; ++tp) {
+                // pixel operands of the NEXT tap are requested (one ds_read_b128 each) between this tap's MFMAs; the final prefetch
+                // re-reads the first position (discarded).  The asm MFMAs are ordered statements: source order is issue order
+                const bool first = q == 0 && tp == 0, last = q == NQ - 1 && tp == T - 1;
+                const int qn = last ? 0 : (tp + 1 < T ? q : q + 1), tn = last ? 0 : (tp + 1 < T ? tp + 1 : 0);
+                const unsigned off_n = (unsigned)(qn * 4 * p.plane + (tn / 3) * P + (tn % 3)) * 16u;
+                u32x4 bn[PS];
+#pragma unroll
+                for (int ps = 0; ps < PS; ++ps) {
+                    bn[ps] = *reinterpret_cast<const u32x4*>(lbase + b_addr[ps] + off_n);
+#pragma unroll
+                    for (int cs = 0; cs < CSW; ++cs) {
+                        constexpr int dummy = 0;
+                        (void)dummy;
+                        const int f = (q * T + tp) * CSW + cs;
+                        if (f < NFA) {
+                            if (first) mfma_a0(acc[ps][cs], Aa[f < NFA ? f : 0], bv[ps]);
+                            else mfma_a(acc[ps][cs], Aa[f < NFA ? f : 0], bv[ps]);
+                        } else {
+                            if (first) mfma_v0(acc[ps][cs], Av[f >= NFA ? f - NFA : 0], bv[ps]);
+                            else mfma_v(acc[ps][cs], Av[f >= NFA ? f - NFA : 0], bv[ps]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int ps = 0; ps < PS; ++ps) bv[ps] = bn[ps];
+            }
+        }
+        // MFMA result -> first VALU read: 4-pass XDL op needs its passes to drain (hipcc pads nothing behind an asm statement)
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+
+        // ---- epilogue: scale / shift, residual, ReLU, one rounding, 16-byte stores per cout-tile pair
+        const u32x2 none = (u32x2){0u, 0u};
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps) {
+                const u32x4 a1 = has1 ? r1p[j][ps] : (u32x4){0u, 0u, 0u, 0u};
+                u32x2 lo = f16_pack4(f16_epi4(acc[ps][2 * j], sc[2 * j], sh[2 * j], has1, (u32x2){a1.x, a1.y}, false, none, p.relu));
+                u32x2 hi = f16_pack4(f16_epi4(acc[ps][2 * j + 1], sc[2 * j + 1], sh[2 * j + 1], has1, (u32x2){a1.z, a1.w}, false, none, p.relu));
+                if constexpr (STATS) {
+                    const bool valid = pix_off[ps] != kInv;
+                    if constexpr (STATS == 2) {
+                        const u32x4 zq = zp[j][ps], yq = yp[j][ps];
+                        f16_stats_acc<2>(lo, valid, st_a[2 * j], st_b[2 * j], (u32x2){zq.x, zq.y}, (u32x2){yq.x, yq.y}, p.st_relu);
+                        f16_stats_acc<2>(hi, valid, st_a[2 * j + 1], st_b[2 * j + 1], (u32x2){zq.z, zq.w}, (u32x2){yq.z, yq.w}, p.st_relu);
+                    } else {
+                        f16_stats_acc<1>(lo, valid, st_a[2 * j], st_b[2 * j], lo, lo, 0);
+                        f16_stats_acc<1>(hi, valid, st_a[2 * j + 1], st_b[2 * j + 1], hi, hi, 0);
+                    }
+                }
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){lo.x, lo.y, hi.x, hi.y}, rs_o, co_off[2 * j] + pix_off[ps], 0, 0);
+            }
+        if (NS) {
+#pragma unroll
+            for (int ps = 0; ps < PS; ++ps) {
+                u32x2 o = f16_pack4(f16_epi4(acc[ps][CSW - 1], sc[CSW - 1], sh[CSW - 1], has1, has1 ? r1s[ps] : none, false, none, p.relu));
+                if constexpr (STATS) {
+                    const bool valid = pix_off[ps] != kInv;
+                    if constexpr (STATS == 2) f16_stats_acc<2>(o, valid, st_a[CSW - 1], st_b[CSW - 1], zs[ps], ys[ps], p.st_relu);
+                    else f16_stats_acc<1>(o, valid, st_a[CSW - 1], st_b[CSW - 1], o, o, 0);
+                }
+                __builtin_amdgcn_raw_buffer_store_b64(o, rs_o, co_off[CSW - 1] + pix_off[ps], 0, 0);
+            }
+        }
+    }
+    if constexpr (STATS)
+        f16_stats_flush<CSW, WAVES_P, WAVES_C>(st_a, st_b, reinterpret_cast<float*>(smem16), p.st_part, p.st_nparts, grp, ct * CT, p.C8out,
+                                               wp_i, wc_i, lq, lr);
+}
+
+template <int NQ, int CSW, int WAVES_P, int PS, int OCC, int STATS>
+int launch_ws_kernel(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
+    auto kern = conv_f16_ws_kernel<NQ, CSW, WAVES_P, PS, OCC, STATS>;
+    static AttrOnce attr_set_once;
+    if (attr_set_once.need()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+    }
+    hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(256), lds_bytes, s, p);
+    return check_launch();
+}
+
+template <int NQ, int CSW, int WAVES_P, int PS, int OCC>
+int launch_ws(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
+    if (p.st_mode == 1) return launch_ws_kernel<NQ, CSW, WAVES_P, PS, OCC, 1>(p, lds_bytes, s);
+    if (p.st_mode == 2) return launch_ws_kernel<NQ, CSW, WAVES_P, PS, OCC, 2>(p, lds_bytes, s);
+    return launch_ws_kernel<NQ, CSW, WAVES_P, PS, OCC, 0>(p, lds_bytes, s);
+}
+
+struct WsShape { int nq, csw, waves_p, ps, occ; };
+// F_WS_BASE + i.  nq = k-steps of 32 input channels (Cin in (32 (nq - 1), 32 nq]); a workgroup = 16 csw (4 / waves_p) couts x
+// 16 ps waves_p pixels
+constexpr WsShape kWsShapes[F_WS_COUNT] = {
+    {1, 2, 4, 3, 2},  // 32 channels: 32 couts x 192 px (training convs of the 32-channel branch; inference runs them as fused blocks)
+    {2, 3, 4, 5, 1},  // 48 (W48 branch 1): 48 couts x 320 px
+    {2, 4, 4, 3, 1},  // 64: 64 couts x 192 px
+    {2, 2, 4, 3, 1},  // 64: two cout slices of 32 x 192 px
+    {3, 3, 2, 4, 1},  // 96 (W48 branch 2): 96 couts x 128 px
+    {3, 3, 4, 3, 1},  // 96: two cout slices of 48 x 192 px
+    {4, 2, 2, 3, 1},  // 128: two cout slices of 64 x 96 px
+    {4, 2, 1, 6, 1},  // 128: 128 couts x 96 px
+};
+
+}  // namespace
+
+void f16_ws_dims(int v, int& ps, int& csw, int& waves_p) {
+    const WsShape& s = kWsShapes[v - F_WS_BASE];
+    ps = s.ps; csw = s.csw; waves_p = s.waves_p;
+}
+
+// geometry: 3x3 stride-1 pad-1 convolutions with a plain output mapping whose rows tile the pixel tile
+bool f16_configure_ws(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
+    const WsShape& sh = kWsShapes[variant - F_WS_BASE];
+    if (d.kh != 3 || d.kw != 3 || d.stride != 1 || d.pad_top != 1 || d.pad_left != 1) return false;
+    if (d.conv_h != d.h || d.conv_w != d.w || d.out_h != d.h || d.out_w != d.w || d.out_mul != 1 || d.out_off_y != 0 || d.out_off_x != 0) return false;
+    if (d.cin <= 32 * (sh.nq - 1) || d.cin > 32 * sh.nq) return false;
+    ConvF16Params& p = L.p;
+    const int WC = 4 / sh.waves_p;
+    const int PT = 16 * sh.ps * sh.waves_p, CT = 16 * sh.csw * WC;
+    p.N = d.n; p.H = d.h; p.W = d.w; p.Cout = d.cout;
+    p.C8in = (d.cin + 7) / 8;
+    p.Cout_pad16 = round_up(d.cout, 16);
+    p.C8out = (d.cout + 7) / 8;
+    p.Ho = d.h; p.Wo = d.w; p.pad_t = 1; p.pad_l = 1;
+    if ((long long)d.n * p.C8in * d.h * d.w * 16 >= 0x7FFFFFF0LL || (long long)d.n * p.C8out * d.h * d.w * 16 >= 0x60000000LL) return false;
+    if (p.Cout_pad16 % CT != 0) return false;  // every wave of every workgroup owns CSW real cout tiles
+    p.PK = sh.nq * 4;
+    p.PKs = p.C8in;
+    p.n_chunks = 1;
+    if (p.W > PT) return false;
+    p.n_ct = p.Cout_pad16 / CT;
+    int groups = sh.occ * 256 / p.n_ct;  // workgroups per cout slice, all resident at once
+    if (const char* e = knob("MP_F16_WS_GROUPS")) {  // tests: force long tile runs on small problems
+        const int v = atoi(e);
+        if (v >= 1) groups = v;
+    }
+    if (groups < 1) return false;
+    const int r_max = PT / p.W < p.H ? PT / p.W : p.H;
+    // rows per tile: the fewest tiles per workgroup win (every tile costs the same MFMA time, padding lanes included), then the taller
+    int best_r = 0, best_tpw = 0;
+    for (int R = r_max; R >= 1 && R >= r_max - 3; --R) {
+        if (R * p.W * 10 < PT * 7) break;  // more than 30 % padding lanes
+        const int plane = round_up((R + 2) * (p.W + 1) + 1, 64);
+        if ((size_t)2 * p.PK * plane * 16 > (size_t)(sh.occ == 1 ? 156 : 78) * 1024) continue;
+        if (plane / 64 > kWsMaxPieces) continue;
+        const int tiles = ((p.H + R - 1) / R) * p.N;
+        const int tpw = (tiles + groups - 1) / groups;
+        if (best_r == 0 || tpw < best_tpw) { best_r = R; best_tpw = tpw; }
+    }
+    if (best_r == 0) return false;
+    p.R = best_r;
+    p.G = 1;
+    p.RWo = p.R * p.W;
+    p.Rin = p.R + 2;
+    p.Wp = p.W + 1;
+    p.img_plane = p.Rin * p.Wp;
+    p.plane = round_up(p.img_plane + 1, 64);
+    p.upc = p.plane / 64;  // DMA pieces per plane
+    p.ncols = p.W;
+    p.in_buf = p.PK * p.plane;
+    p.w_buf = 0;
+    p.nbuf = 2;
+    p.tiles_y = (p.H + p.R - 1) / p.R;
+    p.tiles_n = p.N;
+    p.tiles_total = p.tiles_y * p.N;
+    p.tiles_per_wg = (p.tiles_total + groups - 1) / groups;
+    // a run of ONE tile amortises nothing (the weight fragments would be fetched per tile, as the one-tile kernels do with less LDS)
+    if (p.tiles_per_wg < 2) return false;
+    p.n_groups = (p.tiles_total + p.tiles_per_wg - 1) / p.tiles_per_wg;
+    p.total_blocks = p.n_ct * p.n_groups;
+    p.relu = d.relu;
+    p.out_h = d.out_h; p.out_w = d.out_w; p.out_mul = 1; p.off_y = 0; p.off_x = 0;
+    p.magic_ncols = magic_of((unsigned)p.Wp);      // slot -> row
+    p.magic_wo = magic_of((unsigned)p.W);          // pixel -> row
+    p.magic_rows = magic_of((unsigned)p.tiles_y);  // tile -> image
+    p.magic_rin = p.magic_rwo = 0;
+    p.ni_used = p.nw_used = 0;
+    L.ks = 3; L.stride = 1; L.variant = variant;
+    L.lds_bytes = (size_t)2 * p.in_buf * 16;
+    return true;
+}
+
+int f16_ws_launch(const ConvF16Launch& L, hipStream_t s) {
+    switch (L.variant - F_WS_BASE) {
+        case 0: return launch_ws<1, 2, 4, 3, 2>(L.p, L.lds_bytes, s);
+        case 1: return launch_ws<2, 3, 4, 5, 1>(L.p, L.lds_bytes, s);
+        case 2: return launch_ws<2, 4, 4, 3, 1>(L.p, L.lds_bytes, s);
+        case 3: return launch_ws<2, 2, 4, 3, 1>(L.p, L.lds_bytes, s);
+        case 4: return launch_ws<3, 3, 2, 4, 1>(L.p, L.lds_bytes, s);
+        case 5: return launch_ws<3, 3, 4, 3, 1>(L.p, L.lds_bytes, s);
+        case 6: return launch_ws<4, 2, 2, 3, 1>(L.p, L.lds_bytes, s);
+        case 7: return launch_ws<4, 2, 1, 6, 1>(L.p, L.lds_bytes, s);
+        default: return MP_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace mp

@@ -14,7 +14,7 @@ import torch.nn as nn
 from .. import _lib
 
 BN_EPS = 1e-5  # mindspore.nn.BatchNorm2d default eps
-F16_VARIANTS = 37  # csrc/conv_f16.h F_COUNT: tile shapes the fp16 autotuner times per launch shape
+F16_VARIANTS = 45  # csrc/conv_f16.h F_COUNT: tile shapes the fp16 autotuner times per launch shape
 
 
 class Conv2d(nn.Module):
@@ -117,19 +117,43 @@ def _dist_rank_world():
     return 0, 1
 
 
-def _sync_choice(choice: int) -> int:
-    """Ranks of one job must run the SAME form of every layer (the candidates differ numerically: Winograd vs direct, one GEMM
-    launch vs four phase convs) - rank 0's choice, tuned or read from its cache, is broadcast and every rank adopts it.  All ranks
-    build the same network, so they reach this point for the same keys in the same order.  ``MINDPOSE_TUNE_SYNC=0`` turns the
-    broadcast off (ranks that build different plans)."""
+def share_tuner_choices(group=None) -> int:
+    """THE collective of the tuner, at a point the CALLER chooses: rank 0's whole choice table is broadcast once
+    (``broadcast_object_list``) and every other rank adopts it, so that the ranks of one job run the same numeric form of every
+    layer (the fp32 candidates differ numerically: Winograd vs direct, one GEMM launch vs four phase convs).  Every rank of
+    ``group`` must call it, at the same point of its program - e.g. right after rank 0's warm-up (`tune_on_rank0_first`).  The
+    tuner itself never communicates: a plan that only one rank builds (EvalCallback's rank-0 evaluation, a no-grad probe) can
+    therefore never strand or cross-match a collective.  Returns the number of choices adopted (0 on rank 0 / one rank)."""
     rank, world = _dist_rank_world()
-    if world == 1 or os.environ.get("MINDPOSE_TUNE_SYNC", "1") == "0":
-        return choice
+    if world == 1:
+        return 0
     import torch.distributed as dist
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    t = torch.tensor([int(choice)], dtype=torch.int64, device=dev)
-    dist.broadcast(t, src=0)
-    return int(t.item())
+    box = [{k: v for k, v in _TUNE_CACHE.items() if isinstance(k, str)} if rank == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    if rank == 0:
+        return 0
+    _TUNE_CACHE.update(box[0])
+    return len(box[0])
+
+
+def tune_on_rank0_first(build, group=None):
+    """``build()`` - anything that records plans / runs warm-up passes and contains NO collective - on rank 0 first (it tunes),
+    then `share_tuner_choices`, then on the other ranks (every shape is a cache hit: nothing is timed twice, all ranks run rank 0's
+    forms).  One rank: just ``build()``.  Rank 0 reaches the broadcast even when its ``build()`` raised (the exception is re-raised
+    behind it), so a failure on rank 0 cannot leave the other ranks waiting."""
+    rank, world = _dist_rank_world()
+    if world == 1:
+        return build()
+    out, failure = None, None
+    if rank == 0:
+        try:
+            out = build()
+        except Exception as exc:  # noqa: BLE001 - re-raised below, after the collective every rank is waiting in
+            failure = exc
+    share_tuner_choices(group)
+    if failure is not None:
+        raise failure
+    return out if rank == 0 else build()
 
 
 def _tune_save() -> None:
@@ -175,12 +199,9 @@ def _autotune(key, macs, n_variants, launch) -> int:
     key = repr(key)
     hit = _TUNE_CACHE.get(key)
     if hit is not None:
-        if macs >= (1 << 26) and ("synced", key) not in _TUNE_CACHE:  # first use in this process: agree with rank 0 (no-op on one rank)
-            hit = _TUNE_CACHE[key] = _sync_choice(hit)
-            _TUNE_CACHE[("synced", key)] = 1
         return hit
     best, best_t = -1, None
-    if macs >= (1 << 26) and _dist_rank_world()[0] == 0:
+    if macs >= (1 << 26):  # a miss is timed on whichever rank meets it - no communication here (share_tuner_choices)
         for v in range(n_variants):
             if launch(v) != 0:
                 continue
@@ -200,9 +221,6 @@ def _autotune(key, macs, n_variants, launch) -> int:
             if log:
                 with open(log, "a") as fh:
                     fh.write(f"{key}\t{v}\t{t:.4f}\n")
-    if macs >= (1 << 26):
-        best = _sync_choice(best)
-        _TUNE_CACHE[("synced", key)] = 1
     _TUNE_CACHE[key] = best
     if macs >= (1 << 26):
         _tune_save()

@@ -193,6 +193,88 @@ def test_conv_f16_wreg_vs_oracle_and_bit_identical_to_tile_kernel(case, variant)
         assert not ((got - ref).abs() > tol).any(), float((got - ref).abs().max())
 
 
+WS_CASES = [
+    # n, cin, cout, k, s, h, w, relu, n_res - 3x3 stride-1 layers of the 32 ... 128-channel branches (W32 and W48 widths), ragged
+    # bands (h not a multiple of the rows per tile), padded channel counts, long tile runs (MP_F16_WS_GROUPS)
+    (5, 32, 32, 3, 1, 64, 48, True, 1),
+    (3, 48, 48, 3, 1, 96, 72, True, 1),
+    (3, 48, 48, 3, 1, 23, 72, True, 0),
+    (6, 64, 64, 3, 1, 32, 24, True, 1),
+    (5, 64, 64, 3, 1, 21, 17, False, 1),
+    (6, 96, 96, 3, 1, 48, 36, True, 1),
+    (4, 96, 96, 3, 1, 11, 36, True, 0),
+    (9, 128, 128, 3, 1, 16, 12, True, 1),
+    (3, 40, 48, 3, 1, 30, 33, True, 1),
+    (3, 72, 96, 3, 1, 19, 20, False, 1),
+    (2, 128, 64, 3, 1, 16, 12, True, 0),
+]
+
+
+@pytest.mark.parametrize("case", WS_CASES)
+@pytest.mark.parametrize("variant", list(range(37, 45)))
+@pytest.mark.parametrize("groups", ["2", "5"])
+def test_conv_f16_weight_stationary_vs_oracle_and_bit_identical_to_tile_kernel(case, variant, groups, monkeypatch):
+    """The persistent weight-stationary kernel (conv_f16_ws.hip: weight fragments in AGPRs / VGPRs for the whole launch, pixel tiles
+    through a two-stage LDS-DMA ring) against the oracle arithmetic and bit for bit against the tile kernels; `groups` workgroups
+    per cout slice force tile runs of several tiles (ring parity, ragged last band, ragged last run)."""
+    monkeypatch.setenv("MP_F16_WS_GROUPS", groups)
+    n, cin, cout, k, s, h, w, relu, n_res = case
+    g = torch.Generator().manual_seed(sum(case[:7]) + 1)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    res = [torch.randn(n, cout, h, w, generator=g) for _ in range(n_res)]
+    xa = _to_c8(x)
+    ra = [_to_c8(r) for r in res] + [None]
+    nb = LIB.mp_f16_packed_weight_bytes(cout, cin, k, k)
+    packed = torch.empty(nb // 2, device=DEV, dtype=torch.float16)
+    _lib.check(LIB.mp_f16_pack_weight(_lib.ptr(wt.to(DEV)), _lib.ptr(packed), cout, cin, k, k, 0, 0, 0, _lib.stream()), "pack")
+    padc = (-cout) % 16
+    sc, sh = torch.cat([scale, torch.zeros(padc)]).to(DEV), torch.cat([shift, torch.zeros(padc)]).to(DEV)
+    d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=k, kw=k, stride=s, pad_top=1, pad_left=1, conv_h=h, conv_w=w,
+                      out_h=h, out_w=w, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=int(relu), flags=0)
+
+    def run(v):
+        out = ActC8(n, cout, h, w, DEV)
+        out.c8_tensor.fill_(float("nan"))  # every element of the output must be written
+        rc = LIB.mp_f16_conv2d_fwd(ctypes.byref(d), v, _lib.ptr(xa), _lib.ptr(packed), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(ra[0]), None,
+                                   _lib.ptr(out), _lib.stream())
+        return rc, out
+
+    rc, out = run(variant)
+    if rc != 0:
+        pytest.skip("shape not covered by this weight-stationary build")
+    rc0, base = run(-1)
+    _lib.check(rc0, "mp_f16_conv2d_fwd")
+    # padding channels of the last block are zero in both; everything else bit for bit
+    assert torch.equal(out.c8_tensor, base.c8_tensor), "weight-stationary kernel differs from the tile kernel"
+    ref = F.conv2d(_h(x), _h(wt), None, stride=s, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    for r in res:
+        ref = ref + _h(r)
+    ref = _h(F.relu(ref) if relu else ref)
+    got = _from_c8(out)
+    tol = ref.abs() * 2.0 ** -9 + 1e-4 * ref.abs().max()
+    assert not ((got - ref).abs() > tol).any(), float((got - ref).abs().max())
+
+
+def test_conv_f16_weight_stationary_rejects_what_it_does_not_cover():
+    t = torch.zeros(1 << 16, device=DEV)
+
+    def rc(v, **kw):
+        base = dict(n=8, cin=64, h=32, w=24, cout=64, kh=3, kw=3, stride=1, pad_top=1, pad_left=1, conv_h=32, conv_w=24, out_h=32,
+                    out_w=24, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=0, flags=0)
+        base.update(kw)
+        d = _lib.ConvDesc(**base)
+        return LIB.mp_f16_conv2d_fwd(ctypes.byref(d), v, _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), None, None, _lib.ptr(t), _lib.stream())
+
+    assert rc(39, stride=2, conv_h=16, conv_w=12, out_h=16, out_w=12) != 0            # stride 2
+    assert rc(39, kh=1, kw=1, pad_top=0, pad_left=0) != 0                              # 1x1
+    assert rc(39, cin=96) != 0 and rc(41, cin=64) != 0                                 # k-steps are a template parameter
+    assert rc(39, cout=48) != 0                                                        # couts not a multiple of the workgroup's slice
+    assert rc(39, n=1, h=4, conv_h=4, out_h=4) != 0                                    # one tile per workgroup: nothing to amortise
+
+
 def test_conv_f16_wreg_rejects_what_it_does_not_cover():
     t = torch.zeros(1 << 16, device=DEV)
 
