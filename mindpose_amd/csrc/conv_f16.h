@@ -70,8 +70,13 @@ enum ConvF16Variant { F_CT32_PT192 = 0, F_CT64_PT192 = 1, F_CT48_PT192 = 2, F_CT
                       F_WREG_P6C2_W2 = 31, F_WREG_P6C3_W2 = 32, F_WREG_P3C2_W2 = 33, F_WREG_P6C2_W4 = 34, F_WREG_P6C3_W4 = 35,
                       F_WREG_P3C2_W4 = 36,
                       // weight-stationary persistent kernel (conv_f16_ws.hip): shapes in kWsShapes
-                      F_WS_BASE = 37, F_WS_COUNT = 8, F_COUNT = 45 };
-inline bool f16_variant_wreg(int v) { return v >= F_WREG_P6C2 && v <= F_WREG_P3C2_W4; }
+                      F_WS_BASE = 37, F_WS_COUNT = 8,
+                      // round 4, weights-in-registers shapes whose pixel tile makes W48's deep layers ONE round of 256 workgroups:
+                      // 112 px x 192 couts (192 -> 192 @24x18, N = 64: 6 rows of 18 = 4 tiles per image x 64) and 64 px x 192 couts
+                      // (384 -> 384 @12x9: 7 rows of 9 = 2 tiles per image x 64 x 2 cout slices); P5C4 = 80 px x 256 couts
+                      F_WREG_P7C3 = 45, F_WREG_P4C3 = 46, F_WREG_P5C4 = 47, F_COUNT = 48 };
+inline bool f16_variant_wreg(int v) { return (v >= F_WREG_P6C2 && v <= F_WREG_P3C2_W4) || (v >= F_WREG_P7C3 && v <= F_WREG_P5C4); }
+inline int f16_wreg_index(int v) { return v <= F_WREG_P3C2_W4 ? v - F_WREG_P6C2 : 12 + v - F_WREG_P7C3; }
 inline bool f16_variant_ws(int v) { return v >= F_WS_BASE && v < F_WS_BASE + F_WS_COUNT; }
 inline bool f16_variant_mt(int v) { return (v >= F_MT2_BASE && v < F_CT16_PT192) || v == F_CT16_PT192_MT2 || v == F_CT16_PT192_MT1; }
 inline int f16_variant_mt_occ(int v) { return (v >= F_MT1_BASE && v < F_CT16_PT192) || v == F_CT16_PT192_MT1 ? 1 : 2; }

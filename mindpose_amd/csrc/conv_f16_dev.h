@@ -8,6 +8,8 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
@@ -49,6 +51,10 @@ __device__ __forceinline__ f32x4 f16_epi4(f32x4 acc, f32x4 sc, f32x4 sh, bool ha
         const f16x4 h = __builtin_bit_cast(f16x4, r2);
         v += (f32x4){(float)h.x, (float)h.y, (float)h.z, (float)h.w};
     }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    return v;
+}
+__device__ __forceinline__ f32x4 f16_relu4(f32x4 v, int relu) {  // the ReLU of f16_epi4 alone (kernels that cut the epilogue in two)
     if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     return v;
 }

@@ -22,14 +22,43 @@
 
 namespace mp {
 
+#if defined(MP_WS_STAMPS) && MP_WS_STAMPS
+extern unsigned long long* g_ws_stamp_buf;  // conv_f16_ws.hip (diagnostic build; tools/ws_probe.py reads both kernels' stamps)
+extern size_t g_ws_stamp_bytes;
+#endif
+
 namespace {
+
+constexpr int kWregMaxPieces = 8;  // DMA pieces (64 x 16 B) per plane of the fast staging form
+
+#ifndef MP_WS_STAMPS
+#define MP_WS_STAMPS 0
+#endif
+#if MP_WS_STAMPS
+#define WREG_STAMP(i)                                                                        \
+    do {                                                                                     \
+        if (dbg && wave == 0 && (i) < 64) {                                                  \
+            unsigned long long t_;                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                               \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
+            __builtin_amdgcn_sched_barrier(0);                                               \
+            if (lane == 0) dbg[(size_t)blockIdx.x * 64 + (i)] = t_;                          \
+        }                                                                                    \
+    } while (0)
+#else
+#define WREG_STAMP(i) do { } while (0)
+#endif
 
 // Wave roles: WAVES_P waves split the workgroup's pixel tiles, 4 / WAVES_P split its couts.  WAVES_P = 1 (every wave all pixels,
 // a quarter of the couts) streams each weight byte once per workgroup - the shape for the 128 - 384-channel layers whose weight
 // stream is what the vector-memory path carries; with fewer couts (64 / 32-channel layers) the pixel split keeps two cout tiles
 // per wave, i.e. half the LDS reads per MFMA, at the price of WAVES_P waves fetching the same (small) weight fragments.
 template <int KS, int S, int PS, int CSW, int WAVES_P, int OCC, int STATS = 0>
-__global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Params p) {
+__global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Params p
+#if MP_WS_STAMPS
+                                                                 , unsigned long long* dbg
+#endif
+) {
     constexpr int T = KS * KS;
     constexpr int HALO = KS / 2;
     constexpr bool RES2 = S == 2;  // the stride-2 layers are the exchange unit's down-sampling convs: running sum + identity
@@ -42,6 +71,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp_i = wave % WAVES_P, wc_i = wave / WAVES_P;
     const int lq = lane >> 4, lr = lane & 15;
+    WREG_STAMP(0);
 
     int b = blockIdx.x;
     {
@@ -57,24 +87,34 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
     const int P = p.Wp;  // row pitch W + HALO
     const int y_in0 = y0 * S - HALO;  // image row of the tile's first staged row
 
-    // ---- weight operand: this wave's couts, straight from the packed weights [kq][T][4][Cout_pad16] x 16 B
-    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.wp, (size_t)(p.PK >> 2) * T * 4 * p.Cout_pad16 * 16);
-    unsigned a_goff[CSW];
+    // ---- input tile: every 16-byte slot of the LDS image is written by LDS-DMA, data or (out of range) zero.  The DMA goes FIRST:
+    //      its data comes from HBM and ALL of it must have landed before the first MFMA, the weight fragments behind it come from L2
+    //      and are needed tap by tap
+    if (p.upc > 0) {
+        // fast form (stride 1, one image per tile, plane pitch a multiple of 64 elements - f16_configure_wreg): a DMA piece never
+        // straddles planes, so its slot -> (row, column) map is the same for every plane and is decoded ONCE (the magic
+        // divisions are quarter-rate integer multiplies: ~300 cycles per piece in the generic loop below, round-4 stamps); a
+        // plane only adds its descriptor - rows above / below the image fall outside it and arrive as zeros
+        const unsigned plane_bytes = (unsigned)HW * 16u;
+        unsigned piece_rel[kWregMaxPieces];
 #pragma unroll
-    for (int cs = 0; cs < CSW; ++cs) {
-        const int co = ct * CT + wc_i * CSW * 16 + f16_a_row<CSW>(cs, lr);
-        a_goff[cs] = co < p.Cout_pad16 ? (unsigned)(lq * p.Cout_pad16 + co) * 16u : kOob;
-    }
-    const unsigned tap_bytes = 4u * p.Cout_pad16 * 16u;  // one (k-step, tap): 4 planes x Cout_pad16 x 16 B
-    u32x4 A[T][CSW];
+        for (int s = 0; s < kWregMaxPieces; ++s) {
+            const unsigned slot = (unsigned)(s * 64 + lane);
+            const unsigned r = __umulhi(slot, p.magic_ncols);
+            const int c = (int)(slot - r * P) - HALO;
+            piece_rel[s] = (slot < (unsigned)p.img_plane && c >= 0) ? (unsigned)(((int)r + y_in0) * p.W + c) * 16u : kOob;
+        }
+        const char* img = reinterpret_cast<const char*>(p.x) + (size_t)n0 * p.C8in * plane_bytes;
+        for (int pl = wave; pl < p.PK; pl += 4) {  // wave-uniform
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(img + (size_t)(pl < p.C8in ? pl : 0) * plane_bytes, pl < p.C8in ? plane_bytes : 0);
 #pragma unroll
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int cs = 0; cs < CSW; ++cs)
-            A[t][cs] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, a_goff[cs] == kOob ? kOob : a_goff[cs] + t * tap_bytes, 0, 0);
-
-    // ---- input tile: every 16-byte slot of the LDS image is written by LDS-DMA, data or (out of range) zero
-    {
+            for (int s = 0; s < kWregMaxPieces; ++s) {
+                if (s >= p.upc) break;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds_in + pl * p.plane + s * 64), 16,
+                                                         piece_rel[s], 0, 0, 0);
+            }
+        }
+    } else {
         const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x, (size_t)p.N * p.C8in * HW * 16);
         const int total = p.PK * p.plane;  // a last partial piece spills (zeros) into the 64-element slack behind the image
         const int img_slots = p.G * p.img_plane;
@@ -92,7 +132,24 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(lds_in + s0), 16, off, 0, 0, 0);
         }
     }
+    WREG_STAMP(60);
 
+    // ---- weight operand: this wave's couts, straight from the packed weights [kq][T][4][Cout_pad16] x 16 B
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.wp, (size_t)(p.PK >> 2) * T * 4 * p.Cout_pad16 * 16);
+    unsigned a_goff[CSW];
+#pragma unroll
+    for (int cs = 0; cs < CSW; ++cs) {
+        const int co = ct * CT + wc_i * CSW * 16 + f16_a_row<CSW>(cs, lr);
+        a_goff[cs] = co < p.Cout_pad16 ? (unsigned)(lq * p.Cout_pad16 + co) * 16u : kOob;
+    }
+    const unsigned tap_bytes = 4u * p.Cout_pad16 * 16u;  // one (k-step, tap): 4 planes x Cout_pad16 x 16 B
+    u32x4 A[T][CSW];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int cs = 0; cs < CSW; ++cs)
+            A[t][cs] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, a_goff[cs] == kOob ? kOob : a_goff[cs] + t * tap_bytes, 0, 0);
+    WREG_STAMP(61);
     // ---- pixel operand addresses and the epilogue's pixel offsets (overlap the DMA's flight)
     int b_off[PS];
     unsigned pix_off[PS];
@@ -129,8 +186,13 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
 #pragma unroll
         for (int cs = 0; cs < CSW; ++cs) acc[ps][cs] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces (and its first weight fragments) have landed
+    WREG_STAMP(1);
+    // this wave's DMA pieces have landed: they are OLDER than the T x CSW weight loads of the first k-step (and whatever else was
+    // issued since), so all but that many may still be in flight - the fragments are waited for tap by tap (the compiler counts
+    // them); more than 63 cannot be encoded: wait for the excess
+    __builtin_amdgcn_s_waitcnt(0x0F70 | ((T * CSW < 63 ? T * CSW : 63) & 15) | (((T * CSW < 63 ? T * CSW : 63) >> 4) << 14));
     __syncthreads();                                  // ... and every other wave's: the only barrier of the workgroup
+    WREG_STAMP(2);
 
     constexpr int NP = CSW / 2, NS = CSW - 2 * NP;
     const size_t o_bytes = (size_t)p.N * p.C8out * plane_o * 16;
@@ -186,7 +248,10 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    for (int q = 0; q + 1 < nq; ++q) kstep(q, std::true_type{});
+    for (int q = 0; q + 1 < nq; ++q) {
+        kstep(q, std::true_type{});
+        WREG_STAMP(3 + q);
+    }
     {
         // residual tensor: fetched ahead of the last k-step, so its latency hides under that step's MFMAs.  Unconditional loads
         // (an absent tensor is a zero-length descriptor: the range check answers, nothing is fetched) keep the code branch-free
@@ -239,7 +304,9 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
             }
         }
     }
+    WREG_STAMP(3 + nq - 1);
     kstep(nq - 1, std::false_type{});
+    WREG_STAMP(3 + nq);
 
     // ---- epilogue: scale/shift, residuals, ReLU, one rounding, 16-byte stores per cout-tile pair
     const bool has1 = p.res1 != nullptr, has2 = RES2 && p.res2 != nullptr;
@@ -277,6 +344,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
             __builtin_amdgcn_raw_buffer_store_b64(o, rs_o, co_off[CSW - 1] + pix_off[ps], 0, 0);
         }
     }
+    WREG_STAMP(63);
     if constexpr (STATS)
         f16_stats_flush<CSW, WAVES_P, WAVES_C>(st_a, st_b, reinterpret_cast<float*>(smem16), p.st_part, p.st_nparts, part_idx, ct * CT,
                                                p.C8out, wp_i, wc_i, lq, lr);
@@ -290,7 +358,12 @@ int launch_wreg_kernel(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
     }
+#if MP_WS_STAMPS
+    hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(256), lds_bytes, s, p,
+                       (g_ws_stamp_buf && (size_t)p.total_blocks * 64 * 8 <= g_ws_stamp_bytes) ? g_ws_stamp_buf : nullptr);
+#else
     hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(256), lds_bytes, s, p);
+#endif
     return check_launch();
 }
 
@@ -319,6 +392,15 @@ int launch_wreg_ks(const ConvF16Params& p, int variant, size_t lds_bytes, hipStr
         case F_WREG_P6C2_W4: return launch_wreg<KS, S, 6, 2, 4, 2>(p, lds_bytes, s);
         case F_WREG_P6C3_W4: return launch_wreg<KS, S, 6, 3, 4, 1>(p, lds_bytes, s);
         case F_WREG_P3C2_W4: return launch_wreg<KS, S, 3, 2, 4, 2>(p, lds_bytes, s);
+        case F_WREG_P7C3:
+            if constexpr (KS == 3 && S == 1) return launch_wreg<KS, S, 7, 3, 1, 1>(p, lds_bytes, s);
+            return MP_ERR_UNSUPPORTED;
+        case F_WREG_P4C3:
+            if constexpr (KS == 3 && S == 1) return launch_wreg<KS, S, 4, 3, 1, 1>(p, lds_bytes, s);
+            return MP_ERR_UNSUPPORTED;
+        case F_WREG_P5C4:
+            if constexpr (KS == 3 && S == 1) return launch_wreg<KS, S, 5, 4, 1, 1>(p, lds_bytes, s);
+            return MP_ERR_UNSUPPORTED;
         default: return MP_ERR_UNSUPPORTED;
     }
 }
@@ -326,12 +408,12 @@ int launch_wreg_ks(const ConvF16Params& p, int variant, size_t lds_bytes, hipStr
 }  // namespace
 
 void f16_wreg_dims(int v, int& ps, int& csw, int& waves_p) {
-    static const int pss[12] = {6, 3, 6, 6, 3, 3, 6, 6, 3, 6, 6, 3};
-    static const int css[12] = {2, 2, 1, 3, 3, 4, 2, 3, 2, 2, 3, 2};
-    static const int wps[12] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 4, 4, 4};
-    ps = pss[v - F_WREG_P6C2];
-    csw = css[v - F_WREG_P6C2];
-    waves_p = wps[v - F_WREG_P6C2];
+    static const int pss[15] = {6, 3, 6, 6, 3, 3, 6, 6, 3, 6, 6, 3, 7, 4, 5};
+    static const int css[15] = {2, 2, 1, 3, 3, 4, 2, 3, 2, 2, 3, 2, 3, 3, 4};
+    static const int wps[15] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 4, 4, 4, 1, 1, 1};
+    ps = pss[f16_wreg_index(v)];
+    csw = css[f16_wreg_index(v)];
+    waves_p = wps[f16_wreg_index(v)];
 }
 
 // geometry: 3x3 pad 1 (stride 1 or 2) and 1x1 pad 0 convolutions whose output rows tile the pixel tile
@@ -340,6 +422,7 @@ bool f16_configure_wreg(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
     f16_wreg_dims(variant, PS, CSW, WP);
     const int KS = d.kh, S = d.stride, halo = KS / 2, T = KS * KS;
     if (!((KS == 3 && (S == 1 || S == 2)) || (KS == 1 && S == 1))) return false;
+    if (variant >= F_WREG_P7C3 && !(KS == 3 && S == 1)) return false;  // the round-4 shapes are built for the 3x3 stride-1 branch convs
     if (d.pad_top != halo || d.pad_left != halo) return false;
     if (d.conv_h != (d.h + 2 * halo - KS) / S + 1 || d.conv_w != (d.w + 2 * halo - KS) / S + 1) return false;
     ConvF16Params& p = L.p;
@@ -377,6 +460,11 @@ bool f16_configure_wreg(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
     p.plane = S == 1 ? round_up(p.G * p.img_plane + halo, 16) : ((p.G * p.img_plane + halo) | 1);
     p.ncols = p.W;
     p.upc = 0;
+    if (S == 1 && p.G == 1 && round_up(p.img_plane + halo, 64) / 64 <= 8 && !knob("MP_F16_WREG_SLOW_DMA")) {
+        // fast staging form: plane pitch a multiple of 64 elements, upc = DMA pieces per plane
+        p.plane = round_up(p.img_plane + halo, 64);
+        p.upc = p.plane / 64;
+    }
     p.in_buf = p.PK * p.plane;
     p.w_buf = 0;
     p.nbuf = 1;

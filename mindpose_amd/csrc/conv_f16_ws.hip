@@ -25,10 +25,36 @@
 
 namespace mp {
 
+#if defined(MP_WS_STAMPS) && MP_WS_STAMPS
+unsigned long long* g_ws_stamp_buf = nullptr;
+size_t g_ws_stamp_bytes = 0;
+#endif
+
 namespace {
 
+#ifndef MP_WS_ABLATE
+#define MP_WS_ABLATE 0  // kernel work only (tools/ws_ablate.sh; results are WRONG): 1 no epilogue arithmetic, 2 no DMA of the next tile,
+#endif                  // 4 no residual loads, 8 no pixel-operand reads, 16 no stores, 32 no accumulator copy
+#ifndef MP_WS_STAMPS
+#define MP_WS_STAMPS 0  // 1: s_memtime phase stamps of wave 0 into g_ws_stamp_buf (tools/ws_probe.py; never in the product build)
+#endif
+#if MP_WS_STAMPS
+#define WS_STAMP(i)                                                                          \
+    do {                                                                                     \
+        if (dbg && wave == 0 && (i) < 64) {                                                  \
+            unsigned long long t_;                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                               \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
+            __builtin_amdgcn_sched_barrier(0);                                               \
+            if (lane == 0) dbg[(size_t)blockIdx.x * 64 + (i)] = t_;                          \
+        }                                                                                    \
+    } while (0)
+#else
+#define WS_STAMP(i) do { } while (0)
+#endif
+
 constexpr int kWsMaxPieces = 8;  // DMA pieces (64 x 16 B) per plane: f16_configure_ws admits no more
-constexpr int kWsAgprFrags = 62;  // weight fragments held in the accumulator half of the register file (4 AGPRs each; 256 - slack)
+constexpr int kWsAgprRegs = 252;  // AGPRs handed out by hand: the accumulators first, weight fragments in what is left
 
 // The MFMA as inline assembly: hipcc keeps MFMA source operands in VGPRs and uses AGPRs only as spill space (a 324-register weight set
 // then costs four v_accvgpr_read per MFMA and the spill traffic wrecks the operand prefetch - the first build of this kernel waited
@@ -36,17 +62,30 @@ constexpr int kWsAgprFrags = 62;  // weight fragments held in the accumulator ha
 // "a" the fragment is loaded into AGPRs (buffer_load ... a[..]) and stays there.  Hazards inside these statements: back-to-back MFMAs
 // on independent accumulators need no wait states, the same-accumulator chain (SrcC = vDst of the previous one) needs none either; the
 // epilogue's first VALU read of an accumulator sits behind mfma_results_ready().
+// The ACCUMULATORS are AGPR operands too ("+a"): the two accumulator sets of the pipelined tile loop plus most weight fragments fill the
+// 256 AGPRs, the VGPR half keeps the remaining fragments and everything the VALU touches (the epilogue reads an accumulator through
+// v_accvgpr_read, in the shadow of the next tile's MFMAs).
 __device__ __forceinline__ void mfma_a(f32x4& acc, const u32x4& a, const u32x4& b) {
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "v"(b));
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "a"(a), "v"(b));
 }
 __device__ __forceinline__ void mfma_v(f32x4& acc, const u32x4& a, const u32x4& b) {
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void mfma_a0(f32x4& acc, const u32x4& a, const u32x4& b) {  // first MFMA of a chain: C = 0
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(a), "v"(b));
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&a"(acc) : "a"(a), "v"(b));
 }
 __device__ __forceinline__ void mfma_v0(f32x4& acc, const u32x4& a, const u32x4& b) {
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&a"(acc) : "v"(a), "v"(b));
+}
+// accumulator (AGPR tuple) -> VGPRs, HERE: left to the compiler the copy floats to wherever the register allocator likes it (it read
+// whole accumulator sets at the top of the tile loop and spilled them)
+__device__ __forceinline__ f32x4 acc_read(const f32x4& acc) {
+    f32x4 v;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v.x) : "a"(acc.x));
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v.y) : "a"(acc.y));
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v.z) : "a"(acc.z));
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v.w) : "a"(acc.w));
+    return v;
 }
 __device__ __forceinline__ void load_a(u32x4& dst, unsigned voff, const u32x4& rsrc) {
     asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=a"(dst) : "v"(voff), "s"(rsrc) : "memory");
@@ -55,15 +94,20 @@ __device__ __forceinline__ void load_v(u32x4& dst, unsigned voff, const u32x4& r
     asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rsrc) : "memory");
 }
 
-template <int NQ, int CSW, int WAVES_P, int PS, int OCC, int STATS>
-__global__ __launch_bounds__(256, OCC) void conv_f16_ws_kernel(const ConvF16Params p) {
+template <int NQ, int CSW, int WAVES_P, int PS, int OCC, int STATS, bool RES>
+__global__ __launch_bounds__(256, OCC) void conv_f16_ws_kernel(const ConvF16Params p
+#if MP_WS_STAMPS
+                                                               , unsigned long long* dbg
+#endif
+) {
     constexpr int T = 9;
     constexpr int WAVES_C = 4 / WAVES_P;
     constexpr int CT = 16 * CSW * WAVES_C;  // couts per workgroup
     constexpr int NP = CSW / 2, NS = CSW - 2 * NP;
     constexpr int NST = PS * (NP + NS);  // stores per tile and wave
     constexpr int NF = NQ * T * CSW;     // weight fragments of a wave
-    constexpr int NFA = NF < kWsAgprFrags ? NF : kWsAgprFrags, NFV = NF - NFA;
+    constexpr int kAgprFrags = (kWsAgprRegs / OCC - 4 * PS * CSW) / 4;  // 4 AGPRs per fragment behind the PS CSW accumulators of 4
+    constexpr int NFA = NF < kAgprFrags ? NF : kAgprFrags, NFV = NF - NFA;
     extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
     u32x4* __restrict__ lds_in = smem16;  // [2][PK][plane]
 
@@ -71,6 +115,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_ws_kernel(const ConvF16Para
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp_i = wave % WAVES_P, wc_i = wave / WAVES_P;
     const int lq = lane >> 4, lr = lane & 15;
+    WS_STAMP(0);
 
     int b = blockIdx.x;
     {
@@ -96,11 +141,11 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_ws_kernel(const ConvF16Para
         const int c = (int)(slot - r * P) - 1;
         piece_rel[s] = (slot < (unsigned)p.img_plane && c >= 0) ? (r * p.W + c) * 16u : kOob;
     }
-    auto tile_pos = [&](int t, int& n, int& y0) {
+    auto tile_pos = [&](int t, int& n, int& y0) __attribute__((always_inline)) {
         n = p.tiles_y == 1 ? t : (int)__umulhi((unsigned)t, p.magic_rows);
         y0 = (t - n * p.tiles_y) * p.R;
     };
-    auto dma_tile = [&](int t, int buf) {
+    auto dma_tile = [&](int t, int buf) __attribute__((always_inline)) {
         int n, y0;
         tile_pos(t, n, y0);
         const unsigned row_off = (unsigned)((y0 - 1) * p.W * 16);  // first staged row = y0 - 1 (-1: wraps out of range)
@@ -172,106 +217,242 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_ws_kernel(const ConvF16Para
         pix_rel[ps] = in_tile ? (y * p.W + xx) * 16u : kInv;
         y_rel[ps] = (int)y;
     }
-    f32x4 sc[CSW], sh[CSW];
-    unsigned co_off[CSW];
+    // folded-BatchNorm scale / shift of the workgroup's couts: in LDS behind the ring ([CT] scale, [CT] shift), fetched by the
+    // epilogue item that needs them (registers are what this kernel is short of)
+    float* __restrict__ lds_bn = reinterpret_cast<float*>(smem16 + 2 * buf_elems);
+    if (tid < CT) {
+        lds_bn[tid] = p.scale[ct * CT + tid];  // Cout_pad16 is a multiple of CT: in range
+        lds_bn[CT + tid] = p.shift[ct * CT + tid];
+    }
+    unsigned co_off[CSW], bn_off[CSW];
 #pragma unroll
     for (int cs = 0; cs < CSW; ++cs) {
-        const int co = ct * CT + wc_i * CSW * 16 + f16_d_cout<CSW>(cs, lq);
+        const int cl = wc_i * CSW * 16 + f16_d_cout<CSW>(cs, lq);
+        const int co = ct * CT + cl;
         const bool ok = co < p.C8out * 8;
-        const int cc = co < p.Cout_pad16 ? co : 0;
-        sc[cs] = *reinterpret_cast<const f32x4*>(p.scale + cc);
-        sh[cs] = *reinterpret_cast<const f32x4*>(p.shift + cc);
+        bn_off[cs] = (unsigned)cl;
         co_off[cs] = ok ? (unsigned)(co >> 3) * plane_bytes + ((co >> 2) & 1) * 8u : kInv;
     }
     const size_t o_bytes = (size_t)p.N * p.C8out * plane_bytes;
     const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(p.out, o_bytes);
     const __amdgpu_buffer_rsrc_t rs_r = make_rsrc(p.res1 ? p.res1 : p.out, p.res1 ? o_bytes : 0);  // absent: zero-length, nothing fetched
-    const bool has1 = p.res1 != nullptr;
 
     f32x4 st_a[STATS ? CSW : 1], st_b[STATS ? CSW : 1];
     if constexpr (STATS) {
 #pragma unroll
         for (int cs = 0; cs < CSW; ++cs) st_a[cs] = st_b[cs] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_z = make_rsrc(STATS == 2 ? p.st_z : p.out, STATS == 2 ? o_bytes : 0);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(STATS == 2 && p.st_y ? p.st_y : p.out, STATS == 2 && p.st_y ? o_bytes : 0);
 
+    // ---- the SIDE JOBS of a tile: everything but its MFMAs.  A wave is alone on its SIMD, so whatever it issues between two tiles'
+    //      MFMA loops leaves the matrix pipe idle (round-4 stamps, 48 -> 48 @96x72: 4.3 k cycles of MFMA per tile, 1.0 k issuing the
+    //      next tile's DMA pieces, 2.0 k of epilogue VALU work).  What fits in an MFMA's shadow is small: the MFMA holds the SIMD's
+    //      vector issue for 8 of its 16 cycles, a plain VALU instruction costs 4, a scalar one ~6, and costs ADD - two VALU
+    //      instructions per MFMA are free, a third is paid in full (tools/probes/mfma_shadow.hip; MI355X_MICROARCH constants table).
+    //      The jobs are therefore cut into MICRO-OPS of at most two vector instructions - a DMA piece, a residual load, one
+    //      pk_fma pair, two conversions, two ReLUs, a packed rounding, a store - and micro-op u of tile t - 1 (DMA: of tile t + 1)
+    //      sits behind MFMA number u M / NU of tile t.  The accumulators live in AGPRs and are copied to VGPRs at the tile's end.
+    //      List order = issue order of the vector-memory operations: DMA pieces, then loads, then stores - at the top of the next
+    //      tile everything older than the NST stores has landed (counted vmcnt).
+    constexpr int NDMA = NQ * kWsMaxPieces;              // DMA slots (pieces beyond the plane's size are skipped)
+    constexpr int NLD = NST * (STATS == 2 ? 3 : 1);      // residual (+ z, y) loads
+    constexpr int UH = RES ? 7 : 4;                      // micro-ops of one half (4 couts of one pixel): fma | cvt cvt add | relu relu | pack
+    constexpr int UP = 2 * UH + 1, US = UH + 1;          // ... of a paired / single output group (+ the store)
+    constexpr int NEPI = PS * (NP * UP + NS * US);
+    constexpr int M = NQ * T * PS * CSW;                 // MFMAs per tile
+
+    u32x4 r1p[NP ? NP : 1][PS];
+    u32x2 r1s[PS];
+    u32x4 zp[(STATS == 2 && NP) ? NP : 1][PS], yp[(STATS == 2 && NP) ? NP : 1][PS];
+    u32x2 zs[PS], ys[PS];
+    u32x2 e_lo, e_hi;  // the output group in flight (micro-ops of a group are consecutive)
+    f32x4 e_v;
+    f32x2 e_r01, e_r23;
+    unsigned pix_prev[PS];  // output offsets of the tile whose side jobs are running; kInv: none (loads return zero, stores drop)
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps) pix_prev[ps] = kInv;
+    const float relu_floor = p.relu ? 0.f : -__builtin_inff();  // max(v, floor): the ReLU without a branch
+
+    // scale / shift registers: `lo` serves the even cout tile of a pair (and the single last tile), `hi` the odd one.  Each is
+    // reloaded from LDS right behind the LAST micro-op that used its value (the groups of one cout tile are consecutive), i.e. many
+    // MFMAs ahead of the next use: the epilogue never waits on LDS.  A sequence of one value is never reloaded
+    constexpr int L_LO = NP + NS, L_HI = NP;
+    f32x4 sc_lo, sh_lo, sc_hi, sh_hi;
+    auto bn_load_lo = [&](int i) __attribute__((always_inline)) {
+        const int cs = i < NP ? 2 * i : CSW - 1;
+        sc_lo = *reinterpret_cast<const f32x4*>(lds_bn + bn_off[cs]);
+        sh_lo = *reinterpret_cast<const f32x4*>(lds_bn + CT + bn_off[cs]);
+    };
+    auto bn_load_hi = [&](int i) __attribute__((always_inline)) {
+        sc_hi = *reinterpret_cast<const f32x4*>(lds_bn + bn_off[2 * i + 1]);
+        sh_hi = *reinterpret_cast<const f32x4*>(lds_bn + CT + bn_off[2 * i + 1]);
+    };
+    // one load: l < NP PS pairs (16 B) then NS PS singles (8 B); STATS == 2: then the same for z, then for y
+    auto side_load = [&](int l) __attribute__((always_inline)) {
+        const int which = l / NST, k = l - which * NST;
+        const bool pair = k < NP * PS;
+        const int j = pair ? k / PS : 0, ps = pair ? k - j * PS : k - NP * PS;
+        const unsigned off = co_off[pair ? 2 * j : CSW - 1] + pix_prev[ps];
+        if (which == 0) {
+            if constexpr (RES) {
+                if (pair) r1p[j][ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, off, 0, 0);
+                else r1s[ps] = __builtin_amdgcn_raw_buffer_load_b64(rs_r, off, 0, 0);
+            }
+        } else if (which == 1) {
+            if (pair) zp[j][ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_z, off, 0, 0);
+            else zs[ps] = __builtin_amdgcn_raw_buffer_load_b64(rs_z, off, 0, 0);
+        } else {
+            if (pair) yp[j][ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, off, 0, 0);
+            else ys[ps] = __builtin_amdgcn_raw_buffer_load_b64(rs_y, off, 0, 0);
+        }
+    };
+    // micro-op k of one half: 4 couts of one pixel, accumulator `a`, residual halves `r`; the arithmetic of f16_epi4 / f16_pack4
+    // (fma(acc, scale, shift), + residual, ReLU, one rounding) instruction by instruction
+    auto half_op = [&](int k, const f32x4& a, const f32x4& sc, const f32x4& sh, unsigned r0, unsigned r1, u32x2& out) __attribute__((always_inline)) {
+        const int step = RES ? k : (k == 0 ? 0 : k + 3);  // without a residual: fma, relu, relu, pack
+        if (step == 0) {
+            const f32x2 v01 = __builtin_elementwise_fma((f32x2){a.x, a.y}, (f32x2){sc.x, sc.y}, (f32x2){sh.x, sh.y});
+            const f32x2 v23 = __builtin_elementwise_fma((f32x2){a.z, a.w}, (f32x2){sc.z, sc.w}, (f32x2){sh.z, sh.w});
+            e_v = (f32x4){v01.x, v01.y, v23.x, v23.y};
+        } else if (step == 1) {
+            const f16x2 h = __builtin_bit_cast(f16x2, r0);
+            e_r01 = (f32x2){(float)h.x, (float)h.y};
+        } else if (step == 2) {
+            const f16x2 h = __builtin_bit_cast(f16x2, r1);
+            e_r23 = (f32x2){(float)h.x, (float)h.y};
+        } else if (step == 3) {
+            e_v = (f32x4){e_v.x + e_r01.x, e_v.y + e_r01.y, e_v.z + e_r23.x, e_v.w + e_r23.y};
+        } else if (step == 4) {
+            asm volatile("v_max_f32 %0, %1, %0" : "+v"(e_v.x) : "v"(relu_floor));
+            asm volatile("v_max_f32 %0, %1, %0" : "+v"(e_v.y) : "v"(relu_floor));
+        } else if (step == 5) {
+            asm volatile("v_max_f32 %0, %1, %0" : "+v"(e_v.z) : "v"(relu_floor));
+            asm volatile("v_max_f32 %0, %1, %0" : "+v"(e_v.w) : "v"(relu_floor));
+        } else {
+            out = f16_pack4(e_v);
+        }
+    };
+    // micro-op e of the previous tile's epilogue (accumulators `ac`): paired groups (j, ps), then single groups (ps)
+    auto side_epi = [&](int e, f32x4 (&ac)[PS][CSW]) __attribute__((always_inline)) {
+        const bool pair = e < NP * PS * UP;
+        const int e2 = pair ? e : e - NP * PS * UP;
+        const int grp = e2 / (pair ? UP : US), sub = e2 - grp * (pair ? UP : US);
+        const int j = pair ? grp / PS : 0, ps = pair ? grp - j * PS : grp;
+        [[maybe_unused]] const bool valid = pix_prev[ps] != kInv;
+        if ((MP_WS_ABLATE & 1) && sub < (pair ? 2 * UH : UH)) return;
+        if ((MP_WS_ABLATE & 16) && sub >= (pair ? 2 * UH : UH)) return;
+        if (pair) {
+            if (sub < UH) {
+                half_op(sub, ac[ps][2 * j], sc_lo, sh_lo, RES ? r1p[j][ps].x : 0u, RES ? r1p[j][ps].y : 0u, e_lo);
+                if (sub == 0 && ps == PS - 1 && L_LO > 1) bn_load_lo((j + 1) % L_LO);
+            } else if (sub < 2 * UH) {
+                half_op(sub - UH, ac[ps][2 * j + 1], sc_hi, sh_hi, RES ? r1p[j][ps].z : 0u, RES ? r1p[j][ps].w : 0u, e_hi);
+                if (sub == UH && ps == PS - 1 && L_HI > 1) bn_load_hi((j + 1) % L_HI);
+            } else {
+                if constexpr (STATS == 2) {
+                    const u32x4 zq = zp[j][ps], yq = yp[j][ps];
+                    f16_stats_acc<2>(e_lo, valid, st_a[2 * j], st_b[2 * j], (u32x2){zq.x, zq.y}, (u32x2){yq.x, yq.y}, p.st_relu);
+                    f16_stats_acc<2>(e_hi, valid, st_a[2 * j + 1], st_b[2 * j + 1], (u32x2){zq.z, zq.w}, (u32x2){yq.z, yq.w}, p.st_relu);
+                } else if constexpr (STATS == 1) {
+                    f16_stats_acc<1>(e_lo, valid, st_a[2 * j], st_b[2 * j], e_lo, e_lo, 0);
+                    f16_stats_acc<1>(e_hi, valid, st_a[2 * j + 1], st_b[2 * j + 1], e_hi, e_hi, 0);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){e_lo.x, e_lo.y, e_hi.x, e_hi.y}, rs_o, co_off[2 * j] + pix_prev[ps], 0, 0);
+            }
+        } else {
+            if (sub < UH) {
+                half_op(sub, ac[ps][CSW - 1], sc_lo, sh_lo, RES ? r1s[ps].x : 0u, RES ? r1s[ps].y : 0u, e_lo);
+                if (sub == 0 && ps == PS - 1 && L_LO > 1) bn_load_lo(0);
+            } else {
+                if constexpr (STATS == 2) f16_stats_acc<2>(e_lo, valid, st_a[CSW - 1], st_b[CSW - 1], zs[ps], ys[ps], p.st_relu);
+                else if constexpr (STATS == 1) f16_stats_acc<1>(e_lo, valid, st_a[CSW - 1], st_b[CSW - 1], e_lo, e_lo, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(e_lo, rs_o, co_off[CSW - 1] + pix_prev[ps], 0, 0);
+            }
+        }
+    };
+
+    WS_STAMP(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first tile and the weight fragments (asm loads: this wait is theirs) have landed
     __syncthreads();
+    WS_STAMP(2);
+    bn_load_lo(0);
+    if constexpr (NP > 0) bn_load_hi(0);
 
+    // one tile: MFMAs into `acc` (AGPRs), side jobs of the previous tile from `prev` (its accumulators, copied to VGPRs at its end)
+    f32x4 acc[PS][CSW], prev[PS][CSW];
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps)
+#pragma unroll
+        for (int cs = 0; cs < CSW; ++cs) prev[ps][cs] = (f32x4){0.f, 0.f, 0.f, 0.f};  // read (masked) by the first tile's side jobs
     for (int t = t_begin; t < t_end; ++t) {
         const int cur = (t - t_begin) & 1;
         if (t != t_begin) {
-            // tile t's DMA pieces (issued one tile ago) are OLDER than the previous tile's NST stores: all but those have landed
+            // tile t's DMA pieces and the residual loads (issued one tile ago) are OLDER than the NST stores that followed them
             __builtin_amdgcn_s_waitcnt(0x0F70 | (NST & 15) | ((NST >> 4) << 14));  // vmcnt(NST)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // ... in every wave, and nobody reads the other buffer any more
             asm volatile("" ::: "memory");
         }
-        if (t + 1 < t_end) dma_tile(t + 1, cur ^ 1);
+        WS_STAMP(t - t_begin < 6 ? 3 + 2 * (t - t_begin) : 64);
+        // DMA of tile t + 1: the descriptors of this wave's planes, once per tile and OUTSIDE the MFMA stream (scalar instructions
+        // are the dearest fillers); a DMA micro-op is then m0, one address add, the load
+        const bool more = t + 1 < t_end;
+        int n1, y1;
+        tile_pos(more ? t + 1 : t, n1, y1);
+        const unsigned row_off1 = (unsigned)((y1 - 1) * p.W * 16);
+        const char* img1 = reinterpret_cast<const char*>(p.x) + (size_t)n1 * p.C8in * plane_bytes;
+        // absent plane / no next tile: zero-length descriptor (the piece is still issued: no branch on it in the MFMA stream; it
+        // writes zeros into the padding planes, which is what they hold)
+        auto plane_rsrc = [&](int j) __attribute__((always_inline)) {
+            const int pl = wave + 4 * j;
+            return make_rsrc(img1 + (size_t)(pl < p.C8in ? pl : 0) * plane_bytes, more && pl < p.C8in ? plane_bytes : 0);
+        };
+        // (no arrays of the descriptor type: k-steps beyond NQ repeat the first and are never used)
+        const __amdgpu_buffer_rsrc_t rs_dma0 = plane_rsrc(0), rs_dma1 = plane_rsrc(NQ > 1 ? 1 : 0), rs_dma2 = plane_rsrc(NQ > 2 ? 2 : 0),
+                                     rs_dma3 = plane_rsrc(NQ > 3 ? 3 : 0);
+        u32x4* dst1 = lds_in + (cur ^ 1) * buf_elems;
+        auto side_dma = [&](int w) __attribute__((always_inline)) {
+            const int j = w / kWsMaxPieces, s = w - j * kWsMaxPieces;
+            const int pl = wave + 4 * j;
+            if (s < ppp)  // wave-uniform (scalar compare + branch); pl < PK = 4 NQ always
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(j == 0 ? rs_dma0 : j == 1 ? rs_dma1 : j == 2 ? rs_dma2 : rs_dma3, (__attribute__((address_space(3))) void*)(dst1 + pl * p.plane + s * 64), 16,
+                                                         piece_rel[s] + row_off1, 0, 0, 0);
+        };
 
         int n, y0;
         tile_pos(t, n, y0);
         const int rows_valid = min(p.R, p.H - y0);
         const unsigned tile_o = (unsigned)n * p.C8out * plane_bytes + (unsigned)(y0 * p.W * 16);
-        unsigned pix_off[PS];
-#pragma unroll
-        for (int ps = 0; ps < PS; ++ps) pix_off[ps] = y_rel[ps] < rows_valid ? tile_o + pix_rel[ps] : kInv;
 
-        f32x4 acc[PS][CSW];
+        // pixel operands: one address per (k-step, window row, pixel tile) - the window column is the instruction's immediate offset
         const char* lbase = reinterpret_cast<const char*>(lds_in + cur * buf_elems);
+        const char* brow[PS];
         u32x4 bv[PS];
 #pragma unroll
-        for (int ps = 0; ps < PS; ++ps) bv[ps] = *reinterpret_cast<const u32x4*>(lbase + b_addr[ps]);
-
-        u32x4 r1p[NP ? NP : 1][PS];
-        u32x2 r1s[PS];
-        u32x4 zp[(STATS == 2 && NP) ? NP : 1][PS], yp[(STATS == 2 && NP) ? NP : 1][PS];
-        u32x2 zs[PS], ys[PS];
+        for (int ps = 0; ps < PS; ++ps) {
+            brow[ps] = lbase + b_addr[ps];
+            bv[ps] = *reinterpret_cast<const u32x4*>(brow[ps]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            if (q == NQ - 1) {
-                // residual tensor (and, backward statistics, the BatchNorm's z / y): requested ahead of the last k-step
-#pragma unroll
-                for (int j = 0; j < NP; ++j)
-#pragma unroll
-                    for (int ps = 0; ps < PS; ++ps) r1p[j][ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, co_off[2 * j] + pix_off[ps], 0, 0);
-                if (NS) {
-#pragma unroll
-                    for (int ps = 0; ps < PS; ++ps) r1s[ps] = __builtin_amdgcn_raw_buffer_load_b64(rs_r, co_off[CSW - 1] + pix_off[ps], 0, 0);
-                }
-                if constexpr (STATS == 2) {
-                    const __amdgpu_buffer_rsrc_t rz = make_rsrc(p.st_z, o_bytes);
-                    const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.st_y ? p.st_y : p.st_z, p.st_y ? o_bytes : 0);
-#pragma unroll
-                    for (int j = 0; j < NP; ++j)
-#pragma unroll
-                        for (int ps = 0; ps < PS; ++ps) {
-                            zp[j][ps] = __builtin_amdgcn_raw_buffer_load_b128(rz, co_off[2 * j] + pix_off[ps], 0, 0);
-                            yp[j][ps] = __builtin_amdgcn_raw_buffer_load_b128(ry, co_off[2 * j] + pix_off[ps], 0, 0);
-                        }
-                    if (NS) {
-#pragma unroll
-                        for (int ps = 0; ps < PS; ++ps) {
-                            zs[ps] = __builtin_amdgcn_raw_buffer_load_b64(rz, co_off[CSW - 1] + pix_off[ps], 0, 0);
-                            ys[ps] = __builtin_amdgcn_raw_buffer_load_b64(ry, co_off[CSW - 1] + pix_off[ps], 0, 0);
-                        }
-                    }
-                }
-            }
 #pragma unroll
             for (int tp = 0; tp < T; ++tp) {
                 // pixel operands of the NEXT tap are requested (one ds_read_b128 each) between this tap's MFMAs; the final prefetch
                 // re-reads the first position (discarded).  The asm MFMAs are ordered statements: source order is issue order
                 const bool first = q == 0 && tp == 0, last = q == NQ - 1 && tp == T - 1;
+                WS_STAMP(t - t_begin == 1 ? 16 + q * T + tp : 64);
                 const int qn = last ? 0 : (tp + 1 < T ? q : q + 1), tn = last ? 0 : (tp + 1 < T ? tp + 1 : 0);
-                const unsigned off_n = (unsigned)(qn * 4 * p.plane + (tn / 3) * P + (tn % 3)) * 16u;
+                const unsigned off_row = (unsigned)(qn * 4 * p.plane + (tn / 3) * P) * 16u;
                 u32x4 bn[PS];
 #pragma unroll
                 for (int ps = 0; ps < PS; ++ps) {
-                    bn[ps] = *reinterpret_cast<const u32x4*>(lbase + b_addr[ps] + off_n);
+                    if (tn % 3 == 0) brow[ps] = lbase + b_addr[ps] + off_row;  // a new window row (or k-step): one add
+                    if (MP_WS_ABLATE & 8) bn[ps] = bv[ps];
+                    else bn[ps] = *reinterpret_cast<const u32x4*>(brow[ps] + (tn % 3) * 16);
 #pragma unroll
                     for (int cs = 0; cs < CSW; ++cs) {
-                        constexpr int dummy = 0;
-                        (void)dummy;
                         const int f = (q * T + tp) * CSW + cs;
                         if (f < NFA) {
                             if (first) mfma_a0(acc[ps][cs], Aa[f < NFA ? f : 0], bv[ps]);
@@ -280,72 +461,95 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_ws_kernel(const ConvF16Para
                             if (first) mfma_v0(acc[ps][cs], Av[f >= NFA ? f - NFA : 0], bv[ps]);
                             else mfma_v(acc[ps][cs], Av[f >= NFA ? f - NFA : 0], bv[ps]);
                         }
+                        // micro-ops in the shadow of this MFMA.  FRONT half of the tile: the previous tile's residual loads, then the
+                        // next tile's DMA pieces, spread evenly - every wave-wide 1 KB vector-memory instruction occupies the CU's
+                        // 64 B/clk address path for 16 cycles, and four waves issuing them back to back stall each other on it
+                        // (ablation: ~100 cycles of wave time per piece at one piece per two MFMAs).  BACK half: the epilogue
+                        // micro-ops, evenly spread, each group ending in its store.  All stores are younger than all DMA pieces.
+                        const int m = ((q * T + tp) * PS + ps) * CSW + cs;
+                        constexpr int NFRONT = NLD + NDMA;
+                        constexpr int E0 = NEPI >= M ? 0 : (M - NEPI < M / 2 ? M - NEPI : M / 2);  // first MFMA of the epilogue stretch
+                        constexpr int FE = E0 > 0 ? E0 : M / 2;                                      // the front jobs end here
+                        constexpr int EMAX = (NEPI + (M - E0) - 1) / (M - E0), FMAX = (NFRONT + FE - 1) / FE;
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (m < FE) {
+                            const int f0 = m * NFRONT / FE, f1 = (m + 1) * NFRONT / FE;
+#pragma unroll
+                            for (int i = 0; i < FMAX; ++i) {
+                                const int f = f0 + i;
+                                if (f >= f1) continue;
+                                if (f < NLD) {
+                                    if (!(MP_WS_ABLATE & 4)) side_load(f);
+                                } else if (!(MP_WS_ABLATE & 2)) side_dma(f - NLD);
+                            }
+                        }
+                        if (m >= E0) {
+                            const int e0 = (m - E0) * NEPI / (M - E0), e1 = (m + 1 - E0) * NEPI / (M - E0);
+#pragma unroll
+                            for (int i = 0; i < EMAX; ++i) {
+                                const int e = e0 + i;
+                                if (e >= e1) continue;
+                                side_epi(e, prev);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
 #pragma unroll
                 for (int ps = 0; ps < PS; ++ps) bv[ps] = bn[ps];
             }
         }
-        // MFMA result -> first VALU read: 4-pass XDL op needs its passes to drain (hipcc pads nothing behind an asm statement)
+        // this tile becomes the one whose side jobs run.  MFMA result -> VALU read: a 4-pass XDL op needs its passes to drain (hipcc
+        // pads nothing behind an asm statement)
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
-
-        // ---- epilogue: scale / shift, residual, ReLU, one rounding, 16-byte stores per cout-tile pair
-        const u32x2 none = (u32x2){0u, 0u};
 #pragma unroll
-        for (int j = 0; j < NP; ++j)
+        for (int ps = 0; ps < PS; ++ps) {
 #pragma unroll
-            for (int ps = 0; ps < PS; ++ps) {
-                const u32x4 a1 = has1 ? r1p[j][ps] : (u32x4){0u, 0u, 0u, 0u};
-                u32x2 lo = f16_pack4(f16_epi4(acc[ps][2 * j], sc[2 * j], sh[2 * j], has1, (u32x2){a1.x, a1.y}, false, none, p.relu));
-                u32x2 hi = f16_pack4(f16_epi4(acc[ps][2 * j + 1], sc[2 * j + 1], sh[2 * j + 1], has1, (u32x2){a1.z, a1.w}, false, none, p.relu));
-                if constexpr (STATS) {
-                    const bool valid = pix_off[ps] != kInv;
-                    if constexpr (STATS == 2) {
-                        const u32x4 zq = zp[j][ps], yq = yp[j][ps];
-                        f16_stats_acc<2>(lo, valid, st_a[2 * j], st_b[2 * j], (u32x2){zq.x, zq.y}, (u32x2){yq.x, yq.y}, p.st_relu);
-                        f16_stats_acc<2>(hi, valid, st_a[2 * j + 1], st_b[2 * j + 1], (u32x2){zq.z, zq.w}, (u32x2){yq.z, yq.w}, p.st_relu);
-                    } else {
-                        f16_stats_acc<1>(lo, valid, st_a[2 * j], st_b[2 * j], lo, lo, 0);
-                        f16_stats_acc<1>(hi, valid, st_a[2 * j + 1], st_b[2 * j + 1], hi, hi, 0);
-                    }
-                }
-                __builtin_amdgcn_raw_buffer_store_b128((u32x4){lo.x, lo.y, hi.x, hi.y}, rs_o, co_off[2 * j] + pix_off[ps], 0, 0);
-            }
-        if (NS) {
-#pragma unroll
-            for (int ps = 0; ps < PS; ++ps) {
-                u32x2 o = f16_pack4(f16_epi4(acc[ps][CSW - 1], sc[CSW - 1], sh[CSW - 1], has1, has1 ? r1s[ps] : none, false, none, p.relu));
-                if constexpr (STATS) {
-                    const bool valid = pix_off[ps] != kInv;
-                    if constexpr (STATS == 2) f16_stats_acc<2>(o, valid, st_a[CSW - 1], st_b[CSW - 1], zs[ps], ys[ps], p.st_relu);
-                    else f16_stats_acc<1>(o, valid, st_a[CSW - 1], st_b[CSW - 1], o, o, 0);
-                }
-                __builtin_amdgcn_raw_buffer_store_b64(o, rs_o, co_off[CSW - 1] + pix_off[ps], 0, 0);
-            }
+            for (int cs = 0; cs < CSW; ++cs)
+                if (!(MP_WS_ABLATE & 32)) prev[ps][cs] = acc_read(acc[ps][cs]);
+            pix_prev[ps] = y_rel[ps] < rows_valid ? tile_o + pix_rel[ps] : kInv;
         }
+        WS_STAMP(t - t_begin < 6 ? 4 + 2 * (t - t_begin) : 64);
     }
+    // the last tile's side jobs, alone
+#pragma unroll
+    for (int l = 0; l < NLD; ++l) side_load(l);
+#pragma unroll
+    for (int e = 0; e < NEPI; ++e) side_epi(e, prev);
+    WS_STAMP(15);
     if constexpr (STATS)
         f16_stats_flush<CSW, WAVES_P, WAVES_C>(st_a, st_b, reinterpret_cast<float*>(smem16), p.st_part, p.st_nparts, grp, ct * CT, p.C8out,
                                                wp_i, wc_i, lq, lr);
 }
 
-template <int NQ, int CSW, int WAVES_P, int PS, int OCC, int STATS>
+template <int NQ, int CSW, int WAVES_P, int PS, int OCC, int STATS, bool RES>
 int launch_ws_kernel(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
-    auto kern = conv_f16_ws_kernel<NQ, CSW, WAVES_P, PS, OCC, STATS>;
+    auto kern = conv_f16_ws_kernel<NQ, CSW, WAVES_P, PS, OCC, STATS, RES>;
     static AttrOnce attr_set_once;
     if (attr_set_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
     }
+#if MP_WS_STAMPS
+    hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(256), lds_bytes, s, p,
+                       (g_ws_stamp_buf && (size_t)p.total_blocks * 64 * 8 <= g_ws_stamp_bytes) ? g_ws_stamp_buf : nullptr);
+#else
     hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(256), lds_bytes, s, p);
+#endif
     return check_launch();
 }
 
 template <int NQ, int CSW, int WAVES_P, int PS, int OCC>
 int launch_ws(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
-    if (p.st_mode == 1) return launch_ws_kernel<NQ, CSW, WAVES_P, PS, OCC, 1>(p, lds_bytes, s);
-    if (p.st_mode == 2) return launch_ws_kernel<NQ, CSW, WAVES_P, PS, OCC, 2>(p, lds_bytes, s);
-    return launch_ws_kernel<NQ, CSW, WAVES_P, PS, OCC, 0>(p, lds_bytes, s);
+    // the residual is a template parameter: its loads and the six vector instructions per 4 couts exist only where there is one
+    const bool res = p.res1 != nullptr;
+#if defined(MP_WS_QUICK) && MP_WS_QUICK  // kernel work: inference builds only (a quarter of the compile time)
+    if (p.st_mode != 0) return MP_ERR_UNSUPPORTED;
+#else
+    if (p.st_mode == 1) return res ? launch_ws_kernel<NQ, CSW, WAVES_P, PS, OCC, 1, true>(p, lds_bytes, s) : launch_ws_kernel<NQ, CSW, WAVES_P, PS, OCC, 1, false>(p, lds_bytes, s);
+    if (p.st_mode == 2) return res ? launch_ws_kernel<NQ, CSW, WAVES_P, PS, OCC, 2, true>(p, lds_bytes, s) : launch_ws_kernel<NQ, CSW, WAVES_P, PS, OCC, 2, false>(p, lds_bytes, s);
+#endif
+    return res ? launch_ws_kernel<NQ, CSW, WAVES_P, PS, OCC, 0, true>(p, lds_bytes, s) : launch_ws_kernel<NQ, CSW, WAVES_P, PS, OCC, 0, false>(p, lds_bytes, s);
 }
 
 struct WsShape { int nq, csw, waves_p, ps, occ; };
@@ -356,7 +560,7 @@ constexpr WsShape kWsShapes[F_WS_COUNT] = {
     {2, 3, 4, 5, 1},  // 48 (W48 branch 1): 48 couts x 320 px
     {2, 4, 4, 3, 1},  // 64: 64 couts x 192 px
     {2, 2, 4, 3, 1},  // 64: two cout slices of 32 x 192 px
-    {3, 3, 2, 4, 1},  // 96 (W48 branch 2): 96 couts x 128 px
+    {3, 2, 4, 5, 1},  // 96 (W48 branch 2): three cout slices of 32 x 320 px
     {3, 3, 4, 3, 1},  // 96: two cout slices of 48 x 192 px
     {4, 2, 2, 3, 1},  // 128: two cout slices of 64 x 96 px
     {4, 2, 1, 6, 1},  // 128: 128 couts x 96 px
@@ -437,7 +641,7 @@ bool f16_configure_ws(const mp_conv_desc& d, int variant, ConvF16Launch& L) {
     p.magic_rin = p.magic_rwo = 0;
     p.ni_used = p.nw_used = 0;
     L.ks = 3; L.stride = 1; L.variant = variant;
-    L.lds_bytes = (size_t)2 * p.in_buf * 16;
+    L.lds_bytes = (size_t)2 * p.in_buf * 16 + (size_t)2 * CT * 4;  // ring + scale / shift of the workgroup's couts
     return true;
 }
 
@@ -447,7 +651,7 @@ int f16_ws_launch(const ConvF16Launch& L, hipStream_t s) {
         case 1: return launch_ws<2, 3, 4, 5, 1>(L.p, L.lds_bytes, s);
         case 2: return launch_ws<2, 4, 4, 3, 1>(L.p, L.lds_bytes, s);
         case 3: return launch_ws<2, 2, 4, 3, 1>(L.p, L.lds_bytes, s);
-        case 4: return launch_ws<3, 3, 2, 4, 1>(L.p, L.lds_bytes, s);
+        case 4: return launch_ws<3, 2, 4, 5, 1>(L.p, L.lds_bytes, s);
         case 5: return launch_ws<3, 3, 4, 3, 1>(L.p, L.lds_bytes, s);
         case 6: return launch_ws<4, 2, 2, 3, 1>(L.p, L.lds_bytes, s);
         case 7: return launch_ws<4, 2, 1, 6, 1>(L.p, L.lds_bytes, s);
@@ -456,3 +660,11 @@ int f16_ws_launch(const ConvF16Launch& L, hipStream_t s) {
 }
 
 }  // namespace mp
+
+#if MP_WS_STAMPS
+extern "C" int mp_debug_set_ws_stamp_buffer(void* dev_ptr, size_t bytes) {  // diagnostic build only (tools/ws_probe.py)
+    mp::g_ws_stamp_buf = reinterpret_cast<unsigned long long*>(dev_ptr);
+    mp::g_ws_stamp_bytes = dev_ptr ? bytes : 0;
+    return MP_OK;
+}
+#endif

@@ -14,7 +14,8 @@ import torch.nn as nn
 from .. import _lib
 
 BN_EPS = 1e-5  # mindspore.nn.BatchNorm2d default eps
-F16_VARIANTS = 45  # csrc/conv_f16.h F_COUNT: tile shapes the fp16 autotuner times per launch shape
+F16_VARIANTS = 48  # csrc/conv_f16.h F_COUNT: tile shapes the fp16 autotuner times per launch shape
+F16_WS_BASE = 37   # csrc/conv_f16.h F_WS_BASE: first weight-stationary persistent shape (conv_f16_ws.hip)
 
 
 class Conv2d(nn.Module):
@@ -264,7 +265,11 @@ def tune_conv_variant(lib, d, x, packed, scale, shift, res1, res2, out, half: bo
     if stats is not None and not any(0 < lib.mp_f16_conv_stats_parts(ctypes.byref(d), v) <= 512 for v in range(F16_VARIANTS)):
         slot_cap[0] = 1 << 30
 
+    no_ws = half and os.environ.get("MINDPOSE_F16_WS", "1") == "0"  # before / after evidence: the round-3 candidate set
+
     def launch(v):
+        if no_ws and v >= F16_WS_BASE:  # (the round-4 weights-in-registers shapes 45.. included)
+            return -3
         if stats is not None:
             n_parts = lib.mp_f16_conv_stats_parts(ctypes.byref(d), v)
             if n_parts <= 0 or n_parts > slot_cap[0]:

@@ -653,7 +653,7 @@ class FuseSum16Fn(torch.autograd.Function):
                                                               _lib.ptr(link.z), _lib.ptr(link.y) if link.relu else None, int(link.relu),
                                                               _lib.ptr(part), part.numel() * 4, _lib.stream()),
                            "mp_f16_fuse_sum_bwd_term_stats")
-                link.partials, link.n_parts = part, n_parts
+                link.hand_over(part, n_parts, dst)
             else:
                 plain[k] = dst
         if any(p is not None for p in plain):
@@ -979,11 +979,27 @@ def _bn_fuse_parts() -> int:
 
 class _BnLink:
     """The last BatchNorm of a chain, as seen by whoever consumes the chain's output: its input z, its output y (mask), whether it
-    has a ReLU.  ``claimed`` counts the consumers of y; ``partials`` is filled by the consumer's data-gradient launch."""
-    __slots__ = ("z", "y", "relu", "claimed", "partials", "n_parts")
+    has a ReLU.  ``claimed`` counts the consumers of y that know about links; ``partials`` is filled by the consumer's data-gradient
+    launch together with ``g``, the pre-masked gradient tensor that launch wrote.  The producer trusts the partial sums only for a
+    gradient that IS that tensor (`_link_pre`): a consumer outside this module (a plain torch op, a hook, an auxiliary loss) never
+    calls `_claim`, but autograd then hands the producer the SUM of two gradients in a fresh tensor - the check fails and the
+    BatchNorm falls back to its own reduce-and-apply pass."""
+    __slots__ = ("z", "y", "relu", "claimed", "partials", "n_parts", "g")
 
     def __init__(self, z, y, relu):
-        self.z, self.y, self.relu, self.claimed, self.partials, self.n_parts = z, y, relu, 0, None, 0
+        self.z, self.y, self.relu, self.claimed, self.partials, self.n_parts, self.g = z, y, relu, 0, None, 0, None
+
+    def hand_over(self, part, n_parts, g):
+        self.partials, self.n_parts, self.g = part, n_parts, g
+
+
+def _link_pre(link, dy):
+    """(partials, n_parts) when ``dy`` is the pre-masked gradient the link's consumer wrote, else None."""
+    if link is None or link.partials is None or link.claimed != 1 or link.g is None:
+        return None
+    if link.g.data_ptr() != dy.data_ptr() or tuple(link.g.shape) != tuple(dy.shape) or link.g.dtype != dy.dtype:
+        return None
+    return link.partials, link.n_parts
 
 
 def _claim(t):
@@ -1170,7 +1186,7 @@ def _chain16_bwd_steps(lib, groups, dy, out_link, in_link, needs_dx, res_is_inpu
     grads = []
     # the gradient reaching the LAST BatchNorm: pre-masked with partial sums when the (only) consumer's data gradient made them
     link = out_link
-    pre = (link.partials, link.n_parts) if (link.partials is not None and link.claimed == 1) else None
+    pre = _link_pre(link, dy)
     dres = None
     for gi in range(len(groups) - 1, -1, -1):
         G = groups[gi]
@@ -1236,7 +1252,7 @@ def _chain16_bwd_steps(lib, groups, dy, out_link, in_link, needs_dx, res_is_inpu
                                                          relu=below[2])
                     if part is not None:
                         if below[3] is not None:
-                            below[3].partials, below[3].n_parts = part, n_parts
+                            below[3].hand_over(part, n_parts, dx)
                         else:
                             pre = (part, n_parts)
                 else:
@@ -1253,7 +1269,7 @@ def _chain16_bwd_steps(lib, groups, dy, out_link, in_link, needs_dx, res_is_inpu
                                                      below=use[:3] if use is not None else None)
                     if part is not None:
                         if use[3] is not None:
-                            use[3].partials, use[3].n_parts = part, n_parts
+                            use[3].hand_over(part, n_parts, dx)
                         else:
                             pre = (part, n_parts)
                 else:
@@ -1387,7 +1403,7 @@ class FanOutFn(torch.autograd.Function):
             _lib.check(lib.mp_f16_sum_tensors_stats(_lib.ptr(ops[0]), _lib.ptr(ops[1]), _lib.ptr(ops[2]), _lib.ptr(ops[3]), _lib.ptr(dst),
                                                     _lib.ptr(link.z), _lib.ptr(link.y) if link.relu else None, int(link.relu), n, c8 * 8,
                                                     h * w, _lib.ptr(part), part.numel() * 4, _lib.stream()), "mp_f16_sum_tensors_stats")
-            link.partials, link.n_parts = part, n_parts
+            link.hand_over(part, n_parts, dst)
             return dst, None, None
         out = gs[0]
         for i in range(1, len(gs), 3):  # up to four operands per launch (the running sum + three more)

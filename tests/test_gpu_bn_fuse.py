@@ -521,3 +521,40 @@ def test_link_is_dropped_when_a_tensor_has_two_consumers(monkeypatch):
         gf, gr = run(two, True), run(two, False)
         cos = float(torch.nn.functional.cosine_similarity(gf.double(), gr.double(), dim=0))
         assert cos > 0.9999, (two, cos)
+
+
+def test_link_hand_over_is_checked_against_the_gradient_tensor(monkeypatch):
+    """A consumer that never announces itself (a plain torch op on the channel-blocked activation: an auxiliary loss, a hook) leaves
+    ``claimed`` at 1, but autograd then SUMS its gradient with the chain's pre-masked one.  The producer must notice that the
+    gradient it receives is not the tensor the consumer's data-gradient launch wrote, and reduce for its BatchNorm itself."""
+    from mindpose_amd.models import train_ops as T
+    from mindpose_amd.models.layers import BatchNorm2d, Conv2d
+    torch.manual_seed(2)
+
+    def mk(cin, cout):
+        cv, bn = Conv2d(cin, cout, 3, padding=1), BatchNorm2d(cout)
+        torch.nn.init.normal_(cv.weight, std=(2.0 / (9 * cin)) ** 0.5)
+        return cv.to(DEV), bn.to(DEV)
+
+    (c0, b0), (c1, b1) = mk(16, 32), mk(32, 32)
+    x = torch.randn(2, 16, 16, 12, device=DEV)
+
+    def run(aux, fused):
+        monkeypatch.setenv("MINDPOSE_BN_FUSE", "1" if fused else "0")
+        for m in (c0, b0, c1, b1):
+            for p in m.parameters():
+                p.grad = None
+        a = T.conv_bn_act(T.to_c8(x), c0, b0, relu=True)
+        link = getattr(a, "_mp_bn_link", None)
+        loss = T.from_c8(T.conv_bn_act(a, c1, b1, relu=True), 32).square().mean()
+        if aux:
+            loss = loss + 0.37 * a.float().square().mean()  # plain torch on the c8 tensor: no _claim
+        loss.backward()
+        if fused:
+            assert link.claimed == 1 and link.partials is not None  # the consumer did hand over ...
+        return torch.cat([p.grad.flatten() for m in (c0, b0, c1, b1) for p in m.parameters()])
+
+    for aux in (False, True):
+        gf, gr = run(aux, True), run(aux, False)
+        cos = float(torch.nn.functional.cosine_similarity(gf.double(), gr.double(), dim=0))
+        assert cos > 0.9999, (aux, cos)  # ... and with the extra consumer the producer did not use it

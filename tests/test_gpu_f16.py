@@ -145,11 +145,14 @@ WREG_CASES = [
     (3, 32, 32, 3, 1, 64, 48, True, 1),     # branch 0: pixel-split waves (W4), one k-step (no refill), 8-row bands
     (2, 48, 48, 3, 1, 24, 16, True, 1),     # W48 widths: three cout tiles, cin padded 48 -> 64
     (2, 96, 96, 3, 1, 24, 18, True, 0),     # W48 branch 1: W2 with three cout tiles per wave
+    (3, 192, 192, 3, 1, 24, 18, True, 1),   # W48 branch 2 at config 5's map: P7C3 = 6-row bands, four per image
+    (3, 384, 384, 3, 1, 12, 9, True, 1),    # W48 branch 3 at config 5's map: P4C3 = 7-row bands (7 + 5 rows), two cout slices
+    (2, 256, 256, 3, 1, 10, 8, False, 1),   # P5C4: 256 couts per workgroup, 80-px bands
 ]
 
 
 @pytest.mark.parametrize("case", WREG_CASES)
-@pytest.mark.parametrize("variant", list(range(25, 37)))
+@pytest.mark.parametrize("variant", list(range(25, 37)) + [45, 46, 47])
 def test_conv_f16_wreg_vs_oracle_and_bit_identical_to_tile_kernel(case, variant):
     """The weights-in-registers kernel (LDS-DMA input tile, weight fragments streamed from global memory) against the oracle,
     and bit for bit against the one-tile kernel: same k order, same epilogue arithmetic."""

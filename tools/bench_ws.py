@@ -10,7 +10,8 @@ from mindpose_amd.models.layers import ActC8, F16_VARIANTS
 lib = _lib.load(); dev = torch.device("cuda:0")
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 W32 = [(128, 32, 32, 64, 48), (128, 64, 64, 32, 24), (128, 128, 128, 16, 12)]
-W48 = [(64, 48, 48, 96, 72), (64, 96, 96, 48, 36), (64, 192, 192, 24, 18), (128, 48, 48, 64, 48), (128, 96, 96, 32, 24)]
+W48 = [(64, 48, 48, 96, 72), (64, 96, 96, 48, 36), (64, 192, 192, 24, 18), (64, 384, 384, 12, 9), (128, 48, 48, 64, 48), (128, 96, 96, 32, 24),
+       (128, 192, 192, 16, 12), (128, 256, 256, 8, 6)]
 SHAPES = W32 if which == "w32" else W48 if which == "w48" else W32 + W48
 k = 3
 for nn, cin, cout, h, w in SHAPES:
@@ -49,7 +50,8 @@ for nn, cin, cout, h, w in SHAPES:
     gf = 2 * nn * h * w * cout * cin * k * k / 1e9
     mb = nn * h * w * 2 * ((cin + 7) // 8 * 8 + 2 * ((cout + 7) // 8 * 8)) / 1e6
     old = min((t, v) for v, t in med.items() if v < 37)
-    new = min(((t, v) for v, t in med.items() if v >= 37), default=(float("nan"), -1))
-    print(f"{cin:3d}->{cout:3d} {h}x{w} N={nn} ({gf:.2f} GFLOP, {mb:.0f} MB): best other v{old[1]} {old[0]:6.1f} us ({gf / old[0] * 1e-3:6.1f} TF) | "
-          f"weight-stationary v{new[1]} {new[0]:6.1f} us ({gf / new[0] * 1e-3:6.1f} TF, {mb / new[0] * 1e-3:.2f} TB/s) | ws: "
-          + " ".join(f"v{v}:{t:.1f}" for v, t in sorted(med.items()) if v >= 37), flush=True)
+    new = min(((t, v) for v, t in med.items() if 37 <= v < 45), default=(float("nan"), -1))
+    print(f"{cin:3d}->{cout:3d} {h}x{w} N={nn} ({gf:.2f} GFLOP, {mb:.0f} MB): best other v{old[1]} {old[0]:6.1f} us ({gf / old[0] * 1e3:6.1f} TF) | "
+          f"weight-stationary v{new[1]} {new[0]:6.1f} us ({gf / new[0] * 1e3:6.1f} TF, {mb / new[0]:.2f} TB/s) | ws: "
+          + " ".join(f"v{v}:{t:.1f}" for v, t in sorted(med.items()) if 37 <= v < 45) + " | wreg round 4: "
+          + " ".join(f"v{v}:{t:.1f}" for v, t in sorted(med.items()) if v >= 45), flush=True)
