@@ -79,8 +79,13 @@ def kernel_name(info):
         return {0: "basicblock_f16_kernel<6,5>", 1: "basicblock_f16_kernel<5,3>", 2: "basicblock_f16_v2_kernel<8,4,3>", 3: "basicblock_f16_v2_kernel<4,5,3>"}[info["variant"]]
     if info["kind_id"] == 3:
         v = info["variant"]
+        if 37 <= v < 45:  # weight-stationary persistent kernel <k-steps, cout tiles per wave, pixel-splitting waves, pixel tiles, waves/SIMD
+            # bound> (csrc/conv_f16_ws.hip kWsShapes; rocprof lists two more arguments: statistics mode, residual)
+            nq, csw, wp, ps, occ = {37: (1, 2, 4, 3, 2), 38: (2, 3, 4, 5, 1), 39: (2, 4, 4, 3, 1), 40: (2, 2, 4, 3, 1), 41: (3, 2, 4, 5, 1),
+                                    42: (3, 3, 4, 3, 1), 43: (4, 2, 2, 3, 1), 44: (4, 2, 1, 6, 1)}[v]
+            return f"conv_f16_ws_kernel<{nq},{csw},{wp},{ps},{occ}>"
         if v >= 25:  # weights-in-registers kernel <KS, pixel tiles, cout tiles per wave, waves/SIMD bound>
-            ps, csw, wp, occ = {25: (6, 2, 1, 1), 26: (3, 2, 1, 2), 27: (6, 1, 1, 2), 28: (6, 3, 1, 1), 29: (3, 3, 1, 1), 30: (3, 4, 1, 1),
+            ps, csw, wp, occ = {45: (7, 3, 1, 1), 46: (4, 3, 1, 1), 47: (5, 4, 1, 1), 25: (6, 2, 1, 1), 26: (3, 2, 1, 2), 27: (6, 1, 1, 2), 28: (6, 3, 1, 1), 29: (3, 3, 1, 1), 30: (3, 4, 1, 1),
                                 31: (6, 2, 2, 2), 32: (6, 3, 2, 1), 33: (3, 2, 2, 2), 34: (6, 2, 4, 2), 35: (6, 3, 4, 1), 36: (3, 2, 4, 2)}[v]
             return f"conv_f16_wreg_kernel<{info['ks']},{info['stride']},{ps},{csw},{wp},{occ}>"  # = the rocprof template list
         if v == 24:  # 32 couts x 384 pixels, single-chunk build
@@ -339,6 +344,61 @@ def cpu_baseline(state_dict, mp, dev):
                                   "gpu_samples_per_s": round(n_t / gpu_t, 1), "gpu_us_per_batch_128": round(gpu_t * 1e6, 2),
                                   "gpu_write_GBps": round(target_bytes / gpu_t / 1e9, 1),
                                   "gpu_what": "mp_gaussian_target, 128 x 17 x 64x48 fp32 heat-maps written once (HBM-bound, 8 TB/s peak)"}}
+
+
+def hbm_ops_report(mp, dev, n=128):
+    """The HBM-bound rows of the path at N = 128, 17 x 64x48 fp32 heat-maps: device time per call (HIP events,
+    50 calls after 5 warm-ups, through the host mirror's own wrappers), ALGORITHMIC bytes per call (each tensor read /
+    written once) and the fraction of the 8 TB/s HBM peak they amount to."""
+    from mindpose_amd.engine.inferencer.topdown_inferencer import COCO_FLIP_INDEX
+    g = torch.Generator(device="cpu").manual_seed(7)
+    k, h, w = 17, 64, 48
+    hm_bytes = n * k * h * w * 4
+    hm = torch.rand(n, k, h, w, generator=g).to(dev)
+    hf = torch.rand(n, k, h, w, generator=g).to(dev)
+    tgt = torch.rand(n, k, h, w, generator=g).to(dev)
+    wgt = (torch.rand(n, k, generator=g) < 0.7).float().to(dev)
+    center = (torch.rand(n, 2, generator=g) * 400).to(dev)
+    scale = (torch.rand(n, 2, generator=g) * 2.7 + 0.3).to(dev)
+    score = torch.rand(n, generator=g).to(dev)
+    flip_index = torch.as_tensor(np.array(COCO_FLIP_INDEX), dtype=torch.int32, device=dev)
+    dec_shift = mp.create_decoder("topdown_heatmap", shift_coordinate=True).to(dev)
+    dec_dark = mp.create_decoder("topdown_heatmap", use_udp=True, dark_udp_refine=True, kernel_size=11).to(dev)
+    crit = mp.create_loss("joint_mse", use_target_weight=True)
+    pred = hm.clone().requires_grad_(True)
+
+    def timed(fn, reps=50):
+        for _ in range(5):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    def fwd_bwd():
+        pred.grad = None
+        crit(pred, tgt, wgt).backward()
+
+    t_fwd = timed(lambda: crit(pred.detach(), tgt, wgt))
+    t_fb = timed(fwd_bwd)
+    rows = {
+        "decode_argmax_shift": (timed(lambda: dec_shift(hm, center, scale, score)), hm_bytes,
+                                "mp_decode_topdown (decode_kernel<false>): arg-max + quarter-pixel shift + transform, a11 / a12 / a14"),
+        "decode_dark_udp": (timed(lambda: dec_dark(hm, center, scale, score)), hm_bytes,
+                            "mp_decode_topdown (decode_kernel<true>): arg-max + DARK / UDP refinement (11x11 blur of the 3x3 neighbourhood), a13"),
+        "flip_aggregate_decode": (timed(lambda: dec_shift.decode_flip_aggregated(hm, hf, flip_index, True, center, scale, score)),
+                                  2 * hm_bytes, "mp_flip_aggregate_decode: flip back + shift + average + decode in one kernel, a15"),
+        "joints_mse_fwd": (t_fwd, 2 * hm_bytes, "mp_joints_mse_fwd (mse_row + mse_final): weighted squared error, fixed-order reduction, a10"),
+        "joints_mse_bwd": (max(t_fb - t_fwd, 1e-9), 3 * hm_bytes,
+                           "mp_joints_mse_bwd: 2 w (p - t) / (N K H W); time = (forward + backward through autograd) - forward, a10"),
+    }
+    return {"batch": n, "heatmaps": f"{k}x{h}x{w} fp32", "hbm_peak_GBps": 8000.0,
+            "timing": "HIP events on the launch stream around 50 calls after 5 warm-ups; bytes = algorithmic (each tensor once)",
+            "ops": {name: {"us": round(t * 1e6, 2), "algorithmic_bytes": b, "GBps": round(b / t / 1e9, 1),
+                           "frac_of_hbm_peak": round(b / t / 8e12, 4), "what": what} for name, (t, b, what) in rows.items()}}
 
 
 class CallTimer:
@@ -714,6 +774,13 @@ EXTRA_LEGS = {
     "config1_simplebaseline_r50_256x192_infer_f32": ["--workload", "simplebaseline_r50", "--batch", "128", "--steps", "20", "--warmup", "5"],
     "config3_hrnet_w32_train_f32": ["--workload", "hrnet_w32_train", "--batch", "128", "--steps", "20", "--warmup", "5"],
     "config3_hrnet_w32_train_ampO2": ["--workload", "hrnet_w32_train", "--amp", "O2", "--batch", "128", "--steps", "20", "--warmup", "5"],
+    # SURVEY 8(d) configs 2 / 3, BASELINE.md 3: the batch sweep N in {1, 32, 256} beside the N = 128 lines above (one child per
+    # precision / model; every N is its own tuned plan, 20 timed steps after 5 warm-ups)
+    "batch_sweep_hrnet_w32_f32": ["--workload", "hrnet_w32", "--sweep", "1,32,256", "--steps", "20", "--warmup", "5", "--no-roofline"],
+    "batch_sweep_hrnet_w32_ampO2": ["--workload", "hrnet_w32", "--amp", "O2", "--sweep", "1,32,256", "--steps", "20", "--warmup", "5",
+                                    "--no-roofline"],
+    "batch_sweep_simplebaseline_r50_f32": ["--workload", "simplebaseline_r50", "--sweep", "1,32,256", "--steps", "20", "--warmup", "5",
+                                           "--no-roofline"],
 }
 
 
@@ -737,6 +804,10 @@ def run_extra_legs(selected=None, timeout_s=240):
                 out[name] = {"error": f"rc {proc.returncode}", "stdout_tail": proc.stdout[-400:]}
                 continue
             r = json.loads(line)
+            if "sweep" in r:
+                out[name] = {"sweep": r["sweep"], "unit": r["unit"], "dtype": r["dtype"], "steps": r["steps"], "warmup": r["warmup"],
+                             "workload": r["config"]["workload"], "leg_wall_s": round(time.perf_counter() - t0, 1)}
+                continue
             rl = r.get("roofline") or {}
             out[name] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
                          "warmup": r["warmup"], "dtype": r["dtype"], "per_gpu_batch": r["config"].get("per_gpu_batch"),
@@ -754,6 +825,34 @@ def run_extra_legs(selected=None, timeout_s=240):
         except (ValueError, KeyError) as exc:
             out[name] = {"error": f"unparsable leg output: {exc}"}
     return out
+
+
+def sweep_bench(args, mp, net, eval_net, dev, size, workload_desc, world, rank):
+    """`--sweep 1,32,256`: the same inference step at several per-GPU batch sizes, one tuned launch plan each (no flip test)."""
+    ih, iw = size
+    rows = {}
+    for n in [int(v) for v in args.sweep.split(",") if v]:
+        gen = torch.Generator(device="cpu").manual_seed(1000 + rank)
+        image = net.input_buffer((n, 3, ih, iw), dev)
+        image.copy_(torch.randn(n, 3, ih, iw, generator=gen))
+        center = (torch.rand(n, 2, generator=gen) * 400).to(dev)
+        scale = (torch.rand(n, 2, generator=gen) * 2.7 + 0.3).to(dev)
+        score = torch.rand(n, generator=gen).to(dev)
+        plan_len = len(net.get_plan((n, 3, ih, iw), dev))
+        for _ in range(args.warmup):
+            eval_net(image, center, scale, score)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eval_net(image, center, scale, score)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rows[str(n)] = {"images_per_s": round(n * args.steps / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 3), "launches": plan_len}
+        log(f"sweep N={n}: {rows[str(n)]['images_per_s']} img/s ({rows[str(n)]['ms_per_step']} ms/step)")
+    if rank == 0:
+        print(json.dumps({"metric": f"images/sec, {args.workload} top-down inference (backbone+head+decode), batch sweep", "sweep": rows,
+                          "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "dtype": "f32" if args.amp == "O0" else "f16", "data": "synthetic", "config": {"workload": workload_desc}}))
 
 
 def spawn_ranks(n):
@@ -787,6 +886,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_workloads legs (N=1 headline runs only)")
     ap.add_argument("--extra", default="", help="comma-separated subset of the extra legs to run (default: all)")
     ap.add_argument("--leg", action="store_true", help="this process IS an extra leg: no CPU baseline, no further legs")
+    ap.add_argument("--sweep", default="", help="comma-separated per-GPU batch sizes: time each (its own plan) and report them all")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -828,13 +928,22 @@ def main():
         from mindpose_amd.engine.inferencer.topdown_inferencer import COCO_FLIP_INDEX, _MultiRunNet
         multi_run = _MultiRunNet(eval_net, decoder, np.array(COCO_FLIP_INDEX), shift_heatmap=False).to(dev)
 
+    if args.sweep:
+        return sweep_bench(args, mp, net, eval_net, dev, (ih, iw), workload_desc, world, rank)
     n = args.batch
+    # the flip test runs ONE forward of the 2N batch [crops | mirrors] (layers.py forward_flip_pair; MINDPOSE_FLIP_BATCHED=0: two of N)
+    from mindpose_amd.models.layers import flip_pair_batched
+    n_plan = 2 * n if flip and args.amp != "O0" and flip_pair_batched() else n  # (fp32 keeps the two forwards: topdown_inferencer.py)
+    passes = 2 if flip and n_plan == n else 1
     # synthetic crops written straight into the plan's resident input buffer (inputs in HBM before timing)
     gen = torch.Generator(device="cpu").manual_seed(1000 + rank)
-    image = net.input_buffer((n, 3, ih, iw), dev)
+    if n_plan != n:
+        image = net.input_buffer((n_plan, 3, ih, iw), dev)[:n]  # the crops' half of the 2N plan's input; the mirrors are written per step
+    else:
+        image = net.input_buffer((n, 3, ih, iw), dev)
     image.copy_(torch.randn(n, 3, ih, iw, generator=gen))
-    if flip:
-        image = image.clone()  # the flip test runs two forwards through the same plan input buffer
+    if flip and n_plan == n:
+        image = image.clone()  # the two-forward flip test runs both through the same plan input buffer
     center = (torch.rand(n, 2, generator=gen) * 400).to(dev)
     scale = (torch.rand(n, 2, generator=gen) * 2.7 + 0.3).to(dev)
     score = torch.rand(n, generator=gen).to(dev)
@@ -850,7 +959,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    plan_len = mp.models.tune_on_rank0_first(lambda: len(net.get_plan((n, 3, ih, iw), dev)))  # rank 0 tunes, one broadcast, the rest replay
+    plan_len = mp.models.tune_on_rank0_first(lambda: len(net.get_plan((n_plan, 3, ih, iw), dev)))  # rank 0 tunes, one broadcast, the rest replay
     log(f"rank {rank}: plan built ({plan_len} launches), warming up")
     for _ in range(args.warmup):
         step()
@@ -869,7 +978,7 @@ def main():
     log(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step")
     result = None
     if rank == 0:
-        plan = net.get_plan((n, 3, ih, iw), dev)
+        plan = net.get_plan((n_plan, 3, ih, iw), dev)
         result = {
             "metric": ("images/sec at 256x192, HRNet-W32 top-down inference (backbone+head+decode)" if args.workload == "hrnet_w32"
                        else f"images/sec, {args.workload} top-down inference (backbone+head+decode)"),
@@ -879,14 +988,18 @@ def main():
             "config": {"workload": workload_desc,
                        "per_gpu_batch": n, "global_batch": n * world, "image": f"{ih}x{iw}", "heatmap": f"{ih // 4}x{iw // 4}x17",
                        "sharding": "crops split over ranks, no data-path collective",
-                       "gflop_per_image": round(2e-9 * plan.total_macs / n * (2 if flip else 1), 3),
-                       "launches_per_step": (sum(1 for e in plan.layer_info if e["kind"] != "barrier") + 1) * (2 if flip else 1),
+                       "gflop_per_image": round(2e-9 * plan.total_macs / n * passes, 3),
+                       "launches_per_step": (sum(1 for e in plan.layer_info if e["kind"] != "barrier") + 1) * passes,
+                       "flip_test": (f"one forward of {n_plan} = [{n} crops | {n} mirrors]" if n_plan != n else f"two forwards of {n}") if flip
+                       else None,
                        "execution_lanes": 4 if any(e["kind"] == "barrier" for e in plan.layer_info) else 1},
         }
         if not args.no_roofline:
             result["roofline"] = roofline_report(plan, layers_csv=args.layers, workload=args.workload)
             log("roofline done")
         headline = world == 1 and args.workload == "hrnet_w32" and args.amp == "O0" and not args.leg
+        if headline:
+            result["hbm_ops"] = hbm_ops_report(mp, dev)
         if headline and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(net.state_dict(), mp, dev)
         if headline and not args.no_extra:

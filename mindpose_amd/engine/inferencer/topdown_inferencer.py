@@ -13,6 +13,7 @@ import torch.nn as nn
 
 from ...models import EvalNet
 from ...models.decoders import TopDownHeatMapDecoder
+from ...models.layers import flip_pair_batched
 from ...register import register
 
 
@@ -38,6 +39,13 @@ class _MultiRunNet(nn.Module):
     def forward(self, image: torch.Tensor, center: torch.Tensor, scale: torch.Tensor,
                 score: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         raw_net = self.net.net  # EvalNet.net: backbone + head
+        # planned network under amp O2 / O3: both runs as ONE 2N-crop forward.  The fp16 kernels give the same bits whatever the tile
+        # shape, so this equals the reference's two forwards bit for bit; the fp32 candidates (Winograd / direct / GEMM forms) do not,
+        # and the tuner may pick another form for the 2N shapes - fp32 keeps the two forwards
+        if hasattr(raw_net, "forward_flip_pair") and getattr(raw_net, "amp_level", "O0") != "O0" and flip_pair_batched():
+            both = raw_net.forward_flip_pair(image)
+            n = image.shape[0]
+            return self.decoder.decode_flip_aggregated(both[:n], both[n:], self.flip_index, self.shift_heatmap, center, scale, score)
         heatmap = raw_net(image).clone()  # the plan's output buffer is reused by the second run
         if hasattr(raw_net, "get_plan"):  # planned network: the mirror goes straight into its input buffer (mp_flip_width)
             flipped = raw_net(image, flip_width=True)

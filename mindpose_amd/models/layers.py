@@ -761,6 +761,30 @@ class PlannedModule(nn.Module):
         plan.run()
         return plan.output
 
+    def forward_flip_pair(self, x: torch.Tensor) -> torch.Tensor:
+        """The flip test's two runs (topdown_inferencer.py:168-170: ``net(img)``, ``net(flip_W(img))``) as ONE forward of the batch
+        [x | mirror(x)]: ``mp_flip_width`` writes the mirrored crops straight into the second half of a 2N plan's input buffer.
+        Returns the [2N, K, h, w] output (first N = the crops, last N = their mirrors).  Every sample's arithmetic is what the
+        N-crop plan does (inference BatchNorm is per sample); the persistent kernels amortise their weight prologue over twice
+        the tiles and the step has half the launches."""
+        x = _lib.require_cuda_f32(x, "input")
+        if self.training:
+            raise ValueError("the flip test is an inference-time path")
+        n, c, h, w = x.shape
+        plan = self.get_plan((2 * n, c, h, w), x.device)
+        first, second = plan.input[:n], plan.input[n:]
+        if x.data_ptr() != first.data_ptr():
+            first.copy_(x)
+        _lib.check(plan.lib.mp_flip_width(_lib.ptr(first), _lib.ptr(second), n, c, h, w, _lib.stream()), "mp_flip_width")
+        plan.run()
+        return plan.output
+
+
+def flip_pair_batched() -> bool:
+    """``MINDPOSE_FLIP_BATCHED=0``: the flip test runs two forwards of N crops through one plan (rounds 1 - 3) instead of ONE
+    forward of the 2N-crop batch [crops | mirrored crops]."""
+    return os.environ.get("MINDPOSE_FLIP_BATCHED", "1") != "0"
+
 
 def auto_mixed_precision(network: nn.Module, amp_level: str = "O0") -> nn.Module:
     """``mindspore.amp.auto_mixed_precision(network, amp_level)`` for the planned networks (what

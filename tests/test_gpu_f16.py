@@ -431,6 +431,27 @@ def test_config5_w48_384x288_udp_dark_flip_fp16():
     assert np.mean(dd < 0.25 * px) > 0.9
 
 
+def test_flip_test_as_one_batched_forward_equals_two_forwards(monkeypatch):
+    """The flip test as ONE forward of [crops | mirrors] (PlannedModule.forward_flip_pair, the default) against the reference's
+    two forwards (topdown_inferencer.py:168-170; MINDPOSE_FLIP_BATCHED=0): the fp16 kernels are bit-identical across tile shapes
+    and inference BatchNorm is per sample, so key points and boxes must agree bit for bit."""
+    from tests.golden import recipes
+    from mindpose_amd.engine.inferencer.topdown_inferencer import _MultiRunNet
+    net = _net("hrnet_w32")
+    mp.models.auto_mixed_precision(net, "O2")
+    dec = mp.create_decoder("topdown_heatmap", shift_coordinate=True).to(DEV)
+    ev = mp.create_eval_network(net, dec, output_raw=True)
+    mr = _MultiRunNet(ev, dec, np.array(recipes.FLIP_INDEX), shift_heatmap=True).to(DEV)
+    x = torch.randn(3, 3, 256, 192, generator=torch.Generator().manual_seed(9)).to(DEV)
+    center, scale, score = (torch.from_numpy(a).to(DEV) for a in recipes.boxes(3, 4))
+    monkeypatch.setenv("MINDPOSE_FLIP_BATCHED", "1")
+    p1, b1 = mr(x, center, scale, score)
+    a1 = dec.last_argmax.clone()
+    monkeypatch.setenv("MINDPOSE_FLIP_BATCHED", "0")
+    p0, b0 = mr(x, center, scale, score)
+    assert torch.equal(a1, dec.last_argmax) and torch.equal(p1, p0) and torch.equal(b1, b0)
+
+
 def _block_pair(n, c, h, w, seed):
     """Inputs of one BasicBlock plus the two-launch result (mp_f16_conv2d_fwd x 2, heuristic variant)."""
     g = torch.Generator().manual_seed(seed)

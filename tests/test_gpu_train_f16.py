@@ -263,50 +263,6 @@ def test_fuse_sum_f16_bwd_vs_torch():
         _close16(_from_c8(t), _h(leaf.grad), "dt")
 
 
-def test_hrnet_w32_o2_training_step_vs_fp32_path():
-    """amp O2 training graph (fp16 matrix-core convs / activations, fp32 statistics and parameter gradients, loss scaling)
-    against the fp32 HIP training path, which tests/test_gpu_train.py pins to an fp64 oracle.  fp16 activations and
-    activation gradients perturb every ReLU mask and batch statistic a little, so tensor-wise equality is not the bar:
-    the loss must agree to 1e-2, every parameter gradient must point the same way (cosine > 0.95 per tensor, > 0.98 over
-    all 28.5 M values), the head's must agree to 5e-3."""
-    import numpy as np
-    import mindpose_amd as mp
-    torch.manual_seed(0)
-    net = mp.init_synthetic(mp.create_network("hrnet_w32", "hrnet_head"), seed=0).to(DEV).train()
-    g = torch.Generator().manual_seed(11)
-    x = torch.randn(4, 3, 128, 96, generator=g).to(DEV)
-    kp = (torch.rand(4, 17, 3, generator=g) * torch.tensor([96.0, 128.0, 2.0])).to(DEV)
-    tgt = mp.TopDownGenerateTarget(config=dict(image_size=[96, 128], heatmap_size=[24, 32]), sigma=2.0)
-    target, weight = tgt(kp)
-    nwl = mp.create_network_with_loss(net, mp.create_loss("joint_mse", use_target_weight=True), has_extra_inputs=True)
-    loss32 = nwl(x, target, weight)
-    loss32.backward()
-    g32 = {k: v.grad.detach().clone() for k, v in net.named_parameters()}
-    for v in net.parameters():
-        v.grad = None
-    mp.models.auto_mixed_precision(net, "O2")
-    scale = 1024.0
-    loss16 = nwl(x, target, weight)
-    assert loss16.dtype == torch.float32
-    (loss16 * scale).backward()
-    assert abs(float(loss16.detach()) - float(loss32.detach())) <= 1e-2 * abs(float(loss32.detach()))
-    cos, rel = {}, {}
-    for k, v in net.named_parameters():
-        assert v.grad is not None and v.grad.dtype == torch.float32 and torch.isfinite(v.grad).all(), k
-        a, b = (v.grad / scale).double().flatten(), g32[k].double().flatten()
-        cos[k] = float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-300))
-        rel[k] = float((a - b).abs().max() / b.abs().max().clamp_min(1e-300))
-    allg16 = torch.cat([(v.grad / scale).double().flatten() for v in net.parameters()])
-    allg32 = torch.cat([g32[k].double().flatten() for k, _ in net.named_parameters()])
-    gcos = float((allg16 @ allg32) / (allg16.norm() * allg32.norm()))
-    med = float(np.median(list(cos.values())))
-    print(f"O2 vs fp32 gradients: global cosine {gcos:.5f}, per-tensor cosine median {med:.5f} min {min(cos.values()):.4f}; "
-          f"rel err median {float(np.median(list(rel.values()))):.3e}; loss {float(loss16.detach())} vs {float(loss32.detach())}")
-    print({n: rel[n] for n in ("head.head.weight", "head.head.bias", "backbone.stage4.2.fuse_layers.0.3.0.weight")})
-    assert gcos > 0.98 and med > 0.99 and min(cos.values()) > 0.95
-    assert rel["head.head.weight"] < 5e-3 and rel["head.head.bias"] < 5e-3  # one layer from the loss: tight
-    assert rel["backbone.stage4.2.fuse_layers.0.3.0.weight"] < 6e-2        # a few fp16 layers deep
-
 
 def test_o2_optimizer_steps_with_dynamic_loss_scale():
     import mindpose_amd as mp
