@@ -347,10 +347,13 @@ def cpu_baseline(state_dict, mp, dev):
 
 
 def hbm_ops_report(mp, dev, n=128):
-    """The HBM-bound rows of the path at N = 128, 17 x 64x48 fp32 heat-maps: device time per call (HIP events,
-    50 calls after 5 warm-ups, through the host mirror's own wrappers), ALGORITHMIC bytes per call (each tensor read /
-    written once) and the fraction of the 8 TB/s HBM peak they amount to."""
+    """The HBM-bound rows of the path at N = 128, 17 x 64x48 fp32 heat-maps: device time per launch (HIP events
+    around 50 back-to-back calls of the C-ABI entry on preallocated buffers, after 5 warm-ups - the host mirror's wrappers allocate
+    their outputs per call and would time the host), ALGORITHMIC bytes per launch (each tensor read / written once) and
+    the fraction of the 8 TB/s HBM peak they amount to."""
+    from mindpose_amd import _lib
     from mindpose_amd.engine.inferencer.topdown_inferencer import COCO_FLIP_INDEX
+    lib = _lib.load()
     g = torch.Generator(device="cpu").manual_seed(7)
     k, h, w = 17, 64, 48
     hm_bytes = n * k * h * w * 4
@@ -362,14 +365,38 @@ def hbm_ops_report(mp, dev, n=128):
     scale = (torch.rand(n, 2, generator=g) * 2.7 + 0.3).to(dev)
     score = torch.rand(n, generator=g).to(dev)
     flip_index = torch.as_tensor(np.array(COCO_FLIP_INDEX), dtype=torch.int32, device=dev)
-    dec_shift = mp.create_decoder("topdown_heatmap", shift_coordinate=True).to(dev)
     dec_dark = mp.create_decoder("topdown_heatmap", use_udp=True, dark_udp_refine=True, kernel_size=11).to(dev)
-    crit = mp.create_loss("joint_mse", use_target_weight=True)
-    pred = hm.clone().requires_grad_(True)
+    dec_shift = mp.create_decoder("topdown_heatmap", shift_coordinate=True).to(dev)
+    preds = torch.empty(n, k, 3, device=dev)
+    boxes = torch.empty(n, 6, device=dev)
+    argmax = torch.empty(n, k, device=dev, dtype=torch.int32)
+    grad = torch.empty_like(hm)
+    loss = torch.empty(1, device=dev)
+    go = torch.ones(1, device=dev)
+    ws_bytes = lib.mp_joints_mse_workspace_bytes(n, k)
+    ws = torch.empty(ws_bytes // 4, device=dev)
+    st = _lib.stream()
+
+    def decode(dec):
+        return lambda: lib.mp_decode_topdown(_lib.ptr(hm), _lib.ptr(center), _lib.ptr(scale), _lib.ptr(score), _lib.ptr(preds), _lib.ptr(boxes),
+                                             _lib.ptr(argmax), n, k, h, w, dec.refine_mode, int(dec.use_udp), int(dec.to_original),
+                                             float(dec.pixel_std), _lib.ptr(dec._blur_on(dev)), int(dec.kernel_size), st)
+
+    def flip_decode():
+        return lib.mp_flip_aggregate_decode(_lib.ptr(hm), _lib.ptr(hf), _lib.ptr(flip_index), 1, None, _lib.ptr(center), _lib.ptr(scale),
+                                            _lib.ptr(score), _lib.ptr(preds), _lib.ptr(boxes), _lib.ptr(argmax), n, k, h, w,
+                                            dec_shift.refine_mode, int(dec_shift.use_udp), int(dec_shift.to_original),
+                                            float(dec_shift.pixel_std), _lib.ptr(dec_shift._blur_on(dev)), int(dec_shift.kernel_size), st)
+
+    def mse_fwd():
+        return lib.mp_joints_mse_fwd(_lib.ptr(hm), _lib.ptr(tgt), _lib.ptr(wgt), _lib.ptr(loss), _lib.ptr(ws), ws_bytes, n, k, h * w, st)
+
+    def mse_bwd():
+        return lib.mp_joints_mse_bwd(_lib.ptr(hm), _lib.ptr(tgt), _lib.ptr(wgt), _lib.ptr(go), _lib.ptr(grad), n, k, h * w, st)
 
     def timed(fn, reps=50):
         for _ in range(5):
-            fn()
+            _lib.check(fn(), "hbm_ops")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
@@ -378,25 +405,19 @@ def hbm_ops_report(mp, dev, n=128):
         e1.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / reps
 
-    def fwd_bwd():
-        pred.grad = None
-        crit(pred, tgt, wgt).backward()
-
-    t_fwd = timed(lambda: crit(pred.detach(), tgt, wgt))
-    t_fb = timed(fwd_bwd)
     rows = {
-        "decode_argmax_shift": (timed(lambda: dec_shift(hm, center, scale, score)), hm_bytes,
+        "decode_argmax_shift": (timed(decode(dec_shift)), hm_bytes,
                                 "mp_decode_topdown (decode_kernel<false>): arg-max + quarter-pixel shift + transform, a11 / a12 / a14"),
-        "decode_dark_udp": (timed(lambda: dec_dark(hm, center, scale, score)), hm_bytes,
+        "decode_dark_udp": (timed(decode(dec_dark)), hm_bytes,
                             "mp_decode_topdown (decode_kernel<true>): arg-max + DARK / UDP refinement (11x11 blur of the 3x3 neighbourhood), a13"),
-        "flip_aggregate_decode": (timed(lambda: dec_shift.decode_flip_aggregated(hm, hf, flip_index, True, center, scale, score)),
-                                  2 * hm_bytes, "mp_flip_aggregate_decode: flip back + shift + average + decode in one kernel, a15"),
-        "joints_mse_fwd": (t_fwd, 2 * hm_bytes, "mp_joints_mse_fwd (mse_row + mse_final): weighted squared error, fixed-order reduction, a10"),
-        "joints_mse_bwd": (max(t_fb - t_fwd, 1e-9), 3 * hm_bytes,
-                           "mp_joints_mse_bwd: 2 w (p - t) / (N K H W); time = (forward + backward through autograd) - forward, a10"),
+        "flip_aggregate_decode": (timed(flip_decode), 2 * hm_bytes,
+                                  "mp_flip_aggregate_decode: flip back + one-pixel shift + average + decode in one kernel, a15"),
+        "joints_mse_fwd": (timed(mse_fwd), 2 * hm_bytes, "mp_joints_mse_fwd (mse_row + mse_final): weighted squared error, fixed-order reduction, a10"),
+        "joints_mse_bwd": (timed(mse_bwd), 3 * hm_bytes, "mp_joints_mse_bwd: 2 w (p - t) / (N K H W), a10"),
     }
     return {"batch": n, "heatmaps": f"{k}x{h}x{w} fp32", "hbm_peak_GBps": 8000.0,
-            "timing": "HIP events on the launch stream around 50 calls after 5 warm-ups; bytes = algorithmic (each tensor once)",
+            "timing": "HIP events on the launch stream around 50 back-to-back C-ABI calls after 5 warm-ups; bytes = algorithmic (each "
+                      "tensor once); ~2 us of launch gap per call is inside these figures",
             "ops": {name: {"us": round(t * 1e6, 2), "algorithmic_bytes": b, "GBps": round(b / t / 1e9, 1),
                            "frac_of_hbm_peak": round(b / t / 8e12, 4), "what": what} for name, (t, b, what) in rows.items()}}
 
@@ -663,7 +684,7 @@ def train_bench(args, mp, dev, dist, world, rank):
             "roofline": roofline, "cpu_baseline": None}))
 
 
-def dp_leg_report(step, opt, dist, world, rank, dev, per_gpu_batch, steps, warmup, sync_device=None):
+def dp_leg_report(step, opt, dist, world, rank, dev, per_gpu_batch, steps, warmup, sync_device=None, graphed=None):
     """The data-parallel training leg of a multi-rank run, on ALL ranks: `warmup` + `steps` calls of `step()` (forward + loss +
     backward + bucketed gradient all-reduce + update), timed between barriers with the MAX over ranks like the headline; the
     collectives' share from device events around the optimizer's wait for them (`opt.time_comm`).  Everything that touches the
@@ -691,11 +712,19 @@ def dp_leg_report(step, opt, dist, world, rank, dev, per_gpu_batch, steps, warmu
     comm_ms = [e0.elapsed_time(e1) for e0, e1 in opt.comm_events]
     opt.time_comm = False
     grads = opt.grads
-    return {"value": round(world * per_gpu_batch * steps / elapsed, 2), "unit": "images/s", "ms_per_step": round(elapsed / steps * 1e3, 3),
+    overlap = {}
+    if graphed is not None:  # GraphedTrainStep: the backward pass as several hipGraphs, finished buckets released between them
+        issue = graphed.issue_ms[-steps:]
+        overlap = {"backward_segments": graphed.segments, "buckets_released_per_segment": [len(r) for r in graphed.bucket_schedule],
+                   "allreduce_issue_ms": round(sum(issue) / len(issue), 3) if issue else None,
+                   "allreduce_issue_what": "host time per step spent handing finished buckets to the all-reduce between the segments "
+                                           "(the collectives then run on the communication stream under the next segment's kernels)"}
+    return {**overlap, "value": round(world * per_gpu_batch * steps / elapsed, 2), "unit": "images/s", "ms_per_step": round(elapsed / steps * 1e3, 3),
             "steps": steps, "warmup": warmup, "per_gpu_batch": per_gpu_batch, "global_batch": per_gpu_batch * world,
             "allreduce_ms_per_step": round(sum(comm_ms) / len(comm_ms), 3) if comm_ms else None,
-            "allreduce_what": "device time between 'all gradients in the arena' and 'bucket all-reduces landed' on the compute stream "
-                              "(events around GradientAverager.finish(); rank 0)",
+            "allreduce_what": "EXPOSED wait: device time between 'all gradients in the arena' and 'bucket all-reduces landed' on the "
+                              "compute stream (events around GradientAverager.finish(); rank 0); buckets released between the backward "
+                              "segments have been running since",
             "rccl_nranks": grads.comm_ranks(), "transport": "native (mp_comm_*, RCCL bound by the library)" if grads.native is not None
             else f"torch.distributed ({dist.get_backend()})",
             "gradient_bytes": int(grads.arena.numel() * 4), "buckets": len(grads.buckets), "mean": grads.mean,
@@ -757,9 +786,10 @@ def dp_train_leg(args, mp, dev, dist, world, rank):
 
     log(f"rank {rank}: DP training leg built (hipGraph step, {len(opt.grads.buckets)} gradient buckets)")
     rep = dp_leg_report(step, opt, dist, world, rank, dev, n, steps=max(3, min(args.steps, 10)), warmup=max(1, min(args.warmup, 3)),
-                        sync_device=torch.cuda.synchronize)
+                        sync_device=torch.cuda.synchronize, graphed=gstep)
     rep.update({"workload": "configs[3]: hrnet_w32 + hrnet_head 256x192 amp-O2 training, data parallel: one hipGraph replay per rank, "
-                            "bucketed RCCL all-reduce of the 114 MB gradient arena (1/world folded into the update), AdamWeightDecay",
+                            "bucketed RCCL all-reduce of the 114 MB gradient arena overlapped with the backward segments (1/world folded into the "
+                            "update), AdamWeightDecay",
                 "dtype": "f16", "loss_scale": scaler.loss_scale, "skipped_steps": scaler.skipped_steps})
     opt.close()
     return rep

@@ -121,6 +121,15 @@ def branch_streams_enabled() -> bool:
 
 
 
+def join_branch_streams(device) -> None:
+    """The current stream waits for every branch / row side stream of ``device`` (a segmented capture ends each backward segment
+    with this: the gradients of a stage boundary are produced on the side streams and nothing else joins them before the capture
+    of that segment ends)."""
+    cur = torch.cuda.current_stream(device)
+    for st in _BRANCH_STREAMS.get(device, []):
+        cur.wait_stream(st)
+
+
 def _branch_streams(device, n):
     have = _BRANCH_STREAMS.setdefault(device, [])
     while len(have) < n:
@@ -422,7 +431,21 @@ class HRNet(Backbone):
         for blk in self.layer1:
             x = blk.train_forward(x)
         ys = [x]
+        cuts = getattr(self, "_train_cut_sink", None)
         for idx in (2, 3, 4):
+            if cuts is not None:
+                # stage boundary of a segmented backward pass (utils/graph_step.py): the autograd graph is CUT here - the next stage
+                # continues from detached leaves (no launch: a detach is a view), the step feeds their gradients to the tensors
+                # they were cut from.  The BatchNorm hand-over link travels with the tensor.
+                leaves = []
+                for y in ys:
+                    leaf = y.detach().requires_grad_()
+                    link = getattr(y, "_mp_bn_link", None)
+                    if link is not None:
+                        leaf._mp_bn_link = link
+                    leaves.append(leaf)
+                cuts.append((list(ys), leaves))
+                ys = leaves
             trans = getattr(self, f"transition{idx - 1}")
             flags = getattr(self, f"transition{idx - 1}_flags")
             cfg = getattr(self, f"stage{idx}_cfg")
@@ -446,6 +469,14 @@ class HRNet(Backbone):
                 xs = mod.train_forward(xs)
             ys = xs
         return ys[0]
+
+    def train_segments(self):
+        """Module groups of the training graph in BACKWARD order, cut at the stage boundaries ``train_forward`` reports through
+        ``_train_cut_sink`` (last boundary first): [stage 4 + transition 3], [stage 3 + transition 2], [stage 2 + transition 1],
+        [stage 1 + stem].  A segmented step (utils/graph_step.py) runs the backward pass group by group and hands each group's
+        finished gradient buckets to the all-reduce while the next group computes."""
+        return [[self.stage4, self.transition3], [self.stage3, self.transition2], [self.stage2, self.transition1],
+                [self.layer1, self.conv1, self.bn1, self.conv2, self.bn2]]
 
     @property
     def out_channels(self) -> int:

@@ -1078,6 +1078,12 @@ def _wgrad_flush_key(lib, key):
     for sid in sorted({j[4] for j in jobs}):
         if sid != cur.cuda_stream:
             cur.wait_stream(torch.cuda.ExternalStream(sid, device=dev))
+    for _, x, dz, _, sid in jobs:
+        if sid != cur.cuda_stream:
+            # operands allocated on another stream's pool are read by a launch on THIS stream: tell the caching allocator, or the
+            # blocks could be handed out again on their origin stream while the grouped kernel still reads them
+            x.record_stream(cur)
+            dz.record_stream(cur)
     with torch.cuda.device(dev):
         if n == 1:
             _, x, dz, dw, _ = jobs[0]
@@ -1095,11 +1101,35 @@ def _wgrad_flush_key(lib, key):
 
 
 _WGRAD_CALLBACK = [False]
+_WGRAD_AUTOFLUSH = [True]
+
+
+def set_wgrad_autoflush(on: bool) -> bool:
+    """Whether the end of EVERY backward() call launches the queued remainders (default).  A segmented step (utils/graph_step.py)
+    runs one backward pass as several autograd calls and turns this off in between, so that the weight-gradient groups - and with
+    them the split-K partitions, i.e. the bits - are those of the single-call pass; it flushes itself after the last segment.
+    Returns the previous setting."""
+    prev = _WGRAD_AUTOFLUSH[0]
+    _WGRAD_AUTOFLUSH[0] = bool(on)
+    return prev
+
+
+def pending_wgrad_slots():
+    """data_ptr of every gradient-arena slot that still has a queued (not yet launched) weight gradient."""
+    return {j[3].data_ptr() for jobs in _WGRAD_PENDING.values() for j in jobs}
 
 
 def _wgrad_backward_done() -> None:
     _WGRAD_CALLBACK[0] = False
-    flush_wgrad_jobs()
+    if _WGRAD_AUTOFLUSH[0]:
+        flush_wgrad_jobs()
+
+
+def drop_wgrad_jobs() -> None:
+    """Forget queued weight gradients WITHOUT launching them (a backward pass that raised leaves jobs holding that pass's
+    activations; the gradient arena's ``begin_step`` calls this so they can never be accumulated into the next step)."""
+    _WGRAD_PENDING.clear()
+    _WGRAD_CALLBACK[0] = False
 
 
 def flush_wgrad_jobs() -> None:

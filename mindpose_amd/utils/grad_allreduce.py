@@ -176,6 +176,9 @@ class GradientAverager:
     # -- per step ---------------------------------------------------------------------------------
     def begin_step(self) -> None:
         """Zero the arena and re-arm the buckets (call before forward/backward)."""
+        if self.arena.is_cuda:
+            from ..models.train_ops import drop_wgrad_jobs
+            drop_wgrad_jobs()  # leftovers of a backward pass that raised must not reach this step's arena
         self.arena.zero_()
         self.rearm()
 
@@ -183,9 +186,18 @@ class GradientAverager:
         """Re-arm the buckets without touching the arena (a captured step zeroes it inside its hipGraph)."""
         for b in self.buckets:
             b["pending"] = b["count"]
+            b["launched"] = False
         self._handles = []
 
+    def launch_bucket(self, index: int) -> None:
+        """Start the all-reduce of bucket ``index`` now (a segmented step does this for the buckets whose gradients are complete
+        while the rest of the backward pass still runs); ``finish()`` launches whatever was not."""
+        b = self.buckets[index]
+        if self.active and not b.get("launched"):
+            self._launch(b)
+
     def _launch(self, b: dict) -> None:
+        b["launched"] = True
         view = self.arena[b["start"]:b["end"]]
         if self.native is not None:
             self._handles.append(_EventHandle(self.native.all_reduce(view, average=self.mean == "collective")))
@@ -207,7 +219,8 @@ class GradientAverager:
         if self.active:
             if not self.overlap:
                 for b in self.buckets:
-                    self._launch(b)
+                    if not b.get("launched"):
+                        self._launch(b)
             else:
                 for b in self.buckets:
                     if b["pending"] > 0:  # a parameter received no gradient this step

@@ -123,9 +123,15 @@ def _dp_worker(rank, world, port, out_dir):
         if graphed:
             step = GraphedTrainStep(nwl, opt, (x, target, weight), loss_scale_manager=scaler, warmup=2)
             # local arena of this rank: one replay without the exchange
-            opt.grads.rearm()
-            step.graph.replay()
+            step.replay(exchange=False)
+            torch.cuda.synchronize()
             local = opt.grads.arena.clone()
+            # under an active exchange the step is captured in segments: buckets leave for the all-reduce between them
+            assert step.segments == 4 and len(step.graphs) == 4
+            early = sum(len(r) for r in step.bucket_schedule[:-1])
+            assert sorted(b for r in step.bucket_schedule for b in r) == list(range(len(opt.grads.buckets)))
+            assert early >= len(opt.grads.buckets) // 2, step.bucket_schedule
+            report.setdefault("bucket_schedule", {})[name] = [len(r) for r in step.bucket_schedule]
             before = opt.flat.clone()
             loss = step(x, target, weight)
             assert step.updated
@@ -160,6 +166,25 @@ def _dp_worker(rank, world, port, out_dir):
         del loss
         if graphed:
             del step
+    # the segmented capture is the single backward pass cut in pieces: its gradient arena equals the one-graph step's BIT FOR BIT
+    arenas = {}
+    for segs in (1, 4):
+        mp, net, nwl, opt = _build(dev, True, False, "torch", force=world == 1)
+        x, target, weight = _batch(mp, dev, rank, n=6, hw=128)
+        step = GraphedTrainStep(nwl, opt, (x, target, weight), loss_scale_manager=DynamicLossScaleManager(init_loss_scale=1024.0),
+                                warmup=2, segments=segs)
+        assert step.segments == segs
+        step.replay(exchange=False)
+        torch.cuda.synchronize()
+        arenas[segs] = (opt.grads.arena.clone(), float(step.static_loss))
+        if segs == 4:
+            step(x, target, weight)  # a full step: buckets launched between the segments, the rest from finish()
+            assert step.updated and len(step.issue_ms) == 2
+        opt.close()
+        del step
+    assert arenas[1][1] == arenas[4][1]
+    assert torch.equal(arenas[1][0], arenas[4][0]), "segmented backward differs from the one-graph backward"
+    report["segmented_equals_single"] = True
     # eager step WITH the overlap hooks live (bucket all-reduces launched from backward): equals the non-overlapped result
     mp, net, nwl, opt = _build(dev, False, True, "torch", force=world == 1)
     x, target, weight = _batch(mp, dev, rank)
@@ -182,7 +207,7 @@ def _run_dp(world, tmp_path):
     import torch.multiprocessing as mp_
     mp_.spawn(_dp_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     reports = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(world)]
-    assert all(rep["overlap_equals_single"] for rep in reports)
+    assert all(rep["overlap_equals_single"] and rep["segmented_equals_single"] for rep in reports)
     return reports
 
 

@@ -61,7 +61,6 @@ def test_graphed_o2_step_at_bench_shape_vs_oracle():
         (l * scale).backward()
         return float(l.detach()), {k: (p[k].grad / scale).double().flatten() for k in got}
 
-    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
     l_amp, g_amp = oracle(True)
     l_f32, g_f32 = oracle(False)
 
