@@ -333,12 +333,10 @@ bool blockf16_v2_build(const void* x, const void* w1, const float* scale1, const
     p.x = x; p.w1 = w1; p.w2 = w2; p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2; p.out = out;
     p.N = n; p.H = h; p.W = w;
     p.Wp = w + 1;
-    // shape: 0 = eight waves, one workgroup per CU (PS1 = 4, PS2 = 3: up to 8 rows of 48); 1 = four waves, two workgroups per CU
-    // (PS1 = 5, PS2 = 3: up to 4 rows of 48) - two independent workgroups drift out of phase, so one's epilogues / DMA issue run
-    // beside the other's MFMA loops instead of in lockstep with its SIMD partner (MP_F16_BLOCK_SHAPE selects; measured 26.6 us against 23.3 us for shape 0 at N = 128: default 0)
-    int shape = 0;
-    if (const char* e = knob("MP_F16_BLOCK_SHAPE")) shape = atoi(e) ? 1 : 0;
-    const int waves = shape ? 4 : 8, PS1 = shape ? 5 : 4, PS2 = 3;
+    // eight waves, one workgroup per CU (PS1 = 4, PS2 = 3: up to 8 rows of 48).  (A four-wave / two-workgroups-per-CU shape of the same
+    // code measured 26.6 us against 23.3 us at N = 128 in round 2 and was removed in round 4.)
+    const int shape = 0;
+    const int waves = 8, PS1 = 4, PS2 = 3;
     int best = 0;
     for (int R = (rows > 0 ? rows : (shape ? 4 : 8)); R >= 1; --R) {
         if (R > h && R > 1) continue;
@@ -378,7 +376,7 @@ bool blockf16_v2_build(const void* x, const void* w1, const float* scale1, const
 }
 
 int blockf16_v2_launch(const BlockF16Launch& L, hipStream_t s) {
-    return L.small == 3 ? launch_block_v2<4, 5, 3>(L.p, L.lds_bytes, s) : launch_block_v2<8, 4, 3>(L.p, L.lds_bytes, s);
+    return launch_block_v2<8, 4, 3>(L.p, L.lds_bytes, s);
 }
 
 }  // namespace mp

@@ -224,49 +224,6 @@ class FuseSumFn(torch.autograd.Function):
 # gradient in fp32 (the parameters themselves stay fp32 "master" weights: the pack kernel rounds them to fp16 per step).
 
 
-# ---- weight-gradient lanes -------------------------------------------------------------------------------------------------
-# Nothing in the backward pass depends on a weight gradient (it is a leaf, read by the update after the step), while the data
-# gradient is on the critical chain BN-bwd -> dgrad -> BN-bwd -> ...  Inside a captured step every current stream gets a side
-# stream for its weight-gradient launches: forked where dz is ready, joined once at the end of the backward pass
-# (``join_wgrad_lanes``), so in the hipGraph the weight gradients fill the gaps of the latency-bound chain.
-_WGRAD_LANES = {}
-_WGRAD_LANES_ON = [False]
-_WGRAD_FORKED = []
-
-
-def set_wgrad_lanes(on: bool) -> bool:
-    """``GraphedTrainStep`` asks for the lanes around its warm-up passes and the capture and joins them after each backward
-    pass.  Returns the previous setting.  Opt-in (``MINDPOSE_TRAIN_WGRAD_LANES=1``): measured on HRNet-W32 amp O2, N = 128, the
-    graphed step is SLOWER with them (38.2 vs 36.1 ms) - the replay is throughput-bound, not latency-bound, and the extra
-    concurrent kernels only stretch each other."""
-    prev = _WGRAD_LANES_ON[0]
-    _WGRAD_LANES_ON[0] = bool(on) and os.environ.get("MINDPOSE_TRAIN_WGRAD_LANES", "0") == "1"
-    return prev
-
-
-def _wgrad_lane(device):
-    """Side stream for the weight gradient of a layer whose backward runs on the current stream (None: lanes off)."""
-    if not _WGRAD_LANES_ON[0]:
-        return None, None
-    cur = torch.cuda.current_stream(device)
-    side = _WGRAD_LANES.get((device, cur.cuda_stream))
-    if side is None:
-        side = _WGRAD_LANES[(device, cur.cuda_stream)] = torch.cuda.Stream(device=device)
-    side.wait_stream(cur)
-    if side not in _WGRAD_FORKED:
-        _WGRAD_FORKED.append(side)
-    return cur, side
-
-
-def join_wgrad_lanes(device=None) -> None:
-    """The current stream waits for every weight-gradient lane forked since the last join (end of the backward pass: before
-    the gradient arena is read, and before a stream capture ends)."""
-    cur = torch.cuda.current_stream(device)
-    for side in _WGRAD_FORKED:
-        cur.wait_stream(side)
-    _WGRAD_FORKED.clear()
-
-
 def _direct_grad(param):
     """The parameter's slot in a flat gradient arena when the owner allows kernels to accumulate into it directly
     (``GradientAverager`` without overlap hooks sets ``_mp_grad_direct``): saves one AccumulateGrad add launch per parameter
@@ -551,14 +508,9 @@ class Conv16Fn(torch.autograd.Function):
             dw = direct if direct is not None else torch.empty_like(w)
             d = _desc(n, cin, h, wd, cout, k, s, pad, pad, ho, wo, ho, wo)
             ws_bytes = lib.mp_f16_conv_wgrad_workspace_bytes(ctypes.byref(d))
-            cur, lane = _wgrad_lane(x.device) if direct is not None else (None, None)
-            with torch.cuda.stream(lane) if lane is not None else contextlib.nullcontext():
-                ws = torch.empty(max(ws_bytes // 4, 1), device=x.device, dtype=torch.float32)
-                _lib.check(lib.mp_f16_conv_wgrad(ctypes.byref(d), _lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), 1.0, int(direct is not None),
-                                                 _lib.ptr(ws), ws_bytes, _lib.stream()), "mp_f16_conv_wgrad")
-            if lane is not None:  # the lane still reads x and dz when this node's buffers go back to the allocator
-                x.record_stream(lane)
-                dz.record_stream(lane)
+            ws = torch.empty(max(ws_bytes // 4, 1), device=x.device, dtype=torch.float32)
+            _lib.check(lib.mp_f16_conv_wgrad(ctypes.byref(d), _lib.ptr(x), _lib.ptr(dz), _lib.ptr(dw), 1.0, int(direct is not None),
+                                             _lib.ptr(ws), ws_bytes, _lib.stream()), "mp_f16_conv_wgrad")
             if direct is not None:
                 dw = None
         if ctx.has_bias and ctx.needs_input_grad[2]:

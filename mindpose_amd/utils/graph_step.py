@@ -87,9 +87,7 @@ class GraphedTrainStep:
         # inside the graph the branches of an HRModule run on side streams (fork / join = graph dependencies): +5 % on the step
         from ..models.backbones.hrnet import set_branch_streams
         prev_branch_streams = set_branch_streams(True)
-        # ... and the weight gradients (leaves of the backward pass) on a side stream per branch stream, joined after backward
-        from ..models.train_ops import flush_wgrad_jobs, join_wgrad_lanes, set_wgrad_lanes
-        prev_wgrad_lanes = set_wgrad_lanes(True)
+        from ..models.train_ops import flush_wgrad_jobs
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -98,7 +96,6 @@ class GraphedTrainStep:
                 loss = net_with_loss(*self.static_in)
                 (loss * self.scale_t).backward()
                 flush_wgrad_jobs()
-                join_wgrad_lanes(dev)
                 del loss  # drop the autograd graph before the next pass / the capture
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
@@ -110,12 +107,10 @@ class GraphedTrainStep:
                 self.static_loss = net_with_loss(*self.static_in)
                 (self.static_loss * self.scale_t).backward()
                 flush_wgrad_jobs()  # the remainders of the grouped weight gradients belong to the captured step
-                join_wgrad_lanes(dev)
             self.graphs, self.bucket_schedule = [self.graph], [[]]
         else:
             self._capture_segments(backbone, groups, dev)
         set_branch_streams(prev_branch_streams)
-        set_wgrad_lanes(prev_wgrad_lanes)
         self._planned = [m for m in net_with_loss.modules() if hasattr(m, "_plans")]  # walked once, not per step
 
     def _capture_segments(self, backbone, groups, dev) -> None:
@@ -125,7 +120,7 @@ class GraphedTrainStep:
         next.  (``backward(inputs=[non-leaf])`` is no alternative: the engine EXECUTES the boundary tensor's own producer node to
         capture its gradient - that node's arena side effects would happen twice.)"""
         from ..models.backbones.hrnet import join_branch_streams
-        from ..models.train_ops import flush_wgrad_jobs, join_wgrad_lanes, pending_wgrad_slots, set_wgrad_autoflush
+        from ..models.train_ops import flush_wgrad_jobs, pending_wgrad_slots, set_wgrad_autoflush
         grads = self.opt.grads
         n_groups = len(groups)
         # merge the trailing groups when fewer segments were asked for: segment i covers groups[lo_i : hi_i] (backward order)
@@ -178,7 +173,6 @@ class GraphedTrainStep:
                     join_branch_streams(dev)  # boundary gradients are produced on the branch / row streams
                     if last:
                         flush_wgrad_jobs()  # the remainders of the grouped weight gradients belong to the captured step
-                    join_wgrad_lanes(dev)
                     if not last:
                         pairs = [(r, g_) for r, g_ in zip(roots, got[:len(leaves)]) if g_ is not None]
                         seeds, seed_grads = [r for r, _ in pairs], [g_ for _, g_ in pairs]

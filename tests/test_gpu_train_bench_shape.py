@@ -47,7 +47,7 @@ def test_graphed_o2_step_at_bench_shape_vs_oracle():
     gstep.graph.replay()
     torch.cuda.synchronize()
     assert scaler.loss_scale == scale, "the warm-up steps overflowed: the comparison below would use another scale"
-    loss = float(gstep.static_loss)
+    loss = float(gstep.static_loss.detach())
     got = {k: (v.grad / scale).double().cpu().flatten() for k, v in net.named_parameters()}
     assert all(torch.isfinite(g).all() for g in got.values())
 

@@ -49,8 +49,5 @@ os.environ.setdefault("MINDPOSE_EXPERIMENT_KNOBS", "1")  # the MP_* knobs below 
     os.environ["MP_F16_BLOCK_V2"] = "0"
     res.update({f"v1 R{r}": timeit(fused, r) for r in (6, 5)})
     os.environ["MP_F16_BLOCK_V2"] = "1"
-    os.environ["MP_F16_BLOCK_SHAPE"] = "0"
     res.update({f"v2/8w R{r}": timeit(fused, r) for r in (8, 6)})
-    os.environ["MP_F16_BLOCK_SHAPE"] = "1"
-    res.update({f"v2/4w R{r}": timeit(fused, r) for r in (4, 3, 2)})
     print(f"N={n:4d} us: " + "  ".join(f"{k} {v:6.1f}" for k, v in res.items()), flush=True)
