@@ -379,11 +379,14 @@ int mp_f16_from_c8(const void* x_c8_dev, float* out_nchw_dev, int n, int c, int 
 int mp_f16_conv2d_fwd(const mp_conv_desc* desc, int variant, const void* x_c8_dev, const void* packed_w_dev,
                       const float* scale_dev, const float* shift_dev, const void* res1_c8_dev, const void* res2_c8_dev,
                       void* out_c8_dev, mp_stream_t stream);
-/* Fused BasicBlock of the 32-channel HRNet branch (hrnet.py:30-83, eval mode; SURVEY 8(b) "mp_basicblock_fused"):
- *   out = relu(bn2(conv3x3(relu(bn1(conv3x3(x))))) + x),  x / out channel-blocked fp16 [n][4][h][w][8] (24 < c <= 32), distinct buffers;
- * packed_w1 / packed_w2 = mp_f16_pack_weight(mode 0) of the two [c,c,3,3] weights, scale / shift = folded BatchNorm (32 fp32
- * entries each, zero beyond c).  The intermediate tensor stays in LDS; the result is bit-identical to two mp_f16_conv2d_fwd
- * calls.  rows = output rows per workgroup (0 = the largest that fits, <= 6).  MP_ERR_UNSUPPORTED for other widths. */
+/* Fused BasicBlock of the 32-channel and (round 4) the 64-channel HRNet branch (hrnet.py:30-83, 202-241, eval mode; SURVEY 8(b)
+ * "mp_basicblock_fused"):
+ *   out = relu(bn2(conv3x3(relu(bn1(conv3x3(x))))) + x),  x / out channel-blocked fp16 [n][c/8][h][w][8] (24 < c <= 32, or c == 64),
+ * distinct buffers; packed_w1 / packed_w2 = mp_f16_pack_weight(mode 0) of the two [c,c,3,3] weights, scale / shift = folded
+ * BatchNorm (c rounded up to 16 fp32 entries each, zero beyond c).  The intermediate tensor stays in LDS; the result is bit-identical
+ * to two mp_f16_conv2d_fwd calls.  rows = output rows per workgroup (0 = the largest that fits).  MP_ERR_UNSUPPORTED for other
+ * widths / maps too wide for a band; mp_f16_basicblock_supported answers that question without launching (1 / 0). */
+int mp_f16_basicblock_supported(int n, int c, int h, int w);
 int mp_f16_basicblock_fwd(const void* x_c8_dev, const void* packed_w1_dev, const float* scale1_dev, const float* shift1_dev,
                           const void* packed_w2_dev, const float* scale2_dev, const float* shift2_dev, void* out_c8_dev, int n,
                           int c, int h, int w, int rows, mp_stream_t stream);

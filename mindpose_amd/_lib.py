@@ -147,6 +147,7 @@ _PROTOTYPES = {
     "mp_optimizer_step": (c_int, [c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_size_t, ctypes.c_float,
                                   ctypes.c_float, ctypes.c_float, ctypes.POINTER(ctypes.c_float * 5), ctypes.c_void_p]),
     "mp_f16_basicblock_fwd": (c_int, [c_f32p] * 8 + [c_int] * 5 + [ctypes.c_void_p]),
+    "mp_f16_basicblock_supported": (c_int, [c_int] * 4),
     "mp_plan_add_basicblock_f16": (c_int, [ctypes.c_void_p] + [c_f32p] * 8 + [c_int] * 5),
     "mp_f16_fuse_upsample_sum": (c_int, [c_f32p, c_f32p, c_int, c_f32p, c_int, c_f32p, c_int, c_f32p] + [c_int] * 5 + [ctypes.c_void_p]),
     "mp_plan_add_conv_f16": (c_int, [ctypes.c_void_p, ctypes.POINTER(ConvDesc), c_int] + [c_f32p] * 7),

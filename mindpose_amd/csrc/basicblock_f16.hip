@@ -291,9 +291,10 @@ int blockf16_build(const void* x, const void* w1, const float* scale1, const flo
                    const float* shift2, void* out, int n, int c, int h, int w, int rows, BlockF16Launch& L) {
     if (!x || !w1 || !w2 || !scale1 || !shift1 || !scale2 || !shift2 || !out) return MP_ERR_NULL;
     if (n <= 0 || h <= 0 || w <= 0) return MP_ERR_SHAPE;
-    if (c <= 24 || c > 32) return MP_ERR_UNSUPPORTED;  // exactly four 8-channel blocks (channels beyond c are zero padding)
     if (rows < 0) return MP_ERR_SHAPE;
     if (x == out) return MP_ERR_UNSUPPORTED;  // neighbouring tiles read the halo rows this tile would overwrite
+    if (c == 64) return blockf16_c64_build(x, w1, scale1, shift1, w2, scale2, shift2, out, n, c, h, w, rows, L) ? MP_OK : MP_ERR_UNSUPPORTED;
+    if (c <= 24 || c > 32) return MP_ERR_UNSUPPORTED;  // exactly four 8-channel blocks (channels beyond c are zero padding)
     if (blockf16_v2_build(x, w1, scale1, shift1, w2, scale2, shift2, out, n, c, h, w, rows, L)) return MP_OK;
     if (rows > 6) return MP_ERR_UNSUPPORTED;
     BlockF16Params p{};
@@ -340,6 +341,7 @@ int blockf16_build(const void* x, const void* w1, const float* scale1, const flo
 }
 
 int blockf16_launch(const BlockF16Launch& L, hipStream_t s) {
+    if (L.small == 4) return blockf16_c64_launch(L, s);
     if (L.small >= 2) return blockf16_v2_launch(L, s);
     return L.small ? launch_block<5, 3>(L.p, L.lds_bytes, s) : launch_block<6, 5>(L.p, L.lds_bytes, s);
 }
@@ -349,6 +351,14 @@ int blockf16_launch(const BlockF16Launch& L, hipStream_t s) {
 using namespace mp;
 
 extern "C" {
+
+int mp_f16_basicblock_supported(int n, int c, int h, int w) {
+    BlockF16Launch L{};
+    static const char probe[16] = {0};  // non-null, never dereferenced by the build step; x != out
+    return blockf16_build(probe, probe, reinterpret_cast<const float*>(probe), reinterpret_cast<const float*>(probe), probe,
+                          reinterpret_cast<const float*>(probe), reinterpret_cast<const float*>(probe), const_cast<char*>(probe) + 8, n, c, h,
+                          w, 0, L) == MP_OK ? 1 : 0;
+}
 
 int mp_f16_basicblock_fwd(const void* x, const void* packed_w1, const float* scale1, const float* shift1, const void* packed_w2,
                           const float* scale2, const float* shift2, void* out, int n, int c, int h, int w, int rows,

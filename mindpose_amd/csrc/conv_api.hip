@@ -323,8 +323,7 @@ static int build_launch(const mp_conv_desc* desc, const float* x, const float* w
         return MP_OK;
     }
     if (L.gemm) {
-        if (res2) return MP_ERR_UNSUPPORTED;  // one residual tensor in the GEMM kernel
-        L.gm.p.x = x; L.gm.p.wp = w; L.gm.p.scale = scale; L.gm.p.shift = shift; L.gm.p.res1 = res1; L.gm.p.out = out;
+        L.gm.p.x = x; L.gm.p.wp = w; L.gm.p.scale = scale; L.gm.p.shift = shift; L.gm.p.res1 = res1; L.gm.p.res2 = res2; L.gm.p.out = out;
         return MP_OK;
     }
     L.p.x = x; L.p.wp = w; L.p.scale = scale; L.p.shift = shift; L.p.res1 = res1; L.p.res2 = res2; L.p.out = out;
@@ -520,7 +519,7 @@ static int build_deconv_gemm(const mp_conv_desc* desc, const float* x, const flo
     if (rc != MP_OK) return rc;
     L.gemm = true;
     L.ks = 2; L.stride = 1; L.variant = kGemm; L.lds_bytes = L.gm.lds_bytes;
-    L.gm.p.x = x; L.gm.p.wp = packed4; L.gm.p.scale = scale; L.gm.p.shift = shift; L.gm.p.res1 = nullptr; L.gm.p.out = out;
+    L.gm.p.x = x; L.gm.p.wp = packed4; L.gm.p.scale = scale; L.gm.p.shift = shift; L.gm.p.res1 = nullptr; L.gm.p.res2 = nullptr; L.gm.p.out = out;
     return MP_OK;
 }
 

@@ -114,6 +114,10 @@ int blockf16_launch(const BlockF16Launch& L, hipStream_t s);
 bool blockf16_v2_build(const void* x, const void* w1, const float* scale1, const float* shift1, const void* w2, const float* scale2,
                        const float* shift2, void* out, int n, int c, int h, int w, int rows, BlockF16Launch& L);
 int blockf16_v2_launch(const BlockF16Launch& L, hipStream_t s);
+// 64-channel block (basicblock_f16_c64.hip): one band per workgroup, cout tile per wave; L.small == 4 marks it
+bool blockf16_c64_build(const void* x, const void* w1, const float* scale1, const float* shift1, const void* w2, const float* scale2,
+                        const float* shift2, void* out, int n, int c, int h, int w, int rows, BlockF16Launch& L);
+int blockf16_c64_launch(const BlockF16Launch& L, hipStream_t s);
 
 int f16_build_launch(const mp_conv_desc* desc, int variant, const void* x, const void* w, const float* scale,
                      const float* shift, const void* res1, const void* res2, void* out, ConvF16Launch& L);

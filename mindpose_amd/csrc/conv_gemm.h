@@ -10,6 +10,7 @@ struct GemmParams {
     const float* scale;
     const float* shift;
     const float* res1;
+    const float* res2;  // second residual tensor (the exchange unit's running sum + identity), same geometry as the output
     float* out;
     int N, Cin, Cin_pad4, Cout, Cout_pad16;
     int HWi, Hi, Wi;        // input plane
@@ -17,10 +18,10 @@ struct GemmParams {
     int OHW, OW;            // the output tensor's plane (sub-pixel phases write every out_mul-th pixel of it)
     int out_mul, off_y, off_x;
     int stride, pad_top, pad_left;
-    int T, t_shift, kw_shift;  // taps (1 or 4 = 2x2), log2(T), log2(kw)
+    int T, kw;      // taps (1, 4 = 2x2, 9 = 3x3) and the kernel's width
     int cols;       // N * HWo: the GEMM's column count
     int n_ct;       // cout tiles (128 or 64 channels)
-    int n_iters;    // (Cin / 16) * T k-loop steps
+    int n_iters;    // (Cin / 16) * T k-loop steps, walked as (cin chunk, tap) pairs
     int relu;
     int phases;                 // 1, or 4 = all sub-pixel phases of a transposed convolution in one launch (grid.y)
     unsigned wp_phase_floats;   // floats per phase slice of the packed weights

@@ -13,9 +13,11 @@
 //               from the direct kernel's packing ([Cin][Cout_pad16] for a 1x1 weight: cout contiguous = already k-major)
 //   pipeline    chunk c + 1: global -> registers while chunk c runs on the matrix cores, -> LDS behind it, one barrier per
 //               chunk; branch-free body (the loads past the last chunk are out of range / never consumed)
-//   gather       1x1 stride 2 (the bottleneck down_sample) and the four 2x2 sub-pixel phases of the transposed convolution
-//               (simple_baseline_head.py:80-88) use the same tiles with the input columns fetched one by one - four 4-byte loads
-//               per staging unit instead of one 16-byte load - and, for the phases, a k loop over (cin chunk, tap) pairs
+//   gather       1x1 stride 2 (the bottleneck down_sample), the four 2x2 sub-pixel phases of the transposed convolution
+//               (simple_baseline_head.py:80-88) and - round 4 - the 3x3 stride-2 convolutions of the HRNet transitions and
+//               exchange units (hrnet.py:280-313, 440-496) use the same tiles with the input columns fetched one by one - four
+//               4-byte loads per staging unit instead of one 16-byte load - and a k loop over (cin chunk, tap) pairs; taps outside
+//               the image read zeros through the buffer range check (a 64-bit mask of (tap, column) bits per thread)
 //   epilogue    scale / shift per cout from LDS, (+res1)(+ReLU); the residual tile is requested in one batch behind the k loop
 #include <stdlib.h>
 
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f32_gemm_kernel(const GemmPara
     const unsigned a_row8 = (unsigned)(8 * T * p.Cout_pad16) * 4u, a_chunk = (unsigned)(kKC * T * p.Cout_pad16) * 4u;
     const unsigned a_tap = (unsigned)(4 * p.Cout_pad16) * 4u;
     unsigned b_src[GATHER ? 4 : 1];  // byte offset of the unit's column(s) in channel srow_b of its image, tap 0
-    unsigned b_inv = 0;              // GATHER: bit 4 t + e set = tap t of column e is outside the image (or the column past the end)
+    unsigned long long b_inv = 0;    // GATHER: bit 4 t + e set = tap t of column e is outside the image (or the column past the end)
 #pragma unroll
     for (int e = 0; e < (GATHER ? 4 : 1); ++e) {
         const int j = col0 + c4_b + e;  // HWo % 4 == 0: the four columns of a unit are one image's consecutive pixels
@@ -97,9 +99,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f32_gemm_kernel(const GemmPara
             const int oy = pp / p.Wo, ox = pp - oy * p.Wo;
             const int y0 = oy * p.stride - pad_top, x0 = ox * p.stride - pad_left;
             b_src[e] = (unsigned)((n * p.Cin + srow_b) * p.HWi + y0 * p.Wi + x0) * 4u;  // may wrap below zero: masked then
-            for (int t = 0; t < T; ++t) {
-                const int yy = y0 + (t >> p.kw_shift), xx = x0 + (t & ((1 << p.kw_shift) - 1));
-                if (j >= p.cols || yy < 0 || yy >= p.Hi || xx < 0 || xx >= p.Wi) b_inv |= 1u << (4 * t + e);
+            for (int t = 0, ky = 0, kx = 0; t < T; ++t) {
+                const int yy = y0 + ky, xx = x0 + kx;
+                if (j >= p.cols || yy < 0 || yy >= p.Hi || xx < 0 || xx >= p.Wi) b_inv |= 1ull << (4 * t + e);
+                if (++kx == p.kw) { kx = 0; ++ky; }
             }
         } else {
             b_src[e] = j < p.cols ? (unsigned)((n * p.Cin + srow_b) * p.HWi + pp) * 4u : kOob;
@@ -109,27 +112,39 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f32_gemm_kernel(const GemmPara
     const int s_dst = srow * kPitch + c4, s_dst_b = srow_b * kPitch + c4_b;
 
     f32x4 va[MI], vb[NI];
-    auto stage_load = [&](int it) {  // kOob + offset stays out of range (every tensor here spans < 2 GiB)
-        const int ch = GATHER ? it >> p.t_shift : it, t = GATHER ? it & (T - 1) : 0;
+    // the k loop walks (cin chunk, tap) pairs in order: stage_load is called for iteration 0, 1, 2, ... and steps its own counters
+    // (T is 1, 4 or 9: no shift decodes it)
+    int s_ch = 0, s_t = 0, s_ky = 0, s_kx = 0;
+    auto stage_load = [&](int it) __attribute__((always_inline)) {  // kOob + offset stays out of range (every tensor here spans < 2 GiB)
+        const int ch = GATHER ? s_ch : it, t = GATHER ? s_t : 0;
         const unsigned ao = a_src + ch * a_chunk + t * a_tap;
 #pragma unroll
         for (int i = 0; i < MI; ++i) va[i] = buf_load4(rs_w, ao + i * a_row8);
         if constexpr (GATHER) {
-            const unsigned bo = ch * b_chunk + (unsigned)((t >> p.kw_shift) * p.Wi + (t & ((1 << p.kw_shift) - 1))) * 4u;
+            const unsigned bo = ch * b_chunk + (unsigned)(s_ky * p.Wi + s_kx) * 4u;
+            const unsigned inv4 = (unsigned)(b_inv >> (4 * t)) & 15u;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 // outside the image: top bit set = out of range = zero.  The mask goes on LAST: a column left of / above the image
                 // has a wrapped ("negative") base that a later addition would carry back into range
-                const unsigned inv = (b_inv >> (4 * t + e)) << 31;
+                const unsigned inv = (inv4 >> e) << 31;
 #pragma unroll
                 for (int i = 0; i < NI; ++i) vb[i][e] = buf_load1(rs_x, (b_src[e] + bo + i * b_row8) | inv);
             }
+            // next (chunk, tap): plain selects (an if / else-if over the counters made hipcc index them in scratch memory)
+            ++s_t;
+            ++s_kx;
+            const bool row_end = s_kx == p.kw, chunk_end = s_t == T;
+            s_kx = row_end ? 0 : s_kx;
+            s_ky = chunk_end ? 0 : s_ky + (row_end ? 1 : 0);
+            s_t = chunk_end ? 0 : s_t;
+            s_ch += chunk_end ? 1 : 0;
         } else {
 #pragma unroll
             for (int i = 0; i < NI; ++i) vb[i] = buf_load4(rs_x, b_src[0] + ch * b_chunk + i * b_row8);
         }
     };
-    auto stage_store = [&](int buf) {
+    auto stage_store = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) *reinterpret_cast<f32x4*>(lds_a + buf * kBuf + s_dst + i * 8 * kPitch) = va[i];
 #pragma unroll
@@ -172,7 +187,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f32_gemm_kernel(const GemmPara
     // ---- epilogue.  Accumulator r of a 32x32 tile: row (cout) 8 (r / 4) + 4 lh + r % 4, column (pixel) l31
     const size_t o_bytes = (size_t)p.N * p.Cout * p.OHW * 4;
     const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(p.out, o_bytes);
-    const __amdgpu_buffer_rsrc_t rs_r1 = make_rsrc(p.res1 ? p.res1 : p.out, p.res1 ? o_bytes : 0);
     unsigned o_col[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
@@ -182,25 +196,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f32_gemm_kernel(const GemmPara
         o_col[ni] = j < p.cols ? (unsigned)(n * p.Cout * p.OHW + (oy * p.out_mul + off_y) * p.OW + ox * p.out_mul + off_x) * 4u : kOob;
     }
     const unsigned plane = (unsigned)p.OHW * 4u;
-    f32x16 r1[MI][NI];
-    if (p.res1) {  // workgroup-uniform
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = co0 + wm * 32 * MI + mi * 32 + (r >> 2) * 8 + lh * 4 + (r & 3);
-                    r1[mi][ni][r] = buf_load1(rs_r1, (o_col[ni] + co * plane) | (co < p.Cout ? 0u : kOob));  // kOob + offset stays out of range
-                }
-    } else {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) r1[mi][ni][r] = 0.f;
-    }
+    // scale / shift first, then the residual tensors one after the other through ONE staging set (two sets beside the accumulators
+    // would not fit two workgroups per CU), then ReLU and the stores
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -210,9 +207,40 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f32_gemm_kernel(const GemmPara
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
+                for (int e = 0; e < 4; ++e) acc[mi][ni][g * 4 + e] = acc[mi][ni][g * 4 + e] * sc[e] + sh[e];
+        }
+    for (int which = 0; which < 2; ++which) {
+        const float* res = which == 0 ? p.res1 : p.res2;
+        if (!res) continue;  // workgroup-uniform
+        const __amdgpu_buffer_rsrc_t rs_r = make_rsrc(res, o_bytes);
+        f32x16 rr[MI][NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wm * 32 * MI + mi * 32 + (r >> 2) * 8 + lh * 4 + (r & 3);
+                    rr[mi][ni][r] = buf_load1(rs_r, (o_col[ni] + co * plane) | (co < p.Cout ? 0u : kOob));  // kOob + offset stays out of range
+                }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] += rr[mi][ni][r];
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int row = wm * 32 * MI + mi * 32 + g * 8 + lh * 4;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int co = co0 + row + e;
-                    float v = acc[mi][ni][g * 4 + e] * sc[e] + sh[e] + r1[mi][ni][g * 4 + e];
+                    float v = acc[mi][ni][g * 4 + e];
                     if (p.relu) v = fmaxf(v, 0.f);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_o,
                                                           (o_col[ni] + co * plane) | (co < p.Cout ? 0u : kOob), 0, 0);
@@ -235,18 +263,23 @@ int gemm_configure(const mp_conv_desc* d, GemmLaunch& L) {
                        d->pad_left <= 1 && d->conv_h == d->h && d->conv_w == d->w && d->out_mul >= 1 && d->out_off_y >= 0 &&
                        d->out_off_x >= 0 && (d->conv_h - 1) * d->out_mul + d->out_off_y < d->out_h &&
                        (d->conv_w - 1) * d->out_mul + d->out_off_x < d->out_w;
-    if ((!pointwise && !phase) || d->out_rep != 1) return MP_ERR_UNSUPPORTED;
+    // round 4: the 3x3 stride-2 pad-1 convolutions of the HRNet transitions / exchange units, dense output, as a nine-tap gather
+    const bool conv3s2 = d->kh == 3 && d->kw == 3 && d->stride == 2 && d->pad_top == 1 && d->pad_left == 1 && d->out_mul == 1 &&
+                         d->out_off_y == 0 && d->out_off_x == 0 && d->out_h == d->conv_h && d->out_w == d->conv_w &&
+                         d->conv_h == (d->h - 1) / 2 + 1 && d->conv_w == (d->w - 1) / 2 + 1;
+    if ((!pointwise && !phase && !conv3s2) || d->out_rep != 1) return MP_ERR_UNSUPPORTED;
     const int hwo = d->conv_h * d->conv_w, hwi = d->h * d->w, ohw = d->out_h * d->out_w;
     L.gather = phase || d->stride == 2;
-    // whole chunks of 16 input channels; float4 staging units and columns inside one image; at least most of one cout tile
-    if ((d->cin % kKC) || (hwo & 3) || (!L.gather && (hwi & 3)) || d->cout < 96) return MP_ERR_UNSUPPORTED;
+    // whole chunks of 16 input channels; float4 staging units and columns inside one image; at least most of one cout tile (3x3
+    // stride 2: of one 64-channel tile - the 64-cout layers of the exchange units take 64 x 64 tiles)
+    if ((d->cin % kKC) || (hwo & 3) || (!L.gather && (hwi & 3)) || d->cout < (conv3s2 ? 48 : 96)) return MP_ERR_UNSUPPORTED;
     if ((long long)d->n * d->cin * hwi * 4 >= 0x7FFFFFF0LL || (long long)d->n * d->cout * ohw * 4 >= 0x7FFFFFF0LL) return MP_ERR_UNSUPPORTED;
     GemmParams& p = L.p;
     p.N = d->n; p.Cin = d->cin; p.Cin_pad4 = (d->cin + 3) / 4 * 4; p.Cout = d->cout; p.Cout_pad16 = (d->cout + 15) / 16 * 16;
     p.HWi = hwi; p.Hi = d->h; p.Wi = d->w; p.HWo = hwo; p.Wo = d->conv_w;
     p.OHW = ohw; p.OW = d->out_w; p.out_mul = d->out_mul; p.off_y = d->out_off_y; p.off_x = d->out_off_x;
     p.stride = d->stride; p.pad_top = d->pad_top; p.pad_left = d->pad_left;
-    p.T = d->kh * d->kw; p.t_shift = phase ? 2 : 0; p.kw_shift = phase ? 1 : 0;
+    p.T = d->kh * d->kw; p.kw = d->kw;
     p.phases = 1; p.wp_phase_floats = 0;
     L.phases = 1;
     p.cols = d->n * hwo;
@@ -258,6 +291,7 @@ int gemm_configure(const mp_conv_desc* d, GemmLaunch& L) {
     const long long t128 = (long long)((p.Cout_pad16 + kTM - 1) / kTM) * ((p.cols + kTN - 1) / kTN);
     L.ni = t128 >= 512 ? 2 : 1;
     L.mi = t128 >= 192 ? 2 : 1;
+    if (p.Cout_pad16 <= 64) { L.mi = 1; L.ni = 1; }  // a 128-cout tile would be half empty
     if (const char* e = knob("MP_GEMM_NI")) {  // experiments / tests: 1, 2 = column blocks per wave; 11 = 64 x 64 tiles
         if (atoi(e) == 1 || atoi(e) == 2) { L.ni = atoi(e); L.mi = 2; }
         if (atoi(e) == 11) { L.ni = 1; L.mi = 1; }

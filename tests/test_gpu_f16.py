@@ -478,7 +478,8 @@ def _block_pair(n, c, h, w, seed):
     return xa, packed, scs, shs, two
 
 
-@pytest.mark.parametrize("shape", [(3, 32, 64, 48), (2, 32, 16, 12), (2, 30, 21, 17), (1, 32, 5, 40), (5, 32, 7, 8)])
+@pytest.mark.parametrize("shape", [(3, 32, 64, 48), (2, 32, 16, 12), (2, 30, 21, 17), (1, 32, 5, 40), (5, 32, 7, 8),
+                                   (3, 64, 32, 24), (2, 64, 19, 13), (5, 64, 7, 8), (1, 64, 5, 40), (2, 64, 48, 36)])
 @pytest.mark.parametrize("rows", [0, 4, 1])
 def test_fused_basicblock_equals_two_convs(shape, rows):
     """mp_f16_basicblock_fwd keeps the intermediate tile in LDS; same operands, k order and rounding points as the two-launch
@@ -488,9 +489,11 @@ def test_fused_basicblock_equals_two_convs(shape, rows):
     xa, packed, scs, shs, two = _block_pair(n, c, h, w, seed=h * w + rows)
     fused = ActC8(n, c, h, w, DEV)
     fused.c8_tensor.fill_(7.0)
-    _lib.check(LIB.mp_f16_basicblock_fwd(_lib.ptr(xa), _lib.ptr(packed[0]), _lib.ptr(scs[0]), _lib.ptr(shs[0]), _lib.ptr(packed[1]),
-                                         _lib.ptr(scs[1]), _lib.ptr(shs[1]), _lib.ptr(fused), n, c, h, w, rows, _lib.stream()),
-               "mp_f16_basicblock_fwd")
+    rc = LIB.mp_f16_basicblock_fwd(_lib.ptr(xa), _lib.ptr(packed[0]), _lib.ptr(scs[0]), _lib.ptr(shs[0]), _lib.ptr(packed[1]),
+                                   _lib.ptr(scs[1]), _lib.ptr(shs[1]), _lib.ptr(fused), n, c, h, w, rows, _lib.stream())
+    if rc == -3 and rows > 0 and LIB.mp_f16_basicblock_supported(n, c, h, w) == 1:
+        pytest.skip("this forced band height does not fit the kernel's tile budget for this map (rows = 0 does)")
+    _lib.check(rc, "mp_f16_basicblock_fwd")
     torch.cuda.synchronize()
     assert torch.equal(fused.c8_tensor, two.c8_tensor)
 
@@ -498,7 +501,9 @@ def test_fused_basicblock_equals_two_convs(shape, rows):
 def test_fused_basicblock_rejects_other_widths():
     xa, packed, scs, shs, two = _block_pair(1, 32, 8, 8, seed=1)
     args = (_lib.ptr(packed[0]), _lib.ptr(scs[0]), _lib.ptr(shs[0]), _lib.ptr(packed[1]), _lib.ptr(scs[1]), _lib.ptr(shs[1]))
-    assert LIB.mp_f16_basicblock_fwd(_lib.ptr(xa), *args, _lib.ptr(two), 1, 64, 8, 8, 0, _lib.stream()) == -3  # MP_ERR_UNSUPPORTED
+    assert LIB.mp_f16_basicblock_fwd(_lib.ptr(xa), *args, _lib.ptr(two), 1, 48, 8, 8, 0, _lib.stream()) == -3  # MP_ERR_UNSUPPORTED
+    assert LIB.mp_f16_basicblock_supported(4, 64, 32, 24) == 1 and LIB.mp_f16_basicblock_supported(4, 32, 64, 48) == 1
+    assert LIB.mp_f16_basicblock_supported(4, 48, 32, 24) == 0 and LIB.mp_f16_basicblock_supported(4, 64, 8, 300) == 0
     assert LIB.mp_f16_basicblock_fwd(_lib.ptr(xa), *args, _lib.ptr(xa), 1, 32, 8, 8, 0, _lib.stream()) == -3  # MP_ERR_UNSUPPORTED
     assert LIB.mp_f16_basicblock_fwd(None, *args, _lib.ptr(two), 1, 32, 8, 8, 0, _lib.stream()) == -1  # MP_ERR_NULL
 
