@@ -293,7 +293,7 @@ int blockf16_build(const void* x, const void* w1, const float* scale1, const flo
     if (n <= 0 || h <= 0 || w <= 0) return MP_ERR_SHAPE;
     if (rows < 0) return MP_ERR_SHAPE;
     if (x == out) return MP_ERR_UNSUPPORTED;  // neighbouring tiles read the halo rows this tile would overwrite
-    if (c == 64) return blockf16_c64_build(x, w1, scale1, shift1, w2, scale2, shift2, out, n, c, h, w, rows, L) ? MP_OK : MP_ERR_UNSUPPORTED;
+    if (c == 64 || c == 128) return blockf16_c64_build(x, w1, scale1, shift1, w2, scale2, shift2, out, n, c, h, w, rows, L) ? MP_OK : MP_ERR_UNSUPPORTED;
     if (c <= 24 || c > 32) return MP_ERR_UNSUPPORTED;  // exactly four 8-channel blocks (channels beyond c are zero padding)
     if (blockf16_v2_build(x, w1, scale1, shift1, w2, scale2, shift2, out, n, c, h, w, rows, L)) return MP_OK;
     if (rows > 6) return MP_ERR_UNSUPPORTED;
@@ -341,7 +341,7 @@ int blockf16_build(const void* x, const void* w1, const float* scale1, const flo
 }
 
 int blockf16_launch(const BlockF16Launch& L, hipStream_t s) {
-    if (L.small == 4) return blockf16_c64_launch(L, s);
+    if (L.small >= 4) return blockf16_c64_launch(L, s);
     if (L.small >= 2) return blockf16_v2_launch(L, s);
     return L.small ? launch_block<5, 3>(L.p, L.lds_bytes, s) : launch_block<6, 5>(L.p, L.lds_bytes, s);
 }

@@ -32,16 +32,18 @@ namespace {
 constexpr int kC64MaxPieces = 8;  // DMA pieces (64 x 16 B) per input plane
 constexpr int kC64Win = 8;        // pixel-operand fragments in flight
 
-// PS1 / PS2 = pixel tiles of 16 PER WAVE for the intermediate / output band (two waves split the pixels, two the couts)
-template <int PS1, int PS2>
-__global__ __launch_bounds__(256, 2) void basicblock_f16_c64_kernel(const BlockF16Params p) {
-    constexpr int NQ = 2, T = 9, NPL = 8, CS = 2;  // 64 channels = eight 8-channel planes = two k-steps of 32; two cout tiles per wave
+// NQ = k-steps of 32 channels (C = 32 NQ: 64 or 128); the workgroup has 2 NQ waves - two pixel halves x NQ cout pairs (NQ = 2: four
+// waves, two workgroups per CU; NQ = 4: eight waves, one workgroup per CU, two waves per SIMD).  PS1 / PS2 = pixel tiles of 16 PER
+// WAVE for the intermediate / output band
+template <int NQ, int PS1, int PS2>
+__global__ __launch_bounds__(128 * NQ, NQ == 2 ? 2 : 1) void basicblock_f16_c64_kernel(const BlockF16Params p) {
+    constexpr int T = 9, NPL = 4 * NQ, CS = 2, C = 32 * NQ, NTHREADS = 128 * NQ;  // NPL 8-channel planes; two cout tiles per wave
     extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
     u32x4* __restrict__ lds_in = smem16;                      // [8][plane_in]: pixel (r, x) at r Wp + x + 1, row 0 = image row y0 - 2
     u32x4* __restrict__ lds_mid = smem16 + NPL * p.plane_in;  // [8][plane_mid]: row 0 = image row y0 - 1; + one dummy element behind
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wp = wave & 1, wc = wave >> 1;  // pixel half, cout half (32 couts = one PAIR of cout tiles: 16-byte elements per lane)
+    const int wp = wave & 1, wc = wave >> 1;  // pixel half, cout pair (32 couts = one PAIR of cout tiles: 16-byte elements per lane)
     const int lq = lane >> 4, lr = lane & 15;
 
     int b = blockIdx.x;
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void basicblock_f16_c64_kernel(const BlockF
     const int HW = p.H * p.W, P = p.Wp;
     const unsigned plane_bytes = (unsigned)HW * 16u;
 
-    // ---- input tile by LDS-DMA: wave w stages planes w and w + 4; the slot -> (row, column) map is the same for every plane:
+    // ---- input tile by LDS-DMA: wave w stages planes w and w + 2 NQ; the slot -> (row, column) map is the same for every plane:
     //      decoded once (the division is a quarter-rate multiply)
     {
         const int ppp = p.plane_in >> 6;
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void basicblock_f16_c64_kernel(const BlockF
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int pl = wave + 4 * j;
+            const int pl = wave + 2 * NQ * j;
             const __amdgpu_buffer_rsrc_t rs = make_rsrc(img + (size_t)pl * plane_bytes, plane_bytes);
 #pragma unroll
             for (int s = 0; s < kC64MaxPieces; ++s) {
@@ -80,14 +82,14 @@ __global__ __launch_bounds__(256, 2) void basicblock_f16_c64_kernel(const BlockF
         }
     }
     // ---- weight fragments of this wave's cout pair: a ring of ONE k-step (9 taps x 2 cout tiles = 72 registers).  The ring walks
-    //      conv1 k-step 0 -> conv1 k-step 1 -> conv2 k-step 0 -> conv2 k-step 1: the fragment of tap t is replaced by the next
+    //      conv1 k-step 0 -> ... -> conv1 k-step NQ - 1 -> conv2 k-step 0 -> ...: the fragment of tap t is replaced by the next
     //      sequence element's right behind the MFMAs that consumed it, i.e. one k-step (9 taps) of prefetch distance
-    const unsigned w_bytes = (unsigned)(NQ * T * 4 * 64 * 16);
+    const unsigned w_bytes = (unsigned)(NQ * T * 4 * C * 16);
     const __amdgpu_buffer_rsrc_t rs_w1 = make_rsrc(p.w1, w_bytes), rs_w2 = make_rsrc(p.w2, w_bytes);
     unsigned a_off[CS];
 #pragma unroll
-    for (int cs = 0; cs < CS; ++cs) a_off[cs] = (unsigned)(lq * 64 + wc * 32 + f16_a_row<CS>(cs, lr)) * 16u;
-    constexpr unsigned kTapBytes = 4u * 64u * 16u;
+    for (int cs = 0; cs < CS; ++cs) a_off[cs] = (unsigned)(lq * C + wc * 32 + f16_a_row<CS>(cs, lr)) * 16u;
+    constexpr unsigned kTapBytes = 4u * (unsigned)C * 16u;
     u32x4 A[T][CS];
 #pragma unroll
     for (int t = 0; t < T; ++t)
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void basicblock_f16_c64_kernel(const BlockF
     {
         const int per_plane = p.R + 3;
         const u32x4 zero = (u32x4){0u, 0u, 0u, 0u};
-        for (int i = tid; i < NPL * per_plane; i += 256) {
+        for (int i = tid; i < NPL * per_plane; i += NTHREADS) {
             const int pl = i / per_plane, r = i - pl * per_plane;
             lds_mid[pl * p.plane_mid + r * P] = zero;
         }
@@ -154,10 +156,10 @@ __global__ __launch_bounds__(256, 2) void basicblock_f16_c64_kernel(const BlockF
             if (i + kC64Win < M) win[i % kC64Win] = b_at(i + kC64Win);
             if (ps == PS - 1) {
                 // this tap's fragments are free: the next k-step's (same conv, k-step 1 - or the other conv's k-step 0) take their place
-                if (q == 0) {
+                if (q + 1 < NQ) {
 #pragma unroll
                     for (int cs = 0; cs < CS; ++cs)
-                        A[t][cs] = __builtin_amdgcn_raw_buffer_load_b128(rs_same, a_off[cs] + (unsigned)(T + t) * kTapBytes, 0, 0);
+                        A[t][cs] = __builtin_amdgcn_raw_buffer_load_b128(rs_same, a_off[cs] + (unsigned)((q + 1) * T + t) * kTapBytes, 0, 0);
                 } else if (has_other) {
 #pragma unroll
                     for (int cs = 0; cs < CS; ++cs)
@@ -223,27 +225,29 @@ __global__ __launch_bounds__(256, 2) void basicblock_f16_c64_kernel(const BlockF
     }
 }
 
-template <int PS1, int PS2>
+template <int NQ, int PS1, int PS2>
 int launch_c64(const BlockF16Params& p, size_t lds_bytes, hipStream_t s) {
-    auto kern = basicblock_f16_c64_kernel<PS1, PS2>;
+    auto kern = basicblock_f16_c64_kernel<NQ, PS1, PS2>;
     static AttrOnce attr_set_once;
     if (attr_set_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
     }
-    hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(256), lds_bytes, s, p);
+    hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(128 * NQ), lds_bytes, s, p);
     return check_launch();
 }
 
 }  // namespace
 
-// geometry: exactly 64 channels; a band of R rows whose R + 2 intermediate rows fill at most 16 pixel tiles of 16 (12 for the output)
+// geometry: exactly 64 or 128 channels; a band of R rows whose R + 2 intermediate rows fill at most 2 x PS1 pixel tiles of 16 (2 x PS2
+// for the output): 64 channels 8 / 6 tiles per wave (two workgroups per CU), 128 channels 4 / 3 (one eight-wave workgroup per CU)
 bool blockf16_c64_build(const void* x, const void* w1, const float* scale1, const float* shift1, const void* w2, const float* scale2,
                         const float* shift2, void* out, int n, int c, int h, int w, int rows, BlockF16Launch& L) {
-    if (c != 64 || x == out) return false;
+    if ((c != 64 && c != 128) || x == out) return false;
     if (const char* e = knob("MP_F16_BLOCK_C64"))
         if (atoi(e) == 0) return false;
-    if ((size_t)n * 8 * h * w * 16 > 0x7FFFFFF0u) return false;
+    const int npl = c / 8, ps1 = c == 64 ? 8 : 4, ps2 = c == 64 ? 6 : 3;
+    if ((size_t)n * npl * h * w * 16 > 0x7FFFFFF0u) return false;
     BlockF16Params p{};
     p.x = x; p.w1 = w1; p.w2 = w2; p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2; p.out = out;
     p.N = n; p.H = h; p.W = w;
@@ -251,11 +255,11 @@ bool blockf16_c64_build(const void* x, const void* w1, const float* scale1, cons
     int best = 0;
     for (int R = (rows > 0 ? rows : 12); R >= 1; --R) {
         if (R > h && R > 1) continue;
-        if ((R + 2) * w > 16 * 16 || R * w > 12 * 16) continue;  // two waves x 8 / 6 pixel tiles
+        if ((R + 2) * w > 32 * ps1 || R * w > 32 * ps2) continue;
         const int plane_in = round_up((R + 4) * p.Wp + 1, 64);
         if (plane_in / 64 > kC64MaxPieces) continue;
-        const size_t bytes = ((size_t)8 * (plane_in + round_up((R + 2) * p.Wp + 1, 16)) + 1) * 16;
-        if (bytes > (size_t)78 * 1024) continue;  // two workgroups per CU
+        const size_t bytes = ((size_t)npl * (plane_in + round_up((R + 2) * p.Wp + 1, 16)) + 1) * 16;
+        if (bytes > (size_t)(c == 64 ? 78 : 150) * 1024) continue;  // 64 channels: two workgroups per CU
         best = R;
         break;
     }
@@ -272,11 +276,13 @@ bool blockf16_c64_build(const void* x, const void* w1, const float* scale1, cons
     p.magic_w = magic_of((unsigned)p.Wp);   // DMA slot -> row
     p.magic_rw = magic_of((unsigned)w);     // pixel -> row
     L.p = p;
-    L.small = 4;  // marks this kernel (0 / 1: first structure, 2: second structure of the 32-channel block)
-    L.lds_bytes = ((size_t)8 * (p.plane_in + p.plane_mid) + 1) * 16;
+    L.small = c == 64 ? 4 : 5;  // marks this kernel (0 / 1: first structure, 2: second structure of the 32-channel block)
+    L.lds_bytes = ((size_t)npl * (p.plane_in + p.plane_mid) + 1) * 16;
     return true;
 }
 
-int blockf16_c64_launch(const BlockF16Launch& L, hipStream_t s) { return launch_c64<8, 6>(L.p, L.lds_bytes, s); }
+int blockf16_c64_launch(const BlockF16Launch& L, hipStream_t s) {
+    return L.small == 5 ? launch_c64<4, 4, 3>(L.p, L.lds_bytes, s) : launch_c64<2, 8, 6>(L.p, L.lds_bytes, s);
+}
 
 }  // namespace mp

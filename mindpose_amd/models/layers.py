@@ -566,17 +566,17 @@ class Plan:
 
     def fuses_basic_block(self, x: torch.Tensor, conv1: Conv2d, conv2: Conv2d) -> bool:
         """The fused fp16 BasicBlock kernels cover the 32-channel branch (four 8-channel blocks) and, round 4, the 64-channel branch
-        (3x3 stride 1 both convs; the library says whether the map fits a band: ``mp_f16_basicblock_supported``);
-        ``MINDPOSE_FUSE_BLOCK=0`` keeps the two-launch path, ``MINDPOSE_FUSE_BLOCK64=0`` for the 64-channel blocks only."""
+        and 128-channel branches (3x3 stride 1 both convs; the library says whether the map fits a band: ``mp_f16_basicblock_supported``);
+        ``MINDPOSE_FUSE_BLOCK=0`` keeps the two-launch path, ``MINDPOSE_FUSE_BLOCK64=0`` for the 64 / 128-channel blocks only."""
         if not isinstance(x, ActC8) or os.environ.get("MINDPOSE_FUSE_BLOCK", "1") == "0":
             return False
         n, c, h, w = x.shape
         if not all(cv.in_channels == c and cv.out_channels == c and cv.kernel_size == 3 and cv.stride == 1 and cv.padding == 1
                    and cv.bias is None for cv in (conv1, conv2)):
             return False
-        if c == 64 and os.environ.get("MINDPOSE_FUSE_BLOCK64", "1") == "0":
+        if c in (64, 128) and os.environ.get("MINDPOSE_FUSE_BLOCK64", "1") == "0":
             return False
-        return (24 < c <= 32 or c == 64) and self.lib.mp_f16_basicblock_supported(n, c, h, w) == 1
+        return (24 < c <= 32 or c in (64, 128)) and self.lib.mp_f16_basicblock_supported(n, c, h, w) == 1
 
     def basic_block(self, x: torch.Tensor, conv1: Conv2d, bn1: BatchNorm2d, conv2: Conv2d, bn2: BatchNorm2d) -> torch.Tensor:
         """relu(bn2(conv2(relu(bn1(conv1 x)))) + x) in ONE launch (mp_f16_basicblock_fwd): the intermediate tensor stays in LDS;

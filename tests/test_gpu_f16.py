@@ -479,7 +479,8 @@ def _block_pair(n, c, h, w, seed):
 
 
 @pytest.mark.parametrize("shape", [(3, 32, 64, 48), (2, 32, 16, 12), (2, 30, 21, 17), (1, 32, 5, 40), (5, 32, 7, 8),
-                                   (3, 64, 32, 24), (2, 64, 19, 13), (5, 64, 7, 8), (1, 64, 5, 40), (2, 64, 48, 36)])
+                                   (3, 64, 32, 24), (2, 64, 19, 13), (5, 64, 7, 8), (1, 64, 5, 40), (2, 64, 48, 36),
+                                   (3, 128, 16, 12), (2, 128, 11, 9), (5, 128, 7, 8), (2, 128, 24, 18)])
 @pytest.mark.parametrize("rows", [0, 4, 1])
 def test_fused_basicblock_equals_two_convs(shape, rows):
     """mp_f16_basicblock_fwd keeps the intermediate tile in LDS; same operands, k order and rounding points as the two-launch

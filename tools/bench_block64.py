@@ -11,17 +11,18 @@ from mindpose_amd.models.layers import ActC8, F16_VARIANTS  # noqa: E402
 
 lib = _lib.load()
 dev = torch.device("cuda:0")
-c, h, w = 64, 32, 24
-for n in [int(a) for a in sys.argv[1:]] or [32, 128, 256]:
+c = 128 if "c128" in sys.argv[1:] else 64
+h, w = (16, 12) if c == 128 else (32, 24)
+for n in [int(a) for a in sys.argv[1:] if a.isdigit()] or [32, 128, 256]:
     x, mid, out = (ActC8(n, c, h, w, dev) for _ in range(3))
     x.c8_tensor.normal_()
     pk = []
     for _ in range(2):
-        wt = torch.randn(c, c, 3, 3, device=dev) / 24
+        wt = torch.randn(c, c, 3, 3, device=dev) / (9 * c) ** 0.5
         p = torch.empty(lib.mp_f16_packed_weight_bytes(c, c, 3, 3) // 2, device=dev, dtype=torch.float16)
         _lib.check(lib.mp_f16_pack_weight(_lib.ptr(wt), _lib.ptr(p), c, c, 3, 3, 0, 0, 0, _lib.stream()), "pack")
         pk.append(p)
-    sc, sh = torch.ones(64, device=dev), torch.zeros(64, device=dev)
+    sc, sh = torch.ones(c, device=dev), torch.zeros(c, device=dev)
     d = _lib.ConvDesc(n=n, cin=c, h=h, w=w, cout=c, kh=3, kw=3, stride=1, pad_top=1, pad_left=1, conv_h=h, conv_w=w, out_h=h,
                       out_w=w, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=1, flags=0)
 
@@ -47,4 +48,4 @@ for n in [int(a) for a in sys.argv[1:]] or [32, 128, 256]:
 
     best = min((timeit(two, v), v) for v in range(F16_VARIANTS) if two(v) == 0)
     res = {f"fused R{r}": timeit(fused, r) for r in (8, 6, 4) if fused(r) == 0}
-    print(f"64 ch {h}x{w} N={n:4d} us per BLOCK: two launches (best variant v{best[1]}) {best[0]:6.1f}  " + "  ".join(f"{k} {v:6.1f}" for k, v in res.items()), flush=True)
+    print(f"{c} ch {h}x{w} N={n:4d} us per BLOCK: two launches (best variant v{best[1]}) {best[0]:6.1f}  " + "  ".join(f"{k} {v:6.1f}" for k, v in res.items()), flush=True)
