@@ -76,7 +76,8 @@ def kernel_name(info):
         teams = max(1, info.get("cout_tile", 32) // 32)  # two four-wave teams: a 64-channel cout tile per workgroup
         return f"conv_wino_f32_kernel<{info.get('light', 0)},{'true' if qrow else 'false'},{'true' if group else 'false'},{teams}>"
     if info["kind_id"] == 8:  # fused fp16 BasicBlock: the <5,3> or <6,5> pixel-tile build ("variant" = 1 for the small one)
-        return {0: "basicblock_f16_kernel<6,5>", 1: "basicblock_f16_kernel<5,3>", 2: "basicblock_f16_v2_kernel<8,4,3>"}[info["variant"]]
+        return {0: "basicblock_f16_kernel<6,5>", 1: "basicblock_f16_kernel<5,3>", 2: "basicblock_f16_v2_kernel<8,4,3>",
+                4: "basicblock_f16_c64_kernel<2,8,6>", 5: "basicblock_f16_c64_kernel<4,4,3>"}[info["variant"]]  # 4 / 5: 64 / 128 channels
     if info["kind_id"] == 3:
         v = info["variant"]
         if 37 <= v < 45:  # weight-stationary persistent kernel <k-steps, cout tiles per wave, pixel-splitting waves, pixel tiles, waves/SIMD

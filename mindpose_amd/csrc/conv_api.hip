@@ -701,7 +701,8 @@ int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]) {
         info[11] = e.wino.ni;
     } else if (e.kind == 8) {
         info[1] = 3; info[2] = 1; info[3] = e.block16.small; info[4] = e.block16.p.total_blocks;
-        info[5] = (int64_t)e.block16.lds_bytes; info[6] = 32; info[7] = e.block16.p.M2; info[8] = 32; info[9] = 1;
+        const int blk_c = e.block16.small == 4 ? 64 : e.block16.small == 5 ? 128 : 32;  // cout tile / cin chunk = the block's width
+        info[5] = (int64_t)e.block16.lds_bytes; info[6] = blk_c; info[7] = e.block16.p.M2; info[8] = blk_c; info[9] = 1;
         info[10] = e.block16.p.R;
     }
     return MP_OK;

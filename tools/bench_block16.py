@@ -44,7 +44,7 @@ for n in [int(a) for a in sys.argv[1:]] or [8, 32, 128, 256]:
         return e0.elapsed_time(e1) * 1e3 / 50
 
     import os
-os.environ.setdefault("MINDPOSE_EXPERIMENT_KNOBS", "1")  # the MP_* knobs below are honoured only then
+    os.environ.setdefault("MINDPOSE_EXPERIMENT_KNOBS", "1")  # the MP_* knobs below are honoured only then
     res = {f"two v{v}": timeit(two, v) for v in (10,)}
     os.environ["MP_F16_BLOCK_V2"] = "0"
     res.update({f"v1 R{r}": timeit(fused, r) for r in (6, 5)})
