@@ -435,7 +435,7 @@ class CallTimer:
     OTHER = ("mp_f16_fuse_upsample_sum", "mp_f16_fuse_upsample_sum_bwd", "mp_fuse_upsample_sum", "mp_fuse_upsample_sum_bwd",
              "mp_f16_to_c8", "mp_f16_from_c8", "mp_f16_pack_weight_batch", "mp_conv_pack_weight_batch", "mp_f16_pack_weight",
              "mp_conv_pack_weight", "mp_joints_mse_fwd", "mp_joints_mse_bwd", "mp_gaussian_target", "mp_adamw_step_scaled",
-             "mp_grad_finite_check", "mp_sum_tensors", "mp_f16_sum_tensors_stats", "mp_f16_fuse_sum_bwd_term_stats")
+             "mp_grad_finite_check", "mp_sum_tensors", "mp_f16_sum_tensors_stats", "mp_f16_fuse_sum_bwd_term_stats", "mp_f16_bn_train_finalize")
 
     def __init__(self, lib):
         self.lib, self.records, self._orig = lib, [], {}

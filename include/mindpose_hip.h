@@ -467,8 +467,21 @@ typedef struct mp_f16_conv_stats {
     const float* invstd_dev;
     const float* gamma_dev;
     const float* beta_dev;
+    /* mode 1 only - BatchNorm apply of the layer BELOW on this conv's input operand (hrnet.py:67-72: conv1 -> bn1 -> relu -> conv2
+     * without a pass over y1): x_c8_dev holds the RAW output z of the conv below, pre_scale / pre_shift its folded batch statistics
+     * (mp_f16_bn_train_finalize: [round_up(cin, 32)] floats, zeros behind cin); the kernel convolves
+     * act(z * scale + shift) - the same fp32 fma, ReLU and single fp16 rounding as mp_f16_bn_train_fwd_stats - and, when
+     * pre_out_dev is given, also stores that activation tensor (geometry of x; the backward pass reads it).  Bit-identical to the
+     * apply pass followed by the plain launch.  3x3 stride-1 weights-in-registers variants only: MP_ERR_UNSUPPORTED otherwise. */
+    const float* pre_scale_dev;
+    const float* pre_shift_dev;
+    void* pre_out_dev;
+    int pre_relu;
 } mp_f16_conv_stats;
 int mp_f16_conv_stats_parts(const mp_conv_desc* desc, int variant);
+/* 1 when mp_f16_conv2d_fwd_stats(desc, variant, ...) accepts stats->pre_scale_dev (BatchNorm apply of the layer below on the input
+ * operand): an explicit variant of the weights-in-registers family on a 3x3 stride-1 layer staged one image per tile. */
+int mp_f16_conv_pre_supported(const mp_conv_desc* desc, int variant);
 int mp_f16_conv2d_fwd_stats(const mp_conv_desc* desc, int variant, const void* x_c8_dev, const void* packed_w_dev,
                             const float* scale_dev, const float* shift_dev, const void* res1_c8_dev, void* out_c8_dev,
                             const mp_f16_conv_stats* stats, mp_stream_t stream);
@@ -481,6 +494,14 @@ int mp_f16_bn_train_fwd_stats(const void* z_dev, const float* gamma_dev, const f
                               float* save_mean_dev, float* save_invstd_dev, float* moving_mean_dev, float* moving_var_dev, int n,
                               int c, int hw, float eps, float momentum, int relu, const float* partials_dev, int n_parts,
                               void* workspace_dev, size_t workspace_bytes, mp_stream_t stream);
+/* The statistics half of mp_f16_bn_train_fwd_stats alone (reference: nn.BatchNorm2d in training mode, hrnet.py:51-64): saved mean /
+ * invstd, moving averages and the folded scale_dev / shift_dev ([ceil(c/8)*8] floats, zeros on padding channels) for a consumer
+ * that applies the BatchNorm on its own operand (mp_f16_conv_stats.pre_scale_dev).  Same fold order and arithmetic as the apply
+ * pass: the two routes give bit-identical activations. */
+int mp_f16_bn_train_finalize(const float* gamma_dev, const float* beta_dev, float* save_mean_dev, float* save_invstd_dev,
+                             float* moving_mean_dev, float* moving_var_dev, int n, int c, int hw, float eps, float momentum,
+                             const float* partials_dev, int n_parts, float* scale_dev, float* shift_dev, void* workspace_dev,
+                             size_t workspace_bytes, mp_stream_t stream);
 /* The two element-wise producers of a BatchNorm's output gradient with the same statistics (partials [ceil(c/8)][n_parts][8][2],
  * n_parts = mp_f16_ew_stats_parts(n, c, hw of the OUTPUT tensor)):
  *   mp_f16_sum_tensors_stats: out = fp16(((a + b) + c) + d) * [y > 0] - mp_sum_tensors (the gradients of the consumers of a branch

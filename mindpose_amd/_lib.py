@@ -31,7 +31,8 @@ class ConvStats(ctypes.Structure):
     """``mp_f16_conv_stats`` of include/mindpose_hip.h (BatchNorm partial sums from a conv launch's epilogue)."""
     _fields_ = [("mode", ctypes.c_int), ("relu", ctypes.c_int), ("partials", ctypes.c_void_p), ("partials_bytes", ctypes.c_size_t),
                 ("z", ctypes.c_void_p), ("y", ctypes.c_void_p), ("mean", ctypes.c_void_p), ("invstd", ctypes.c_void_p),
-                ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p)]
+                ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("pre_scale", ctypes.c_void_p), ("pre_shift", ctypes.c_void_p),
+                ("pre_out", ctypes.c_void_p), ("pre_relu", ctypes.c_int)]
 
 
 class MindposeHipError(RuntimeError):
@@ -137,6 +138,9 @@ _PROTOTYPES = {
     "mp_f16_conv2d_fwd_stats": (c_int, [ctypes.POINTER(ConvDesc), c_int] + [c_f32p] * 6 + [ctypes.POINTER(ConvStats), ctypes.c_void_p]),
     "mp_f16_bn_train_fwd_stats": (c_int, [c_f32p] * 9 + [c_int] * 3 + [ctypes.c_float, ctypes.c_float, c_int, c_f32p, c_int, c_f32p,
                                           c_size_t, ctypes.c_void_p]),
+    "mp_f16_conv_pre_supported": (c_int, [ctypes.POINTER(ConvDesc), c_int]),
+    "mp_f16_bn_train_finalize": (c_int, [c_f32p] * 6 + [c_int] * 3 + [ctypes.c_float, ctypes.c_float, c_f32p, c_int, c_f32p, c_f32p, c_f32p,
+                                         c_size_t, ctypes.c_void_p]),
     "mp_f16_bn_train_bwd_stats": (c_int, [c_f32p] * 10 + [c_int] * 3 + [c_f32p, c_int, c_f32p, c_size_t, ctypes.c_void_p]),
     "mp_f16_bn_train_fwd_stats_grouped": (c_int, [ctypes.POINTER(BnFwdJob), c_int, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),
     "mp_f16_bn_train_bwd_stats_grouped": (c_int, [ctypes.POINTER(BnBwdJob), c_int, ctypes.c_void_p]),

@@ -46,6 +46,13 @@ struct ConvF16Params {
     float* st_part;        // [C8out][st_nparts][8][2] fp32
     const void* st_z;      // mode 2: the BatchNorm's input (output geometry, c8 halfs)
     const void* st_y;      // mode 2, st_relu == 1: the BatchNorm's output (mask = y > 0)
+    // BatchNorm apply on the INPUT operand (training, mode 1, weights-in-registers kernel): the tensor at x is the raw conv output z
+    // of the layer below; the staged tile becomes act(z * pre_scale[c] + pre_shift[c]) in LDS (padding stays zero) and the tile's own
+    // rows are also written to pre_out - the activation tensor the backward pass reads - so no separate apply pass runs
+    const float* pre_scale;  // [PK * 8] (zeros behind Cin); null: off
+    const float* pre_shift;
+    void* pre_out;           // may be null
+    int pre_relu;
 };
 
 struct ConvF16Launch {

@@ -946,6 +946,17 @@ int mp_f16_conv_stats_parts(const mp_conv_desc* desc, int variant) {
     return f16_stats_parts(L);
 }
 
+int mp_f16_conv_pre_supported(const mp_conv_desc* desc, int variant) {
+    if (!desc || variant < 0 || variant >= F_COUNT || f16_validate(desc) != MP_OK || !f16_stats_shape_ok(desc)) return 0;
+    ConvF16Launch L{};
+    const void* dummy = reinterpret_cast<const void*>(static_cast<uintptr_t>(16));
+    if (f16_build_launch(desc, variant, dummy, dummy, reinterpret_cast<const float*>(dummy), reinterpret_cast<const float*>(dummy), nullptr,
+                         nullptr, const_cast<void*>(dummy), L) != MP_OK)
+        return 0;
+    // the conditions of mp_f16_conv2d_fwd_stats for stats->pre_scale_dev
+    return (f16_variant_wreg(L.variant) && L.ks == 3 && L.stride == 1 && L.p.upc > 0 && L.p.G == 1) ? 1 : 0;
+}
+
 int mp_f16_conv2d_fwd_stats(const mp_conv_desc* desc, int variant, const void* x, const void* packed_w, const float* scale,
                             const float* shift, const void* res1, void* out, const mp_f16_conv_stats* st, mp_stream_t stream) {
     if (!st || !st->partials_dev) return MP_ERR_NULL;
@@ -967,6 +978,16 @@ int mp_f16_conv2d_fwd_stats(const mp_conv_desc* desc, int variant, const void* x
         L.p.st_relu = st->relu != 0 ? 1 : 0;
         L.p.st_z = st->z_dev;
         L.p.st_y = st->relu != 0 ? st->y_dev : nullptr;
+    }
+    if (st->pre_scale_dev || st->pre_shift_dev || st->pre_out_dev) {
+        // BatchNorm apply on the input operand: the fast staging form of the weights-in-registers kernel (decoded pieces, one image
+        // per tile), forward statistics mode
+        if (!st->pre_scale_dev || !st->pre_shift_dev) return MP_ERR_NULL;
+        if (st->mode != 1 || !f16_variant_wreg(L.variant) || L.ks != 3 || L.stride != 1 || L.p.upc <= 0 || L.p.G != 1) return MP_ERR_UNSUPPORTED;
+        L.p.pre_scale = st->pre_scale_dev;
+        L.p.pre_shift = st->pre_shift_dev;
+        L.p.pre_out = st->pre_out_dev;
+        L.p.pre_relu = st->pre_relu != 0 ? 1 : 0;
     }
     return f16_launch(L, as_stream(stream));
 }

@@ -53,7 +53,10 @@ constexpr int kWregMaxPieces = 8;  // DMA pieces (64 x 16 B) per plane of the fa
 // a quarter of the couts) streams each weight byte once per workgroup - the shape for the 128 - 384-channel layers whose weight
 // stream is what the vector-memory path carries; with fewer couts (64 / 32-channel layers) the pixel split keeps two cout tiles
 // per wave, i.e. half the LDS reads per MFMA, at the price of WAVES_P waves fetching the same (small) weight fragments.
-template <int KS, int S, int PS, int CSW, int WAVES_P, int OCC, int STATS = 0>
+// PRE (training, forward statistics builds of the 3x3 stride-1 form): the tensor at p.x is the RAW output z of the conv below; each
+// wave turns the planes it staged into act(z * pre_scale + pre_shift) in place - the BatchNorm apply pass of the layer below, done
+// on this conv's operand (hrnet.py:67-72) - and writes the tile's own rows to p.pre_out for the backward pass.
+template <int KS, int S, int PS, int CSW, int WAVES_P, int OCC, int STATS = 0, bool PRE = false>
 __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Params p
 #if MP_WS_STAMPS
                                                                  , unsigned long long* dbg
@@ -90,13 +93,13 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
     // ---- input tile: every 16-byte slot of the LDS image is written by LDS-DMA, data or (out of range) zero.  The DMA goes FIRST:
     //      its data comes from HBM and ALL of it must have landed before the first MFMA, the weight fragments behind it come from L2
     //      and are needed tap by tap
+    [[maybe_unused]] unsigned piece_rel[kWregMaxPieces];  // fast form: byte offset of a piece's slot inside its image plane; kOob = zero slot
     if (p.upc > 0) {
         // fast form (stride 1, one image per tile, plane pitch a multiple of 64 elements - f16_configure_wreg): a DMA piece never
         // straddles planes, so its slot -> (row, column) map is the same for every plane and is decoded ONCE (the magic
         // divisions are quarter-rate integer multiplies: ~300 cycles per piece in the generic loop below, round-4 stamps); a
         // plane only adds its descriptor - rows above / below the image fall outside it and arrive as zeros
         const unsigned plane_bytes = (unsigned)HW * 16u;
-        unsigned piece_rel[kWregMaxPieces];
 #pragma unroll
         for (int s = 0; s < kWregMaxPieces; ++s) {
             const unsigned slot = (unsigned)(s * 64 + lane);
@@ -191,6 +194,38 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
     // issued since), so all but that many may still be in flight - the fragments are waited for tap by tap (the compiler counts
     // them); more than 63 cannot be encoded: wait for the excess
     __builtin_amdgcn_s_waitcnt(0x0F70 | ((T * CSW < 63 ? T * CSW : 63) & 15) | (((T * CSW < 63 ? T * CSW : 63) >> 4) << 14));
+    if constexpr (PRE) {
+        // The planes THIS wave staged are complete in LDS (its own vmcnt): sweep them in place, one 16-byte element (8 channels of a
+        // pixel) per lane and piece - the arithmetic of bn16_apply_pre_body (fp32 fma, ReLU, one rounding).  Slots outside the
+        // image (halo column, rows above / below, padding planes) hold the DMA's zeros and keep them: the conv's zero padding applies
+        // to the ACTIVATION.  The rows [y0, y0 + R) belong to this tile alone: cout slice 0 writes them out.
+        const unsigned plane_bytes = (unsigned)HW * 16u;
+        const unsigned own_lo = (unsigned)(y0 * p.W) * 16u, own_hi = (unsigned)(min(y0 + p.R, p.H) * p.W) * 16u;
+        char* yimg = reinterpret_cast<char*>(p.pre_out) + (size_t)n0 * p.C8in * plane_bytes;
+        const float floor_v = p.pre_relu ? 0.f : -__builtin_inff();
+        for (int pl = wave; pl < p.C8in; pl += 4) {  // wave-uniform: scale / shift through scalar loads
+            float psc[8], psh[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                psc[j] = p.pre_scale[pl * 8 + j];
+                psh[j] = p.pre_shift[pl * 8 + j];
+            }
+            const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(yimg + (size_t)pl * plane_bytes, (p.pre_out && ct == 0) ? plane_bytes : 0);
+#pragma unroll
+            for (int s = 0; s < kWregMaxPieces; ++s) {
+                if (s >= p.upc) break;
+                u32x4* slot = lds_in + pl * p.plane + s * 64 + lane;
+                const unsigned rel = piece_rel[s];
+                const f16x8 zv = __builtin_bit_cast(f16x8, *slot);
+                f16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (_Float16)fmaxf(__builtin_fmaf((float)zv[j], psc[j], psh[j]), floor_v);
+                const u32x4 yv = rel < plane_bytes ? __builtin_bit_cast(u32x4, o) : (u32x4){0u, 0u, 0u, 0u};
+                *slot = yv;
+                __builtin_amdgcn_raw_buffer_store_b128(yv, rs_y, (rel >= own_lo && rel < own_hi) ? rel : kOob, 0, 0);
+            }
+        }
+    }
     __syncthreads();                                  // ... and every other wave's: the only barrier of the workgroup
     WREG_STAMP(2);
 
@@ -350,9 +385,9 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
                                                p.C8out, wp_i, wc_i, lq, lr);
 }
 
-template <int KS, int S, int PS, int CSW, int WAVES_P, int OCC, int STATS>
+template <int KS, int S, int PS, int CSW, int WAVES_P, int OCC, int STATS, bool PRE = false>
 int launch_wreg_kernel(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
-    auto kern = conv_f16_wreg_kernel<KS, S, PS, CSW, WAVES_P, OCC, STATS>;
+    auto kern = conv_f16_wreg_kernel<KS, S, PS, CSW, WAVES_P, OCC, STATS, PRE>;
     static AttrOnce attr_set_once;
     if (attr_set_once.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -369,6 +404,12 @@ int launch_wreg_kernel(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) 
 
 template <int KS, int S, int PS, int CSW, int WAVES_P, int OCC>
 int launch_wreg(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
+    if (p.pre_scale) {  // BatchNorm apply on the input operand: mp_f16_conv2d_fwd_stats admits it for this form only
+        if constexpr (KS == 3 && S == 1) {
+            if (p.st_mode == 1 && p.upc > 0) return launch_wreg_kernel<KS, S, PS, CSW, WAVES_P, OCC, 1, true>(p, lds_bytes, s);
+        }
+        return MP_ERR_UNSUPPORTED;
+    }
     if (p.st_mode == 1) return launch_wreg_kernel<KS, S, PS, CSW, WAVES_P, OCC, 1>(p, lds_bytes, s);  // training builds: epilogue statistics
     if (p.st_mode == 2) {
         if constexpr (S == 1) return launch_wreg_kernel<KS, S, PS, CSW, WAVES_P, OCC, 2>(p, lds_bytes, s);

@@ -664,6 +664,59 @@ __global__ __launch_bounds__(256) void bn16_fold_kernel(const float* __restrict_
             (float)(((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x]);
 }
 
+// channel j of block blk: batch mean / variance from the folded sums -> the forward scale / shift (0 / 0 on a padding channel);
+// `publish`: this block also writes the saved statistics and the moving averages
+__device__ __forceinline__ void bn16_fwd_coeffs(int j, int blk, int c, const double* s_tot, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, float* __restrict__ save_mean,
+                                                float* __restrict__ save_invstd, float* __restrict__ moving_mean,
+                                                float* __restrict__ moving_var, double inv_count, double unbias, float eps, float momentum,
+                                                bool publish, float& sc, float& sh) {
+    const int ch = blk * 8 + j;
+    sc = 0.f;
+    sh = 0.f;
+    if (ch < c) {
+        const double mean = s_tot[2 * j] * inv_count;
+        double var = s_tot[2 * j + 1] * inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        // 1 / sqrt(var + eps): fp32 estimate + one Newton step in fp64 (relative error ~1e-14, no fp64 divide / sqrt sequence)
+        const double x = var + (double)eps;
+        double r = (double)rsqrtf((float)x);
+        r = r * (1.5 - 0.5 * x * r * r);
+        const float invstd = (float)r;
+        sc = gamma[ch] * invstd;
+        sh = bn16_shift(beta[ch], (float)mean, sc);
+        if (publish) {
+            save_mean[ch] = (float)mean;
+            save_invstd[ch] = invstd;
+            if (moving_mean) {
+                moving_mean[ch] = momentum * moving_mean[ch] + (1.f - momentum) * (float)mean;
+                moving_var[ch] = momentum * moving_var[ch] + (1.f - momentum) * (float)(var * unbias);
+            }
+        }
+    }
+}
+
+// The prologue of the apply pass as a launch of its own, grid (C8): the statistics of a mode-1 conv launch -> the folded scale /
+// shift its CONSUMER applies on its own operand (conv_f16_wreg.hip, PRE) - same fold, same arithmetic, same saved statistics
+__global__ __launch_bounds__(256) void bn16_finalize_kernel(const float* __restrict__ pre, int n_parts, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ save_mean,
+                                                            float* __restrict__ save_invstd, float* __restrict__ moving_mean,
+                                                            float* __restrict__ moving_var, float* __restrict__ scale,
+                                                            float* __restrict__ shift, int c, double inv_count, double unbias, float eps,
+                                                            float momentum) {
+    __shared__ double s_tot[16];
+    __shared__ double s_sm[4][16];
+    const int blk = blockIdx.x;
+    bn16_fold_parts(pre, blk, n_parts, s_tot, s_sm);
+    if (threadIdx.x < 8) {
+        float sc, sh;
+        bn16_fwd_coeffs(threadIdx.x, blk, c, s_tot, gamma, beta, save_mean, save_invstd, moving_mean, moving_var, inv_count, unbias, eps,
+                        momentum, true, sc, sh);
+        scale[blk * 8 + threadIdx.x] = sc;
+        shift[blk * 8 + threadIdx.x] = sh;
+    }
+}
+
 // forward apply with the statistics folded from the conv's partials: y = act(z * scale + shift (+ res))
 // (a __device__ body: the one-layer kernel passes blockIdx, the grouped kernel below the block's place inside its job)
 __device__ __forceinline__ void bn16_apply_pre_body(const u32x4_t* __restrict__ z, const float* __restrict__ pre, int n_parts,
@@ -708,30 +761,11 @@ __device__ __forceinline__ void bn16_apply_pre_body(const u32x4_t* __restrict__ 
     request(e0, cz, cr, ci);
     bn16_fold_parts(pre, blk, n_parts, s_tot, s_sm);
     if (threadIdx.x < 8) {
-        const int j = threadIdx.x, ch = blk * 8 + j;
-        float sc = 0.f, sh = 0.f;
-        if (ch < c) {
-            const double mean = s_tot[2 * j] * inv_count;
-            double var = s_tot[2 * j + 1] * inv_count - mean * mean;
-            if (var < 0.0) var = 0.0;
-            // 1 / sqrt(var + eps): fp32 estimate + one Newton step in fp64 (relative error ~1e-14, no fp64 divide / sqrt sequence)
-            const double x = var + (double)eps;
-            double r = (double)rsqrtf((float)x);
-            r = r * (1.5 - 0.5 * x * r * r);
-            const float invstd = (float)r;
-            sc = gamma[ch] * invstd;
-            sh = bn16_shift(beta[ch], (float)mean, sc);
-            if (chunk == 0) {
-                save_mean[ch] = (float)mean;
-                save_invstd[ch] = invstd;
-                if (moving_mean) {
-                    moving_mean[ch] = momentum * moving_mean[ch] + (1.f - momentum) * (float)mean;
-                    moving_var[ch] = momentum * moving_var[ch] + (1.f - momentum) * (float)(var * unbias);
-                }
-            }
-        }
-        s_scale[j] = sc;
-        s_shift[j] = sh;
+        float sc, sh;
+        bn16_fwd_coeffs(threadIdx.x, blk, c, s_tot, gamma, beta, save_mean, save_invstd, moving_mean, moving_var, inv_count, unbias, eps,
+                        momentum, chunk == 0, sc, sh);
+        s_scale[threadIdx.x] = sc;
+        s_shift[threadIdx.x] = sh;
     }
     __syncthreads();
     float sc[8], sh[8];
@@ -1640,6 +1674,23 @@ int mp_f16_bn_train_fwd_stats(const void* z, const float* gamma, const float* be
                        partials, n_parts, gamma, beta, save_mean, save_invstd, moving_mean, moving_var,
                        reinterpret_cast<const u32x4_t*>(res), reinterpret_cast<u32x4_t*>(y), n, c, c8, hw, 1.0 / ((double)n * hw),
                        (double)n * hw > 1.0 ? ((double)n * hw) / ((double)n * hw - 1.0) : 1.0, eps, momentum, relu ? 1 : 0);
+    return check_launch();
+}
+
+int mp_f16_bn_train_finalize(const float* gamma, const float* beta, float* save_mean, float* save_invstd, float* moving_mean,
+                             float* moving_var, int n, int c, int hw, float eps, float momentum, const float* partials, int n_parts,
+                             float* scale, float* shift, void* workspace, size_t workspace_bytes, mp_stream_t stream) {
+    if (!gamma || !beta || !save_mean || !save_invstd || !partials || !scale || !shift) return MP_ERR_NULL;
+    if ((moving_mean == nullptr) != (moving_var == nullptr)) return MP_ERR_NULL;
+    if (n <= 0 || c <= 0 || hw <= 0 || n_parts <= 0) return MP_ERR_SHAPE;
+    if (!workspace || workspace_bytes < mp_bn_workspace_bytes(c)) return MP_ERR_WORKSPACE;
+    const int c8 = (c + 7) / 8;
+    hipStream_t s = as_stream(stream);
+    int rc = bn16_prefold(partials, n_parts, c8, workspace, s);
+    if (rc != MP_OK) return rc;
+    hipLaunchKernelGGL(bn16_finalize_kernel, dim3(c8), dim3(256), 0, s, partials, n_parts, gamma, beta, save_mean, save_invstd, moving_mean,
+                       moving_var, scale, shift, c, 1.0 / ((double)n * hw),
+                       (double)n * hw > 1.0 ? ((double)n * hw) / ((double)n * hw - 1.0) : 1.0, eps, momentum);
     return check_launch();
 }
 

@@ -243,12 +243,15 @@ def tune_conv_variant(lib, d, x, packed, scale, shift, res1, res2, out, half: bo
     are cached per shape, so a network's ~40 distinct shapes are tuned once per process.  ``packed_u`` (fp32 only): the
     Winograd-transformed weights; the Winograd form then competes as index ``F32_WINOGRAD``.  ``stats`` (fp16 training):
     ``dict(mode, z, y, relu)`` - the launch is the one with BatchNorm statistics in its epilogue (mp_f16_conv2d_fwd_stats: other
-    register budgets, two more tensor reads in mode 2), timed as such and cached under its own key."""
+    register budgets, two more tensor reads in mode 2), timed as such and cached under its own key; with ``pre = dict(scale, shift, y,
+    relu)`` the launch also applies the BatchNorm of the layer below on its operand (candidates: mp_f16_conv_pre_supported)."""
     key = tuple(getattr(d, f) for f, _ in d._fields_) + (res1 is not None, res2 is not None, str(out.device), half)
     if packed_u is not None:
         key += ("wino",)
     if stats is not None:
         key += ("stats", int(stats["mode"]), int(bool(stats.get("relu"))))
+        if stats.get("pre") is not None:  # BatchNorm apply of the layer below on the operand: its own candidate set, its own key
+            key += ("pre",)
     macs = d.n * d.conv_h * d.conv_w * d.cout * d.cin * d.kh * d.kw
     stream = _lib.stream()
     # in-place accumulation (out aliases res1) must not be disturbed by trial launches: tune into a scratch copy
@@ -262,7 +265,9 @@ def tune_conv_variant(lib, d, x, packed, scale, shift, res1, res2, out, half: bo
     # a statistics build that leaves more than 512 partial slots per channel costs its consumer an extra fold launch (~5 us): such
     # variants compete only when no variant of the shape stays within 512
     slot_cap = [512]
-    if stats is not None and not any(0 < lib.mp_f16_conv_stats_parts(ctypes.byref(d), v) <= 512 for v in range(F16_VARIANTS)):
+    with_pre = stats is not None and stats.get("pre") is not None
+    if stats is not None and not any(0 < lib.mp_f16_conv_stats_parts(ctypes.byref(d), v) <= 512 for v in range(F16_VARIANTS)
+                                     if not with_pre or lib.mp_f16_conv_pre_supported(ctypes.byref(d), v)):
         slot_cap[0] = 1 << 30
 
     no_ws = half and os.environ.get("MINDPOSE_F16_WS", "1") == "0"  # before / after evidence: the round-3 candidate set
@@ -279,6 +284,11 @@ def tune_conv_variant(lib, d, x, packed, scale, shift, res1, res2, out, half: bo
                 stats_buf["t"], stats_buf["n"] = torch.empty(need, device=out.device, dtype=torch.float32), need
             st = _lib.ConvStats(mode=int(stats["mode"]), relu=int(bool(stats.get("relu"))), partials=stats_buf["t"].data_ptr(),
                                 partials_bytes=need * 4, z=_lib.ptr(stats.get("z")), y=_lib.ptr(stats.get("y")) if stats.get("relu") else None)
+            pre = stats.get("pre")
+            if pre is not None:
+                if not lib.mp_f16_conv_pre_supported(ctypes.byref(d), v):
+                    return -3
+                st.pre_scale, st.pre_shift, st.pre_out, st.pre_relu = _lib.ptr(pre["scale"]), _lib.ptr(pre["shift"]), _lib.ptr(pre["y"]), int(pre["relu"])
             return lib.mp_f16_conv2d_fwd_stats(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift),
                                                _lib.ptr(res1), _lib.ptr(trial_out), ctypes.byref(st), stream)
         if not half and v == F32_WINOGRAD:

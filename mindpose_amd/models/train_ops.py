@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from .layers import BN_EPS, F32_WINOGRAD, tune_conv_variant, winograd_enabled
+from .layers import BN_EPS, F16_VARIANTS, F32_WINOGRAD, tune_conv_variant, winograd_enabled
 
 BN_MOMENTUM = 0.9  # mindspore.nn.BatchNorm2d(momentum=0.9): moving = 0.9*moving + 0.1*batch [MS-knowledge]
 
@@ -971,17 +971,53 @@ def _stats_alloc(lib, d, v, c8out, device):
     return torch.empty(c8out * n_parts * 16, device=device, dtype=torch.float32), n_parts
 
 
-def _conv16_stats_launch(lib, d, x, packed, scale, shift, out, res1, mode, z=None, y=None, relu=0):
+def bn_pre_enabled() -> bool:
+    """``MINDPOSE_BN_PRE=1``: inside a chain, conv -> BatchNorm -> ReLU -> 3x3 conv runs WITHOUT an apply pass over the first conv's
+    output: the statistics are finalised by a one-block launch and the second conv applies them while it stages its operand,
+    writing the activation for the backward pass on the way (bit-identical to the apply pass at launch level,
+    tests/test_gpu_bn_fuse.py).  Off by default: measured on HRNet-W32 N = 128 the eager step's kernel time drops 2 % (27.2 ->
+    26.6 ms) but the graph-replayed multi-lane step gets 0.8 % SLOWER (5.59 -> 5.55 k img/s, four interleaved pairs on two boxes) -
+    the apply passes it removes are HBM-bound launches that were already hidden under the other lanes' convs, the time it adds sits
+    in CU-filling conv launches."""
+    return os.environ.get("MINDPOSE_BN_PRE", "0") == "1"
+
+
+_PRE_CAPABLE = {}
+
+
+def _pre_capable(lib, d) -> bool:
+    """Can a conv launch of shape ``d`` apply the BatchNorm of the layer below on its own operand?  (some variant of the
+    weights-in-registers family takes it, and the layer is large enough for the tuner to pick variants at all)"""
+    key = tuple(getattr(d, f) for f, _ in d._fields_)
+    hit = _PRE_CAPABLE.get(key)
+    if hit is None:
+        macs = d.n * d.conv_h * d.conv_w * d.cout * d.cin * d.kh * d.kw
+        hit = (os.environ.get("MINDPOSE_AUTOTUNE", "1") != "0" and macs >= (1 << 26)
+               and any(lib.mp_f16_conv_pre_supported(ctypes.byref(d), v) for v in range(F16_VARIANTS)))
+        _PRE_CAPABLE[key] = hit
+    return hit
+
+
+def _conv16_stats_launch(lib, d, x, packed, scale, shift, out, res1, mode, z=None, y=None, relu=0, pre=None):
     """The tuned conv launch with epilogue statistics (mode 1 forward / 2 backward); returns (partials, n_parts) or (None, 0) after
-    a PLAIN launch when the tuned variant has no statistics build."""
-    v = tune_conv_variant(lib, d, x, packed, scale, shift, res1, None, out, half=True, stats=dict(mode=mode, z=z, y=y, relu=relu))
+    a PLAIN launch when the tuned variant has no statistics build.  ``pre`` = dict(scale, shift, y, relu): ``x`` is the RAW output of
+    the conv below and the launch applies that layer's BatchNorm on its operand, writing the activation to ``pre["y"]`` (the caller
+    checked `_pre_capable`)."""
+    stats = dict(mode=mode, z=z, y=y, relu=relu)
+    if pre is not None:
+        stats["pre"] = pre
+    v = tune_conv_variant(lib, d, x, packed, scale, shift, res1, None, out, half=True, stats=stats)
     part, n_parts = _stats_alloc(lib, d, v, (d.cout + 7) // 8, out.device)
+    if pre is not None and (part is None or v < 0):
+        raise _lib.MindposeHipError("no conv variant applies the BatchNorm on its operand for a shape _pre_capable admitted")
     if part is None:
         _lib.check(lib.mp_f16_conv2d_fwd(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift),
                                          _lib.ptr(res1), None, _lib.ptr(out), _lib.stream()), "mp_f16_conv2d_fwd")
         return None, 0
     st = _lib.ConvStats(mode=mode, relu=int(relu), partials=part.data_ptr(), partials_bytes=part.numel() * 4,
                         z=_lib.ptr(z), y=_lib.ptr(y) if relu else None)
+    if pre is not None:
+        st.pre_scale, st.pre_shift, st.pre_out, st.pre_relu = _lib.ptr(pre["scale"]), _lib.ptr(pre["shift"]), _lib.ptr(pre["y"]), int(pre["relu"])
     _lib.check(lib.mp_f16_conv2d_fwd_stats(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift),
                                            _lib.ptr(res1), _lib.ptr(out), ctypes.byref(st), _lib.stream()), "mp_f16_conv2d_fwd_stats")
     return part, n_parts
@@ -1096,7 +1132,14 @@ def flush_wgrad_jobs() -> None:
 
 
 def _run_bn_fwd_job(lib, j):
-    """The BatchNorm forward pass a chain yielded: apply-only when the statistics came with the conv, reduce + apply otherwise."""
+    """The BatchNorm forward pass a chain yielded: apply-only when the statistics came with the conv, reduce + apply otherwise;
+    statistics only (``pre``) when the next conv of the chain applies them on its operand."""
+    if j.get("pre") is not None:
+        _lib.check(lib.mp_f16_bn_train_finalize(_lib.ptr(j["g"]), _lib.ptr(j["b"]), _lib.ptr(j["mean"]), _lib.ptr(j["invstd"]), _lib.ptr(j["mm"]),
+                                                _lib.ptr(j["mv"]), j["n"], j["c"], j["hw"], BN_EPS, BN_MOMENTUM, _lib.ptr(j["part"]),
+                                                j["n_parts"], _lib.ptr(j["pre"]["scale"]), _lib.ptr(j["pre"]["shift"]), _lib.ptr(j["ws"]),
+                                                j["ws_bytes"], _lib.stream()), "mp_f16_bn_train_finalize")
+        return
     if j["part"] is None:
         _lib.check(lib.mp_f16_bn_train_fwd(_lib.ptr(j["z"]), _lib.ptr(j["g"]), _lib.ptr(j["b"]), _lib.ptr(j["res"]), _lib.ptr(j["y"]),
                                            _lib.ptr(j["mean"]), _lib.ptr(j["invstd"]), _lib.ptr(j["mm"]), _lib.ptr(j["mv"]), j["n"], j["c"],
@@ -1129,6 +1172,7 @@ def _chain16_fwd_steps(lib, x, meta, residual, res_ext, params):
     groups = []
     a = x
     n_groups = len(meta)
+    pre = None  # the previous group's BatchNorm, left to THIS group's conv: dict(scale, shift, y, relu, z)
     for gi, (stride, padding, mm, mv, relu) in enumerate(meta):
         weight, gamma, beta = params[3 * gi: 3 * gi + 3]
         w = weight.detach().contiguous()
@@ -1141,7 +1185,10 @@ def _chain16_fwd_steps(lib, x, meta, residual, res_ext, params):
         z = _c8_alloc(n, cout, ho, wo, a.device)
         d = _desc(n, cin, h, wd, cout, k, stride, padding, padding, ho, wo, ho, wo)
         packed = _pack16(lib, w, cout, cin, k, 0, owner=weight)
-        if _bn_fuse_parts() & 1:
+        if pre is not None:  # operand = the raw output below; this launch applies its BatchNorm and writes the activation `a`
+            part, n_parts = _conv16_stats_launch(lib, d, pre["z"], packed, ones, zeros, z, None, 1, pre=pre)
+            pre = None
+        elif _bn_fuse_parts() & 1:
             part, n_parts = _conv16_stats_launch(lib, d, a, packed, ones, zeros, z, None, 1)
         else:
             part, n_parts = None, 0
@@ -1153,8 +1200,21 @@ def _chain16_fwd_steps(lib, x, meta, residual, res_ext, params):
         invstd = torch.empty(cout, device=z.device)
         ws, ws_bytes = _bn16_workspace(lib, cout, z.device)
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
-        yield dict(z=z, g=g, b=b, res=res, y=y, mean=mean, invstd=invstd, mm=mm, mv=mv, n=n, c=cout, hw=ho * wo, relu=int(relu),
+        job = dict(z=z, g=g, b=b, res=res, y=y, mean=mean, invstd=invstd, mm=mm, mv=mv, n=n, c=cout, hw=ho * wo, relu=int(relu),
                    part=part, n_parts=n_parts, ws=ws, ws_bytes=ws_bytes)
+        if not last and part is not None and bn_pre_enabled() and cout % 8 == 0:
+            # conv -> BatchNorm -> ReLU -> 3x3 conv (hrnet.py:67-72): when the next conv can take the raw z, only the statistics
+            # are finalised here - no pass over z / y; the next launch writes y (the backward pass reads it) on the way
+            ns, npad = meta[gi + 1][0], meta[gi + 1][1]
+            nw = params[3 * (gi + 1)]
+            if nw.shape[2] == 3 and ns == 1 and npad == 1:
+                dn = _desc(n, cout, ho, wo, nw.shape[0], 3, 1, 1, 1, ho, wo, ho, wo)
+                only = os.environ.get("MINDPOSE_BN_PRE_CH")  # kernel work: the operand route for these channel counts only
+                if _pre_capable(lib, dn) and (not only or str(cout) in only.split(",")):
+                    pre = dict(scale=torch.empty((cout + 7) // 8 * 8, device=z.device), shift=torch.empty((cout + 7) // 8 * 8, device=z.device),
+                               y=y, relu=int(relu), z=z)
+                    job["pre"] = pre
+        yield job
         groups.append(dict(a=a, w=w, weight=weight, gamma=gamma, beta=beta, g=g, b=b, z=z, y=y, mean=mean, invstd=invstd,
                            stride=stride, padding=padding, relu=bool(relu), res=res is not None))
         a = y

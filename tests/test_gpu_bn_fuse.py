@@ -558,3 +558,130 @@ def test_link_hand_over_is_checked_against_the_gradient_tensor(monkeypatch):
         gf, gr = run(aux, True), run(aux, False)
         cos = float(torch.nn.functional.cosine_similarity(gf.double(), gr.double(), dim=0))
         assert cos > 0.9999, (aux, cos)  # ... and with the extra consumer the producer did not use it
+
+
+# ---- BatchNorm apply on the consumer's operand (round 4): conv1 -> bn1 -> relu -> conv2 without a pass over y1 ------------------
+PRE_CASES = [
+    # n, cin, cout, h, w
+    (5, 32, 32, 64, 48),    # W32 branch 0
+    (6, 64, 64, 32, 24),
+    (6, 128, 128, 16, 12),
+    (3, 48, 48, 24, 18),    # W48 width: padding planes behind Cin (48 -> 64)
+    (3, 40, 64, 21, 13),    # ragged rows (last tile short), cin not a multiple of 16
+    (2, 96, 96, 48, 36),
+]
+
+
+@pytest.mark.parametrize("relu", [1, 0])
+@pytest.mark.parametrize("case", PRE_CASES, ids=[f"n{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}" for c in PRE_CASES])
+def test_conv_applies_the_batchnorm_below_on_its_operand(case, relu):
+    """mp_f16_bn_train_finalize + mp_f16_conv2d_fwd_stats(pre_scale / pre_shift / pre_out) against the apply pass
+    (mp_f16_bn_train_fwd_stats) followed by the same conv launch: activation tensor, conv output, its partial sums, saved statistics
+    and moving averages all bit-identical, on every variant that takes the form (hrnet.py:67-72; nn.BatchNorm2d in training mode)."""
+    n, cin, cout, h, w = case
+    g = torch.Generator().manual_seed(sum(case) + relu)
+    z = _to_c8(torch.randn(n, cin, h, w, generator=g) * 1.7 + 0.3)
+    # partial sums of z as a producing conv would leave them: [C8][n_parts][8][2], here three slots splitting the batch
+    zf = _from_c8(z)
+    c8 = (cin + 7) // 8
+    n_parts_in = 3
+    part_in = torch.zeros(c8, n_parts_in, 8, 2, device=DEV)
+    for sl, idx in enumerate(torch.arange(n).chunk(n_parts_in)):
+        zz = zf[idx.to(DEV)]
+        a = torch.zeros(c8 * 8, device=DEV); b = torch.zeros(c8 * 8, device=DEV)
+        a[:cin] = zz.sum(dim=(0, 2, 3)); b[:cin] = (zz * zz).sum(dim=(0, 2, 3))
+        part_in[:, sl, :, 0] = a.reshape(c8, 8); part_in[:, sl, :, 1] = b.reshape(c8, 8)
+    part_in = part_in.reshape(-1).contiguous()
+    gamma, beta = torch.rand(cin, generator=g).to(DEV) + 0.5, (torch.randn(cin, generator=g) * 0.2).to(DEV)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    packed = _pack(wt)
+    d, ho, wo = _desc(n, cin, h, w, cout, 3, 1)
+    c16 = (cout + 15) // 16 * 16
+    ones, zeros = torch.ones(c16, device=DEV), torch.zeros(c16, device=DEV)
+    wsb = LIB.mp_bn_workspace_bytes(2048)
+    ws = torch.zeros(wsb // 4 + 1, device=DEV)
+
+    # route A: the apply pass, then the conv on the activation
+    mean_a, inv_a = torch.empty(cin, device=DEV), torch.empty(cin, device=DEV)
+    mm_a, mv_a = torch.zeros(cin, device=DEV), torch.ones(cin, device=DEV)
+    y_a = ActC8(n, cin, h, w, DEV)
+    _lib.check(LIB.mp_f16_bn_train_fwd_stats(_lib.ptr(z), _lib.ptr(gamma), _lib.ptr(beta), None, _lib.ptr(y_a), _lib.ptr(mean_a), _lib.ptr(inv_a),
+                                             _lib.ptr(mm_a), _lib.ptr(mv_a), n, cin, h * w, 1e-5, 0.9, relu, _lib.ptr(part_in), n_parts_in,
+                                             _lib.ptr(ws), wsb, _lib.stream()), "apply")
+    # route B: statistics only ...
+    mean_b, inv_b = torch.empty(cin, device=DEV), torch.empty(cin, device=DEV)
+    mm_b, mv_b = torch.zeros(cin, device=DEV), torch.ones(cin, device=DEV)
+    sc, sh = torch.full((c8 * 8,), float("nan"), device=DEV), torch.full((c8 * 8,), float("nan"), device=DEV)
+    _lib.check(LIB.mp_f16_bn_train_finalize(_lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean_b), _lib.ptr(inv_b), _lib.ptr(mm_b), _lib.ptr(mv_b), n,
+                                            cin, h * w, 1e-5, 0.9, _lib.ptr(part_in), n_parts_in, _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(ws), wsb,
+                                            _lib.stream()), "finalize")
+    assert torch.equal(mean_b, mean_a) and torch.equal(inv_b, inv_a) and torch.equal(mm_b, mm_a) and torch.equal(mv_b, mv_a)
+    assert torch.isfinite(sc).all() and torch.isfinite(sh).all() and (sc[cin:] == 0).all() and (sh[cin:] == 0).all()
+    tested = 0
+    for v in range(F16_VARIANTS):
+        if not LIB.mp_f16_conv_pre_supported(ctypes.byref(d), v):
+            continue
+        n_parts = LIB.mp_f16_conv_stats_parts(ctypes.byref(d), v)
+        assert n_parts > 0
+        co8 = (cout + 7) // 8
+        pa = torch.full((co8 * n_parts * 16,), float("nan"), device=DEV)
+        pb = torch.full((co8 * n_parts * 16,), float("nan"), device=DEV)
+        z2a, z2b = ActC8(n, cout, ho, wo, DEV), ActC8(n, cout, ho, wo, DEV)
+        st = _lib.ConvStats(mode=1, relu=0, partials=pa.data_ptr(), partials_bytes=pa.numel() * 4)
+        _lib.check(LIB.mp_f16_conv2d_fwd_stats(ctypes.byref(d), v, _lib.ptr(y_a), _lib.ptr(packed), _lib.ptr(ones), _lib.ptr(zeros), None,
+                                               _lib.ptr(z2a), ctypes.byref(st), _lib.stream()), f"plain route, variant {v}")
+        # ... and the conv applies them on the raw tensor, writing the activation on the way
+        y_b = ActC8(n, cin, h, w, DEV)
+        y_b.c8_tensor.fill_(float("nan"))
+        st = _lib.ConvStats(mode=1, relu=0, partials=pb.data_ptr(), partials_bytes=pb.numel() * 4, pre_scale=_lib.ptr(sc), pre_shift=_lib.ptr(sh),
+                            pre_out=_lib.ptr(y_b), pre_relu=relu)
+        _lib.check(LIB.mp_f16_conv2d_fwd_stats(ctypes.byref(d), v, _lib.ptr(z), _lib.ptr(packed), _lib.ptr(ones), _lib.ptr(zeros), None,
+                                               _lib.ptr(z2b), ctypes.byref(st), _lib.stream()), f"operand route, variant {v}")
+        assert torch.equal(y_b.c8_tensor, y_a.c8_tensor), f"variant {v}: activation written by the conv differs from the apply pass"
+        assert torch.equal(z2b.c8_tensor, z2a.c8_tensor), f"variant {v}: conv output"
+        assert torch.equal(pb, pa), f"variant {v}: partial sums"
+        # without an activation tensor the launch still convolves the same operand
+        z2c = ActC8(n, cout, ho, wo, DEV)
+        st = _lib.ConvStats(mode=1, relu=0, partials=pb.data_ptr(), partials_bytes=pb.numel() * 4, pre_scale=_lib.ptr(sc), pre_shift=_lib.ptr(sh),
+                            pre_relu=relu)
+        _lib.check(LIB.mp_f16_conv2d_fwd_stats(ctypes.byref(d), v, _lib.ptr(z), _lib.ptr(packed), _lib.ptr(ones), _lib.ptr(zeros), None,
+                                               _lib.ptr(z2c), ctypes.byref(st), _lib.stream()), f"operand route without pre_out, variant {v}")
+        assert torch.equal(z2c.c8_tensor, z2a.c8_tensor)
+        tested += 1
+    assert tested >= 1, "no variant takes the BatchNorm on its operand for this shape"
+    # the form is refused where it is not built: backward statistics, other kernel families, stride 2
+    st = _lib.ConvStats(mode=1, relu=0, partials=pb.data_ptr(), partials_bytes=pb.numel() * 4, pre_scale=_lib.ptr(sc), pre_shift=_lib.ptr(sh))
+    z2d = ActC8(n, cout, ho, wo, DEV)
+    for v in range(F16_VARIANTS):
+        if not LIB.mp_f16_conv_pre_supported(ctypes.byref(d), v):
+            assert LIB.mp_f16_conv2d_fwd_stats(ctypes.byref(d), v, _lib.ptr(z), _lib.ptr(packed), _lib.ptr(ones), _lib.ptr(zeros), None,
+                                               _lib.ptr(z2d), ctypes.byref(st), _lib.stream()) != 0, v
+    st = _lib.ConvStats(mode=1, relu=0, partials=pb.data_ptr(), partials_bytes=pb.numel() * 4, pre_scale=_lib.ptr(sc))  # shift missing
+    assert LIB.mp_f16_conv2d_fwd_stats(ctypes.byref(d), 34, _lib.ptr(z), _lib.ptr(packed), _lib.ptr(ones), _lib.ptr(zeros), None,
+                                       _lib.ptr(z2d), ctypes.byref(st), _lib.stream()) != 0
+
+
+@pytest.mark.parametrize("backbone,head,size", [("hrnet_w32", "hrnet_head", (10, 128, 96)), ("resnet50", "simple_baseline_head", (12, 64, 64))])
+def test_step_with_batchnorm_on_the_operand_equals_the_apply_pass_step(backbone, head, size, monkeypatch):
+    """The whole amp-O2 step with MINDPOSE_BN_PRE=1 (chains leave bn1's apply to conv2's operand staging) against MINDPOSE_BN_PRE=0:
+    the operand route is actually taken (batches large enough for the tuner to pick variants: below 2^26 MACs a layer keeps the
+    library's heuristic and the apply pass), agrees with the apply-pass step to summation order and repeats bit for bit."""
+    from mindpose_amd.models import train_ops as T
+    monkeypatch.setenv("MINDPOSE_BN_PRE", "0")
+    l0, g0, s0 = _step(True, monkeypatch, backbone, head, size)
+    monkeypatch.setenv("MINDPOSE_BN_PRE", "1")
+    taken = []
+    run = T._run_bn_fwd_job
+    monkeypatch.setattr(T, "_run_bn_fwd_job", lambda lib, j: (taken.append(j.get("pre") is not None), run(lib, j))[1])
+    l1, g1, s1 = _step(True, monkeypatch, backbone, head, size)
+    assert sum(taken) >= 4, f"{sum(taken)} of {len(taken)} BatchNorms went the operand route"
+    # conv2 now runs on another tile variant than the apply-pass step tuned for it: same conv bits, but ITS partial sums are cut
+    # differently, so bn2's statistics come out in another fp32 summation order - two fp16 evaluations of one graph (cf.
+    # test_fused_chain_step_vs_per_cell_step); the launch-level test above pins the route itself bit for bit
+    assert abs(l1 - l0) <= 1e-3 * abs(l0), (l1, l0)
+    cos = float(torch.nn.functional.cosine_similarity(g1.double(), g0.double(), dim=0))
+    assert cos > 0.985, cos
+    for k in s0:
+        assert torch.allclose(s1[k], s0[k], rtol=5e-3, atol=5e-4), k
+    l2, g2, _ = _step(True, monkeypatch, backbone, head, size)  # fixed partitions and orders: bit-reproducible
+    assert l2 == l1 and torch.equal(g2, g1)
