@@ -76,17 +76,49 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeParams p) {
 
     float best = -INFINITY;
     int bidx = 0x7fffffff;
-    if (!FLIP && (hw & 3) == 0) {
-        // float4 streaming: lane reads 16 B at float4 index lane + 64 t (indices ascend per lane)
+    if ((hw & 3) == 0 && (!FLIP || (w & 3) == 0)) {
+        // float4 streaming: lane reads 16 B at float4 index lane + 64 t (indices ascend per lane), FOUR quads requested before the
+        // first is looked at (a 64x48 map is 12 quads per lane: three round trips instead of twelve).  Flip test: the four values of
+        // the mirrored run that meet pixels x .. x + 3 of row y are b[y][W-1-xs], xs = x - 1 (x >= 1, shift) - four consecutive
+        // floats read backwards, one element off 16-byte alignment when shifted: scalar loads of one cache line
         const float4* a4 = reinterpret_cast<const float4*>(a);
-        const int nq = hw >> 2;
-        for (int q = lane; q < nq; q += 64) {
-            float4 v = a4[q];
-            int i = q << 2;
-            if (v.x > best) { best = v.x; bidx = i; }
-            if (v.y > best) { best = v.y; bidx = i + 1; }
-            if (v.z > best) { best = v.z; bidx = i + 2; }
-            if (v.w > best) { best = v.w; bidx = i + 3; }
+        float4* avg4 = reinterpret_cast<float4*>(avg);
+        const int nq = hw >> 2, wq = w >> 2;
+        constexpr int B = 4;
+        for (int q0 = lane; q0 < nq; q0 += 64 * B) {
+            float4 v[B], f[B];
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                const int q = q0 + 64 * j;
+                if (q < nq) {
+                    v[j] = a4[q];
+                    if (FLIP) {
+                        const int y = q / wq, x = (q - y * wq) << 2;
+                        const float* br = b + y * w;
+                        const int s = p.shift_heatmap ? 1 : 0;
+                        f[j].x = br[w - 1 - (x >= 1 ? x - s : x)];
+                        f[j].y = br[w - 1 - (x + 1 - s)];
+                        f[j].z = br[w - 1 - (x + 2 - s)];
+                        f[j].w = br[w - 1 - (x + 3 - s)];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                const int q = q0 + 64 * j;
+                if (q < nq) {
+                    float4 u = v[j];
+                    if (FLIP) {  // the expression of plane_val: (v + f) * 0.5f
+                        u.x = (u.x + f[j].x) * 0.5f; u.y = (u.y + f[j].y) * 0.5f; u.z = (u.z + f[j].z) * 0.5f; u.w = (u.w + f[j].w) * 0.5f;
+                        if (avg) avg4[q] = u;
+                    }
+                    const int i = q << 2;
+                    if (u.x > best) { best = u.x; bidx = i; }
+                    if (u.y > best) { best = u.y; bidx = i + 1; }
+                    if (u.z > best) { best = u.z; bidx = i + 2; }
+                    if (u.w > best) { best = u.w; bidx = i + 3; }
+                }
+            }
         }
     } else {
         for (int y = 0; y < h; ++y) {
@@ -125,6 +157,41 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeParams p) {
         // :171-205  only the 3x3 neighbourhood of the arg-max needs the k x k blur
         const int ks = p.ks, r = ks >> 1, taps = ks * ks;
         float L[3][3];
+        const int side = ks + 2;  // the nine blurred values read a (ks + 2)^2 patch around the arg-max
+        if (side * side <= 192) {
+            // every pixel of the patch is fetched ONCE (<= 3 per lane; zero outside the map = the blur's padding) and feeds the
+            // windows of all nine positions from registers; nine wave sums
+            float pv[3];
+            int pdy[3], pdx[3];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                const int idx = lane + 64 * e;
+                const int iy = idx / side, ix = idx - iy * side;
+                pdy[e] = iy - (r + 1);
+                pdx[e] = ix - (r + 1);
+                const int yy = yi + pdy[e], xx = xi + pdx[e];
+                const bool ok = idx < side * side && yy >= 0 && yy < h && xx >= 0 && xx < w;
+                pv[e] = ok ? plane_val<FLIP>(a, b, w, p.shift_heatmap, yy, xx) : 0.f;
+                if (idx >= side * side) pdy[e] = pdx[e] = 1 << 20;  // no window holds it
+            }
+#pragma unroll
+            for (int oy = -1; oy <= 1; ++oy) {
+#pragma unroll
+                for (int ox = -1; ox <= 1; ++ox) {
+                    const int py = yi + oy, px = xi + ox;
+                    const bool inside = (py >= 0 && py < h && px >= 0 && px < w);
+                    float part = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) {
+                        const int ti = pdy[e] - oy + r, tj = pdx[e] - ox + r;  // the tap of window (oy, ox) that meets this pixel
+                        if (ti >= 0 && ti < ks && tj >= 0 && tj < ks) part += p.blur[ti * ks + tj] * pv[e];
+                    }
+                    const float s = wave_sum(part);
+                    // clip [1e-3, 50] -> log ; positions outside the map are the zero pad applied AFTER log
+                    L[oy + 1][ox + 1] = inside ? logf(fminf(fmaxf(s, 0.001f), 50.f)) : 0.f;
+                }
+            }
+        } else {
 #pragma unroll
         for (int oy = -1; oy <= 1; ++oy) {
 #pragma unroll
@@ -144,6 +211,7 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeParams p) {
                 // clip [1e-3, 50] -> log ; positions outside the map are the zero pad applied AFTER log
                 L[oy + 1][ox + 1] = inside ? logf(fminf(fmaxf(s, 0.001f), 50.f)) : 0.f;
             }
+        }
         }
         const float i_ = L[1][1], ix1 = L[1][2], ix1_ = L[1][0], iy1 = L[2][1], iy1_ = L[0][1];
         const float ix1y1 = L[2][2], ix1_y1_ = L[0][0];
