@@ -383,7 +383,7 @@ class Plan:
                 # (_replay_lanes): the lanes as torch streams, every barrier a STAR - side lanes join the origin stream and fork
                 # from it again - which is the only fork / join shape capture survives here (the captured training step has no
                 # other).  Inside a hipGraph a cross-lane dependency costs ~10 us instead of the ~30 us of an event wait between
-                # two queues (tools/trace_infer.sh: 12 barriers per HRNet-W32 forward): O2 inference +10 %, fp32 +2 %.
+                # two queues (tools/timeline.sh on the inference plan: 12 barriers per HRNet-W32 forward): O2 inference +10 %, fp32 +2 %.
                 # MINDPOSE_PLAN_GRAPH_LANES=0: keep replaying through the native call.
                 self._multi = True
                 if os.environ.get("MINDPOSE_PLAN_GRAPH_LANES", "1") == "0":
