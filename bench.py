@@ -257,6 +257,28 @@ def host_cores():
     return cores, note
 
 
+def graph_time(fn, dev, reps=50, warm=5):
+    """Device seconds per call of ``fn``: ``reps`` calls captured once and replayed as ONE hipGraph between two events (a Python ->
+    ctypes call costs the host ~9 us, more than the HBM-bound kernels of the path run: back-to-back calls would time the host)."""
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(warm):
+            fn()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=side):
+            for _ in range(reps):
+                fn()
+        gr.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        gr.replay()
+        e1.record()
+        e1.synchronize()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
 def cpu_baseline(state_dict, mp, dev):
     """the CPU oracle (same graph, torch-CPU fp32) on the host cores of this box - threads = the CPU affinity
     of the process, 3 warm-up + 10 timed iterations at N=1 and N=32 (HRNet-W32 256x192 forward + decode) - and the reference's
@@ -322,14 +344,7 @@ def cpu_baseline(state_dict, mp, dev):
     torch.set_num_threads(cores)
     tgt = mp.TopDownGenerateTarget(config=dict(image_size=[192, 256], heatmap_size=[48, 64]), sigma=2.0)
     kpd = torch.from_numpy(kp).to(dev)
-    tgt(kpd)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(20):
-        tgt(kpd)
-    e1.record()
-    e1.synchronize()
-    gpu_t = e0.elapsed_time(e1) * 1e-3 / 20
+    gpu_t = graph_time(lambda: tgt(kpd), dev, reps=20, warm=2)  # device time (the host mirror's call costs the host more)
     target_bytes = n_t * 17 * 64 * 48 * 4
     return {"value": rates[32]["images_per_s"], "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"SURVEY 8(d) protocol: 3 warm-up + {rates[32]['timed_iters']} timed iterations of batch 32 (and batch 1) HRNet-W32 "
@@ -397,25 +412,8 @@ def hbm_ops_report(mp, dev, n=128):
         return lib.mp_joints_mse_bwd(_lib.ptr(hm), _lib.ptr(tgt), _lib.ptr(wgt), _lib.ptr(go), _lib.ptr(grad), n, k, h * w, st)
 
     def timed(fn, reps=50):
-        # the calls are captured once and replayed as ONE hipGraph: a Python -> ctypes call costs the host ~9 us, more than these
-        # kernels run, so back-to-back calls would time the host
-        side = torch.cuda.Stream(device=dev)
-        with torch.cuda.stream(side):
-            stream = _lib.stream()
-            for _ in range(5):
-                _lib.check(fn(stream), "hbm_ops")
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr, stream=side):
-                for _ in range(reps):
-                    fn(_lib.stream())
-            gr.replay()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            gr.replay()
-            e1.record()
-            e1.synchronize()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        return e0.elapsed_time(e1) * 1e-3 / reps
+        _lib.check(fn(_lib.stream()), "hbm_ops")
+        return graph_time(lambda: fn(_lib.stream()), dev, reps=reps)
 
     rows = {
         "decode_argmax_shift": (timed(decode(dec_shift)), hm_bytes,
