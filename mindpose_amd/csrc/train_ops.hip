@@ -664,17 +664,15 @@ __global__ __launch_bounds__(256) void bn16_fold_kernel(const float* __restrict_
             (float)(((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x]);
 }
 
-// channel j of block blk: batch mean / variance from the folded sums -> the forward scale / shift (0 / 0 on a padding channel);
-// `publish`: this block also writes the saved statistics and the moving averages
-__device__ __forceinline__ void bn16_fwd_coeffs(int j, int blk, int c, const double* s_tot, const float* __restrict__ gamma,
-                                                const float* __restrict__ beta, float* __restrict__ save_mean,
-                                                float* __restrict__ save_invstd, float* __restrict__ moving_mean,
-                                                float* __restrict__ moving_var, double inv_count, double unbias, float eps, float momentum,
-                                                bool publish, float& sc, float& sh) {
-    const int ch = blk * 8 + j;
-    sc = 0.f;
-    sh = 0.f;
-    if (ch < c) {
+// channel j of block blk: batch mean / variance from the folded sums -> the forward scale / shift (0 / 0 on a padding channel).
+// gamma_v / beta_v were requested at the top of the kernel (their latency runs under the fold's); the saved statistics and the
+// moving averages are written by `bn16_fwd_publish` AFTER the caller has released scale / shift to the other threads - the
+// read-modify-write of the moving averages is a memory round trip nobody should wait for
+struct Bn16Coeffs { float sc, sh, mean, invstd, var_unbiased; };
+__device__ __forceinline__ Bn16Coeffs bn16_fwd_coeffs(int j, int blk, int c, const double* s_tot, float gamma_v, float beta_v, double inv_count,
+                                                      double unbias, float eps) {
+    Bn16Coeffs o = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (blk * 8 + j < c) {
         const double mean = s_tot[2 * j] * inv_count;
         double var = s_tot[2 * j + 1] * inv_count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -682,16 +680,24 @@ __device__ __forceinline__ void bn16_fwd_coeffs(int j, int blk, int c, const dou
         const double x = var + (double)eps;
         double r = (double)rsqrtf((float)x);
         r = r * (1.5 - 0.5 * x * r * r);
-        const float invstd = (float)r;
-        sc = gamma[ch] * invstd;
-        sh = bn16_shift(beta[ch], (float)mean, sc);
-        if (publish) {
-            save_mean[ch] = (float)mean;
-            save_invstd[ch] = invstd;
-            if (moving_mean) {
-                moving_mean[ch] = momentum * moving_mean[ch] + (1.f - momentum) * (float)mean;
-                moving_var[ch] = momentum * moving_var[ch] + (1.f - momentum) * (float)(var * unbias);
-            }
+        o.invstd = (float)r;
+        o.mean = (float)mean;
+        o.var_unbiased = (float)(var * unbias);
+        o.sc = gamma_v * o.invstd;
+        o.sh = bn16_shift(beta_v, o.mean, o.sc);
+    }
+    return o;
+}
+__device__ __forceinline__ void bn16_fwd_publish(int j, int blk, int c, const Bn16Coeffs& o, float* __restrict__ save_mean,
+                                                 float* __restrict__ save_invstd, float* __restrict__ moving_mean,
+                                                 float* __restrict__ moving_var, float momentum) {
+    const int ch = blk * 8 + j;
+    if (ch < c) {
+        save_mean[ch] = o.mean;
+        save_invstd[ch] = o.invstd;
+        if (moving_mean) {
+            moving_mean[ch] = momentum * moving_mean[ch] + (1.f - momentum) * o.mean;
+            moving_var[ch] = momentum * moving_var[ch] + (1.f - momentum) * o.var_unbiased;
         }
     }
 }
@@ -707,13 +713,14 @@ __global__ __launch_bounds__(256) void bn16_finalize_kernel(const float* __restr
     __shared__ double s_tot[16];
     __shared__ double s_sm[4][16];
     const int blk = blockIdx.x;
+    const bool coef = threadIdx.x < 8 && blk * 8 + (int)threadIdx.x < c;
+    const float gamma_v = coef ? gamma[blk * 8 + threadIdx.x] : 0.f, beta_v = coef ? beta[blk * 8 + threadIdx.x] : 0.f;
     bn16_fold_parts(pre, blk, n_parts, s_tot, s_sm);
     if (threadIdx.x < 8) {
-        float sc, sh;
-        bn16_fwd_coeffs(threadIdx.x, blk, c, s_tot, gamma, beta, save_mean, save_invstd, moving_mean, moving_var, inv_count, unbias, eps,
-                        momentum, true, sc, sh);
-        scale[blk * 8 + threadIdx.x] = sc;
-        shift[blk * 8 + threadIdx.x] = sh;
+        const Bn16Coeffs o = bn16_fwd_coeffs(threadIdx.x, blk, c, s_tot, gamma_v, beta_v, inv_count, unbias, eps);
+        scale[blk * 8 + threadIdx.x] = o.sc;
+        shift[blk * 8 + threadIdx.x] = o.sh;
+        bn16_fwd_publish(threadIdx.x, blk, c, o, save_mean, save_invstd, moving_mean, moving_var, momentum);
     }
 }
 
@@ -758,16 +765,18 @@ __device__ __forceinline__ void bn16_apply_pre_body(const u32x4_t* __restrict__ 
             qr[k] = (ok && has_res) ? res[qi[k]] : zero4;
         }
     };
+    const bool coef = threadIdx.x < 8 && blk * 8 + (int)threadIdx.x < c;
+    const float gamma_v = coef ? gamma[blk * 8 + threadIdx.x] : 0.f, beta_v = coef ? beta[blk * 8 + threadIdx.x] : 0.f;
     request(e0, cz, cr, ci);
     bn16_fold_parts(pre, blk, n_parts, s_tot, s_sm);
+    Bn16Coeffs co = {0.f, 0.f, 0.f, 0.f, 0.f};
     if (threadIdx.x < 8) {
-        float sc, sh;
-        bn16_fwd_coeffs(threadIdx.x, blk, c, s_tot, gamma, beta, save_mean, save_invstd, moving_mean, moving_var, inv_count, unbias, eps,
-                        momentum, chunk == 0, sc, sh);
-        s_scale[threadIdx.x] = sc;
-        s_shift[threadIdx.x] = sh;
+        co = bn16_fwd_coeffs(threadIdx.x, blk, c, s_tot, gamma_v, beta_v, inv_count, unbias, eps);
+        s_scale[threadIdx.x] = co.sc;
+        s_shift[threadIdx.x] = co.sh;
     }
     __syncthreads();
+    if (threadIdx.x < 8 && chunk == 0) bn16_fwd_publish(threadIdx.x, blk, c, co, save_mean, save_invstd, moving_mean, moving_var, momentum);
     float sc[8], sh[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sc[j] = s_scale[j]; sh[j] = s_shift[j]; }  // 0 / 0 on the padding channels: they stay zero
@@ -875,31 +884,39 @@ __device__ __forceinline__ void bn16_bwd_apply_pre_body(const u32x4_t* __restric
             qz[k] = ok ? z[qi[k]] : zero4;
         }
     };
+    // the per-channel parameters are requested first: their latency runs under the fold's (they used to be a second, dependent
+    // round trip behind it)
+    const bool coef = threadIdx.x < 8 && blk * 8 + (int)threadIdx.x < c;
+    const float mean_v = coef ? mean[blk * 8 + threadIdx.x] : 0.f, invstd_v = coef ? invstd[blk * 8 + threadIdx.x] : 0.f;
+    const float gamma_v = coef ? gamma[blk * 8 + threadIdx.x] : 0.f;
     request(e0, cg, cz, ci);
     bn16_fold_parts(pre, blk, n_parts, s_tot, s_sm);
+    float db = 0.f, dg = 0.f;
     if (threadIdx.x < 8) {
-        const int j = threadIdx.x, ch = blk * 8 + j;
+        const int j = threadIdx.x;
         float k = 0.f, mu = 0.f, is = 0.f, mb = 0.f, mg = 0.f;
-        if (ch < c) {
-            mu = mean[ch];
-            is = invstd[ch];
+        if (coef) {
+            mu = mean_v;
+            is = invstd_v;
             // the conv epilogue summed g and g * z (raw z): sum g * xhat = invstd * (sum g z - mean * sum g), in fp64
-            const float db = (float)s_tot[2 * j], dg = (float)((s_tot[2 * j + 1] - (double)mu * s_tot[2 * j]) * (double)is);
-            k = gamma[ch] * is;
+            db = (float)s_tot[2 * j];
+            dg = (float)((s_tot[2 * j + 1] - (double)mu * s_tot[2 * j]) * (double)is);
+            k = gamma_v * is;
             mb = db * inv_count;
             mg = dg * inv_count;
-            if (chunk == 0) {
-                dbeta[ch] = db;
-                dgamma[ch] = dg;
-                if (dgamma_acc && dbeta_acc) {
-                    dbeta_acc[ch] += db;
-                    dgamma_acc[ch] += dg;
-                }
-            }
         }
         s_k[j] = k; s_mu[j] = mu; s_is[j] = is; s_mb[j] = mb; s_mg[j] = mg;
     }
     __syncthreads();
+    if (coef && chunk == 0) {  // parameter gradients: published behind the barrier (the accumulating form reads the arena first)
+        const int ch = blk * 8 + threadIdx.x;
+        dbeta[ch] = db;
+        dgamma[ch] = dg;
+        if (dgamma_acc && dbeta_acc) {
+            dbeta_acc[ch] += db;
+            dgamma_acc[ch] += dg;
+        }
+    }
     float k[8], mu[8], is[8], mb[8], mg[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { k[j] = s_k[j]; mu[j] = s_mu[j]; is[j] = s_is[j]; mb[j] = s_mb[j]; mg[j] = s_mg[j]; }  // zeros on padding channels

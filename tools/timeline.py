@@ -76,6 +76,13 @@ def main():
             depth += d
             last = t
         rec["alone_top"] = [(k2, round(v / 1e6, 3)) for k2, v in sorted(alone.items(), key=lambda kv: -kv[1])[:12]]
+        fams = {}
+        for s_, e_, n_ in ks:
+            f_ = n_.replace("void ", "").replace("mp::(anonymous namespace)::", "").replace("mp::", "").split("(")[0].split("<")[0][:48]
+            c_ = fams.setdefault(f_, [0, 0])
+            c_[0] += 1
+            c_[1] += e_ - s_
+        rec["families"] = [(k2, v[0], round(v[1] / 1e6, 3)) for k2, v in sorted(fams.items(), key=lambda kv: -kv[1][1])[:16]]
         if split_t is not None:
             rec["phases"] = {k2: {str(d2): round(v / 1e6, 3) for d2, v in sorted(ph.items())} for k2, ph in phase.items()}
         out.append(rec)
@@ -85,6 +92,7 @@ def main():
     for g in out[-1]["top_gaps"]:
         print("   gap", g)
     print("   running alone (ms):", out[-1]["alone_top"])
+    print("   kernel families (launches, ms of duration):", out[-1]["families"])
     if "phases" in out[-1]:
         print("   ms with 0 / 1 / 2 / 3+ kernels running, before and from the first", a.split, ":", out[-1]["phases"])
     if a.json:
