@@ -390,6 +390,21 @@ int mp_f16_basicblock_supported(int n, int c, int h, int w);
 int mp_f16_basicblock_fwd(const void* x_c8_dev, const void* packed_w1_dev, const float* scale1_dev, const float* shift1_dev,
                           const void* packed_w2_dev, const float* scale2_dev, const float* shift2_dev, void* out_c8_dev, int n,
                           int c, int h, int w, int rows, mp_stream_t stream);
+/* Two chained fp16 1x1 convolutions in ONE launch (hrnet.py:107-123, 126-146, stage 1): the expand conv of Bottleneck i,
+ *   y = act3(conv1x1(mid; w3) * scale3 + shift3 + res)      cm -> ce channels, res = the block's identity,
+ * and the reduce conv of Bottleneck i + 1 on it,
+ *   z = act1(conv1x1(y; w1) * scale1 + shift1)               ce -> cr channels,
+ * y written once and never read back from HBM.  Channel-blocked fp16 tensors, weights packed by mp_f16_pack_weight (1x1).  y and z
+ * are bit-identical to two mp_f16_conv2d_fwd launches.  Built for cm = 64, ce = 256, cr = 64 and h * w a multiple of 64:
+ * MP_ERR_UNSUPPORTED otherwise (the caller launches the two convs). */
+int mp_f16_expand_reduce_fwd(const void* mid_c8_dev, const void* res_c8_dev, const void* packed_w3_dev, const float* scale3_dev,
+                             const float* shift3_dev, int relu3, const void* packed_w1_dev, const float* scale1_dev,
+                             const float* shift1_dev, int relu1, void* y_c8_dev, void* z_c8_dev, int n, int cm, int ce, int cr, int h,
+                             int w, mp_stream_t stream);
+int mp_plan_add_expand_reduce_f16(mp_plan* plan, const void* mid_c8_dev, const void* res_c8_dev, const void* packed_w3_dev,
+                                  const float* scale3_dev, const float* shift3_dev, int relu3, const void* packed_w1_dev,
+                                  const float* scale1_dev, const float* shift1_dev, int relu1, void* y_c8_dev, void* z_c8_dev, int n,
+                                  int cm, int ce, int cr, int h, int w);
 int mp_plan_add_basicblock_f16(mp_plan* plan, const void* x_c8_dev, const void* packed_w1_dev, const float* scale1_dev,
                                const float* shift1_dev, const void* packed_w2_dev, const float* scale2_dev, const float* shift2_dev,
                                void* out_c8_dev, int n, int c, int h, int w, int rows);

@@ -337,11 +337,13 @@ using namespace mp;
 struct mp_plan {
     struct Entry {
         int kind;  // 0 conv, 1 maxpool, 2 fuse-sum; fp16 layout: 3 conv, 4 fuse-sum, 5 NCHW fp32 -> c8, 6 c8 -> NCHW fp32;
-                   // 7 = all-lane barrier (no launch), 8 = fused fp16 BasicBlock, 9 = fp32 Winograd conv
+                   // 7 = all-lane barrier (no launch), 8 = fused fp16 BasicBlock, 9 = fp32 Winograd conv,
+                   // 10 = fp16 expand + reduce 1x1 chain (stage 1)
         int lane;  // execution lane: 0 = the caller's stream, 1..3 = the plan's own side streams
         ConvLaunch conv;
         ConvF16Launch conv16;
         BlockF16Launch block16;
+        PwChainLaunch pwchain;
         WinoLaunch wino;
         const void* t16[3];
         const void* x16;
@@ -385,6 +387,7 @@ static int run_entry(const mp_plan::Entry& e, mp_stream_t stream) {
         case 7: return MP_OK;
         case 8: return blockf16_launch(e.block16, as_stream(stream));
         case 9: return wino_launch(e.wino, as_stream(stream));
+        case 10: return pwchain_launch(e.pwchain, as_stream(stream));
         default: return MP_ERR_UNSUPPORTED;
     }
 }
@@ -630,6 +633,20 @@ int mp_plan_add_basicblock_f16(mp_plan* plan, const void* x, const void* packed_
     return MP_OK;
 }
 
+int mp_plan_add_expand_reduce_f16(mp_plan* plan, const void* mid, const void* res, const void* packed_w3, const float* scale3,
+                                  const float* shift3, int relu3, const void* packed_w1, const float* scale1, const float* shift1,
+                                  int relu1, void* y, void* z, int n, int cm, int ce, int cr, int h, int w) {
+    if (!plan) return MP_ERR_NULL;
+    mp_plan::Entry e{};
+    e.kind = 10;
+    int rc = pwchain_build(mid, res, packed_w3, scale3, shift3, relu3, packed_w1, scale1, shift1, relu1, y, z, n, cm, ce, cr, h, w, e.pwchain);
+    if (rc != MP_OK) return rc;
+    e.n = n; e.c = ce; e.h = h; e.w = w;
+    e.lane = plan->cur_lane;
+    plan->entries.push_back(e);
+    return MP_OK;
+}
+
 int mp_plan_add_fuse_sum_f16(mp_plan* plan, const void* base, const void* t1, int s1, const void* t2, int s2, const void* t3,
                              int s3, void* out, int n, int c, int h, int w, int relu) {
     if (!plan || !base || !t1 || !out) return MP_ERR_NULL;
@@ -699,6 +716,9 @@ int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]) {
         info[1] = 3; info[2] = 1; info[3] = 9 /* the tuner's index of the Winograd form */; info[4] = e.wino.p.total_blocks;
         info[5] = (int64_t)e.wino.lds_bytes; info[6] = 32 * e.wino.teams; info[7] = e.wino.p.M * 4; info[8] = 8; info[9] = 1; info[10] = e.wino.p.R;
         info[11] = e.wino.ni;
+    } else if (e.kind == 10) {
+        info[1] = 1; info[2] = 1; info[3] = 0; info[4] = e.pwchain.p.total_blocks;
+        info[5] = (int64_t)e.pwchain.lds_bytes; info[6] = e.pwchain.ce; info[7] = 64; info[8] = e.pwchain.cm; info[9] = 1; info[10] = 0;
     } else if (e.kind == 8) {
         info[1] = 3; info[2] = 1; info[3] = e.block16.small; info[4] = e.block16.p.total_blocks;
         const int blk_c = e.block16.small == 4 ? 64 : e.block16.small == 5 ? 128 : 32;  // cout tile / cin chunk = the block's width

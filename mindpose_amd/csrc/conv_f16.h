@@ -126,6 +126,30 @@ bool blockf16_c64_build(const void* x, const void* w1, const float* scale1, cons
                         const float* shift2, void* out, int n, int c, int h, int w, int rows, BlockF16Launch& L);
 int blockf16_c64_launch(const BlockF16Launch& L, hipStream_t s);
 
+// two chained 1x1 convs of HRNet's stage 1 in one launch (pwchain_f16.hip): expand conv of Bottleneck i + reduce conv of i + 1
+struct PwChainParams {
+    const void* mid;   // [N][CM/8][HW] x 16 B: the 3x3 conv's output
+    const void* res;   // [N][CE/8][HW]: the identity of the expand conv
+    const void* w3;    // packed 1x1 weights CM -> CE
+    const float* scale3;
+    const float* shift3;
+    const void* w1;    // packed 1x1 weights CE -> CR
+    const float* scale1;
+    const float* shift1;
+    void* y;           // [N][CE/8][HW]
+    void* z;           // [N][CR/8][HW]
+    int N, HW, tiles_per_img, total_blocks, relu3, relu1;
+};
+struct PwChainLaunch {
+    PwChainParams p;
+    int cm, ce, cr, h, w;
+    size_t lds_bytes;
+};
+int pwchain_build(const void* mid, const void* res, const void* w3, const float* scale3, const float* shift3, int relu3, const void* w1,
+                  const float* scale1, const float* shift1, int relu1, void* y, void* z, int n, int cm, int ce, int cr, int h, int w,
+                  PwChainLaunch& L);
+int pwchain_launch(const PwChainLaunch& L, hipStream_t s);
+
 int f16_build_launch(const mp_conv_desc* desc, int variant, const void* x, const void* w, const float* scale,
                      const float* shift, const void* res1, const void* res2, void* out, ConvF16Launch& L);
 int f16_launch(const ConvF16Launch& L, hipStream_t s);

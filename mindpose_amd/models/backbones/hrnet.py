@@ -68,13 +68,19 @@ class Bottleneck(nn.Module):
         self.bn3 = BatchNorm2d(channels * self.expansion)
         self.down_sample = down_sample
 
-    def emit(self, plan: Plan, x: torch.Tensor) -> torch.Tensor:
+    def emit(self, plan: Plan, x: torch.Tensor, reduced: torch.Tensor = None, nxt: "Bottleneck" = None):
+        """``reduced``: relu(bn1(conv1 x)) when the previous block's last launch already produced it; ``nxt``: the following
+        Bottleneck - when its reduce conv can ride on this block's expand conv (``Plan.fuses_expand_reduce``, fp16 plans) the pair
+        (output, reduced output for ``nxt``) is returned instead of the output alone."""
         identity = x
         if self.down_sample is not None:
             identity = plan.conv(x, self.down_sample[0], self.down_sample[1])
-        out = plan.conv(x, self.conv1, self.bn1, relu=True)
+        out = reduced if reduced is not None else plan.conv(x, self.conv1, self.bn1, relu=True)
         out = plan.conv(out, self.conv2, self.bn2, relu=True)
-        return plan.conv(out, self.conv3, self.bn3, relu=True, res1=identity)
+        if nxt is not None and self.conv2.stride == 1 and plan.fuses_expand_reduce(out, identity, self.conv3, nxt.conv1):
+            return plan.expand_reduce(out, identity, self.conv3, self.bn3, nxt.conv1, nxt.bn1)
+        y = plan.conv(out, self.conv3, self.bn3, relu=True, res1=identity)
+        return y if nxt is None else (y, None)
 
     def train_forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.down_sample is None:
@@ -396,8 +402,14 @@ class HRNet(Backbone):
         x = plan.enter(x)
         x = plan.conv(x, self.conv1, self.bn1, relu=True)
         x = plan.conv(x, self.conv2, self.bn2, relu=True)
-        for blk in self.layer1:
-            x = blk.emit(plan, x)
+        blocks, reduced = list(self.layer1), None
+        for i, blk in enumerate(blocks):
+            if isinstance(blk, Bottleneck) and i + 1 < len(blocks) and isinstance(blocks[i + 1], Bottleneck):
+                x, reduced = blk.emit(plan, x, reduced, blocks[i + 1])  # (output, the next block's reduced input or None)
+            elif isinstance(blk, Bottleneck):
+                x, reduced = blk.emit(plan, x, reduced), None
+            else:
+                x, reduced = blk.emit(plan, x), None
         ys = [x]
         for idx in (2, 3, 4):
             trans = getattr(self, f"transition{idx - 1}")

@@ -602,6 +602,33 @@ class Plan:
                                     macs=2 * n * h * w * c * c * 9))
         return out
 
+    def fuses_expand_reduce(self, mid: torch.Tensor, res: torch.Tensor, conv3: Conv2d, conv1_next: Conv2d) -> bool:
+        """Can the expand conv of a Bottleneck and the reduce conv of the next one run as ONE launch (mp_f16_expand_reduce_fwd)?
+        fp16 plans, the 64 -> 256 -> 64 widths of HRNet's stage 1, 1x1 stride-1 convs without bias, maps whose pixel count is a
+        multiple of 64.  ``MINDPOSE_FUSE_PWCHAIN=0`` keeps the two launches (same bits)."""
+        if not isinstance(mid, ActC8) or not isinstance(res, ActC8) or os.environ.get("MINDPOSE_FUSE_PWCHAIN", "1") == "0":
+            return False
+        n, cm, h, w = mid.shape
+        ok = lambda cv, ci, co: (cv.in_channels == ci and cv.out_channels == co and cv.kernel_size == 1 and cv.stride == 1  # noqa: E731
+                                 and cv.padding == 0 and cv.bias is None)
+        return (cm == 64 and tuple(res.shape) == (n, 256, h, w) and ok(conv3, 64, 256) and ok(conv1_next, 256, 64) and (h * w) % 64 == 0
+                and n * 32 * h * w * 16 < 0x7FFFFFF0)
+
+    def expand_reduce(self, mid: torch.Tensor, res: torch.Tensor, conv3: Conv2d, bn3: BatchNorm2d, conv1_next: Conv2d,
+                      bn1_next: BatchNorm2d) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(y, z) = (relu(bn3(conv3 mid) + res), relu(bn1'(conv1' y))) in one launch: y never comes back from HBM for the second conv;
+        bit-identical to the two conv launches (hrnet.py:107-146)."""
+        n, cm, h, w = mid.shape
+        ce, cr = conv3.out_channels, conv1_next.out_channels
+        y, z = self.alloc(n, ce, h, w), self.alloc(n, cr, h, w)
+        p3, p1 = self._pack(conv3.weight, ce, cm, 1, False, 0, 0, True), self._pack(conv1_next.weight, cr, ce, 1, False, 0, 0, True)
+        (s3, b3), (s1, b1) = self._affine(ce, bn3, None, True), self._affine(cr, bn1_next, None, True)
+        _lib.check(self.lib.mp_plan_add_expand_reduce_f16(self.handle, _lib.ptr(mid), _lib.ptr(res), _lib.ptr(p3), _lib.ptr(s3), _lib.ptr(b3), 1,
+                                                          _lib.ptr(p1), _lib.ptr(s1), _lib.ptr(b1), 1, _lib.ptr(y), _lib.ptr(z), n, cm, ce, cr, h, w),
+                   "mp_plan_add_expand_reduce_f16")
+        self.layer_info.append(dict(kind="pwchain_f16", k=1, stride=1, cin=cm, cout=ce, h=h, w=w, n=n, macs=n * h * w * (cm * ce + ce * cr)))
+        return y, z
+
     def deconv4x4s2(self, x: torch.Tensor, deconv: Conv2dTranspose, bn: BatchNorm2d, relu: bool = True) -> torch.Tensor:
         """Conv2dTranspose(k=4, s=2, p=1) + BN + ReLU as four 2x2 sub-pixel phase convolutions - four launches with a tuned form each,
         or (fp32, where the tuner finds it faster: the small maps of the head) all four phases in ONE launch of the blocked-GEMM

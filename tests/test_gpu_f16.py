@@ -560,3 +560,72 @@ def test_conv_f16_wreg_stride2_bit_identical_to_tile_kernel(case, variant):
     got = _from_c8(out)
     tol = ref.abs() * 2.0 ** -9 + 1e-4 * ref.abs().max()
     assert not ((got - ref).abs() > tol).any(), float((got - ref).abs().max())
+
+
+def _pw_conv(xa, wt, scale, shift, res, relu, n, cin, cout, h, w):
+    """one 1x1 fp16 conv launch (library's own variant choice) -> (ActC8 output, packed weights, padded scale, padded shift)"""
+    nb = LIB.mp_f16_packed_weight_bytes(cout, cin, 1, 1)
+    pk = torch.empty(nb // 2, device=DEV, dtype=torch.float16)
+    _lib.check(LIB.mp_f16_pack_weight(_lib.ptr(wt.to(DEV)), _lib.ptr(pk), cout, cin, 1, 1, 0, 0, 0, _lib.stream()), "pack")
+    sc, sh = scale.to(DEV).contiguous(), shift.to(DEV).contiguous()
+    d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=1, kw=1, stride=1, pad_top=0, pad_left=0, conv_h=h, conv_w=w, out_h=h,
+                      out_w=w, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=relu, flags=0)
+    out = ActC8(n, cout, h, w, DEV)
+    _lib.check(LIB.mp_f16_conv2d_fwd(ctypes.byref(d), -1, _lib.ptr(xa), _lib.ptr(pk), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(res) if res is not None else None,
+                                     None, _lib.ptr(out), _lib.stream()), "1x1 conv")
+    return out, pk, sc, sh
+
+
+@pytest.mark.parametrize("relus", [(1, 1), (0, 1), (1, 0)])
+@pytest.mark.parametrize("shape", [(3, 64, 48), (2, 16, 12), (5, 8, 8), (2, 96, 72), (1, 4, 16)])
+def test_expand_reduce_chain_equals_two_convs(shape, relus):
+    """mp_f16_expand_reduce_fwd (expand conv of Bottleneck i + reduce conv of Bottleneck i + 1, hrnet.py:107-146, y kept in LDS for
+    the second GEMM) against two mp_f16_conv2d_fwd launches: y and z bit-identical - HRNet's stage-1 map, W48's, small maps with
+    one / few pixel tiles per image."""
+    n, h, w = shape
+    g = torch.Generator().manual_seed(n * h * w + relus[0])
+    mid = _to_c8(torch.randn(n, 64, h, w, generator=g))
+    res = _to_c8(torch.randn(n, 256, h, w, generator=g))
+    w3 = torch.randn(256, 64, 1, 1, generator=g) * (2.0 / 64) ** 0.5
+    w1 = torch.randn(64, 256, 1, 1, generator=g) * (2.0 / 256) ** 0.5
+    s3, b3 = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.1
+    s1, b1 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    y_ref, pk3, sc3, sh3 = _pw_conv(mid, w3, s3, b3, res, relus[0], n, 64, 256, h, w)
+    z_ref, pk1, sc1, sh1 = _pw_conv(y_ref, w1, s1, b1, None, relus[1], n, 256, 64, h, w)
+    y, z = ActC8(n, 256, h, w, DEV), ActC8(n, 64, h, w, DEV)
+    y.c8_tensor.fill_(7.0); z.c8_tensor.fill_(7.0)
+    _lib.check(LIB.mp_f16_expand_reduce_fwd(_lib.ptr(mid), _lib.ptr(res), _lib.ptr(pk3), _lib.ptr(sc3), _lib.ptr(sh3), relus[0], _lib.ptr(pk1),
+                                            _lib.ptr(sc1), _lib.ptr(sh1), relus[1], _lib.ptr(y), _lib.ptr(z), n, 64, 256, 64, h, w,
+                                            _lib.stream()), "mp_f16_expand_reduce_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(y.c8_tensor, y_ref.c8_tensor)
+    assert torch.equal(z.c8_tensor, z_ref.c8_tensor)
+
+
+def test_expand_reduce_chain_rejects_what_it_is_not_built_for():
+    a = ActC8(1, 256, 8, 8, DEV)
+    p = _lib.ptr(a)
+    f = torch.zeros(256, device=DEV)
+    args = lambda cm, ce, cr, h, w: (p, p, p, _lib.ptr(f), _lib.ptr(f), 1, p, _lib.ptr(f), _lib.ptr(f), 1, p, p, 1, cm, ce, cr, h, w, _lib.stream())  # noqa: E731
+    assert LIB.mp_f16_expand_reduce_fwd(*args(32, 128, 32, 8, 8)) == -3   # other widths: MP_ERR_UNSUPPORTED
+    assert LIB.mp_f16_expand_reduce_fwd(*args(64, 256, 64, 8, 6)) == -3   # 48 pixels: a tile would straddle images
+    assert LIB.mp_f16_expand_reduce_fwd(None, *args(64, 256, 64, 8, 8)[1:]) == -1  # MP_ERR_NULL
+
+
+@pytest.mark.parametrize("backbone,shape", [("hrnet_w32", (3, 3, 256, 192)), ("hrnet_w48", (2, 3, 128, 96))])
+def test_network_with_the_stage1_chain_launch_equals_the_two_launch_plan(backbone, shape, monkeypatch):
+    """The amp-O2 plan with the expand + reduce chain launches of stage 1 (MINDPOSE_FUSE_PWCHAIN, default) against the plan with one
+    launch per conv: heat-maps bit for bit, and the chain entries are really in the plan."""
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(3)).to(DEV)
+    outs, kinds = {}, {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MINDPOSE_FUSE_PWCHAIN", flag)
+        net = _net(backbone)
+        mp.models.auto_mixed_precision(net, "O2")
+        outs[flag] = net(x).clone()
+        plan = next(iter(net._plans.values())) if hasattr(net, "_plans") else None
+        kinds[flag] = [e["kind"] for e in plan.layer_info] if plan is not None else None
+    assert torch.equal(outs["1"], outs["0"])
+    if kinds["1"] is not None:
+        assert kinds["1"].count("pwchain_f16") == 3 and kinds["0"].count("pwchain_f16") == 0
+        assert len(kinds["1"]) == len(kinds["0"]) - 3
