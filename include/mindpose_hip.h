@@ -390,6 +390,15 @@ int mp_f16_basicblock_supported(int n, int c, int h, int w);
 int mp_f16_basicblock_fwd(const void* x_c8_dev, const void* packed_w1_dev, const float* scale1_dev, const float* shift1_dev,
                           const void* packed_w2_dev, const float* scale2_dev, const float* shift2_dev, void* out_c8_dev, int n,
                           int c, int h, int w, int rows, mp_stream_t stream);
+/* First convolution of the network under amp O2, straight from the fp32 NCHW image (hrnet.py:377-385: 3x3, stride 2, padding 1,
+ * 3 -> 64 channels, folded BatchNorm, ReLU): out = act(conv(fp16(x); fp16(weight)) * scale + shift), channel-blocked fp16
+ * [n][8][h/2][w/2][8].  weight = the fp32 tensor [64][3][3][3] itself (no packing).  Replaces mp_f16_to_c8 + mp_f16_conv2d_fwd: same
+ * fp16 operands and fp32 accumulation, the 27 products per output summed in ONE k-step (tap-major) instead of nine - equal within one
+ * fp16 rounding of the output.  h even, w a multiple of 32: MP_ERR_UNSUPPORTED otherwise. */
+int mp_f16_stem_conv_fwd(const float* x_dev, const float* weight_dev, const float* scale_dev, const float* shift_dev, int relu,
+                         void* out_c8_dev, int n, int h, int w, mp_stream_t stream);
+int mp_plan_add_stem_conv_f16(mp_plan* plan, const float* x_dev, const float* weight_dev, const float* scale_dev, const float* shift_dev,
+                              int relu, void* out_c8_dev, int n, int h, int w);
 /* Two chained fp16 1x1 convolutions in ONE launch (hrnet.py:107-123, 126-146, stage 1): the expand conv of Bottleneck i,
  *   y = act3(conv1x1(mid; w3) * scale3 + shift3 + res)      cm -> ce channels, res = the block's identity,
  * and the reduce conv of Bottleneck i + 1 on it,

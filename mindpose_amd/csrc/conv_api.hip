@@ -338,12 +338,13 @@ struct mp_plan {
     struct Entry {
         int kind;  // 0 conv, 1 maxpool, 2 fuse-sum; fp16 layout: 3 conv, 4 fuse-sum, 5 NCHW fp32 -> c8, 6 c8 -> NCHW fp32;
                    // 7 = all-lane barrier (no launch), 8 = fused fp16 BasicBlock, 9 = fp32 Winograd conv,
-                   // 10 = fp16 expand + reduce 1x1 chain (stage 1)
+                   // 10 = fp16 expand + reduce 1x1 chain (stage 1), 11 = fp16 first conv from the fp32 image
         int lane;  // execution lane: 0 = the caller's stream, 1..3 = the plan's own side streams
         ConvLaunch conv;
         ConvF16Launch conv16;
         BlockF16Launch block16;
         PwChainLaunch pwchain;
+        StemF16Launch stem16;
         WinoLaunch wino;
         const void* t16[3];
         const void* x16;
@@ -388,6 +389,7 @@ static int run_entry(const mp_plan::Entry& e, mp_stream_t stream) {
         case 8: return blockf16_launch(e.block16, as_stream(stream));
         case 9: return wino_launch(e.wino, as_stream(stream));
         case 10: return pwchain_launch(e.pwchain, as_stream(stream));
+        case 11: return stemf16_launch(e.stem16, as_stream(stream));
         default: return MP_ERR_UNSUPPORTED;
     }
 }
@@ -647,6 +649,19 @@ int mp_plan_add_expand_reduce_f16(mp_plan* plan, const void* mid, const void* re
     return MP_OK;
 }
 
+int mp_plan_add_stem_conv_f16(mp_plan* plan, const float* x, const float* weight, const float* scale, const float* shift, int relu,
+                              void* out, int n, int h, int w) {
+    if (!plan) return MP_ERR_NULL;
+    mp_plan::Entry e{};
+    e.kind = 11;
+    int rc = stemf16_build(x, weight, scale, shift, relu, out, n, h, w, e.stem16);
+    if (rc != MP_OK) return rc;
+    e.n = n; e.c = 64; e.h = h; e.w = w;
+    e.lane = plan->cur_lane;
+    plan->entries.push_back(e);
+    return MP_OK;
+}
+
 int mp_plan_add_fuse_sum_f16(mp_plan* plan, const void* base, const void* t1, int s1, const void* t2, int s2, const void* t3,
                              int s3, void* out, int n, int c, int h, int w, int relu) {
     if (!plan || !base || !t1 || !out) return MP_ERR_NULL;
@@ -716,6 +731,9 @@ int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]) {
         info[1] = 3; info[2] = 1; info[3] = 9 /* the tuner's index of the Winograd form */; info[4] = e.wino.p.total_blocks;
         info[5] = (int64_t)e.wino.lds_bytes; info[6] = 32 * e.wino.teams; info[7] = e.wino.p.M * 4; info[8] = 8; info[9] = 1; info[10] = e.wino.p.R;
         info[11] = e.wino.ni;
+    } else if (e.kind == 11) {
+        info[1] = 3; info[2] = 2; info[3] = 0; info[4] = e.stem16.p.total_blocks;
+        info[5] = (int64_t)e.stem16.lds_bytes; info[6] = 64; info[7] = 8 * e.stem16.p.Wo; info[8] = 3; info[9] = 1; info[10] = 8;
     } else if (e.kind == 10) {
         info[1] = 1; info[2] = 1; info[3] = 0; info[4] = e.pwchain.p.total_blocks;
         info[5] = (int64_t)e.pwchain.lds_bytes; info[6] = e.pwchain.ce; info[7] = 64; info[8] = e.pwchain.cm; info[9] = 1; info[10] = 0;

@@ -150,6 +150,24 @@ int pwchain_build(const void* mid, const void* res, const void* w3, const float*
                   PwChainLaunch& L);
 int pwchain_launch(const PwChainLaunch& L, hipStream_t s);
 
+// first conv of the network straight from the fp32 NCHW image (stem_f16.hip): 3x3 stride 2 padding 1, 3 -> 64 channels
+struct StemF16Params {
+    const float* x;      // [N][3][H][W] fp32
+    const float* w;      // [64][3][3][3] fp32
+    const float* scale;  // [64]
+    const float* shift;
+    void* out;           // [N][8][H/2][W/2] x 16 B
+    int N, H, W, Ho, Wo, pitch, tiles_y, total_blocks, relu;
+    unsigned magic_upr;  // / (W / 4)
+};
+struct StemF16Launch {
+    StemF16Params p;
+    size_t lds_bytes;
+};
+int stemf16_build(const float* x, const float* w, const float* scale, const float* shift, int relu, void* out, int n, int h, int wd,
+                  StemF16Launch& L);
+int stemf16_launch(const StemF16Launch& L, hipStream_t s);
+
 int f16_build_launch(const mp_conv_desc* desc, int variant, const void* x, const void* w, const float* scale,
                      const float* shift, const void* res1, const void* res2, void* out, ConvF16Launch& L);
 int f16_launch(const ConvF16Launch& L, hipStream_t s);

@@ -399,8 +399,11 @@ class HRNet(Backbone):
 
     def emit(self, plan: Plan, x: torch.Tensor) -> torch.Tensor:
         """Recorded form of ``forward_feature`` hrnet.py:559-605."""
-        x = plan.enter(x)
-        x = plan.conv(x, self.conv1, self.bn1, relu=True)
+        if plan.fuses_stem(x, self.conv1):  # fp16 plans: the first conv reads the fp32 image itself (no layout pass)
+            x = plan.stem(x, self.conv1, self.bn1)
+        else:
+            x = plan.enter(x)
+            x = plan.conv(x, self.conv1, self.bn1, relu=True)
         x = plan.conv(x, self.conv2, self.bn2, relu=True)
         blocks, reduced = list(self.layer1), None
         for i, blk in enumerate(blocks):

@@ -602,6 +602,28 @@ class Plan:
                                     macs=2 * n * h * w * c * c * 9))
         return out
 
+    def fuses_stem(self, x: torch.Tensor, conv: Conv2d) -> bool:
+        """fp16 plans: can the first conv read the fp32 NCHW image itself (mp_f16_stem_conv_fwd: no layout pass, the 27 real k positions
+        of a 3-channel 3x3 conv in ONE k-step)?  ``MINDPOSE_FUSE_STEM=0`` keeps layout pass + general conv."""
+        if not self.half or isinstance(x, ActC8) or os.environ.get("MINDPOSE_FUSE_STEM", "1") == "0":
+            return False
+        n, c, h, w = x.shape
+        return (c == 3 and conv.in_channels == 3 and conv.out_channels == 64 and conv.kernel_size == 3 and conv.stride == 2
+                and conv.padding == 1 and conv.bias is None and h % 2 == 0 and w % 32 == 0 and x.dtype == torch.float32
+                and 6 * (w + 4) * 17 + 16 <= 64 * 1024 and n * 8 * (h // 2) * (w // 2) * 16 < 0x7FFFFFF0)
+
+    def stem(self, x: torch.Tensor, conv: Conv2d, bn: BatchNorm2d) -> "ActC8":
+        """relu(bn(conv x)) from the fp32 image to the channel-blocked fp16 activation in one launch (hrnet.py:377-385)."""
+        n, _, h, w = x.shape
+        out = self.alloc(n, 64, h // 2, w // 2)
+        wt = conv.weight.detach().to(self.device, torch.float32).contiguous()
+        scale, shift = self._affine(64, bn, None, True)
+        self.keep.append(wt)
+        _lib.check(self.lib.mp_plan_add_stem_conv_f16(self.handle, _lib.ptr(x), _lib.ptr(wt), _lib.ptr(scale), _lib.ptr(shift), 1, _lib.ptr(out),
+                                                      n, h, w), "mp_plan_add_stem_conv_f16")
+        self.layer_info.append(dict(kind="stem_f16", k=3, stride=2, cin=3, cout=64, h=h, w=w, n=n, macs=n * (h // 2) * (w // 2) * 64 * 27))
+        return out
+
     def fuses_expand_reduce(self, mid: torch.Tensor, res: torch.Tensor, conv3: Conv2d, conv1_next: Conv2d) -> bool:
         """Can the expand conv of a Bottleneck and the reduce conv of the next one run as ONE launch (mp_f16_expand_reduce_fwd)?
         fp16 plans, the 64 -> 256 -> 64 widths of HRNet's stage 1, 1x1 stride-1 convs without bias, maps whose pixel count is a

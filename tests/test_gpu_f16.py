@@ -629,3 +629,66 @@ def test_network_with_the_stage1_chain_launch_equals_the_two_launch_plan(backbon
     if kinds["1"] is not None:
         assert kinds["1"].count("pwchain_f16") == 3 and kinds["0"].count("pwchain_f16") == 0
         assert len(kinds["1"]) == len(kinds["0"]) - 3
+
+
+@pytest.mark.parametrize("shape", [(3, 256, 192), (2, 384, 288), (2, 64, 64), (5, 8, 32), (1, 6, 96)])
+@pytest.mark.parametrize("relu", [1, 0])
+def test_stem_conv_from_the_fp32_image(shape, relu):
+    """mp_f16_stem_conv_fwd (first conv of HRNet, hrnet.py:377-385, read from the fp32 NCHW image with (tap, channel) as the k axis)
+    against (a) an fp64 convolution of the fp16-rounded image and weights: within one fp16 rounding of the output, and (b) the layout
+    pass + general fp16 conv it replaces: equal except for rare one-ulp flips (another summation order of the same 27 products)."""
+    n, h, w = shape
+    g = torch.Generator().manual_seed(n * h + w + relu)
+    x = torch.randn(n, 3, h, w, generator=g)
+    wt = torch.randn(64, 3, 3, 3, generator=g) * (2.0 / 27) ** 0.5
+    scale, shift = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    out = ActC8(n, 64, h // 2, w // 2, DEV)
+    out.c8_tensor.fill_(7.0)
+    xd, wd, sd, bd = x.to(DEV), wt.to(DEV).contiguous(), scale.to(DEV), shift.to(DEV)
+    _lib.check(LIB.mp_f16_stem_conv_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(sd), _lib.ptr(bd), relu, _lib.ptr(out), n, h, w, _lib.stream()), "stem")
+    got = _from_c8(out).cpu().double()
+    ref = F.conv2d(x.half().double(), wt.half().double(), stride=2, padding=1) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    if relu:
+        ref = ref.clamp_min(0)
+    tol = 2.0 ** -10 * ref.abs().clamp_min(2.0 ** -14) + 1e-6 * ref.abs().max()  # one fp16 rounding + fp32 accumulation
+    assert bool(((got - ref).abs() <= tol).all()), float(((got - ref).abs() / tol).max())
+    # the two launches it replaces
+    xa = _to_c8(x)
+    nb = LIB.mp_f16_packed_weight_bytes(64, 3, 3, 3)
+    pk = torch.empty(nb // 2, device=DEV, dtype=torch.float16)
+    _lib.check(LIB.mp_f16_pack_weight(_lib.ptr(wd), _lib.ptr(pk), 64, 3, 3, 3, 0, 0, 0, _lib.stream()), "pack")
+    d = _lib.ConvDesc(n=n, cin=3, h=h, w=w, cout=64, kh=3, kw=3, stride=2, pad_top=1, pad_left=1, conv_h=h // 2, conv_w=w // 2, out_h=h // 2,
+                      out_w=w // 2, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=relu, flags=0)
+    two = ActC8(n, 64, h // 2, w // 2, DEV)
+    _lib.check(LIB.mp_f16_conv2d_fwd(ctypes.byref(d), -1, _lib.ptr(xa), _lib.ptr(pk), _lib.ptr(sd), _lib.ptr(bd), None, None, _lib.ptr(two),
+                                     _lib.stream()), "general conv")
+    a, b = out.c8_tensor.float(), two.c8_tensor.float()
+    assert float((a != b).float().mean()) < 2e-3
+    # (near a zero of the pre-activation the two summation orders differ by fp32 rounding of O(1) terms, not by an fp16 ulp of the result)
+    assert bool(((a - b).abs() <= 2.0 ** -10 * b.abs() + 4e-6 * float(b.abs().max())).all())
+
+
+def test_stem_conv_rejects_other_geometries():
+    x = torch.zeros(1, 3, 8, 40, device=DEV)
+    wd, f = torch.zeros(64, 3, 3, 3, device=DEV), torch.zeros(64, device=DEV)
+    out = ActC8(1, 64, 4, 20, DEV)
+    assert LIB.mp_f16_stem_conv_fwd(_lib.ptr(x), _lib.ptr(wd), _lib.ptr(f), _lib.ptr(f), 1, _lib.ptr(out), 1, 8, 40, _lib.stream()) == -3   # w % 32
+    assert LIB.mp_f16_stem_conv_fwd(_lib.ptr(x), _lib.ptr(wd), _lib.ptr(f), _lib.ptr(f), 1, _lib.ptr(out), 1, 7, 64, _lib.stream()) == -3   # odd h
+    assert LIB.mp_f16_stem_conv_fwd(None, _lib.ptr(wd), _lib.ptr(f), _lib.ptr(f), 1, _lib.ptr(out), 1, 8, 64, _lib.stream()) == -1
+
+
+def test_network_with_the_fused_stem_agrees_with_the_layout_pass_plan(monkeypatch):
+    """amp-O2 HRNet-W32 with the first conv reading the fp32 image (MINDPOSE_FUSE_STEM, default) against layout pass + general conv:
+    the stem is really in the plan, the layout pass is gone, heat-maps agree to fp16 noise of one early layer."""
+    x = torch.randn(3, 3, 256, 192, generator=torch.Generator().manual_seed(4)).to(DEV)
+    outs, kinds = {}, {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MINDPOSE_FUSE_STEM", flag)
+        net = _net("hrnet_w32")
+        mp.models.auto_mixed_precision(net, "O2")
+        outs[flag] = net(x).clone()
+        kinds[flag] = [e["kind"] for e in next(iter(net._plans.values())).layer_info]
+    assert kinds["1"].count("stem_f16") == 1 and "to_c8" not in kinds["1"] and kinds["0"].count("to_c8") == 1
+    # rare one-ulp flips in the first layer travel through ~100 fp16 layers of a randomly initialised net: two fp16 evaluations of one
+    # graph, a fraction of either one's distance to the fp32 oracle (test_network_o2_vs_amp_oracle: up to 2e-2)
+    assert _nerr(outs["1"], outs["0"]) < 1e-2
