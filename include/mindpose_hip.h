@@ -410,6 +410,15 @@ int mp_f16_expand_reduce_fwd(const void* mid_c8_dev, const void* res_c8_dev, con
                              const float* shift3_dev, int relu3, const void* packed_w1_dev, const float* scale1_dev,
                              const float* shift1_dev, int relu1, void* y_c8_dev, void* z_c8_dev, int n, int cm, int ce, int cr, int h,
                              int w, mp_stream_t stream);
+/* The same kernel with BOTH convs on one 64-channel input (the first Bottleneck of stage 1, hrnet.py:74-81, 107-123: its down-sample
+ * conv ya = act_a(conv1x1(x; wa) * scale_a + shift_a), 64 -> 256, and its reduce conv zb = act_b(conv1x1(x; wb) * scale_b + shift_b),
+ * 64 -> 64): x read once, one launch; bit-identical to the two launches. */
+int mp_f16_dual_pw_fwd(const void* x_c8_dev, const void* packed_wa_dev, const float* scale_a_dev, const float* shift_a_dev, int relu_a,
+                       const void* packed_wb_dev, const float* scale_b_dev, const float* shift_b_dev, int relu_b, void* ya_c8_dev,
+                       void* zb_c8_dev, int n, int cm, int ce, int cr, int h, int w, mp_stream_t stream);
+int mp_plan_add_dual_pw_f16(mp_plan* plan, const void* x_c8_dev, const void* packed_wa_dev, const float* scale_a_dev,
+                            const float* shift_a_dev, int relu_a, const void* packed_wb_dev, const float* scale_b_dev,
+                            const float* shift_b_dev, int relu_b, void* ya_c8_dev, void* zb_c8_dev, int n, int cm, int ce, int cr, int h, int w);
 int mp_plan_add_expand_reduce_f16(mp_plan* plan, const void* mid_c8_dev, const void* res_c8_dev, const void* packed_w3_dev,
                                   const float* scale3_dev, const float* shift3_dev, int relu3, const void* packed_w1_dev,
                                   const float* scale1_dev, const float* shift1_dev, int relu1, void* y_c8_dev, void* z_c8_dev, int n,

@@ -154,6 +154,8 @@ _PROTOTYPES = {
     "mp_f16_basicblock_supported": (c_int, [c_int] * 4),
     "mp_f16_stem_conv_fwd": (c_int, [c_f32p] * 4 + [c_int, c_f32p] + [c_int] * 3 + [ctypes.c_void_p]),
     "mp_plan_add_stem_conv_f16": (c_int, [ctypes.c_void_p] + [c_f32p] * 4 + [c_int, c_f32p] + [c_int] * 3),
+    "mp_f16_dual_pw_fwd": (c_int, [c_f32p] * 4 + [c_int] + [c_f32p] * 3 + [c_int] + [c_f32p] * 2 + [c_int] * 6 + [ctypes.c_void_p]),
+    "mp_plan_add_dual_pw_f16": (c_int, [ctypes.c_void_p] + [c_f32p] * 4 + [c_int] + [c_f32p] * 3 + [c_int] + [c_f32p] * 2 + [c_int] * 6),
     "mp_f16_expand_reduce_fwd": (c_int, [c_f32p] * 5 + [c_int] + [c_f32p] * 3 + [c_int] + [c_f32p] * 2 + [c_int] * 6 + [ctypes.c_void_p]),
     "mp_plan_add_expand_reduce_f16": (c_int, [ctypes.c_void_p] + [c_f32p] * 5 + [c_int] + [c_f32p] * 3 + [c_int] + [c_f32p] * 2 + [c_int] * 6),
     "mp_plan_add_basicblock_f16": (c_int, [ctypes.c_void_p] + [c_f32p] * 8 + [c_int] * 5),

@@ -649,6 +649,20 @@ int mp_plan_add_expand_reduce_f16(mp_plan* plan, const void* mid, const void* re
     return MP_OK;
 }
 
+int mp_plan_add_dual_pw_f16(mp_plan* plan, const void* x, const void* packed_wa, const float* scale_a, const float* shift_a, int relu_a,
+                            const void* packed_wb, const float* scale_b, const float* shift_b, int relu_b, void* ya, void* zb, int n, int cm,
+                            int ce, int cr, int h, int w) {
+    if (!plan) return MP_ERR_NULL;
+    mp_plan::Entry e{};
+    e.kind = 10;
+    int rc = pwchain_build(x, x, packed_wa, scale_a, shift_a, relu_a, packed_wb, scale_b, shift_b, relu_b, ya, zb, n, cm, ce, cr, h, w, e.pwchain);
+    if (rc != MP_OK) return rc;
+    e.n = n; e.c = ce; e.h = h; e.w = w;
+    e.lane = plan->cur_lane;
+    plan->entries.push_back(e);
+    return MP_OK;
+}
+
 int mp_plan_add_stem_conv_f16(mp_plan* plan, const float* x, const float* weight, const float* scale, const float* shift, int relu,
                               void* out, int n, int h, int w) {
     if (!plan) return MP_ERR_NULL;
@@ -735,7 +749,7 @@ int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]) {
         info[1] = 3; info[2] = 2; info[3] = 0; info[4] = e.stem16.p.total_blocks;
         info[5] = (int64_t)e.stem16.lds_bytes; info[6] = 64; info[7] = 8 * e.stem16.p.Wo; info[8] = 3; info[9] = 1; info[10] = 8;
     } else if (e.kind == 10) {
-        info[1] = 1; info[2] = 1; info[3] = 0; info[4] = e.pwchain.p.total_blocks;
+        info[1] = 1; info[2] = 1; info[3] = e.pwchain.dual ? 1 : 0; info[4] = e.pwchain.p.total_blocks;
         info[5] = (int64_t)e.pwchain.lds_bytes; info[6] = e.pwchain.ce; info[7] = 64; info[8] = e.pwchain.cm; info[9] = 1; info[10] = 0;
     } else if (e.kind == 8) {
         info[1] = 3; info[2] = 1; info[3] = e.block16.small; info[4] = e.block16.p.total_blocks;

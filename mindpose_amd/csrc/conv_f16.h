@@ -143,6 +143,7 @@ struct PwChainParams {
 struct PwChainLaunch {
     PwChainParams p;
     int cm, ce, cr, h, w;
+    bool dual;  // both convs read `mid` (the first Bottleneck's down-sample + reduce convs): res == mid marks it
     size_t lds_bytes;
 };
 int pwchain_build(const void* mid, const void* res, const void* w3, const float* scale3, const float* shift3, int relu3, const void* w1,

@@ -31,11 +31,13 @@ __device__ __forceinline__ void pw_barrier() {
     asm volatile("" ::: "memory");
 }
 
-// CM / CE / CR: channels of m, y, z (multiples of 32 / 64 / 64)
-template <int CM, int CE, int CR>
+// CM / CE / CR: channels of m, y, z (multiples of 32 / 64 / 64).  DUAL: the second conv reads m as well (z = act1(conv1x1(m; w1))):
+// the down-sample conv and the reduce conv of the FIRST Bottleneck (hrnet.py:74-81, 107-123), both on the block's 64-channel input -
+// one read of it, one launch; no identity, y is not staged in LDS.
+template <int CM, int CE, int CR, bool DUAL = false>
 __global__ __launch_bounds__(256, 3) void expand_reduce_f16_kernel(const PwChainParams p) {
     static_assert(CE == 256 && CR == 64 && CM % 32 == 0, "four waves x 64 expanded channels; 64 reduced channels");
-    constexpr int KQ1 = CM / 32, KQ2 = CE / 32, CM8 = CM / 8, CE8 = CE / 8, CR8 = CR / 8, PS = kPT / 16, CS = 4;
+    constexpr int KQ1 = CM / 32, KQ2 = DUAL ? CM / 32 : CE / 32, CM8 = CM / 8, CE8 = CE / 8, CR8 = CR / 8, PS = kPT / 16, CS = 4;
     extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
     u32x4* __restrict__ lds_m = smem16;             // [CM8][64]
     u32x4* __restrict__ lds_y = smem16 + CM8 * kPT;  // [CE8][64]
@@ -82,10 +84,11 @@ __global__ __launch_bounds__(256, 3) void expand_reduce_f16_kernel(const PwChain
 #pragma unroll
     for (int ps = 0; ps < PS; ++ps)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) r[ps][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, off_e0 + 256u * ps + 64u * HW * j, 0, 0);
+        for (int j = 0; j < 2; ++j)
+            r[ps][j] = DUAL ? (u32x4){0u, 0u, 0u, 0u} : __builtin_amdgcn_raw_buffer_load_b128(rs_r, off_e0 + 256u * ps + 64u * HW * j, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     // the DMA pieces and the weight fragments are OLDER than the 2 PS identity loads: those stay in flight across the barrier
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PS) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DUAL ? 0 : 2 * PS) : "memory");
     pw_barrier();
 
     f32x4 acc1[PS][CS];
@@ -113,12 +116,12 @@ __global__ __launch_bounds__(256, 3) void expand_reduce_f16_kernel(const PwChain
 #pragma unroll
         for (int ps = 0; ps < PS; ++ps) {
             const u32x4 a1 = r[ps][j];
-            const u32x2 lo = f16_pack4(f16_epi4(acc1[ps][2 * j], sc_lo, sh_lo, true, (u32x2){a1.x, a1.y}, false, (u32x2){0u, 0u}, p.relu3));
-            const u32x2 hi = f16_pack4(f16_epi4(acc1[ps][2 * j + 1], sc_hi, sh_hi, true, (u32x2){a1.z, a1.w}, false,
+            const u32x2 lo = f16_pack4(f16_epi4(acc1[ps][2 * j], sc_lo, sh_lo, !DUAL, (u32x2){a1.x, a1.y}, false, (u32x2){0u, 0u}, p.relu3));
+            const u32x2 hi = f16_pack4(f16_epi4(acc1[ps][2 * j + 1], sc_hi, sh_hi, !DUAL, (u32x2){a1.z, a1.w}, false,
                                                 (u32x2){0u, 0u}, p.relu3));
             const u32x4 v = (u32x4){lo.x, lo.y, hi.x, hi.y};
             __builtin_amdgcn_raw_buffer_store_b128(v, rs_y, off_e0 + 256u * ps + 64u * HW * j, 0, 0);
-            lds_y[(8 * wave + 4 * j + lq) * kPT + ps * 16 + lr] = v;
+            if constexpr (!DUAL) lds_y[(8 * wave + 4 * j + lq) * kPT + ps * 16 + lr] = v;
         }
     }
     // ---- GEMM 2 (K = CE): wave = (pixel half wp, cout half wc): pixel tiles 2 wp, 2 wp + 1 x ONE pair of cout tiles (32 channels) -
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256, 3) void expand_reduce_f16_kernel(const PwChain
     for (int q = 0; q < KQ2; ++q) {
 #pragma unroll
         for (int ps = 0; ps < PS2; ++ps) {
-            const u32x4 bv = lds_y[(4 * q + lq) * kPT + (2 * wp + ps) * 16 + lr];
+            const u32x4 bv = (DUAL ? lds_m : lds_y)[(4 * q + lq) * kPT + (2 * wp + ps) * 16 + lr];
 #pragma unroll
             for (int cs = 0; cs < CS2; ++cs)
                 acc2[ps][cs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A2[q & 1][cs]), __builtin_bit_cast(f16x8, bv),
@@ -180,6 +183,7 @@ int pwchain_build(const void* mid, const void* res, const void* w3, const float*
     if (!mid || !res || !w3 || !scale3 || !shift3 || !w1 || !scale1 || !shift1 || !y || !z) return MP_ERR_NULL;
     if (n <= 0 || h <= 0 || w <= 0) return MP_ERR_SHAPE;
     if (cm != 64 || ce != 256 || cr != 64) return MP_ERR_UNSUPPORTED;  // HRNet's stage 1 (hrnet.py:377-385: Bottleneck, 64 channels, x 4)
+    L.dual = res == mid;  // the caller's mark for the two-convs-on-one-input form (mp_f16_dual_pw_fwd passes the input twice)
     const long long hw = (long long)h * w;
     if (hw % kPT != 0) return MP_ERR_UNSUPPORTED;  // a pixel tile never straddles images
     if ((long long)n * (ce / 8) * hw * 16 >= 0x7FFFFFF0LL) return MP_ERR_UNSUPPORTED;  // 32-bit buffer offsets
@@ -190,18 +194,13 @@ int pwchain_build(const void* mid, const void* res, const void* w3, const float*
     p.tiles_per_img = (int)(hw / kPT);
     p.total_blocks = n * p.tiles_per_img;
     L.cm = cm; L.ce = ce; L.cr = cr; L.h = h; L.w = w;
-    L.lds_bytes = (size_t)(cm / 8 + ce / 8) * kPT * 16;
+    L.lds_bytes = (size_t)(cm / 8 + (L.dual ? 0 : ce / 8)) * kPT * 16;
     return MP_OK;
 }
 
 int pwchain_launch(const PwChainLaunch& L, hipStream_t s) {
-    auto kern = expand_reduce_f16_kernel<64, 256, 64>;
-    static AttrOnce attr_set_once;
-    if (attr_set_once.need()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        (void)hipGetLastError();
-    }
-    hipLaunchKernelGGL(kern, dim3(L.p.total_blocks), dim3(256), L.lds_bytes, s, L.p);
+    if (L.dual) hipLaunchKernelGGL((expand_reduce_f16_kernel<64, 256, 64, true>), dim3(L.p.total_blocks), dim3(256), L.lds_bytes, s, L.p);
+    else hipLaunchKernelGGL((expand_reduce_f16_kernel<64, 256, 64, false>), dim3(L.p.total_blocks), dim3(256), L.lds_bytes, s, L.p);
     return check_launch();
 }
 
@@ -214,6 +213,15 @@ extern "C" int mp_f16_expand_reduce_fwd(const void* mid, const void* res, const 
                                         void* z, int n, int cm, int ce, int cr, int h, int w, mp_stream_t stream) {
     PwChainLaunch L{};
     const int rc = pwchain_build(mid, res, packed_w3, scale3, shift3, relu3, packed_w1, scale1, shift1, relu1, y, z, n, cm, ce, cr, h, w, L);
+    if (rc != MP_OK) return rc;
+    return pwchain_launch(L, as_stream(stream));
+}
+
+extern "C" int mp_f16_dual_pw_fwd(const void* x, const void* packed_wa, const float* scale_a, const float* shift_a, int relu_a,
+                                  const void* packed_wb, const float* scale_b, const float* shift_b, int relu_b, void* ya, void* zb, int n,
+                                  int cm, int ce, int cr, int h, int w, mp_stream_t stream) {
+    PwChainLaunch L{};
+    const int rc = pwchain_build(x, x, packed_wa, scale_a, shift_a, relu_a, packed_wb, scale_b, shift_b, relu_b, ya, zb, n, cm, ce, cr, h, w, L);
     if (rc != MP_OK) return rc;
     return pwchain_launch(L, as_stream(stream));
 }

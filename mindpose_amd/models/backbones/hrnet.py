@@ -73,7 +73,11 @@ class Bottleneck(nn.Module):
         Bottleneck - when its reduce conv can ride on this block's expand conv (``Plan.fuses_expand_reduce``, fp16 plans) the pair
         (output, reduced output for ``nxt``) is returned instead of the output alone."""
         identity = x
-        if self.down_sample is not None:
+        if (self.down_sample is not None and reduced is None and len(self.down_sample) == 2
+                and plan.fuses_dual_pw(x, self.down_sample[0], self.conv1)):
+            # the down-sample conv and the reduce conv read the same input: one launch (fp16 plans)
+            identity, reduced = plan.dual_pw(x, self.down_sample[0], self.down_sample[1], False, self.conv1, self.bn1, True)
+        elif self.down_sample is not None:
             identity = plan.conv(x, self.down_sample[0], self.down_sample[1])
         out = reduced if reduced is not None else plan.conv(x, self.conv1, self.bn1, relu=True)
         out = plan.conv(out, self.conv2, self.bn2, relu=True)

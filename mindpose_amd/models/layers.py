@@ -602,6 +602,32 @@ class Plan:
                                     macs=2 * n * h * w * c * c * 9))
         return out
 
+    def fuses_dual_pw(self, x: torch.Tensor, conv_a: Conv2d, conv_b: Conv2d) -> bool:
+        """Two 1x1 convs on ONE 64-channel input as one launch (mp_f16_dual_pw_fwd): the down-sample conv (64 -> 256) and the reduce conv
+        (64 -> 64) of stage 1's first Bottleneck.  fp16 plans, stride 1, no bias, pixel count a multiple of 64; switched with the chain
+        launch (``MINDPOSE_FUSE_PWCHAIN``)."""
+        if not isinstance(x, ActC8) or os.environ.get("MINDPOSE_FUSE_PWCHAIN", "1") == "0":
+            return False
+        n, c, h, w = x.shape
+        ok = lambda cv, co: (cv.in_channels == 64 and cv.out_channels == co and cv.kernel_size == 1 and cv.stride == 1  # noqa: E731
+                             and cv.padding == 0 and cv.bias is None)
+        return c == 64 and ok(conv_a, 256) and ok(conv_b, 64) and (h * w) % 64 == 0 and n * 32 * h * w * 16 < 0x7FFFFFF0
+
+    def dual_pw(self, x: torch.Tensor, conv_a: Conv2d, bn_a: BatchNorm2d, relu_a: bool, conv_b: Conv2d, bn_b: BatchNorm2d,
+                relu_b: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(act_a(bn_a(conv_a x)), act_b(bn_b(conv_b x))) in one launch, x read once; bit-identical to the two conv launches."""
+        n, c, h, w = x.shape
+        ya, zb = self.alloc(n, conv_a.out_channels, h, w), self.alloc(n, conv_b.out_channels, h, w)
+        pa = self._pack(conv_a.weight, conv_a.out_channels, c, 1, False, 0, 0, True)
+        pb = self._pack(conv_b.weight, conv_b.out_channels, c, 1, False, 0, 0, True)
+        (sa, ba), (sb, bb) = self._affine(conv_a.out_channels, bn_a, None, True), self._affine(conv_b.out_channels, bn_b, None, True)
+        _lib.check(self.lib.mp_plan_add_dual_pw_f16(self.handle, _lib.ptr(x), _lib.ptr(pa), _lib.ptr(sa), _lib.ptr(ba), int(relu_a), _lib.ptr(pb),
+                                                    _lib.ptr(sb), _lib.ptr(bb), int(relu_b), _lib.ptr(ya), _lib.ptr(zb), n, c,
+                                                    conv_a.out_channels, conv_b.out_channels, h, w), "mp_plan_add_dual_pw_f16")
+        self.layer_info.append(dict(kind="pwchain_f16", k=1, stride=1, cin=c, cout=conv_a.out_channels, h=h, w=w, n=n,
+                                    macs=n * h * w * c * (conv_a.out_channels + conv_b.out_channels)))
+        return ya, zb
+
     def fuses_stem(self, x: torch.Tensor, conv: Conv2d) -> bool:
         """fp16 plans: can the first conv read the fp32 NCHW image itself (mp_f16_stem_conv_fwd: no layout pass, the 27 real k positions
         of a 3-channel 3x3 conv in ONE k-step)?  ``MINDPOSE_FUSE_STEM=0`` keeps layout pass + general conv."""

@@ -627,8 +627,8 @@ def test_network_with_the_stage1_chain_launch_equals_the_two_launch_plan(backbon
         kinds[flag] = [e["kind"] for e in plan.layer_info] if plan is not None else None
     assert torch.equal(outs["1"], outs["0"])
     if kinds["1"] is not None:
-        assert kinds["1"].count("pwchain_f16") == 3 and kinds["0"].count("pwchain_f16") == 0
-        assert len(kinds["1"]) == len(kinds["0"]) - 3
+        assert kinds["1"].count("pwchain_f16") == 4 and kinds["0"].count("pwchain_f16") == 0  # three chains + the first block's dual 1x1
+        assert len(kinds["1"]) == len(kinds["0"]) - 4
 
 
 @pytest.mark.parametrize("shape", [(3, 256, 192), (2, 384, 288), (2, 64, 64), (5, 8, 32), (1, 6, 96)])
@@ -692,3 +692,24 @@ def test_network_with_the_fused_stem_agrees_with_the_layout_pass_plan(monkeypatc
     # rare one-ulp flips in the first layer travel through ~100 fp16 layers of a randomly initialised net: two fp16 evaluations of one
     # graph, a fraction of either one's distance to the fp32 oracle (test_network_o2_vs_amp_oracle: up to 2e-2)
     assert _nerr(outs["1"], outs["0"]) < 1e-2
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 48), (2, 96, 72), (5, 8, 8)])
+def test_dual_pointwise_launch_equals_two_convs(shape):
+    """mp_f16_dual_pw_fwd (down-sample conv 64 -> 256 without ReLU + reduce conv 64 -> 64 with ReLU of stage 1's first Bottleneck,
+    hrnet.py:74-81, 107-123, on ONE staged input tile) against two mp_f16_conv2d_fwd launches: both outputs bit-identical."""
+    n, h, w = shape
+    g = torch.Generator().manual_seed(n * h * w)
+    x = _to_c8(torch.randn(n, 64, h, w, generator=g))
+    wa = torch.randn(256, 64, 1, 1, generator=g) * (2.0 / 64) ** 0.5
+    wb = torch.randn(64, 64, 1, 1, generator=g) * (2.0 / 64) ** 0.5
+    sa, ba = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.1
+    sb, bb = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    ya_ref, pka, sca, sha = _pw_conv(x, wa, sa, ba, None, 0, n, 64, 256, h, w)
+    zb_ref, pkb, scb, shb = _pw_conv(x, wb, sb, bb, None, 1, n, 64, 64, h, w)
+    ya, zb = ActC8(n, 256, h, w, DEV), ActC8(n, 64, h, w, DEV)
+    ya.c8_tensor.fill_(7.0); zb.c8_tensor.fill_(7.0)
+    _lib.check(LIB.mp_f16_dual_pw_fwd(_lib.ptr(x), _lib.ptr(pka), _lib.ptr(sca), _lib.ptr(sha), 0, _lib.ptr(pkb), _lib.ptr(scb), _lib.ptr(shb), 1,
+                                      _lib.ptr(ya), _lib.ptr(zb), n, 64, 256, 64, h, w, _lib.stream()), "mp_f16_dual_pw_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(ya.c8_tensor, ya_ref.c8_tensor) and torch.equal(zb.c8_tensor, zb_ref.c8_tensor)
