@@ -75,6 +75,8 @@ def kernel_name(info):
         qrow = not group and tr * tw == 48 and tw % 4 == 0 and info["h"] % (2 * tr) == 0
         teams = max(1, info.get("cout_tile", 32) // 32)  # two four-wave teams: a 64-channel cout tile per workgroup
         return f"conv_wino_f32_kernel<{info.get('light', 0)},{'true' if qrow else 'false'},{'true' if group else 'false'},{teams}>"
+    if info["kind_id"] == 12:  # fp32 first conv as a streaming kernel (stem_f32.hip)
+        return "stem_conv_f32_kernel"
     if info["kind_id"] == 11:  # first conv straight from the fp32 image (stem_f16.hip)
         return "stem_conv_f16_kernel"
     if info["kind_id"] == 10:  # expand conv of a Bottleneck + reduce conv of the next one in one launch (pwchain_f16.hip)
@@ -155,7 +157,7 @@ def roofline_report(plan, reps=5, layers_csv="", workload=""):
             f.write("index,kind,kernel,us,tflops,n,cin,cout,k,stride,h,w,workgroups,lds_bytes,cin_chunk,images_per_tile,rows_per_tile\n")
             for i, t in enumerate(per_entry):
                 e = plan.entry_info(i)
-                name = kernel_name(e) if e["kind_id"] in (0, 3, 8, 9, 10, 11) else e["kind"]
+                name = kernel_name(e) if e["kind_id"] in (0, 3, 8, 9, 10, 11, 12) else e["kind"]
                 tf = 2.0 * e.get("macs", 0) / t / 1e12 if t > 0 else 0.0
                 f.write(f"{i},{e['kind']},\"{name}\",{t * 1e6:.2f},{tf:.2f},{e.get('n', '')},{e.get('cin', e.get('c', ''))},"
                         f"{e.get('cout', '')},{e.get('k', '')},{e.get('stride', '')},{e.get('h', '')},{e.get('w', '')},"
@@ -168,7 +170,7 @@ def roofline_report(plan, reps=5, layers_csv="", workload=""):
     groups = {}
     for i, t in enumerate(per_entry):
         info = plan.entry_info(i)
-        if info["kind_id"] not in (0, 3, 8, 9, 10, 11):
+        if info["kind_id"] not in (0, 3, 8, 9, 10, 11, 12):
             continue
         g = groups.setdefault(kernel_name(info), dict(time=0.0, flops=0.0, exec_flops=0.0, launches=0, wino=info["kind_id"] == 9))
         g["time"] += t

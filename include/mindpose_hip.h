@@ -390,6 +390,14 @@ int mp_f16_basicblock_supported(int n, int c, int h, int w);
 int mp_f16_basicblock_fwd(const void* x_c8_dev, const void* packed_w1_dev, const float* scale1_dev, const float* shift1_dev,
                           const void* packed_w2_dev, const float* scale2_dev, const float* shift2_dev, void* out_c8_dev, int n,
                           int c, int h, int w, int rows, mp_stream_t stream);
+/* First convolution of the network in fp32 (hrnet.py:377-385: 3x3, stride 2, padding 1, 3 -> 64 channels, folded BatchNorm, ReLU) as a
+ * streaming kernel: out[n][64][h/2][w/2] = act(conv(x; weight) * scale + shift), x fp32 NCHW [n][3][h][w], weight = the [64][3][3][3]
+ * tensor itself (no packing).  Same arithmetic as mp_conv2d_fwd on this layer with the 27 products summed in (tap, channel) order.
+ * h even, w a multiple of 32: MP_ERR_UNSUPPORTED otherwise. */
+int mp_stem_conv_fwd(const float* x_dev, const float* weight_dev, const float* scale_dev, const float* shift_dev, int relu, float* out_dev,
+                     int n, int h, int w, mp_stream_t stream);
+int mp_plan_add_stem_conv(mp_plan* plan, const float* x_dev, const float* weight_dev, const float* scale_dev, const float* shift_dev,
+                          int relu, float* out_dev, int n, int h, int w);
 /* First convolution of the network under amp O2, straight from the fp32 NCHW image (hrnet.py:377-385: 3x3, stride 2, padding 1,
  * 3 -> 64 channels, folded BatchNorm, ReLU): out = act(conv(fp16(x); fp16(weight)) * scale + shift), channel-blocked fp16
  * [n][8][h/2][w/2][8].  weight = the fp32 tensor [64][3][3][3] itself (no packing).  Replaces mp_f16_to_c8 + mp_f16_conv2d_fwd: same

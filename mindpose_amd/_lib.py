@@ -152,6 +152,8 @@ _PROTOTYPES = {
                                   ctypes.c_float, ctypes.c_float, ctypes.POINTER(ctypes.c_float * 5), ctypes.c_void_p]),
     "mp_f16_basicblock_fwd": (c_int, [c_f32p] * 8 + [c_int] * 5 + [ctypes.c_void_p]),
     "mp_f16_basicblock_supported": (c_int, [c_int] * 4),
+    "mp_stem_conv_fwd": (c_int, [c_f32p] * 4 + [c_int, c_f32p] + [c_int] * 3 + [ctypes.c_void_p]),
+    "mp_plan_add_stem_conv": (c_int, [ctypes.c_void_p] + [c_f32p] * 4 + [c_int, c_f32p] + [c_int] * 3),
     "mp_f16_stem_conv_fwd": (c_int, [c_f32p] * 4 + [c_int, c_f32p] + [c_int] * 3 + [ctypes.c_void_p]),
     "mp_plan_add_stem_conv_f16": (c_int, [ctypes.c_void_p] + [c_f32p] * 4 + [c_int, c_f32p] + [c_int] * 3),
     "mp_f16_dual_pw_fwd": (c_int, [c_f32p] * 4 + [c_int] + [c_f32p] * 3 + [c_int] + [c_f32p] * 2 + [c_int] * 6 + [ctypes.c_void_p]),

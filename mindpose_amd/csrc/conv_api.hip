@@ -9,6 +9,7 @@
 #include "conv_mfma.h"
 #include "conv_pw.h"
 #include "conv_wino.h"
+#include "conv_stem.h"
 #include "conv_gemm.h"
 
 namespace mp {
@@ -338,13 +339,14 @@ struct mp_plan {
     struct Entry {
         int kind;  // 0 conv, 1 maxpool, 2 fuse-sum; fp16 layout: 3 conv, 4 fuse-sum, 5 NCHW fp32 -> c8, 6 c8 -> NCHW fp32;
                    // 7 = all-lane barrier (no launch), 8 = fused fp16 BasicBlock, 9 = fp32 Winograd conv,
-                   // 10 = fp16 expand + reduce 1x1 chain (stage 1), 11 = fp16 first conv from the fp32 image
+                   // 10 = fp16 expand + reduce 1x1 chain (stage 1), 11 = fp16 first conv from the fp32 image, 12 = fp32 first conv (streaming form)
         int lane;  // execution lane: 0 = the caller's stream, 1..3 = the plan's own side streams
         ConvLaunch conv;
         ConvF16Launch conv16;
         BlockF16Launch block16;
         PwChainLaunch pwchain;
         StemF16Launch stem16;
+        StemF32Launch stem32;
         WinoLaunch wino;
         const void* t16[3];
         const void* x16;
@@ -390,6 +392,7 @@ static int run_entry(const mp_plan::Entry& e, mp_stream_t stream) {
         case 9: return wino_launch(e.wino, as_stream(stream));
         case 10: return pwchain_launch(e.pwchain, as_stream(stream));
         case 11: return stemf16_launch(e.stem16, as_stream(stream));
+        case 12: return stemf32_launch(e.stem32, as_stream(stream));
         default: return MP_ERR_UNSUPPORTED;
     }
 }
@@ -663,6 +666,19 @@ int mp_plan_add_dual_pw_f16(mp_plan* plan, const void* x, const void* packed_wa,
     return MP_OK;
 }
 
+int mp_plan_add_stem_conv(mp_plan* plan, const float* x, const float* weight, const float* scale, const float* shift, int relu, float* out,
+                          int n, int h, int w) {
+    if (!plan) return MP_ERR_NULL;
+    mp_plan::Entry e{};
+    e.kind = 12;
+    int rc = stemf32_build(x, weight, scale, shift, relu, out, n, h, w, e.stem32);
+    if (rc != MP_OK) return rc;
+    e.n = n; e.c = 64; e.h = h; e.w = w;
+    e.lane = plan->cur_lane;
+    plan->entries.push_back(e);
+    return MP_OK;
+}
+
 int mp_plan_add_stem_conv_f16(mp_plan* plan, const float* x, const float* weight, const float* scale, const float* shift, int relu,
                               void* out, int n, int h, int w) {
     if (!plan) return MP_ERR_NULL;
@@ -745,6 +761,9 @@ int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]) {
         info[1] = 3; info[2] = 1; info[3] = 9 /* the tuner's index of the Winograd form */; info[4] = e.wino.p.total_blocks;
         info[5] = (int64_t)e.wino.lds_bytes; info[6] = 32 * e.wino.teams; info[7] = e.wino.p.M * 4; info[8] = 8; info[9] = 1; info[10] = e.wino.p.R;
         info[11] = e.wino.ni;
+    } else if (e.kind == 12) {
+        info[1] = 3; info[2] = 2; info[3] = 0; info[4] = e.stem32.p.total_blocks;
+        info[5] = (int64_t)e.stem32.lds_bytes; info[6] = 64; info[7] = 8 * e.stem32.p.Wo; info[8] = 3; info[9] = 1; info[10] = 8;
     } else if (e.kind == 11) {
         info[1] = 3; info[2] = 2; info[3] = 0; info[4] = e.stem16.p.total_blocks;
         info[5] = (int64_t)e.stem16.lds_bytes; info[6] = 64; info[7] = 8 * e.stem16.p.Wo; info[8] = 3; info[9] = 1; info[10] = 8;

@@ -403,7 +403,7 @@ class HRNet(Backbone):
 
     def emit(self, plan: Plan, x: torch.Tensor) -> torch.Tensor:
         """Recorded form of ``forward_feature`` hrnet.py:559-605."""
-        if plan.fuses_stem(x, self.conv1):  # fp16 plans: the first conv reads the fp32 image itself (no layout pass)
+        if plan.fuses_stem(x, self.conv1):  # the dedicated first-conv kernels (fp16 plans: reads the fp32 image itself, no layout pass)
             x = plan.stem(x, self.conv1, self.bn1)
         else:
             x = plan.enter(x)

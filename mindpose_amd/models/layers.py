@@ -629,22 +629,32 @@ class Plan:
         return ya, zb
 
     def fuses_stem(self, x: torch.Tensor, conv: Conv2d) -> bool:
-        """fp16 plans: can the first conv read the fp32 NCHW image itself (mp_f16_stem_conv_fwd: no layout pass, the 27 real k positions
-        of a 3-channel 3x3 conv in ONE k-step)?  ``MINDPOSE_FUSE_STEM=0`` keeps layout pass + general conv."""
-        if not self.half or isinstance(x, ActC8) or os.environ.get("MINDPOSE_FUSE_STEM", "1") == "0":
+        """Can the first conv run as the dedicated streaming kernel with (tap, channel) as its k axis?  fp16 plans: mp_f16_stem_conv_fwd
+        reads the fp32 NCHW image itself (no layout pass, the 27 real k positions of a 3-channel 3x3 conv in ONE k-step); fp32 plans:
+        mp_stem_conv_fwd (seven k-steps of 4).  ``MINDPOSE_FUSE_STEM=0`` keeps (layout pass +) the general conv."""
+        if isinstance(x, ActC8) or os.environ.get("MINDPOSE_FUSE_STEM", "1") == "0":
             return False
         n, c, h, w = x.shape
+        lds = (6 if self.half else 12) * (w + 4) * 17 + 16  # the 17 staged rows of the three planes (fp16 / fp32)
         return (c == 3 and conv.in_channels == 3 and conv.out_channels == 64 and conv.kernel_size == 3 and conv.stride == 2
                 and conv.padding == 1 and conv.bias is None and h % 2 == 0 and w % 32 == 0 and x.dtype == torch.float32
-                and 6 * (w + 4) * 17 + 16 <= 64 * 1024 and n * 8 * (h // 2) * (w // 2) * 16 < 0x7FFFFFF0)
+                and lds <= 64 * 1024 and n * 8 * (h // 2) * (w // 2) * 16 < 0x7FFFFFF0)
 
-    def stem(self, x: torch.Tensor, conv: Conv2d, bn: BatchNorm2d) -> "ActC8":
-        """relu(bn(conv x)) from the fp32 image to the channel-blocked fp16 activation in one launch (hrnet.py:377-385)."""
+    def stem(self, x: torch.Tensor, conv: Conv2d, bn: BatchNorm2d):
+        """relu(bn(conv x)) of the network's first conv (hrnet.py:377-385) in one launch of the dedicated kernel: fp16 plans - from the
+        fp32 image to the channel-blocked fp16 activation; fp32 plans - NCHW to NCHW."""
         n, _, h, w = x.shape
-        out = self.alloc(n, 64, h // 2, w // 2)
         wt = conv.weight.detach().to(self.device, torch.float32).contiguous()
-        scale, shift = self._affine(64, bn, None, True)
         self.keep.append(wt)
+        if not self.half:  # fp32 plans: the same (tap, channel) k axis on the fp32 matrix cores, NCHW in and out (mp_stem_conv_fwd)
+            out = self.alloc_f32(n, 64, h // 2, w // 2)
+            scale, shift = self._affine(64, bn, None, False)
+            _lib.check(self.lib.mp_plan_add_stem_conv(self.handle, _lib.ptr(x), _lib.ptr(wt), _lib.ptr(scale), _lib.ptr(shift), 1, _lib.ptr(out),
+                                                      n, h, w), "mp_plan_add_stem_conv")
+            self.layer_info.append(dict(kind="stem_f32", k=3, stride=2, cin=3, cout=64, h=h, w=w, n=n, macs=n * (h // 2) * (w // 2) * 64 * 27))
+            return out
+        out = self.alloc(n, 64, h // 2, w // 2)
+        scale, shift = self._affine(64, bn, None, True)
         _lib.check(self.lib.mp_plan_add_stem_conv_f16(self.handle, _lib.ptr(x), _lib.ptr(wt), _lib.ptr(scale), _lib.ptr(shift), 1, _lib.ptr(out),
                                                       n, h, w), "mp_plan_add_stem_conv_f16")
         self.layer_info.append(dict(kind="stem_f16", k=3, stride=2, cin=3, cout=64, h=h, w=w, n=n, macs=n * (h // 2) * (w // 2) * 64 * 27))

@@ -639,3 +639,42 @@ def test_deconv_all_phases_in_one_gemm_launch(case, ni, monkeypatch):
     assert torch.equal(out1, out4)
     # only the phase (0, 0) descriptor of the k=4 / s=2 / p=1 recipe is taken
     assert lib.mp_deconv4x4s2_gemm_supported(ctypes.byref(descs[1])) == -3
+
+
+@pytest.mark.parametrize("shape", [(3, 256, 192), (2, 384, 288), (2, 64, 64), (5, 8, 32), (1, 6, 96)])
+@pytest.mark.parametrize("relu", [1, 0])
+def test_stem_conv_streaming_kernel_fp32(shape, relu):
+    """mp_stem_conv_fwd (the network's first conv, hrnet.py:377-385, with (tap, channel) as the k axis of the fp32 matrix cores)
+    against an fp64 convolution: 1e-5 of the output scale, like the direct kernel - odd tile counts, maps smaller than a workgroup's
+    8 rows, W48's 384x288 input."""
+    import ctypes
+    from mindpose_amd import _lib
+    lib = _lib.load()
+    n, h, w = shape
+    g = torch.Generator().manual_seed(n * h + w + relu)
+    x = torch.randn(n, 3, h, w, generator=g)
+    wt = torch.randn(64, 3, 3, 3, generator=g) * (2.0 / 27) ** 0.5
+    scale, shift = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    out = torch.full((n, 64, h // 2, w // 2), 7.0, device=DEV)
+    xd, wd, sd, bd = x.to(DEV), wt.to(DEV).contiguous(), scale.to(DEV), shift.to(DEV)
+    _lib.check(lib.mp_stem_conv_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(sd), _lib.ptr(bd), relu, _lib.ptr(out), n, h, w, _lib.stream()), "stem")
+    ref = F.conv2d(x.double(), wt.double(), stride=2, padding=1) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    if relu:
+        ref = ref.clamp_min(0)
+    assert _nerr(out.cpu().double(), ref) < 1e-5
+    assert lib.mp_stem_conv_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(sd), _lib.ptr(bd), relu, _lib.ptr(out), n, h + 1, w, _lib.stream()) == -3
+    assert lib.mp_stem_conv_fwd(None, _lib.ptr(wd), _lib.ptr(sd), _lib.ptr(bd), relu, _lib.ptr(out), n, h, w, _lib.stream()) == -1
+
+
+def test_fp32_plan_takes_the_streaming_stem(monkeypatch):
+    """The fp32 HRNet plan uses the dedicated first-conv kernel (MINDPOSE_FUSE_STEM, default) and agrees with the plan that runs the
+    general direct kernel there to fp32 summation order."""
+    x = torch.randn(3, 3, 256, 192, generator=torch.Generator().manual_seed(4)).to(DEV)
+    outs, kinds = {}, {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MINDPOSE_FUSE_STEM", flag)
+        net = _net("hrnet_w32", "hrnet_head")
+        outs[flag] = net(x).clone()
+        kinds[flag] = [e["kind"] for e in next(iter(net._plans.values())).layer_info]
+    assert kinds["1"].count("stem_f32") == 1 and kinds["0"].count("stem_f32") == 0 and len(kinds["1"]) == len(kinds["0"])
+    assert _nerr(outs["1"], outs["0"]) < 2e-5
