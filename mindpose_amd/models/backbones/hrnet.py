@@ -122,6 +122,14 @@ def set_branch_streams(on: bool) -> bool:
     of the deep branches with the large ones).  Returns the previous setting.  ``MINDPOSE_TRAIN_BRANCH_STREAMS=0/1`` overrides."""
     prev = _BRANCH_STREAMS_ON[0]
     _BRANCH_STREAMS_ON[0] = bool(on)
+    if on:
+        # Parameters whose gradient goes back through autograd (not written into the arena by the launches themselves) then meet an
+        # AccumulateGrad node created on the caller's stream while the node that produced the gradient ran on a branch stream.  That
+        # mismatch is this design - the branch streams are joined explicitly, graph == eager and segmented == one-graph are tested
+        # bit for bit - so torch's once-per-process warning about it is switched off where torch offers the switch
+        quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if quiet is not None:
+            quiet(False)
     return prev
 
 
