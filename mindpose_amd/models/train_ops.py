@@ -1210,7 +1210,8 @@ def _chain16_fwd_steps(lib, x, meta, residual, res_ext, params):
             if nw.shape[2] == 3 and ns == 1 and npad == 1:
                 dn = _desc(n, cout, ho, wo, nw.shape[0], 3, 1, 1, 1, ho, wo, ho, wo)
                 only = os.environ.get("MINDPOSE_BN_PRE_CH")  # kernel work: the operand route for these channel counts only
-                if _pre_capable(lib, dn) and (not only or str(cout) in only.split(",")):
+                min_hw = int(os.environ.get("MINDPOSE_BN_PRE_MINHW", "0"))  # ... and maps of at least this many pixels
+                if _pre_capable(lib, dn) and (not only or str(cout) in only.split(",")) and ho * wo >= min_hw:
                     pre = dict(scale=torch.empty((cout + 7) // 8 * 8, device=z.device), shift=torch.empty((cout + 7) // 8 * 8, device=z.device),
                                y=y, relu=int(relu), z=z)
                     job["pre"] = pre
