@@ -523,6 +523,11 @@ int mp_f16_conv_stats_parts(const mp_conv_desc* desc, int variant);
 /* 1 when mp_f16_conv2d_fwd_stats(desc, variant, ...) accepts stats->pre_scale_dev (BatchNorm apply of the layer below on the input
  * operand): an explicit variant of the weights-in-registers family on a 3x3 stride-1 layer staged one image per tile. */
 int mp_f16_conv_pre_supported(const mp_conv_desc* desc, int variant);
+/* 1 when mp_f16_conv2d_fwd (stats_mode 0; n_res = 0 / 1 / 2 residual tensors) or mp_f16_conv2d_fwd_stats (stats_mode 1 / 2; n_res
+ * 0 / 1) would ACCEPT this (shape, tile variant) - the entry's own checks and the kernel family's own dispatch run without the
+ * launch; host-only, no device work.  0 = the entry would answer MP_ERR_UNSUPPORTED (or a shape error).  The test matrix is
+ * generated from this query, so a pair that stops being served shows up as a failing floor test instead of a skip. */
+int mp_f16_conv_supported(const mp_conv_desc* desc, int variant, int n_res, int stats_mode);
 int mp_f16_conv2d_fwd_stats(const mp_conv_desc* desc, int variant, const void* x_c8_dev, const void* packed_w_dev,
                             const float* scale_dev, const float* shift_dev, const void* res1_c8_dev, void* out_c8_dev,
                             const mp_f16_conv_stats* stats, mp_stream_t stream);

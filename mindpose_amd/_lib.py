@@ -139,6 +139,7 @@ _PROTOTYPES = {
     "mp_f16_bn_train_fwd_stats": (c_int, [c_f32p] * 9 + [c_int] * 3 + [ctypes.c_float, ctypes.c_float, c_int, c_f32p, c_int, c_f32p,
                                           c_size_t, ctypes.c_void_p]),
     "mp_f16_conv_pre_supported": (c_int, [ctypes.POINTER(ConvDesc), c_int]),
+    "mp_f16_conv_supported": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_int, c_int]),
     "mp_f16_bn_train_finalize": (c_int, [c_f32p] * 6 + [c_int] * 3 + [ctypes.c_float, ctypes.c_float, c_f32p, c_int, c_f32p, c_f32p, c_f32p,
                                          c_size_t, ctypes.c_void_p]),
     "mp_f16_bn_train_bwd_stats": (c_int, [c_f32p] * 10 + [c_int] * 3 + [c_f32p, c_int, c_f32p, c_size_t, ctypes.c_void_p]),

@@ -9,6 +9,8 @@
 namespace mp {
 
 extern thread_local int g_last_hip_error;
+// set around a dispatch by the "would this launch be accepted" queries: the leaf launch functions return MP_OK without launching
+extern thread_local bool g_dry_launch;
 
 inline int check_launch() {
     hipError_t e = hipGetLastError();

@@ -363,6 +363,7 @@ constexpr bool f16_has_stats(int ks) { return ks == 1 || ks == 3; }
 
 template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, bool LIGHT, bool ONE_CHUNK, int STATS>
 int launch_f16_kernel(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
+    if (g_dry_launch) return MP_OK;  // mp_f16_conv_supported: the dispatch alone
     auto kern = conv_f16_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, f16_ni(KS, LIGHT), f16_nw(KS, LIGHT), ONE_CHUNK ? 2 : f16_occ(LIGHT),
                                 ONE_CHUNK, STATS>;
     static AttrOnce attr_set_once;
@@ -957,10 +958,10 @@ int mp_f16_conv_pre_supported(const mp_conv_desc* desc, int variant) {
     return (f16_variant_wreg(L.variant) && L.ks == 3 && L.stride == 1 && L.p.upc > 0 && L.p.G == 1) ? 1 : 0;
 }
 
-int mp_f16_conv2d_fwd_stats(const mp_conv_desc* desc, int variant, const void* x, const void* packed_w, const float* scale,
-                            const float* shift, const void* res1, void* out, const mp_f16_conv_stats* st, mp_stream_t stream) {
+// everything mp_f16_conv2d_fwd_stats checks and fills in before the launch (shared with the mp_f16_conv_supported query)
+static int f16_prepare_stats(const mp_conv_desc* desc, int variant, const void* x, const void* packed_w, const float* scale, const float* shift,
+                             const void* res1, void* out, const mp_f16_conv_stats* st, ConvF16Launch& L) {
     if (!st || !st->partials_dev) return MP_ERR_NULL;
-    ConvF16Launch L{};
     int rc = f16_build_launch(desc, variant, x, packed_w, scale, shift, res1, nullptr, out, L);
     if (rc != MP_OK) return rc;
     if (!f16_stats_shape_ok(desc)) return MP_ERR_UNSUPPORTED;
@@ -989,7 +990,43 @@ int mp_f16_conv2d_fwd_stats(const mp_conv_desc* desc, int variant, const void* x
         L.p.pre_out = st->pre_out_dev;
         L.p.pre_relu = st->pre_relu != 0 ? 1 : 0;
     }
+    return MP_OK;
+}
+
+int mp_f16_conv2d_fwd_stats(const mp_conv_desc* desc, int variant, const void* x, const void* packed_w, const float* scale,
+                            const float* shift, const void* res1, void* out, const mp_f16_conv_stats* st, mp_stream_t stream) {
+    ConvF16Launch L{};
+    const int rc = f16_prepare_stats(desc, variant, x, packed_w, scale, shift, res1, out, st, L);
+    if (rc != MP_OK) return rc;
     return f16_launch(L, as_stream(stream));
+}
+
+int mp_f16_conv_supported(const mp_conv_desc* desc, int variant, int n_res, int stats_mode) {
+    if (!desc || n_res < 0 || n_res > 2 || stats_mode < 0 || stats_mode > 2 || (stats_mode != 0 && n_res > 1)) return 0;
+    // the launch exactly as the entry points build it, on placeholder pointers (nothing is dereferenced on the host), then the
+    // family's own dispatch with the leaf launch switched off: whatever the entry would answer, by construction
+    const void* dummy = reinterpret_cast<const void*>(static_cast<uintptr_t>(16));
+    const float* fdummy = reinterpret_cast<const float*>(dummy);
+    ConvF16Launch L{};
+    int rc;
+    if (stats_mode == 0) {
+        rc = f16_build_launch(desc, variant, dummy, dummy, fdummy, fdummy, n_res >= 1 ? dummy : nullptr, n_res >= 2 ? dummy : nullptr,
+                              const_cast<void*>(dummy), L);
+    } else {
+        mp_f16_conv_stats st{};
+        st.mode = stats_mode;
+        st.relu = 1;
+        st.partials_dev = reinterpret_cast<float*>(const_cast<void*>(dummy));
+        st.partials_bytes = ~(size_t)0;
+        st.z_dev = dummy;
+        st.y_dev = dummy;
+        rc = f16_prepare_stats(desc, variant, dummy, dummy, fdummy, fdummy, n_res >= 1 ? dummy : nullptr, const_cast<void*>(dummy), &st, L);
+    }
+    if (rc != MP_OK) return 0;
+    g_dry_launch = true;
+    rc = f16_launch(L, nullptr);
+    g_dry_launch = false;
+    return rc == MP_OK ? 1 : 0;
 }
 
 int mp_f16_fuse_upsample_sum(const void* base, const void* t1, int s1, const void* t2, int s2, const void* t3, int s3, void* out,

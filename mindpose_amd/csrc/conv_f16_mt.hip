@@ -325,6 +325,7 @@ constexpr int mt_ni(int occ) { return occ == 1 ? 12 : 8; }
 
 template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, int OCC, int STATS>
 int launch_mt_kernel(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
+    if (g_dry_launch) return MP_OK;  // mp_f16_conv_supported: the dispatch alone
     auto kern = conv_f16_mt_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, mt_ni(OCC), OCC, STATS>;
     static AttrOnce attr_set_once;
     if (attr_set_once.need()) {

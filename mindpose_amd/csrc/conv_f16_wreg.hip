@@ -387,6 +387,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_wreg_kernel(const ConvF16Pa
 
 template <int KS, int S, int PS, int CSW, int WAVES_P, int OCC, int STATS, bool PRE = false>
 int launch_wreg_kernel(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
+    if (g_dry_launch) return MP_OK;  // mp_f16_conv_supported: the dispatch alone
     auto kern = conv_f16_wreg_kernel<KS, S, PS, CSW, WAVES_P, OCC, STATS, PRE>;
     static AttrOnce attr_set_once;
     if (attr_set_once.need()) {

@@ -90,9 +90,10 @@ __device__ __forceinline__ f32x4 acc_read(const f32x4& acc) {
 __device__ __forceinline__ void load_a(u32x4& dst, unsigned voff, const u32x4& rsrc) {
     asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=a"(dst) : "v"(voff), "s"(rsrc) : "memory");
 }
-__device__ __forceinline__ void load_v(u32x4& dst, unsigned voff, const u32x4& rsrc) {
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(rsrc) : "memory");
-}
+// (fragments kept in VGPRs are loaded by the COMPILER-TRACKED builtin at their use site: a register the allocator decides to spill or
+// copy is then waited for first.  An asm load into a VGPR is invisible to the waitcnt pass - round 4's statistics builds stored such
+// registers to scratch before the data had arrived.  The asm AGPR loads stay: the AGPR budget is handed out by hand (kWsAgprRegs), the
+// allocator never moves those tuples, and the build fails if any instantiation gets scratch memory - csrc/Makefile.)
 
 template <int NQ, int CSW, int WAVES_P, int PS, int OCC, int STATS, bool RES>
 __global__ __launch_bounds__(256, OCC) void conv_f16_ws_kernel(const ConvF16Params p
@@ -189,8 +190,14 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_ws_kernel(const ConvF16Para
         for (int f = 0; f < NF; ++f) {
             const unsigned off = goff[f % CSW] + (unsigned)(f / CSW) * tap_bytes;
             if (f < NFA) load_a(Aa[f], off, rs_w);
-            else load_v(Av[f - NFA], off, rs_w);
         }
+        // the VGPR fragments: AFTER every asm load, so that a compiler-placed vmcnt(k) - which counts only the loads the compiler
+        // knows, all of them younger than the asm loads - never under-waits
+        asm volatile("" ::: "memory");
+        const __amdgpu_buffer_rsrc_t rs_wv = make_rsrc(p.wp, w_bytes);
+#pragma unroll
+        for (int f = NFA; f < NF; ++f)
+            Av[f - NFA] = __builtin_amdgcn_raw_buffer_load_b128(rs_wv, goff[f % CSW] + (unsigned)(f / CSW) * tap_bytes, 0, 0);
     }
     // the zero planes behind the last channel block (Cin not a multiple of 32) are never staged: cleared once, in both buffers
     {
@@ -522,8 +529,24 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_ws_kernel(const ConvF16Para
                                                wp_i, wc_i, lq, lr);
 }
 
+// Builds that do not fit the register file (hipcc gives them scratch memory: 24 - 328 B per lane, measured with
+// -Rpass-analysis=kernel-resource-usage) are NOT instantiated: the launch answers "unsupported" and the tuner takes another variant
+// of the shape.  A spill is slow here (one wave per SIMD hides nothing) and it is the one place where a compiler-made register copy
+// could meet a fragment that an asm load has not delivered yet.  csrc/Makefile fails the build if any instantiated
+// conv_f16_ws_kernel reports ScratchSize != 0, so this list cannot go stale silently.
+template <int NQ, int CSW, int WAVES_P, int PS, int OCC, int STATS, bool RES>
+constexpr bool ws_build_fits() {
+    if (NQ == 2 && CSW == 3 && PS == 5) return STATS != 2;                      // 48 ch: 54 fragments + 15 accumulators
+    if ((NQ == 2 && CSW == 4) || (NQ == 3 && CSW == 3)) return STATS == 0 || (STATS == 1 && !RES);  // 72 / 81 fragments
+    if (NQ == 4 && CSW == 2 && WAVES_P == 1) return STATS != 2 && !RES;         // 72 fragments, 6 pixel tiles
+    return true;
+}
+
 template <int NQ, int CSW, int WAVES_P, int PS, int OCC, int STATS, bool RES>
 int launch_ws_kernel(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
+    if constexpr (!ws_build_fits<NQ, CSW, WAVES_P, PS, OCC, STATS, RES>()) return MP_ERR_UNSUPPORTED;
+    else {
+    if (g_dry_launch) return MP_OK;  // mp_f16_conv_supported: the dispatch alone
     auto kern = conv_f16_ws_kernel<NQ, CSW, WAVES_P, PS, OCC, STATS, RES>;
     static AttrOnce attr_set_once;
     if (attr_set_once.need()) {
@@ -537,6 +560,7 @@ int launch_ws_kernel(const ConvF16Params& p, size_t lds_bytes, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(256), lds_bytes, s, p);
 #endif
     return check_launch();
+    }
 }
 
 template <int NQ, int CSW, int WAVES_P, int PS, int OCC>

@@ -14,6 +14,7 @@
 namespace mp {
 
 thread_local int g_last_hip_error = 0;
+thread_local bool g_dry_launch = false;
 
 struct DecodeParams {
     const float* hm;          // [N,K,H,W]

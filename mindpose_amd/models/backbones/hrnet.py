@@ -459,8 +459,9 @@ class HRNet(Backbone):
             x = blk.train_forward(x)
         ys = [x]
         cuts = getattr(self, "_train_cut_sink", None)
+        cut_at = getattr(self, "_train_cut_at", None)  # boundaries to cut (0 = in front of stage 2 ... 2 = stage 4); None = all three
         for idx in (2, 3, 4):
-            if cuts is not None:
+            if cuts is not None and (cut_at is None or idx - 2 in cut_at):
                 # stage boundary of a segmented backward pass (utils/graph_step.py): the autograd graph is CUT here - the next stage
                 # continues from detached leaves (no launch: a detach is a view), the step feeds their gradients to the tensors
                 # they were cut from.  The BatchNorm hand-over link travels with the tensor.

@@ -125,10 +125,12 @@ def share_tuner_choices(group=None) -> int:
     ``group`` must call it, at the same point of its program - e.g. right after rank 0's warm-up (`tune_on_rank0_first`).  The
     tuner itself never communicates: a plan that only one rank builds (EvalCallback's rank-0 evaluation, a no-grad probe) can
     therefore never strand or cross-match a collective.  Returns the number of choices adopted (0 on rank 0 / one rank)."""
-    rank, world = _dist_rank_world()
-    if world == 1:
+    if _dist_rank_world()[1] == 1:
         return 0
     import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)  # ranks OF THE GROUP: a sub-group without global rank 0 has its own sender
+    if world <= 1:
+        return 0
     box = [{k: v for k, v in _TUNE_CACHE.items() if isinstance(k, str)} if rank == 0 else None]
     dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     if rank == 0:
@@ -142,9 +144,10 @@ def tune_on_rank0_first(build, group=None):
     then `share_tuner_choices`, then on the other ranks (every shape is a cache hit: nothing is timed twice, all ranks run rank 0's
     forms).  One rank: just ``build()``.  Rank 0 reaches the broadcast even when its ``build()`` raised (the exception is re-raised
     behind it), so a failure on rank 0 cannot leave the other ranks waiting."""
-    rank, world = _dist_rank_world()
-    if world == 1:
+    if _dist_rank_world()[1] == 1:
         return build()
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
     out, failure = None, None
     if rank == 0:
         try:
@@ -191,8 +194,8 @@ class ActC8:
 
 
 def _autotune(key, macs, n_variants, launch) -> int:
-    """Time ``launch(v)`` for every tile variant (HIP events, best of two groups of 5 launches; a non-zero return code = variant not
-    available) and cache the winner per launch shape; -1 = library heuristic when tuning is off (MINDPOSE_AUTOTUNE=0) or
+    """Time ``launch(v)`` for every tile variant (HIP events, best of two groups of 5 launches; MP_ERR_UNSUPPORTED = variant not
+    available, any other error code raises) and cache the winner per launch shape; -1 = library heuristic when tuning is off (MINDPOSE_AUTOTUNE=0) or
     pointless (tiny layers)."""
     if os.environ.get("MINDPOSE_AUTOTUNE", "1") == "0":
         return -1
@@ -204,8 +207,10 @@ def _autotune(key, macs, n_variants, launch) -> int:
     best, best_t = -1, None
     if macs >= (1 << 26):  # a miss is timed on whichever rank meets it - no communication here (share_tuner_choices)
         for v in range(n_variants):
-            if launch(v) != 0:
+            rc = launch(v)
+            if rc == -3:  # MP_ERR_UNSUPPORTED: this variant does not serve the shape
                 continue
+            _lib.check(rc, f"tuner trial launch, variant {v}, {key}")  # any other code (a HIP error) must not silently drop a candidate
             t = None
             for _ in range(2):  # best of two groups of five: one group of three mis-ranked close candidates run to run (+-1.5 %)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1113,11 +1113,19 @@ def _wgrad_backward_done() -> None:
         flush_wgrad_jobs()
 
 
-def drop_wgrad_jobs() -> None:
+def drop_wgrad_jobs(lo: int = 0, hi: int = 1 << 63) -> None:
     """Forget queued weight gradients WITHOUT launching them (a backward pass that raised leaves jobs holding that pass's
-    activations; the gradient arena's ``begin_step`` calls this so they can never be accumulated into the next step)."""
-    _WGRAD_PENDING.clear()
-    _WGRAD_CALLBACK[0] = False
+    activations; the gradient arena's ``begin_step`` calls this so they can never be accumulated into the next step).  Only jobs
+    whose destination slot lies in ``[lo, hi)`` - the caller's own arena - are dropped: a second model / optimizer in the process
+    keeps its queue."""
+    for key in list(_WGRAD_PENDING):
+        keep = [j for j in _WGRAD_PENDING[key] if not (lo <= j[3].data_ptr() < hi)]
+        if keep:
+            _WGRAD_PENDING[key] = keep
+        else:
+            del _WGRAD_PENDING[key]
+    if not _WGRAD_PENDING:
+        _WGRAD_CALLBACK[0] = False
 
 
 def flush_wgrad_jobs() -> None:

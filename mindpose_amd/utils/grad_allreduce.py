@@ -178,7 +178,8 @@ class GradientAverager:
         """Zero the arena and re-arm the buckets (call before forward/backward)."""
         if self.arena.is_cuda:
             from ..models.train_ops import drop_wgrad_jobs
-            drop_wgrad_jobs()  # leftovers of a backward pass that raised must not reach this step's arena
+            # leftovers of a backward pass that raised must not reach this step's arena (THIS arena's slots only)
+            drop_wgrad_jobs(self.arena.data_ptr(), self.arena.data_ptr() + self.arena.numel() * self.arena.element_size())
         self.arena.zero_()
         self.rearm()
 

@@ -155,14 +155,20 @@ class GraphedTrainStep:
                 with torch.cuda.graph(g, pool=pool):
                     if i == 0:
                         grads.arena.zero_()
+                        # the backbone cuts ONLY the boundaries between segments: groups merged into one segment stay one autograd
+                        # graph (a cut inside a segment would end its autograd.grad call at the inner leaves)
                         backbone._train_cut_sink = cuts_all
+                        backbone._train_cut_at = {n_groups - 1 - bounds[j + 1] for j in range(self.segments - 1)}
                         try:
                             self.static_loss = self.nwl(*self.static_in)
                         finally:
                             backbone._train_cut_sink = None
+                            backbone._train_cut_at = None
+                        assert len(cuts_all) == self.segments - 1, (len(cuts_all), self.segments)
                         seeds, seed_grads = [self.static_loss * self.scale_t], [None]
-                    # boundary in front of this segment's modules: cuts_all[k] = the inputs of stage k + 2, groups are in backward order
-                    roots, leaves = ([], []) if last else cuts_all[len(cuts_all) - bounds[i + 1]]
+                    # boundary in front of this segment's modules: cuts_all holds the cut boundaries in FORWARD order, the segments run
+                    # in backward order
+                    roots, leaves = ([], []) if last else cuts_all[len(cuts_all) - 1 - i]
                     # autograd.grad (not backward): the boundary gradients come back as the very tensors the consumers' data-gradient
                     # launches wrote (AccumulateGrad would clone them - the BatchNorm hand-over checks that identity); weight
                     # gradients are side effects of the nodes (direct arena slots), anything returned instead is added here

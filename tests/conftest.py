@@ -15,13 +15,12 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
-    """`gpu` tests are skipped (not failed) on a machine without a HIP device or without the built extension."""
+    """`gpu` tests are skipped (not failed) on a machine without a HIP device."""
     import torch
     reason = None
     if not torch.cuda.is_available():
         reason = "no HIP device (run on the GPU box: pytest -m gpu)"
-    elif not os.path.exists(os.path.join(ROOT, "mindpose_amd", "csrc", "libmindpose_hip.so")):
-        reason = "libmindpose_hip.so not built"
+    # (a GPU box WITHOUT the built library is not a reason to skip: the gpu tests then fail at `_lib.load()` - loudly, as they should)
     if reason:
         skip = pytest.mark.skip(reason=reason)
         for item in items:

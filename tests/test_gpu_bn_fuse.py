@@ -19,6 +19,7 @@ if not torch.cuda.is_available():
 
 from mindpose_amd import _lib  # noqa: E402
 from mindpose_amd.models.layers import ActC8, F16_VARIANTS  # noqa: E402
+from tests import f16_matrix as fm  # noqa: E402
 
 DEV = torch.device("cuda:0")
 LIB = _lib.load()
@@ -79,6 +80,7 @@ CASES = [
 def test_conv_epilogue_statistics_forward(case, monkeypatch):
     n, cin, cout, k, s, h, w = case
     monkeypatch.setenv("MP_F16_MT_GROUPS", "7")  # persistent kernels: several tiles per workgroup even at this size
+    monkeypatch.setenv("MP_F16_WS_GROUPS", "7")  # ... and the weight-stationary ones (variants 37 - 44 engage only with >= 2 tiles per workgroup)
     g = torch.Generator().manual_seed(sum(case))
     x = _to_c8(torch.randn(n, cin, h, w, generator=g))
     wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
@@ -89,11 +91,15 @@ def test_conv_epilogue_statistics_forward(case, monkeypatch):
     tested = 0
     for v in range(F16_VARIANTS):
         z0 = ActC8(n, cout, ho, wo, DEV)
-        if LIB.mp_f16_conv2d_fwd(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(ones), _lib.ptr(zeros), None, None,
-                                 _lib.ptr(z0), _lib.stream()) != 0:
+        if not fm.supported(d, v, 0, 0):  # the library's own answer: a variant it serves must launch (no silent drop-outs)
             continue
+        _lib.check(LIB.mp_f16_conv2d_fwd(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(ones), _lib.ptr(zeros), None, None,
+                                         _lib.ptr(z0), _lib.stream()), f"plain launch, variant {v}")
         n_parts = LIB.mp_f16_conv_stats_parts(ctypes.byref(d), v)
         assert n_parts > 0, f"variant {v} runs this shape but has no statistics build"
+        if not fm.supported(d, v, 0, 1):  # weight-stationary builds that do not fit the register file with the statistics (ws_build_fits)
+            assert v in fm.WS_VARIANTS, f"variant {v}: only weight-stationary shapes may leave out a statistics build"
+            continue
         c8 = (cout + 7) // 8
         part = torch.full((c8 * n_parts * 16,), float("nan"), device=DEV)
         st = _lib.ConvStats(mode=1, relu=0, partials=part.data_ptr(), partials_bytes=part.numel() * 4)
@@ -123,6 +129,7 @@ def test_conv_epilogue_statistics_backward(case, relu, monkeypatch):
     """Mode 2: a data-gradient-shaped launch (residual gradient in res1) masks its output with y > 0 and sums g, g * z."""
     n, cin, cout, k, s, h, w = case
     monkeypatch.setenv("MP_F16_MT_GROUPS", "5")
+    monkeypatch.setenv("MP_F16_WS_GROUPS", "5")
     g = torch.Generator().manual_seed(sum(case) + relu)
     x = _to_c8(torch.randn(n, cin, h, w, generator=g))
     packed = _pack(torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5)
@@ -136,11 +143,15 @@ def test_conv_epilogue_statistics_backward(case, relu, monkeypatch):
     tested = 0
     for v in range(F16_VARIANTS):
         o0 = ActC8(n, cout, ho, wo, DEV)
-        if LIB.mp_f16_conv2d_fwd(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(ones), _lib.ptr(zeros), _lib.ptr(res), None,
-                                 _lib.ptr(o0), _lib.stream()) != 0:
+        if not fm.supported(d, v, 1, 0):
             continue
+        _lib.check(LIB.mp_f16_conv2d_fwd(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(ones), _lib.ptr(zeros), _lib.ptr(res), None,
+                                         _lib.ptr(o0), _lib.stream()), f"plain launch, variant {v}")
         n_parts = LIB.mp_f16_conv_stats_parts(ctypes.byref(d), v)
         assert n_parts > 0
+        if not fm.supported(d, v, 1, 2):
+            assert v in fm.WS_VARIANTS, f"variant {v}: only weight-stationary shapes may leave out a statistics build"
+            continue
         c8 = (cout + 7) // 8
         part = torch.full((c8 * n_parts * 16,), float("nan"), device=DEV)
         st = _lib.ConvStats(mode=2, relu=relu, partials=part.data_ptr(), partials_bytes=part.numel() * 4, z=_lib.ptr(z),

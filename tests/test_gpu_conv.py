@@ -539,66 +539,6 @@ def test_simplebaseline_whole_network_tuned_forms_vs_library_heuristic(monkeypat
     assert torch.equal(a.reshape(n, k, -1).argmax(2)[safe], b.reshape(n, k, -1).argmax(2)[safe])
 
 
-GEMM_S2_CASES = [
-    # n, cin, cout, h, w, relu, residual tensors - the 3x3 stride-2 pad-1 convolutions of the HRNet transitions and exchange units
-    (3, 32, 64, 64, 48, True, 0),     # transition / exchange 32 -> 64 @64x48: 64-cout tile
-    (5, 64, 128, 32, 24, False, 2),   # exchange unit's last down conv: running sum + identity
-    (6, 128, 256, 16, 12, False, 1),  # 8x6 output planes: a column tile spans images
-    (2, 256, 64, 64, 48, True, 0),    # transition 256 -> 64: 144 k-loop steps
-    (3, 32, 128, 32, 24, True, 1),
-    (2, 64, 64, 15, 10, False, 1),    # odd height (conv_h = 8), 40 output pixels per plane
-    (2, 48, 96, 12, 8, True, 0),      # W48 widths, 24-pixel planes
-]
-
-
-@pytest.mark.parametrize("ni", ["0", "1", "2", "11"])
-@pytest.mark.parametrize("case", GEMM_S2_CASES, ids=[f"n{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}_r{c[6]}" for c in GEMM_S2_CASES])
-def test_gemm_kernel_3x3_stride2_vs_torch_and_direct(case, ni, monkeypatch):
-    """Forced variant 10 on a 3x3 stride-2 pad-1 convolution (hrnet.py:280-313, 440-496): the blocked-GEMM kernel's nine-tap gather
-    form - k loop over (cin chunk, tap) pairs, taps outside the image from the buffer range check - on the direct kernel's packed
-    weights, against fp64 torch at the direct kernel's own bar and against the direct kernel, with up to two residual tensors."""
-    import ctypes
-    from mindpose_amd import _lib
-    if ni != "0":
-        monkeypatch.setenv("MP_GEMM_NI", ni)  # "0": the library's own tile choice
-    n, cin, cout, h, w, relu, n_res = case
-    lib = _lib.load()
-    g = torch.Generator().manual_seed(cin + cout + h)
-    x = torch.randn(n, cin, h, w, generator=g)
-    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
-    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
-    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
-    res = [torch.randn(n, cout, ho, wo, generator=g) for _ in range(n_res)]
-    ref = F.conv2d(x.double(), wt.double(), stride=2, padding=1) * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]
-    for r in res:
-        ref = ref + r.double()
-    if relu:
-        ref = F.relu(ref)
-    d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=3, kw=3, stride=2, pad_top=1, pad_left=1, conv_h=ho, conv_w=wo, out_h=ho,
-                      out_w=wo, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=int(relu), flags=0)
-    st = _lib.stream()
-    xd, wd, sc, sh = x.to(DEV), wt.to(DEV), scale.to(DEV), shift.to(DEV)
-    rd = [r.to(DEV) for r in res] + [None, None]
-    pk = torch.empty(lib.mp_conv_packed_weight_bytes(cout, cin, 3, 3) // 4, device=DEV)
-    _lib.check(lib.mp_conv_pack_weight(_lib.ptr(wd), _lib.ptr(pk), cout, cin, 3, 3, 0, 0, 0, st), "pack")
-    out = torch.full((n, cout, ho, wo), float("nan"), device=DEV)
-    out_d = torch.empty(n, cout, ho, wo, device=DEV)
-    _lib.check(lib.mp_conv2d_fwd_variant(ctypes.byref(d), 10, _lib.ptr(xd), _lib.ptr(pk), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(rd[0]),
-                                         _lib.ptr(rd[1]), _lib.ptr(out), st), "gemm 3x3 s2")
-    _lib.check(lib.mp_conv2d_fwd(ctypes.byref(d), _lib.ptr(xd), _lib.ptr(pk), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(rd[0]), _lib.ptr(rd[1]),
-                                 _lib.ptr(out_d), st), "direct 3x3 s2")
-    torch.cuda.synchronize()
-    assert torch.isfinite(out).all()  # every element written
-    assert _nerr(out.double().cpu(), ref) <= 2e-5
-    assert _nerr(out.double().cpu(), out_d.double().cpu()) <= 2e-5
-    if n_res:  # in-place on the running sum (how the exchange unit accumulates): same bits
-        acc = rd[0].clone()
-        _lib.check(lib.mp_conv2d_fwd_variant(ctypes.byref(d), 10, _lib.ptr(xd), _lib.ptr(pk), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(acc),
-                                             _lib.ptr(rd[1]), _lib.ptr(acc), st), "gemm 3x3 s2 in place")
-        torch.cuda.synchronize()
-        assert torch.equal(acc, out)
-
-
 @pytest.mark.parametrize("ni", ["1", "2", "11"])
 @pytest.mark.parametrize("case", [(3, 64, 256, 8, 6), (2, 32, 128, 16, 12), (5, 16, 100, 4, 4)], ids=lambda c: f"n{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}")
 def test_deconv_all_phases_in_one_gemm_launch(case, ni, monkeypatch):

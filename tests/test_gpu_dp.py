@@ -168,7 +168,7 @@ def _dp_worker(rank, world, port, out_dir):
             del step
     # the segmented capture is the single backward pass cut in pieces: its gradient arena equals the one-graph step's BIT FOR BIT
     arenas = {}
-    for segs in (1, 4):
+    for segs in (1, 2, 3, 4):  # 2 / 3: groups merged into one segment stay one autograd graph (only the boundaries BETWEEN segments are cut)
         mp, net, nwl, opt = _build(dev, True, False, "torch", force=world == 1)
         x, target, weight = _batch(mp, dev, rank, n=6, hw=128)
         step = GraphedTrainStep(nwl, opt, (x, target, weight), loss_scale_manager=DynamicLossScaleManager(init_loss_scale=1024.0),
@@ -182,8 +182,9 @@ def _dp_worker(rank, world, port, out_dir):
             assert step.updated and len(step.issue_ms) == 2
         opt.close()
         del step
-    assert arenas[1][1] == arenas[4][1]
-    assert torch.equal(arenas[1][0], arenas[4][0]), "segmented backward differs from the one-graph backward"
+    for segs in (2, 3, 4):
+        assert arenas[1][1] == arenas[segs][1]
+        assert torch.equal(arenas[1][0], arenas[segs][0]), f"{segs}-segment backward differs from the one-graph backward"
     report["segmented_equals_single"] = True
     # eager step WITH the overlap hooks live (bucket all-reduces launched from backward): equals the non-overlapped result
     mp, net, nwl, opt = _build(dev, False, True, "torch", force=world == 1)

@@ -23,6 +23,8 @@ import mindpose_amd as mp  # noqa: E402
 from mindpose_amd import _lib  # noqa: E402
 from mindpose_amd.models.layers import ActC8  # noqa: E402
 from oracle import nets as onets  # noqa: E402
+from tests import f16_matrix as fm  # noqa: E402
+from tests.f16_matrix import CONV_CASES, WREG_CASES, WREG_S2_CASES, WS_CASES  # noqa: E402
 
 DEV = torch.device("cuda:0")
 LIB = _lib.load()
@@ -57,25 +59,10 @@ def test_layout_round_trip(c):
     assert torch.all(blk[:, c:] == 0)
 
 
-CONV_CASES = [
-    # n, cin, cout, k, s, h, w, relu, n_res
-    (2, 32, 32, 3, 1, 64, 48, True, 1),     # W32 branch 0
-    (3, 64, 64, 3, 1, 32, 24, True, 1),     # branch 1 (two chunks with the 64-cout tile)
-    (3, 128, 128, 3, 1, 16, 12, True, 0),
-    (5, 256, 256, 3, 1, 8, 6, True, 2),     # multi-image tiles, many chunks
-    (2, 3, 64, 3, 2, 64, 48, True, 0),      # stem conv1: 3 channels in one block, zero planes
-    (2, 64, 64, 3, 2, 32, 24, True, 0),     # stem conv2 (stride 2)
-    (2, 48, 48, 3, 1, 24, 16, True, 1),     # W48 widths: cin padded to 64, cout tile 48
-    (2, 96, 192, 3, 2, 16, 12, False, 2),   # fuse-layer down-sampling conv with both residuals
-    (2, 64, 256, 1, 1, 16, 12, True, 1),    # bottleneck 1x1
-    (2, 256, 64, 1, 1, 16, 12, True, 0),
-    (3, 32, 17, 1, 1, 64, 48, False, 0),    # head: 17 couts + bias
-    (1, 40, 24, 3, 1, 9, 7, False, 0),      # ragged everything
-]
-
-
-@pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("variant", [-1] + list(range(10)) + [20, 21, 24])
+# the library's heuristic (-1) on every case + every (case, tile variant) pair the library serves (tests/f16_matrix.py: generated from
+# mp_f16_conv_supported, so nothing is skipped and a collected pair that fails to launch FAILS)
+@pytest.mark.parametrize("case,variant", [pytest.param(c, -1, id=f"case{i}-heuristic") for i, c in enumerate(CONV_CASES)]
+                         + fm.served_pairs(CONV_CASES, fm.TILE_VARIANTS, fm.conv_case_desc, fm.conv_case_res))
 def test_conv_f16_vs_oracle(case, variant):
     n, cin, cout, k, s, h, w, relu, n_res = case
     g = torch.Generator().manual_seed(hash(case) % 1000)
@@ -108,9 +95,7 @@ def test_conv_f16_vs_oracle(case, variant):
                       flags=0)
     rc = LIB.mp_f16_conv2d_fwd(ctypes.byref(d), variant, _lib.ptr(xa), _lib.ptr(packed), _lib.ptr(sc), _lib.ptr(sh),
                                _lib.ptr(ra[0]), _lib.ptr(ra[1]), _lib.ptr(out), _lib.stream())
-    if rc != 0 and variant >= 0:
-        pytest.skip("tile variant not available for this shape")
-    _lib.check(rc, "mp_f16_conv2d_fwd")
+    _lib.check(rc, f"mp_f16_conv2d_fwd, variant {variant}")
     got = _from_c8(out)
     tol = ref.abs() * 2.0 ** -9 + 1e-4 * ref.abs().max()
     bad = (got - ref).abs() > tol
@@ -120,9 +105,8 @@ def test_conv_f16_vs_oracle(case, variant):
     assert torch.all(blk[:, cout:] == 0)
 
 
-@pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("variant", list(range(10, 20)) + [22, 23])
-@pytest.mark.parametrize("groups", ["1", "3"])
+@pytest.mark.parametrize("groups,case,variant", [pytest.param(g, *pr.values, id=f"g{g}-{pr.id}") for g in ("1", "3") for pr in
+                                                 fm.served_pairs(CONV_CASES, fm.MT_VARIANTS, fm.conv_case_desc, fm.conv_case_res, MP_F16_MT_GROUPS=g)])
 def test_conv_f16_multi_tile_vs_oracle(case, variant, groups, monkeypatch):
     # the persistent multi-tile kernel only engages when a workgroup gets >= 2 tiles; MP_F16_MT_GROUPS caps the number of
     # workgroups per cout tile so that small problems exercise long tile runs (1 group = every tile in one workgroup,
@@ -131,28 +115,7 @@ def test_conv_f16_multi_tile_vs_oracle(case, variant, groups, monkeypatch):
     test_conv_f16_vs_oracle(case, variant)
 
 
-WREG_CASES = [
-    # n, cin, cout, k, s, h, w, relu, n_res  - stride-1 "same" convs with >= 64 input channels (conv_f16_wreg.hip)
-    (3, 64, 64, 3, 1, 32, 24, True, 1),     # branch 1: row bands of 4, 8 bands per image
-    (3, 128, 128, 3, 1, 16, 12, True, 1),   # branch 2: half-image bands (P6) / quarter bands (P3)
-    (5, 256, 256, 3, 1, 8, 6, True, 1),     # branch 3: two images per tile, odd batch -> a half-empty last tile
-    (2, 192, 192, 3, 1, 16, 12, True, 0),   # W48 branch 2: three cout tiles per wave
-    (3, 96, 192, 3, 1, 12, 9, False, 1),    # ragged: 10-row bands of a 12-row map, 6 padding lanes per tile
-    (2, 72, 64, 3, 1, 10, 7, True, 0),      # input channels padded 72 -> 96: three zero planes from the range check
-    (2, 256, 64, 1, 1, 16, 12, True, 0),    # 1x1 (no halo column), 8 k-steps
-    (2, 64, 256, 1, 1, 16, 12, True, 1),    # 1x1, four cout tiles per wave
-    (130, 128, 128, 3, 1, 16, 12, True, 1), # more workgroups than CUs
-    (3, 32, 32, 3, 1, 64, 48, True, 1),     # branch 0: pixel-split waves (W4), one k-step (no refill), 8-row bands
-    (2, 48, 48, 3, 1, 24, 16, True, 1),     # W48 widths: three cout tiles, cin padded 48 -> 64
-    (2, 96, 96, 3, 1, 24, 18, True, 0),     # W48 branch 1: W2 with three cout tiles per wave
-    (3, 192, 192, 3, 1, 24, 18, True, 1),   # W48 branch 2 at config 5's map: P7C3 = 6-row bands, four per image
-    (3, 384, 384, 3, 1, 12, 9, True, 1),    # W48 branch 3 at config 5's map: P4C3 = 7-row bands (7 + 5 rows), two cout slices
-    (2, 256, 256, 3, 1, 10, 8, False, 1),   # P5C4: 256 couts per workgroup, 80-px bands
-]
-
-
-@pytest.mark.parametrize("case", WREG_CASES)
-@pytest.mark.parametrize("variant", list(range(25, 37)) + [45, 46, 47])
+@pytest.mark.parametrize("case,variant", fm.served_pairs(WREG_CASES, fm.WREG_VARIANTS, fm.conv_case_desc, fm.conv_case_res))
 def test_conv_f16_wreg_vs_oracle_and_bit_identical_to_tile_kernel(case, variant):
     """The weights-in-registers kernel (LDS-DMA input tile, weight fragments streamed from global memory) against the oracle,
     and bit for bit against the one-tile kernel: same k order, same epilogue arithmetic."""
@@ -181,8 +144,7 @@ def test_conv_f16_wreg_vs_oracle_and_bit_identical_to_tile_kernel(case, variant)
         return rc, out
 
     rc, out = run(variant)
-    if rc != 0:
-        pytest.skip("tile variant not available for this shape")
+    _lib.check(rc, f"mp_f16_conv2d_fwd, variant {variant}")
     rc0, base = run(-1)
     _lib.check(rc0, "mp_f16_conv2d_fwd")
     assert torch.equal(out.c8_tensor, base.c8_tensor), "weights-in-registers kernel differs from the tile kernel"
@@ -196,26 +158,8 @@ def test_conv_f16_wreg_vs_oracle_and_bit_identical_to_tile_kernel(case, variant)
         assert not ((got - ref).abs() > tol).any(), float((got - ref).abs().max())
 
 
-WS_CASES = [
-    # n, cin, cout, k, s, h, w, relu, n_res - 3x3 stride-1 layers of the 32 ... 128-channel branches (W32 and W48 widths), ragged
-    # bands (h not a multiple of the rows per tile), padded channel counts, long tile runs (MP_F16_WS_GROUPS)
-    (5, 32, 32, 3, 1, 64, 48, True, 1),
-    (3, 48, 48, 3, 1, 96, 72, True, 1),
-    (3, 48, 48, 3, 1, 23, 72, True, 0),
-    (6, 64, 64, 3, 1, 32, 24, True, 1),
-    (5, 64, 64, 3, 1, 21, 17, False, 1),
-    (6, 96, 96, 3, 1, 48, 36, True, 1),
-    (4, 96, 96, 3, 1, 11, 36, True, 0),
-    (9, 128, 128, 3, 1, 16, 12, True, 1),
-    (3, 40, 48, 3, 1, 30, 33, True, 1),
-    (3, 72, 96, 3, 1, 19, 20, False, 1),
-    (2, 128, 64, 3, 1, 16, 12, True, 0),
-]
-
-
-@pytest.mark.parametrize("case", WS_CASES)
-@pytest.mark.parametrize("variant", list(range(37, 45)))
-@pytest.mark.parametrize("groups", ["2", "5"])
+@pytest.mark.parametrize("groups,case,variant", [pytest.param(g, *pr.values, id=f"g{g}-{pr.id}") for g in ("2", "5") for pr in
+                                                 fm.served_pairs(WS_CASES, fm.WS_VARIANTS, fm.conv_case_desc, fm.conv_case_res, MP_F16_WS_GROUPS=g)])
 def test_conv_f16_weight_stationary_vs_oracle_and_bit_identical_to_tile_kernel(case, variant, groups, monkeypatch):
     """The persistent weight-stationary kernel (conv_f16_ws.hip: weight fragments in AGPRs / VGPRs for the whole launch, pixel tiles
     through a two-stage LDS-DMA ring) against the oracle arithmetic and bit for bit against the tile kernels; `groups` workgroups
@@ -246,8 +190,7 @@ def test_conv_f16_weight_stationary_vs_oracle_and_bit_identical_to_tile_kernel(c
         return rc, out
 
     rc, out = run(variant)
-    if rc != 0:
-        pytest.skip("shape not covered by this weight-stationary build")
+    _lib.check(rc, f"mp_f16_conv2d_fwd, variant {variant}")
     rc0, base = run(-1)
     _lib.check(rc0, "mp_f16_conv2d_fwd")
     # padding channels of the last block are zero in both; everything else bit for bit
@@ -294,7 +237,18 @@ def test_conv_f16_wreg_rejects_what_it_does_not_cover():
     assert rc(pad_top=0, pad_left=0, conv_h=14, conv_w=10, out_h=14, out_w=10) != 0  # not a "same" convolution
 
 
-@pytest.mark.parametrize("variant", [-1, 1, 3, 11, 16])
+def _deconv_phase_desc(n, cin, cout, h, w, py, px):
+    return _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=2, kw=2, stride=1, pad_top=1 - py, pad_left=1 - px, conv_h=h, conv_w=w,
+                         out_h=2 * h, out_w=2 * w, out_mul=2, out_rep=1, out_off_y=py, out_off_x=px, relu=1, flags=0)
+
+
+# one-tile 1 / 3 and persistent 11 / 16: the ones of them that serve all four phases of the shape below (tests/test_f16_matrix_cpu.py
+# holds the floor: at least one of each family)
+DECONV_VARIANTS = [-1] + [v for v in (1, 3, 11, 16) if all(fm.supported(_deconv_phase_desc(3, 64, 48, 16, 12, py, px), v, 0, 0, MP_F16_MT_GROUPS=2)
+                                                         for py in (0, 1) for px in (0, 1))]
+
+
+@pytest.mark.parametrize("variant", DECONV_VARIANTS)
 def test_deconv_phases_f16_vs_oracle(variant, monkeypatch):
     # Conv2dTranspose(k=4, s=2, p=1) + BN + ReLU as four 2x2 sub-pixel phase convs with the strided-scatter output mapping
     monkeypatch.setenv("MP_F16_MT_GROUPS", "2")
@@ -315,14 +269,10 @@ def test_deconv_phases_f16_vs_oracle(variant, monkeypatch):
         for px in (0, 1):
             packed = torch.empty(nb // 2, device=DEV, dtype=torch.float16)
             _lib.check(LIB.mp_f16_pack_weight(_lib.ptr(wt.to(DEV)), _lib.ptr(packed), cout, cin, 2, 2, 1, py, px, _lib.stream()), "pack")
-            d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=2, kw=2, stride=1, pad_top=1 - py, pad_left=1 - px, conv_h=h,
-                              conv_w=w, out_h=2 * h, out_w=2 * w, out_mul=2, out_rep=1, out_off_y=py, out_off_x=px, relu=1,
-                              flags=0)
+            d = _deconv_phase_desc(n, cin, cout, h, w, py, px)
             rc = LIB.mp_f16_conv2d_fwd(ctypes.byref(d), variant, _lib.ptr(xa), _lib.ptr(packed), _lib.ptr(sc), _lib.ptr(sh), None,
                                        None, _lib.ptr(out), _lib.stream())
-            if rc != 0 and variant >= 0:
-                pytest.skip("tile variant not available for this shape")
-            _lib.check(rc, "deconv phase")
+            _lib.check(rc, f"deconv phase ({py}, {px}), variant {variant}")
             ran = True
     assert ran
     got = _from_c8(out)
@@ -509,20 +459,7 @@ def test_fused_basicblock_rejects_other_widths():
     assert LIB.mp_f16_basicblock_fwd(None, *args, _lib.ptr(two), 1, 32, 8, 8, 0, _lib.stream()) == -1  # MP_ERR_NULL
 
 
-WREG_S2_CASES = [
-    # n, cin, cout, h, w, n_res - 3x3 stride-2 pad-1 convs of the transition / exchange-unit layers (conv_f16_wreg.hip, S = 2)
-    (3, 32, 64, 64, 48, 2),     # fuse down-sampling conv with running sum + identity
-    (3, 64, 128, 32, 24, 1),
-    (5, 128, 256, 16, 12, 0),   # two images per tile, odd batch
-    (2, 32, 32, 64, 48, 0),
-    (2, 64, 64, 30, 22, 2),     # ragged: odd output extents after the stride
-    (2, 96, 192, 24, 18, 1),    # W48 widths
-    (2, 256, 64, 17, 13, 0),    # odd input extents: the last tap column reads the shared zero slot
-]
-
-
-@pytest.mark.parametrize("case", WREG_S2_CASES)
-@pytest.mark.parametrize("variant", list(range(25, 37)))
+@pytest.mark.parametrize("case,variant", fm.served_pairs(WREG_S2_CASES, fm.WREG_S2_VARIANTS, fm.s2_case_desc, fm.s2_case_res))
 def test_conv_f16_wreg_stride2_bit_identical_to_tile_kernel(case, variant):
     n, cin, cout, h, w, n_res = case
     g = torch.Generator().manual_seed(sum(case))
@@ -548,8 +485,7 @@ def test_conv_f16_wreg_stride2_bit_identical_to_tile_kernel(case, variant):
         return rc, out
 
     rc, out = run(variant)
-    if rc != 0:
-        pytest.skip("tile variant not available for this shape")
+    _lib.check(rc, f"mp_f16_conv2d_fwd, variant {variant}")
     rc0, base = run(-1)
     _lib.check(rc0, "mp_f16_conv2d_fwd")
     assert torch.equal(out.c8_tensor, base.c8_tensor)

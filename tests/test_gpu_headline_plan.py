@@ -86,6 +86,56 @@ def test_headline_plan_n128_amp_o2_vs_amp_oracle():
     assert torch.equal(got.reshape(n, k, -1).argmax(2)[safe], rf.argmax(2)[safe])
 
 
+def test_config5_plan_2n128_amp_o2_vs_oracle():
+    """BASELINE.json configs[4] at the size bench.py times it: HRNet-W48 384x288, N = 64 crops, amp O2, the flip test as ONE forward
+    of 2N = 128 = [crops | mirrors] (PlannedModule.forward_flip_pair), UDP + DARK (k = 17) decode of the flip-averaged maps.  The
+    plan is built as bench.py builds it (tuner on: weight-stationary / weights-in-registers picks, the stage-1 chain / dual launches,
+    the fused first conv at 96x72); crops [0:2] + [62:64] AND their mirrors are compared with oracle/nets.py (fp32 and the amp-O2
+    emulation), the decoded key points of those crops with oracle/decoder.py on the same heat maps."""
+    import numpy as np
+    from oracle import decoder as od
+    from mindpose_amd.engine.inferencer.topdown_inferencer import COCO_FLIP_INDEX, _MultiRunNet
+    n, h, w = 64, 384, 288
+    sl = [0, 1, n - 2, n - 1]
+    net = mp.init_synthetic(mp.create_network("hrnet_w48", "hrnet_head"), seed=0).to(DEV).eval()
+    mp.models.auto_mixed_precision(net, "O2")
+    dec = mp.create_decoder("topdown_heatmap", use_udp=True, dark_udp_refine=True, kernel_size=17).to(DEV)
+    ev = mp.create_eval_network(net, dec, output_raw=True)
+    mr = _MultiRunNet(ev, dec, np.array(COCO_FLIP_INDEX), shift_heatmap=False).to(DEV)
+    gen = torch.Generator(device="cpu").manual_seed(1000)
+    x = torch.randn(n, 3, h, w, generator=gen)
+    image = net.input_buffer((2 * n, 3, h, w), DEV)[:n]  # as bench.py: the crops' half of the 2N plan's input
+    image.copy_(x)
+    center = torch.rand(n, 2, generator=gen) * 400
+    scale = torch.rand(n, 2, generator=gen) * 2.7 + 0.3
+    score = torch.rand(n, generator=gen)
+    preds, boxes = mr(image, center.to(DEV), scale.to(DEV), score.to(DEV))
+    plan = net.get_plan((2 * n, 3, h, w), DEV)
+    assert plan.output.shape[0] == 2 * n  # the batched flip test ran (one forward of 128)
+    both = plan.output.cpu().clone()
+    got = torch.cat([both[sl], both[[n + i for i in sl]]])  # 4 crops, then their 4 mirrors
+    xs = torch.cat([x[sl], torch.flip(x[sl], dims=[3])])
+    params = {k: v.cpu() for k, v in net.state_dict().items()}
+    ref32 = onets.net_forward(params, xs, "hrnet_w48", "hrnet_head")
+    ref16 = onets.net_forward(params, xs, "hrnet_w48", "hrnet_head", amp=True)
+    e_hip = float((got - ref32).abs().max() / ref32.abs().max())
+    e_emul = float((ref16 - ref32).abs().max() / ref32.abs().max())
+    assert e_hip <= 1.5 * e_emul + 1e-3, f"HIP fp16 {e_hip} vs op-by-op amp-O2 emulation {e_emul}"
+    assert e_hip < 2e-2
+    k = got.shape[1]
+    rf = ref32.reshape(8, k, -1)
+    top2 = rf.topk(2, dim=2).values
+    safe = (top2[..., 0] - top2[..., 1]) > 2.5 * e_hip * ref32.abs().max()
+    assert safe.float().mean() > 0.5
+    assert torch.equal(got.reshape(8, k, -1).argmax(2)[safe], rf.argmax(2)[safe])
+    # decode: the oracle's flip aggregation + UDP / DARK refinement on the HIP heat maps of the same crops
+    avg = od.flip_aggregate(both[sl].numpy(), both[[n + i for i in sl]].numpy(), COCO_FLIP_INDEX, shift_heatmap=False)
+    rp, rb, _ = od.decode(avg, center[sl].numpy(), scale[sl].numpy(), score[sl].numpy(), use_udp=True, dark_udp_refine=True, kernel_size=17)
+    assert np.array_equal(boxes.cpu().numpy()[sl], rb)
+    d = np.abs(preds.cpu().numpy()[sl][..., :2] - rp[..., :2])
+    assert np.mean(d < 1e-2) > 0.98  # DARK's Hessian solve is ill-conditioned on a few flat maps (tests/test_gpu_pose_ops.py)
+
+
 _CHILD = r"""
 import hashlib, json, sys, torch
 sys.path.insert(0, {root!r})

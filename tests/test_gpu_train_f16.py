@@ -14,6 +14,7 @@ if not torch.cuda.is_available():
 
 from mindpose_amd import _lib  # noqa: E402
 from mindpose_amd.models.layers import ActC8  # noqa: E402
+from tests import f16_matrix as fm  # noqa: E402
 
 DEV = torch.device("cuda:0")
 LIB = _lib.load()
@@ -136,11 +137,11 @@ def test_dgrad_f16_vs_torch(case):
     _close16(_from_c8(dx), ref, "dx")
 
 
-@pytest.mark.parametrize("case", [(2, 32, 64, 32, 24), (3, 64, 128, 16, 12), (2, 48, 96, 24, 16), (5, 32, 32, 64, 48)])
-@pytest.mark.parametrize("variant", [-1, 0, 4, 10, 13, 17])
+@pytest.mark.parametrize("case,variant", [pytest.param(c, -1, id=f"case{i}-heuristic") for i, c in enumerate(fm.PHASES4_CASES)]
+                         + fm.served_pairs(fm.PHASES4_CASES, fm.PHASES4_VARIANTS, fm.phases4_case_desc))
 def test_stride2_dgrad_four_phases_in_one_launch_equal_four_launches(case, variant):
     """MP_CONV_PHASES4: phase = second grid dimension, weight slice and output offset from it - bit-identical to the four launches
-    (one-tile and persistent multi-tile variants; a variant that does not serve the shape is skipped)."""
+    (one-tile and persistent multi-tile variants; only the pairs the library serves are collected - tests/f16_matrix.py)."""
     n, cin, cout, h, w = case
     g = torch.Generator().manual_seed(sum(case) + 7)
     ho, wo = h // 2, w // 2
@@ -159,9 +160,7 @@ def test_stride2_dgrad_four_phases_in_one_launch_equal_four_launches(case, varia
     d.flags = _lib.MP_CONV_PHASES4
     rc = LIB.mp_f16_conv2d_fwd(ctypes.byref(d), variant, _lib.ptr(dza), _lib.ptr(packed), _lib.ptr(ones), _lib.ptr(zeros), None, None,
                                _lib.ptr(one), _lib.stream())
-    if rc != 0 and variant >= 0:
-        pytest.skip(f"variant {variant} does not serve this shape (rc {rc})")
-    _lib.check(rc, "phases4")
+    _lib.check(rc, f"phases4, variant {variant}")
     for py in (0, 1):
         for px in (0, 1):
             dd = _desc(n, cout, ho, wo, cin, 2, 1, 0, ho, wo, oh=h, ow=w, mul=2, oy=py, ox=px)

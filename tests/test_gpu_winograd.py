@@ -42,15 +42,14 @@ def _desc(n, cin, cout, h, w, relu):
                          out_w=w, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=int(relu), flags=0)
 
 
-@pytest.mark.parametrize("teams", [0, 2])
-@pytest.mark.parametrize("case", CASES, ids=[f"n{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}" for c in CASES])
+# (image-grouped bands - map widths that are not a multiple of 4 - have one team: those pairs are not collected)
+@pytest.mark.parametrize("case,teams", [pytest.param(c, t, id=f"n{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}-teams{t}") for c in CASES for t in (0, 2)
+                                        if not (t and c[4] % 4)])
 def test_winograd_conv_vs_fp64_and_direct(case, teams, monkeypatch):
     """teams = 2 forces the two-team workgroup (64 output channels on one shared input transform; by itself only taken when the
     launch still covers every CU) on every shape incl. cout tiles whose second team is partly or wholly past Cout."""
     n, cin, cout, h, w, relu, has_r1, has_r2 = case
     if teams:
-        if w % 4:
-            pytest.skip("image-grouped bands have one team")
         monkeypatch.setenv("MP_WINO_TEAMS", str(teams))
     lib = _lib.load()
     g = torch.Generator().manual_seed(cin * 131 + cout * 7 + h)
