@@ -368,58 +368,82 @@ def cpu_baseline(state_dict, mp, dev):
                                   "gpu_what": "mp_gaussian_target, 128 x 17 x 64x48 fp32 heat-maps written once (HBM-bound, 8 TB/s peak)"}}
 
 
-def hbm_ops_report(mp, dev, n=128):
-    """The HBM-bound rows of the path at N = 128, 17 x 64x48 fp32 heat-maps: device time per launch (HIP events
-    around 50 back-to-back calls of the C-ABI entry on preallocated buffers, after 5 warm-ups - the host mirror's wrappers allocate
-    their outputs per call and would time the host), ALGORITHMIC bytes per launch (each tensor read / written once) and
-    the fraction of the 8 TB/s HBM peak they amount to."""
+def hbm_ops_report(mp, dev, n=128, n_sets=12):
+    """The HBM-bound rows of the path at N = 128, 17 x 64x48 fp32 heat-maps: device time per launch (HIP
+    events around ONE replay of a hipGraph holding 48 back-to-back calls of the C-ABI entry on preallocated buffers - the host mirror's
+    wrappers allocate their outputs per call and would time the host), ALGORITHMIC bytes per launch (each tensor read /
+    written once) and the fraction of the 8 TB/s HBM peak they amount to.  Two timings per op: `hbm_resident` rotates the calls over
+    ``n_sets`` distinct buffer sets (12 x 27 - 80 MB = 320 - 960 MB, more than the 256 MB memory-side cache holds, so every launch
+    streams from / to HBM: THE roofline number), `cache_resident` replays the same 27 - 80 MB every launch (what a decode right
+    behind the network's last kernel sees)."""
     from mindpose_amd import _lib
     from mindpose_amd.engine.inferencer.topdown_inferencer import COCO_FLIP_INDEX
     lib = _lib.load()
     g = torch.Generator(device="cpu").manual_seed(7)
     k, h, w = 17, 64, 48
     hm_bytes = n * k * h * w * 4
-    hm = torch.rand(n, k, h, w, generator=g).to(dev)
-    hf = torch.rand(n, k, h, w, generator=g).to(dev)
-    tgt = torch.rand(n, k, h, w, generator=g).to(dev)
+    hms = [torch.rand(n, k, h, w, generator=g).to(dev) for _ in range(n_sets)]
+    hfs = [torch.rand(n, k, h, w, generator=g).to(dev) for _ in range(n_sets)]
+    tgts = [torch.rand(n, k, h, w, generator=g).to(dev) for _ in range(n_sets)]
+    grads = [torch.empty_like(hms[0]) for _ in range(n_sets)]
     wgt = (torch.rand(n, k, generator=g) < 0.7).float().to(dev)
     center = (torch.rand(n, 2, generator=g) * 400).to(dev)
     scale = (torch.rand(n, 2, generator=g) * 2.7 + 0.3).to(dev)
     score = torch.rand(n, generator=g).to(dev)
+    kp = torch.empty(n, k, 3)
+    kp[..., 0] = torch.rand(n, k, generator=g) * 232 - 20
+    kp[..., 1] = torch.rand(n, k, generator=g) * 296 - 20
+    kp[..., 2] = (torch.rand(n, k, generator=g) < 0.7).float()
+    kp = kp.to(dev)
     flip_index = torch.as_tensor(np.array(COCO_FLIP_INDEX), dtype=torch.int32, device=dev)
     dec_dark = mp.create_decoder("topdown_heatmap", use_udp=True, dark_udp_refine=True, kernel_size=11).to(dev)
     dec_shift = mp.create_decoder("topdown_heatmap", shift_coordinate=True).to(dev)
     preds = torch.empty(n, k, 3, device=dev)
     boxes = torch.empty(n, 6, device=dev)
     argmax = torch.empty(n, k, device=dev, dtype=torch.int32)
-    grad = torch.empty_like(hm)
+    tweight = torch.empty(n, k, device=dev)
     loss = torch.empty(1, device=dev)
     go = torch.ones(1, device=dev)
     ws_bytes = lib.mp_joints_mse_workspace_bytes(n, k)
     ws = torch.empty(ws_bytes // 4, device=dev)
+    tgt_gen = mp.TopDownGenerateTarget(config=dict(image_size=[192, 256], heatmap_size=[48, 64]), sigma=2.0)
+    patch = torch.from_numpy(tgt_gen._gaussian_patch()).to(dev)  # the constants exactly as TopDownGenerateTarget.generate passes them
+    side = patch.shape[0]
+    fsx, fsy = tgt_gen._feat_stride()
 
     blur = {id(d): d._blur_on(dev) for d in (dec_dark, dec_shift)}  # (cached by the decoder; fetched outside the captures)
 
     def decode(dec):
-        return lambda st: lib.mp_decode_topdown(_lib.ptr(hm), _lib.ptr(center), _lib.ptr(scale), _lib.ptr(score), _lib.ptr(preds), _lib.ptr(boxes),
-                                                _lib.ptr(argmax), n, k, h, w, dec.refine_mode, int(dec.use_udp), int(dec.to_original),
-                                                float(dec.pixel_std), _lib.ptr(blur[id(dec)]), int(dec.kernel_size), st)
+        return lambda i, st: lib.mp_decode_topdown(_lib.ptr(hms[i]), _lib.ptr(center), _lib.ptr(scale), _lib.ptr(score), _lib.ptr(preds), _lib.ptr(boxes),
+                                                   _lib.ptr(argmax), n, k, h, w, dec.refine_mode, int(dec.use_udp), int(dec.to_original),
+                                                   float(dec.pixel_std), _lib.ptr(blur[id(dec)]), int(dec.kernel_size), st)
 
-    def flip_decode(st):
-        return lib.mp_flip_aggregate_decode(_lib.ptr(hm), _lib.ptr(hf), _lib.ptr(flip_index), 1, None, _lib.ptr(center), _lib.ptr(scale),
+    def flip_decode(i, st):
+        return lib.mp_flip_aggregate_decode(_lib.ptr(hms[i]), _lib.ptr(hfs[i]), _lib.ptr(flip_index), 1, None, _lib.ptr(center), _lib.ptr(scale),
                                             _lib.ptr(score), _lib.ptr(preds), _lib.ptr(boxes), _lib.ptr(argmax), n, k, h, w,
                                             dec_shift.refine_mode, int(dec_shift.use_udp), int(dec_shift.to_original),
                                             float(dec_shift.pixel_std), _lib.ptr(blur[id(dec_shift)]), int(dec_shift.kernel_size), st)
 
-    def mse_fwd(st):
-        return lib.mp_joints_mse_fwd(_lib.ptr(hm), _lib.ptr(tgt), _lib.ptr(wgt), _lib.ptr(loss), _lib.ptr(ws), ws_bytes, n, k, h * w, st)
+    def mse_fwd(i, st):
+        return lib.mp_joints_mse_fwd(_lib.ptr(hms[i]), _lib.ptr(tgts[i]), _lib.ptr(wgt), _lib.ptr(loss), _lib.ptr(ws), ws_bytes, n, k, h * w, st)
 
-    def mse_bwd(st):
-        return lib.mp_joints_mse_bwd(_lib.ptr(hm), _lib.ptr(tgt), _lib.ptr(wgt), _lib.ptr(go), _lib.ptr(grad), n, k, h * w, st)
+    def mse_bwd(i, st):
+        return lib.mp_joints_mse_bwd(_lib.ptr(hms[i]), _lib.ptr(tgts[i]), _lib.ptr(wgt), _lib.ptr(go), _lib.ptr(grads[i]), n, k, h * w, st)
 
-    def timed(fn, reps=50):
-        _lib.check(fn(_lib.stream()), "hbm_ops")
-        return graph_time(lambda: fn(_lib.stream()), dev, reps=reps)
+    def target(i, st):
+        return lib.mp_gaussian_target(_lib.ptr(kp), _lib.ptr(patch), int(side), None, _lib.ptr(tgts[i]), _lib.ptr(tweight), n, k, h, w,
+                                      fsx, fsy, 2.0, 0, st)
+
+    def timed(fn, reps=48):
+        out = {}
+        for mode, sets in (("hbm_resident", n_sets), ("cache_resident", 1)):
+            counter = [0]
+
+            def call():
+                _lib.check(fn(counter[0] % sets, _lib.stream()), "hbm_ops")
+                counter[0] += 1
+            out[mode] = graph_time(call, dev, reps=reps)
+        return out
 
     rows = {
         "decode_argmax_shift": (timed(decode(dec_shift)), hm_bytes,
@@ -431,12 +455,17 @@ def hbm_ops_report(mp, dev, n=128):
         "joints_mse_fwd": (timed(mse_fwd), 2 * hm_bytes, "mp_joints_mse_fwd (mse_row + mse_final): weighted squared error, fixed-order reduction, a10"),
         "joints_mse_bwd": (timed(mse_bwd), 3 * hm_bytes, "mp_joints_mse_bwd: 2 w (p - t) / (N K H W), a10"),
     }
-    return {"batch": n, "heatmaps": f"{k}x{h}x{w} fp32", "hbm_peak_GBps": 8000.0,
-            "timing": "HIP events around one replay of a hipGraph holding 50 back-to-back C-ABI calls (5 warm-ups; a Python call costs the "
-                      "host more than these kernels run); bytes = algorithmic (each tensor once); the same 27 - 80 MB every launch, i.e. "
-                      "served in part by the 256 MB memory-side cache",
-            "ops": {name: {"us": round(t * 1e6, 2), "algorithmic_bytes": b, "GBps": round(b / t / 1e9, 1),
-                           "frac_of_hbm_peak": round(b / t / 8e12, 4), "what": what} for name, (t, b, what) in rows.items()}}
+    rows["gaussian_target"] = (timed(target), hm_bytes, "mp_gaussian_target: 128 x 17 x 64x48 fp32 heat-maps written once (zero planes + one 13x13 stamp each), a8")
+    return {"batch": n, "heatmaps": f"{k}x{h}x{w} fp32", "hbm_peak_GBps": 8000.0, "buffer_sets": n_sets,
+            "timing": "HIP events around one replay of a hipGraph holding 48 back-to-back C-ABI calls (5 warm-ups; a Python call costs the "
+                      "host more than these kernels run); bytes = algorithmic (each tensor once).  us / GBps / frac_of_hbm_peak = the "
+                      f"HBM-resident figure (calls rotate over {n_sets} buffer sets, more than the 256 MB memory-side cache holds); "
+                      "cache_resident_* = the same buffers every launch",
+            "ops": {name: {"us": round(t["hbm_resident"] * 1e6, 2), "algorithmic_bytes": b, "GBps": round(b / t["hbm_resident"] / 1e9, 1),
+                           "frac_of_hbm_peak": round(b / t["hbm_resident"] / 8e12, 4),
+                           "cache_resident_us": round(t["cache_resident"] * 1e6, 2),
+                           "cache_resident_frac": round(b / t["cache_resident"] / 8e12, 4), "what": what}
+                    for name, (t, b, what) in rows.items()}}
 
 
 class CallTimer:
@@ -600,6 +629,31 @@ def train_roofline(eager_step, half):
     return out
 
 
+def train_step_hbm(roofline, step_s, n, backbone, half):
+    """The WHOLE step against the HBM roof.  The per-kernel view above prices the dominant conv against the matrix pipe; the step as a
+    whole moves ~88 GB through HBM at N = 128 (rocprofv3 FETCH_SIZE / WRITE_SIZE over every launch of a step: profiles/
+    r05_a_train_o2_pmc_traffic.json "step"), i.e. it is bandwidth-bound as a sum - this block divides bytes by the TIMED step:
+    `algorithmic` = each C-ABI call's tensors once (the CallTimer's byte model), `pmc` = the counters (N = 128 amp-O2 HRNet-W32 only)."""
+    alg = sum(e.get("GBps", 0.0) * e["ms"] * 1e-3 for e in roofline.get("per_entry", {}).values())  # GB: GB/s x s per entry
+    out = {"bound": "hbm", "peak_GBps": PEAK_HBM_GBPS, "ms_per_step": round(step_s * 1e3, 3),
+           "algorithmic_GB_per_step": round(alg, 2), "algorithmic_GBps": round(alg / step_s, 1),
+           "algorithmic_frac_of_hbm_peak": round(alg / step_s / PEAK_HBM_GBPS, 4)}
+    if half and n == 128 and backbone == "hrnet_w32":
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_train_o2_pmc_traffic.json")), reverse=True):
+            try:
+                with open(path) as f:
+                    st = json.load(f).get("step")
+                if st:
+                    gb = st["hbm_GB_per_step"]
+                    out.update({"pmc_GB_per_step": gb, "pmc_GBps": round(gb / step_s, 1), "pmc_frac_of_hbm_peak": round(gb / step_s / PEAK_HBM_GBPS, 4),
+                                "pmc_source": os.path.relpath(path, ROOT), "pmc_sum_kernel_ms_per_step": st["sum_kernel_ms_per_step"]})
+                    break
+            except (OSError, ValueError, KeyError):
+                continue
+    return out
+
+
 def train_bench(args, mp, dev, dist, world, rank):
     """configs[3]: HRNet-W32 256x192 training step, data parallel - Gaussian targets on the device, forward with
     batch-statistics BatchNorm, JointsMSELoss, backward (MFMA dgrad/wgrad), RCCL gradient mean, AdamWeightDecay.
@@ -677,6 +731,7 @@ def train_bench(args, mp, dev, dist, world, rank):
     roofline = None
     if world == 1 and not args.no_roofline:  # one rank only: an extra instrumented step on rank 0 alone would strand its collectives
         roofline = train_roofline(lambda: eager_step(update=False), half=scaler is not None)
+        roofline["step_hbm"] = train_step_hbm(roofline, elapsed / args.steps, n, bb, half=scaler is not None)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -821,6 +876,9 @@ EXTRA_LEGS = {
     "config1_simplebaseline_r50_256x192_infer_f32": ["--workload", "simplebaseline_r50", "--batch", "128", "--steps", "20", "--warmup", "5"],
     "config3_hrnet_w32_train_f32": ["--workload", "hrnet_w32_train", "--batch", "128", "--steps", "20", "--warmup", "5"],
     "config3_hrnet_w32_train_ampO2": ["--workload", "hrnet_w32_train", "--amp", "O2", "--batch", "128", "--steps", "20", "--warmup", "5"],
+    # (the reference recipe is 128 per device - hrnet_w32_ascend.yaml:19; the same step at 256: every launch carries twice the work)
+    "config3_hrnet_w32_train_ampO2_n256": ["--workload", "hrnet_w32_train", "--amp", "O2", "--batch", "256", "--steps", "12", "--warmup", "3",
+                                           "--no-roofline"],
     # SURVEY 8(d) configs 2 / 3, BASELINE.md 3: the batch sweep N in {1, 32, 256} beside the N = 128 lines above (one child per
     # precision / model; every N is its own tuned plan, 20 timed steps after 5 warm-ups)
     "batch_sweep_hrnet_w32_f32": ["--workload", "hrnet_w32", "--sweep", "1,32,256", "--steps", "20", "--warmup", "5", "--no-roofline"],
@@ -861,7 +919,7 @@ def run_extra_legs(selected=None, timeout_s=240):
                          "workload": r["config"]["workload"],
                          "roofline": {k: rl.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "algorithm", "mfma_tflops",
                                                              "kernel", "avg_launch_us", "launches_per_step", "all_conv_launches",
-                                                             "all_launches_of_entry", "per_entry", "share_of_step_kernel_time")
+                                                             "all_launches_of_entry", "per_entry", "share_of_step_kernel_time", "step_hbm")
                                       if k in rl},
                          "leg_wall_s": round(time.perf_counter() - t0, 1)}
             for k in ("gflop_per_image", "step_tflops", "final_loss", "step", "loss_scale", "skipped_steps"):
@@ -934,6 +992,7 @@ def main():
     ap.add_argument("--extra", default="", help="comma-separated subset of the extra legs to run (default: all)")
     ap.add_argument("--leg", action="store_true", help="this process IS an extra leg: no CPU baseline, no further legs")
     ap.add_argument("--sweep", default="", help="comma-separated per-GPU batch sizes: time each (its own plan) and report them all")
+    ap.add_argument("--hbm-ops", action="store_true", help="print only the hbm_ops block (decode / loss / target kernels against the HBM roofline)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -961,6 +1020,9 @@ def main():
     import mindpose_amd as mp
 
     torch.manual_seed(0)
+    if args.hbm_ops:
+        print(json.dumps(hbm_ops_report(mp, dev)))
+        return
     if args.workload in ("hrnet_w32_train", "simplebaseline_r50_train"):
         return train_bench(args, mp, dev, dist, world, rank)
     backbone, head, (ih, iw), dec_kw, flip, workload_desc = WORKLOADS[args.workload]

@@ -63,11 +63,28 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // One wave per (n, k) map.  top_down_decoder.py:72-205.
+constexpr int kDarkFastKs = 17;                                  // largest blur kernel of the register-patch path: (17 + 2)^2 = 361 <= 6 x 64
+constexpr int kDarkPatchPerLane = 6;
+constexpr int kDarkTable = (kDarkFastKs + 4) * (kDarkFastKs + 4);  // the blur table with a two-wide zero border
+
 template <bool FLIP>
 __global__ __launch_bounds__(256) void decode_kernel(DecodeParams p) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int rows = p.n * p.k;
+    // DARK: the k x k blur table goes to LDS ONCE per block, zero-padded by two on every side - the nine windows around the arg-max
+    // then read their taps at fixed offsets from one address per patch pixel, no bounds test and no dependent global load per tap
+    // (27 scattered table loads per lane were most of the refinement's 5 us)
+    __shared__ float s_blur[kDarkTable];
+    const bool dark_fast = p.refine == MP_REFINE_DARK && p.ks <= kDarkFastKs;
+    if (dark_fast) {
+        const int tw = p.ks + 4;
+        for (int i = threadIdx.x; i < tw * tw; i += 256) {
+            const int ty = i / tw - 2, tx = i - (i / tw) * tw - 2;
+            s_blur[i] = (ty >= 0 && ty < p.ks && tx >= 0 && tx < p.ks) ? p.blur[ty * p.ks + tx] : 0.f;
+        }
+        __syncthreads();
+    }
     if (row >= rows) return;  // whole wave exits; no block-level barrier below
     const int n = row / p.k, k = row - n * p.k;
     const int h = p.h, w = p.w, hw = h * w;
@@ -85,7 +102,9 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeParams p) {
         const float4* a4 = reinterpret_cast<const float4*>(a);
         float4* avg4 = reinterpret_cast<float4*>(avg);
         const int nq = hw >> 2, wq = w >> 2;
-        constexpr int B = 4;
+        // (plain decode: all twelve quads of a 64x48 map per lane in ONE round trip - a wave is one of ~2 on its SIMD, so what it does
+        // not request at once it waits for three times over; the flip test has two tensors and scalar mirror loads: four)
+        constexpr int B = FLIP ? 4 : 12;
         for (int q0 = lane; q0 < nq; q0 += 64 * B) {
             float4 v[B], f[B];
 #pragma unroll
@@ -159,37 +178,47 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeParams p) {
         const int ks = p.ks, r = ks >> 1, taps = ks * ks;
         float L[3][3];
         const int side = ks + 2;  // the nine blurred values read a (ks + 2)^2 patch around the arg-max
-        if (side * side <= 192) {
-            // every pixel of the patch is fetched ONCE (<= 3 per lane; zero outside the map = the blur's padding) and feeds the
-            // windows of all nine positions from registers; nine wave sums
-            float pv[3];
-            int pdy[3], pdx[3];
+        if (dark_fast) {
+            // every pixel of the patch is fetched ONCE (<= 6 per lane, all requested before the first is used; zero outside the map =
+            // the blur's padding) and feeds the windows of all nine positions from registers: window (oy, ox) meets patch pixel
+            // (iy, ix) with tap (iy - 1 - oy, ix - 1 - ox) = padded-table entry (iy + 1 - oy, ix + 1 - ox).  Nine wave sums.
+            const int tw = ks + 4, np = side * side;
+            float pv[kDarkPatchPerLane];
+            int tb[kDarkPatchPerLane];
 #pragma unroll
-            for (int e = 0; e < 3; ++e) {
-                const int idx = lane + 64 * e;
+            for (int e = 0; e < kDarkPatchPerLane; ++e) {
+                const int idx = min(lane + 64 * e, np - 1);
                 const int iy = idx / side, ix = idx - iy * side;
-                pdy[e] = iy - (r + 1);
-                pdx[e] = ix - (r + 1);
-                const int yy = yi + pdy[e], xx = xi + pdx[e];
-                const bool ok = idx < side * side && yy >= 0 && yy < h && xx >= 0 && xx < w;
+                const int yy = yi + iy - (r + 1), xx = xi + ix - (r + 1);
+                const bool ok = lane + 64 * e < np && yy >= 0 && yy < h && xx >= 0 && xx < w;
                 pv[e] = ok ? plane_val<FLIP>(a, b, w, p.shift_heatmap, yy, xx) : 0.f;
-                if (idx >= side * side) pdy[e] = pdx[e] = 1 << 20;  // no window holds it
+                tb[e] = (iy + 1) * tw + ix + 1;
             }
+            float part[3][3];
+#pragma unroll
+            for (int oy = 0; oy < 3; ++oy)
+#pragma unroll
+                for (int ox = 0; ox < 3; ++ox) part[oy][ox] = 0.f;
+#pragma unroll
+            for (int e = 0; e < kDarkPatchPerLane; ++e) {
+                if (64 * e >= np) break;  // wave-uniform
+#pragma unroll
+                for (int oy = -1; oy <= 1; ++oy)
+#pragma unroll
+                    for (int ox = -1; ox <= 1; ++ox) part[oy + 1][ox + 1] += s_blur[tb[e] - oy * tw - ox] * pv[e];
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1)  // the nine butterflies advance together (independent chains)
+#pragma unroll
+                for (int i = 0; i < 9; ++i) part[i / 3][i % 3] += __shfl_xor(part[i / 3][i % 3], off, 64);
 #pragma unroll
             for (int oy = -1; oy <= 1; ++oy) {
 #pragma unroll
                 for (int ox = -1; ox <= 1; ++ox) {
                     const int py = yi + oy, px = xi + ox;
                     const bool inside = (py >= 0 && py < h && px >= 0 && px < w);
-                    float part = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 3; ++e) {
-                        const int ti = pdy[e] - oy + r, tj = pdx[e] - ox + r;  // the tap of window (oy, ox) that meets this pixel
-                        if (ti >= 0 && ti < ks && tj >= 0 && tj < ks) part += p.blur[ti * ks + tj] * pv[e];
-                    }
-                    const float s = wave_sum(part);
                     // clip [1e-3, 50] -> log ; positions outside the map are the zero pad applied AFTER log
-                    L[oy + 1][ox + 1] = inside ? logf(fminf(fmaxf(s, 0.001f), 50.f)) : 0.f;
+                    L[oy + 1][ox + 1] = inside ? logf(fminf(fmaxf(part[oy + 1][ox + 1], 0.001f), 50.f)) : 0.f;
                 }
             }
         } else {
@@ -279,8 +308,8 @@ __global__ __launch_bounds__(256) void flip_aggregate_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------
-// Gaussian target: one 256-thread block per (n, k) plane; writes every pixel exactly once
-// (zero or Gaussian), 16 B / lane when W % 4 == 0.  topdown_transform.py:324-430.
+// Gaussian target: one 256-thread block per (n, k) plane; zero stores of the whole plane (16 B / lane
+// when W % 4 == 0) first, the stamp's pixels behind them.  topdown_transform.py:324-430.
 // ------------------------------------------------------------------------------------------
 struct TargetParams {
     const float* kp;
@@ -311,6 +340,18 @@ __global__ __launch_bounds__(256) void gaussian_target_kernel(TargetParams p) {
     const int row = blockIdx.x;
     const int k = row % p.k;
     const int h = p.h, w = p.w;
+    float* out = p.target + (size_t)row * h * w;
+    // The plane is zeros but for one (6 sigma + 1)^2 stamp, and WHERE the stamp lies takes a chain of fp64 divisions and roundings:
+    // the zero stores go out first - nothing of them depends on the key point - and the set-up runs under them (round 4 did the
+    // set-up first: 8.2 us for 26.7 MB of stores, 0.40 of the HBM peak).  The stamp's pixels are stored a second time behind a
+    // workgroup barrier (same block, so the barrier's release orders them behind the zeros): <= 5 % more bytes.
+    if ((w & 3) == 0) {
+        const int nq = (h * w) >> 2;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = threadIdx.x; q < nq; q += blockDim.x) reinterpret_cast<float4*>(out)[q] = z4;
+    } else {
+        for (int i = threadIdx.x; i < h * w; i += blockDim.x) out[i] = 0.f;
+    }
     const float kx = p.kp[(size_t)row * 3 + 0], ky = p.kp[(size_t)row * 3 + 1], vis = p.kp[(size_t)row * 3 + 2];
     double fx = (double)kx / p.fsx, fy = (double)ky / p.fsy;  // fp32 scalar / fp64 scalar -> fp64
     fx = fmin(fmax(fx, -1.0e9), 1.0e9);
@@ -337,22 +378,12 @@ __global__ __launch_bounds__(256) void gaussian_target_kernel(TargetParams p) {
     const double x0p = c0 + fx - (double)mu_x, y0p = c0 + fy - (double)mu_y;
     const double two_sigma2 = 2.0 * (p.sigma * p.sigma);
 
-    float* out = p.target + (size_t)row * h * w;
-    if ((w & 3) == 0) {
-        const int wq = w >> 2, nq = h * wq;
-        for (int q = threadIdx.x; q < nq; q += blockDim.x) {
-            int y = q / wq, x = (q - y * wq) << 2;
-            float4 v;
-            v.x = target_value(p, stamp, y, x, ix0, ix1, iy0, iy1, gx0, gy0, x0p, y0p, two_sigma2);
-            v.y = target_value(p, stamp, y, x + 1, ix0, ix1, iy0, iy1, gx0, gy0, x0p, y0p, two_sigma2);
-            v.z = target_value(p, stamp, y, x + 2, ix0, ix1, iy0, iy1, gx0, gy0, x0p, y0p, two_sigma2);
-            v.w = target_value(p, stamp, y, x + 3, ix0, ix1, iy0, iy1, gx0, gy0, x0p, y0p, two_sigma2);
-            reinterpret_cast<float4*>(out)[q] = v;
-        }
-    } else {
-        for (int i = threadIdx.x; i < h * w; i += blockDim.x) {
-            int y = i / w, x = i - y * w;
-            out[i] = target_value(p, stamp, y, x, ix0, ix1, iy0, iy1, gx0, gy0, x0p, y0p, two_sigma2);
+    __syncthreads();  // (uniform: every thread of the block gets here)
+    if (stamp && ix1 > ix0 && iy1 > iy0) {
+        const int sw = ix1 - ix0, cnt = sw * (iy1 - iy0);
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const int dy = i / sw, y = iy0 + dy, x = ix0 + (i - dy * sw);
+            out[y * w + x] = target_value(p, true, y, x, ix0, ix1, iy0, iy1, gx0, gy0, x0p, y0p, two_sigma2);
         }
     }
     if (threadIdx.x == 0) {

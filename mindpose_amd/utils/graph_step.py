@@ -14,6 +14,7 @@ grouped weight gradient still queued - are handed to the all-reduce, which then 
 segment's kernels; only the last buckets are exposed.  The segments are the single backward pass cut in pieces: same node order,
 same weight-gradient groups (they are carried across the cuts), so the gradient arena equals the one-graph step's bit for bit.
 """
+import os
 import time
 from typing import List, Optional, Sequence
 
@@ -102,12 +103,17 @@ class GraphedTrainStep:
         self.issue_ms: List[float] = []  # host time spent handing buckets to the all-reduce between the segments, per step
         if self.segments == 1:
             self.graph = torch.cuda.CUDAGraph()
+            dot = os.environ.get("MINDPOSE_GRAPH_DEBUG_DOT")  # kernel work: the captured graph's nodes and edges as a DOT file
+            if dot:
+                self.graph.enable_debug_mode()
             with torch.cuda.graph(self.graph):
                 optimizer.grads.arena.zero_()
                 self.static_loss = net_with_loss(*self.static_in)
                 (self.static_loss * self.scale_t).backward()
                 flush_wgrad_jobs()  # the remainders of the grouped weight gradients belong to the captured step
             self.graphs, self.bucket_schedule = [self.graph], [[]]
+            if dot:
+                self.graph.debug_dump(dot)
         else:
             self._capture_segments(backbone, groups, dev)
         set_branch_streams(prev_branch_streams)

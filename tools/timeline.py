@@ -15,12 +15,14 @@ def main():
     ap.add_argument("--marker", required=True)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--dump", default=None, help="write the LAST step's launches (start us, duration us, queue, grid, short name) to this CSV")
     ap.add_argument("--split", default=None, help="kernel substring: report the part of a step before / from its first launch separately")
     a = ap.parse_args()
-    rows = []
+    rows, extra = [], {}
     with open(a.trace) as fh:
         for r in csv.DictReader(fh):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+            extra[(int(r["Start_Timestamp"]), r["Kernel_Name"])] = (r.get("Queue_Id", ""), r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Workgroup_Size_X", r.get("Workgroup_Size", "")))
     rows.sort()
     marks = []
     for s, e, name in rows:
@@ -28,6 +30,15 @@ def main():
             marks.append(s)
     if len(marks) < 2:
         raise SystemExit(f"marker {a.marker!r}: {len(marks)} occurrence(s)")
+    if a.dump:
+        t0, t1 = marks[-2], marks[-1]
+        with open(a.dump, "w") as fh:
+            fh.write("start_us,dur_us,queue,grid,wg,name\n")
+            for s_, e_, n_ in rows:
+                if t0 <= s_ < t1:
+                    q, g, wg = extra.get((s_, n_), ("", "", ""))
+                    short = n_.replace("void ", "").replace("mp::", "").replace("(anonymous namespace)::", "").split("(")[0][:70]
+                    fh.write(f"{(s_ - t0) / 1e3:.2f},{(e_ - s_) / 1e3:.2f},{q},{g},{wg},\"{short}\"\n")
     out = []
     for k in range(max(0, len(marks) - 1 - a.steps), len(marks) - 1):
         t0, t1 = marks[k], marks[k + 1]

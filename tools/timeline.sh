@@ -10,5 +10,5 @@ python3 bench.py "$@" --steps 2 --warmup 1 > /dev/null 2> $out/${tag}_tune.err
 cd /tmp
 rocprofv3 --kernel-trace --output-format csv -d $out/${tag}_prof -o ${tag} -- python3 $root/bench.py "$@" --steps 6 --warmup 3 > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_rocprof.err
 f=$(find $out/${tag}_prof -name "*kernel_trace.csv" | head -1)
-python3 $root/tools/timeline.py "$f" --marker "$marker" --steps 3 --json $out/${tag}_timeline.json ${TIMELINE_SPLIT:+--split "$TIMELINE_SPLIT"}
+python3 $root/tools/timeline.py "$f" --marker "$marker" --steps 3 --json $out/${tag}_timeline.json --dump $out/${tag}_last_step.csv ${TIMELINE_SPLIT:+--split "$TIMELINE_SPLIT"}
 rm -rf $out/${tag}_prof
