@@ -879,6 +879,8 @@ EXTRA_LEGS = {
     # (the reference recipe is 128 per device - hrnet_w32_ascend.yaml:19; the same step at 256: every launch carries twice the work)
     "config3_hrnet_w32_train_ampO2_n256": ["--workload", "hrnet_w32_train", "--amp", "O2", "--batch", "256", "--steps", "12", "--warmup", "3",
                                            "--no-roofline"],
+    # what the input pipeline delivers next to what the training step consumes (run_extra_legs adds the ratio)
+    "loader_coco_topdown_train_pipeline": ["--workload", "loader_coco_topdown", "--batch", "128", "--steps", "24", "--warmup", "1"],
     # SURVEY 8(d) configs 2 / 3, BASELINE.md 3: the batch sweep N in {1, 32, 256} beside the N = 128 lines above (one child per
     # precision / model; every N is its own tuned plan, 20 timed steps after 5 warm-ups)
     "batch_sweep_hrnet_w32_f32": ["--workload", "hrnet_w32", "--sweep", "1,32,256", "--steps", "20", "--warmup", "5", "--no-roofline"],
@@ -922,9 +924,12 @@ def run_extra_legs(selected=None, timeout_s=240):
                                                              "all_launches_of_entry", "per_entry", "share_of_step_kernel_time", "step_hbm")
                                       if k in rl},
                          "leg_wall_s": round(time.perf_counter() - t0, 1)}
-            for k in ("gflop_per_image", "step_tflops", "final_loss", "step", "loss_scale", "skipped_steps"):
+            for k in ("gflop_per_image", "step_tflops", "final_loss", "step", "loss_scale", "skipped_steps", "host_threads", "cpu", "prefetch_2",
+                      "synchronous", "what"):
                 if k in r["config"]:
                     out[name][k] = r["config"][k]
+            if name.startswith("loader_") and "value" in out.get("config3_hrnet_w32_train_ampO2", {}):
+                out[name]["ratio_to_training_consumption"] = round(r["value"] / out["config3_hrnet_w32_train_ampO2"]["value"], 3)
         except subprocess.TimeoutExpired:
             out[name] = {"error": f"timeout after {timeout_s}s"}
         except (ValueError, KeyError) as exc:
@@ -960,6 +965,73 @@ def sweep_bench(args, mp, net, eval_net, dev, size, workload_desc, world, rank):
                           "dtype": "f32" if args.amp == "O0" else "f16", "data": "synthetic", "config": {"workload": workload_desc}}))
 
 
+def loader_bench(args, mp, dev):
+    """SURVEY 8(f) N2 / data_factory.py:59-151: the training input pipeline on its own - synthetic COCO-format JPEGs (640x480) on
+    local disk -> create_dataset (shuffled records) -> create_pipeline(batch 128, is_train=True: box -> centre / scale, random flip,
+    half-body, random scale / rotation on the host in sample order; decode in a thread pool; ONE pinned upload, ONE mp_warp_affine
+    and ONE mp_gaussian_target launch per batch), batches prepared ahead on a side stream.  Reports what the loader ALONE delivers
+    (the consumer only waits for each batch) with and without the prefetch thread."""
+    import tempfile
+    from PIL import Image
+    n_img, per_img, batch = 384, 2, args.batch
+    rng = np.random.RandomState(3)
+    tmp = tempfile.mkdtemp(prefix="mindpose_loader_")
+    images, anns = [], []
+    yy, xx = np.mgrid[0:480, 0:640].astype(np.float32)
+    for i in range(n_img):
+        # smooth structure + mild noise: JPEG entropy (decode cost) in the range of photographs, not of white noise
+        base = np.stack([127 + 90 * np.sin(xx / rng.uniform(20, 90) + rng.uniform(0, 6)) * np.cos(yy / rng.uniform(20, 90)) for _ in range(3)], axis=2)
+        im = np.clip(base + rng.normal(0, 12, base.shape), 0, 255).astype(np.uint8)
+        Image.fromarray(im).save(os.path.join(tmp, f"{i:06d}.jpg"), quality=90)
+        images.append(dict(id=i + 1, file_name=f"{i:06d}.jpg", width=640, height=480))
+        for j in range(per_img):
+            x0, y0 = rng.uniform(20, 300), rng.uniform(20, 200)
+            bw, bh = rng.uniform(120, 300), rng.uniform(150, 260)
+            kp = np.concatenate([rng.uniform([x0, y0], [x0 + bw, y0 + bh], (17, 2)), rng.randint(1, 3, (17, 1))], axis=1)
+            anns.append(dict(id=len(anns) + 1, image_id=i + 1, category_id=1, iscrowd=0, bbox=[x0, y0, bw, bh], area=float(bw * bh),
+                             num_keypoints=17, keypoints=kp.reshape(-1).tolist()))
+    ann = os.path.join(tmp, "train.json")
+    with open(ann, "w") as f:
+        json.dump(dict(images=images, annotations=anns, categories=[dict(id=1, name="person")]), f)
+    cfg = dict(image_size=[192, 256], heatmap_size=[48, 64], pixel_std=200.0, scale_padding=1.25, upper_body_ids=list(range(11)),
+               flip_pairs=[[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]], det_bbox_thr=0.0)
+    names = ["topdown_box_to_center_scale", {"topdown_horizontal_random_flip": {"flip_prob": 0.5}}, "topdown_halfbody_transform",
+             "topdown_randomscale_rotation", "topdown_affine", {"topdown_generate_target": {"sigma": 2.0}}]
+    threads = host_cores()[0]
+    ds = mp.create_dataset(tmp, ann, is_train=True, config=cfg)
+    out = {}
+    for label, prefetch in (("prefetch_2", 2), ("synchronous", 0)):
+        pipe = mp.create_pipeline(ds, names, batch_size=batch, is_train=True, num_workers=threads, config=cfg, prefetch=prefetch)
+        np.random.seed(5)
+        seen, t0, first = 0, None, None
+        for epoch in range(64):
+            for b in pipe:
+                torch.cuda.current_stream().synchronize()  # the consumer: takes delivery of the batch, nothing else
+                if t0 is None:
+                    t0, first = time.perf_counter(), b  # (the first batch pays thread start-up and the kernels' first launch)
+                    continue
+                seen += 1
+            if seen >= args.steps:
+                break
+        dt = time.perf_counter() - t0
+        out[label] = {"images_per_s": round(seen * batch / dt, 1), "ms_per_batch": round(dt / seen * 1e3, 2), "batches": seen}
+        log(f"loader {label}: {out[label]}")
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    best = out["prefetch_2"]
+    print(json.dumps({
+        "metric": "images/sec, training input pipeline alone (decode + host transforms + GPU crop / normalise / target)", "value": best["images_per_s"],
+        "unit": "images/s", "n_gpus": 1, "steps": best["batches"], "warmup": 1, "ms_per_step": best["ms_per_batch"], "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"SURVEY 8(f) N2: create_dataset('coco_topdown') + create_pipeline(batch {batch}, is_train=True) over {n_img} synthetic "
+                               f"640x480 JPEGs ({n_img * per_img} person records), the recipe's transform list, 256x192 crops + 17x64x48 targets",
+                   "per_gpu_batch": batch, "host_threads": threads, "cpu": _cpu_model(), "prefetch_2": out["prefetch_2"], "synchronous": out["synchronous"],
+                   "what": "the consumer only waits for each batch: the loader's own rate.  decode = PIL in a thread pool (releases the GIL); "
+                           "the per-sample geometry / random draws run on one thread in sample order (the reference maps them over "
+                           "num_parallel_workers processes: data_factory.py:116-151)"},
+        "roofline": None, "cpu_baseline": None}))
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks through torch.distributed.run as ONE child process tree.
     Nothing in this process has touched the GPU yet (importing torch does not), so no GPU-initialised process is replaced."""
@@ -981,7 +1053,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="crops per GPU per step (reference per-device batch_size)")
-    ap.add_argument("--workload", default="hrnet_w32", choices=list(WORKLOADS) + ["hrnet_w32_train", "simplebaseline_r50_train"],
+    ap.add_argument("--workload", default="hrnet_w32", choices=list(WORKLOADS) + ["hrnet_w32_train", "simplebaseline_r50_train", "loader_coco_topdown"],
                     help="hrnet_w32 = BASELINE.json metric / configs[2] (default); the others are extra measurements")
     ap.add_argument("--layers", default="", help="write a per-launch timing table (CSV) to this path")
     ap.add_argument("--amp", default="O0", choices=["O0", "O2"],
@@ -1023,6 +1095,8 @@ def main():
     if args.hbm_ops:
         print(json.dumps(hbm_ops_report(mp, dev)))
         return
+    if args.workload == "loader_coco_topdown":
+        return loader_bench(args, mp, dev)
     if args.workload in ("hrnet_w32_train", "simplebaseline_r50_train"):
         return train_bench(args, mp, dev, dist, world, rank)
     backbone, head, (ih, iw), dec_kw, flip, workload_desc = WORKLOADS[args.workload]

@@ -60,6 +60,13 @@ class RecordTable:
         return rec
 
 
+class ImagePath(str):
+    """The ``image`` column as a path whose bytes have not been read yet (`TopDownDataset.lazy_image`)."""
+
+    def read(self) -> np.ndarray:
+        return np.fromfile(str(self), dtype=np.uint8)
+
+
 class TopDownDataset:
     """Args (topdown.py:41-67): image_root, annotation_file, is_train, num_joints, use_gt_bbox_for_val, detection_file, config.
 
@@ -103,7 +110,9 @@ class TopDownDataset:
     def _column_sources(self, idx: int) -> Dict[str, Callable[[], Any]]:
         t = self._table
         return {
-            "image": lambda: np.fromfile(t.image_file(idx), dtype=np.uint8),  # ENCODED bytes: decoding is a pipeline step
+            # ENCODED bytes: decoding is a pipeline step.  ``lazy_image`` (set by a pipeline whose codec runs in worker processes): only
+            # the path travels, the worker reads the file itself
+            "image": (lambda: ImagePath(t.image_file(idx))) if getattr(self, "lazy_image", False) else (lambda: np.fromfile(t.image_file(idx), dtype=np.uint8)),
             "image_file": lambda: t.image_file(idx),
             "boxes": lambda: t.boxes[idx].astype(np.float32),
             "keypoints": lambda: t.keypoints[idx].astype(np.float32),

@@ -122,15 +122,24 @@ def set_branch_streams(on: bool) -> bool:
     of the deep branches with the large ones).  Returns the previous setting.  ``MINDPOSE_TRAIN_BRANCH_STREAMS=0/1`` overrides."""
     prev = _BRANCH_STREAMS_ON[0]
     _BRANCH_STREAMS_ON[0] = bool(on)
-    if on:
-        # Parameters whose gradient goes back through autograd (not written into the arena by the launches themselves) then meet an
-        # AccumulateGrad node created on the caller's stream while the node that produced the gradient ran on a branch stream.  That
-        # mismatch is this design - the branch streams are joined explicitly, graph == eager and segmented == one-graph are tested
-        # bit for bit - so torch's once-per-process warning about it is switched off where torch offers the switch
-        quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
-        if quiet is not None:
-            quiet(False)
     return prev
+
+
+@contextlib.contextmanager
+def quiet_accumulate_grad_stream_warning():
+    """Parameters whose gradient goes back through autograd (the head conv's bias, the few fp32 parameters outside the arena's direct
+    path) meet an AccumulateGrad node created on the caller's stream while the node that produced the gradient ran on a branch
+    stream.  Inside a graphed step that mismatch is the design (the branch streams are joined explicitly; graph == eager and
+    segmented == one-graph are tested bit for bit), so torch's warning about it is off WHILE the step's warm-up passes and capture
+    run the autograd engine - and on again afterwards: the user's own eager backward passes keep the diagnostic."""
+    switch = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+    if switch is not None:
+        switch(False)
+    try:
+        yield
+    finally:
+        if switch is not None:
+            switch(True)
 
 
 def branch_streams_enabled() -> bool:

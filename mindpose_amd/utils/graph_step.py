@@ -86,8 +86,14 @@ class GraphedTrainStep:
             segments = len(groups) if (groups and optimizer.grads.active) else 1
         self.segments = max(1, min(int(segments), len(groups))) if groups else 1
         # inside the graph the branches of an HRModule run on side streams (fork / join = graph dependencies): +5 % on the step
-        from ..models.backbones.hrnet import set_branch_streams
+        from ..models.backbones.hrnet import quiet_accumulate_grad_stream_warning, set_branch_streams
         prev_branch_streams = set_branch_streams(True)
+        with quiet_accumulate_grad_stream_warning():  # (only the warm-up passes and the capture run the autograd engine)
+            self._warm_up_and_capture(net_with_loss, optimizer, backbone, groups, dev, warmup)
+        set_branch_streams(prev_branch_streams)
+        self._planned = [m for m in net_with_loss.modules() if hasattr(m, "_plans")]  # walked once, not per step
+
+    def _warm_up_and_capture(self, net_with_loss, optimizer, backbone, groups, dev, warmup) -> None:
         from ..models.train_ops import flush_wgrad_jobs
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -116,8 +122,6 @@ class GraphedTrainStep:
                 self.graph.debug_dump(dot)
         else:
             self._capture_segments(backbone, groups, dev)
-        set_branch_streams(prev_branch_streams)
-        self._planned = [m for m in net_with_loss.modules() if hasattr(m, "_plans")]  # walked once, not per step
 
     def _capture_segments(self, backbone, groups, dev) -> None:
         """Forward + loss + the backward pass of the LAST module group in the first graph, one graph per earlier group after it.

@@ -223,3 +223,33 @@ def test_two_rank_nccl_hrnet_w32_step(tmp_path):
     reports = _run_dp(2, tmp_path)
     # different data per rank: the losses differ, the reduced arenas agree with the mean of the local ones (checked in-worker)
     assert reports[0]["graph_torch_o2"]["loss"] != reports[1]["graph_torch_o2"]["loss"]
+
+
+def test_bench_two_rank_rehearsal_on_one_gpu_reports_the_dp_leg():
+    """`bench.py --gpus 2` as the driver launches it (bench.py spawns its ranks through torch.distributed.run), rehearsed on ONE GPU:
+    MINDPOSE_BENCH_SHARED_GPU_REHEARSAL=1 puts both ranks on device 0 with gloo for the barrier / MAX / gradient exchange.  Not a
+    measurement - the first real multi-GPU run must not fail on plumbing: the line parses, names two ranks and carries the
+    data-parallel training leg with its exchange figures (segmented backward, buckets released between the segments)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MINDPOSE_BENCH_SHARED_GPU_REHEARSAL="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    # a child process tree of its own: nothing here has to be exec'ed from this (GPU-initialised) process
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-roofline",
+                           "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    line = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["global_batch"] == 2 * line["config"]["per_gpu_batch"]
+    leg = line["extra_workloads"]["config3_train_ampO2_dp"]
+    assert "error" not in leg, leg
+    for key in ("rccl_nranks", "transport", "allreduce_ms_per_step", "allreduce_issue_ms", "backward_segments", "buckets_released_per_segment",
+                "gradient_bytes", "buckets", "value", "ms_per_step"):
+        assert key in leg, key
+    assert leg["rccl_nranks"] == 2 and leg["global_batch"] == 2 * leg["per_gpu_batch"]
+    assert leg["backward_segments"] == 4 and len(leg["buckets_released_per_segment"]) == 4
+    assert sum(leg["buckets_released_per_segment"]) == leg["buckets"]  # every bucket leaves exactly once
+    assert leg["allreduce_ms_per_step"] is not None and leg["value"] > 0

@@ -179,3 +179,59 @@ def test_training_pipeline_batches_match_per_sample_transforms(tmp_path):
             kp = ts[4].transform_keypoints(st["keypoints"].copy(), ts[4].get_matrix(st["center"], st["scale"], st["rotation"]))
             tgt, wgt = otarget.generate_target(kp[None], (192, 256), (48, 64), sigma=2.0)
             assert np.array_equal(b["target"][j].cpu().numpy(), tgt[0]) and np.array_equal(b["target_weight"][j].cpu().numpy(), wgt[0])
+
+
+def test_prefetched_batches_equal_the_synchronous_ones(tmp_path):
+    """`create_pipeline(prefetch=2)` - the batches prepared ahead by a background thread on a side stream, one pinned upload per
+    batch - against `prefetch=0`: same samples, same order of the np.random draws, so every column is bit-equal; JPEG payloads
+    (PIL decode in the thread pool), several epochs, the consumer running kernels of its own between batches."""
+    import json
+    import os
+    from PIL import Image
+    rng = np.random.RandomState(8)
+    cfg = dict(image_size=[192, 256], heatmap_size=[48, 64], pixel_std=200.0, scale_padding=1.25, upper_body_ids=list(range(11)),
+               flip_pairs=[[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]], det_bbox_thr=0.0)
+    images, anns = [], []
+    for i in range(11):
+        h, w = 120 + 8 * i, 160 + 4 * i
+        Image.fromarray(rng.randint(0, 256, (h, w, 3)).astype(np.uint8)).save(os.path.join(tmp_path, f"{i}.jpg"), quality=92)
+        images.append(dict(id=i + 1, file_name=f"{i}.jpg", width=w, height=h))
+        kp = np.concatenate([rng.uniform(20, 100, (17, 2)), rng.randint(0, 3, (17, 1))], axis=1)
+        kp[kp[:, 2] == 0, :2] = 0
+        anns.append(dict(id=i + 1, image_id=i + 1, category_id=1, iscrowd=0, bbox=[15.0, 12.0, 100.0, 90.0], area=9000.0,
+                         num_keypoints=int((kp[:, 2] > 0).sum()), keypoints=kp.reshape(-1).tolist()))
+    ann = os.path.join(tmp_path, "train.json")
+    with open(ann, "w") as f:
+        json.dump(dict(images=images, annotations=anns, categories=[dict(id=1, name="person")]), f)
+    names = ["topdown_box_to_center_scale", {"topdown_horizontal_random_flip": {"flip_prob": 0.5}}, "topdown_halfbody_transform",
+             "topdown_randomscale_rotation", "topdown_affine", {"topdown_generate_target": {"sigma": 2.0}}]
+
+    def epochs(prefetch):
+        ds = mp.create_dataset(str(tmp_path), ann, is_train=True, config=cfg)
+        pipe = mp.create_pipeline(ds, names, batch_size=4, is_train=True, num_workers=3, config=cfg, prefetch=prefetch)
+        assert pipe.prefetch == prefetch
+        np.random.seed(23)
+        got = []
+        busy = torch.randn(512, 512, device=DEV)
+        for _ in range(3):
+            for b in pipe:
+                busy = busy @ busy * 1e-3  # the consumer's own work on its stream while the next batch is prepared
+                got.append({k: v.clone() for k, v in b.items()})
+        return got
+
+    a, b = epochs(0), epochs(2)
+    assert len(a) == len(b) == 6  # 11 samples, batch 4, drop_remainder, 3 epochs (a new shuffle each)
+    for x, y in zip(a, b):
+        assert list(x) == list(y) == ["image", "target", "target_weight"]
+        for k in x:
+            assert torch.equal(x[k], y[k]), k
+    assert not torch.equal(a[0]["image"], a[2]["image"])  # epochs differ
+
+    # an abandoned iteration (break) stops the producer thread
+    import threading
+    ds = mp.create_dataset(str(tmp_path), ann, is_train=True, config=cfg)
+    pipe = mp.create_pipeline(ds, names, batch_size=2, is_train=True, config=cfg, prefetch=2)
+    it = iter(pipe)
+    next(it)
+    it.close()
+    assert not [t for t in threading.enumerate() if t.name == "mindpose-loader-prefetch" and t.is_alive()]

@@ -139,3 +139,43 @@ def test_point_helpers_match_reference_goldens():
         assert b.dtype == g[f"tk_out_{i}"].dtype and np.array_equal(b, g[f"tk_out_{i}"])
     with np.testing.assert_raises(AssertionError):
         U.affine_transform((1.0, 2.0, 3.0), g["mats"][0])
+
+
+def test_codec_processes_decode_into_shared_memory_slots():
+    """`_DecodeProcesses` (data/decode_worker.py as child processes): every payload comes back as a view of the shared block equal to
+    the in-process decode - JPEG and .npy payloads, ragged sizes, several regions in flight - an image larger than a slot is handed
+    back (None) for the caller to decode, a corrupt payload raises, and the block is unlinked on close."""
+    import io
+    import os
+    from PIL import Image
+    from mindpose_amd.data.data_factory import _DecodeProcesses, _decode
+    rng = np.random.RandomState(0)
+    payloads = []
+    for i in range(21):
+        im = rng.randint(0, 256, (60 + i, 80 + 2 * i, 3)).astype(np.uint8)
+        b = io.BytesIO()
+        if i % 3 == 0:
+            np.save(b, im)
+        else:
+            Image.fromarray(im).save(b, format="JPEG", quality=90)
+        payloads.append(np.frombuffer(b.getvalue(), np.uint8))
+    b = io.BytesIO()
+    np.save(b, rng.randint(0, 256, (400, 300, 3)).astype(np.uint8))  # 360 kB: larger than the 256 kB slots below
+    payloads.append(np.frombuffer(b.getvalue(), np.uint8))
+    codec = _DecodeProcesses(workers=3, batch=32, slot_bytes=256 << 10, regions=2)
+    name = codec.shm.name
+    try:
+        tickets = [codec.submit(payloads), codec.submit(payloads[::-1])]  # two regions in flight
+        for ticket, pay in zip(tickets, (payloads, payloads[::-1])):
+            images = codec.collect(ticket)
+            for p, im in zip(pay, images):
+                ref = _decode(p)
+                if ref.nbytes > codec.slot_bytes:
+                    assert im is None
+                else:
+                    assert np.array_equal(im, ref)
+        with pytest.raises(ValueError):
+            codec.collect(codec.submit([np.frombuffer(b"not an image at all", np.uint8)]))
+    finally:
+        codec.close()
+    assert not os.path.exists(os.path.join("/dev/shm", name.lstrip("/")))
