@@ -193,6 +193,12 @@ class ActC8:
         return self.c8_tensor.permute(0, 1, 4, 2, 3).reshape(n, -1, h, w)[:, :c].float().contiguous()
 
 
+# launches below this many multiply-accumulates keep the library's heuristic (MINDPOSE_TUNE_MIN_MACS overrides).  Round 4 tuned from
+# 2^26 up - which left EVERY layer of a one-crop forward (28 M MACs per 32-channel conv at N = 1) on the heuristic: a top-down
+# pipeline serves a handful of crops per frame, and there the tile choice decides whether a launch covers 8 or 64 CUs
+_TUNE_MIN_MACS = int(os.environ.get("MINDPOSE_TUNE_MIN_MACS", str(1 << 22)))
+
+
 def _autotune(key, macs, n_variants, launch) -> int:
     """Time ``launch(v)`` for every tile variant (HIP events, best of two groups of 5 launches; MP_ERR_UNSUPPORTED = variant not
     available, any other error code raises) and cache the winner per launch shape; -1 = library heuristic when tuning is off (MINDPOSE_AUTOTUNE=0) or
@@ -205,7 +211,7 @@ def _autotune(key, macs, n_variants, launch) -> int:
     if hit is not None:
         return hit
     best, best_t = -1, None
-    if macs >= (1 << 26):  # a miss is timed on whichever rank meets it - no communication here (share_tuner_choices)
+    if macs >= _TUNE_MIN_MACS:  # a miss is timed on whichever rank meets it - no communication here (share_tuner_choices)
         for v in range(n_variants):
             rc = launch(v)
             if rc == -3:  # MP_ERR_UNSUPPORTED: this variant does not serve the shape
@@ -228,11 +234,12 @@ def _autotune(key, macs, n_variants, launch) -> int:
                 with open(log, "a") as fh:
                     fh.write(f"{key}\t{v}\t{t:.4f}\n")
     _TUNE_CACHE[key] = best
-    if macs >= (1 << 26):
+    if macs >= _TUNE_MIN_MACS:
         _tune_save()
     return best
 
 
+BLOCK_ROWS = (0, 4, 2, 1)  # band heights the fused-BasicBlock tuner times (0 = the tallest that fits)
 F32_VARIANTS = 9   # direct MFMA tile variants 0..7 (csrc/conv_mfma.h ConvVariant) + 8 = the streaming 1x1 kernel (conv_pw_f32.hip)
 F32_WINOGRAD = 9   # the tuner's index of the Winograd F(2x2,3x3) form (csrc/conv_wino_f32.hip)
 F32_GEMM = 10      # the blocked-GEMM 1x1 kernel (csrc/conv_gemm_f32.hip; conv_api.hip kGemm)
@@ -600,8 +607,17 @@ class Plan:
         out = self.alloc(n, c, h, w)
         p1, p2 = (self._pack(cv.weight, c, c, 3, False, 0, 0, True) for cv in (conv1, conv2))
         (s1, b1), (s2, b2) = self._affine(c, bn1, None, True), self._affine(c, bn2, None, True)
+        # rows per workgroup band: 0 = the tallest band that fits (fewest halo rows: right when N x bands fills the chip); a handful
+        # of crops leaves 2 - 8 workgroups per launch, and shorter bands trade recomputed halo rows for parallelism - timed per shape
+        stream = _lib.stream()
+
+        def launch(v):
+            return self.lib.mp_f16_basicblock_fwd(_lib.ptr(x), _lib.ptr(p1), _lib.ptr(s1), _lib.ptr(b1), _lib.ptr(p2), _lib.ptr(s2), _lib.ptr(b2),
+                                                  _lib.ptr(out), n, c, h, w, BLOCK_ROWS[v], stream)
+        pick = _autotune(("basicblock_f16", n, c, h, w, str(out.device)), 2 * n * h * w * c * c * 9, len(BLOCK_ROWS), launch)
+        rows = BLOCK_ROWS[pick] if pick >= 0 else 0
         _lib.check(self.lib.mp_plan_add_basicblock_f16(self.handle, _lib.ptr(x), _lib.ptr(p1), _lib.ptr(s1), _lib.ptr(b1),
-                                                       _lib.ptr(p2), _lib.ptr(s2), _lib.ptr(b2), _lib.ptr(out), n, c, h, w, 0),
+                                                       _lib.ptr(p2), _lib.ptr(s2), _lib.ptr(b2), _lib.ptr(out), n, c, h, w, rows),
                    "mp_plan_add_basicblock_f16")
         self.layer_info.append(dict(kind="basicblock_f16", k=3, stride=1, cin=c, cout=c, h=h, w=w, n=n,
                                     macs=2 * n * h * w * c * c * 9))
