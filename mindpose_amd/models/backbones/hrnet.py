@@ -281,28 +281,24 @@ class HRModule(nn.Module):
     def train_forward(self, xs: List[torch.Tensor]) -> List[torch.Tensor]:
         """Training form of hrnet.py:318-344: same term order; one exchange-unit sum kernel per row."""
         xs = list(xs)
-        handles_pre = {}
         if self.num_branches > 1 and xs[0].is_cuda and branch_streams_enabled():
             # the branches are independent until the exchange unit: branch i > 0 on side stream i (forked from / joined to the
             # current stream), so the small launches of the deep branches overlap the large ones; autograd replays each node on
             # its forward stream, which parallelises the backward the same way
             cur = torch.cuda.current_stream(xs[0].device)
             side = _branch_streams(xs[0].device, self.num_branches - 1)
-            rows_ = len(self.fuse_layers)
-            fan_on_branch = os.environ.get("MINDPOSE_TRAIN_FANOUT_ON_BRANCH", "0") == "1"
             for i in range(1, self.num_branches):
                 side[i - 1].wait_stream(cur)
                 with torch.cuda.stream(side[i - 1]):
                     for blk in self.branches[i]:
                         xs[i] = blk.train_forward(xs[i])
-                    if fan_on_branch:
-                        handles_pre[i] = T.fan_out(xs[i], rows_)
             for blk in self.branches[0]:
                 xs[0] = blk.train_forward(xs[0])
-            if fan_on_branch:
-                handles_pre[0] = T.fan_out(xs[0], rows_)
             for st in side:
                 cur.wait_stream(st)
+            # (the fan-out nodes below stay on the current stream: forked onto the branch streams - so that the backward pass has no
+            # main-stream spine through the fan-ins - a side stream waits on several other side streams, and ROCm 7.2 faults in
+            # hipStreamEndCapture on that shape; tried in round 5, DESIGN 4.11)
         else:
             for i in range(self.num_branches):
                 for blk in self.branches[i]:
@@ -312,7 +308,7 @@ class HRModule(nn.Module):
         # every branch output feeds every row of the exchange unit: one handle per row, so that the backward pass sums the rows'
         # gradients in one launch per branch (T.FanOutFn) instead of pairwise
         rows = len(self.fuse_layers)
-        handles = [handles_pre[i] if i in handles_pre else T.fan_out(x, rows) for i, x in enumerate(xs)]
+        handles = [T.fan_out(x, rows) for x in xs]
         outs = []
         # The rows of the exchange unit (hrnet.py:318-344) are independent chains of small launches - 1x1 conv + BatchNorm per
         # up-sampled term, one to three stride-2 conv + BatchNorm groups per down-sampled one, the sum - ~17 (three branches) to ~36
