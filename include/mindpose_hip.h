@@ -173,7 +173,9 @@ int mp_conv2d_fwd(const mp_conv_desc* desc, const float* x_dev, const float* pac
  * kernel; 8 = the streaming 1x1 kernel for the HBM-bound stage-1 / layer1 layers - Cin 64 / 128 / 256 with Cin * Cout <= 16384,
  * image planes a multiple of 64 pixels, one residual tensor, same packed weights; 10 = the blocked-GEMM kernel for 1x1 stride 1 / 2
  * and the 2x2 stride-1 sub-pixel phases of the transposed convolution - Cin a multiple of 16, Cout >= 96, planes a multiple of 4
- * pixels, one residual tensor, same packed weights; 9 is the host tuner's index of the Winograd form, which has its own entry
+ * pixels, one residual tensor, same packed weights; 11 = the K-split kernel for SMALL problems - 3x3 pad 1 stride 1 / 2 and 1x1 stride 1 (a handful of
+ * crops: 16 couts x 16 pixels per workgroup, its eight waves split the k loop - csrc/conv_small_f32.hip; at most 1024 workgroups,
+ * up to two residual tensors, same packed weights); 9 is the host tuner's index of the Winograd form, which has its own entry
  * points below; -1 = library heuristic).  Returns MP_ERR_UNSUPPORTED when that variant cannot run the shape.  Used by the host-side autotuner, which times the candidates once per distinct layer shape. */
 int mp_conv2d_fwd_variant(const mp_conv_desc* desc, int variant, const float* x_dev, const float* packed_w_dev,
                           const float* scale_dev, const float* shift_dev, const float* res1_dev, const float* res2_dev,

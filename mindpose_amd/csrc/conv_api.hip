@@ -11,6 +11,7 @@
 #include "conv_wino.h"
 #include "conv_stem.h"
 #include "conv_gemm.h"
+#include "conv_small.h"
 
 namespace mp {
 
@@ -125,9 +126,12 @@ struct ConvLaunch {
     PwLaunch pw;
     bool gemm;       // variant kGemm: the blocked-GEMM 1x1 kernel (conv_gemm_f32.hip), launch record in gm
     GemmLaunch gm;
+    bool small_k;    // variant kSmall: the K-split 3x3 kernel for small problems (conv_small_f32.hip), launch record in sm
+    SmallLaunch sm;
 };
 
 constexpr int kGemm = V_COUNT + 2;   // forced-variant index of the blocked-GEMM 1x1 kernel (V_COUNT + 1 is the tuner's index of the Winograd form)
+constexpr int kSmall = V_COUNT + 3;  // forced-variant index of the K-split small-problem 3x3 kernel (the tuner's index 11)
 constexpr int kPointwise = V_COUNT;  // forced-variant index of the streaming 1x1 kernel (never chosen by the library heuristic)
 
 static const int kLdsMax = 150 * 1024;
@@ -240,6 +244,14 @@ static int choose_variant(const mp_conv_desc& d, ConvLaunch& best, int forced = 
         best.lds_bytes = best.gm.lds_bytes;
         return MP_OK;
     }
+    if (forced == kSmall) {
+        int rc = small_configure(&d, best.sm);
+        if (rc != MP_OK) return rc;
+        best.small_k = true;
+        best.ks = d.kh; best.stride = d.stride; best.variant = kSmall;
+        best.lds_bytes = best.sm.lds_bytes;
+        return MP_OK;
+    }
     if (forced >= 0) {
         if (forced >= V_COUNT) return MP_ERR_UNSUPPORTED;
         return configure(d, forced, best) ? MP_OK : MP_ERR_UNSUPPORTED;
@@ -298,6 +310,7 @@ static int validate_desc(const mp_conv_desc* d) {
 static int launch(const ConvLaunch& L0, hipStream_t s) {
     if (L0.pointwise) return pw_launch(L0.pw, s);
     if (L0.gemm) return gemm_launch(L0.gm, s);
+    if (L0.small_k) return small_launch(L0.sm, s);
     ConvLaunch L = L0;
     L.p.dbg = (g_stamp_buf && (size_t)L.p.total_blocks * 64 <= g_stamp_bytes) ? g_stamp_buf : nullptr;
     switch (L.ks) {
@@ -325,6 +338,10 @@ static int build_launch(const mp_conv_desc* desc, const float* x, const float* w
     }
     if (L.gemm) {
         L.gm.p.x = x; L.gm.p.wp = w; L.gm.p.scale = scale; L.gm.p.shift = shift; L.gm.p.res1 = res1; L.gm.p.res2 = res2; L.gm.p.out = out;
+        return MP_OK;
+    }
+    if (L.small_k) {
+        L.sm.p.x = x; L.sm.p.wp = w; L.sm.p.scale = scale; L.sm.p.shift = shift; L.sm.p.res1 = res1; L.sm.p.res2 = res2; L.sm.p.out = out;
         return MP_OK;
     }
     L.p.x = x; L.p.wp = w; L.p.scale = scale; L.p.shift = shift; L.p.res1 = res1; L.p.res2 = res2; L.p.out = out;
@@ -743,6 +760,9 @@ int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]) {
     } else if (e.kind == 0 && e.conv.gemm) {
         info[1] = e.conv.ks; info[2] = e.conv.gm.stride; info[3] = kGemm; info[11] = e.conv.gm.gather ? 1 : 0; info[4] = (int64_t)e.conv.gm.grid * e.conv.gm.phases; info[5] = (int64_t)e.conv.gm.lds_bytes;
         info[6] = 64 * e.conv.gm.mi; info[7] = 64 * e.conv.gm.ni; info[8] = 16; info[9] = e.conv.gm.phases; info[10] = 1;
+    } else if (e.kind == 0 && e.conv.small_k) {
+        info[1] = e.conv.ks; info[2] = e.conv.stride; info[3] = kSmall; info[4] = e.conv.sm.grid; info[5] = (int64_t)e.conv.sm.lds_bytes;
+        info[6] = 16; info[7] = 16; info[8] = e.conv.sm.p.Cin_pad4; info[9] = 1; info[10] = e.conv.sm.p.rows;
     } else if (e.kind == 0) {
         int ct, pt;
         variant_dims(e.conv.variant, ct, pt);

@@ -1,0 +1,212 @@
+// fp32 3x3 (stride 1 / 2, pad 1) and 1x1 convolution for SMALL problems - a handful of crops (N in {1, 32}; a top-down pipeline serves
+// the people of one frame) - HRNet's branch convs hrnet.py:51-64, 202-241 in eval mode with the BatchNorm folded.
+//
+// Why another form: at N = 1 the 128 / 256-channel layers are 48 - 192 output pixels against 1.2 - 2.4 MB of weights.  The tile kernels
+// (32 - 64 couts x 96 - 192 pixels, the whole k loop in one workgroup) and the Winograd kernel put such a layer on FOUR to EIGHT
+// workgroups for 32 - 60 us (profiles/r05_d_timeline_infer_f32_n1.json: 80 of those launches are 3.2 of the step's 4.6 ms of kernel
+// time).  Here the layer is cut the other way: a workgroup = 16 couts x 16 consecutive pixels of one image, and its eight waves SPLIT K
+// (wave w takes the cin quads q = w, w + 8, ...: the same 16 x 16 tile, an eighth of the 9 Cin / 4 k-steps each), folded through LDS in
+// wave order (bit-reproducible).  256 -> 256 @8x6, one crop: 48 workgroups of 72 MFMAs per wave instead of 8 of 3456.
+//   * A operand (weights, v_mfma_f32_16x16x4_f32: lane = (cout row l % 16, k l / 16)) straight from the direct kernel's packing
+//     [cin quad][tap][4][Cout_pad16] - 16 consecutive floats per k row, one dword per lane and k-step, eight k-steps in flight;
+//   * B operand (pixels) from an LDS image of the rows the tile touches (+ halo, zeros outside the map) of ALL input channels,
+//     staged once per workgroup: [cin][row][W + 2], plane pitch = 16 mod 32 floats (the four k rows of a step hit four bank groups);
+//   * epilogue by wave 0: scale / shift, up to two residuals, ReLU, 64-byte runs of one cout's 16 pixels.
+// The tuner times it as fp32 variant 11 next to the direct, Winograd and GEMM forms; it wins where the launch would otherwise
+// cover a few CUs, and loses (many workgroups re-staging the same rows) where the other forms fill the chip.
+#include "conv_small.h"
+
+namespace mp {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline unsigned magic_of(unsigned d) { return d <= 1 ? 0u : (unsigned)(0x100000000ULL / d) + 1u; }
+__device__ __forceinline__ unsigned fdiv(unsigned e, unsigned d, unsigned magic) { return d == 1 ? e : __umulhi(e, magic); }
+
+// weight k-steps in flight per wave = four cin quads x the taps (3x3: 36 dwords per lane, 9 KB per wave - the k loop is a weight
+// STREAM: with eight in flight the 256-channel layer took 44 us)
+
+constexpr int kWaves = 8;  // K is split eight ways: the 256-channel layer's 576 k-steps = 72 per wave = two fills of the weight ring
+
+template <int KS, int S>
+__global__ __launch_bounds__(64 * kWaves) void conv_small_f32_kernel(const SmallParams p) {
+    constexpr int T = KS * KS, PAD = KS / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lk = lane >> 4;  // MFMA row / column index, k index (inputs) = row group (outputs)
+
+    // block -> (cout tile, image, pixel tile): the cout tiles of one pixel tile are neighbours (they stage the same rows: one L2)
+    const unsigned b = blockIdx.x;
+    const unsigned pt = fdiv(b, (unsigned)p.n_ct, p.magic_nct);
+    const int ct = (int)(b - pt * p.n_ct);
+    const unsigned n = fdiv(pt, (unsigned)p.tiles_img, p.magic_tiles);
+    const int tile = (int)(pt - n * p.tiles_img);
+    const int p0 = tile * 16;                        // first pixel of the tile (flattened y * W + x)
+    const int y_first = (int)fdiv((unsigned)p0, (unsigned)p.W, p.magic_w);
+    const int row0 = S * y_first - PAD;              // input row of staged row 0
+
+    // ---- this lane's pixel (B operand column lr) and weight row (A operand row lr)
+    const int px = p0 + lr;
+    const bool px_ok = px < p.HW;
+    const int py = (int)fdiv((unsigned)(px_ok ? px : p0), (unsigned)p.W, p.magic_w);
+    const int pxx = (px_ok ? px : p0) - py * p.W;
+    // window origin (tap 0 = input row S py - PAD, column S pxx - PAD) inside the staged plane (staged column 0 = input column -PAD)
+    const unsigned b_base = (unsigned)(lk * p.plane + (S * py - PAD - row0) * p.Wp + S * pxx);
+    const float* __restrict__ wrow = p.wp + (size_t)lk * p.Cout_pad16 + ct * 16 + lr;  // + ((q * T + t) * 4) * Cout_pad16 per k-step
+    const unsigned w_step = 4u * (unsigned)p.Cout_pad16;
+
+    // (requested BEFORE the staging loop: the first fill of the weight ring flies under it)
+    // this wave's k-steps: cin quads q = wave, wave + 8, ... ; per quad the nine taps.  Four quads (36 k-steps) of weights are in
+    // flight: slot (j, t) holds tap t of the wave's quad qi0 + j and is refilled for quad qi0 + j + 4 right behind its MFMA
+    // (every index below is a compile-time constant: the ring stays in registers)
+    const int nq = (p.kq - wave + kWaves - 1) / kWaves;  // quads of this wave
+    float a_reg[4 * T];
+    auto w_at = [&](int qi, int t) __attribute__((always_inline)) { return wrow[(size_t)((wave + kWaves * qi) * T + t) * w_step]; };
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < T; ++t) a_reg[j * T + t] = j < nq ? w_at(j, t) : 0.f;
+    // ---- stage: rows row0 .. row0 + rows - 1, columns -1 .. W (zeros outside the map).  Wave w reads ONLY the channels of its own cin
+    //      quads (q = w, w + 8, ...), so every wave stages exactly those planes itself - no workgroup barrier in front of the k loop -
+    //      with sixteen loads in flight per lane (a dependent load / store pair per element was most of the first version's 44 us)
+    {
+        const float* __restrict__ xin = p.x + (size_t)n * p.Cin * p.HWin;
+        const int per_plane = p.rows * p.Wp;
+        const int nq_w = (p.kq - wave + kWaves - 1) / kWaves;  // this wave's quads
+        const int total = nq_w * 4 * per_plane;       // elements of this wave's planes
+        constexpr int U = 16;
+        for (int i0 = lane; i0 < total; i0 += 64 * U) {
+            float v[U];
+            unsigned dst[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + 64 * u;
+                const unsigned cl = fdiv((unsigned)(i < total ? i : 0), (unsigned)per_plane, p.magic_per_plane);  // plane index inside the wave's set
+                const unsigned e = (unsigned)(i < total ? i : 0) - cl * per_plane;
+                const unsigned ci = (unsigned)(wave + kWaves * (cl >> 2)) * 4u + (cl & 3u);
+                const unsigned r = fdiv(e, (unsigned)p.Wp, p.magic_wp);
+                const int c = (int)(e - r * p.Wp) - PAD, y = row0 + (int)r;
+                const bool ok = i < total && (int)ci < p.Cin && y >= 0 && y < p.Hin && c >= 0 && c < p.Win;
+                v[u] = ok ? xin[(size_t)ci * p.HWin + y * p.Win + c] : 0.f;
+                dst[u] = i < total ? ci * p.plane + e : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (dst[u] != 0xFFFFFFFFu) smem[dst[u]] = v[u];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // this wave's own LDS stores above are read back by its other lanes
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int qi0 = 0; qi0 < nq; qi0 += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int qi = qi0 + j;
+            if (qi < nq) {  // wave-uniform
+                const unsigned q_off = b_base + (unsigned)((wave + kWaves * qi) * 4 * p.plane);
+                float bv[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) bv[t] = smem[q_off + (unsigned)((t / KS) * p.Wp + (t % KS))];
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const float av = a_reg[j * T + t];
+                    if (qi + 4 < nq) a_reg[j * T + t] = w_at(qi + 4, t);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], acc, 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- fold the four K quarters through LDS in wave order (the staged image is dead: every wave has passed its last read)
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(smem);
+    if (wave > 0) red[(wave - 1) * 64 + lane] = acc;
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int k = 0; k < kWaves - 1; ++k) acc = acc + red[k * 64 + lane];  // wave 1, 2, ... in order
+    // ---- epilogue: lane = (pixel column lr, cout rows 4 lk .. 4 lk + 3)
+    if (!px_ok) return;
+    const int co0 = ct * 16 + lk * 4;
+    const size_t o_img = (size_t)n * p.Cout * p.HW + px;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int co = co0 + j;
+        if (co >= p.Cout) break;
+        float v = acc[j] * p.scale[co] + p.shift[co];
+        const size_t o = o_img + (size_t)co * p.HW;
+        if (p.res1) v += p.res1[o];
+        if (p.res2) v += p.res2[o];
+        if (p.relu) v = fmaxf(v, 0.f);
+        p.out[o] = v;
+    }
+}
+
+}  // namespace
+
+int small_configure(const mp_conv_desc* d, SmallLaunch& L) {
+    if (!d) return MP_ERR_NULL;
+    if (d->n <= 0 || d->cin <= 0 || d->cout <= 0 || d->h <= 0 || d->w <= 0) return MP_ERR_SHAPE;
+    // built forms: 3x3 pad 1 stride 1 / 2 (branch convs; transition / exchange-unit down-paths), 1x1 stride 1 (exchange-unit up-paths, head)
+    const bool k3 = d->kh == 3 && d->kw == 3 && (d->stride == 1 || d->stride == 2) && d->pad_top == 1 && d->pad_left == 1;
+    const bool k1 = d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_top == 0 && d->pad_left == 0;
+    if (!k3 && !k1) return MP_ERR_UNSUPPORTED;
+    const int ho = (d->h + 2 * d->pad_top - d->kh) / d->stride + 1, wo = (d->w + 2 * d->pad_left - d->kw) / d->stride + 1;
+    if (d->conv_h != ho || d->conv_w != wo || d->out_h != ho || d->out_w != wo) return MP_ERR_UNSUPPORTED;
+    if (d->out_mul != 1 || d->out_rep != 1 || d->out_off_y != 0 || d->out_off_x != 0 || d->flags) return MP_ERR_UNSUPPORTED;
+    SmallParams& p = L.p;
+    p.N = d->n; p.Cin = d->cin; p.Cin_pad4 = (d->cin + 3) / 4 * 4; p.Cout = d->cout; p.Cout_pad16 = (d->cout + 15) / 16 * 16;
+    p.H = ho; p.W = wo; p.HW = ho * wo;
+    p.Hin = d->h; p.Win = d->w; p.HWin = d->h * d->w;
+    p.ks = d->kh; p.stride = d->stride; p.pad = d->pad_top;
+    p.Wp = d->stride * (wo - 1) + d->kh;
+    int span = (16 + wo - 2) / wo + 1;  // output rows 16 consecutive pixels can touch
+    if (span > ho) span = ho;
+    p.rows = d->stride * (span - 1) + d->kh;
+    const int raw = p.rows * p.Wp;
+    int plane = (raw + 15) / 32 * 32 + 16;  // smallest value >= raw that is 16 (mod 32)
+    if (plane - 32 >= raw) plane -= 32;
+    p.plane = plane;
+    p.tiles_img = (p.HW + 15) / 16;
+    p.n_ct = p.Cout_pad16 / 16;
+    p.kq = p.Cin_pad4 / 4;
+    p.relu = d->relu;
+    p.magic_w = magic_of((unsigned)p.W);
+    p.magic_wp = magic_of((unsigned)p.Wp);
+    p.magic_tiles = magic_of((unsigned)p.tiles_img);
+    p.magic_nct = magic_of((unsigned)p.n_ct);
+    p.magic_per_plane = magic_of((unsigned)(p.rows * p.Wp));
+    const long long blocks = (long long)p.N * p.tiles_img * p.n_ct;
+    // what the form is for: launches the tile kernels would put on a few CUs.  Beyond ~1 k workgroups the other forms fill the
+    // chip and stage each input row once instead of once per cout tile - and the tuner, which times a launch ALONE, would pick this
+    // form for layers where it only wins alone (same-box A/B at N = 32: 5.20 ms without it, 5.43 ms with the bound at 2 k or 16 k)
+    if (blocks > 1024) return MP_ERR_UNSUPPORTED;
+    if ((long long)p.N * p.Cin * p.HWin >= (1LL << 31) || (long long)p.N * p.Cout * p.HW >= (1LL << 31)) return MP_ERR_UNSUPPORTED;
+    L.grid = (int)blocks;
+    L.lds_bytes = (size_t)p.Cin_pad4 * p.plane * 4;
+    if (L.lds_bytes < 7 * 64 * 16) L.lds_bytes = 7 * 64 * 16;  // the fold's seven accumulator tiles
+    if (L.lds_bytes > 150 * 1024) return MP_ERR_UNSUPPORTED;
+    return MP_OK;
+}
+
+template <int KS, int S>
+static int small_launch_ks(const SmallLaunch& L, hipStream_t s) {
+    static AttrOnce attr_set_once;
+    if (attr_set_once.need()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_small_f32_kernel<KS, S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+    }
+    hipLaunchKernelGGL((conv_small_f32_kernel<KS, S>), dim3(L.grid), dim3(64 * kWaves), L.lds_bytes, s, L.p);
+    return check_launch();
+}
+
+int small_launch(const SmallLaunch& L, hipStream_t s) {
+    if (L.p.ks == 3) return L.p.stride == 1 ? small_launch_ks<3, 1>(L, s) : small_launch_ks<3, 2>(L, s);
+    return small_launch_ks<1, 1>(L, s);
+}
+
+}  // namespace mp

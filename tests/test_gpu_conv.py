@@ -618,3 +618,107 @@ def test_fp32_plan_takes_the_streaming_stem(monkeypatch):
         kinds[flag] = [e["kind"] for e in next(iter(net._plans.values())).layer_info]
     assert kinds["1"].count("stem_f32") == 1 and kinds["0"].count("stem_f32") == 0 and len(kinds["1"]) == len(kinds["0"])
     assert _nerr(outs["1"], outs["0"]) < 2e-5
+
+
+SMALL_CASES = [
+    # n, cin, cout, h, w, relu, n_res, k, stride - layers at the sizes a handful of crops gives them (hrnet.py:51-64, 202-241, 280-344)
+    (1, 256, 256, 8, 6, True, 1, 3, 1),     # branch 3, one crop: 48 pixels = three 16-pixel tiles, 64 cin quads over eight waves
+    (1, 128, 128, 16, 12, True, 1, 3, 1),   # branch 2
+    (2, 64, 64, 32, 24, True, 2, 3, 1),     # branch 1, both residuals
+    (1, 32, 32, 64, 48, False, 0, 3, 1),    # branch 0
+    (3, 24, 40, 7, 5, True, 1, 3, 1),       # ragged: 35 pixels per image (a padded last tile), cout % 16 != 0, 6 cin quads (idle K waves)
+    (2, 6, 16, 3, 20, False, 0, 3, 1),      # cin % 4 != 0 (padding channel), a tile inside one row, H smaller than the row span
+    (5, 48, 96, 5, 3, True, 0, 3, 1),       # 15 pixels per image: one partly filled tile, tiles span all five rows
+    (1, 32, 64, 64, 48, True, 0, 3, 2),     # exchange-unit down-path 32 -> 64 (stride 2): staged rows / columns at twice the pitch
+    (2, 64, 128, 32, 24, False, 2, 3, 2),   # ... with the running sum and the identity as residuals
+    (2, 16, 24, 9, 7, True, 1, 3, 2),       # stride 2 on odd extents (5 x 4 outputs)
+    (1, 256, 32, 8, 6, False, 0, 1, 1),     # exchange-unit up-path 1x1 (256 -> 32 at the low resolution)
+    (3, 64, 17, 12, 10, False, 0, 1, 1),    # 1x1 with 17 couts (the head's shape class), 120 pixels per image
+]
+
+
+@pytest.mark.parametrize("case", SMALL_CASES, ids=[f"n{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}_k{c[7]}s{c[8]}" for c in SMALL_CASES])
+def test_small_problem_kernel_vs_torch_and_direct(case):
+    """Forced variant 11 of mp_conv2d_fwd_variant (csrc/conv_small_f32.hip: 16 couts x 16 pixels per workgroup, the eight waves split
+    the k loop and fold through LDS in wave order; 3x3 stride 1 / 2 and 1x1) on the direct kernel's packed weights - against fp64
+    torch at the direct kernel's bar, against the direct kernel, bit-reproducible run to run, and as a plan entry."""
+    import ctypes
+    from mindpose_amd import _lib
+    n, cin, cout, h, w, relu, n_res, k, stride = case
+    pad = k // 2
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(cin * 7 + cout + h + stride)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    res = [torch.randn(n, cout, ho, wo, generator=g) for _ in range(n_res)]
+    ref = F.conv2d(x.double(), wt.double(), stride=stride, padding=pad) * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]
+    for r in res:
+        ref = ref + r.double()
+    if relu:
+        ref = F.relu(ref)
+    d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=k, kw=k, stride=stride, pad_top=pad, pad_left=pad, conv_h=ho, conv_w=wo, out_h=ho,
+                      out_w=wo, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=int(relu), flags=0)
+    st = _lib.stream()
+    xd, wd = x.to(DEV), wt.to(DEV)
+    padc = (-cout) % 16
+    sc, sh = torch.cat([scale, torch.zeros(padc)]).to(DEV), torch.cat([shift, torch.zeros(padc)]).to(DEV)
+    rd = [r.to(DEV) for r in res] + [None, None]
+    pk = torch.empty(lib.mp_conv_packed_weight_bytes(cout, cin, k, k) // 4, device=DEV)
+    _lib.check(lib.mp_conv_pack_weight(_lib.ptr(wd), _lib.ptr(pk), cout, cin, k, k, 0, 0, 0, st), "pack")
+
+    def run(variant):
+        out = torch.full((n, cout, ho, wo), float("nan"), device=DEV)
+        _lib.check(lib.mp_conv2d_fwd_variant(ctypes.byref(d), variant, _lib.ptr(xd), _lib.ptr(pk), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(rd[0]),
+                                             _lib.ptr(rd[1]), _lib.ptr(out), st), f"variant {variant}")
+        torch.cuda.synchronize()
+        return out
+
+    out = run(11)
+    assert torch.isfinite(out).all()  # every element written
+    assert _nerr(out.double().cpu(), ref) <= 2e-5
+    assert _nerr(out.double().cpu(), run(-1).double().cpu()) <= 2e-5
+    assert torch.equal(out, run(11))  # fixed fold order: the same bits every launch
+    # in place on the first residual (the accumulate-into form of the exchange unit)
+    if n_res:
+        acc = rd[0].clone()
+        _lib.check(lib.mp_conv2d_fwd_variant(ctypes.byref(d), 11, _lib.ptr(xd), _lib.ptr(pk), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(acc),
+                                             _lib.ptr(rd[1]), _lib.ptr(acc), st), "in place")
+        torch.cuda.synchronize()
+        assert torch.equal(acc, out)
+    # as a plan entry
+    plan = lib.mp_plan_create()
+    try:
+        out_p = torch.empty_like(out)
+        _lib.check(lib.mp_plan_add_conv_variant(plan, ctypes.byref(d), 11, _lib.ptr(xd), _lib.ptr(pk), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(rd[0]),
+                                                _lib.ptr(rd[1]), _lib.ptr(out_p)), "plan add")
+        _lib.check(lib.mp_plan_run(plan, st), "plan run")
+        torch.cuda.synchronize()
+        assert torch.equal(out_p, out)
+    finally:
+        lib.mp_plan_destroy(plan)
+
+
+def test_small_problem_kernel_rejects_what_it_does_not_cover():
+    import ctypes
+    from mindpose_amd import _lib
+    lib = _lib.load()
+    buf = torch.zeros(1 << 20, device=DEV)
+
+    def rc(**kw):
+        base = dict(n=1, cin=64, h=8, w=8, cout=64, kh=3, kw=3, stride=1, pad_top=1, pad_left=1, conv_h=8, conv_w=8, out_h=8, out_w=8,
+                    out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=0, flags=0)
+        base.update(kw)
+        d = _lib.ConvDesc(**base)
+        return lib.mp_conv2d_fwd_variant(ctypes.byref(d), 11, _lib.ptr(buf), _lib.ptr(buf), _lib.ptr(buf), _lib.ptr(buf), None, None,
+                                         _lib.ptr(buf), _lib.stream())
+
+    assert rc() == 0
+    assert rc(kh=1, kw=1, pad_top=0, pad_left=0) == 0 and rc(stride=2, conv_h=4, conv_w=4, out_h=4, out_w=4) == 0  # built forms
+    assert rc(kh=1, kw=1, pad_top=0, pad_left=0, stride=2, conv_h=4, conv_w=4, out_h=4, out_w=4) == -3    # 1x1 stride 2
+    assert rc(kh=2, kw=2, pad_top=0, pad_left=0, conv_h=7, conv_w=7, out_h=7, out_w=7) == -3              # 2x2 phase convs
+    assert rc(n=128, h=64, w=48, conv_h=64, conv_w=48, out_h=64, out_w=48) == -3        # a chip-filling problem: the other forms' job
+    assert rc(n=6, h=32, w=24, conv_h=32, conv_w=24, out_h=32, out_w=24) == -3           # 6 images x 48 pixel tiles x 4 cout tiles = 1152 > 1024 workgroups
+    assert rc(n=5, h=32, w=24, conv_h=32, conv_w=24, out_h=32, out_w=24) == 0
+    assert rc(out_mul=2, out_h=16, out_w=16) == -3                                      # no scatter mapping
