@@ -103,8 +103,8 @@ def kernel_name(info):
         if v >= 10:
             return f"conv_f16_mt_kernel<{info['ks']},{info['stride']},{F16_VARIANT_TEMPLATE[v % 5]}>/occ{1 if v >= 15 else 2}"
         return f"conv_f16_kernel<{info['ks']},{info['stride']},{F16_VARIANT_TEMPLATE[v]}>" + ("/occ3" if info.get("light") else "")
-    if info["variant"] == 11:  # K-split 3x3 kernel for small problems (conv_small_f32.hip)
-        return f"conv_small_f32_kernel<{info['ks']},{info['stride']}>"
+    if info["variant"] in (11, 12):  # K-split kernel for small problems (conv_small_f32.hip): <KS, S, 16-pixel tiles per workgroup>
+        return f"conv_small_f32_kernel<{info['ks']},{info['stride']},{info.get('pixel_tile', 16) // 16}>"
     if info["variant"] == 10:  # blocked-GEMM kernel <GATHER (stride 2 / 2x2 phases; entry_info: light), 32-column blocks per wave>
         return f"conv1x1_f32_gemm_kernel<{'true' if info.get('light', 0) else 'false'},{info.get('pixel_tile', 128) // 64},{info.get('cout_tile', 128) // 64}>"
     if info["variant"] == 8:  # streaming 1x1 kernel <Cin / 4, cout blocks per wave> (entry_info: light = Cin / 4, images_per_tile = CBW)

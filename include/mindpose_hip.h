@@ -175,7 +175,8 @@ int mp_conv2d_fwd(const mp_conv_desc* desc, const float* x_dev, const float* pac
  * and the 2x2 stride-1 sub-pixel phases of the transposed convolution - Cin a multiple of 16, Cout >= 96, planes a multiple of 4
  * pixels, one residual tensor, same packed weights; 11 = the K-split kernel for SMALL problems - 3x3 pad 1 stride 1 / 2 and 1x1 stride 1 (a handful of
  * crops: 16 couts x 16 pixels per workgroup, its eight waves split the k loop - csrc/conv_small_f32.hip; at most 1024 workgroups,
- * up to two residual tensors, same packed weights); 9 is the host tuner's index of the Winograd form, which has its own entry
+ * up to two residual tensors, same packed weights), 12 = the same kernel with 48 / 64 pixels per workgroup (a few dozen crops; at
+ * most 2048 workgroups; bit-identical to 11); 9 is the host tuner's index of the Winograd form, which has its own entry
  * points below; -1 = library heuristic).  Returns MP_ERR_UNSUPPORTED when that variant cannot run the shape.  Used by the host-side autotuner, which times the candidates once per distinct layer shape. */
 int mp_conv2d_fwd_variant(const mp_conv_desc* desc, int variant, const float* x_dev, const float* packed_w_dev,
                           const float* scale_dev, const float* shift_dev, const float* res1_dev, const float* res2_dev,

@@ -244,11 +244,11 @@ static int choose_variant(const mp_conv_desc& d, ConvLaunch& best, int forced = 
         best.lds_bytes = best.gm.lds_bytes;
         return MP_OK;
     }
-    if (forced == kSmall) {
-        int rc = small_configure(&d, best.sm);
+    if (forced == kSmall || forced == kSmall + 1) {  // + 1: the wide form (48 / 64 pixels per workgroup)
+        int rc = small_configure(&d, best.sm, forced - kSmall);
         if (rc != MP_OK) return rc;
         best.small_k = true;
-        best.ks = d.kh; best.stride = d.stride; best.variant = kSmall;
+        best.ks = d.kh; best.stride = d.stride; best.variant = forced;
         best.lds_bytes = best.sm.lds_bytes;
         return MP_OK;
     }
@@ -761,8 +761,8 @@ int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]) {
         info[1] = e.conv.ks; info[2] = e.conv.gm.stride; info[3] = kGemm; info[11] = e.conv.gm.gather ? 1 : 0; info[4] = (int64_t)e.conv.gm.grid * e.conv.gm.phases; info[5] = (int64_t)e.conv.gm.lds_bytes;
         info[6] = 64 * e.conv.gm.mi; info[7] = 64 * e.conv.gm.ni; info[8] = 16; info[9] = e.conv.gm.phases; info[10] = 1;
     } else if (e.kind == 0 && e.conv.small_k) {
-        info[1] = e.conv.ks; info[2] = e.conv.stride; info[3] = kSmall; info[4] = e.conv.sm.grid; info[5] = (int64_t)e.conv.sm.lds_bytes;
-        info[6] = 16; info[7] = 16; info[8] = e.conv.sm.p.Cin_pad4; info[9] = 1; info[10] = e.conv.sm.p.rows;
+        info[1] = e.conv.ks; info[2] = e.conv.stride; info[3] = e.conv.variant; info[4] = e.conv.sm.grid; info[5] = (int64_t)e.conv.sm.lds_bytes;
+        info[6] = 16; info[7] = 16 * e.conv.sm.p.pt; info[8] = e.conv.sm.p.Cin_pad4; info[9] = 1; info[10] = e.conv.sm.p.rows;
     } else if (e.kind == 0) {
         int ct, pt;
         variant_dims(e.conv.variant, ct, pt);

@@ -18,7 +18,8 @@ struct SmallParams {
     int HW, Wp;          // Wp: a staged input row with its halo columns (stride * (W - 1) + ks)
     int rows;            // staged input rows per tile: what the output rows 16 consecutive pixels can span need
     int plane;           // floats per staged channel plane (rows * Wp, padded to 16 mod 32)
-    int tiles_img;       // 16-pixel tiles per image
+    int pt;              // 16-pixel tiles per workgroup (1; the wide form: 3 or 4)
+    int tiles_img;       // workgroup tiles (16 pt pixels) per image
     int n_ct;            // 16-cout tiles
     int kq;              // Cin_pad4 / 4: k-steps of one tap
     int relu;
@@ -31,7 +32,7 @@ struct SmallLaunch {
     size_t lds_bytes;
 };
 
-int small_configure(const mp_conv_desc* d, SmallLaunch& L);  // MP_OK / MP_ERR_UNSUPPORTED; pointers left null
+int small_configure(const mp_conv_desc* d, SmallLaunch& L, int wide);  // wide: 48 / 64 pixels per workgroup;  // MP_OK / MP_ERR_UNSUPPORTED; pointers left null
 int small_launch(const SmallLaunch& L, hipStream_t s);
 
 }  // namespace mp

@@ -30,7 +30,10 @@ __device__ __forceinline__ unsigned fdiv(unsigned e, unsigned d, unsigned magic)
 
 constexpr int kWaves = 8;  // K is split eight ways: the 256-channel layer's 576 k-steps = 72 per wave = two fills of the weight ring
 
-template <int KS, int S>
+// PT = 16-pixel tiles per workgroup (consecutive pixels of one image): 1 for a handful of crops (most workgroups); 3 / 4 when the
+// batch is large enough that every workgroup re-streaming its 16 couts' weights becomes the cost (N = 8 ... 32: the weights of a
+// workgroup then serve 48 / 64 pixels)
+template <int KS, int S, int PT>
 __global__ __launch_bounds__(64 * kWaves) void conv_small_f32_kernel(const SmallParams p) {
     constexpr int T = KS * KS, PAD = KS / 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -44,17 +47,21 @@ __global__ __launch_bounds__(64 * kWaves) void conv_small_f32_kernel(const Small
     const int ct = (int)(b - pt * p.n_ct);
     const unsigned n = fdiv(pt, (unsigned)p.tiles_img, p.magic_tiles);
     const int tile = (int)(pt - n * p.tiles_img);
-    const int p0 = tile * 16;                        // first pixel of the tile (flattened y * W + x)
+    const int p0 = tile * 16 * PT;                   // first pixel of the workgroup's tiles (flattened y * W + x)
     const int y_first = (int)fdiv((unsigned)p0, (unsigned)p.W, p.magic_w);
     const int row0 = S * y_first - PAD;              // input row of staged row 0
 
-    // ---- this lane's pixel (B operand column lr) and weight row (A operand row lr)
-    const int px = p0 + lr;
-    const bool px_ok = px < p.HW;
-    const int py = (int)fdiv((unsigned)(px_ok ? px : p0), (unsigned)p.W, p.magic_w);
-    const int pxx = (px_ok ? px : p0) - py * p.W;
-    // window origin (tap 0 = input row S py - PAD, column S pxx - PAD) inside the staged plane (staged column 0 = input column -PAD)
-    const unsigned b_base = (unsigned)(lk * p.plane + (S * py - PAD - row0) * p.Wp + S * pxx);
+    // ---- this lane's pixels (B operand column lr of every tile) and weight row (A operand row lr)
+    int px[PT];
+    unsigned b_base[PT];  // window origin (tap 0 = input row S py - PAD, column S pxx - PAD) in the staged plane (column 0 = input column -PAD)
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        px[i] = p0 + 16 * i + lr;
+        const int pv = px[i] < p.HW ? px[i] : p0;
+        const int py = (int)fdiv((unsigned)pv, (unsigned)p.W, p.magic_w);
+        const int pxx = pv - py * p.W;
+        b_base[i] = (unsigned)(lk * p.plane + (S * py - PAD - row0) * p.Wp + S * pxx);
+    }
     const float* __restrict__ wrow = p.wp + (size_t)lk * p.Cout_pad16 + ct * 16 + lr;  // + ((q * T + t) * 4) * Cout_pad16 per k-step
     const unsigned w_step = 4u * (unsigned)p.Cout_pad16;
 
@@ -102,53 +109,66 @@ __global__ __launch_bounds__(64 * kWaves) void conv_small_f32_kernel(const Small
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[PT];
+#pragma unroll
+    for (int i = 0; i < PT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int qi0 = 0; qi0 < nq; qi0 += 4) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int qi = qi0 + j;
             if (qi < nq) {  // wave-uniform
-                const unsigned q_off = b_base + (unsigned)((wave + kWaves * qi) * 4 * p.plane);
-                float bv[T];
+                const unsigned q_off = (unsigned)((wave + kWaves * qi) * 4 * p.plane);
+                float bv[PT][T];
 #pragma unroll
-                for (int t = 0; t < T; ++t) bv[t] = smem[q_off + (unsigned)((t / KS) * p.Wp + (t % KS))];
+                for (int i = 0; i < PT; ++i)
+#pragma unroll
+                    for (int t = 0; t < T; ++t) bv[i][t] = smem[b_base[i] + q_off + (unsigned)((t / KS) * p.Wp + (t % KS))];
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
                     const float av = a_reg[j * T + t];
                     if (qi + 4 < nq) a_reg[j * T + t] = w_at(qi + 4, t);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], acc, 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < PT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[i][t], acc[i], 0, 0, 0);
                 }
             }
         }
     }
-    // ---- fold the four K quarters through LDS in wave order (the staged image is dead: every wave has passed its last read)
+    // ---- fold the K parts through LDS in wave order (the staged image is dead: every wave has passed its last read)
     __syncthreads();
     f32x4* red = reinterpret_cast<f32x4*>(smem);
-    if (wave > 0) red[(wave - 1) * 64 + lane] = acc;
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < PT; ++i) red[((wave - 1) * PT + i) * 64 + lane] = acc[i];
+    }
     __syncthreads();
     if (wave != 0) return;
 #pragma unroll
-    for (int k = 0; k < kWaves - 1; ++k) acc = acc + red[k * 64 + lane];  // wave 1, 2, ... in order
-    // ---- epilogue: lane = (pixel column lr, cout rows 4 lk .. 4 lk + 3)
-    if (!px_ok) return;
-    const int co0 = ct * 16 + lk * 4;
-    const size_t o_img = (size_t)n * p.Cout * p.HW + px;
+    for (int k = 0; k < kWaves - 1; ++k)  // wave 1, 2, ... in order
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int co = co0 + j;
-        if (co >= p.Cout) break;
-        float v = acc[j] * p.scale[co] + p.shift[co];
-        const size_t o = o_img + (size_t)co * p.HW;
-        if (p.res1) v += p.res1[o];
-        if (p.res2) v += p.res2[o];
-        if (p.relu) v = fmaxf(v, 0.f);
-        p.out[o] = v;
+        for (int i = 0; i < PT; ++i) acc[i] = acc[i] + red[(k * PT + i) * 64 + lane];
+    // ---- epilogue: lane = (pixel column lr, cout rows 4 lk .. 4 lk + 3)
+    const int co0 = ct * 16 + lk * 4;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        if (px[i] >= p.HW) continue;
+        const size_t o_img = (size_t)n * p.Cout * p.HW + px[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int co = co0 + j;
+            if (co >= p.Cout) break;
+            float v = acc[i][j] * p.scale[co] + p.shift[co];
+            const size_t o = o_img + (size_t)co * p.HW;
+            if (p.res1) v += p.res1[o];
+            if (p.res2) v += p.res2[o];
+            if (p.relu) v = fmaxf(v, 0.f);
+            p.out[o] = v;
+        }
     }
 }
 
 }  // namespace
 
-int small_configure(const mp_conv_desc* d, SmallLaunch& L) {
+int small_configure(const mp_conv_desc* d, SmallLaunch& L, int wide) {
     if (!d) return MP_ERR_NULL;
     if (d->n <= 0 || d->cin <= 0 || d->cout <= 0 || d->h <= 0 || d->w <= 0) return MP_ERR_SHAPE;
     // built forms: 3x3 pad 1 stride 1 / 2 (branch convs; transition / exchange-unit down-paths), 1x1 stride 1 (exchange-unit up-paths, head)
@@ -164,14 +184,17 @@ int small_configure(const mp_conv_desc* d, SmallLaunch& L) {
     p.Hin = d->h; p.Win = d->w; p.HWin = d->h * d->w;
     p.ks = d->kh; p.stride = d->stride; p.pad = d->pad_top;
     p.Wp = d->stride * (wo - 1) + d->kh;
-    int span = (16 + wo - 2) / wo + 1;  // output rows 16 consecutive pixels can touch
+    // pixel tiles per workgroup: one; the wide form: a whole 48-pixel map (three) or 64 pixels (four)
+    p.pt = !wide ? 1 : (ho * wo <= 48 ? 3 : 4);
+    if (wide && ho * wo <= 16) return MP_ERR_UNSUPPORTED;
+    int span = (16 * p.pt + wo - 2) / wo + 1;  // output rows the workgroup's consecutive pixels can touch
     if (span > ho) span = ho;
     p.rows = d->stride * (span - 1) + d->kh;
     const int raw = p.rows * p.Wp;
     int plane = (raw + 15) / 32 * 32 + 16;  // smallest value >= raw that is 16 (mod 32)
     if (plane - 32 >= raw) plane -= 32;
     p.plane = plane;
-    p.tiles_img = (p.HW + 15) / 16;
+    p.tiles_img = (p.HW + 16 * p.pt - 1) / (16 * p.pt);
     p.n_ct = p.Cout_pad16 / 16;
     p.kq = p.Cin_pad4 / 4;
     p.relu = d->relu;
@@ -184,29 +207,39 @@ int small_configure(const mp_conv_desc* d, SmallLaunch& L) {
     // what the form is for: launches the tile kernels would put on a few CUs.  Beyond ~1 k workgroups the other forms fill the
     // chip and stage each input row once instead of once per cout tile - and the tuner, which times a launch ALONE, would pick this
     // form for layers where it only wins alone (same-box A/B at N = 32: 5.20 ms without it, 5.43 ms with the bound at 2 k or 16 k)
-    if (blocks > 1024) return MP_ERR_UNSUPPORTED;
+    if (blocks > (wide ? 2048 : 1024)) return MP_ERR_UNSUPPORTED;
     if ((long long)p.N * p.Cin * p.HWin >= (1LL << 31) || (long long)p.N * p.Cout * p.HW >= (1LL << 31)) return MP_ERR_UNSUPPORTED;
     L.grid = (int)blocks;
     L.lds_bytes = (size_t)p.Cin_pad4 * p.plane * 4;
-    if (L.lds_bytes < 7 * 64 * 16) L.lds_bytes = 7 * 64 * 16;  // the fold's seven accumulator tiles
+    if (L.lds_bytes < (size_t)7 * p.pt * 64 * 16) L.lds_bytes = (size_t)7 * p.pt * 64 * 16;  // the fold's seven accumulator sets
     if (L.lds_bytes > 150 * 1024) return MP_ERR_UNSUPPORTED;
     return MP_OK;
 }
 
-template <int KS, int S>
+template <int KS, int S, int PT>
 static int small_launch_ks(const SmallLaunch& L, hipStream_t s) {
     static AttrOnce attr_set_once;
     if (attr_set_once.need()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_small_f32_kernel<KS, S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_small_f32_kernel<KS, S, PT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
     }
-    hipLaunchKernelGGL((conv_small_f32_kernel<KS, S>), dim3(L.grid), dim3(64 * kWaves), L.lds_bytes, s, L.p);
+    hipLaunchKernelGGL((conv_small_f32_kernel<KS, S, PT>), dim3(L.grid), dim3(64 * kWaves), L.lds_bytes, s, L.p);
     return check_launch();
 }
 
+template <int KS, int S>
+static int small_launch_pt(const SmallLaunch& L, hipStream_t s) {
+    switch (L.p.pt) {
+        case 1: return small_launch_ks<KS, S, 1>(L, s);
+        case 3: return small_launch_ks<KS, S, 3>(L, s);
+        case 4: return small_launch_ks<KS, S, 4>(L, s);
+        default: return MP_ERR_UNSUPPORTED;
+    }
+}
+
 int small_launch(const SmallLaunch& L, hipStream_t s) {
-    if (L.p.ks == 3) return L.p.stride == 1 ? small_launch_ks<3, 1>(L, s) : small_launch_ks<3, 2>(L, s);
-    return small_launch_ks<1, 1>(L, s);
+    if (L.p.ks == 3) return L.p.stride == 1 ? small_launch_pt<3, 1>(L, s) : small_launch_pt<3, 2>(L, s);
+    return small_launch_pt<1, 1>(L, s);
 }
 
 }  // namespace mp

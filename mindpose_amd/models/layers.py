@@ -243,7 +243,8 @@ BLOCK_ROWS = (0, 4, 2, 1)  # band heights the fused-BasicBlock tuner times (0 = 
 F32_VARIANTS = 9   # direct MFMA tile variants 0..7 (csrc/conv_mfma.h ConvVariant) + 8 = the streaming 1x1 kernel (conv_pw_f32.hip)
 F32_WINOGRAD = 9   # the tuner's index of the Winograd F(2x2,3x3) form (csrc/conv_wino_f32.hip)
 F32_GEMM = 10      # the blocked-GEMM 1x1 kernel (csrc/conv_gemm_f32.hip; conv_api.hip kGemm)
-F32_SMALL = 11     # the K-split 3x3 kernel for small problems - a handful of crops (csrc/conv_small_f32.hip; conv_api.hip kSmall)
+F32_SMALL = 11     # the K-split kernel for small problems - a handful of crops (csrc/conv_small_f32.hip; conv_api.hip kSmall)
+F32_SMALL_WIDE = 12  # ... with 48 / 64 pixels per workgroup (a few dozen crops: the weights of a workgroup serve more pixels)
 
 
 def winograd_enabled() -> bool:
@@ -305,7 +306,7 @@ def tune_conv_variant(lib, d, x, packed, scale, shift, res1, res2, out, half: bo
                 st.pre_scale, st.pre_shift, st.pre_out, st.pre_relu = _lib.ptr(pre["scale"]), _lib.ptr(pre["shift"]), _lib.ptr(pre["y"]), int(pre["relu"])
             return lib.mp_f16_conv2d_fwd_stats(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift),
                                                _lib.ptr(res1), _lib.ptr(trial_out), ctypes.byref(st), stream)
-        if not half and v == F32_SMALL and no_small:
+        if not half and v in (F32_SMALL, F32_SMALL_WIDE) and no_small:
             return -3
         if not half and v == F32_WINOGRAD:
             if packed_u is None:
@@ -315,7 +316,7 @@ def tune_conv_variant(lib, d, x, packed, scale, shift, res1, res2, out, half: bo
         return fn(ctypes.byref(d), v, _lib.ptr(x), _lib.ptr(packed), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(res1),
                   _lib.ptr(res2), _lib.ptr(trial_out), stream)
 
-    return _autotune(key, macs, F16_VARIANTS if half else F32_SMALL + 1, launch)
+    return _autotune(key, macs, F16_VARIANTS if half else F32_SMALL_WIDE + 1, launch)
 
 
 class Plan:

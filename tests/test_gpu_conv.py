@@ -680,6 +680,13 @@ def test_small_problem_kernel_vs_torch_and_direct(case):
     assert _nerr(out.double().cpu(), ref) <= 2e-5
     assert _nerr(out.double().cpu(), run(-1).double().cpu()) <= 2e-5
     assert torch.equal(out, run(11))  # fixed fold order: the same bits every launch
+    # the wide form (variant 12: 48 / 64 pixels per workgroup; same k order per output, so the same bits) - every map of more than
+    # one pixel tile has it
+    if ho * wo > 16:
+        assert torch.equal(run(12), out)
+    else:
+        assert lib.mp_conv2d_fwd_variant(ctypes.byref(d), 12, _lib.ptr(xd), _lib.ptr(pk), _lib.ptr(sc), _lib.ptr(sh), None, None,
+                                         _lib.ptr(out), st) == -3
     # in place on the first residual (the accumulate-into form of the exchange unit)
     if n_res:
         acc = rd[0].clone()
