@@ -112,6 +112,11 @@ def _train_conv_bn(seq: nn.Sequential, x: torch.Tensor, relu=None) -> torch.Tens
     return T.conv_bn_act(x, seq[0], seq[1], relu=(len(seq) > 2) if relu is None else relu)
 
 
+def _flush_queued_weight_gradients(grad):
+    T.flush_wgrad_jobs_early()
+    return None  # the gradient is not changed
+
+
 _BRANCH_STREAMS = {}
 _BRANCH_STREAMS_ON = [False]
 
@@ -469,6 +474,10 @@ class HRNet(Backbone):
         x = T.conv_bn_act(x, self.conv2, self.bn2, relu=True)
         for blk in self.layer1:
             x = blk.train_forward(x)
+        if x.requires_grad and x.is_cuda:
+            # when the backward pass arrives here only the branch-less stage 1 and the stem are left: the weight gradients queued so
+            # far go out on a side stream beside them (train_ops.flush_wgrad_jobs_early) instead of alone behind the pass
+            x.register_hook(_flush_queued_weight_gradients)
         ys = [x]
         cuts = getattr(self, "_train_cut_sink", None)
         cut_at = getattr(self, "_train_cut_at", None)  # boundaries to cut (0 = in front of stage 2 ... 2 = stage 4); None = all three

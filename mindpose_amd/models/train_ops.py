@@ -1047,6 +1047,9 @@ def _wgrad_enqueue(lib, d, x, dz, dw):
     jobs = _WGRAD_PENDING.setdefault(key, [])
     jobs.append((d, x, dz, dw, torch.cuda.current_stream(dev).cuda_stream))
     if len(jobs) >= _wgrad_group_size():
+        # (keeping a full group of the branch-0 chain queued for the side stream at the module boundary - instead of 140 us of
+        # bandwidth-bound launches at the end of the longest chain - was measured SLOWER: 23.7 vs 22.0 ms per step; the concurrent
+        # stream takes HBM from the chain it was meant to shorten)
         _wgrad_flush_key(lib, key)
     elif not _WGRAD_CALLBACK[0]:
         # the remainders are launched when THIS backward pass ends (autograd's final callbacks run after the engine has joined the
@@ -1055,16 +1058,17 @@ def _wgrad_enqueue(lib, d, x, dz, dw):
         torch.autograd.Variable._execution_engine.queue_callback(_wgrad_backward_done)
 
 
-def _wgrad_flush_key(lib, key):
+def _wgrad_flush_key(lib, key, joined: bool = False):
     jobs = _WGRAD_PENDING.pop(key, [])
     if not jobs:
         return
     d, dev = jobs[0][0], key[1]
     n = len(jobs)
-    # the group runs on the current stream, behind the producers of every operand (layers that ran on other streams)
+    # the group runs on the current stream, behind the producers of every operand (layers that ran on other streams); ``joined``: the
+    # caller's stream is already ordered behind all of them (the early flush below forks from such a point)
     cur = torch.cuda.current_stream(dev)
     for sid in sorted({j[4] for j in jobs}):
-        if sid != cur.cuda_stream:
+        if sid != cur.cuda_stream and not joined:
             cur.wait_stream(torch.cuda.ExternalStream(sid, device=dev))
     for _, x, dz, _, sid in jobs:
         if sid != cur.cuda_stream:
@@ -1128,10 +1132,41 @@ def drop_wgrad_jobs(lo: int = 0, hi: int = 1 << 63) -> None:
         _WGRAD_CALLBACK[0] = False
 
 
+_WGRAD_SIDE = {}          # device -> the stream of the early flush
+_WGRAD_SIDE_BUSY = set()  # devices whose early flush has not been joined yet
+
+
+def flush_wgrad_jobs_early() -> None:
+    """Launch what is queued NOW on a side stream forked from the current one, to be joined by the next `flush_wgrad_jobs`.  HRNet
+    calls it (a gradient hook on the stage-1 output) when the backward pass reaches stage 1: the remainders of stages 2 - 4 - ~1.5 ms
+    of bandwidth-bound launches that used to run alone behind the backward pass - then stream beside the branch-less stage-1 /
+    stem backward (also bandwidth-bound, on ONE queue: two such streams together get more of the HBM than either alone).  The jobs
+    and their groups are those the end-of-pass flush would have formed (no later layer has the shapes of stages 2 - 4): same bits.
+    Only with the automatic end-of-pass flush on (a segmented capture carries its groups across the cuts itself)."""
+    if not _WGRAD_PENDING or not _WGRAD_AUTOFLUSH[0] or os.environ.get("MINDPOSE_WGRAD_EARLY_FLUSH", "1") == "0":
+        return
+    dev = next(iter(_WGRAD_PENDING))[1]
+    cur = torch.cuda.current_stream(dev)
+    side = _WGRAD_SIDE.get(dev)
+    if side is None:
+        side = _WGRAD_SIDE[dev] = torch.cuda.Stream(device=dev)
+    # every queued job was produced by a node upstream of the caller's gradient: the current stream is ordered behind all of them
+    keys = [k for k in _WGRAD_PENDING if k[1] == dev]
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        lib = _lib.load()
+        for key in keys:
+            _wgrad_flush_key(lib, key, joined=True)
+    _WGRAD_SIDE_BUSY.add(dev)
+
+
 def flush_wgrad_jobs() -> None:
     """Launch every queued weight gradient on the current stream (each group behind the producers of its operands): the arena is
     complete for whatever the caller enqueues next."""
     _WGRAD_CALLBACK[0] = False
+    for dev in list(_WGRAD_SIDE_BUSY):  # an early flush of this pass: its launches are part of "the arena is complete"
+        torch.cuda.current_stream(dev).wait_stream(_WGRAD_SIDE[dev])
+        _WGRAD_SIDE_BUSY.discard(dev)
     if not _WGRAD_PENDING:
         return
     lib = _lib.load()
