@@ -313,7 +313,11 @@ class HRModule(nn.Module):
         # every branch output feeds every row of the exchange unit: one handle per row, so that the backward pass sums the rows'
         # gradients in one launch per branch (T.FanOutFn) instead of pairwise
         rows = len(self.fuse_layers)
-        handles = [T.fan_out(x, rows) for x in xs]
+        if rows == 1:
+            # one row = one consumer per branch output, no fan-in node: the branch chains of the backward pass would each be released
+            # behind "their" term's launches on the current stream - one after the other in a replayed graph.  One node in between.
+            xs = T.grad_join(xs)
+        handles = T.fan_out_many(xs, [rows] * len(xs))  # ONE autograd node: the backward pass forks the branch chains from a single point
         outs = []
         # The rows of the exchange unit (hrnet.py:318-344) are independent chains of small launches - 1x1 conv + BatchNorm per
         # up-sampled term, one to three stride-2 conv + BatchNorm groups per down-sampled one, the sum - ~17 (three branches) to ~36
@@ -502,7 +506,7 @@ class HRNet(Backbone):
             # that the gradients meet in one fan-in launch instead of autograd's adds
             uses = [1 if i < len(ys) else 0 for i in range(len(ys))]
             uses[-1] += sum(1 for i in range(cfg["num_branches"]) if i >= len(ys))
-            handles = [list(T.fan_out(y, u)) for y, u in zip(ys, uses)]
+            handles = [list(hs) for hs in T.fan_out_many(ys, uses)]
             xs = []
             for i in range(cfg["num_branches"]):
                 if not flags[i]:

@@ -1471,35 +1471,117 @@ class FanOutFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        gs = [g.contiguous() for g in grads if g is not None]
-        if not gs:
-            return None, None, None
-        if len(gs) == 1:
-            return gs[0], None, None
-        lib = _lib.load()
-        half = gs[0].dtype == torch.float16
-        link = ctx.link
-        if (half and link is not None and link.claimed == 1 and len(gs) <= 4 and (_bn_fuse_parts() & 8)
-                and tuple(link.z.shape) == tuple(gs[0].shape)):
-            n, c8, h, w, _ = gs[0].shape
-            n_parts = lib.mp_f16_ew_stats_parts(n, c8 * 8, h * w)
-            part = torch.empty(c8 * n_parts * 16, device=gs[0].device, dtype=torch.float32)
-            dst = torch.empty_like(gs[0])
-            ops = gs + [None] * (4 - len(gs))
-            _lib.check(lib.mp_f16_sum_tensors_stats(_lib.ptr(ops[0]), _lib.ptr(ops[1]), _lib.ptr(ops[2]), _lib.ptr(ops[3]), _lib.ptr(dst),
-                                                    _lib.ptr(link.z), _lib.ptr(link.y) if link.relu else None, int(link.relu), n, c8 * 8,
-                                                    h * w, _lib.ptr(part), part.numel() * 4, _lib.stream()), "mp_f16_sum_tensors_stats")
-            link.hand_over(part, n_parts, dst)
-            return dst, None, None
-        out = gs[0]
-        for i in range(1, len(gs), 3):  # up to four operands per launch (the running sum + three more)
-            ops = gs[i:i + 3]
-            dst = torch.empty_like(gs[0])
-            _lib.check(lib.mp_sum_tensors(_lib.ptr(out), _lib.ptr(ops[0]), _lib.ptr(ops[1]) if len(ops) > 1 else None,
-                                          _lib.ptr(ops[2]) if len(ops) > 2 else None, _lib.ptr(dst), dst.numel() * dst.element_size(),
-                                          int(half), _lib.stream()), "mp_sum_tensors")
-            out = dst
-        return out, None, None
+        return _fan_in(grads, ctx.link), None, None
+
+
+def _fan_in(grads, link):
+    """The sum of one tensor's consumer gradients (None entries skipped) in one launch - with ``link`` (the tensor is the output of a
+    fused chain whose only consumer is the fan-out) also the mask and the last BatchNorm's backward sums."""
+    gs = [g.contiguous() for g in grads if g is not None]
+    if not gs:
+        return None
+    if len(gs) == 1:
+        return gs[0]
+    lib = _lib.load()
+    half = gs[0].dtype == torch.float16
+    if (half and link is not None and link.claimed == 1 and len(gs) <= 4 and (_bn_fuse_parts() & 8)
+            and tuple(link.z.shape) == tuple(gs[0].shape)):
+        n, c8, h, w, _ = gs[0].shape
+        n_parts = lib.mp_f16_ew_stats_parts(n, c8 * 8, h * w)
+        part = torch.empty(c8 * n_parts * 16, device=gs[0].device, dtype=torch.float32)
+        dst = torch.empty_like(gs[0])
+        ops = gs + [None] * (4 - len(gs))
+        _lib.check(lib.mp_f16_sum_tensors_stats(_lib.ptr(ops[0]), _lib.ptr(ops[1]), _lib.ptr(ops[2]), _lib.ptr(ops[3]), _lib.ptr(dst),
+                                                _lib.ptr(link.z), _lib.ptr(link.y) if link.relu else None, int(link.relu), n, c8 * 8,
+                                                h * w, _lib.ptr(part), part.numel() * 4, _lib.stream()), "mp_f16_sum_tensors_stats")
+        link.hand_over(part, n_parts, dst)
+        return dst
+    out = gs[0]
+    for i in range(1, len(gs), 3):  # up to four operands per launch (the running sum + three more)
+        ops = gs[i:i + 3]
+        dst = torch.empty_like(gs[0])
+        _lib.check(lib.mp_sum_tensors(_lib.ptr(out), _lib.ptr(ops[0]), _lib.ptr(ops[1]) if len(ops) > 1 else None,
+                                      _lib.ptr(ops[2]) if len(ops) > 2 else None, _lib.ptr(dst), dst.numel() * dst.element_size(),
+                                      int(half), _lib.stream()), "mp_sum_tensors")
+        out = dst
+    return out
+
+
+class FanOutManyFn(torch.autograd.Function):
+    """`FanOutFn` for SEVERAL tensors as ONE autograd node: handles ``ks[j]`` on ``xs[j]``; the backward pass runs the tensors' fan-in
+    sums one after the other inside one node.  Why one node: the branch chains of an HRModule's backward each start at "their"
+    fan-in; as separate nodes on the current stream the fan-ins form a spine, every chain is released by an event behind a
+    DIFFERENT kernel of it - and the hipGraph runtime then replays the chains almost one after the other (tools/probes/
+    graph_spine_probe.py: 2217 us against 790 us concurrent / 2839 us serial), while chains forked from ONE point run concurrently
+    (846 us).  As one node the engine records its consumers' events behind the LAST fan-in kernel: a single fork point."""
+
+    @staticmethod
+    def forward(ctx, ks, links, *xs):
+        ctx.set_materialize_grads(False)
+        ctx.ks, ctx.links = ks, links
+        outs = []
+        for x, k in zip(xs, ks):
+            outs += [x.view_as(x) for _ in range(k)]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        res, i = [], 0
+        for k, link in zip(ctx.ks, ctx.links):
+            res.append(_fan_in(grads[i:i + k], link))
+            i += k
+        return (None, None, *res)
+
+
+class GradJoinFn(torch.autograd.Function):
+    """Identity over several tensors as ONE autograd node: in the backward pass their gradients - produced at different points of
+    the current stream - leave through one node, so the chains that consume them on side streams fork from a SINGLE point (see
+    `FanOutManyFn`: chains released behind different kernels of a spine replay one after the other)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for x in xs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return grads  # the very tensors that came in: a BatchNorm hand-over (`_link_pre`) still recognises its gradient
+
+
+def grad_join(xs):
+    """``xs`` routed through `GradJoinFn` (the BatchNorm links travel with the tensors); a list of one, CPU tensors or tensors without
+    gradient pass through."""
+    xs = list(xs)
+    if len(xs) < 2 or not all(x.is_cuda and x.requires_grad for x in xs) or os.environ.get("MINDPOSE_FAN_OUT_ONE_NODE", "1") == "0":
+        return xs
+    outs = GradJoinFn.apply(*xs)
+    for o, x in zip(outs, xs):
+        link = getattr(x, "_mp_bn_link", None)
+        if link is not None:
+            o._mp_bn_link = link
+    return list(outs)
+
+
+def fan_out_many(xs, ks):
+    """``[fan_out(x, k) for x, k in zip(xs, ks)]`` with the fan-ins of the backward pass in ONE autograd node (`FanOutManyFn`);
+    tensors with at most one consumer (or that `fan_out` would pass through) stay outside it."""
+    outs = [None] * len(xs)
+    pick = []
+    for j, (x, k) in enumerate(zip(xs, ks)):
+        if k <= 1 or not x.is_cuda or not x.requires_grad or (x.numel() * x.element_size()) % 16 or os.environ.get("MINDPOSE_FAN_OUT", "1") == "0":
+            outs[j] = (x,) * k
+        else:
+            pick.append(j)
+    if len(pick) == 1 or os.environ.get("MINDPOSE_FAN_OUT_ONE_NODE", "1") == "0":
+        for j in pick:
+            outs[j] = fan_out(xs[j], ks[j])
+    elif pick:
+        flat = FanOutManyFn.apply([ks[j] for j in pick], [_claim(xs[j]) for j in pick], *[xs[j] for j in pick])
+        i = 0
+        for j in pick:
+            outs[j] = tuple(flat[i:i + ks[j]])
+            i += ks[j]
+    return outs
 
 
 def fan_out(x, k: int):
