@@ -283,8 +283,11 @@ class HRModule(nn.Module):
             outs.append(ybuf)
         return outs
 
-    def train_forward(self, xs: List[torch.Tensor]) -> List[torch.Tensor]:
-        """Training form of hrnet.py:318-344: same term order; one exchange-unit sum kernel per row."""
+    def train_forward(self, xs: List[torch.Tensor], fork: bool = True, join: bool = True) -> List[torch.Tensor]:
+        """Training form of hrnet.py:318-344: same term order; one exchange-unit sum kernel per row.  ``join`` = False: the rows stay on
+        their side streams when this returns, ``fork`` = False: the branches start on theirs without waiting for the current stream -
+        row i of one module feeds branch i of the next ON THE SAME STREAM, so consecutive modules of a stage need no join / fork star
+        in between (MINDPOSE_TRAIN_CHAIN_MODULES=0: one after every module, as before)."""
         xs = list(xs)
         if self.num_branches > 1 and xs[0].is_cuda and branch_streams_enabled():
             # the branches are independent until the exchange unit: branch i > 0 on side stream i (forked from / joined to the
@@ -293,7 +296,8 @@ class HRModule(nn.Module):
             cur = torch.cuda.current_stream(xs[0].device)
             side = _branch_streams(xs[0].device, self.num_branches - 1)
             for i in range(1, self.num_branches):
-                side[i - 1].wait_stream(cur)
+                if fork:
+                    side[i - 1].wait_stream(cur)
                 with torch.cuda.stream(side[i - 1]):
                     for blk in self.branches[i]:
                         xs[i] = blk.train_forward(xs[i])
@@ -333,7 +337,7 @@ class HRModule(nn.Module):
             ctxm = torch.cuda.stream(row_streams[i - 1]) if (row_streams is not None and i > 0) else contextlib.nullcontext()
             with ctxm:
                 outs.append(self._train_row(i, xs, handles))
-        if row_streams is not None:
+        if row_streams is not None and join:
             for st in row_streams:
                 cur.wait_stream(st)
         return outs
@@ -518,8 +522,11 @@ class HRNet(Backbone):
                     for seq in trans[i]:
                         t = _train_conv_bn(seq, t)
                     xs.append(t)
-            for mod in getattr(self, f"stage{idx}"):
-                xs = mod.train_forward(xs)
+            mods = list(getattr(self, f"stage{idx}"))
+            chain = os.environ.get("MINDPOSE_TRAIN_CHAIN_MODULES", "1") != "0"
+            for k, mod in enumerate(mods):
+                first, last = k == 0, k == len(mods) - 1
+                xs = mod.train_forward(xs, fork=first or not chain, join=last or not chain)
             ys = xs
         return ys[0]
 
