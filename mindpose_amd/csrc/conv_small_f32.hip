@@ -34,8 +34,12 @@ constexpr int kWaves = 8;  // K is split eight ways: the 256-channel layer's 576
 // batch is large enough that every workgroup re-streaming its 16 couts' weights becomes the cost (N = 8 ... 32: the weights of a
 // workgroup then serve 48 / 64 pixels)
 template <int KS, int S, int PT>
-__global__ __launch_bounds__(64 * kWaves) void conv_small_f32_kernel(const SmallParams p) {
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 8))) void conv_small_f32_kernel(const SmallParams p) {
     constexpr int T = KS * KS, PAD = KS / 2;
+    // cin quads of weights in flight per wave: four (36 dwords for 3x3); the wide forms keep two - with 3 - 4 accumulator tiles and
+    // their pixel operands four would take the kernel past 128 registers, i.e. to ONE workgroup per CU (measured: 128 -> 128 @16x12,
+    // N = 32: 47 us on 768 workgroups)
+    constexpr int RQ = PT >= 3 ? 2 : 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -70,10 +74,10 @@ __global__ __launch_bounds__(64 * kWaves) void conv_small_f32_kernel(const Small
     // flight: slot (j, t) holds tap t of the wave's quad qi0 + j and is refilled for quad qi0 + j + 4 right behind its MFMA
     // (every index below is a compile-time constant: the ring stays in registers)
     const int nq = (p.kq - wave + kWaves - 1) / kWaves;  // quads of this wave
-    float a_reg[4 * T];
+    float a_reg[RQ * T];
     auto w_at = [&](int qi, int t) __attribute__((always_inline)) { return wrow[(size_t)((wave + kWaves * qi) * T + t) * w_step]; };
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < RQ; ++j)
 #pragma unroll
         for (int t = 0; t < T; ++t) a_reg[j * T + t] = j < nq ? w_at(j, t) : 0.f;
     // ---- stage: rows row0 .. row0 + rows - 1, columns -1 .. W (zeros outside the map).  Wave w reads ONLY the channels of its own cin
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(64 * kWaves) void conv_small_f32_kernel(const Small
         const int per_plane = p.rows * p.Wp;
         const int nq_w = (p.kq - wave + kWaves - 1) / kWaves;  // this wave's quads
         const int total = nq_w * 4 * per_plane;       // elements of this wave's planes
-        constexpr int U = 16;
+        constexpr int U = PT >= 3 ? 12 : 16;  // (the wide forms run two workgroups per CU under 128 registers)
         for (int i0 = lane; i0 < total; i0 += 64 * U) {
             float v[U];
             unsigned dst[U];
@@ -112,23 +116,33 @@ __global__ __launch_bounds__(64 * kWaves) void conv_small_f32_kernel(const Small
     f32x4 acc[PT];
 #pragma unroll
     for (int i = 0; i < PT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int qi0 = 0; qi0 < nq; qi0 += 4) {
+    for (int qi0 = 0; qi0 < nq; qi0 += RQ) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < RQ; ++j) {
             const int qi = qi0 + j;
             if (qi < nq) {  // wave-uniform
                 const unsigned q_off = (unsigned)((wave + kWaves * qi) * 4 * p.plane);
-                float bv[PT][T];
+                // pixel operands one tap ROW at a time (the wide forms: all nine taps of four tiles would be 36 registers)
+                constexpr int TR = PT >= 4 ? KS : 1;       // tap rows per operand batch
+                constexpr int TB = T / TR;                 // taps per batch
 #pragma unroll
-                for (int i = 0; i < PT; ++i)
+                for (int tr = 0; tr < TR; ++tr) {
+                    float bv[PT][TB];
 #pragma unroll
-                    for (int t = 0; t < T; ++t) bv[i][t] = smem[b_base[i] + q_off + (unsigned)((t / KS) * p.Wp + (t % KS))];
+                    for (int i = 0; i < PT; ++i)
 #pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    const float av = a_reg[j * T + t];
-                    if (qi + 4 < nq) a_reg[j * T + t] = w_at(qi + 4, t);
+                        for (int tb = 0; tb < TB; ++tb) {
+                            const int t = tr * TB + tb;
+                            bv[i][tb] = smem[b_base[i] + q_off + (unsigned)((t / KS) * p.Wp + (t % KS))];
+                        }
 #pragma unroll
-                    for (int i = 0; i < PT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[i][t], acc[i], 0, 0, 0);
+                    for (int tb = 0; tb < TB; ++tb) {
+                        const int t = tr * TB + tb;
+                        const float av = a_reg[j * T + t];
+                        if (qi + RQ < nq) a_reg[j * T + t] = w_at(qi + RQ, t);
+#pragma unroll
+                        for (int i = 0; i < PT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[i][tb], acc[i], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -142,7 +156,9 @@ __global__ __launch_bounds__(64 * kWaves) void conv_small_f32_kernel(const Small
     }
     __syncthreads();
     if (wave != 0) return;
-#pragma unroll
+    // (a ROLLED loop: unrolled, the compiler issues all 7 PT partial-tile reads at once and sinks the adds into the epilogue - 112
+    //  registers for the wide forms, which then spill or drop to one workgroup per CU)
+#pragma unroll 1
     for (int k = 0; k < kWaves - 1; ++k)  // wave 1, 2, ... in order
 #pragma unroll
         for (int i = 0; i < PT; ++i) acc[i] = acc[i] + red[(k * PT + i) * 64 + lane];
@@ -163,6 +179,7 @@ __global__ __launch_bounds__(64 * kWaves) void conv_small_f32_kernel(const Small
             if (p.relu) v = fmaxf(v, 0.f);
             p.out[o] = v;
         }
+        if (PT >= 3) __builtin_amdgcn_sched_barrier(0);  // (one tile's residual loads at a time)
     }
 }
 
