@@ -28,6 +28,10 @@ __device__ __forceinline__ unsigned fdiv(unsigned e, unsigned d, unsigned magic)
 // weight k-steps in flight per wave = four cin quads x the taps (3x3: 36 dwords per lane, 9 KB per wave - the k loop is a weight
 // STREAM: with eight in flight the 256-channel layer took 44 us)
 
+#ifndef MP_SMALL_ABLATE
+#define MP_SMALL_ABLATE 0  // diagnostic builds (tools/small_ablate.sh): 1 = no staging, 2 = no MFMA loop, 4 = no weight loads, 8 = no fold; results wrong, timings meaningful
+#endif
+
 constexpr int kWaves = 8;  // K is split eight ways: the 256-channel layer's 576 k-steps = 72 per wave = two fills of the weight ring
 
 // PT = 16-pixel tiles per workgroup (consecutive pixels of one image): 1 for a handful of crops (most workgroups); 3 / 4 when the
@@ -36,10 +40,9 @@ constexpr int kWaves = 8;  // K is split eight ways: the 256-channel layer's 576
 template <int KS, int S, int PT>
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 8))) void conv_small_f32_kernel(const SmallParams p) {
     constexpr int T = KS * KS, PAD = KS / 2;
-    // cin quads of weights in flight per wave: four (36 dwords for 3x3); the wide forms keep two - with 3 - 4 accumulator tiles and
-    // their pixel operands four would take the kernel past 128 registers, i.e. to ONE workgroup per CU (measured: 128 -> 128 @16x12,
-    // N = 32: 47 us on 768 workgroups)
-    constexpr int RQ = PT >= 3 ? 2 : 4;
+    // cin quads of weights in flight per wave: four (36 dwords for 3x3; three with four accumulator tiles) - the budget is 128
+    // registers = TWO workgroups per CU (one: 128 -> 128 @16x12, N = 32 took 47 us on 768 workgroups; now 32)
+    constexpr int RQ = (PT == 4 && KS == 3) ? 3 : 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -75,38 +78,44 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
     // (every index below is a compile-time constant: the ring stays in registers)
     const int nq = (p.kq - wave + kWaves - 1) / kWaves;  // quads of this wave
     float a_reg[RQ * T];
-    auto w_at = [&](int qi, int t) __attribute__((always_inline)) { return wrow[(size_t)((wave + kWaves * qi) * T + t) * w_step]; };
+    auto w_at = [&](int qi, int t) __attribute__((always_inline)) {
+        if (MP_SMALL_ABLATE & 4) return (float)(qi + t);
+        return wrow[(size_t)((wave + kWaves * qi) * T + t) * w_step];
+    };
 #pragma unroll
     for (int j = 0; j < RQ; ++j)
 #pragma unroll
         for (int t = 0; t < T; ++t) a_reg[j * T + t] = j < nq ? w_at(j, t) : 0.f;
-    // ---- stage: rows row0 .. row0 + rows - 1, columns -1 .. W (zeros outside the map).  Wave w reads ONLY the channels of its own cin
-    //      quads (q = w, w + 8, ...), so every wave stages exactly those planes itself - no workgroup barrier in front of the k loop -
-    //      with sixteen loads in flight per lane (a dependent load / store pair per element was most of the first version's 44 us)
+    // ---- stage: rows row0 .. row0 + rows - 1, columns -PAD .. (zeros outside the map).  Wave w reads ONLY the channels of its own cin
+    //      quads (q = w, w + 8, ...), so every wave stages exactly those planes itself - no workgroup barrier in front of the k loop.
+    //      Every plane has the same geometry: a lane decodes its slot (element lane + 64 s of a plane -> source offset, in / out of the
+    //      map) ONCE and then walks the wave's planes with one add per element, sixteen loads in flight (decoding every element - two
+    //      divisions, the bounds, a 64-bit address - made the staging a ~800-instruction VALU phase per lane: as long as the MFMA phase)
     {
         const float* __restrict__ xin = p.x + (size_t)n * p.Cin * p.HWin;
         const int per_plane = p.rows * p.Wp;
-        const int nq_w = (p.kq - wave + kWaves - 1) / kWaves;  // this wave's quads
-        const int total = nq_w * 4 * per_plane;       // elements of this wave's planes
-        constexpr int U = PT >= 3 ? 12 : 16;  // (the wide forms run two workgroups per CU under 128 registers)
-        for (int i0 = lane; i0 < total; i0 += 64 * U) {
-            float v[U];
-            unsigned dst[U];
+        const int n_pl = nq * 4;  // planes of this wave (the last quad may run past Cin: zeros)
+        constexpr int U = 16;  // (32 in flight - two slots x 16 planes, or 32 planes - measured slower: 256 -> 256 @8x6, N = 32: 31.8 -> 34.3 us)
+        for (int e = lane; e < ((MP_SMALL_ABLATE & 1) ? 0 : per_plane); e += 64) {
+            const unsigned r = fdiv((unsigned)e, (unsigned)p.Wp, p.magic_wp);
+            const int c = (int)((unsigned)e - r * p.Wp) - PAD, y = row0 + (int)r;
+            const bool in_map = y >= 0 && y < p.Hin && c >= 0 && c < p.Win;
+            const int src = in_map ? y * p.Win + c : 0;
+            for (int k0 = 0; k0 < n_pl; k0 += U) {
+                float v[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = i0 + 64 * u;
-                const unsigned cl = fdiv((unsigned)(i < total ? i : 0), (unsigned)per_plane, p.magic_per_plane);  // plane index inside the wave's set
-                const unsigned e = (unsigned)(i < total ? i : 0) - cl * per_plane;
-                const unsigned ci = (unsigned)(wave + kWaves * (cl >> 2)) * 4u + (cl & 3u);
-                const unsigned r = fdiv(e, (unsigned)p.Wp, p.magic_wp);
-                const int c = (int)(e - r * p.Wp) - PAD, y = row0 + (int)r;
-                const bool ok = i < total && (int)ci < p.Cin && y >= 0 && y < p.Hin && c >= 0 && c < p.Win;
-                v[u] = ok ? xin[(size_t)ci * p.HWin + y * p.Win + c] : 0.f;
-                dst[u] = i < total ? ci * p.plane + e : 0xFFFFFFFFu;
+                for (int u = 0; u < U; ++u) {
+                    const int k = k0 + u;  // plane k of the wave = channel (wave + 8 (k >> 2)) 4 + (k & 3)
+                    const int ci = (wave + kWaves * (k >> 2)) * 4 + (k & 3);
+                    v[u] = (in_map && k < n_pl && ci < p.Cin) ? xin[(size_t)ci * p.HWin + src] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int k = k0 + u;
+                    const int ci = (wave + kWaves * (k >> 2)) * 4 + (k & 3);
+                    if (k < n_pl) smem[ci * p.plane + e] = v[u];
+                }
             }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (dst[u] != 0xFFFFFFFFu) smem[dst[u]] = v[u];
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // this wave's own LDS stores above are read back by its other lanes
@@ -116,7 +125,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
     f32x4 acc[PT];
 #pragma unroll
     for (int i = 0; i < PT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int qi0 = 0; qi0 < nq; qi0 += RQ) {
+    for (int qi0 = 0; qi0 < ((MP_SMALL_ABLATE & 2) ? 0 : nq); qi0 += RQ) {
 #pragma unroll
         for (int j = 0; j < RQ; ++j) {
             const int qi = qi0 + j;
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
     // (a ROLLED loop: unrolled, the compiler issues all 7 PT partial-tile reads at once and sinks the adds into the epilogue - 112
     //  registers for the wide forms, which then spill or drop to one workgroup per CU)
 #pragma unroll 1
-    for (int k = 0; k < kWaves - 1; ++k)  // wave 1, 2, ... in order
+    for (int k = 0; k < ((MP_SMALL_ABLATE & 8) ? 0 : kWaves - 1); ++k)  // wave 1, 2, ... in order
 #pragma unroll
         for (int i = 0; i < PT; ++i) acc[i] = acc[i] + red[(k * PT + i) * 64 + lane];
     // ---- epilogue: lane = (pixel column lr, cout rows 4 lk .. 4 lk + 3)
