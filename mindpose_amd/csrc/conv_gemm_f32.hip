@@ -30,6 +30,10 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef MP_GEMM_ABLATE
+#define MP_GEMM_ABLATE 0  // diagnostic builds (tools/gemm_ablate.sh): 1 = no stores, 2 = no MFMA; results wrong, timings meaningful
+#endif
+
 constexpr int kTM = 128;     // couts per workgroup
 constexpr int kTN = 128;     // pixel columns per workgroup
 constexpr int kKC = 16;      // input channels per chunk
@@ -178,7 +182,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f32_gemm_kernel(const GemmPara
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                for (int ni = 0; ni < NI; ++ni) {
+                    if (MP_GEMM_ABLATE & 2) acc[mi][ni][0] += a[mi] * b[ni];
+                    else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                }
         }
         stage_store((it + 1) & 1);  // the other buffer: its last readers finished before the previous barrier
         gemm_barrier();
@@ -242,6 +249,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_f32_gemm_kernel(const GemmPara
                     const int co = co0 + row + e;
                     float v = acc[mi][ni][g * 4 + e];
                     if (p.relu) v = fmaxf(v, 0.f);
+                    if ((MP_GEMM_ABLATE & 1) && v != 12345.678f) continue;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_o,
                                                           (o_col[ni] + co * plane) | (co < p.Cout ? 0u : kOob), 0, 0);
                 }
