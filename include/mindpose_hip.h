@@ -434,6 +434,25 @@ int mp_plan_add_expand_reduce_f16(mp_plan* plan, const void* mid_c8_dev, const v
                                   const float* scale3_dev, const float* shift3_dev, int relu3, const void* packed_w1_dev,
                                   const float* scale1_dev, const float* shift1_dev, int relu1, void* y_c8_dev, void* z_c8_dev, int n,
                                   int cm, int ce, int cr, int h, int w);
+/* The fp32 form of the chain (csrc/pwchain_f32.hip; hrnet.py:86-146 Bottleneck, 440-470 layer1): expand conv of Bottleneck i
+ *   y = relu(conv1x1(mid; w3) * scale3 + shift3 + r)        64 -> 256 channels
+ * and reduce conv of Bottleneck i + 1
+ *   z = relu(conv1x1(y; w1) * scale1 + shift1)               256 -> 64 channels
+ * in one persistent launch with all weight matrices held in registers; NCHW fp32 tensors, weights packed by mp_conv_pack_weight
+ * (1x1), y written once and never read back.  The residual r is EITHER the tensor res_dev (x0_dev / packed_wd_dev / scale_d_dev /
+ * shift_d_dev null) OR the block's down-sample conv conv1x1(x0; wd) * scale_d + shift_d of its 64-channel input (hrnet.py:74-81),
+ * computed inside the launch (res_dev null).  packed_w1_dev / scale1_dev / shift1_dev / z_dev null = the expand conv alone (the last
+ * Bottleneck of the stage; not with the down-sample form).  Same values as the stand-alone mp_conv2d_fwd launches up to fp32
+ * rounding (the k sums are associated differently).  Built for cm = 64, ce = 256, cr = 64 and h * w a multiple of 64:
+ * MP_ERR_UNSUPPORTED otherwise (the caller launches the convs one by one). */
+int mp_expand_reduce_fwd(const float* mid_dev, const float* res_dev, const float* x0_dev, const float* packed_wd_dev,
+                         const float* scale_d_dev, const float* shift_d_dev, const float* packed_w3_dev, const float* scale3_dev,
+                         const float* shift3_dev, const float* packed_w1_dev, const float* scale1_dev, const float* shift1_dev,
+                         float* y_dev, float* z_dev, int n, int cm, int ce, int cr, int h, int w, mp_stream_t stream);
+int mp_plan_add_expand_reduce(mp_plan* plan, const float* mid_dev, const float* res_dev, const float* x0_dev, const float* packed_wd_dev,
+                              const float* scale_d_dev, const float* shift_d_dev, const float* packed_w3_dev, const float* scale3_dev,
+                              const float* shift3_dev, const float* packed_w1_dev, const float* scale1_dev, const float* shift1_dev,
+                              float* y_dev, float* z_dev, int n, int cm, int ce, int cr, int h, int w);
 int mp_plan_add_basicblock_f16(mp_plan* plan, const void* x_c8_dev, const void* packed_w1_dev, const float* scale1_dev,
                                const float* shift1_dev, const void* packed_w2_dev, const float* scale2_dev, const float* shift2_dev,
                                void* out_c8_dev, int n, int c, int h, int w, int rows);

@@ -12,6 +12,7 @@
 #include "conv_stem.h"
 #include "conv_gemm.h"
 #include "conv_small.h"
+#include "pwchain_f32.h"
 
 namespace mp {
 
@@ -356,12 +357,14 @@ struct mp_plan {
     struct Entry {
         int kind;  // 0 conv, 1 maxpool, 2 fuse-sum; fp16 layout: 3 conv, 4 fuse-sum, 5 NCHW fp32 -> c8, 6 c8 -> NCHW fp32;
                    // 7 = all-lane barrier (no launch), 8 = fused fp16 BasicBlock, 9 = fp32 Winograd conv,
-                   // 10 = fp16 expand + reduce 1x1 chain (stage 1), 11 = fp16 first conv from the fp32 image, 12 = fp32 first conv (streaming form)
+                   // 10 = fp16 expand + reduce 1x1 chain (stage 1), 11 = fp16 first conv from the fp32 image, 12 = fp32 first conv (streaming form),
+                   // 13 = fp32 expand + reduce 1x1 chain (stage 1)
         int lane;  // execution lane: 0 = the caller's stream, 1..3 = the plan's own side streams
         ConvLaunch conv;
         ConvF16Launch conv16;
         BlockF16Launch block16;
         PwChainLaunch pwchain;
+        PwChainF32Launch pwchain32;
         StemF16Launch stem16;
         StemF32Launch stem32;
         WinoLaunch wino;
@@ -410,6 +413,7 @@ static int run_entry(const mp_plan::Entry& e, mp_stream_t stream) {
         case 10: return pwchain_launch(e.pwchain, as_stream(stream));
         case 11: return stemf16_launch(e.stem16, as_stream(stream));
         case 12: return stemf32_launch(e.stem32, as_stream(stream));
+        case 13: return pwchain32_launch(e.pwchain32, as_stream(stream));
         default: return MP_ERR_UNSUPPORTED;
     }
 }
@@ -669,6 +673,21 @@ int mp_plan_add_expand_reduce_f16(mp_plan* plan, const void* mid, const void* re
     return MP_OK;
 }
 
+int mp_plan_add_expand_reduce(mp_plan* plan, const float* mid, const float* res, const float* x0, const float* packed_wd, const float* scale_d,
+                              const float* shift_d, const float* packed_w3, const float* scale3, const float* shift3, const float* packed_w1,
+                              const float* scale1, const float* shift1, float* y, float* z, int n, int cm, int ce, int cr, int h, int w) {
+    if (!plan) return MP_ERR_NULL;
+    mp_plan::Entry e{};
+    e.kind = 13;
+    int rc = pwchain32_build(mid, res, x0, packed_wd, scale_d, shift_d, packed_w3, scale3, shift3, packed_w1, scale1, shift1, y, z, n, cm, ce, cr,
+                             h, w, e.pwchain32);
+    if (rc != MP_OK) return rc;
+    e.n = n; e.c = ce; e.h = h; e.w = w;
+    e.lane = plan->cur_lane;
+    plan->entries.push_back(e);
+    return MP_OK;
+}
+
 int mp_plan_add_dual_pw_f16(mp_plan* plan, const void* x, const void* packed_wa, const float* scale_a, const float* shift_a, int relu_a,
                             const void* packed_wb, const float* scale_b, const float* shift_b, int relu_b, void* ya, void* zb, int n, int cm,
                             int ce, int cr, int h, int w) {
@@ -787,6 +806,9 @@ int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]) {
     } else if (e.kind == 11) {
         info[1] = 3; info[2] = 2; info[3] = 0; info[4] = e.stem16.p.total_blocks;
         info[5] = (int64_t)e.stem16.lds_bytes; info[6] = 64; info[7] = 8 * e.stem16.p.Wo; info[8] = 3; info[9] = 1; info[10] = 8;
+    } else if (e.kind == 13) {
+        info[1] = 1; info[2] = 1; info[3] = (e.pwchain32.ds ? 1 : 0) + (e.pwchain32.red ? 0 : 2); info[4] = e.pwchain32.grid;
+        info[5] = (int64_t)e.pwchain32.lds_bytes; info[6] = 256; info[7] = 64; info[8] = 64; info[9] = 1; info[10] = 0;
     } else if (e.kind == 10) {
         info[1] = 1; info[2] = 1; info[3] = e.pwchain.dual ? 1 : 0; info[4] = e.pwchain.p.total_blocks;
         info[5] = (int64_t)e.pwchain.lds_bytes; info[6] = e.pwchain.ce; info[7] = 64; info[8] = e.pwchain.cm; info[9] = 1; info[10] = 0;

@@ -73,16 +73,26 @@ class Bottleneck(nn.Module):
         Bottleneck - when its reduce conv can ride on this block's expand conv (``Plan.fuses_expand_reduce``, fp16 plans) the pair
         (output, reduced output for ``nxt``) is returned instead of the output alone."""
         identity = x
+        ds_in_chain = None
         if (self.down_sample is not None and reduced is None and len(self.down_sample) == 2
                 and plan.fuses_dual_pw(x, self.down_sample[0], self.conv1)):
             # the down-sample conv and the reduce conv read the same input: one launch (fp16 plans)
             identity, reduced = plan.dual_pw(x, self.down_sample[0], self.down_sample[1], False, self.conv1, self.bn1, True)
+        elif (self.down_sample is not None and len(self.down_sample) == 2 and nxt is not None and self.conv2.stride == 1
+              and self.conv2.out_channels == 64 and plan.fuses_ds_expand_reduce(x, self.down_sample[0], self.conv3, nxt.conv1)):
+            # fp32 plans: the down-sample conv is computed INSIDE the expand + reduce chain launch below - its 256-channel output is
+            # neither written nor read back
+            ds_in_chain = (x, self.down_sample[0], self.down_sample[1])
         elif self.down_sample is not None:
             identity = plan.conv(x, self.down_sample[0], self.down_sample[1])
         out = reduced if reduced is not None else plan.conv(x, self.conv1, self.bn1, relu=True)
         out = plan.conv(out, self.conv2, self.bn2, relu=True)
+        if ds_in_chain is not None:
+            return plan.expand_reduce(out, None, self.conv3, self.bn3, nxt.conv1, nxt.bn1, ds=ds_in_chain)
         if nxt is not None and self.conv2.stride == 1 and plan.fuses_expand_reduce(out, identity, self.conv3, nxt.conv1):
             return plan.expand_reduce(out, identity, self.conv3, self.bn3, nxt.conv1, nxt.bn1)
+        if nxt is None and plan.fuses_expand_only(out, identity, self.conv3):
+            return plan.expand_reduce(out, identity, self.conv3, self.bn3, None, None)
         y = plan.conv(out, self.conv3, self.bn3, relu=True, res1=identity)
         return y if nxt is None else (y, None)
 

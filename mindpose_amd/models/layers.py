@@ -687,30 +687,81 @@ class Plan:
         return out
 
     def fuses_expand_reduce(self, mid: torch.Tensor, res: torch.Tensor, conv3: Conv2d, conv1_next: Conv2d) -> bool:
-        """Can the expand conv of a Bottleneck and the reduce conv of the next one run as ONE launch (mp_f16_expand_reduce_fwd)?
-        fp16 plans, the 64 -> 256 -> 64 widths of HRNet's stage 1, 1x1 stride-1 convs without bias, maps whose pixel count is a
-        multiple of 64.  ``MINDPOSE_FUSE_PWCHAIN=0`` keeps the two launches (same bits)."""
-        if not isinstance(mid, ActC8) or not isinstance(res, ActC8) or os.environ.get("MINDPOSE_FUSE_PWCHAIN", "1") == "0":
+        """Can the expand conv of a Bottleneck and the reduce conv of the next one run as ONE launch (fp16 plans:
+        mp_f16_expand_reduce_fwd, bit-identical to the two launches; fp32 plans: mp_expand_reduce_fwd, the persistent weight-stationary
+        form - same values up to the association of the k sums)?  The 64 -> 256 -> 64 widths of HRNet's stage 1, 1x1 stride-1 convs
+        without bias, maps whose pixel count is a multiple of 64.  ``MINDPOSE_FUSE_PWCHAIN=0`` (fp16) / ``MINDPOSE_FUSE_PWCHAIN32=0``
+        (fp32) keep the two launches."""
+        half = isinstance(mid, ActC8)
+        if half != isinstance(res, ActC8) or os.environ.get("MINDPOSE_FUSE_PWCHAIN" if half else "MINDPOSE_FUSE_PWCHAIN32", "1") == "0":
             return False
         n, cm, h, w = mid.shape
-        ok = lambda cv, ci, co: (cv.in_channels == ci and cv.out_channels == co and cv.kernel_size == 1 and cv.stride == 1  # noqa: E731
-                                 and cv.padding == 0 and cv.bias is None)
-        return (cm == 64 and tuple(res.shape) == (n, 256, h, w) and ok(conv3, 64, 256) and ok(conv1_next, 256, 64) and (h * w) % 64 == 0
-                and n * 32 * h * w * 16 < 0x7FFFFFF0)
+        if not (cm == 64 and tuple(res.shape) == (n, 256, h, w) and self._pw(conv3, 64, 256) and self._pw(conv1_next, 256, 64)
+                and (h * w) % 64 == 0):
+            return False
+        return n * 32 * h * w * 16 < 0x7FFFFFF0 if half else n * 256 * h * w * 4 < 0x7FFFFFF0
 
-    def expand_reduce(self, mid: torch.Tensor, res: torch.Tensor, conv3: Conv2d, bn3: BatchNorm2d, conv1_next: Conv2d,
-                      bn1_next: BatchNorm2d) -> Tuple[torch.Tensor, torch.Tensor]:
-        """(y, z) = (relu(bn3(conv3 mid) + res), relu(bn1'(conv1' y))) in one launch: y never comes back from HBM for the second conv;
-        bit-identical to the two conv launches (hrnet.py:107-146)."""
+    @staticmethod
+    def _pw(cv: Conv2d, ci: int, co: int) -> bool:
+        return (cv.in_channels == ci and cv.out_channels == co and cv.kernel_size == 1 and cv.stride == 1 and cv.padding == 0
+                and cv.bias is None)
+
+    def fuses_ds_expand_reduce(self, x0: torch.Tensor, ds_conv: Conv2d, conv3: Conv2d, conv1_next: Conv2d) -> bool:
+        """fp32 plans: can the FIRST Bottleneck's down-sample conv (hrnet.py:74-81, 64 -> 256 on the block's input) be computed inside
+        the expand + reduce chain launch, instead of being written and read back as the residual tensor by a launch of its own?
+        ``MINDPOSE_FUSE_PWCHAIN32_DS=0`` keeps the separate launch."""
+        if isinstance(x0, ActC8) or os.environ.get("MINDPOSE_FUSE_PWCHAIN32", "1") == "0" or os.environ.get("MINDPOSE_FUSE_PWCHAIN32_DS", "1") == "0":
+            return False
+        n, c, h, w = x0.shape
+        return (c == 64 and self._pw(ds_conv, 64, 256) and self._pw(conv3, 64, 256) and self._pw(conv1_next, 256, 64) and (h * w) % 64 == 0
+                and n * 256 * h * w * 4 < 0x7FFFFFF0)
+
+    def fuses_expand_only(self, mid: torch.Tensor, res: torch.Tensor, conv3: Conv2d) -> bool:
+        """fp32 plans: the LAST Bottleneck's expand conv + identity through the persistent weight-stationary kernel (no reduce conv
+        follows).  ``MINDPOSE_FUSE_PWCHAIN32_LAST=0`` keeps the tuned general conv."""
+        if isinstance(mid, ActC8) or isinstance(res, ActC8) or os.environ.get("MINDPOSE_FUSE_PWCHAIN32", "1") == "0":
+            return False
+        if os.environ.get("MINDPOSE_FUSE_PWCHAIN32_LAST", "1") == "0":
+            return False
         n, cm, h, w = mid.shape
-        ce, cr = conv3.out_channels, conv1_next.out_channels
+        return cm == 64 and tuple(res.shape) == (n, 256, h, w) and self._pw(conv3, 64, 256) and (h * w) % 64 == 0 and n * 256 * h * w * 4 < 0x7FFFFFF0
+
+    def expand_reduce(self, mid: torch.Tensor, res: Optional[torch.Tensor], conv3: Conv2d, bn3: BatchNorm2d, conv1_next: Optional[Conv2d],
+                      bn1_next: Optional[BatchNorm2d], ds=None):
+        """(y, z) = (relu(bn3(conv3 mid) + res), relu(bn1'(conv1' y))) in one launch: y never comes back from HBM for the second conv
+        (hrnet.py:107-146).  fp16: bit-identical to the two conv launches; fp32: equal up to the association of the k sums.
+        fp32 only: ``ds = (x0, conv, bn)`` - the residual is the block's down-sample conv of its input x0, computed in the launch
+        (``res`` None); ``conv1_next`` None - the expand conv alone, returns y."""
+        n, cm, h, w = mid.shape
+        ce = conv3.out_channels
+        cr = conv1_next.out_channels if conv1_next is not None else 0
+        macs = n * h * w * (cm * ce + ce * cr + (cm * ce if ds is not None else 0))
+        if not isinstance(mid, ActC8):
+            y = self.alloc_f32(n, ce, h, w)
+            z = self.alloc_f32(n, cr, h, w) if conv1_next is not None else None
+            p3 = self._pack(conv3.weight, ce, cm, 1, False, 0, 0)
+            s3, b3 = self._affine(ce, bn3, None)
+            p1 = s1 = b1 = pd = sd = bd = x0 = None
+            if conv1_next is not None:
+                p1 = self._pack(conv1_next.weight, cr, ce, 1, False, 0, 0)
+                s1, b1 = self._affine(cr, bn1_next, None)
+            if ds is not None:
+                x0, ds_conv, ds_bn = ds
+                pd = self._pack(ds_conv.weight, ce, cm, 1, False, 0, 0)
+                sd, bd = self._affine(ce, ds_bn, None)
+            _lib.check(self.lib.mp_plan_add_expand_reduce(self.handle, _lib.ptr(mid), _lib.ptr(res), _lib.ptr(x0), _lib.ptr(pd), _lib.ptr(sd),
+                                                          _lib.ptr(bd), _lib.ptr(p3), _lib.ptr(s3), _lib.ptr(b3), _lib.ptr(p1), _lib.ptr(s1), _lib.ptr(b1),
+                                                          _lib.ptr(y), _lib.ptr(z), n, cm, ce, cr if cr else 64, h, w),
+                       "mp_plan_add_expand_reduce")
+            self.layer_info.append(dict(kind="pwchain_f32", k=1, stride=1, cin=cm, cout=ce, h=h, w=w, n=n, macs=macs))
+            return (y, z) if conv1_next is not None else y
         y, z = self.alloc(n, ce, h, w), self.alloc(n, cr, h, w)
         p3, p1 = self._pack(conv3.weight, ce, cm, 1, False, 0, 0, True), self._pack(conv1_next.weight, cr, ce, 1, False, 0, 0, True)
         (s3, b3), (s1, b1) = self._affine(ce, bn3, None, True), self._affine(cr, bn1_next, None, True)
         _lib.check(self.lib.mp_plan_add_expand_reduce_f16(self.handle, _lib.ptr(mid), _lib.ptr(res), _lib.ptr(p3), _lib.ptr(s3), _lib.ptr(b3), 1,
                                                           _lib.ptr(p1), _lib.ptr(s1), _lib.ptr(b1), 1, _lib.ptr(y), _lib.ptr(z), n, cm, ce, cr, h, w),
                    "mp_plan_add_expand_reduce_f16")
-        self.layer_info.append(dict(kind="pwchain_f16", k=1, stride=1, cin=cm, cout=ce, h=h, w=w, n=n, macs=n * h * w * (cm * ce + ce * cr)))
+        self.layer_info.append(dict(kind="pwchain_f16", k=1, stride=1, cin=cm, cout=ce, h=h, w=w, n=n, macs=macs))
         return y, z
 
     def deconv4x4s2(self, x: torch.Tensor, deconv: Conv2dTranspose, bn: BatchNorm2d, relu: bool = True) -> torch.Tensor:

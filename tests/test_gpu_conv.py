@@ -328,6 +328,107 @@ def test_streaming_1x1_kernel_vs_torch_and_direct(case):
                                      st) == -3  # Cin = 48 is not a built shape
 
 
+@pytest.mark.parametrize("form", ["identity", "down_sample", "expand_only"])
+@pytest.mark.parametrize("shape", [(3, 64, 48), (2, 16, 12), (5, 8, 8), (2, 96, 72), (1, 4, 16), (7, 32, 24)])
+def test_expand_reduce_chain_f32(shape, form, monkeypatch):
+    """mp_expand_reduce_fwd - expand conv of Bottleneck i + reduce conv of Bottleneck i + 1 (hrnet.py:107-146) as ONE persistent,
+    weight-stationary fp32 launch (csrc/pwchain_f32.hip) - against fp64 torch at the direct kernel's bar, and against the
+    mp_conv2d_fwd launches it replaces (same values up to the association of the k sums).  Forms: the residual is a tensor
+    (identity), the residual is the first block's down-sample conv computed in the launch (hrnet.py:74-81), the expand conv alone
+    (last block).  HRNet's stage-1 map, W48's, small maps with one / few tiles per image, more tiles than workgroups
+    (MP_PWCHAIN32_WGS: a workgroup walks several tiles) and fewer."""
+    import ctypes
+    from mindpose_amd import _lib
+    n, h, w = shape
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n * h * w)
+    mid, res, x0 = torch.randn(n, 64, h, w, generator=g), torch.randn(n, 256, h, w, generator=g), torch.randn(n, 64, h, w, generator=g)
+    w3 = torch.randn(256, 64, 1, 1, generator=g) * (2.0 / 64) ** 0.5
+    wd = torch.randn(256, 64, 1, 1, generator=g) * (2.0 / 64) ** 0.5
+    w1 = torch.randn(64, 256, 1, 1, generator=g) * (2.0 / 256) ** 0.5
+    s3, b3 = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.1
+    sd, bd = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.1
+    s1, b1 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    bc = lambda v: v.double()[None, :, None, None]  # noqa: E731
+    r_ref = F.conv2d(x0.double(), wd.double()) * bc(sd) + bc(bd) if form == "down_sample" else res.double()
+    y_ref = F.relu(F.conv2d(mid.double(), w3.double()) * bc(s3) + bc(b3) + r_ref)
+    z_ref = F.relu(F.conv2d(y_ref, w1.double()) * bc(s1) + bc(b1))
+    st = _lib.stream()
+    dev = lambda t: t.to(DEV)  # noqa: E731
+    midd, resd, x0d, s3d, b3d, sdd, bdd, s1d, b1d = map(dev, (mid, res, x0, s3, b3, sd, bd, s1, b1))
+
+    def pack(wt, co, ci):
+        pk = torch.empty(lib.mp_conv_packed_weight_bytes(co, ci, 1, 1) // 4, device=DEV)
+        _lib.check(lib.mp_conv_pack_weight(_lib.ptr(dev(wt)), _lib.ptr(pk), co, ci, 1, 1, 0, 0, 0, st), "pack")
+        return pk
+    pk3, pkd, pk1 = pack(w3, 256, 64), pack(wd, 256, 64), pack(w1, 64, 256)
+    red = form != "expand_only"
+    for wgs in (None, "3"):  # default grid; three persistent workgroups (every one walks several tiles, uneven counts)
+        if wgs is not None:
+            monkeypatch.setenv("MP_PWCHAIN32_WGS", wgs)
+        y = torch.full((n, 256, h, w), float("nan"), device=DEV)
+        z = torch.full((n, 64, h, w), float("nan"), device=DEV) if red else None
+        ds = form == "down_sample"
+        _lib.check(lib.mp_expand_reduce_fwd(_lib.ptr(midd), None if ds else _lib.ptr(resd), _lib.ptr(x0d) if ds else None,
+                                            _lib.ptr(pkd) if ds else None, _lib.ptr(sdd) if ds else None, _lib.ptr(bdd) if ds else None,
+                                            _lib.ptr(pk3), _lib.ptr(s3d), _lib.ptr(b3d), _lib.ptr(pk1) if red else None,
+                                            _lib.ptr(s1d) if red else None, _lib.ptr(b1d) if red else None, _lib.ptr(y), _lib.ptr(z), n, 64, 256, 64,
+                                            h, w, st), "mp_expand_reduce_fwd")
+        torch.cuda.synchronize()
+        assert torch.isfinite(y).all() and _nerr(y.double().cpu(), y_ref) <= 2e-5
+        if red:
+            assert torch.isfinite(z).all() and _nerr(z.double().cpu(), z_ref) <= 2e-5
+    monkeypatch.delenv("MP_PWCHAIN32_WGS")
+
+    # the launches it replaces
+    def conv(x, pk, sc, sh, r, cin, cout, relu):
+        d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=1, kw=1, stride=1, pad_top=0, pad_left=0, conv_h=h, conv_w=w, out_h=h, out_w=w,
+                          out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=relu, flags=0)
+        out = torch.empty(n, cout, h, w, device=DEV)
+        _lib.check(lib.mp_conv2d_fwd(ctypes.byref(d), _lib.ptr(x), _lib.ptr(pk), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(r), None, _lib.ptr(out), st), "conv")
+        return out
+    r2 = conv(x0d, pkd, sdd, bdd, None, 64, 256, 0) if form == "down_sample" else resd
+    y2 = conv(midd, pk3, s3d, b3d, r2, 64, 256, 1)
+    torch.cuda.synchronize()
+    assert _nerr(y.double().cpu(), y2.double().cpu()) <= 2e-6
+    if red:
+        z2 = conv(y2, pk1, s1d, b1d, None, 256, 64, 1)
+        torch.cuda.synchronize()
+        assert _nerr(z.double().cpu(), z2.double().cpu()) <= 4e-6
+
+
+def test_expand_reduce_chain_f32_rejects_what_it_is_not_built_for():
+    from mindpose_amd import _lib
+    lib = _lib.load()
+    f = torch.zeros(256 * 64 * 64, device=DEV)
+    p = _lib.ptr(f)
+    args = lambda cm, ce, cr, h, w: (p, p, None, None, None, None, p, p, p, p, p, p, p, p, 1, cm, ce, cr, h, w, _lib.stream())  # noqa: E731
+    assert lib.mp_expand_reduce_fwd(*args(32, 128, 32, 8, 8)) == -3   # other widths: MP_ERR_UNSUPPORTED
+    assert lib.mp_expand_reduce_fwd(*args(64, 256, 64, 8, 6)) == -3   # 48 pixels: a tile would straddle images
+    assert lib.mp_expand_reduce_fwd(None, *args(64, 256, 64, 8, 8)[1:]) == -1  # MP_ERR_NULL
+    both = list(args(64, 256, 64, 8, 8)); both[2:6] = [p, p, p, p]
+    assert lib.mp_expand_reduce_fwd(*both) == -1                       # a residual tensor AND a down-sample conv
+    ds_only = list(args(64, 256, 64, 8, 8)); ds_only[1] = None; ds_only[2:6] = [p, p, p, p]; ds_only[9:12] = [None, None, None]; ds_only[13] = None
+    assert lib.mp_expand_reduce_fwd(*ds_only) == -3                    # down-sample form without a reduce conv: not built
+
+
+def test_fp32_network_with_the_stage1_chain_launches_vs_one_launch_per_conv(monkeypatch):
+    """The fp32 plan with the chain launches of stage 1 (MINDPOSE_FUSE_PWCHAIN32, default: three expand + reduce launches - the first
+    with the down-sample conv inside - and the last block's expand conv) against the plan with one launch per conv: heat-maps equal
+    to fp32 rounding, and the entries are really in the plan."""
+    x = torch.randn(3, 3, 256, 192, generator=torch.Generator().manual_seed(3)).to(DEV)
+    outs, kinds = {}, {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MINDPOSE_FUSE_PWCHAIN32", flag)
+        net = _net("hrnet_w32", "hrnet_head")
+        outs[flag] = net(x).clone()
+        plan = next(iter(net._plans.values()))
+        kinds[flag] = [e["kind"] for e in plan.layer_info]
+    assert kinds["1"].count("pwchain_f32") == 4 and kinds["0"].count("pwchain_f32") == 0
+    assert len(kinds["1"]) == len(kinds["0"]) - 4  # three reduce convs and the down-sample conv have no launch of their own
+    assert _nerr(outs["1"].double().cpu(), outs["0"].double().cpu()) <= 1e-5
+
+
 GEMM_CASES = [
     # n, cin, cout, h, w, stride, relu, res
     (3, 256, 1024, 16, 12, 1, False, True),   # ResNet layer3 conv3 + identity (resnet.py:74-138): 576 columns = 4.5 column tiles
