@@ -106,6 +106,20 @@ class Bottleneck(nn.Module):
         return T.conv_bn_act(out, self.conv3, self.bn3, relu=True, res=identity)
 
 
+def emit_block_sequence(plan: Plan, blocks, x: torch.Tensor) -> torch.Tensor:
+    """A run of residual blocks (HRNet's layer1, a ResNet layer): consecutive Bottlenecks hand the next block's reduced input over
+    when the pair ran as one chain launch (``Bottleneck.emit``: (output, the next block's reduced input or None))."""
+    reduced = None
+    for i, blk in enumerate(blocks):
+        if isinstance(blk, Bottleneck) and i + 1 < len(blocks) and isinstance(blocks[i + 1], Bottleneck):
+            x, reduced = blk.emit(plan, x, reduced, blocks[i + 1])
+        elif isinstance(blk, Bottleneck):
+            x, reduced = blk.emit(plan, x, reduced), None
+        else:
+            x, reduced = blk.emit(plan, x), None
+    return x
+
+
 def _conv_bn(cin: int, cout: int, k: int, stride: int = 1, padding: int = 0, relu: bool = False) -> nn.Sequential:
     """SequentialCell(conv, bn[, relu]) of the reference; the ReLU is a marker only (fused in the epilogue)."""
     layers = [Conv2d(cin, cout, k, stride=stride, padding=padding), BatchNorm2d(cout)]
@@ -452,14 +466,7 @@ class HRNet(Backbone):
             x = plan.enter(x)
             x = plan.conv(x, self.conv1, self.bn1, relu=True)
         x = plan.conv(x, self.conv2, self.bn2, relu=True)
-        blocks, reduced = list(self.layer1), None
-        for i, blk in enumerate(blocks):
-            if isinstance(blk, Bottleneck) and i + 1 < len(blocks) and isinstance(blocks[i + 1], Bottleneck):
-                x, reduced = blk.emit(plan, x, reduced, blocks[i + 1])  # (output, the next block's reduced input or None)
-            elif isinstance(blk, Bottleneck):
-                x, reduced = blk.emit(plan, x, reduced), None
-            else:
-                x, reduced = blk.emit(plan, x), None
+        x = emit_block_sequence(plan, list(self.layer1), x)
         ys = [x]
         for idx in (2, 3, 4):
             trans = getattr(self, f"transition{idx - 1}")

@@ -12,7 +12,7 @@ from ...register import register
 from ..layers import BatchNorm2d, Conv2d, Plan
 from .backbone import Backbone
 from .hrnet import Bottleneck as _HRBottleneck
-from .hrnet import _conv_bn
+from .hrnet import _conv_bn, emit_block_sequence
 from .utils import load_pretrained
 
 __all__ = ["ResNet", "resnet50", "resnet101", "resnet152"]
@@ -52,8 +52,9 @@ class ResNet(Backbone):
         x = plan.maxpool3x3s2_same(x)
         x = plan.enter(x)
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
-            for blk in layer:
-                x = blk.emit(plan, x)
+            # (layer1 has HRNet stage 1's widths - 64 -> 256 Bottlenecks on the 64x48 map: its expand / reduce / down-sample 1x1 convs
+            # take the chain launches where the plan has them)
+            x = emit_block_sequence(plan, list(layer), x)
         return x
 
     def train_forward(self, x: torch.Tensor) -> torch.Tensor:
