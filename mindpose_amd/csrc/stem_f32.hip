@@ -59,6 +59,8 @@ __global__ __launch_bounds__(256) void stem_conv_f32_kernel(const StemF32Params 
     {
         const int upr = p.W >> 2, units = 3 * RIN * upr;
         const float* img = p.x + (size_t)n * 3 * p.H * p.W;
+        // (one request per loop pass: twelve units per thread requested up front measured SLOWER - 138 -> 166 us - the registers cost a
+        //  resident workgroup, and it is the other workgroups of the CU that hide this loop's round trips)
         for (int u = tid; u < units; u += 256) {
             const int cr = (int)__umulhi((unsigned)u, p.magic_upr), xu = u - cr * upr;
             const int c = cr / RIN, r = cr - c * RIN;
@@ -77,7 +79,10 @@ __global__ __launch_bounds__(256) void stem_conv_f32_kernel(const StemF32Params 
     const size_t plane_o = (size_t)p.Ho * p.Wo;
     float* outn = p.out + (size_t)n * 64 * plane_o;
     const int zero_slot = 3 * RIN * pitch;
-    for (int t = wave; t < n_tiles; t += 4) {
+    // a wave takes PAIRS of neighbouring tiles: a lane group's 64-byte store of tile 2 i and the one of tile 2 i + 1 are the two halves
+    // of one 128-byte line of an output row - written back to back by the same wave they leave L2 as one line
+    for (int tt = 2 * wave; tt < n_tiles; tt += (tt & 1) ? 7 : 1) {
+        const int t = tt;
         const int ry = t / tiles_row, ox0 = (t - ry * tiles_row) * 16;
         const int base = 2 * ry * pitch + 2 * (ox0 + lr);  // window origin of pixel lr of the tile
         float a[KQ];
