@@ -664,25 +664,59 @@ __global__ __launch_bounds__(256) void pack_weight_f16_batch_kernel(const mp_f16
     }
     const mp_f16_pack_job jb = jobs[lo];
     const int T = jb.kh * jb.kw, cp = (jb.cout + 15) / 16 * 16, kq = (jb.cin + 31) / 32;
-    const unsigned units = (unsigned)kq * T * 4 * cp;
+    // A thread takes one (cin group of 8, cout) pair and walks the T taps (the job owns units / 256 blocks = T times the threads
+    // this needs: the rest leave at once).  A thread per packed 16-byte unit - taps across threads - read the fp32 master weights
+    // through 8 dwords 4 T bytes apart, every line ~12 times per launch: 193 us of every training step for 171 MB.  Here the 8 T
+    // source floats of a thread are ONE contiguous run (forward weights: 16-byte loads), or T-float runs that neighbouring lanes
+    // continue (data-gradient weights: roles swapped) - every line is fetched once; the stores of a tap are 1 KB runs across lanes.
+    const unsigned groups = (unsigned)kq * 4u * (unsigned)cp;
     const unsigned u = (blockIdx.x - first_block[lo]) * 256u + threadIdx.x;
-    if (u >= units) return;
+    if (u >= groups) return;
     const int co = (int)(u % cp);
-    unsigned r = u / cp;
-    const int g = (int)(r & 3);
-    r >>= 2;
-    const int t = (int)(r % T);
-    const int q = (int)(r / T);
-    f16x8 o;
+    const unsigned r = u / cp;
+    const int g = (int)(r & 3), q = (int)(r >> 2);
+    const int ci0 = q * 32 + g * 8;
+    u32x4* __restrict__ out = reinterpret_cast<u32x4*>(jb.packed);
+    const size_t t_stride = (size_t)4 * cp;  // units between consecutive taps of one (q, g, co)
+    const size_t o0 = ((size_t)q * T * 4 + g) * cp + co;
+    if (!jb.transposed && co < jb.cout && ci0 + 8 <= jb.cin && (T == 9 || T == 1) &&
+        ((reinterpret_cast<uintptr_t>(jb.w) | ((size_t)jb.cin * T * 4)) & 15) == 0) {
+        // forward weights [cout][cin][kh][kw]: the thread's 8 T floats are contiguous from (co cin + ci0) T
+        const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(jb.w + ((size_t)co * jb.cin + ci0) * T);
+        if (T == 9) {
+            float v[72];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int ci = q * 32 + g * 8 + j;
-        float v = 0.f;
-        if (co < jb.cout && ci < jb.cin)
-            v = pack_f16_source(jb.w, jb.cout, jb.cin, jb.kh, jb.kw, jb.transposed, jb.phase_y, jb.phase_x, co, ci, t);
-        o[j] = (_Float16)v;
+            for (int i = 0; i < 18; ++i) {
+                const f32x4 x = src[i];
+                v[4 * i] = x[0]; v[4 * i + 1] = x[1]; v[4 * i + 2] = x[2]; v[4 * i + 3] = x[3];
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                f16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (_Float16)v[j * 9 + t];
+                out[o0 + t * t_stride] = __builtin_bit_cast(u32x4, o);
+            }
+        } else {
+            const f32x4 x0 = src[0], x1 = src[1];
+            const f16x8 o = (f16x8){(_Float16)x0[0], (_Float16)x0[1], (_Float16)x0[2], (_Float16)x0[3],
+                                    (_Float16)x1[0], (_Float16)x1[1], (_Float16)x1[2], (_Float16)x1[3]};
+            out[o0] = __builtin_bit_cast(u32x4, o);
+        }
+        return;
     }
-    reinterpret_cast<u32x4*>(jb.packed)[u] = __builtin_bit_cast(u32x4, o);
+    for (int t = 0; t < T; ++t) {
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ci = ci0 + j;
+            float v = 0.f;
+            if (co < jb.cout && ci < jb.cin)
+                v = pack_f16_source(jb.w, jb.cout, jb.cin, jb.kh, jb.kw, jb.transposed, jb.phase_y, jb.phase_x, co, ci, t);
+            o[j] = (_Float16)v;
+        }
+        out[o0 + t * t_stride] = __builtin_bit_cast(u32x4, o);
+    }
 }
 
 // NCHW fp32 -> c8 fp16: one thread per (n, block, pixel): 8 strided plane reads (coalesced across lanes), one 16-B store
