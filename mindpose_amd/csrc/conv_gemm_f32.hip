@@ -31,7 +31,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #ifndef MP_GEMM_ABLATE
-#define MP_GEMM_ABLATE 0  // diagnostic builds (tools/gemm_ablate.sh): 1 = no stores, 2 = no MFMA; results wrong, timings meaningful
+#define MP_GEMM_ABLATE 0  // diagnostic builds (tools/variant_builds.sh): 1 = no stores, 2 = no MFMA; results wrong, timings meaningful
 #endif
 
 constexpr int kTM = 128;     // couts per workgroup

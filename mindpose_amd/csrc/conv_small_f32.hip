@@ -29,7 +29,7 @@ __device__ __forceinline__ unsigned fdiv(unsigned e, unsigned d, unsigned magic)
 // STREAM: with eight in flight the 256-channel layer took 44 us)
 
 #ifndef MP_SMALL_ABLATE
-#define MP_SMALL_ABLATE 0  // diagnostic builds (tools/small_ablate.sh): 1 = no staging, 2 = no MFMA loop, 4 = no weight loads, 8 = no fold; results wrong, timings meaningful
+#define MP_SMALL_ABLATE 0  // diagnostic builds (tools/variant_builds.sh): 1 = no staging, 2 = no MFMA loop, 4 = no weight loads, 8 = no fold; results wrong, timings meaningful
 #endif
 
 constexpr int kWaves = 8;  // K is split eight ways: the 256-channel layer's 576 k-steps = 72 per wave = two fills of the weight ring

@@ -9,7 +9,7 @@
 //
 // Why: as two launches the pair is 199 + 140 us at N = 128 (64x48 maps): the expand conv moves 830 MB at 4.1 TB/s with the matrix
 // pipe 37 % busy - bound by neither, a 128 x 128 tile with four k chunks is mostly skeleton (barriers behind fresh round trips, a
-// store tail that holds the workgroup's slot; tools/gemm_ablate.sh) - and the reduce conv reads y (403 MB) back.  Here:
+// store tail that holds the workgroup's slot; tools/variant_builds.sh) - and the reduce conv reads y (403 MB) back.  Here:
 //   * one workgroup per CU for the whole launch, walking 64-pixel tiles (pixels of one image plane; stride = the grid);
 //   * ALL weight matrices live in registers for the kernel's life as MFMA A operands (v_mfma_f32_32x32x2_f32: lane = (row l % 32,
 //     k l / 32)): wave w owns the expand couts 64 w .. 64 w + 63 (2 row tiles x 32 k-steps = 64 registers; the same again for the
@@ -27,7 +27,7 @@
 //     exchange, 4.5 KB of scale / shift tables.
 // Per tile and wave 128 + 128 MFMAs = 16 384 matrix-pipe cycles = 6.8 us: 24 tiles per CU at N = 128 = 164 us if nothing else showed
 // (the fp32 matrix peak: 25.8 GFLOP), against 1006 MB of HBM traffic = 188 us (measured with the MFMAs taken out:
-// tools/pwchain32_variants.sh).  Measured 280 - 296 us: one wave per SIMD (the weights fill the register file) serialises the
+// tools/variant_builds.sh).  Measured 280 - 296 us: one wave per SIMD (the weights fill the register file) serialises the
 // epilogue, the hand-over and the memory waits with the MFMAs; requesting the residual a tile ahead and batching the LDS operand
 // reads moved nothing (292 - 302 us).  The two launches it replaces: 339 us.
 // Results: y as the stand-alone expand conv up to fp32 rounding; z differs from the stand-alone reduce conv by the association of the
@@ -44,7 +44,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #ifndef PWC_ABLATE
-#define PWC_ABLATE 0  // diagnostic builds (tools/pwchain32_variants.sh): 1 no y stores, 2 no MFMA, 4 no residual loads; results wrong, timings meaningful
+#define PWC_ABLATE 0  // diagnostic builds (tools/variant_builds.sh): 1 no y stores, 2 no MFMA, 4 no residual loads; results wrong, timings meaningful
 #endif
 
 __device__ __forceinline__ f32x16 pwc_fake_mfma(float a, float b, f32x16 c) { c[0] += a * b; return c; }

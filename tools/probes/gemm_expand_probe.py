@@ -1,6 +1,6 @@
 """HRNet's stage-1 expand conv (64 -> 256 @64x48, N = 128: 12.9 GFLOP against 830 MB with the residual) through the blocked-GEMM
 (tuner id 10) and the streaming (8) fp32 1x1 kernels, with and without the residual tensor; stream-timed, 20 launches.
-   python tools/probes/gemm_expand_probe.py     (MINDPOSE_HIP_LIB=build/gemm_ablate_<m>/... for the ablation builds of tools/gemm_ablate.sh)"""
+   python tools/probes/gemm_expand_probe.py     (MINDPOSE_HIP_LIB=build/conv_gemm_f32_<tag>/... for the ablation builds of tools/variant_builds.sh)"""
 import ctypes, os, statistics, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mindpose_amd import _lib
