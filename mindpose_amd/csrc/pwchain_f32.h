@@ -27,6 +27,7 @@ struct PwChainF32Params {
 struct PwChainF32Launch {
     PwChainF32Params p;
     bool ds, red;  // the instantiation: down-sample residual computed here / reduce conv follows
+    int form;      // 4: four waves, 64-pixel tiles; 8: eight waves (pixel half x cout quarter); 2: four waves, 32-pixel tiles, two workgroups per CU
     int grid;
     size_t lds_bytes;
 };

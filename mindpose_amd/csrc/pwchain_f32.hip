@@ -29,7 +29,8 @@
 // (the fp32 matrix peak: 25.8 GFLOP), against 1006 MB of HBM traffic = 188 us (measured with the MFMAs taken out:
 // tools/variant_builds.sh).  Measured 280 - 296 us: one wave per SIMD (the weights fill the register file) serialises the
 // epilogue, the hand-over and the memory waits with the MFMAs; requesting the residual a tile ahead and batching the LDS operand
-// reads moved nothing (292 - 302 us).  The two launches it replaces: 339 us.
+// reads moved nothing (292 - 302 us).  The two launches it replaces: 339 us.  A second resident wave per SIMD is what helped: four
+// waves on 32-pixel tiles with TWO workgroups per CU (272 us; eight waves in one workgroup: 285 - its barriers keep them in step).
 // Results: y as the stand-alone expand conv up to fp32 rounding; z differs from the stand-alone reduce conv by the association of the
 // k sum (four slices of 64, pairs (c, c + 4)) - tests/test_gpu_conv.py::test_expand_reduce_chain_f32 compares both with fp64 torch
 // at the direct kernel's bar.
@@ -334,6 +335,195 @@ __global__ __launch_bounds__(256, 1) void expand_reduce_f32_kernel(const PwChain
     }
 }
 
+
+// The same chain with EIGHT waves (two per SIMD): wave = (pixel half pw, cout quarter cw).  A wave keeps the same 128 weight registers
+// but half the accumulators (its 64 couts x 32 pixels), which is what fits 256 registers per wave - and a second resident wave is what
+// the four-wave form lacks: its epilogue, hand-over and memory waits (288 us per launch against a 164 us MFMA-only and a 188 us
+// memory-only time) now run under the other wave's MFMAs.  Two accumulators alternate per wave, four per SIMD.  The K-slice partials
+// of z are folded in the same wave order: z and y are bit-identical to the four-wave form's.  (The down-sample form keeps four waves:
+// its three weight matrices are 192 registers.)
+// PW = 2: the eight-wave form above (64-pixel tiles, one workgroup per CU).  PW = 1: FOUR waves on 32-pixel tiles, TWO workgroups per
+// CU: the same two waves per SIMD, but the two pixel halves are separate workgroups - the barriers of the K-slice hand-over hold the
+// eight waves of one workgroup in step (all in the MFMA phases together, all in the epilogue together); two workgroups drift apart.
+template <bool RED, int PW>
+__global__ __launch_bounds__(256 * PW, 3 - PW) void expand_reduce_f32_w8_kernel(const PwChainF32Params p) {
+    constexpr int kXBuf = 64 * kXP;
+    constexpr int TPX = 32 * PW;  // pixels per tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* __restrict__ lds_x = smem;                // [2][64][kXP]
+    float* __restrict__ lds_ex = smem + 2 * kXBuf;   // [4 PW waves][3 owners][2][64 lanes] float4
+    float* __restrict__ lds_ss = lds_ex + kExBuf / 2 * PW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cw = wave & 3, pw = wave >> 2;
+    const int tiles_per_img = p.tiles_per_img * (2 / PW), total_tiles = p.total_tiles * (2 / PW);
+    const int l31 = lane & 31, h = lane >> 5;
+
+    if (tid < 256) {
+        lds_ss[tid] = p.scale3[tid];
+        lds_ss[256 + tid] = p.shift3[tid];
+    }
+    if (RED && tid < 64) {
+        lds_ss[kSs1 + tid] = p.scale1[tid];
+        lds_ss[kSs1 + 64 + tid] = p.shift1[tid];
+    }
+    float a3[2][32];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int s = 0; s < 32; ++s) a3[rt][s] = p.w3[(2 * s + h) * 256 + 64 * cw + 32 * rt + l31];
+    float a1[RED ? 2 : 1][RED ? 2 : 1][RED ? 16 : 1];
+    if constexpr (RED) {
+#pragma unroll
+        for (int rt2 = 0; rt2 < 2; ++rt2)
+#pragma unroll
+            for (int rt1 = 0; rt1 < 2; ++rt1)
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    a1[rt2][rt1][s] = p.w1[(64 * cw + 32 * rt1 + 8 * (s >> 2) + 4 * h + (s & 3)) * 64 + 32 * rt2 + l31];
+    }
+    const unsigned plane = (unsigned)p.HW * 4u;
+    const __amdgpu_buffer_rsrc_t rs_mid = make_rsrc(p.mid, (size_t)p.N * 64 * plane);
+    const __amdgpu_buffer_rsrc_t rs_res = make_rsrc(p.res, (size_t)p.N * 256 * plane);
+    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(p.y, (size_t)p.N * 256 * plane);
+    const __amdgpu_buffer_rsrc_t rs_z = make_rsrc(RED ? p.z : p.y, (size_t)p.N * (RED ? 64 : 256) * plane);
+
+    // input staging: thread -> channel k = tid / (4 PW), eight pixels 8 (tid % (4 PW)) ..: two 16-byte loads
+    const int xk = tid / (4 * PW), xq = tid % (4 * PW);
+    auto x_offset = [&](int tile) {
+        const int n = tile / tiles_per_img, p0 = (tile - n * tiles_per_img) * TPX;
+        return (unsigned)((n * 64 + xk) * p.HW + p0 + 8 * xq) * 4u;
+    };
+    f32x4 xv[2];
+    auto x_load = [&](unsigned off) __attribute__((always_inline)) {
+        xv[0] = buf_load4(rs_mid, off);
+        xv[1] = buf_load4(rs_mid, off + 16u);
+    };
+    auto x_store = [&](int buf) __attribute__((always_inline)) {
+        *reinterpret_cast<f32x4*>(lds_x + buf * kXBuf + xk * kXP + 8 * xq) = xv[0];
+        *reinterpret_cast<f32x4*>(lds_x + buf * kXBuf + xk * kXP + 8 * xq + 4) = xv[1];
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= total_tiles) return;
+    x_load(x_offset(tile));
+    x_store(0);
+    chain_barrier();
+
+    const int b_off = h * kXP + 32 * pw + l31;
+    for (int it = 0; tile < total_tiles; ++it, tile += gridDim.x) {
+        const int cur = it & 1;
+        const int n = tile / tiles_per_img, p0 = (tile - n * tiles_per_img) * TPX;
+        const bool has_next = tile + (int)gridDim.x < total_tiles;
+        const unsigned v_y = (unsigned)((n * 256 + 4 * h) * p.HW + p0 + 32 * pw + l31) * 4u;
+        f32x16 rr[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned s_off = (unsigned)(64 * cw + 32 * rt + 8 * (r >> 2) + (r & 3)) * plane;
+                rr[rt][r] = (PWC_ABLATE & 4) ? (float)(v_y + s_off) : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, v_y, s_off, 0));
+            }
+        if (!RED && has_next) x_load(x_offset(tile + gridDim.x));
+        // ---- expand: 64 couts x 32 pixels of this wave, K = 64
+        const float* __restrict__ xs = lds_x + cur * kXBuf + b_off;
+        f32x16 acc1[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[rt][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const float b = xs[2 * s * kXP];
+            acc1[0] = PWC_MFMA(a3[0][s], b, acc1[0]);
+            acc1[1] = PWC_MFMA(a3[1][s], b, acc1[1]);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int row = 64 * cw + 32 * rt + 8 * g + 4 * h;
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(lds_ss + row), sh = *reinterpret_cast<const f32x4*>(lds_ss + 256 + row);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = fmaxf(acc1[rt][4 * g + e] * sc[e] + sh[e] + rr[rt][4 * g + e], 0.f);
+                    acc1[rt][4 * g + e] = v;
+                    if (RED && (PWC_ABLATE & 1)) continue;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, v_y, (unsigned)(64 * cw + 32 * rt + 8 * g + e) * plane, 0);
+                }
+            }
+        if constexpr (!RED) {
+            if (has_next) x_store(cur ^ 1);
+            chain_barrier();
+            continue;
+        } else {
+            if (has_next) x_load(x_offset(tile + gridDim.x));
+            // ---- reduce: this wave's K slice (its own 64 channels of y) for all 64 couts x its 32 pixels
+            f32x16 acc2[2];
+#pragma unroll
+            for (int rt2 = 0; rt2 < 2; ++rt2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[rt2][r] = 0.f;
+#pragma unroll
+            for (int rt1 = 0; rt1 < 2; ++rt1)
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    acc2[0] = PWC_MFMA(a1[0][rt1][s], acc1[rt1][s], acc2[0]);
+                    acc2[1] = PWC_MFMA(a1[1][rt1][s], acc1[rt1][s], acc2[1]);
+                }
+            // ---- hand-over inside the pixel half: owner o of (row tile o / 2, registers 8 (o % 2) .. + 7) is wave (pw, o)
+            if (has_next) x_store(cur ^ 1);
+            f32x4* __restrict__ ex4 = reinterpret_cast<f32x4*>(lds_ex);
+            if (it > 0) chain_barrier();  // every wave has read the last tile's partials
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                if (o == cw) continue;  // wave-uniform
+                const int slot = o < cw ? o : o - 1;
+                const f32x16& a = acc2[o >> 1];
+#pragma unroll
+                for (int gg = 0; gg < 2; ++gg) {
+                    const int r0 = 8 * (o & 1) + 4 * gg;
+                    ex4[(((pw * 4 + cw) * 3 + slot) * 2 + gg) * 64 + lane] = (f32x4){a[r0], a[r0 + 1], a[r0 + 2], a[r0 + 3]};
+                }
+            }
+            float mine[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                mine[i] = cw == 0 ? acc2[0][i] : cw == 1 ? acc2[0][8 + i] : cw == 2 ? acc2[1][i] : acc2[1][8 + i];
+            chain_barrier();
+            float tot[8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float val[8];
+                if (u == cw) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) val[i] = mine[i];
+                } else {
+                    const int slot = cw < u ? cw : cw - 1;
+#pragma unroll
+                    for (int gg = 0; gg < 2; ++gg) {
+                        const f32x4 t = ex4[(((pw * 4 + u) * 3 + slot) * 2 + gg) * 64 + lane];
+                        val[4 * gg] = t[0]; val[4 * gg + 1] = t[1]; val[4 * gg + 2] = t[2]; val[4 * gg + 3] = t[3];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) tot[i] = u == 0 ? val[i] : tot[i] + val[i];
+            }
+            const int rt2 = cw >> 1, hh = cw & 1;
+            const unsigned v_z = (unsigned)((n * 64 + 4 * h) * p.HW + p0 + 32 * pw + l31) * 4u;
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {
+                const int g = 2 * hh + gg, row = 32 * rt2 + 8 * g + 4 * h;
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(lds_ss + kSs1 + row), sh = *reinterpret_cast<const f32x4*>(lds_ss + kSs1 + 64 + row);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = fmaxf(tot[4 * gg + e] * sc[e] + sh[e], 0.f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_z, v_z, (unsigned)(32 * rt2 + 8 * g + e) * plane, 0);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int pwchain32_build(const float* mid, const float* res, const float* x0, const float* packed_wd, const float* scale_d, const float* shift_d,
@@ -353,10 +543,20 @@ int pwchain32_build(const float* mid, const float* res, const float* x0, const f
     p.w3 = packed_w3; p.scale3 = scale3; p.shift3 = shift3; p.w1 = packed_w1; p.scale1 = scale1; p.shift1 = shift1;
     p.y = y; p.z = z; p.N = n; p.HW = h * w; p.tiles_per_img = p.HW / 64; p.total_tiles = n * p.tiles_per_img;
     L.ds = ds; L.red = red;
+    // forms: 4 = four waves, 64-pixel tiles, one workgroup per CU (the down-sample form's only one); 8 = eight waves; 2 = four waves on
+    // 32-pixel tiles, two workgroups per CU.  Measured at N = 128 (64x48): chain 300 / 285 / 272 us for forms 4 / 8 / 2, expand conv
+    // alone 185 / 165 / 174 us
+    L.form = ds ? 4 : red ? 2 : 8;
+    if (const char* e = knob("MP_PWCHAIN32_WAVES")) {  // experiments / tests
+        const int v = atoi(e);
+        if (!ds && (v == 2 || v == 4 || v == 8)) L.form = v;
+    }
     int cus = 256;
     if (const char* e = knob("MP_PWCHAIN32_WGS")) cus = atoi(e) > 0 ? atoi(e) : cus;  // experiments
-    L.grid = p.total_tiles < cus ? p.total_tiles : cus;
-    L.lds_bytes = (size_t)(2 * (ds ? 128 : 64) * kXP + kExBuf + kSs) * 4;
+    const int tiles = L.form == 2 ? 2 * p.total_tiles : p.total_tiles, slots = L.form == 2 ? 2 * cus : cus;
+    L.grid = tiles < slots ? tiles : slots;
+    L.lds_bytes = L.form == 4 ? (size_t)(2 * (ds ? 128 : 64) * kXP + kExBuf + kSs) * 4
+                              : (size_t)(2 * 64 * kXP + kExBuf / 2 * (L.form == 8 ? 2 : 1) + kSs) * 4;
     return MP_OK;
 }
 
@@ -371,7 +571,18 @@ int pwchain32_launch(const PwChainF32Launch& L, hipStream_t s) {
         hipLaunchKernelGGL(kern, dim3(L.grid), dim3(256), L.lds_bytes, s, L.p);
         return check_launch();
     };
+    auto go8 = [&](auto kern, int threads) {
+        static AttrOnce attr_once;
+        if (attr_once.need()) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipGetLastError();
+        }
+        hipLaunchKernelGGL(kern, dim3(L.grid), dim3(threads), L.lds_bytes, s, L.p);
+        return check_launch();
+    };
     if (L.ds) return go(expand_reduce_f32_kernel<true, true>);
+    if (L.form == 8) return L.red ? go8(expand_reduce_f32_w8_kernel<true, 2>, 512) : go8(expand_reduce_f32_w8_kernel<false, 2>, 512);
+    if (L.form == 2) return L.red ? go8(expand_reduce_f32_w8_kernel<true, 1>, 256) : go8(expand_reduce_f32_w8_kernel<false, 1>, 256);
     if (L.red) return go(expand_reduce_f32_kernel<false, true>);
     return go(expand_reduce_f32_kernel<false, false>);
 }

@@ -379,6 +379,19 @@ def test_expand_reduce_chain_f32(shape, form, monkeypatch):
         if red:
             assert torch.isfinite(z).all() and _nerr(z.double().cpu(), z_ref) <= 2e-5
     monkeypatch.delenv("MP_PWCHAIN32_WGS")
+    if form != "down_sample":
+        # the default form (four waves on 32-pixel tiles, two workgroups per CU) against the one-workgroup forms - four waves / eight
+        # waves on 64-pixel tiles: same bits
+        for waves in ("4", "8"):
+            monkeypatch.setenv("MP_PWCHAIN32_WAVES", waves)
+            y4 = torch.full((n, 256, h, w), float("nan"), device=DEV)
+            z4 = torch.full((n, 64, h, w), float("nan"), device=DEV) if red else None
+            _lib.check(lib.mp_expand_reduce_fwd(_lib.ptr(midd), _lib.ptr(resd), None, None, None, None, _lib.ptr(pk3), _lib.ptr(s3d), _lib.ptr(b3d),
+                                                _lib.ptr(pk1) if red else None, _lib.ptr(s1d) if red else None, _lib.ptr(b1d) if red else None,
+                                                _lib.ptr(y4), _lib.ptr(z4), n, 64, 256, 64, h, w, st), f"mp_expand_reduce_fwd ({waves} waves)")
+            torch.cuda.synchronize()
+            assert torch.equal(y4, y) and (not red or torch.equal(z4, z))
+        monkeypatch.delenv("MP_PWCHAIN32_WAVES")
 
     # the launches it replaces
     def conv(x, pk, sc, sh, r, cin, cout, relu):
