@@ -80,7 +80,10 @@ def kernel_name(info):
     if info["kind_id"] == 11:  # first conv straight from the fp32 image (stem_f16.hip)
         return "stem_conv_f16_kernel"
     if info["kind_id"] == 13:  # fp32 expand + reduce chain of stage 1, persistent weight-stationary launch (pwchain_f32.hip)
-        return "expand_reduce_f32_kernel"
+        form, v = info.get("light", 4), info.get("variant", 0)  # entry_info: light = the form (waves / tile), variant = down-sample + 2 * no reduce
+        if form == 4:
+            return f"expand_reduce_f32_kernel<{'true' if v & 1 else 'false'},{'false' if v & 2 else 'true'}>"
+        return f"expand_reduce_f32_w8_kernel<{'false' if v & 2 else 'true'},{2 if form == 8 else 1}>"
     if info["kind_id"] == 10:  # expand conv of a Bottleneck + reduce conv of the next one in one launch (pwchain_f16.hip)
         return "expand_reduce_f16_kernel<64,256,64,true>" if info.get("variant") == 1 else "expand_reduce_f16_kernel<64,256,64,false>"
     if info["kind_id"] == 8:  # fused fp16 BasicBlock: the <5,3> or <6,5> pixel-tile build ("variant" = 1 for the small one)

@@ -808,7 +808,8 @@ int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]) {
         info[5] = (int64_t)e.stem16.lds_bytes; info[6] = 64; info[7] = 8 * e.stem16.p.Wo; info[8] = 3; info[9] = 1; info[10] = 8;
     } else if (e.kind == 13) {
         info[1] = 1; info[2] = 1; info[3] = (e.pwchain32.ds ? 1 : 0) + (e.pwchain32.red ? 0 : 2); info[4] = e.pwchain32.grid;
-        info[5] = (int64_t)e.pwchain32.lds_bytes; info[6] = 256; info[7] = 64; info[8] = 64; info[9] = 1; info[10] = 0;
+        info[5] = (int64_t)e.pwchain32.lds_bytes; info[6] = 256; info[7] = e.pwchain32.form == 2 ? 32 : 64; info[8] = 64; info[9] = 1; info[10] = 0;
+        info[11] = e.pwchain32.form;  // 4 / 8 waves per workgroup on 64-pixel tiles, 2 = four waves on 32-pixel tiles, two workgroups per CU
     } else if (e.kind == 10) {
         info[1] = 1; info[2] = 1; info[3] = e.pwchain.dual ? 1 : 0; info[4] = e.pwchain.p.total_blocks;
         info[5] = (int64_t)e.pwchain.lds_bytes; info[6] = e.pwchain.ce; info[7] = 64; info[8] = e.pwchain.cm; info[9] = 1; info[10] = 0;

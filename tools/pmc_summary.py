@@ -22,7 +22,7 @@ def key_of(name):
         # pixel tiles, cout tiles per wave, pixel-splitting waves, occupancy | statistics mode>: the head is bench.py's kernel_name
         keep = 5 if m.group(1) == "conv_f16_ws_kernel" else 6
         return f"{m.group(1)}<{','.join(a.strip() for a in m.group(2).split(',')[:keep])}>"
-    m = re.search(r"(expand_reduce_f16_kernel|basicblock_f16_c64_kernel|basicblock_f16_v2_kernel|basicblock_f16_kernel|conv_wino_f32_kernel|conv1x1_f32_stream_kernel|conv1x1_f32_gemm_kernel)<([^>]*)>", name)
+    m = re.search(r"(expand_reduce_f32_w8_kernel|expand_reduce_f32_kernel|expand_reduce_f16_kernel|basicblock_f16_c64_kernel|basicblock_f16_v2_kernel|basicblock_f16_kernel|conv_wino_f32_kernel|conv1x1_f32_stream_kernel|conv1x1_f32_gemm_kernel)<([^>]*)>", name)
     if m:  # these names are used with their full template argument list
         return f"{m.group(1)}<{','.join(a.strip() for a in m.group(2).split(','))}>"
     m = re.search(r"(conv_mfma_kernel|conv_f16_mt_kernel|conv_f16_kernel)<([^>]*)>", name)
