@@ -63,6 +63,45 @@ def test_headline_plan_n128_fp32_vs_oracle(backbone, head):
     _check_slice(got, ref, 1e-3)
 
 
+@pytest.mark.parametrize("n", [1, 32])
+def test_small_batch_plans_fp32_vs_oracle(n):
+    """SURVEY 8(d) names N in {1, 32, 128, 256}: the plans `bench.py --sweep` times at N = 1 and N = 32 (their own tuner choices - the
+    K-split small-problem kernel on the deep branches, the stage-1 chain launches on few tiles) against `oracle/nets.py`."""
+    net = mp.init_synthetic(mp.create_network("hrnet_w32", "hrnet_head"), seed=0).to(DEV).eval()
+    x = _bench_like_batch(n, 256, 192)
+    image = net.input_buffer((n, 3, 256, 192), DEV)
+    image.copy_(x)
+    sl = sorted(set(list(range(0, min(2, n))) + list(range(max(0, n - 2), n))))
+    got = net(image)[sl].cpu()
+    plan = net.get_plan((n, 3, 256, 192), DEV)
+    variants = [plan.entry_info(i).get("variant") for i in range(len(plan)) if plan.layer_info[i]["kind"] == "conv"]
+    assert any(v in (11, 12) for v in variants), "the small-problem kernel is in neither plan"
+    assert [e["kind"] for e in plan.layer_info].count("pwchain_f32") == 4
+    params = {k: v.cpu() for k, v in net.state_dict().items()}
+    ref = onets.net_forward(params, x[sl], "hrnet_w32", "hrnet_head")
+    _check_slice(got, ref, 1e-3)
+
+
+@pytest.mark.parametrize("n", [1, 32])
+def test_small_batch_plans_amp_o2_vs_amp_oracle(n):
+    """The amp-O2 plans of the same two batch sizes (fused-block band heights and conv variants tuned per N) against the oracle's fp32
+    graph and its op-by-op amp emulation - the asserts of the N = 128 test."""
+    net = mp.init_synthetic(mp.create_network("hrnet_w32", "hrnet_head"), seed=0).to(DEV).eval()
+    mp.models.auto_mixed_precision(net, "O2")
+    x = _bench_like_batch(n, 256, 192)
+    image = net.input_buffer((n, 3, 256, 192), DEV)
+    image.copy_(x)
+    sl = sorted(set(list(range(0, min(2, n))) + list(range(max(0, n - 2), n))))
+    got = net(image)[sl].cpu()
+    params = {k: v.cpu() for k, v in net.state_dict().items()}
+    ref32 = onets.net_forward(params, x[sl], "hrnet_w32", "hrnet_head")
+    ref16 = onets.net_forward(params, x[sl], "hrnet_w32", "hrnet_head", amp=True)
+    e_hip = float((got - ref32).abs().max() / ref32.abs().max())
+    e_emul = float((ref16 - ref32).abs().max() / ref32.abs().max())
+    assert e_hip <= 1.5 * e_emul + 1e-3, f"HIP fp16 {e_hip} vs op-by-op amp-O2 emulation {e_emul}"
+    assert e_hip < 2e-2
+
+
 def test_headline_plan_n128_amp_o2_vs_amp_oracle():
     net = mp.init_synthetic(mp.create_network("hrnet_w32", "hrnet_head"), seed=0).to(DEV).eval()
     mp.models.auto_mixed_precision(net, "O2")
