@@ -85,7 +85,8 @@ def kernel_name(info):
             return f"expand_reduce_f32_kernel<{'true' if v & 1 else 'false'},{'false' if v & 2 else 'true'}>"
         return f"expand_reduce_f32_w8_kernel<{'false' if v & 2 else 'true'},{2 if form == 8 else 1}>"
     if info["kind_id"] == 10:  # expand conv of a Bottleneck + reduce conv of the next one in one launch (pwchain_f16.hip)
-        return "expand_reduce_f16_kernel<64,256,64,true>" if info.get("variant") == 1 else "expand_reduce_f16_kernel<64,256,64,false>"
+        return {1: "expand_reduce_f16_kernel<64,256,64,true,false>", 2: "expand_reduce_f16_kernel<64,256,64,false,true>"}.get(
+            info.get("variant"), "expand_reduce_f16_kernel<64,256,64,false,false>")  # dual 1x1 / down-sample inside / identity chain
     if info["kind_id"] == 8:  # fused fp16 BasicBlock: the <5,3> or <6,5> pixel-tile build ("variant" = 1 for the small one)
         return {0: "basicblock_f16_kernel<6,5>", 1: "basicblock_f16_kernel<5,3>", 2: "basicblock_f16_v2_kernel<8,4,3>",
                 4: "basicblock_f16_c64_kernel<2,8,6>", 5: "basicblock_f16_c64_kernel<4,4,3>"}[info["variant"]]  # 4 / 5: 64 / 128 channels

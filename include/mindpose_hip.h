@@ -427,6 +427,18 @@ int mp_f16_expand_reduce_fwd(const void* mid_c8_dev, const void* res_c8_dev, con
 int mp_f16_dual_pw_fwd(const void* x_c8_dev, const void* packed_wa_dev, const float* scale_a_dev, const float* shift_a_dev, int relu_a,
                        const void* packed_wb_dev, const float* scale_b_dev, const float* shift_b_dev, int relu_b, void* ya_c8_dev,
                        void* zb_c8_dev, int n, int cm, int ce, int cr, int h, int w, mp_stream_t stream);
+/* The chain with the FIRST Bottleneck's identity computed inside (hrnet.py:74-81, 107-146): y = act3(conv1x1(mid; w3) * scale3 + shift3 + d),
+ * d = conv1x1(x0; wd) * scale_d + shift_d rounded to fp16 (the block's down-sample conv of its 64-channel input, no ReLU), then z as
+ * in mp_f16_expand_reduce_fwd.  d is neither written nor read back; y and z are bit-identical to the three mp_f16_conv2d_fwd launches. */
+int mp_f16_ds_expand_reduce_fwd(const void* mid_c8_dev, const void* x0_c8_dev, const void* packed_wd_dev, const float* scale_d_dev,
+                                const float* shift_d_dev, const void* packed_w3_dev, const float* scale3_dev, const float* shift3_dev,
+                                int relu3, const void* packed_w1_dev, const float* scale1_dev, const float* shift1_dev, int relu1,
+                                void* y_c8_dev, void* z_c8_dev, int n, int cm, int ce, int cr, int h, int w, mp_stream_t stream);
+int mp_plan_add_ds_expand_reduce_f16(mp_plan* plan, const void* mid_c8_dev, const void* x0_c8_dev, const void* packed_wd_dev,
+                                     const float* scale_d_dev, const float* shift_d_dev, const void* packed_w3_dev,
+                                     const float* scale3_dev, const float* shift3_dev, int relu3, const void* packed_w1_dev,
+                                     const float* scale1_dev, const float* shift1_dev, int relu1, void* y_c8_dev, void* z_c8_dev, int n,
+                                     int cm, int ce, int cr, int h, int w);
 int mp_plan_add_dual_pw_f16(mp_plan* plan, const void* x_c8_dev, const void* packed_wa_dev, const float* scale_a_dev,
                             const float* shift_a_dev, int relu_a, const void* packed_wb_dev, const float* scale_b_dev,
                             const float* shift_b_dev, int relu_b, void* ya_c8_dev, void* zb_c8_dev, int n, int cm, int ce, int cr, int h, int w);

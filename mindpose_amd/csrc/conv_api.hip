@@ -688,6 +688,22 @@ int mp_plan_add_expand_reduce(mp_plan* plan, const float* mid, const float* res,
     return MP_OK;
 }
 
+int mp_plan_add_ds_expand_reduce_f16(mp_plan* plan, const void* mid, const void* x0, const void* packed_wd, const float* scale_d,
+                                     const float* shift_d, const void* packed_w3, const float* scale3, const float* shift3, int relu3,
+                                     const void* packed_w1, const float* scale1, const float* shift1, int relu1, void* y, void* z, int n,
+                                     int cm, int ce, int cr, int h, int w) {
+    if (!plan || !x0) return MP_ERR_NULL;
+    mp_plan::Entry e{};
+    e.kind = 10;
+    int rc = pwchain_build(mid, nullptr, packed_w3, scale3, shift3, relu3, packed_w1, scale1, shift1, relu1, y, z, n, cm, ce, cr, h, w, e.pwchain,
+                           x0, packed_wd, scale_d, shift_d);
+    if (rc != MP_OK) return rc;
+    e.n = n; e.c = ce; e.h = h; e.w = w;
+    e.lane = plan->cur_lane;
+    plan->entries.push_back(e);
+    return MP_OK;
+}
+
 int mp_plan_add_dual_pw_f16(mp_plan* plan, const void* x, const void* packed_wa, const float* scale_a, const float* shift_a, int relu_a,
                             const void* packed_wb, const float* scale_b, const float* shift_b, int relu_b, void* ya, void* zb, int n, int cm,
                             int ce, int cr, int h, int w) {
@@ -811,7 +827,7 @@ int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]) {
         info[5] = (int64_t)e.pwchain32.lds_bytes; info[6] = 256; info[7] = e.pwchain32.form == 2 ? 32 : 64; info[8] = 64; info[9] = 1; info[10] = 0;
         info[11] = e.pwchain32.form;  // 4 / 8 waves per workgroup on 64-pixel tiles, 2 = four waves on 32-pixel tiles, two workgroups per CU
     } else if (e.kind == 10) {
-        info[1] = 1; info[2] = 1; info[3] = e.pwchain.dual ? 1 : 0; info[4] = e.pwchain.p.total_blocks;
+        info[1] = 1; info[2] = 1; info[3] = e.pwchain.dual ? 1 : e.pwchain.ds ? 2 : 0; info[4] = e.pwchain.p.total_blocks;
         info[5] = (int64_t)e.pwchain.lds_bytes; info[6] = e.pwchain.ce; info[7] = 64; info[8] = e.pwchain.cm; info[9] = 1; info[10] = 0;
     } else if (e.kind == 8) {
         info[1] = 3; info[2] = 1; info[3] = e.block16.small; info[4] = e.block16.p.total_blocks;

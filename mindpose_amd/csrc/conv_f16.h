@@ -139,16 +139,23 @@ struct PwChainParams {
     void* y;           // [N][CE/8][HW]
     void* z;           // [N][CR/8][HW]
     int N, HW, tiles_per_img, total_blocks, relu3, relu1;
+    // down-sample form: the identity is conv1x1(x0; wd) * scale_d + shift_d (no ReLU), computed in the launch (res unused)
+    const void* x0;    // [N][CM/8][HW]: the block's input
+    const void* wd;    // packed 1x1 weights CM -> CE
+    const float* scale_d;
+    const float* shift_d;
 };
 struct PwChainLaunch {
     PwChainParams p;
     int cm, ce, cr, h, w;
     bool dual;  // both convs read `mid` (the first Bottleneck's down-sample + reduce convs): res == mid marks it
+    bool ds;    // the identity is the block's down-sample conv of x0, computed in the launch
     size_t lds_bytes;
 };
 int pwchain_build(const void* mid, const void* res, const void* w3, const float* scale3, const float* shift3, int relu3, const void* w1,
                   const float* scale1, const float* shift1, int relu1, void* y, void* z, int n, int cm, int ce, int cr, int h, int w,
-                  PwChainLaunch& L);
+                  PwChainLaunch& L, const void* x0 = nullptr, const void* wd = nullptr, const float* scale_d = nullptr,
+                  const float* shift_d = nullptr);
 int pwchain_launch(const PwChainLaunch& L, hipStream_t s);
 
 // first conv of the network straight from the fp32 NCHW image (stem_f16.hip): 3x3 stride 2 padding 1, 3 -> 64 channels

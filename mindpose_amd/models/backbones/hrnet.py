@@ -74,15 +74,15 @@ class Bottleneck(nn.Module):
         (output, reduced output for ``nxt``) is returned instead of the output alone."""
         identity = x
         ds_in_chain = None
-        if (self.down_sample is not None and reduced is None and len(self.down_sample) == 2
-                and plan.fuses_dual_pw(x, self.down_sample[0], self.conv1)):
-            # the down-sample conv and the reduce conv read the same input: one launch (fp16 plans)
-            identity, reduced = plan.dual_pw(x, self.down_sample[0], self.down_sample[1], False, self.conv1, self.bn1, True)
-        elif (self.down_sample is not None and len(self.down_sample) == 2 and nxt is not None and self.conv2.stride == 1
-              and self.conv2.out_channels == 64 and plan.fuses_ds_expand_reduce(x, self.down_sample[0], self.conv3, nxt.conv1)):
-            # fp32 plans: the down-sample conv is computed INSIDE the expand + reduce chain launch below - its 256-channel output is
-            # neither written nor read back
+        if (self.down_sample is not None and len(self.down_sample) == 2 and nxt is not None and self.conv2.stride == 1
+                and self.conv2.out_channels == 64 and plan.fuses_ds_expand_reduce(x, self.down_sample[0], self.conv3, nxt.conv1)):
+            # the down-sample conv is computed INSIDE the expand + reduce chain launch below - its 256-channel output is neither
+            # written nor read back
             ds_in_chain = (x, self.down_sample[0], self.down_sample[1])
+        elif (self.down_sample is not None and reduced is None and len(self.down_sample) == 2
+              and plan.fuses_dual_pw(x, self.down_sample[0], self.conv1)):
+            # the down-sample conv and the reduce conv read the same input: one launch (fp16 plans without the form above)
+            identity, reduced = plan.dual_pw(x, self.down_sample[0], self.down_sample[1], False, self.conv1, self.bn1, True)
         elif self.down_sample is not None:
             identity = plan.conv(x, self.down_sample[0], self.down_sample[1])
         out = reduced if reduced is not None else plan.conv(x, self.conv1, self.bn1, relu=True)

@@ -707,14 +707,19 @@ class Plan:
                 and cv.bias is None)
 
     def fuses_ds_expand_reduce(self, x0: torch.Tensor, ds_conv: Conv2d, conv3: Conv2d, conv1_next: Conv2d) -> bool:
-        """fp32 plans: can the FIRST Bottleneck's down-sample conv (hrnet.py:74-81, 64 -> 256 on the block's input) be computed inside
-        the expand + reduce chain launch, instead of being written and read back as the residual tensor by a launch of its own?
-        ``MINDPOSE_FUSE_PWCHAIN32_DS=0`` keeps the separate launch."""
-        if isinstance(x0, ActC8) or os.environ.get("MINDPOSE_FUSE_PWCHAIN32", "1") == "0" or os.environ.get("MINDPOSE_FUSE_PWCHAIN32_DS", "1") == "0":
+        """Can the FIRST Bottleneck's down-sample conv (hrnet.py:74-81, 64 -> 256 on the block's input) be computed inside the expand +
+        reduce chain launch, instead of being written and read back as the residual tensor by a launch of its own?
+        ``MINDPOSE_FUSE_PWCHAIN32_DS=0`` (fp32) / ``MINDPOSE_FUSE_PWCHAIN_DS=0`` (fp16: the dual 1x1 launch + the identity chain instead)
+        keep the separate launch."""
+        half = isinstance(x0, ActC8)
+        if half and (os.environ.get("MINDPOSE_FUSE_PWCHAIN", "1") == "0" or os.environ.get("MINDPOSE_FUSE_PWCHAIN_DS", "1") == "0"):
+            return False
+        if not half and (os.environ.get("MINDPOSE_FUSE_PWCHAIN32", "1") == "0" or os.environ.get("MINDPOSE_FUSE_PWCHAIN32_DS", "1") == "0"):
             return False
         n, c, h, w = x0.shape
-        return (c == 64 and self._pw(ds_conv, 64, 256) and self._pw(conv3, 64, 256) and self._pw(conv1_next, 256, 64) and (h * w) % 64 == 0
-                and n * 256 * h * w * 4 < 0x7FFFFFF0)
+        if not (c == 64 and self._pw(ds_conv, 64, 256) and self._pw(conv3, 64, 256) and self._pw(conv1_next, 256, 64) and (h * w) % 64 == 0):
+            return False
+        return n * 32 * h * w * 16 < 0x7FFFFFF0 if half else n * 256 * h * w * 4 < 0x7FFFFFF0
 
     def fuses_expand_only(self, mid: torch.Tensor, res: torch.Tensor, conv3: Conv2d) -> bool:
         """fp32 plans: the LAST Bottleneck's expand conv + identity through the persistent weight-stationary kernel (no reduce conv
@@ -758,6 +763,16 @@ class Plan:
         y, z = self.alloc(n, ce, h, w), self.alloc(n, cr, h, w)
         p3, p1 = self._pack(conv3.weight, ce, cm, 1, False, 0, 0, True), self._pack(conv1_next.weight, cr, ce, 1, False, 0, 0, True)
         (s3, b3), (s1, b1) = self._affine(ce, bn3, None, True), self._affine(cr, bn1_next, None, True)
+        if ds is not None:
+            x0, ds_conv, ds_bn = ds
+            pd = self._pack(ds_conv.weight, ce, cm, 1, False, 0, 0, True)
+            sd, bd = self._affine(ce, ds_bn, None, True)
+            _lib.check(self.lib.mp_plan_add_ds_expand_reduce_f16(self.handle, _lib.ptr(mid), _lib.ptr(x0), _lib.ptr(pd), _lib.ptr(sd), _lib.ptr(bd),
+                                                                 _lib.ptr(p3), _lib.ptr(s3), _lib.ptr(b3), 1, _lib.ptr(p1), _lib.ptr(s1), _lib.ptr(b1), 1,
+                                                                 _lib.ptr(y), _lib.ptr(z), n, cm, ce, cr, h, w),
+                       "mp_plan_add_ds_expand_reduce_f16")
+            self.layer_info.append(dict(kind="pwchain_f16", k=1, stride=1, cin=cm, cout=ce, h=h, w=w, n=n, macs=macs))
+            return y, z
         _lib.check(self.lib.mp_plan_add_expand_reduce_f16(self.handle, _lib.ptr(mid), _lib.ptr(res), _lib.ptr(p3), _lib.ptr(s3), _lib.ptr(b3), 1,
                                                           _lib.ptr(p1), _lib.ptr(s1), _lib.ptr(b1), 1, _lib.ptr(y), _lib.ptr(z), n, cm, ce, cr, h, w),
                    "mp_plan_add_expand_reduce_f16")

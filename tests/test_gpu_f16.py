@@ -538,6 +538,35 @@ def test_expand_reduce_chain_equals_two_convs(shape, relus):
     assert torch.equal(z.c8_tensor, z_ref.c8_tensor)
 
 
+@pytest.mark.parametrize("shape", [(3, 64, 48), (2, 16, 12), (5, 8, 8), (2, 96, 72), (1, 4, 16)])
+def test_down_sample_chain_equals_three_convs(shape):
+    """mp_f16_ds_expand_reduce_fwd - the FIRST Bottleneck's chain launch with its down-sample conv (hrnet.py:74-81) computed inside,
+    rounded to fp16 as the stand-alone conv stores it - against the three mp_f16_conv2d_fwd launches: y and z bit-identical."""
+    n, h, w = shape
+    g = torch.Generator().manual_seed(7 * n * h * w)
+    mid, x0 = _to_c8(torch.randn(n, 64, h, w, generator=g)), _to_c8(torch.randn(n, 64, h, w, generator=g))
+    w3 = torch.randn(256, 64, 1, 1, generator=g) * (2.0 / 64) ** 0.5
+    wd = torch.randn(256, 64, 1, 1, generator=g) * (2.0 / 64) ** 0.5
+    w1 = torch.randn(64, 256, 1, 1, generator=g) * (2.0 / 256) ** 0.5
+    s3, b3 = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.1
+    sd, bd = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.1
+    s1, b1 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    d_ref, pkd, scd, shd = _pw_conv(x0, wd, sd, bd, None, 0, n, 64, 256, h, w)
+    y_ref, pk3, sc3, sh3 = _pw_conv(mid, w3, s3, b3, d_ref, 1, n, 64, 256, h, w)
+    z_ref, pk1, sc1, sh1 = _pw_conv(y_ref, w1, s1, b1, None, 1, n, 256, 64, h, w)
+    y, z = ActC8(n, 256, h, w, DEV), ActC8(n, 64, h, w, DEV)
+    y.c8_tensor.fill_(7.0); z.c8_tensor.fill_(7.0)
+    _lib.check(LIB.mp_f16_ds_expand_reduce_fwd(_lib.ptr(mid), _lib.ptr(x0), _lib.ptr(pkd), _lib.ptr(scd), _lib.ptr(shd), _lib.ptr(pk3), _lib.ptr(sc3),
+                                               _lib.ptr(sh3), 1, _lib.ptr(pk1), _lib.ptr(sc1), _lib.ptr(sh1), 1, _lib.ptr(y), _lib.ptr(z), n, 64,
+                                               256, 64, h, w, _lib.stream()), "mp_f16_ds_expand_reduce_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(y.c8_tensor, y_ref.c8_tensor)
+    assert torch.equal(z.c8_tensor, z_ref.c8_tensor)
+    assert LIB.mp_f16_ds_expand_reduce_fwd(_lib.ptr(mid), None, _lib.ptr(pkd), _lib.ptr(scd), _lib.ptr(shd), _lib.ptr(pk3), _lib.ptr(sc3),
+                                           _lib.ptr(sh3), 1, _lib.ptr(pk1), _lib.ptr(sc1), _lib.ptr(sh1), 1, _lib.ptr(y), _lib.ptr(z), n, 64, 256,
+                                           64, h, w, _lib.stream()) == -1  # no block input: MP_ERR_NULL
+
+
 def test_expand_reduce_chain_rejects_what_it_is_not_built_for():
     a = ActC8(1, 256, 8, 8, DEV)
     p = _lib.ptr(a)
@@ -563,8 +592,18 @@ def test_network_with_the_stage1_chain_launch_equals_the_two_launch_plan(backbon
         kinds[flag] = [e["kind"] for e in plan.layer_info] if plan is not None else None
     assert torch.equal(outs["1"], outs["0"])
     if kinds["1"] is not None:
-        assert kinds["1"].count("pwchain_f16") == 4 and kinds["0"].count("pwchain_f16") == 0  # three chains + the first block's dual 1x1
+        # three chain launches, the first with the block's down-sample conv inside: its launch and three reduce convs are gone
+        assert kinds["1"].count("pwchain_f16") == 3 and kinds["0"].count("pwchain_f16") == 0
         assert len(kinds["1"]) == len(kinds["0"]) - 4
+    # the form before the down-sample conv moved inside (dual 1x1 launch + identity chain): same bits again
+    monkeypatch.setenv("MINDPOSE_FUSE_PWCHAIN", "1")
+    monkeypatch.setenv("MINDPOSE_FUSE_PWCHAIN_DS", "0")
+    net = _net(backbone)
+    mp.models.auto_mixed_precision(net, "O2")
+    assert torch.equal(net(x), outs["1"])
+    plan = next(iter(net._plans.values())) if hasattr(net, "_plans") else None
+    if plan is not None:
+        assert [e["kind"] for e in plan.layer_info].count("pwchain_f16") == 4
 
 
 @pytest.mark.parametrize("shape", [(3, 256, 192), (2, 384, 288), (2, 64, 64), (5, 8, 32), (1, 6, 96)])
