@@ -364,8 +364,9 @@ int mp_f16_pack_weight(const float* w_dev, void* packed_dev, int cout, int cin, 
 /* All weight packings of one training step in ONE launch (the fp32 master weights change every step, and an HRNet-W32 step
  * needs 700 packings: forward + data-gradient forms).  jobs_dev: device array of n_jobs descriptors with the arguments of
  * mp_f16_pack_weight (same validity rules, checked by the caller); first_block_dev: device array of n_jobs + 1 prefix sums of
- * ceil(units_j / 256), units_j = ceil(cin/32) * kh * kw * 4 * Cout_pad16 (the job's 16-byte groups); total_blocks = its last
- * entry.  Both tables are caller-owned and must stay alive until the launch has run. */
+ * ceil(units_j / 256), units_j = ceil(cin/32) * 4 * Cout_pad16 (one thread per (8 input channels, cout) pair: it walks the kh * kw
+ * taps; a table with MORE blocks per job - e.g. the units of round 4, x kh * kw - is accepted: the surplus blocks leave at once);
+ * total_blocks = its last entry.  Both tables are caller-owned and must stay alive until the launch has run. */
 typedef struct mp_f16_pack_job {
     const float* w;
     void* packed;

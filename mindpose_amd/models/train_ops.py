@@ -374,7 +374,8 @@ def repack_weights(module):
             for i, (prm, (_, cout, cin, k, mode, py, px), entry) in enumerate(group):
                 arr[i] = _PackJob(prm.data_ptr(), entry.buf.data_ptr(), cout, cin, k, k, mode, py, px, 0)
                 cp = (cout + 15) // 16 * 16
-                units = (cin + 31) // 32 * k * k * 4 * cp if half else (cin + 3) // 4 * 4 * k * k * (cp // 4)
+                # fp16: one thread per (group of 8 input channels, cout) pair - it walks the taps itself
+                units = (cin + 31) // 32 * 4 * cp if half else (cin + 3) // 4 * 4 * k * k * (cp // 4)
                 if not half and mode in (5, 6):  # Winograd forms: one thread per (cin, cout) pair
                     units = (cin + 3) // 4 * 4 * cp
                 first[i + 1] = first[i] + (units + 255) // 256

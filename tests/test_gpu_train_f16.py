@@ -349,7 +349,8 @@ def test_batched_weight_pack_equals_individual_packs():
         a, b = torch.full((nb // 2,), 7.0, device=DEV, dtype=torch.float16), torch.full((nb // 2,), 9.0, device=DEV, dtype=torch.float16)
         _lib.check(LIB.mp_f16_pack_weight(_lib.ptr(w), _lib.ptr(a), cout, cin, k, k, mode, py, px, _lib.stream()), "pack")
         arr[i] = T._PackJob(w.data_ptr(), b.data_ptr(), cout, cin, k, k, mode, py, px, 0)
-        first[i + 1] = first[i] + ((cin + 31) // 32 * k * k * 4 * ((cout + 15) // 16 * 16) + 255) // 256
+        # one thread per (8 input channels, cout) pair; every other job with the x k * k block count of round 4 (surplus blocks leave)
+        first[i + 1] = first[i] + ((cin + 31) // 32 * (k * k if i % 2 else 1) * 4 * ((cout + 15) // 16 * 16) + 255) // 256
         single.append(a)
         batch.append(b)
     jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
