@@ -347,12 +347,15 @@ __global__ __launch_bounds__(256, 1) void expand_reduce_f32_kernel(const PwChain
 // eight waves of one workgroup in step (all in the MFMA phases together, all in the epilogue together); two workgroups drift apart.
 template <bool RED, int PW>
 __global__ __launch_bounds__(256 * PW, 3 - PW) void expand_reduce_f32_w8_kernel(const PwChainF32Params p) {
-    constexpr int kXBuf = 64 * kXP;
     constexpr int TPX = 32 * PW;  // pixels per tile
+    // row pitch of the staged tile: the two k rows of a fetch on disjoint bank halves - 96 floats for 64-pixel rows, 32 for 32-pixel rows
+    constexpr int XP = PW == 2 ? kXP : 32;
+    constexpr int kXBuf = 64 * XP;
+    constexpr int EXB = PW == 2 ? 1 : 2;  // exchange buffers: the 32-pixel form has the LDS for two (no second barrier per tile)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* __restrict__ lds_x = smem;                // [2][64][kXP]
     float* __restrict__ lds_ex = smem + 2 * kXBuf;   // [4 PW waves][3 owners][2][64 lanes] float4
-    float* __restrict__ lds_ss = lds_ex + kExBuf / 2 * PW;
+    float* __restrict__ lds_ss = lds_ex + kExBuf / 2 * PW * EXB;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cw = wave & 3, pw = wave >> 2;
     const int tiles_per_img = p.tiles_per_img * (2 / PW), total_tiles = p.total_tiles * (2 / PW);
@@ -399,8 +402,8 @@ __global__ __launch_bounds__(256 * PW, 3 - PW) void expand_reduce_f32_w8_kernel(
         xv[1] = buf_load4(rs_mid, off + 16u);
     };
     auto x_store = [&](int buf) __attribute__((always_inline)) {
-        *reinterpret_cast<f32x4*>(lds_x + buf * kXBuf + xk * kXP + 8 * xq) = xv[0];
-        *reinterpret_cast<f32x4*>(lds_x + buf * kXBuf + xk * kXP + 8 * xq + 4) = xv[1];
+        *reinterpret_cast<f32x4*>(lds_x + buf * kXBuf + xk * XP + 8 * xq) = xv[0];
+        *reinterpret_cast<f32x4*>(lds_x + buf * kXBuf + xk * XP + 8 * xq + 4) = xv[1];
     };
 
     int tile = blockIdx.x;
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(256 * PW, 3 - PW) void expand_reduce_f32_w8_kernel(
     x_store(0);
     chain_barrier();
 
-    const int b_off = h * kXP + 32 * pw + l31;
+    const int b_off = h * XP + 32 * pw + l31;
     for (int it = 0; tile < total_tiles; ++it, tile += gridDim.x) {
         const int cur = it & 1;
         const int n = tile / tiles_per_img, p0 = (tile - n * tiles_per_img) * TPX;
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(256 * PW, 3 - PW) void expand_reduce_f32_w8_kernel(
             for (int r = 0; r < 16; ++r) acc1[rt][r] = 0.f;
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
-            const float b = xs[2 * s * kXP];
+            const float b = xs[2 * s * XP];
             acc1[0] = PWC_MFMA(a3[0][s], b, acc1[0]);
             acc1[1] = PWC_MFMA(a3[1][s], b, acc1[1]);
         }
@@ -472,8 +475,8 @@ __global__ __launch_bounds__(256 * PW, 3 - PW) void expand_reduce_f32_w8_kernel(
                 }
             // ---- hand-over inside the pixel half: owner o of (row tile o / 2, registers 8 (o % 2) .. + 7) is wave (pw, o)
             if (has_next) x_store(cur ^ 1);
-            f32x4* __restrict__ ex4 = reinterpret_cast<f32x4*>(lds_ex);
-            if (it > 0) chain_barrier();  // every wave has read the last tile's partials
+            f32x4* __restrict__ ex4 = reinterpret_cast<f32x4*>(lds_ex) + (EXB == 2 ? cur * (kExBuf / 8) : 0);
+            if (EXB == 1 && it > 0) chain_barrier();  // every wave has read the last tile's partials (two buffers: the barrier two tiles on says so)
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
                 if (o == cw) continue;  // wave-uniform
@@ -556,7 +559,7 @@ int pwchain32_build(const float* mid, const float* res, const float* x0, const f
     const int tiles = L.form == 2 ? 2 * p.total_tiles : p.total_tiles, slots = L.form == 2 ? 2 * cus : cus;
     L.grid = tiles < slots ? tiles : slots;
     L.lds_bytes = L.form == 4 ? (size_t)(2 * (ds ? 128 : 64) * kXP + kExBuf + kSs) * 4
-                              : (size_t)(2 * 64 * kXP + kExBuf / 2 * (L.form == 8 ? 2 : 1) + kSs) * 4;
+                              : L.form == 8 ? (size_t)(2 * 64 * kXP + kExBuf + kSs) * 4 : (size_t)(2 * 64 * 32 + kExBuf + kSs) * 4;
     return MP_OK;
 }
 
