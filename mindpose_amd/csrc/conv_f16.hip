@@ -23,8 +23,11 @@ namespace {
 // ONE_CHUNK: the build for layers whose whole K fits one chunk (the 32-channel layers): no chunk loop, so the staging
 // registers are dead before the MFMA loop and a wave can own six pixel tiles instead of three
 // STATS: the training build whose epilogue also produces the partial BatchNorm sums of conv_f16_dev.h (p.st_mode 1 / 2)
+// The kernel body as a device function of (parameters, workgroup index, phase index): conv_f16_kernel below passes its own launch
+// parameters and blockIdx; conv_f16_group_kernel serves several convolutions of ONE instantiation from a job table (the independent
+// small convs of an HRModule at small batch sizes, where the launch count is the cost).
 template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, int NI, int NW, int OCC, bool ONE_CHUNK = false, int STATS = 0>
-__global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params p) {
+__device__ __forceinline__ void conv_f16_body(const ConvF16Params& p, const int block_x, const int block_y) {
     static_assert(WAVES_P * WAVES_C == 4, "4 waves per workgroup");
     constexpr int T = KS * KS;
     constexpr int CT = 16 * CS * WAVES_C;
@@ -37,7 +40,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
     const int lq = lane >> 4, lr = lane & 15;
 
     // XCD-aware tile id (blocks b, b+8, ... share an XCD): every XCD walks a contiguous run of tiles
-    int b = blockIdx.x;
+    int b = block_x;
     {
         const int nb = p.total_blocks, q8 = nb >> 3, r8 = nb & 7, xcd = b & 7, j = b >> 3;
         b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
@@ -45,7 +48,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
     const int ct = b % p.n_ct;
     b /= p.n_ct;
     // pixel tile (of its phase, MP_CONV_PHASES4) = partial-sum slot of the epilogue statistics
-    const int part_idx = (p.phases > 1 ? (int)blockIdx.y * (p.tiles_y * p.tiles_n) : 0) + b;
+    const int part_idx = (p.phases > 1 ? block_y * (p.tiles_y * p.tiles_n) : 0) + b;
     const int ty = b % p.tiles_y, tn = b / p.tiles_y;
     const int n0 = tn * p.G, y0 = ty * p.R;
     const int y_in0 = y0 * S - p.pad_t;
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
     const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(xg, (size_t)n_img * p.C8in * HW * 16);
     const int w_units = p.PK * T * CT;  // 16-B elements of one weight chunk of this cout tile
     const __amdgpu_buffer_rsrc_t rs_w =
-        make_rsrc(reinterpret_cast<const char*>(p.wp) + (p.phases > 1 ? (size_t)blockIdx.y * p.w_phase_bytes : (size_t)0),
+        make_rsrc(reinterpret_cast<const char*>(p.wp) + (p.phases > 1 ? (size_t)block_y * p.w_phase_bytes : (size_t)0),
                   (size_t)p.n_chunks * p.PK * T * p.Cout_pad16 * 16);
     unsigned wsrc[NW];
 #pragma unroll
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
     const size_t grp = (size_t)n0 * p.C8out * plane_o * 16;
     const size_t grp_bytes = (size_t)n_img * p.C8out * plane_o * 16;
     const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(reinterpret_cast<char*>(p.out) + grp, grp_bytes);
-    const int off_y = p.phases > 1 ? (int)(blockIdx.y >> 1) : p.off_y, off_x = p.phases > 1 ? (int)(blockIdx.y & 1) : p.off_x;
+    const int off_y = p.phases > 1 ? (int)(block_y >> 1) : p.off_y, off_x = p.phases > 1 ? (int)(block_y & 1) : p.off_x;
     unsigned pix_off[PS];
 #pragma unroll
     for (int ps = 0; ps < PS; ++ps) {
@@ -351,6 +354,12 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
     if constexpr (STATS)
         f16_stats_flush<CS, WAVES_P, WAVES_C>(st_a, st_b, reinterpret_cast<float*>(smem16), p.st_part, p.st_nparts, part_idx, ct * CT,
                                               p.C8out, wp_i, wc_i, lq, lr);
+}
+
+
+template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, int NI, int NW, int OCC, bool ONE_CHUNK = false, int STATS = 0>
+__global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params p) {
+    conv_f16_body<KS, S, PS, CS, WAVES_P, WAVES_C, NI, NW, OCC, ONE_CHUNK, STATS>(p, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // regular: big chunks, two workgroups per CU; light: small chunks / few staging registers, three per CU (<= 52 KiB LDS)
