@@ -411,18 +411,6 @@ int mp_f16_stem_conv_fwd(const float* x_dev, const float* weight_dev, const floa
                          void* out_c8_dev, int n, int h, int w, mp_stream_t stream);
 int mp_plan_add_stem_conv_f16(mp_plan* plan, const float* x_dev, const float* weight_dev, const float* scale_dev, const float* shift_dev,
                               int relu, void* out_c8_dev, int n, int h, int w);
-/* Up to eight INDEPENDENT fp16 convolutions of one kernel size / stride (1x1 stride 1, 3x3 stride 1, 3x3 stride 2) in ONE launch -
- * the k-th conv of every branch of an HRModule, the up- / down-sampling convs of its exchange unit (hrnet.py:202-241, 258-316): at
- * small batch sizes the launch count is what a forward costs.  Job j = (descs[j], xs[j], packed_ws[j], scales[j], shifts[j],
- * res1s[j], res2s[j], outs[j]) with the meaning of mp_f16_conv2d_fwd's arguments (res1s / res2s or their entries may be null);
- * variant = the small-tile shape 4 or its light build 9 (32 couts x 96 pixels).  Every job's result is bit-identical to its own
- * mp_f16_conv2d_fwd(variant) launch.  MP_ERR_UNSUPPORTED: mixed kernel sizes / strides, another variant, a job that variant cannot run. */
-int mp_f16_conv2d_group_fwd(int n_jobs, const mp_conv_desc* descs, int variant, const void* const* xs_c8_dev,
-                            const void* const* packed_ws_dev, const float* const* scales_dev, const float* const* shifts_dev,
-                            const void* const* res1s_dev, const void* const* res2s_dev, void* const* outs_c8_dev, mp_stream_t stream);
-int mp_plan_add_conv_f16_group(mp_plan* plan, int n_jobs, const mp_conv_desc* descs, int variant, const void* const* xs_c8_dev,
-                               const void* const* packed_ws_dev, const float* const* scales_dev, const float* const* shifts_dev,
-                               const void* const* res1s_dev, const void* const* res2s_dev, void* const* outs_c8_dev);
 /* Two chained fp16 1x1 convolutions in ONE launch (hrnet.py:107-123, 126-146, stage 1): the expand conv of Bottleneck i,
  *   y = act3(conv1x1(mid; w3) * scale3 + shift3 + res)      cm -> ce channels, res = the block's identity,
  * and the reduce conv of Bottleneck i + 1 on it,

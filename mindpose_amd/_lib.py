@@ -161,8 +161,6 @@ _PROTOTYPES = {
     "mp_plan_add_dual_pw_f16": (c_int, [ctypes.c_void_p] + [c_f32p] * 4 + [c_int] + [c_f32p] * 3 + [c_int] + [c_f32p] * 2 + [c_int] * 6),
     "mp_f16_expand_reduce_fwd": (c_int, [c_f32p] * 5 + [c_int] + [c_f32p] * 3 + [c_int] + [c_f32p] * 2 + [c_int] * 6 + [ctypes.c_void_p]),
     "mp_plan_add_expand_reduce_f16": (c_int, [ctypes.c_void_p] + [c_f32p] * 5 + [c_int] + [c_f32p] * 3 + [c_int] + [c_f32p] * 2 + [c_int] * 6),
-    "mp_f16_conv2d_group_fwd": (c_int, [c_int, ctypes.POINTER(ConvDesc), c_int] + [ctypes.c_void_p] * 7 + [ctypes.c_void_p]),
-    "mp_plan_add_conv_f16_group": (c_int, [ctypes.c_void_p, c_int, ctypes.POINTER(ConvDesc), c_int] + [ctypes.c_void_p] * 7),
     "mp_f16_ds_expand_reduce_fwd": (c_int, [c_f32p] * 8 + [c_int] + [c_f32p] * 3 + [c_int] + [c_f32p] * 2 + [c_int] * 6 + [ctypes.c_void_p]),
     "mp_plan_add_ds_expand_reduce_f16": (c_int, [ctypes.c_void_p] + [c_f32p] * 8 + [c_int] + [c_f32p] * 3 + [c_int] + [c_f32p] * 2 + [c_int] * 6),
     "mp_expand_reduce_fwd": (c_int, [c_f32p] * 14 + [c_int] * 6 + [ctypes.c_void_p]),

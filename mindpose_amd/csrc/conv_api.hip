@@ -358,14 +358,13 @@ struct mp_plan {
         int kind;  // 0 conv, 1 maxpool, 2 fuse-sum; fp16 layout: 3 conv, 4 fuse-sum, 5 NCHW fp32 -> c8, 6 c8 -> NCHW fp32;
                    // 7 = all-lane barrier (no launch), 8 = fused fp16 BasicBlock, 9 = fp32 Winograd conv,
                    // 10 = fp16 expand + reduce 1x1 chain (stage 1), 11 = fp16 first conv from the fp32 image, 12 = fp32 first conv (streaming form),
-                   // 13 = fp32 expand + reduce 1x1 chain (stage 1), 14 = grouped fp16 convs (up to eight independent convs of one shape class)
+                   // 13 = fp32 expand + reduce 1x1 chain (stage 1)
         int lane;  // execution lane: 0 = the caller's stream, 1..3 = the plan's own side streams
         ConvLaunch conv;
         ConvF16Launch conv16;
         BlockF16Launch block16;
         PwChainLaunch pwchain;
         PwChainF32Launch pwchain32;
-        ConvF16GroupLaunch group16;
         StemF16Launch stem16;
         StemF32Launch stem32;
         WinoLaunch wino;
@@ -415,7 +414,6 @@ static int run_entry(const mp_plan::Entry& e, mp_stream_t stream) {
         case 11: return stemf16_launch(e.stem16, as_stream(stream));
         case 12: return stemf32_launch(e.stem32, as_stream(stream));
         case 13: return pwchain32_launch(e.pwchain32, as_stream(stream));
-        case 14: return f16_group_launch(e.group16, as_stream(stream));
         default: return MP_ERR_UNSUPPORTED;
     }
 }
@@ -690,20 +688,6 @@ int mp_plan_add_expand_reduce(mp_plan* plan, const float* mid, const float* res,
     return MP_OK;
 }
 
-int mp_plan_add_conv_f16_group(mp_plan* plan, int n_jobs, const mp_conv_desc* descs, int variant, const void* const* xs,
-                               const void* const* packed_ws, const float* const* scales, const float* const* shifts,
-                               const void* const* res1s, const void* const* res2s, void* const* outs) {
-    if (!plan) return MP_ERR_NULL;
-    mp_plan::Entry e{};
-    e.kind = 14;
-    int rc = f16_group_build(n_jobs, descs, variant, xs, packed_ws, scales, shifts, res1s, res2s, outs, e.group16);
-    if (rc != MP_OK) return rc;
-    e.n = descs[0].n; e.c = descs[0].cout; e.h = descs[0].h; e.w = descs[0].w;
-    e.lane = plan->cur_lane;
-    plan->entries.push_back(e);
-    return MP_OK;
-}
-
 int mp_plan_add_ds_expand_reduce_f16(mp_plan* plan, const void* mid, const void* x0, const void* packed_wd, const float* scale_d,
                                      const float* shift_d, const void* packed_w3, const float* scale3, const float* shift3, int relu3,
                                      const void* packed_w1, const float* scale1, const float* shift1, int relu1, void* y, void* z, int n,
@@ -838,9 +822,6 @@ int mp_plan_entry_info(const mp_plan* plan, int index, int64_t info[12]) {
     } else if (e.kind == 11) {
         info[1] = 3; info[2] = 2; info[3] = 0; info[4] = e.stem16.p.total_blocks;
         info[5] = (int64_t)e.stem16.lds_bytes; info[6] = 64; info[7] = 8 * e.stem16.p.Wo; info[8] = 3; info[9] = 1; info[10] = 8;
-    } else if (e.kind == 14) {
-        info[1] = e.group16.ks; info[2] = e.group16.stride; info[3] = e.group16.variant; info[4] = e.group16.g.first[e.group16.g.n];
-        info[5] = (int64_t)e.group16.lds_bytes; info[6] = 32; info[7] = 96; info[8] = 0; info[9] = e.group16.g.n; info[10] = 0;
     } else if (e.kind == 13) {
         info[1] = 1; info[2] = 1; info[3] = (e.pwchain32.ds ? 1 : 0) + (e.pwchain32.red ? 0 : 2); info[4] = e.pwchain32.grid;
         info[5] = (int64_t)e.pwchain32.lds_bytes; info[6] = 256; info[7] = e.pwchain32.form == 2 ? 32 : 64; info[8] = 64; info[9] = 1; info[10] = 0;

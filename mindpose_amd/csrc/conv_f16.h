@@ -61,24 +61,6 @@ struct ConvF16Launch {
     size_t lds_bytes;
 };
 
-// several independent convolutions of ONE one-tile instantiation (same kernel size, stride and tile variant) in one launch: the flat
-// grid is [job 0's workgroups | job 1's | ...] (conv_f16_group_kernel)
-constexpr int kF16GroupMax = 8;
-struct ConvF16Group {
-    ConvF16Params job[kF16GroupMax];
-    int first[kF16GroupMax + 1];  // first workgroup of job j in the flat grid; first[n] = the grid
-    int n;
-};
-struct ConvF16GroupLaunch {
-    ConvF16Group g;
-    int ks, stride, variant;
-    size_t lds_bytes;  // the largest job's
-};
-int f16_group_build(int n_jobs, const mp_conv_desc* descs, int variant, const void* const* xs, const void* const* ws,
-                    const float* const* scales, const float* const* shifts, const void* const* res1s, const void* const* res2s,
-                    void* const* outs, ConvF16GroupLaunch& L);
-int f16_group_launch(const ConvF16GroupLaunch& L, hipStream_t s);
-
 // 0..4 tile shapes (cout tile x pixel tile), 5..9 their light builds, 10..14 / 15..19 the persistent multi-tile kernel
 // (weights resident in LDS, input tiles double-buffered) compiled for two / one workgroup per CU
 enum ConvF16Variant { F_CT32_PT192 = 0, F_CT64_PT192 = 1, F_CT48_PT192 = 2, F_CT64_PT96 = 3, F_CT32_PT96 = 4,

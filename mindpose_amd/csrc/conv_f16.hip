@@ -362,19 +362,6 @@ __global__ __launch_bounds__(256, OCC) void conv_f16_kernel(const ConvF16Params 
     conv_f16_body<KS, S, PS, CS, WAVES_P, WAVES_C, NI, NW, OCC, ONE_CHUNK, STATS>(p, (int)blockIdx.x, (int)blockIdx.y);
 }
 
-// Grouped launch: workgroup b serves job j with first[j] <= b < first[j + 1] (at most eight jobs: compares on constant indices) with
-// that job's own parameter block - the same body, the same bits as the job's stand-alone launch.
-template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, int NI, int NW, int OCC>
-__global__ __launch_bounds__(256, OCC) void conv_f16_group_kernel(const ConvF16Group g) {
-    const int b = (int)blockIdx.x;
-    int j = 0;
-#pragma unroll
-    for (int i = 1; i < kF16GroupMax; ++i) j += (i < g.n && b >= g.first[i]) ? 1 : 0;
-    j = __builtin_amdgcn_readfirstlane(j);
-    const ConvF16Params p = g.job[j];
-    conv_f16_body<KS, S, PS, CS, WAVES_P, WAVES_C, NI, NW, OCC, false, 0>(p, b - g.first[j], 0);
-}
-
 // regular: big chunks, two workgroups per CU; light: small chunks / few staging registers, three per CU (<= 52 KiB LDS)
 constexpr int f16_ni(int ks, bool light) { return light ? 5 : 10; }
 constexpr int f16_nw(int ks, bool light) { return light ? 5 : (ks == 3 ? 9 : 8); }  // ks 2 (deconv phases): 8
@@ -912,63 +899,6 @@ int f16_stats_parts(const ConvF16Launch& L) {
     return ((f16_variant_mt(L.variant) || f16_variant_ws(L.variant)) ? L.p.n_groups : L.p.tiles_y * L.p.tiles_n) * (L.p.phases > 1 ? L.p.phases : 1);
 }
 
-template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, bool LIGHT>
-static int launch_f16_group_kernel(const ConvF16GroupLaunch& L, hipStream_t s) {
-    if (g_dry_launch) return MP_OK;
-    auto kern = conv_f16_group_kernel<KS, S, PS, CS, WAVES_P, WAVES_C, f16_ni(KS, LIGHT), f16_nw(KS, LIGHT), f16_occ(LIGHT)>;
-    static AttrOnce attr_set_once;
-    if (attr_set_once.need()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipGetLastError();
-    }
-    hipLaunchKernelGGL(kern, dim3(L.g.first[L.g.n]), dim3(256), L.lds_bytes, s, L.g);
-    return check_launch();
-}
-
-template <int KS, int S>
-static int launch_f16_group_ks(const ConvF16GroupLaunch& L, hipStream_t s) {
-    // the two small-tile shapes (32 couts x 96 pixels; its light build): grouped launches serve small batches
-    switch (L.variant) {
-        case F_CT32_PT96: return launch_f16_group_kernel<KS, S, 3, 1, 2, 2, false>(L, s);
-        case F_CT32_PT96_L: return launch_f16_group_kernel<KS, S, 3, 1, 2, 2, true>(L, s);
-        default: return MP_ERR_UNSUPPORTED;
-    }
-}
-
-int f16_group_launch(const ConvF16GroupLaunch& L, hipStream_t s) {
-    if (L.ks == 1 && L.stride == 1) return launch_f16_group_ks<1, 1>(L, s);
-    if (L.ks == 3 && L.stride == 1) return launch_f16_group_ks<3, 1>(L, s);
-    if (L.ks == 3 && L.stride == 2) return launch_f16_group_ks<3, 2>(L, s);
-    return MP_ERR_UNSUPPORTED;
-}
-
-int f16_group_build(int n_jobs, const mp_conv_desc* descs, int variant, const void* const* xs, const void* const* ws,
-                    const float* const* scales, const float* const* shifts, const void* const* res1s, const void* const* res2s,
-                    void* const* outs, ConvF16GroupLaunch& L) {
-    if (!descs || !xs || !ws || !scales || !shifts || !outs) return MP_ERR_NULL;
-    if (n_jobs < 1 || n_jobs > kF16GroupMax) return MP_ERR_SHAPE;
-    if (variant != F_CT32_PT96 && variant != F_CT32_PT96_L) return MP_ERR_UNSUPPORTED;
-    L.variant = variant;
-    L.lds_bytes = 0;
-    L.g.n = n_jobs;
-    L.g.first[0] = 0;
-    for (int j = 0; j < n_jobs; ++j) {
-        if (descs[j].flags & MP_CONV_PHASES4) return MP_ERR_UNSUPPORTED;
-        ConvF16Launch one{};
-        const int rc = f16_build_launch(&descs[j], variant, xs[j], ws[j], scales[j], shifts[j], res1s ? res1s[j] : nullptr,
-                                        res2s ? res2s[j] : nullptr, outs[j], one);
-        if (rc != MP_OK) return rc;
-        if (j == 0) { L.ks = one.ks; L.stride = one.stride; }
-        if (one.ks != L.ks || one.stride != L.stride || one.variant != variant) return MP_ERR_UNSUPPORTED;  // one instantiation per launch
-        L.g.job[j] = one.p;
-        L.g.first[j + 1] = L.g.first[j] + one.p.total_blocks;
-        if (one.lds_bytes > L.lds_bytes) L.lds_bytes = one.lds_bytes;
-    }
-    for (int j = n_jobs + 1; j <= kF16GroupMax; ++j) L.g.first[j] = L.g.first[n_jobs];
-    if (!((L.ks == 1 && L.stride == 1) || (L.ks == 3 && (L.stride == 1 || L.stride == 2)))) return MP_ERR_UNSUPPORTED;
-    return MP_OK;
-}
-
 int f16_launch(const ConvF16Launch& L, hipStream_t s) {
     if (f16_variant_ws(L.variant)) return f16_ws_launch(L, s);
     if (f16_variant_wreg(L.variant)) return f16_wreg_launch(L, s);
@@ -1041,15 +971,6 @@ int mp_f16_conv2d_fwd(const mp_conv_desc* desc, int variant, const void* x, cons
     int rc = f16_build_launch(desc, variant, x, packed_w, scale, shift, res1, res2, out, L);
     if (rc != MP_OK) return rc;
     return f16_launch(L, as_stream(stream));
-}
-
-int mp_f16_conv2d_group_fwd(int n_jobs, const mp_conv_desc* descs, int variant, const void* const* xs, const void* const* packed_ws,
-                            const float* const* scales, const float* const* shifts, const void* const* res1s, const void* const* res2s,
-                            void* const* outs, mp_stream_t stream) {
-    ConvF16GroupLaunch L{};
-    const int rc = f16_group_build(n_jobs, descs, variant, xs, packed_ws, scales, shifts, res1s, res2s, outs, L);
-    if (rc != MP_OK) return rc;
-    return f16_group_launch(L, as_stream(stream));
 }
 
 static bool f16_stats_shape_ok(const mp_conv_desc* d) {

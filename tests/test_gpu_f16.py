@@ -567,72 +567,6 @@ def test_down_sample_chain_equals_three_convs(shape):
                                            64, h, w, _lib.stream()) == -1  # no block input: MP_ERR_NULL
 
 
-GROUP_SETS = [
-    # (kernel size, stride, [(cin, cout, h, w, relu, res1, res2)] ...): the independent convs of an HRModule at one "level"
-    (1, 1, [(64, 32, 32, 24, 0, 0, 0), (128, 32, 16, 12, 0, 0, 0), (256, 32, 8, 6, 0, 0, 0), (128, 64, 16, 12, 0, 0, 0), (256, 64, 8, 6, 0, 0, 0),
-            (256, 128, 8, 6, 0, 0, 0)]),                                           # stage-4 exchange unit: the six up-path 1x1 convs
-    (3, 1, [(32, 32, 64, 48, 1, 0, 0), (64, 64, 32, 24, 1, 0, 0), (128, 128, 16, 12, 1, 0, 0), (256, 256, 8, 6, 1, 0, 0)]),  # conv1 of every branch's block
-    (3, 1, [(32, 32, 64, 48, 1, 1, 0), (64, 64, 32, 24, 1, 1, 0), (128, 128, 16, 12, 1, 1, 0), (256, 256, 8, 6, 1, 1, 0)]),  # conv2 + identity
-    (3, 2, [(32, 64, 64, 48, 0, 0, 1), (32, 32, 64, 48, 1, 0, 0), (64, 128, 32, 24, 0, 1, 1)]),                              # down paths (both residuals)
-    (3, 1, [(48, 48, 24, 16, 1, 1, 0)]),                                                                                     # a group of one
-]
-
-
-@pytest.mark.parametrize("n", [1, 3])
-@pytest.mark.parametrize("variant", [4, 9])
-@pytest.mark.parametrize("gi", range(len(GROUP_SETS)))
-def test_grouped_conv_launch_equals_the_single_launches(gi, variant, n):
-    """mp_f16_conv2d_group_fwd: up to eight independent convs of one kernel size / stride in ONE launch (the same kernel body, a job
-    table) - every job bit-identical to its own mp_f16_conv2d_fwd launch of the same variant."""
-    k, stride, jobs = GROUP_SETS[gi]
-    g = torch.Generator().manual_seed(100 * gi + variant + n)
-    descs, xs, pks, scs, shs, r1s, r2s, outs, refs, keep = [], [], [], [], [], [], [], [], [], []
-    for cin, cout, h, w, relu, has1, has2 in jobs:
-        pad = k // 2
-        oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
-        x = _to_c8(torch.randn(n, cin, h, w, generator=g))
-        wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
-        pk = torch.empty(LIB.mp_f16_packed_weight_bytes(cout, cin, k, k) // 2, device=DEV, dtype=torch.float16)
-        _lib.check(LIB.mp_f16_pack_weight(_lib.ptr(wt.to(DEV)), _lib.ptr(pk), cout, cin, k, k, 0, 0, 0, _lib.stream()), "pack")
-        cp = (cout + 15) // 16 * 16
-        sc = torch.cat([torch.rand(cout, generator=g) + 0.5, torch.zeros(cp - cout)]).to(DEV)
-        sh = torch.cat([torch.randn(cout, generator=g) * 0.1, torch.zeros(cp - cout)]).to(DEV)
-        r1 = _to_c8(torch.randn(n, cout, oh, ow, generator=g)) if has1 else None
-        r2 = _to_c8(torch.randn(n, cout, oh, ow, generator=g)) if has2 else None
-        d = _lib.ConvDesc(n=n, cin=cin, h=h, w=w, cout=cout, kh=k, kw=k, stride=stride, pad_top=pad, pad_left=pad, conv_h=oh, conv_w=ow, out_h=oh,
-                          out_w=ow, out_mul=1, out_rep=1, out_off_y=0, out_off_x=0, relu=relu, flags=0)
-        ref, out = ActC8(n, cout, oh, ow, DEV), ActC8(n, cout, oh, ow, DEV)
-        out.c8_tensor.fill_(7.0)
-        _lib.check(LIB.mp_f16_conv2d_fwd(ctypes.byref(d), variant, _lib.ptr(x), _lib.ptr(pk), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(r1), _lib.ptr(r2),
-                                         _lib.ptr(ref), _lib.stream()), "single launch")
-        descs.append(d); xs.append(x); pks.append(pk); scs.append(sc); shs.append(sh); r1s.append(r1); r2s.append(r2); outs.append(out); refs.append(ref)
-    nj = len(jobs)
-    arr = lambda ts: (ctypes.c_void_p * nj)(*[(_lib.ptr(t) if t is not None else None) for t in ts])  # noqa: E731
-    _lib.check(LIB.mp_f16_conv2d_group_fwd(nj, (_lib.ConvDesc * nj)(*descs), variant, arr(xs), arr(pks), arr(scs), arr(shs), arr(r1s), arr(r2s),
-                                           arr(outs), _lib.stream()), "mp_f16_conv2d_group_fwd")
-    torch.cuda.synchronize()
-    for out, ref in zip(outs, refs):
-        assert torch.equal(out.c8_tensor, ref.c8_tensor)
-
-
-def test_grouped_conv_launch_rejects_mixed_groups():
-    x = _to_c8(torch.randn(1, 32, 8, 8))
-    pk = torch.zeros(64 * 64 * 9, device=DEV, dtype=torch.float16)
-    f = torch.zeros(64, device=DEV)
-    o = ActC8(1, 32, 8, 8, DEV)
-    d3 = _lib.ConvDesc(n=1, cin=32, h=8, w=8, cout=32, kh=3, kw=3, stride=1, pad_top=1, pad_left=1, conv_h=8, conv_w=8, out_h=8, out_w=8, out_mul=1,
-                       out_rep=1, out_off_y=0, out_off_x=0, relu=0, flags=0)
-    d1 = _lib.ConvDesc(n=1, cin=32, h=8, w=8, cout=32, kh=1, kw=1, stride=1, pad_top=0, pad_left=0, conv_h=8, conv_w=8, out_h=8, out_w=8, out_mul=1,
-                       out_rep=1, out_off_y=0, out_off_x=0, relu=0, flags=0)
-    two = lambda t: (ctypes.c_void_p * 2)(_lib.ptr(t), _lib.ptr(t))  # noqa: E731
-    call = lambda descs, v, n=2: LIB.mp_f16_conv2d_group_fwd(n, (_lib.ConvDesc * 2)(*descs), v, two(x), two(pk), two(f), two(f), None, None, two(o),  # noqa: E731
-                                                             _lib.stream())
-    assert call([d3, d1], 4) == -3     # a 3x3 and a 1x1 conv: two instantiations
-    assert call([d3, d3], 0) == -3     # another tile variant
-    assert call([d3, d3], 4, n=9) == -2  # more than eight jobs: MP_ERR_SHAPE
-    assert call([d3, d3], 4) == 0
-
-
 def test_expand_reduce_chain_rejects_what_it_is_not_built_for():
     a = ActC8(1, 256, 8, 8, DEV)
     p = _lib.ptr(a)
