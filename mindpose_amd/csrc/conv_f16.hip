@@ -23,9 +23,10 @@ namespace {
 // ONE_CHUNK: the build for layers whose whole K fits one chunk (the 32-channel layers): no chunk loop, so the staging
 // registers are dead before the MFMA loop and a wave can own six pixel tiles instead of three
 // STATS: the training build whose epilogue also produces the partial BatchNorm sums of conv_f16_dev.h (p.st_mode 1 / 2)
-// The kernel body as a device function of (parameters, workgroup index, phase index): conv_f16_kernel below passes its own launch
-// parameters and blockIdx; conv_f16_group_kernel serves several convolutions of ONE instantiation from a job table (the independent
-// small convs of an HRModule at small batch sizes, where the launch count is the cost).
+// The kernel body as a device function of (parameters, workgroup index, phase index); conv_f16_kernel below passes its own launch
+// parameters and blockIdx.  (Round 5 put a grouped launch on top of it - several independent convs of one instantiation from a job
+// table, bit-identical to the single launches - for the branches of an HRModule at small batch sizes; the one-crop amp-O2 forward
+// got SLOWER with it, 1.06 -> 1.63 ms: DESIGN 7.  The kernel is gone again, the split stays.)
 template <int KS, int S, int PS, int CS, int WAVES_P, int WAVES_C, int NI, int NW, int OCC, bool ONE_CHUNK = false, int STATS = 0>
 __device__ __forceinline__ void conv_f16_body(const ConvF16Params& p, const int block_x, const int block_y) {
     static_assert(WAVES_P * WAVES_C == 4, "4 waves per workgroup");
